@@ -1,0 +1,515 @@
+"""CPU oracle for the differentiable inventory-rollout path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain PyTorch-CPU (float32, eager, autograd), the algorithm of the
+upstream reference's hot path so that the HIP kernels can be checked on the GPU box where
+the reference itself cannot travel.  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it; the product package
+(`neural_inventory_control_amd/`) never does and has no CPU fallback.
+
+Pinning: `tests/test_oracle_vs_reference.py` imports the real reference (this container only)
+and requires BIT-EQUAL data tensors, per-period rewards, states and parameter gradients for
+every BASELINE configuration at small sizes; `tests/golden/make_golden.py` dumps the reference's
+outputs into `tests/golden/*.npz`, which `tests/test_oracle_golden.py` re-checks everywhere
+(including the shipped-checkpoint known answer 6.854347).
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+The code is a functional restatement (no classes mirrored, no gym), not a copy.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from collections import defaultdict
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# 1. Scenario generation  (data_handling.py:9-81, 125-383)
+# --------------------------------------------------------------------------------------
+
+
+def _flag(params: dict, key: str):
+    """Missing keys read as False (data_handling.py:248 wraps the dict in a defaultdict)."""
+    return params.get(key, False)
+
+
+def _per_store_table(n_samples, n_stores, spec, seed, integer):
+    """Cost / lead-time table for every (sample, store).  data_handling.py:239-271.
+
+    Seeds the GLOBAL numpy legacy RNG (:244) then draws either one value per store (:256-257),
+    one value per sample (:258-259), or broadcasts a configured constant / matrix (:260-271).
+    """
+    np.random.seed(seed)
+    draw = np.random.randint if integer else np.random.uniform
+    if _flag(spec, "file_location"):
+        raise NotImplementedError("oracle: file-backed parameters are outside the synthetic path")
+    if _flag(spec, "sample_across_stores"):
+        return torch.tensor(draw(*spec["range"], n_stores)).expand(n_samples, -1)
+    if _flag(spec, "vary_across_samples"):
+        return torch.tensor(draw(*spec["range"], n_samples)).unsqueeze(1).expand(-1, n_stores)
+    if _flag(spec, "expand"):
+        v = torch.tensor(spec["value"])
+        if v.dim() == 2:  # [n_stores, n_warehouses] matrix (:263-266)
+            return v.unsqueeze(0).expand(n_samples, -1, -1)
+        return v.expand(n_samples, n_stores)
+    return torch.tensor(spec["value"])
+
+
+def _sample_store_demand_moments(n_stores, demand_spec, seeds):
+    """Per-store mean ~ U(mean_range).round(3), std = (mean*cv).round(3).  data_handling.py:225-237."""
+    np.random.seed(seeds["mean"])
+    lo, hi = demand_spec["mean_range"]
+    means = np.random.uniform(lo, hi, n_stores).round(3)
+    np.random.seed(seeds["coef_of_var"])
+    lo, hi = demand_spec["coef_of_var_range"]
+    cv = np.random.uniform(lo, hi, n_stores)
+    return means, (means * cv).round(3)
+
+
+def _demand_traces(n_samples, n_stores, periods, demand_spec, seed):
+    """(N,S,T) demand array.  data_handling.py:178-211."""
+    kind = demand_spec["distribution"]
+    if seed is not None:
+        np.random.seed(seed)
+    if kind == "poisson":  # :205-211
+        return np.random.poisson(demand_spec["mean"], size=(n_samples, n_stores, periods))
+    if kind != "normal":
+        raise NotImplementedError("oracle: only synthetic normal/poisson demand is on the hot path")
+    if n_stores == 1:  # :187-191
+        return np.random.normal(demand_spec["mean"], demand_spec["std"], size=(n_samples, 1, periods))
+    # correlated multivariate normal, cov_ij = rho*s_i*s_j (i != j), s_i^2 on the diagonal (:194-201)
+    rho = demand_spec["correlation"]
+    stds = demand_spec["std"]
+    cov = [[rho * a * b if i != j else a * b for i, a in enumerate(stds)] for j, b in enumerate(stds)]
+    draws = np.random.multivariate_normal(demand_spec["mean"], cov=cov, size=(n_samples, periods))
+    return np.transpose(draws, (0, 2, 1))
+
+
+def generate_scenario_data(periods, problem_params, store_params, warehouse_params, echelon_params,
+                           num_samples, observation_params, seeds):
+    """Restates `Scenario.__init__` + `get_data` (data_handling.py:9-81).
+
+    MUTATES `store_params['demand']` (gains numpy mean/std, :176) and `seeds['demand']`
+    (:155-158) exactly like the reference, because downstream code reads the mutated values
+    (neural_networks.py:1543).  Returns the float32 batch dict (None entries dropped, :81).
+    """
+    S = problem_params["n_stores"]
+    Wn = problem_params["n_warehouses"]
+    demand_spec = store_params["demand"]
+
+    # --- demand (data_handling.py:125-148)
+    if _flag(demand_spec, "sample_across_stores"):  # :175-176
+        m, s = _sample_store_demand_moments(S, demand_spec, seeds)
+        demand_spec.update({"mean": m, "std": s})
+    if Wn == 0 and S == 1 and demand_spec["distribution"] != "real":  # :150-160
+        try:
+            seeds["demand"] = seeds["demand"] + int(store_params["lead_time"]["value"]
+                                                    + 10 * store_params["underage_cost"]["value"])
+        except Exception as e:  # reference swallows and prints
+            print(f"Error: {e}")
+    demand = _demand_traces(num_samples, S, periods, demand_spec, seeds["demand"])
+    if demand_spec["clip"]:
+        demand = np.clip(demand, 0, None)
+    demands = torch.tensor(demand)
+
+    # --- per-store costs and lead times (data_handling.py:20-22, 273-288)
+    underage = _per_store_table(num_samples, S, store_params["underage_cost"], seeds["underage_cost"], False)
+    holding = _per_store_table(num_samples, S, store_params["holding_cost"], seeds["holding_cost"], False)
+    lead = _per_store_table(num_samples, S, store_params["lead_time"], seeds["lead_time"], True)
+    if lead.dim() == 2:
+        lead = lead.unsqueeze(2).expand(-1, -1, Wn) if Wn > 0 else lead.unsqueeze(2)
+    lead = lead.to(torch.int64)
+
+    # --- demand moments as static features (data_handling.py:373-383)
+    feats = observation_params["include_static_features"]
+    mean_t = std_t = None
+    if feats.get("mean"):
+        mean_t = torch.tensor(demand_spec["mean"]).unsqueeze(0).expand(num_samples, -1)
+    if feats.get("std"):
+        std_t = torch.tensor(demand_spec["std"]).unsqueeze(0).expand(num_samples, -1)
+
+    # --- initial store pipelines (data_handling.py:290-310): global per-store demand mean (:298)
+    np.random.seed(seeds["initial_inventory"])
+    init_spec = store_params["initial_inventory"]
+    if init_spec["sample"]:
+        store_mean = demands.float().mean(dim=2).mean(dim=0)
+        slots = max(init_spec["inventory_periods"], lead.max().item())
+        mults = np.random.uniform(*init_spec["range_mult"], size=(num_samples, S, slots))
+        init_inv = store_mean[None, :, None] * mults  # float32 tensor * float64 ndarray -> float64
+    else:
+        init_inv = torch.zeros(num_samples, S, init_spec["inventory_periods"])
+
+    out = {
+        "demands": demands, "underage_costs": underage, "holding_costs": holding, "lead_times": lead,
+        "mean": mean_t, "std": std_t, "initial_inventories": init_inv,
+    }
+
+    # --- warehouses (data_handling.py:312-329, 343-361)
+    if warehouse_params is not None:
+        wl = warehouse_params["lead_time"]
+        out["initial_warehouse_inventories"] = torch.zeros(num_samples, Wn, max(wl) if isinstance(wl, list) else wl)
+        for key, name in (("lead_time", "warehouse_lead_times"), ("holding_cost", "warehouse_holding_costs"),
+                          ("edge_cost", "warehouse_edge_costs")):
+            if key == "edge_cost" and "edge_cost" not in warehouse_params:
+                continue
+            v = warehouse_params[key]
+            if isinstance(v, list):
+                if len(v) != Wn:
+                    raise ValueError(f"warehouse_params['{key}'] list length {len(v)} doesn't match n_warehouses {Wn}")
+                out[name] = torch.tensor(v).unsqueeze(0).expand(num_samples, -1)
+            else:
+                out[name] = torch.tensor([v]).expand(num_samples, Wn)
+
+    # --- extra echelons (data_handling.py:331-341, 363-371)
+    if echelon_params is not None:
+        el = echelon_params["lead_time"]
+        out["initial_echelon_inventories"] = torch.zeros(num_samples, len(el), max(el))
+        out["echelon_holding_costs"] = torch.tensor(echelon_params["holding_cost"]).unsqueeze(0).expand(num_samples, -1)
+        out["echelon_lead_times"] = torch.tensor(el).unsqueeze(0).expand(num_samples, -1)
+
+    return {k: v.float() for k, v in out.items() if v is not None}
+
+
+# --------------------------------------------------------------------------------------
+# 2. One period of inventory dynamics  (environment.py:110-299, 391-434)
+# --------------------------------------------------------------------------------------
+
+
+def shift_pipeline_and_place(pipeline, on_hand_after, orders, lead_times):
+    """environment.py:391-434.
+
+    new[0] = on_hand_after + old[1]; new[k] = old[k+1]; new[W-1] = 0 (:405-412); then every order
+    with value != 0 is added to slot L-1 of its location (:422-432), accumulating in ascending
+    flattened (b, location, supplier) order like `Tensor.put(accumulate=True)` on CPU.  Orders
+    that are exactly 0 are filtered out BEFORE the put (:426-429) so they carry no gradient on
+    this path; if every order is 0 the put is skipped (:427).
+    """
+    B, N, W = pipeline.shape
+    cols = [on_hand_after + pipeline[:, :, 1]]
+    cols += [pipeline[:, :, k + 1] for k in range(1, W - 1)]
+    cols.append(torch.zeros(orders.shape[0], orders.shape[1], dtype=pipeline.dtype))
+    fresh = torch.stack(cols, dim=2)
+
+    n_sup = orders.shape[2]
+    base = (torch.arange(B) * (W * N))[:, None] + (torch.arange(N) * W).expand(B, N)  # :77-101
+    flat_pos = (base.unsqueeze(2).expand(-1, -1, n_sup) + lead_times.long() - 1).flatten()
+    vals = orders.flatten()
+    keep = vals != 0
+    if keep.any():
+        fresh = fresh.put(flat_pos[keep], vals[keep].to(fresh.dtype), accumulate=True)
+    return fresh
+
+
+@dataclass
+class OracleEnv:
+    """State of one rollout: the reference keeps these in `Simulator.observation` / `_internal_data`."""
+    problem: dict
+    demands: torch.Tensor
+    period_shift: int
+    periods: int
+    obs: Dict[str, torch.Tensor] = field(default_factory=dict)
+    t: int = 0
+
+
+def env_reset(periods, problem_params, data, observation_params) -> OracleEnv:
+    """environment.py:24-75 + 301-345 (observation dict built by reference, no clone)."""
+    env = OracleEnv(problem=problem_params, demands=data["demands"],
+                    period_shift=observation_params["demand"]["period_shift"], periods=periods)
+    obs = {"store_inventories": data["initial_inventories"], "current_period": torch.tensor([0])}
+    if observation_params["include_warehouse_inventory"]:
+        obs["warehouse_lead_times"] = data["warehouse_lead_times"]
+        obs["warehouse_holding_costs"] = data["warehouse_holding_costs"]
+        obs["warehouse_inventories"] = data["initial_warehouse_inventories"]
+        if data.get("warehouse_edge_costs") is not None:
+            obs["warehouse_edge_costs"] = data["warehouse_edge_costs"]
+    if problem_params["n_extra_echelons"] > 0:
+        obs["echelon_lead_times"] = data["echelon_lead_times"]
+        obs["echelon_holding_costs"] = data["echelon_holding_costs"]
+        obs["echelon_inventories"] = data["initial_echelon_inventories"]
+    for k, on in observation_params["include_static_features"].items():
+        if on:
+            obs[k] = data[k]
+    if observation_params["demand"]["past_periods"] > 0 or observation_params.get("time_features") \
+            or observation_params.get("sample_features"):
+        raise NotImplementedError("oracle: real-data observation features are outside the hot path (SURVEY §8 f4)")
+    env.obs = obs
+    return env
+
+
+def env_step(env: OracleEnv, action: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """One period; returns the per-scenario cost (B,) and rebinds the state.  environment.py:110-169."""
+    obs, prob = env.obs, env.problem
+    d = env.demands[:, :, env.t + env.period_shift]  # :171-177
+
+    # --- stores (:179-234)
+    inv = obs["store_inventories"]
+    on_hand = inv[:, :, 0]
+    after = inv[:, :, 0] - d
+    p, h = obs["underage_costs"], obs["holding_costs"]
+    if prob["maximize_profit"]:
+        cost = -p * torch.minimum(on_hand, d) + h * torch.clip(after, min=0)  # :191-194
+    else:
+        cost = p * torch.clip(-after, min=0) + h * torch.clip(after, min=0)  # :198-201
+    if prob["lost_demand"]:
+        after = torch.clip(after, min=0)  # :204-205
+    obs["store_inventories"] = shift_pipeline_and_place(inv, after, action["stores"], obs["lead_times"])
+    total = cost.sum(dim=1)
+
+    # --- warehouses (:236-270)
+    if prob["n_warehouses"] > 0:
+        winv = obs["warehouse_inventories"]
+        shipped = action["stores"].sum(dim=1)
+        w_after = winv[:, :, 0] - shipped  # may go negative: feasibility is the policy's job
+        w_cost = obs["warehouse_holding_costs"] * torch.clip(w_after, min=0)
+        if obs.get("warehouse_edge_costs") is not None:
+            w_cost = w_cost + obs["warehouse_edge_costs"] * action["warehouses"].sum(dim=2)  # :254-259
+        obs["warehouse_inventories"] = shift_pipeline_and_place(
+            winv, w_after, action["warehouses"], obs["warehouse_lead_times"].unsqueeze(2))
+        total = total + w_cost.sum(dim=1)
+
+    # --- extra echelons (:272-299): echelon k ships what echelon k+1 ordered; the last one feeds the warehouses
+    if prob["n_extra_echelons"] > 0:
+        einv = obs["echelon_inventories"]
+        downstream = action["echelons"][:, 1:, :].sum(dim=2)
+        to_wh = action["warehouses"].sum(dim=(1, 2)).unsqueeze(1)
+        e_after = einv[:, :, 0] - torch.concat([downstream, to_wh], dim=1)
+        e_cost = obs["echelon_holding_costs"] * torch.clip(e_after, min=0)
+        obs["echelon_inventories"] = shift_pipeline_and_place(
+            einv, e_after, action["echelons"], obs["echelon_lead_times"].unsqueeze(2))
+        total = total + e_cost.sum(dim=1)
+
+    obs["current_period"] = obs["current_period"] + 1  # reference mutates in place (:165)
+    env.t += 1
+    return total
+
+
+# --------------------------------------------------------------------------------------
+# 3. Policies  (neural_networks.py:6-427, 1495-1574)
+# --------------------------------------------------------------------------------------
+
+_ACT = {
+    "relu": F.relu, "elu": F.elu, "tanh": torch.tanh, "softplus": F.softplus, "sigmoid": torch.sigmoid,
+    "softmax": lambda x: F.softmax(x, dim=1),
+}
+
+
+@dataclass
+class OraclePolicy:
+    """A policy = architecture name + ordered (weight, bias) pairs of its 'master' MLP."""
+    name: str
+    layers: List[Tuple[torch.Tensor, torch.Tensor]]
+    inner_activation: Optional[str]
+    output_activation: Optional[str]
+    warehouse_upper_bound: Optional[torch.Tensor] = None
+    adjacency: Optional[Sequence[Sequence[int]]] = None  # problem_params['warehouse_store_adjacency']
+    transshipment: bool = False
+
+    def parameters(self):
+        return [t for wb in self.layers for t in wb]
+
+
+def policy_from_state_dict(nn_params, state_dict, problem_params=None, warehouse_upper_bound=None):
+    """Builds an OraclePolicy from reference-format keys `net.master.<i>.weight/bias`
+    (layout produced by neural_networks.py:80-106)."""
+    idx = sorted({int(k.split(".")[2]) for k in state_dict if k.startswith("net.master.")})
+    layers = [(state_dict[f"net.master.{i}.weight"].detach().clone().float().requires_grad_(True),
+               state_dict[f"net.master.{i}.bias"].detach().clone().float().requires_grad_(True)) for i in idx]
+    return OraclePolicy(
+        name=nn_params["name"], layers=layers,
+        inner_activation=nn_params["inner_layer_activations"]["master"],
+        output_activation=nn_params["output_layer_activation"]["master"],
+        warehouse_upper_bound=warehouse_upper_bound,
+        adjacency=(problem_params or {}).get("warehouse_store_adjacency"),
+        transshipment=nn_params.get("transshipment", False),
+    )
+
+
+def default_master_output_size(problem_params):
+    """neural_networks.py:1500-1517."""
+    S, Wn = problem_params["n_stores"], problem_params["n_warehouses"]
+    return S * Wn + Wn if Wn > 1 else S + Wn
+
+
+def warehouse_upper_bound(mult, store_params):
+    """neural_networks.py:1538-1546 (reads the MUTATED store_params['demand']['mean'])."""
+    mean = store_params["demand"]["mean"]
+    if type(mean) == float:
+        mean = [mean]
+    return torch.tensor([mult * sum(mean)]).float()
+
+
+def init_policy(nn_params, problem_params, in_features, generator_seed, store_params=None):
+    """Random-init policy with torch's default Linear init (kaiming-uniform(a=sqrt(5)), as LazyLinear/Linear do,
+    neural_networks.py:88-97).  Used for synthetic benchmarks; parity tests load reference weights instead."""
+    g = torch.Generator().manual_seed(generator_seed)
+    hidden = list(nn_params["neurons_per_hidden_layer"]["master"])
+    out = nn_params["output_sizes"]["master"]
+    if out is None:
+        out = default_master_output_size(problem_params)
+    dims = [in_features] + hidden + [out]
+    layers = []
+    for fan_in, fan_out in zip(dims[:-1], dims[1:]):
+        bound = 1.0 / math.sqrt(fan_in)
+        w = (torch.rand(fan_out, fan_in, generator=g) * 2 - 1) * bound
+        b = (torch.rand(fan_out, generator=g) * 2 - 1) * bound
+        layers.append((w.requires_grad_(True), b.requires_grad_(True)))
+    bias0 = (nn_params.get("initial_bias") or {}).get("master")
+    if bias0 is not None:  # neural_networks.py:53-58
+        with torch.no_grad():
+            layers[-1][1].fill_(bias0)
+    ub = None
+    if "warehouse_upper_bound_mult" in nn_params and store_params is not None:
+        ub = warehouse_upper_bound(nn_params["warehouse_upper_bound_mult"], store_params)
+    return OraclePolicy(nn_params["name"], layers, nn_params["inner_layer_activations"]["master"],
+                        nn_params["output_layer_activation"]["master"], ub,
+                        problem_params.get("warehouse_store_adjacency"), nn_params.get("transshipment", False))
+
+
+def _mlp(pol: OraclePolicy, x):
+    """Sequential(Linear, act, ..., Linear[, out_act]).  neural_networks.py:80-106."""
+    n = len(pol.layers)
+    for i, (w, b) in enumerate(pol.layers):
+        x = F.linear(x, w, b)
+        if i < n - 1:
+            x = _ACT[pol.inner_activation](x)
+    if pol.output_activation is not None:
+        x = _ACT[pol.output_activation](x)
+    return x
+
+
+def _softmax_share_of_stock(logits, warehouse_pipeline, transshipment):
+    """neural_networks.py:140-166: softmax over connected stores (+ a constant-1 'keep' column unless
+    transshipment) times the warehouse's on-hand stock."""
+    stock = warehouse_pipeline[:, :, 0].sum(dim=1)
+    z = logits
+    if not transshipment:
+        z = torch.cat((z, torch.ones_like(z[:, 0])[:, None]), dim=1)
+    sm = F.softmax(z, dim=1)
+    if not transshipment:
+        sm = sm[:, :-1]
+    return torch.multiply(sm, stock[:, None])
+
+
+def policy_act(pol: OraclePolicy, obs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Forward of the in-scope architectures; action tensors are always 3-D."""
+    name = pol.name
+    if name == "vanilla_one_store":  # neural_networks.py:200-214
+        x = obs["store_inventories"].flatten(start_dim=1)
+        x = F.softplus(_mlp(pol, x) + 1)
+        return {"stores": x.unsqueeze(2)}
+
+    if name == "base_stock":  # :221-229
+        pos = obs["store_inventories"].sum(dim=2)
+        level = _mlp(pol, torch.tensor([0.0]))
+        return {"stores": torch.clip(level - pos, min=0).unsqueeze(2)}
+
+    if name == "capped_base_stock":  # :301-311
+        pos = obs["store_inventories"].sum(dim=2)
+        out = _mlp(pol, torch.tensor([0.0]))
+        return {"stores": torch.clip(out[0] - pos, min=torch.tensor([0.0]), max=out[1]).unsqueeze(2)}
+
+    if name == "echelon_stock":  # :236-294
+        s_inv, w_inv, e_inv = obs["store_inventories"], obs["warehouse_inventories"], obs["echelon_inventories"]
+        E = e_inv.size(1)
+        x = F.softplus(_mlp(pol, torch.tensor([0.0])) + 10.0)
+        levels = torch.cumsum(x, dim=0).flip(dims=[0])
+        pos = torch.concat((e_inv.sum(dim=2), w_inv.sum(dim=2), s_inv.sum(dim=2)), dim=1)
+        upstream = torch.concat((1000000 * torch.ones_like(w_inv[:, :, 0]), e_inv[:, :, 0], w_inv[:, :, 0]), dim=1)
+        want = torch.clip(torch.stack([levels[k] - pos[:, k:].sum(dim=1) for k in range(2 + E)], dim=1), min=0)
+        alloc = torch.minimum(want, upstream)
+        return {"stores": alloc[:, -1:].unsqueeze(2), "warehouses": alloc[:, -2:-1].unsqueeze(2),
+                "echelons": alloc[:, :E].unsqueeze(2)}
+
+    if name == "vanilla_serial":  # :319-355
+        s_inv, w_inv, e_inv = obs["store_inventories"], obs["warehouse_inventories"], obs["echelon_inventories"]
+        E = e_inv.size(1)
+        feats = torch.cat([t.flatten(start_dim=1) for t in (s_inv, w_inv, e_inv)], dim=1)
+        # :329 wraps the input in torch.tensor(...), which copy-constructs and DETACHES it: no gradient reaches
+        # the state through the MLP input in this architecture (only through `upstream` below).  Replicated.
+        x = _mlp(pol, feats.detach().clone())
+        upstream = torch.concat((pol.warehouse_upper_bound.unsqueeze(1).expand(e_inv.shape[0], -1),
+                                 e_inv[:, :, 0], w_inv[:, :, 0]), dim=1)
+        alloc = torch.sigmoid(x) * upstream
+        return {"stores": alloc[:, -1:].unsqueeze(2), "warehouses": alloc[:, -2:-1].unsqueeze(2),
+                "echelons": alloc[:, :E].unsqueeze(2)}
+
+    if name == "vanilla_warehouse":  # :369-427
+        s_inv, w_inv = obs["store_inventories"], obs["warehouse_inventories"]
+        S, Wn = s_inv.size(1), w_inv.size(1)
+        out = _mlp(pol, torch.cat((s_inv.flatten(start_dim=1), w_inv.flatten(start_dim=1)), dim=1))
+        if Wn == 1:
+            adj = torch.ones(1, S)
+        else:
+            if pol.adjacency is None:
+                raise ValueError(f"warehouse_store_adjacency matrix required for n_warehouses={Wn}")
+            adj = torch.tensor(pol.adjacency, dtype=torch.float32)
+        store_logits = out[:, :S * Wn].view(-1, S, Wn)
+        wh_logits = out[:, S * Wn:]
+        alloc = torch.zeros_like(store_logits)
+        for w in range(Wn):
+            conn = adj[w].nonzero(as_tuple=True)[0]
+            if len(conn) > 0:
+                alloc[:, conn, w] = _softmax_share_of_stock(store_logits[:, conn, w], w_inv[:, w:w + 1], pol.transshipment)
+        wh = torch.sigmoid(wh_logits) * pol.warehouse_upper_bound
+        return {"stores": alloc, "warehouses": wh.unsqueeze(2)}
+
+    raise KeyError(name)
+
+
+# --------------------------------------------------------------------------------------
+# 4. Rollout, cost reduction, training step  (trainer.py:143-216, loss_functions.py:11-12)
+# --------------------------------------------------------------------------------------
+
+
+@dataclass
+class RolloutResult:
+    total: torch.Tensor            # sum_t sum_b reward (0-d, carries grad)      trainer.py:208
+    reported: torch.Tensor         # same from t >= ignore_periods               trainer.py:209-210
+    per_period: torch.Tensor       # (T, B) detached rewards
+    final_obs: Dict[str, torch.Tensor]
+
+
+def rollout(pol: OraclePolicy, periods, problem_params, data, observation_params,
+            ignore_periods=0, discrete_allocation=False, keep_states=False) -> RolloutResult:
+    """trainer.py:181-216.  PolicyLoss = reward.sum() (loss_functions.py:11-12)."""
+    env = env_reset(periods, problem_params, dict(data), observation_params)
+    total, reported = 0, 0
+    per_period = []
+    states = []
+    for t in range(periods):
+        if keep_states:
+            states.append({k: v.detach().clone() for k, v in env.obs.items() if k.endswith("inventories")})
+        action = policy_act(pol, env.obs)
+        if discrete_allocation:
+            action = {k: v.round() for k, v in action.items()}  # trainer.py:201-202 (half-to-even)
+        reward = env_step(env, action)
+        r = reward.sum()
+        total = total + r
+        if t >= ignore_periods:
+            reported = reported + r
+        per_period.append(reward.detach())
+    res = RolloutResult(total, reported, torch.stack(per_period), env.obs)
+    if keep_states:
+        res.states = states
+    return res
+
+
+def train_step_gradients(pol: OraclePolicy, periods, problem_params, data, observation_params, ignore_periods=0):
+    """Forward + backward of one batch exactly as trainer.py:160-173 (mean over B*T*S, then backward).
+    Returns (rollout result, mean_loss value, list of grads aligned with pol.parameters())."""
+    for p in pol.parameters():
+        p.grad = None
+    res = rollout(pol, periods, problem_params, data, observation_params, ignore_periods)
+    B = len(data["demands"])
+    mean_loss = res.total / (B * periods * problem_params["n_stores"])
+    mean_loss.backward()
+    return res, mean_loss.detach(), [p.grad.detach().clone() for p in pol.parameters()]
+
+
+def epoch_losses(total, reported, n_samples, periods, ignore_periods, n_stores):
+    """Normalisations returned by do_one_epoch (trainer.py:179)."""
+    return total / (n_samples * periods * n_stores), reported / (n_samples * (periods - ignore_periods) * n_stores)

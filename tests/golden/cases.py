@@ -1,0 +1,61 @@
+"""Parity cases shared by make_golden.py (reference side) and the tests (oracle / HIP side).
+
+Each case names a reference setting + policy YAML, the overrides applied to them, and the
+(small) sizes at which the reference was run.  The five `cfg*` families are BASELINE.json's
+five configurations scaled down to sizes the CPU finishes in well under a second.
+"""
+
+CASES = {
+    # cfg1: one_store_lost + vanilla_one_store (Poisson demand, lost sales)
+    "cfg1_one_store_lost_vanilla": dict(
+        setting="one_store_lost", policy="vanilla_one_store", n=48, periods=14, ignore=5, torch_seed=11),
+    # cfg2: one_store_backlogged + vanilla_one_store / closed-form policies
+    "cfg2_one_store_backlogged_vanilla": dict(
+        setting="one_store_backlogged", policy="vanilla_one_store", n=40, periods=16, ignore=6, torch_seed=12),
+    "cfg2_one_store_backlogged_base_stock": dict(
+        setting="one_store_backlogged", policy="base_stock", n=40, periods=16, ignore=6, torch_seed=13),
+    "cfg2_one_store_backlogged_capped": dict(
+        setting="one_store_backlogged", policy="capped_base_stock", n=40, periods=16, ignore=6, torch_seed=14),
+    # cfg3: one_warehouse_lost_demand with 16 stores + vanilla_warehouse (hidden width cut to keep the fixture small)
+    "cfg3_one_warehouse_16_vanilla": dict(
+        setting="one_warehouse_lost_demand", policy="vanilla_warehouse", n=24, periods=12, ignore=4, torch_seed=15,
+        problem_overrides={"n_stores": 16}, hidden=[64, 64, 64]),
+    "cfg3_one_warehouse_5_vanilla": dict(
+        setting="one_warehouse_lost_demand", policy="vanilla_warehouse", n=20, periods=10, ignore=3, torch_seed=16,
+        hidden=[48, 48]),
+    # cfg4: serial_system (store + warehouse + 2 echelons) + vanilla_serial / echelon_stock
+    "cfg4_serial_vanilla": dict(
+        setting="serial_system", policy="vanilla_serial", n=32, periods=15, ignore=5, torch_seed=17),
+    "cfg4_serial_echelon_stock": dict(
+        setting="serial_system", policy="echelon_stock", n=32, periods=15, ignore=5, torch_seed=18),
+    # cfg5: many_warehouses_lost_demand (shipped 2x10 adjacency) + vanilla_warehouse
+    "cfg5_many_warehouses_2x10_vanilla": dict(
+        setting="many_warehouses_lost_demand", policy="vanilla_warehouse", n=20, periods=12, ignore=4, torch_seed=19,
+        hidden=[64, 64]),
+    # cfg5 scaled: 3 warehouses x 8 stores, synthetic adjacency / lead-time matrix in the YAML's format
+    "cfg5_many_warehouses_3x8_vanilla": dict(
+        setting="many_warehouses_lost_demand", policy="vanilla_warehouse", n=16, periods=10, ignore=3, torch_seed=20,
+        hidden=[32, 32],
+        problem_overrides={
+            "n_stores": 8, "n_warehouses": 3,
+            "warehouse_store_adjacency": [[1, 1, 0, 0, 1, 0, 1, 0],
+                                          [0, 1, 1, 1, 0, 0, 1, 1],
+                                          [1, 0, 0, 1, 0, 1, 0, 1]]},
+        store_overrides={"lead_time": {"sample_across_stores": False, "vary_across_samples": False, "expand": True,
+                                       "value": [[2, 0, 3], [1, 4, 0], [0, 2, 0], [0, 6, 1],
+                                                 [3, 0, 0], [0, 0, 2], [5, 2, 0], [0, 1, 3]]}},
+        warehouse_overrides={"holding_cost": [0.3, 0.4, 0.2], "lead_time": 3, "edge_cost": [0.5, 1.5, 0.7]}),
+}
+
+
+def apply_overrides(case, config_setting, config_hyper):
+    """Returns deep-copied (setting, hyper) dicts with the case's overrides applied."""
+    import copy
+    cs, ch = copy.deepcopy(config_setting), copy.deepcopy(config_hyper)
+    cs["problem_params"].update(case.get("problem_overrides", {}))
+    cs["store_params"].update(case.get("store_overrides", {}))
+    if case.get("warehouse_overrides"):
+        cs["warehouse_params"] = dict(case["warehouse_overrides"])
+    if case.get("hidden") is not None:
+        ch["nn_params"]["neurons_per_hidden_layer"]["master"] = list(case["hidden"])
+    return cs, ch

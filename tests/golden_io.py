@@ -1,0 +1,54 @@
+"""Loads tests/golden/*.npz fixtures (written by tests/golden/make_golden.py from the upstream reference)."""
+import copy
+import json
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+        self.z = z
+        self.cfg = json.loads(str(z["cfg_json"]))
+
+    def tensor(self, key):
+        return torch.from_numpy(np.array(self.z[key]))
+
+    def group(self, prefix):
+        plen = len(prefix) + 1
+        return {k[plen:]: self.tensor(k) for k in self.z.files if k.startswith(prefix + "/")}
+
+    @property
+    def data(self):
+        return self.group("data")
+
+    @property
+    def params(self):
+        return self.group("param")
+
+    @property
+    def grads(self):
+        return self.group("grad")
+
+    def states(self, t):
+        return self.group(f"states/{t}")
+
+    def actions(self, t):
+        return self.group(f"actions/{t}")
+
+    def fresh_config(self):
+        """Deep copies of the pre-mutation config dicts (Scenario mutates its inputs)."""
+        c = copy.deepcopy(self.cfg)
+        c["observation_params"] = defaultdict(lambda: None, c["observation_params"])
+        return c
+
+
+def case_names():
+    from cases import CASES
+    return list(CASES.keys())

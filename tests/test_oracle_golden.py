@@ -1,0 +1,115 @@
+"""Oracle (oracle/inventory_oracle.py) against the committed golden vectors produced by the upstream reference.
+
+Bit-exact: the oracle is an op-for-op PyTorch-CPU restatement, so data tensors, per-period rewards, states and
+the scalar totals must be EQUAL; parameter gradients are compared exactly as well (same autograd graph shape).
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_io import Golden, case_names
+from oracle import inventory_oracle as orc
+
+
+def _build(g):
+    c = g.fresh_config()
+    data = orc.generate_scenario_data(c["periods"], c["problem_params"], c["store_params"], c["warehouse_params"],
+                                      c["echelon_params"], c["n"], c["observation_params"], c["seeds"])
+    return c, data
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_scenario_data_bit_equal(name):
+    g = Golden(name)
+    c, data = _build(g)
+    ref = g.data
+    assert set(data.keys()) == set(ref.keys())
+    for k in ref:
+        assert data[k].dtype == torch.float32
+        assert tuple(data[k].shape) == tuple(ref[k].shape), k
+        assert torch.equal(data[k], ref[k]), k
+    # the reference mutates its config in place; downstream code depends on it
+    assert c["seeds"]["demand"] == int(g.z["mutated_demand_seed"])
+    np.testing.assert_array_equal(np.asarray(c["store_params"]["demand"]["mean"], dtype=np.float64), g.z["mutated_mean"])
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_rollout_and_gradients_bit_equal(name):
+    g = Golden(name)
+    c, _ = _build(g)
+    data = g.data
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"],
+                                     warehouse_upper_bound=g.tensor("warehouse_upper_bound"))
+    res, mean_loss, grads = orc.train_step_gradients(pol, c["periods"], c["problem_params"], data,
+                                                     c["observation_params"], c["ignore"])
+    assert torch.equal(res.per_period, g.tensor("rewards"))
+    assert float(res.total) == float(g.z["total"])
+    assert float(res.reported) == float(g.z["reported"])
+    assert float(mean_loss) == float(g.z["mean_loss"])
+    for k, v in g.states(c["periods"]).items():
+        assert torch.equal(res.final_obs[k], v), k
+    ref_grads = g.grads
+    keys = sorted(ref_grads.keys(), key=lambda s: (int(s.split(".")[2]), s.split(".")[3] != "weight"))
+    assert len(keys) == len(grads)
+    for k, mine in zip(keys, grads):
+        assert torch.equal(mine, ref_grads[k]), (k, (mine - ref_grads[k]).abs().max())
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_states_and_actions_trace(name):
+    g = Golden(name)
+    c, _ = _build(g)
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"],
+                                     warehouse_upper_bound=g.tensor("warehouse_upper_bound"))
+    env = orc.env_reset(c["periods"], c["problem_params"], g.data, c["observation_params"])
+    with torch.no_grad():
+        for t in range(c["periods"]):
+            for k, v in g.states(t).items():
+                assert torch.equal(env.obs[k], v), (t, k)
+            a = orc.policy_act(pol, env.obs)
+            for k, v in g.actions(t).items():
+                assert torch.equal(a[k], v), (t, k)
+            orc.env_step(env, a)
+
+
+def test_checkpoint_known_answer():
+    """The reference's shipped checkpoint stores best dev loss 6.854347610473633; SURVEY §4 KAT."""
+    g = Golden("checkpoint_kat")
+    c = g.fresh_config()
+    data = orc.generate_scenario_data(c["scenario_periods"], c["problem_params"], c["store_params"], None, None,
+                                      c["scenario_samples"], c["observation_params"], c["seeds"])
+    dev = {k: v[:c["dev_samples"]] for k, v in data.items()}
+    assert float(dev["demands"].double().sum()) == float(g.z["demand_checksum"])
+    assert float(dev["initial_inventories"].double().sum()) == float(g.z["init_inv_checksum"])
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"])
+    with torch.no_grad():
+        res = orc.rollout(pol, c["periods"], c["problem_params"], dev, c["observation_params"], c["ignore"])
+    _, reported = orc.epoch_losses(float(res.total), float(res.reported), c["dev_samples"], c["periods"], c["ignore"], 1)
+    assert float(res.reported) == float(g.z["reported"])
+    assert abs(reported - 6.854347610473633) < 5e-7
+    assert abs(reported - float(g.z["stored_best_dev_loss"])) < 5e-7
+
+
+def test_semantics_probe_worked_example():
+    """inv=[2,4,0,0], d=3, a=5, L=4, lost demand, p=9,h=1 -> cost 9, inv'=[4,0,0,5]."""
+    prob = {"n_stores": 1, "n_warehouses": 0, "n_extra_echelons": 0, "lost_demand": True, "maximize_profit": False}
+    data = {"demands": torch.tensor([[[3.0]]]), "initial_inventories": torch.tensor([[[2.0, 4.0, 0.0, 0.0]]]),
+            "underage_costs": torch.tensor([[9.0]]), "holding_costs": torch.tensor([[1.0]]),
+            "lead_times": torch.tensor([[[4.0]]])}
+    obsp = {"include_warehouse_inventory": False, "demand": {"past_periods": 0, "period_shift": 0},
+            "include_static_features": {"holding_costs": True, "underage_costs": True, "lead_times": True}}
+    env = orc.env_reset(1, prob, data, obsp)
+    r = orc.env_step(env, {"stores": torch.tensor([[[5.0]]])})
+    assert r.tolist() == [9.0]
+    assert env.obs["store_inventories"].tolist() == [[[4.0, 0.0, 0.0, 5.0]]]
+
+
+def test_zero_order_has_no_placement_gradient():
+    """environment.py:426-432: orders that are exactly 0 are filtered before the put -> zero gradient through the
+    pipeline, while the warehouse outflow sum (environment.py:247) still sees them."""
+    pipe = torch.zeros(2, 1, 3)
+    orders = torch.tensor([[[0.0]], [[2.0]]], requires_grad=True)
+    lead = torch.tensor([[[2.0]], [[2.0]]])
+    new = orc.shift_pipeline_and_place(pipe, torch.zeros(2, 1), orders, lead)
+    new.sum().backward()
+    assert orders.grad.flatten().tolist() == [0.0, 1.0]

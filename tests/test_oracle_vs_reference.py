@@ -1,0 +1,76 @@
+"""Live pin of the oracle against the upstream reference imported from /root/reference (THIS CONTAINER ONLY;
+skipped wherever the reference tree is absent, e.g. on the GPU box).  Complements the committed golden vectors with
+fresh seeds / sizes and the variants the YAMLs do not exercise (profit objective, discrete allocation)."""
+import copy
+from collections import defaultdict
+
+import pytest
+import torch
+
+import reference_harness as rh
+from cases import CASES, apply_overrides
+from oracle import inventory_oracle as orc
+
+pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="upstream reference not mounted")
+
+
+def _run_both(case, n, periods, ignore, torch_seed, maximize_profit=False, discrete=False):
+    ref = rh.load_reference()
+    cs, ch = rh.load_reference_configs(case["setting"], case["policy"])
+    cs, ch = apply_overrides(case, cs, ch)
+    cs["problem_params"]["maximize_profit"] = maximize_profit
+    cs_o = copy.deepcopy(cs)
+    obs_r = defaultdict(lambda: None, cs["observation_params"])
+    obs_o = defaultdict(lambda: None, cs_o["observation_params"])
+    with rh.in_reference_dir():
+        sc = ref.Scenario(periods, cs["problem_params"], cs["store_params"], cs["warehouse_params"],
+                          cs["echelon_params"], n, obs_r, cs["seeds"])
+        data_r = sc.get_data()
+        torch.manual_seed(torch_seed)
+        model = ref.NeuralNetworkCreator().create_neural_network(sc, ch["nn_params"], device="cpu")
+        sim, tr = ref.Simulator(device="cpu"), ref.Trainer(device="cpu")
+        o, _ = sim.reset(periods, cs["problem_params"], dict(data_r), obs_r)
+        with torch.no_grad():
+            oo = dict(o)
+            oo["internal_data"] = sim._internal_data
+            model(oo)
+        model.zero_grad()
+        total, rep = tr.simulate_batch(ref.PolicyLoss(), sim, model, periods, cs["problem_params"], dict(data_r),
+                                       obs_r, ignore, discrete)
+        (total / (n * periods * cs["problem_params"]["n_stores"])).backward()
+    data_o = orc.generate_scenario_data(periods, cs_o["problem_params"], cs_o["store_params"], cs_o["warehouse_params"],
+                                        cs_o["echelon_params"], n, obs_o, cs_o["seeds"])
+    for k in data_r:
+        assert torch.equal(data_r[k], data_o[k]), k
+    wub = model.warehouse_upper_bound if torch.is_tensor(model.warehouse_upper_bound) else None
+    pol = orc.policy_from_state_dict(ch["nn_params"], model.state_dict(), cs_o["problem_params"], wub)
+    for p in pol.parameters():
+        p.grad = None
+    res = orc.rollout(pol, periods, cs_o["problem_params"], data_o, obs_o, ignore, discrete)
+    (res.total / (n * periods * cs_o["problem_params"]["n_stores"])).backward()
+    assert float(res.total.detach()) == float(total.detach())
+    assert float(res.reported.detach()) == float(rep.detach())
+    for (k, p), mine in zip(model.named_parameters(), pol.parameters()):
+        if p.grad is None:
+            assert mine.grad is None or float(mine.grad.abs().max()) == 0.0
+        else:
+            assert torch.equal(p.grad, mine.grad), k
+    for k in ("store_inventories", "warehouse_inventories", "echelon_inventories"):
+        if k in sim.observation:
+            assert torch.equal(sim.observation[k], res.final_obs[k]), k
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fresh_seed_and_size(name):
+    _run_both(CASES[name], n=37, periods=9, ignore=2, torch_seed=1234)
+
+
+@pytest.mark.parametrize("name", ["cfg1_one_store_lost_vanilla", "cfg3_one_warehouse_5_vanilla"])
+def test_profit_objective(name):
+    _run_both(CASES[name], n=21, periods=7, ignore=0, torch_seed=5, maximize_profit=True)
+
+
+@pytest.mark.parametrize("name", ["cfg1_one_store_lost_vanilla", "cfg2_one_store_backlogged_base_stock",
+                                  "cfg5_many_warehouses_2x10_vanilla"])
+def test_discrete_allocation(name):
+    _run_both(CASES[name], n=21, periods=7, ignore=0, torch_seed=6, discrete=True)
