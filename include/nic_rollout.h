@@ -1,0 +1,189 @@
+/*
+ * nic_rollout.h — C ABI of the MI355X-native differentiable inventory-rollout engine (libnic_hip.so).
+ *
+ * This is the drop-in boundary.  The upstream reference (MatiasAlvo/Neural_inventory_control) is pure
+ * Python/PyTorch and has no FFI of its own; the entry points below are what its hot path would bind if it
+ * called native code, one per group of aten ops it issues today.  Each entry point cites the reference
+ * interface it replaces (paths relative to the reference root).  The reference-side ctypes stubs a maintainer
+ * would add are shown in INTEGRATION.md; neural_inventory_control_amd/_lib.py is the in-tree binding.
+ *
+ * Conventions
+ *  - All buffers are DEVICE pointers owned by the caller (PyTorch's caching allocator in-tree). Kernels never
+ *    allocate and never synchronise; every call enqueues work on `stream` (a hipStream_t passed as void*).
+ *  - float32 everywhere (the reference casts every tensor to f32, data_handling.py:81); lead times are
+ *    integer-valued floats and are converted with (int) exactly like `.long()` (environment.py:422).
+ *  - "Scenario-minor" (SoA) layout: a per-scenario quantity with R rows is stored [R][ldb] with the scenario
+ *    index contiguous (ldb >= n_scenarios, multiple of 64 recommended) so that the 64 lanes of a wavefront read
+ *    64 consecutive scenarios.  Pipelines are [location][slot][ldb]; slot 0 = on hand.
+ *  - Return value: 0 on success, nonzero on error; nic_last_error() returns a thread-local message.
+ */
+#ifndef NIC_ROLLOUT_H
+#define NIC_ROLLOUT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIC_ABI_VERSION 1
+#define NIC_MAX_SLOTS 16 /* longest supported pipeline (max lead time) */
+
+/* element (loc, b) of a per-location table lives at p[loc*loc_stride + b*scn_stride]; scn_stride == 0 broadcasts
+ * one row to every scenario (the reference's `expand` views, data_handling.py:257-269). */
+typedef struct NicTable2 {
+    const float* p;
+    int64_t loc_stride;
+    int64_t scn_stride;
+} NicTable2;
+
+/* element (loc, supplier, b) at p[loc*loc_stride + sup*sup_stride + b*scn_stride] */
+typedef struct NicTable3 {
+    const float* p;
+    int64_t loc_stride;
+    int64_t sup_stride;
+    int64_t scn_stride;
+} NicTable3;
+
+typedef struct NicEnvDims {
+    int32_t n_scenarios;      /* B */
+    int32_t ldb;              /* scenario stride between rows of SoA buffers */
+    int32_t n_stores;         /* S  (problem_params['n_stores']) */
+    int32_t n_warehouses;     /* Wn (0 => store orders have a single outside supplier column) */
+    int32_t n_echelons;       /* E  (problem_params['n_extra_echelons']) */
+    int32_t store_slots;      /* Ws = initial_inventories.shape[2]  (>= 2) */
+    int32_t warehouse_slots;  /* Ww */
+    int32_t echelon_slots;    /* We */
+    int32_t lost_demand;      /* problem_params['lost_demand'] */
+    int32_t maximize_profit;  /* problem_params['maximize_profit'] */
+} NicEnvDims;
+
+/* Everything one period of dynamics reads.  Replaces Simulator.step's inputs:
+ * observation[...] + action[...] + _internal_data['demands'][:, :, t]  (environment.py:110-169). */
+typedef struct NicEnvStepIO {
+    NicEnvDims dims;
+    const float* store_inv;   /* [S][Ws][ldb]   observation['store_inventories']      */
+    const float* wh_inv;      /* [Wn][Ww][ldb]  observation['warehouse_inventories']  (NULL if Wn == 0) */
+    const float* ech_inv;     /* [E][We][ldb]   observation['echelon_inventories']    (NULL if E == 0)  */
+    NicTable2 demand;         /* (s, b) demand of this period (environment.py:171-177) */
+    NicTable3 store_orders;   /* (s, w, b) action['stores']     (B,S,max(Wn,1)) */
+    NicTable2 wh_orders;      /* (w, b)    action['warehouses'] (B,Wn,1) */
+    NicTable2 ech_orders;     /* (e, b)    action['echelons']   (B,E,1)  */
+    NicTable2 underage;       /* (s, b) observation['underage_costs'] */
+    NicTable2 holding;        /* (s, b) observation['holding_costs']  */
+    NicTable3 lead_times;     /* (s, w, b) observation['lead_times'] */
+    NicTable2 wh_holding;     /* (w, b) */
+    NicTable2 wh_lead_times;  /* (w, b) */
+    NicTable2 wh_edge_costs;  /* (w, b); p == NULL when the setting has no edge costs (environment.py:254) */
+    NicTable2 ech_holding;    /* (e, b) */
+    NicTable2 ech_lead_times; /* (e, b) */
+} NicEnvStepIO;
+
+/* ---- library ------------------------------------------------------------------------------------------- */
+int nic_abi_version(void);
+const char* nic_last_error(void);
+/* number of visible HIP devices (does not initialise a context beyond hipGetDeviceCount) */
+int nic_device_count(void);
+
+/* ---- one period of inventory dynamics -------------------------------------------------------------------
+ * Forward.  Replaces Simulator.step (environment.py:110-169) = store / warehouse / echelon cost and pipeline
+ * update (environment.py:179-299) incl. update_inventory_for_heterogeneous_lead_times (environment.py:391-434).
+ * Writes the next state and reward[b] = per-scenario cost of the period (the `reward` Simulator.step returns). */
+int nic_env_step_fwd(const NicEnvStepIO* io, float* store_inv_out, float* wh_inv_out, float* ech_inv_out,
+                     float* reward /* [ldb] */, void* stream);
+
+/* Backward of the same period (what autograd derives from environment.py:179-299,405-432, including the
+ * `allocation != 0` filter at :426-429 and torch's clamp / minimum tie rules).
+ * g_*_out: gradient w.r.t. the NEXT state (NULL = zeros); g_reward: (b) table, scn_stride 0 = one scalar.
+ * Outputs (all SoA, fully overwritten for b < n_scenarios): gradient w.r.t. the CURRENT state and the orders. */
+int nic_env_step_bwd(const NicEnvStepIO* io, const float* g_store_out, const float* g_wh_out,
+                     const float* g_ech_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in,
+                     float* g_ech_in, float* g_store_orders /* [S][max(Wn,1)][ldb] */,
+                     float* g_wh_orders /* [Wn][ldb] */, float* g_ech_orders /* [E][ldb] */, void* stream);
+
+/* ---- policy MLP layers (feature-major activations) ------------------------------------------------------
+ * Replaces nn.Linear + activation inside MyNeuralNetwork.create_sequential_net (neural_networks.py:80-106):
+ *   Y[n][b] = act( sum_k W[n][k] * X[k][b] + bias[n] )          X: [K][ldb], Y: [N][ldb], W: [N][ldw]
+ * on the FP32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate).
+ * act: 0 = identity, 1 = ELU(alpha=1) (nn.ELU, neural_networks.py:38). */
+#define NIC_ACT_NONE 0
+#define NIC_ACT_ELU 1
+int nic_linear_fwd(const float* W, int64_t ldw, const float* bias /* may be NULL */, const float* X, float* Y,
+                   int32_t N, int32_t K, int32_t n_scenarios, int32_t ldb, int32_t act, void* stream);
+
+/* Input gradient of the same layer (autograd of F.linear + activation of the PREVIOUS layer):
+ *   dX[k][b] = (sum_n Wt[k][n] * dY[n][b]) * act'(Hprev[k][b])  (+ dX[k][b] if accumulate)
+ * Wt = W transposed ([K][ldwt], refreshed by the caller once per optimizer step); Hprev = the previous layer's
+ * POST-activation output (ELU' is recovered from the output: x>0 ? 1 : y+1), NULL when the input is not an
+ * activation (first layer). */
+int nic_linear_dgrad(const float* Wt, int64_t ldwt, const float* dY, const float* Hprev, float* dX, int32_t N,
+                     int32_t K, int32_t n_scenarios, int32_t ldb, int32_t act_prev, int32_t accumulate,
+                     void* stream);
+
+/* Weight/bias gradient, accumulated over scenarios into per-split slabs that persist across the periods of a
+ * rollout (deterministic: no atomics):
+ *   slab[split][n][k] += sum_{b in split} dY[n][b] * X[k][b]   for k < K;   slab[split][n][K] += sum_b dY[n][b]
+ * slab: [n_splits][N][lds] with lds >= K+1.  nic_wgrad_num_splits gives the split count the kernel expects. */
+int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios);
+int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds, int32_t N, int32_t K,
+                     int32_t n_scenarios, int32_t ldb, int32_t n_splits, void* stream);
+/* dW[n][k] = scale * sum_split slab[split][n][k] (k < K), db[n] = scale * sum_split slab[split][n][K] */
+int nic_wgrad_reduce(const float* slab, int64_t lds, int32_t n_splits, float* dW, int64_t lddw, float* db,
+                     int32_t N, int32_t K, float scale, void* stream);
+
+/* ---- policy heads (logits -> feasible orders) ------------------------------------------------------------
+ * vanilla_warehouse (neural_networks.py:369-427 + apply_softmax_feasibility_function :140-166):
+ *   logits Z: [S*Wn + Wn][ldb] (row s*Wn + w = store s from warehouse w; then Wn warehouse rows)
+ *   store_orders[s][w][b] = adjacency[w][s] ? softmax_{connected s' of w, plus a constant-1 'keep' logit}(Z)[s]
+ *                                             * wh_inv[w][0][b] : 0
+ *   wh_orders[w][b] = sigmoid(Z[S*Wn + w][b]) * upper_bound
+ * adjacency: device int32 [Wn][S] (all ones for Wn == 1, neural_networks.py:384-385). */
+int nic_head_warehouse_fwd(const float* Z, const float* wh_inv /* [Wn][Ww][ldb] */, const int32_t* adjacency,
+                           float upper_bound, int32_t transshipment, float* store_orders /* [S][Wn][ldb] */,
+                           float* wh_orders /* [Wn][ldb] */, int32_t S, int32_t Wn, int32_t Ww,
+                           int32_t n_scenarios, int32_t ldb, void* stream);
+/* backward: given gradients of the orders, produce dZ and ADD the head's contribution to the gradient of the
+ * warehouse on-hand slot (g_wh_inv[w][0][b] += ...). */
+int nic_head_warehouse_bwd(const float* Z, const float* wh_inv, const int32_t* adjacency, float upper_bound,
+                           int32_t transshipment, const float* g_store_orders, const float* g_wh_orders,
+                           float* dZ, float* g_wh_inv, int32_t S, int32_t Wn, int32_t Ww, int32_t n_scenarios,
+                           int32_t ldb, void* stream);
+
+/* vanilla_one_store (neural_networks.py:200-214): orders[s][b] = softplus(Z[s][b] + 1)  (threshold 20 like
+ * nn.Softplus).  rows = number of output rows (1 for the shipped config). */
+int nic_head_softplus_fwd(const float* Z, float* orders, int32_t rows, int32_t n_scenarios, int32_t ldb,
+                          void* stream);
+int nic_head_softplus_bwd(const float* Z, const float* g_orders, float* dZ, int32_t rows, int32_t n_scenarios,
+                          int32_t ldb, void* stream);
+
+/* vanilla_serial (neural_networks.py:319-355): Z rows = [E echelons..., warehouse, store]; each row is
+ * sigmoid(Z) * upstream on-hand, where upstream = [upper_bound, ech_inv[0..E-1][0], wh_inv[0][0]].
+ * NOTE: the reference detaches the MLP input (torch.tensor(...) at :329); that is the caller's concern. */
+int nic_head_serial_fwd(const float* Z, const float* wh_inv, const float* ech_inv, float upper_bound,
+                        float* store_orders, float* wh_orders, float* ech_orders, int32_t E, int32_t Ww,
+                        int32_t We, int32_t n_scenarios, int32_t ldb, void* stream);
+int nic_head_serial_bwd(const float* Z, const float* wh_inv, const float* ech_inv, float upper_bound,
+                        const float* g_store_orders, const float* g_wh_orders, const float* g_ech_orders,
+                        float* dZ, float* g_wh_inv, float* g_ech_inv, int32_t E, int32_t Ww, int32_t We,
+                        int32_t n_scenarios, int32_t ldb, void* stream);
+
+/* ---- batched demand sampler -------------------------------------------------------------------------------
+ * Replaces Scenario.generate_normal_demand / generate_poisson_demand (data_handling.py:178-211) for synthetic
+ * throughput runs: counter-based Philox4x32-10 keyed by (seed, global scenario index, period), so results do not
+ * depend on how scenarios are sharded over GPUs.  Output layout [T][S][ldb] (the layout nic_env_step reads).
+ *   kind 0: normal   d = mean[s] + sum_j chol[s][j] * z[j]   (chol = lower Cholesky factor of the covariance,
+ *                    row-major [S][S]; identity*std for independent stores), clipped at 0 if clip != 0
+ *   kind 1: poisson  d ~ Poisson(mean[s]) (inversion by sequential search; mean <= ~30)
+ * Statistical (not bitwise) parity with numpy's MT19937 stream — see DESIGN.md. */
+int nic_sample_demand(float* out, int32_t T, int32_t S, int32_t n_scenarios, int32_t ldb, int64_t scenario_offset,
+                      uint64_t seed, int32_t kind, const float* mean /* [S] */, const float* chol /* [S][S] */,
+                      int32_t clip, void* stream);
+
+/* ---- small utilities on SoA buffers ---------------------------------------------------------------------- */
+/* out[b] += in[b] for b < n (per-scenario running cost); */
+int nic_axpy(float* out, const float* in, float alpha, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIC_ROLLOUT_H */

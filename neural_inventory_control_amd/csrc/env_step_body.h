@@ -1,0 +1,285 @@
+// Per-scenario body of one period of inventory dynamics (forward + analytic backward).
+//
+// One GPU lane owns one scenario b: every reduction the reference performs inside a period is over the stores /
+// warehouses of ONE scenario (environment.py:234,247,270,299), so a lane loops over its locations and needs no
+// cross-lane traffic; with the scenario-minor layout each of its loads is one coalesced 256-B wave access.
+//
+// The body is NIC_HD (host + device) so that tests can run the identical arithmetic on the CPU against the oracle
+// (tests/hostsim) before any GPU time is spent; the product only ever launches the __global__ wrappers in
+// env_step.hip.  Compiled with -ffp-contract=off so that mul/add round separately like the reference's aten ops.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/nic_rollout.h"
+
+#if defined(__HIPCC__)
+#define NIC_HD __host__ __device__ __forceinline__
+#else
+#define NIC_HD inline
+#endif
+
+namespace nic {
+
+NIC_HD float t2(const NicTable2& t, int loc, int64_t b) { return t.p[loc * t.loc_stride + b * t.scn_stride]; }
+NIC_HD float t3(const NicTable3& t, int loc, int sup, int64_t b) {
+    return t.p[loc * t.loc_stride + sup * t.sup_stride + b * t.scn_stride];
+}
+NIC_HD float relu(float x) { return x > 0.f ? x : 0.f; }
+
+// Sum over the locations of one scenario with four interleaved accumulators combined as ((a0+a1)+a2)+a3.
+// Four independent chains give the lane ILP; the order also coincides with what the reference's CPU `sum(dim=1)`
+// does for outer-dimension reductions (measured on torch 2.10), which keeps knife-edge `>= 0` masks on the
+// warehouse on-hand (environment.py:249-251) on the reference's side of zero more often than a serial sum.
+struct Sum4 {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    NIC_HD void add(int i, float v) {
+        switch (i & 3) {
+            case 0: a0 += v; break;
+            case 1: a1 += v; break;
+            case 2: a2 += v; break;
+            default: a3 += v; break;
+        }
+    }
+    NIC_HD float total() const { return ((a0 + a1) + a2) + a3; }
+};
+
+// new[0] = on_hand_after + old[1]; new[k] = old[k+1]; new[W-1] = 0            (environment.py:405-412)
+template <int MAXW>
+NIC_HD void shifted_pipeline(const float* old_slots, int64_t ldb, int W, float on_hand_after, float (&nv)[MAXW]) {
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) {
+        float v = 0.f;
+        if (k == 0) v = on_hand_after + old_slots[ldb];
+        else if (k < W - 1) v = old_slots[(int64_t)(k + 1) * ldb];
+        nv[k] = v;
+    }
+}
+
+// add `a` into slot L-1 when a != 0 (the reference filters zero orders before the put, environment.py:426-432)
+template <int MAXW>
+NIC_HD void place_order(float (&nv)[MAXW], int W, float a, float lead) {
+    const int slot = (int)lead - 1;
+    if (a != 0.f) {
+#pragma unroll
+        for (int k = 0; k < MAXW; ++k)
+            if (k == slot && k < W) nv[k] += a;
+    }
+}
+
+template <int MAXW>
+NIC_HD void store_pipeline(float* out_slots, int64_t ldb, int W, const float (&nv)[MAXW]) {
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k)
+        if (k < W) out_slots[(int64_t)k * ldb] = nv[k];
+}
+
+template <int MAXW>
+NIC_HD float pick(const float (&g)[MAXW], int W, int slot) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k)
+        if (k == slot && k < W) r = g[k];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Forward of one scenario.  Follows Simulator.step: stores (environment.py:179-234), warehouses (:236-270),
+// echelons (:272-299).
+// ------------------------------------------------------------------------------------------------------------
+template <int MAXW>
+NIC_HD void env_step_fwd_scenario(const NicEnvStepIO& io, float* store_out, float* wh_out, float* ech_out,
+                                  float* reward, int64_t b) {
+    const NicEnvDims& d = io.dims;
+    const int64_t ldb = d.ldb;
+    const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
+
+    // ---- stores
+    Sum4 r_store;
+    for (int s = 0; s < d.n_stores; ++s) {
+        const float* inv = io.store_inv + (int64_t)s * d.store_slots * ldb + b;
+        const float on_hand = inv[0];
+        const float dem = t2(io.demand, s, b);
+        float after = on_hand - dem;
+        const float p = t2(io.underage, s, b), h = t2(io.holding, s, b);
+        float c;
+        if (d.maximize_profit) {
+            c = (-p) * (on_hand < dem ? on_hand : dem) + h * relu(after);  // :191-194
+        } else {
+            c = p * relu(-after) + h * relu(after);  // :198-201
+        }
+        r_store.add(s, c);
+        if (d.lost_demand) after = relu(after);  // :204-205
+        float nv[MAXW];
+        shifted_pipeline<MAXW>(inv, ldb, d.store_slots, after, nv);
+        for (int w = 0; w < nsup; ++w)
+            place_order<MAXW>(nv, d.store_slots, t3(io.store_orders, s, w, b), t3(io.lead_times, s, w, b));
+        store_pipeline<MAXW>(store_out + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, nv);
+    }
+    float total = r_store.total();
+
+    // ---- warehouses: ship whatever the stores ordered (no feasibility clip: :249)
+    float wh_orders_sum = 0.f;
+    if (d.n_warehouses > 0) {
+        float r_wh = 0.f;
+        for (int w = 0; w < d.n_warehouses; ++w) {
+            Sum4 ship4;
+            for (int s = 0; s < d.n_stores; ++s) ship4.add(s, t3(io.store_orders, s, w, b));  // :247
+            const float shipped = ship4.total();
+            const float* inv = io.wh_inv + (int64_t)w * d.warehouse_slots * ldb + b;
+            const float after = inv[0] - shipped;
+            float c = t2(io.wh_holding, w, b) * relu(after);  // :251
+            const float a = t2(io.wh_orders, w, b);
+            if (io.wh_edge_costs.p) c = c + t2(io.wh_edge_costs, w, b) * a;  // :254-259
+            r_wh += c;
+            wh_orders_sum += a;
+            float nv[MAXW];
+            shifted_pipeline<MAXW>(inv, ldb, d.warehouse_slots, after, nv);
+            place_order<MAXW>(nv, d.warehouse_slots, a, t2(io.wh_lead_times, w, b));
+            store_pipeline<MAXW>(wh_out + (int64_t)w * d.warehouse_slots * ldb + b, ldb, d.warehouse_slots, nv);
+        }
+        total += r_wh;
+    }
+
+    // ---- extra echelons: echelon e ships what echelon e+1 ordered; the last one feeds the warehouses (:282-285)
+    if (d.n_echelons > 0) {
+        float r_e = 0.f;
+        for (int e = 0; e < d.n_echelons; ++e) {
+            const float ship = (e < d.n_echelons - 1) ? t2(io.ech_orders, e + 1, b) : wh_orders_sum;
+            const float* inv = io.ech_inv + (int64_t)e * d.echelon_slots * ldb + b;
+            const float after = inv[0] - ship;
+            r_e += t2(io.ech_holding, e, b) * relu(after);  // :287
+            float nv[MAXW];
+            shifted_pipeline<MAXW>(inv, ldb, d.echelon_slots, after, nv);
+            place_order<MAXW>(nv, d.echelon_slots, t2(io.ech_orders, e, b), t2(io.ech_lead_times, e, b));
+            store_pipeline<MAXW>(ech_out + (int64_t)e * d.echelon_slots * ldb + b, ldb, d.echelon_slots, nv);
+        }
+        total += r_e;
+    }
+    reward[b] = total;
+}
+
+// gradient w.r.t. the old pipeline given the gradient of the new one and of the post-demand on-hand:
+// old[0] <- g_after (through on_hand_after), old[1] <- g_new[0], old[k] <- g_new[k-1] (k >= 2)
+template <int MAXW>
+NIC_HD void store_pipeline_grad(float* g_in, int64_t ldb, int W, const float (&gn)[MAXW], float g_on_hand) {
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) {
+        if (k < W) {
+            float v;
+            if (k == 0) v = g_on_hand;
+            else if (k == 1) v = gn[0];
+            else v = gn[k - 1];
+            g_in[(int64_t)k * ldb] = v;
+        }
+    }
+}
+
+template <int MAXW>
+NIC_HD void load_grad(const float* g_out, int64_t ldb, int W, float (&gn)[MAXW]) {
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) gn[k] = (g_out != nullptr && k < W) ? g_out[(int64_t)k * ldb] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward of one scenario (what autograd derives for the ops cited above).  Tie rules of torch 2.x:
+// clamp(min=0) passes the gradient where x >= 0; minimum splits it 0.5/0.5 on ties; orders that are exactly 0
+// get no gradient through the pipeline placement but still through the warehouse / echelon outflow sums.
+// ------------------------------------------------------------------------------------------------------------
+template <int MAXW>
+NIC_HD void env_step_bwd_scenario(const NicEnvStepIO& io, const float* g_store_out, const float* g_wh_out,
+                                  const float* g_ech_out, const NicTable2& g_reward, float* g_store_in,
+                                  float* g_wh_in, float* g_ech_in, float* g_store_orders, float* g_wh_orders,
+                                  float* g_ech_orders, int64_t b) {
+    const NicEnvDims& d = io.dims;
+    const int64_t ldb = d.ldb;
+    const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
+    const float gr = g_reward.p[b * g_reward.scn_stride];
+
+    // ---- echelons (most upstream first: their outflow gradient lands on downstream orders)
+    float g_to_wh_orders = 0.f;  // d/d(sum_w wh_orders) coming from the last echelon's outflow
+    if (d.n_echelons > 0) {
+        float wh_orders_sum = 0.f;
+        for (int w = 0; w < d.n_warehouses; ++w) wh_orders_sum += t2(io.wh_orders, w, b);
+        float prev_g_after = 0.f;
+        for (int e = 0; e < d.n_echelons; ++e) {
+            const float ship = (e < d.n_echelons - 1) ? t2(io.ech_orders, e + 1, b) : wh_orders_sum;
+            const float* inv = io.ech_inv + (int64_t)e * d.echelon_slots * ldb + b;
+            const float after = inv[0] - ship;
+            float gn[MAXW];
+            load_grad<MAXW>(g_ech_out ? g_ech_out + (int64_t)e * d.echelon_slots * ldb + b : nullptr, ldb,
+                            d.echelon_slots, gn);
+            const float a = t2(io.ech_orders, e, b);
+            float ga = (a != 0.f) ? pick<MAXW>(gn, d.echelon_slots, (int)t2(io.ech_lead_times, e, b) - 1) : 0.f;
+            float g_after = gn[0];
+            if (after >= 0.f) g_after += gr * t2(io.ech_holding, e, b);
+            store_pipeline_grad<MAXW>(g_ech_in + (int64_t)e * d.echelon_slots * ldb + b, ldb, d.echelon_slots, gn,
+                                      g_after);
+            // echelon e's own order is shipped by echelon e-1
+            g_ech_orders[(int64_t)e * ldb + b] = ga - prev_g_after;
+            prev_g_after = g_after;
+        }
+        g_to_wh_orders = -prev_g_after;
+    }
+
+    // ---- warehouses
+    if (d.n_warehouses > 0) {
+        for (int w = 0; w < d.n_warehouses; ++w) {
+            Sum4 ship4;
+            for (int s = 0; s < d.n_stores; ++s) ship4.add(s, t3(io.store_orders, s, w, b));
+            const float shipped = ship4.total();
+            const float* inv = io.wh_inv + (int64_t)w * d.warehouse_slots * ldb + b;
+            const float after = inv[0] - shipped;
+            float gn[MAXW];
+            load_grad<MAXW>(g_wh_out ? g_wh_out + (int64_t)w * d.warehouse_slots * ldb + b : nullptr, ldb,
+                            d.warehouse_slots, gn);
+            const float a = t2(io.wh_orders, w, b);
+            float ga = (a != 0.f) ? pick<MAXW>(gn, d.warehouse_slots, (int)t2(io.wh_lead_times, w, b) - 1) : 0.f;
+            if (io.wh_edge_costs.p) ga += gr * t2(io.wh_edge_costs, w, b);
+            ga += g_to_wh_orders;
+            g_wh_orders[(int64_t)w * ldb + b] = ga;
+            float g_after = gn[0];
+            if (after >= 0.f) g_after += gr * t2(io.wh_holding, w, b);
+            store_pipeline_grad<MAXW>(g_wh_in + (int64_t)w * d.warehouse_slots * ldb + b, ldb, d.warehouse_slots, gn,
+                                      g_after);
+            // every store order from this warehouse reduces its on-hand stock (no zero filter on this path)
+            for (int s = 0; s < d.n_stores; ++s) g_store_orders[((int64_t)s * nsup + w) * ldb + b] = -g_after;
+        }
+    }
+
+    // ---- stores
+    for (int s = 0; s < d.n_stores; ++s) {
+        const float* inv = io.store_inv + (int64_t)s * d.store_slots * ldb + b;
+        const float on_hand = inv[0];
+        const float dem = t2(io.demand, s, b);
+        const float after = on_hand - dem;
+        const float p = t2(io.underage, s, b), h = t2(io.holding, s, b);
+        float gn[MAXW];
+        load_grad<MAXW>(g_store_out ? g_store_out + (int64_t)s * d.store_slots * ldb + b : nullptr, ldb,
+                        d.store_slots, gn);
+        // through the carried inventory (lost demand clips it at 0: gradient where after >= 0)
+        float g_after = gn[0];
+        if (d.lost_demand && !(after >= 0.f)) g_after = 0.f;
+        float g_on_hand;
+        if (d.maximize_profit) {
+            if (after >= 0.f) g_after += gr * h;
+            float share = on_hand < dem ? 1.f : (on_hand == dem ? 0.5f : 0.f);  // minimum() tie rule
+            g_on_hand = g_after + gr * (-p) * share;
+        } else {
+            float gc = 0.f;
+            if (-after >= 0.f) gc += -p;  // d/d(after) of p*clamp(-after, 0)
+            if (after >= 0.f) gc += h;    // d/d(after) of h*clamp(after, 0)
+            g_on_hand = g_after + gr * gc;
+        }
+        store_pipeline_grad<MAXW>(g_store_in + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, gn,
+                                  g_on_hand);
+        for (int w = 0; w < nsup; ++w) {
+            const float a = t3(io.store_orders, s, w, b);
+            float ga = (a != 0.f) ? pick<MAXW>(gn, d.store_slots, (int)t3(io.lead_times, s, w, b) - 1) : 0.f;
+            float* dst = g_store_orders + ((int64_t)s * nsup + w) * ldb + b;
+            if (d.n_warehouses > 0) ga += *dst;  // outflow term written in the warehouse pass above
+            *dst = ga;
+        }
+    }
+}
+
+}  // namespace nic

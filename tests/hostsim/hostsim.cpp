@@ -1,0 +1,63 @@
+// TEST INFRASTRUCTURE: runs the NIC_HD per-scenario bodies of the HIP kernels on the host (plain g++), looping
+// over scenarios, so their arithmetic can be checked against the oracle without a GPU.  Never linked into the
+// product library; the product has no CPU path.
+#include "../../neural_inventory_control_amd/csrc/env_step_body.h"
+#include "../../neural_inventory_control_amd/csrc/policy_heads_body.h"
+
+template <int MAXW>
+static void fwd_all(const NicEnvStepIO& io, float* so, float* wo, float* eo, float* r) {
+    for (int64_t b = 0; b < io.dims.n_scenarios; ++b) nic::env_step_fwd_scenario<MAXW>(io, so, wo, eo, r, b);
+}
+template <int MAXW>
+static void bwd_all(const NicEnvStepIO& io, const float* gso, const float* gwo, const float* geo, NicTable2 gr,
+                    float* gsi, float* gwi, float* gei, float* gas, float* gaw, float* gae) {
+    for (int64_t b = 0; b < io.dims.n_scenarios; ++b)
+        nic::env_step_bwd_scenario<MAXW>(io, gso, gwo, geo, gr, gsi, gwi, gei, gas, gaw, gae, b);
+}
+
+extern "C" {
+int hostsim_env_step_fwd(const NicEnvStepIO* io, float* so, float* wo, float* eo, float* r) {
+    fwd_all<NIC_MAX_SLOTS>(*io, so, wo, eo, r);
+    return 0;
+}
+int hostsim_env_step_bwd(const NicEnvStepIO* io, const float* gso, const float* gwo, const float* geo, NicTable2 gr,
+                         float* gsi, float* gwi, float* gei, float* gas, float* gaw, float* gae) {
+    bwd_all<NIC_MAX_SLOTS>(*io, gso, gwo, geo, gr, gsi, gwi, gei, gas, gaw, gae);
+    return 0;
+}
+int hostsim_head_warehouse_fwd(const float* Z, const float* wh_inv, const int32_t* adj, float ub, int32_t trans,
+                               float* so, float* wo, int32_t S, int32_t Wn, int32_t Ww, int32_t B, int32_t ldb) {
+    for (int64_t b = 0; b < B; ++b) nic::head_warehouse_fwd_scenario(Z, wh_inv, adj, ub, trans, so, wo, S, Wn, Ww, ldb, b);
+    return 0;
+}
+int hostsim_head_warehouse_bwd(const float* Z, const float* wh_inv, const int32_t* adj, float ub, int32_t trans,
+                               const float* gso, const float* gwo, float* dZ, float* gwi, int32_t S, int32_t Wn,
+                               int32_t Ww, int32_t B, int32_t ldb) {
+    for (int64_t b = 0; b < B; ++b)
+        nic::head_warehouse_bwd_scenario(Z, wh_inv, adj, ub, trans, gso, gwo, dZ, gwi, S, Wn, Ww, ldb, b);
+    return 0;
+}
+int hostsim_head_softplus_fwd(const float* Z, float* o, int32_t rows, int32_t B, int32_t ldb) {
+    for (int r = 0; r < rows; ++r)
+        for (int64_t b = 0; b < B; ++b) o[(int64_t)r * ldb + b] = nic::softplus1_fwd(Z[(int64_t)r * ldb + b]);
+    return 0;
+}
+int hostsim_head_softplus_bwd(const float* Z, const float* g, float* dZ, int32_t rows, int32_t B, int32_t ldb) {
+    for (int r = 0; r < rows; ++r)
+        for (int64_t b = 0; b < B; ++b)
+            dZ[(int64_t)r * ldb + b] = g[(int64_t)r * ldb + b] * nic::softplus1_grad(Z[(int64_t)r * ldb + b]);
+    return 0;
+}
+int hostsim_head_serial_fwd(const float* Z, const float* wh_inv, const float* ech_inv, float ub, float* so, float* wo,
+                            float* eo, int32_t E, int32_t Ww, int32_t We, int32_t B, int32_t ldb) {
+    for (int64_t b = 0; b < B; ++b) nic::head_serial_fwd_scenario(Z, wh_inv, ech_inv, ub, so, wo, eo, E, Ww, We, ldb, b);
+    return 0;
+}
+int hostsim_head_serial_bwd(const float* Z, const float* wh_inv, const float* ech_inv, float ub, const float* gso,
+                            const float* gwo, const float* geo, float* dZ, float* gwi, float* gei, int32_t E,
+                            int32_t Ww, int32_t We, int32_t B, int32_t ldb) {
+    for (int64_t b = 0; b < B; ++b)
+        nic::head_serial_bwd_scenario(Z, wh_inv, ech_inv, ub, gso, gwo, geo, dZ, gwi, gei, E, Ww, We, ldb, b);
+    return 0;
+}
+}

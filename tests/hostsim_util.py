@@ -1,0 +1,36 @@
+"""Builds/loads tests/hostsim (the NIC_HD kernel bodies compiled for the host with g++).  Test infrastructure."""
+import ctypes as C
+import os
+import subprocess
+
+from neural_inventory_control_amd import _lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostsim", "hostsim.cpp")
+OUT_DIR = os.path.join(HERE, "hostsim", "_build")
+OUT = os.path.join(OUT_DIR, "libhostsim.so")
+_h = None
+
+
+def load():
+    global _h
+    if _h is not None:
+        return _h
+    os.makedirs(OUT_DIR, exist_ok=True)
+    deps = [SRC] + [os.path.join(HERE, "..", "neural_inventory_control_amd", "csrc", f)
+                    for f in ("env_step_body.h", "policy_heads_body.h")] + [os.path.join(HERE, "..", "include", "nic_rollout.h")]
+    if not os.path.isfile(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", OUT])
+    h = C.CDLL(OUT)
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    IOP = C.POINTER(_lib.NicEnvStepIO)
+    h.hostsim_env_step_fwd.argtypes = [IOP, vp, vp, vp, vp]
+    h.hostsim_env_step_bwd.argtypes = [IOP, vp, vp, vp, _lib.NicTable2, vp, vp, vp, vp, vp, vp]
+    h.hostsim_head_warehouse_fwd.argtypes = [vp, vp, vp, f32, i32, vp, vp, i32, i32, i32, i32, i32]
+    h.hostsim_head_warehouse_bwd.argtypes = [vp, vp, vp, f32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32]
+    h.hostsim_head_softplus_fwd.argtypes = [vp, vp, i32, i32, i32]
+    h.hostsim_head_softplus_bwd.argtypes = [vp, vp, vp, i32, i32, i32]
+    h.hostsim_head_serial_fwd.argtypes = [vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32]
+    h.hostsim_head_serial_bwd.argtypes = [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32]
+    _h = h
+    return h
