@@ -13,7 +13,8 @@
 #include "../../include/nic_rollout.h"
 
 #if defined(__HIPCC__)
-#define NIC_HD __host__ __device__ __forceinline__
+#include <hip/hip_runtime.h>
+#define NIC_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define NIC_HD inline
 #endif

@@ -1,0 +1,34 @@
+// Library-level entry points of include/nic_rollout.h.
+#include "nic_common.h"
+
+namespace nic {
+char* last_error_buffer() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+}  // namespace nic
+
+extern "C" {
+
+int nic_abi_version(void) { return NIC_ABI_VERSION; }
+
+const char* nic_last_error(void) { return nic::last_error_buffer(); }
+
+int nic_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+__global__ void axpy_kernel(float* __restrict__ out, const float* __restrict__ in, float alpha, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += alpha * in[i];
+}
+
+int nic_axpy(float* out, const float* in, float alpha, int64_t n, void* stream) {
+    NIC_REQUIRE(out && in, "nic_axpy: null buffer");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3(nic::ceil_div(n, 256)), dim3(256), 0, nic::as_stream(stream), out, in, alpha, n);
+    return nic::check_launch("nic_axpy");
+}
+}

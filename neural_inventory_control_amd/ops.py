@@ -1,0 +1,155 @@
+"""Thin torch-facing wrappers over the C ABI (include/nic_rollout.h).
+
+Every function takes/returns CUDA tensors in the scenario-minor layout of `layout.py`, enqueues exactly one HIP
+kernel on torch's current stream and never synchronises.  There is no CPU path: CPU tensors raise.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, lib, ptr
+from .layout import EnvProblem, Table
+
+
+def _dev(t):
+    if t is not None and not t.is_cuda:
+        raise _lib.NicUnavailableError("nic ops need device tensors (no CPU fallback; see oracle/ for the CPU checker)")
+    return t
+
+
+class EnvState:
+    """The three pipelines of one period in SoA layout: store [S][Ws][ldb], wh [Wn][Ww][ldb], ech [E][We][ldb]."""
+    __slots__ = ("store", "wh", "ech")
+
+    def __init__(self, store, wh=None, ech=None):
+        self.store, self.wh, self.ech = store, wh, ech
+
+    @staticmethod
+    def zeros_like(prob: EnvProblem):
+        dev, ld = prob.device, prob.ldb
+        return EnvState(
+            torch.zeros(prob.S, prob.Ws, ld, device=dev),
+            torch.zeros(prob.Wn, prob.Ww, ld, device=dev) if prob.Wn else None,
+            torch.zeros(prob.E, prob.We, ld, device=dev) if prob.E else None)
+
+
+def env_step_fwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders: Table, wh_orders, ech_orders,
+                 out: EnvState = None, reward=None):
+    """nic_env_step_fwd.  Returns (next_state, reward[ldb])."""
+    _dev(state.store)
+    out = out or EnvState.zeros_like(prob)
+    if reward is None:
+        reward = torch.zeros(prob.ldb, device=prob.device)
+    io = prob.make_io(state.store, state.wh, state.ech, demand, store_orders, wh_orders, ech_orders)
+    check(lib().nic_env_step_fwd(io, ptr(out.store), ptr(out.wh), ptr(out.ech), ptr(reward), current_stream()))
+    return out, reward
+
+
+def env_step_bwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders: Table, wh_orders, ech_orders,
+                 g_out: EnvState, g_reward: Table, g_in: EnvState = None, g_orders=None):
+    """nic_env_step_bwd.  g_out members may be None (zeros).  Returns (g_state_in, (g_store_orders [S][nsup][ldb],
+    g_wh_orders [Wn][ldb] | None, g_ech_orders [E][ldb] | None))."""
+    _dev(state.store)
+    dev, ld = prob.device, prob.ldb
+    g_in = g_in or EnvState.zeros_like(prob)
+    if g_orders is None:
+        g_orders = (torch.zeros(prob.S, prob.nsup, ld, device=dev),
+                    torch.zeros(prob.Wn, ld, device=dev) if prob.Wn else None,
+                    torch.zeros(prob.E, ld, device=dev) if prob.E else None)
+    io = prob.make_io(state.store, state.wh, state.ech, demand, store_orders, wh_orders, ech_orders)
+    check(lib().nic_env_step_bwd(io, ptr(g_out.store), ptr(g_out.wh), ptr(g_out.ech), g_reward.t2(), ptr(g_in.store),
+                                 ptr(g_in.wh), ptr(g_in.ech), ptr(g_orders[0]), ptr(g_orders[1]), ptr(g_orders[2]),
+                                 current_stream()))
+    return g_in, g_orders
+
+
+# ---- policy MLP layers (feature-major: X is [K][ldb]) ----------------------------------------------------------
+
+def linear_fwd(W, bias, X, Y, n_scenarios, act):
+    """Y[N][ldb] = act(W[N][K(ldw)] @ X[K][ldb] + bias)."""
+    _dev(X)
+    N, K = W.shape[0], X.shape[0]
+    check(lib().nic_linear_fwd(ptr(W), W.stride(0), ptr(bias), ptr(X), ptr(Y), N, K, n_scenarios, X.stride(0), act,
+                               current_stream()))
+    return Y
+
+
+def linear_dgrad(Wt, dY, Hprev, dX, n_scenarios, act_prev, accumulate):
+    """dX[K][ldb] (+)= (Wt[K][N(ldwt)] @ dY[N][ldb]) * act'(Hprev)."""
+    _dev(dY)
+    K, N = dX.shape[0], dY.shape[0]
+    check(lib().nic_linear_dgrad(ptr(Wt), Wt.stride(0), ptr(dY), ptr(Hprev), ptr(dX), N, K, n_scenarios, dY.stride(0),
+                                 act_prev, int(accumulate), current_stream()))
+    return dX
+
+
+def wgrad_num_splits(N, K, n_scenarios):
+    return lib().nic_wgrad_num_splits(N, K, n_scenarios)
+
+
+def linear_wgrad(dY, X, slab, n_scenarios):
+    """slab[split][N][lds] += per-split sum_b dY[N][b] X[K][b] (column K = bias gradient)."""
+    _dev(dY)
+    N, K = dY.shape[0], X.shape[0]
+    check(lib().nic_linear_wgrad(ptr(dY), ptr(X), ptr(slab), slab.stride(1), N, K, n_scenarios, dY.stride(0),
+                                 slab.shape[0], current_stream()))
+    return slab
+
+
+def wgrad_reduce(slab, dW, db, K, scale=1.0):
+    N = dW.shape[0]
+    check(lib().nic_wgrad_reduce(ptr(slab), slab.stride(1), slab.shape[0], ptr(dW), dW.stride(0), ptr(db), N, K,
+                                 float(scale), current_stream()))
+
+
+# ---- policy heads ----------------------------------------------------------------------------------------------
+
+def head_warehouse_fwd(Z, wh_inv, adjacency, ub, transshipment, store_orders, wh_orders, S, Wn, Ww, B):
+    _dev(Z)
+    check(lib().nic_head_warehouse_fwd(ptr(Z), ptr(wh_inv), ptr(adjacency), float(ub), int(transshipment),
+                                       ptr(store_orders), ptr(wh_orders), S, Wn, Ww, B, Z.stride(0), current_stream()))
+
+
+def head_warehouse_bwd(Z, wh_inv, adjacency, ub, transshipment, g_store_orders, g_wh_orders, dZ, g_wh_inv, S, Wn, Ww, B):
+    _dev(Z)
+    check(lib().nic_head_warehouse_bwd(ptr(Z), ptr(wh_inv), ptr(adjacency), float(ub), int(transshipment),
+                                       ptr(g_store_orders), ptr(g_wh_orders), ptr(dZ), ptr(g_wh_inv), S, Wn, Ww, B,
+                                       Z.stride(0), current_stream()))
+
+
+def head_softplus_fwd(Z, orders, rows, B):
+    _dev(Z)
+    check(lib().nic_head_softplus_fwd(ptr(Z), ptr(orders), rows, B, Z.stride(0), current_stream()))
+
+
+def head_softplus_bwd(Z, g_orders, dZ, rows, B):
+    _dev(Z)
+    check(lib().nic_head_softplus_bwd(ptr(Z), ptr(g_orders), ptr(dZ), rows, B, Z.stride(0), current_stream()))
+
+
+def head_serial_fwd(Z, wh_inv, ech_inv, ub, store_orders, wh_orders, ech_orders, E, Ww, We, B):
+    _dev(Z)
+    check(lib().nic_head_serial_fwd(ptr(Z), ptr(wh_inv), ptr(ech_inv), float(ub), ptr(store_orders), ptr(wh_orders),
+                                    ptr(ech_orders), E, Ww, We, B, Z.stride(0), current_stream()))
+
+
+def head_serial_bwd(Z, wh_inv, ech_inv, ub, g_store_orders, g_wh_orders, g_ech_orders, dZ, g_wh_inv, g_ech_inv, E, Ww,
+                    We, B):
+    _dev(Z)
+    check(lib().nic_head_serial_bwd(ptr(Z), ptr(wh_inv), ptr(ech_inv), float(ub), ptr(g_store_orders), ptr(g_wh_orders),
+                                    ptr(g_ech_orders), ptr(dZ), ptr(g_wh_inv), ptr(g_ech_inv), E, Ww, We, B, Z.stride(0),
+                                    current_stream()))
+
+
+# ---- sampler / utilities ---------------------------------------------------------------------------------------
+
+def sample_demand(out, T, S, n_scenarios, scenario_offset, seed, kind, mean, chol, clip):
+    """out: [T][S][ldb] device tensor; kind 0 normal (chol: [S][S] lower factor), 1 poisson."""
+    _dev(out)
+    check(lib().nic_sample_demand(ptr(out), T, S, n_scenarios, out.stride(1), int(scenario_offset), int(seed), kind,
+                                  ptr(mean), ptr(chol), int(clip), current_stream()))
+    return out
+
+
+def axpy(out, x, alpha=1.0):
+    _dev(out)
+    check(lib().nic_axpy(ptr(out), ptr(x), float(alpha), out.numel(), current_stream()))

@@ -1,0 +1,316 @@
+"""Backend-agnostic parity checks of the kernel arithmetic.
+
+The same checks run against two builds of the same NIC_HD bodies:
+  * HostSimBackend — tests/hostsim (g++), CPU tensors, runs on the CPU container (`-m "not gpu"`);
+  * HipBackend     — the product library libnic_hip.so through the C ABI, device tensors (`-m gpu`).
+Expected values come from the golden fixtures (reference outputs) and the oracle's autograd.
+"""
+import torch
+import torch.nn.functional as F
+
+from golden_io import Golden
+from neural_inventory_control_amd import _lib, layout
+from neural_inventory_control_amd.layout import EnvProblem, Table, pad_ld, ref_view, to_soa
+from oracle import inventory_oracle as orc
+
+P = lambda x: x.data_ptr() if x is not None else None  # noqa: E731
+
+
+class HostSimBackend:
+    device = "cpu"
+
+    def __init__(self):
+        import hostsim_util
+        self.h = hostsim_util.load()
+
+    def sync(self):
+        pass
+
+    def env_fwd(self, io, so, wo, eo, r):
+        self.h.hostsim_env_step_fwd(io, P(so), P(wo), P(eo), P(r))
+
+    def env_bwd(self, io, gso, gwo, geo, gr, gsi, gwi, gei, gas, gaw, gae):
+        self.h.hostsim_env_step_bwd(io, P(gso), P(gwo), P(geo), gr, P(gsi), P(gwi), P(gei), P(gas), P(gaw), P(gae))
+
+    def head_warehouse_fwd(self, Z, wh, adj, ub, trans, so, wo, S, Wn, Ww, B, ldb):
+        self.h.hostsim_head_warehouse_fwd(P(Z), P(wh), P(adj), ub, trans, P(so), P(wo), S, Wn, Ww, B, ldb)
+
+    def head_warehouse_bwd(self, Z, wh, adj, ub, trans, gso, gwo, dZ, gwi, S, Wn, Ww, B, ldb):
+        self.h.hostsim_head_warehouse_bwd(P(Z), P(wh), P(adj), ub, trans, P(gso), P(gwo), P(dZ), P(gwi), S, Wn, Ww, B, ldb)
+
+    def head_softplus_fwd(self, Z, o, rows, B, ldb):
+        self.h.hostsim_head_softplus_fwd(P(Z), P(o), rows, B, ldb)
+
+    def head_softplus_bwd(self, Z, g, dZ, rows, B, ldb):
+        self.h.hostsim_head_softplus_bwd(P(Z), P(g), P(dZ), rows, B, ldb)
+
+    def head_serial_fwd(self, Z, wh, ech, ub, so, wo, eo, E, Ww, We, B, ldb):
+        self.h.hostsim_head_serial_fwd(P(Z), P(wh), P(ech), ub, P(so), P(wo), P(eo), E, Ww, We, B, ldb)
+
+    def head_serial_bwd(self, Z, wh, ech, ub, gso, gwo, geo, dZ, gwi, gei, E, Ww, We, B, ldb):
+        self.h.hostsim_head_serial_bwd(P(Z), P(wh), P(ech), ub, P(gso), P(gwo), P(geo), P(dZ), P(gwi), P(gei), E, Ww, We, B, ldb)
+
+
+class HipBackend:
+    device = "cuda"
+
+    def __init__(self):
+        _lib.require_device()
+        self.l = _lib.lib()
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def _s():
+        return _lib.current_stream()
+
+    def env_fwd(self, io, so, wo, eo, r):
+        _lib.check(self.l.nic_env_step_fwd(io, P(so), P(wo), P(eo), P(r), self._s()))
+
+    def env_bwd(self, io, gso, gwo, geo, gr, gsi, gwi, gei, gas, gaw, gae):
+        _lib.check(self.l.nic_env_step_bwd(io, P(gso), P(gwo), P(geo), gr, P(gsi), P(gwi), P(gei), P(gas), P(gaw), P(gae),
+                                           self._s()))
+
+    def head_warehouse_fwd(self, Z, wh, adj, ub, trans, so, wo, S, Wn, Ww, B, ldb):
+        _lib.check(self.l.nic_head_warehouse_fwd(P(Z), P(wh), P(adj), ub, trans, P(so), P(wo), S, Wn, Ww, B, ldb, self._s()))
+
+    def head_warehouse_bwd(self, Z, wh, adj, ub, trans, gso, gwo, dZ, gwi, S, Wn, Ww, B, ldb):
+        _lib.check(self.l.nic_head_warehouse_bwd(P(Z), P(wh), P(adj), ub, trans, P(gso), P(gwo), P(dZ), P(gwi), S, Wn, Ww,
+                                                 B, ldb, self._s()))
+
+    def head_softplus_fwd(self, Z, o, rows, B, ldb):
+        _lib.check(self.l.nic_head_softplus_fwd(P(Z), P(o), rows, B, ldb, self._s()))
+
+    def head_softplus_bwd(self, Z, g, dZ, rows, B, ldb):
+        _lib.check(self.l.nic_head_softplus_bwd(P(Z), P(g), P(dZ), rows, B, ldb, self._s()))
+
+    def head_serial_fwd(self, Z, wh, ech, ub, so, wo, eo, E, Ww, We, B, ldb):
+        _lib.check(self.l.nic_head_serial_fwd(P(Z), P(wh), P(ech), ub, P(so), P(wo), P(eo), E, Ww, We, B, ldb, self._s()))
+
+    def head_serial_bwd(self, Z, wh, ech, ub, gso, gwo, geo, dZ, gwi, gei, E, Ww, We, B, ldb):
+        _lib.check(self.l.nic_head_serial_bwd(P(Z), P(wh), P(ech), ub, P(gso), P(gwo), P(geo), P(dZ), P(gwi), P(gei), E, Ww,
+                                              We, B, ldb, self._s()))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+
+def _state_soa(st, prob, dev):
+    s = to_soa(st["store_inventories"].to(dev), prob.ldb)
+    w = to_soa(st["warehouse_inventories"].to(dev), prob.ldb) if prob.Wn else None
+    e = to_soa(st["echelon_inventories"].to(dev), prob.ldb) if prob.E else None
+    return s, w, e
+
+
+def _orders_tables(act, dev):
+    """Orders exactly as a reference-style policy hands them over: (B,S,Wn) scenario-major tensors."""
+    a = {k: v.to(dev) for k, v in act.items()}
+    keep = list(a.values())
+    return (Table.from_orders(a["stores"]),
+            Table.from_orders(a["warehouses"][:, :, 0]) if "warehouses" in a else None,
+            Table.from_orders(a["echelons"][:, :, 0]) if "echelons" in a else None, keep)
+
+
+def _demand_table(demands_dev, t):
+    d = demands_dev
+    return Table(d[:, :, t], d.stride(1), d.stride(0))
+
+
+def knife_edge_scenarios(st, act):
+    """Scenarios whose warehouse on-hand after shipping (environment.py:249) is within float noise of 0 WITHOUT being
+    structurally 0: the `>= 0` mask of clamp's backward then depends on the summation order of `sum(dim=1)`, which no
+    two implementations share (the reference's own CPU and GPU paths differ there too).  Excluded from gradient
+    comparisons; exact zeros (structural ties) stay in."""
+    B = st["store_inventories"].shape[0]
+    bad = torch.zeros(B, dtype=torch.bool)
+    if "warehouse_inventories" in st:
+        orders = act["stores"].detach().double()
+        after = st["warehouse_inventories"].detach()[:, :, 0].double() - orders.sum(dim=1)
+        scale = orders.abs().sum(dim=1) + 1e-30
+        bad |= ((after.abs() / scale < 1e-6) & ((orders != 0).sum(dim=1) >= 2)).any(dim=1)  # >= 2 addends: order matters
+    return bad
+
+
+def check_env_forward(be, name):
+    g = Golden(name)
+    c = g.fresh_config()
+    data = g.data
+    dev = be.device
+    prob = EnvProblem(c["problem_params"], data, dev)
+    B, T = c["n"], c["periods"]
+    rewards = g.tensor("rewards")
+    demands = data["demands"].to(dev)
+    for t in range(T):
+        s, w, e = _state_soa(g.states(t), prob, dev)
+        ts, tw, te, _keep = _orders_tables(g.actions(t), dev)
+        io = prob.make_io(s, w, e, _demand_table(demands, t), ts, tw, te)
+        so = torch.zeros_like(s)
+        wo = torch.zeros_like(w) if w is not None else None
+        eo = torch.zeros_like(e) if e is not None else None
+        r = torch.zeros(prob.ldb, device=dev)
+        be.env_fwd(io, so, wo, eo, r)
+        be.sync()
+        nxt = g.states(t + 1)
+        # integer slot placement and the store pipelines are exact; sums over stores may differ in the last bit
+        assert torch.equal(ref_view(so, B).cpu(), nxt["store_inventories"]), (t, "stores")
+        if prob.Wn:
+            torch.testing.assert_close(ref_view(wo, B).cpu(), nxt["warehouse_inventories"], rtol=2e-6, atol=1e-5)
+        if prob.E:
+            torch.testing.assert_close(ref_view(eo, B).cpu(), nxt["echelon_inventories"], rtol=2e-6, atol=1e-5)
+        torch.testing.assert_close(r[:B].cpu(), rewards[t], rtol=2e-6, atol=1e-5)
+        assert float(r[B:].abs().sum()) == 0.0
+
+
+def check_env_backward(be, name, profit):
+    g = Golden(name)
+    c = g.fresh_config()
+    c["problem_params"]["maximize_profit"] = profit
+    data = g.data
+    dev = be.device
+    prob = EnvProblem(c["problem_params"], data, dev)
+    B = c["n"]
+    demands = data["demands"].to(dev)
+    gen = torch.Generator().manual_seed(7)
+    compared = 0
+    for t in (0, 1, c["periods"] // 2, c["periods"] - 1):
+        st = {k: v.clone().requires_grad_(True) for k, v in g.states(t).items()}
+        act = {k: v.clone().requires_grad_(True) for k, v in g.actions(t).items()}
+        with torch.no_grad():  # force exact ties / zeros: on-hand == demand, zero orders
+            st["store_inventories"][0, :, 0] = data["demands"][0, :, t]
+            act["stores"][1 % B] = 0.0
+        env = orc.env_reset(c["periods"], c["problem_params"], data, c["observation_params"])
+        env.obs.update(st)
+        env.t = t
+        reward = orc.env_step(env, act)
+        keys = [k for k in ("store_inventories", "warehouse_inventories", "echelon_inventories") if k in st]
+        g_out = {k: torch.randn(env.obs[k].shape, generator=gen) for k in keys}
+        g_r = torch.randn(B, generator=gen)
+        ((reward * g_r).sum() + sum((env.obs[k] * g_out[k]).sum() for k in keys)).backward()
+        for leaf in list(st.values()) + list(act.values()):
+            if leaf.grad is None:  # e.g. every order is 0 -> the reference skips the put entirely (environment.py:427)
+                leaf.grad = torch.zeros_like(leaf)
+
+        s, w, e = _state_soa({k: v.detach() for k, v in st.items()}, prob, dev)
+        ts, tw, te, _keep = _orders_tables({k: v.detach() for k, v in act.items()}, dev)
+        io = prob.make_io(s, w, e, _demand_table(demands, t), ts, tw, te)
+        gso = to_soa(g_out["store_inventories"].to(dev), prob.ldb)
+        gwo = to_soa(g_out["warehouse_inventories"].to(dev), prob.ldb) if prob.Wn else None
+        geo = to_soa(g_out["echelon_inventories"].to(dev), prob.ldb) if prob.E else None
+        grs = torch.zeros(prob.ldb, device=dev)
+        grs[:B] = g_r.to(dev)
+        gsi = torch.zeros_like(s)
+        gwi = torch.zeros_like(w) if prob.Wn else None
+        gei = torch.zeros_like(e) if prob.E else None
+        gas = torch.zeros(prob.S, prob.nsup, prob.ldb, device=dev)
+        gaw = torch.zeros(prob.Wn, prob.ldb, device=dev) if prob.Wn else None
+        gae = torch.zeros(prob.E, prob.ldb, device=dev) if prob.E else None
+        be.env_bwd(io, gso, gwo, geo, layout.Table(grs, 0, 1).t2(), gsi, gwi, gei, gas, gaw, gae)
+        be.sync()
+        tol = dict(rtol=1e-5, atol=1e-5)
+        ok = ~knife_edge_scenarios(st, act)
+        compared += int(ok.sum())
+        torch.testing.assert_close(ref_view(gsi, B).cpu()[ok], st["store_inventories"].grad[ok], **tol)
+        torch.testing.assert_close(ref_view(gas, B).cpu()[ok], act["stores"].grad[ok], **tol)
+        if prob.Wn:
+            torch.testing.assert_close(ref_view(gwi, B).cpu()[ok], st["warehouse_inventories"].grad[ok], **tol)
+            torch.testing.assert_close(ref_view(gaw, B).cpu()[ok], act["warehouses"].grad[:, :, 0][ok], **tol)
+        if prob.E:
+            torch.testing.assert_close(ref_view(gei, B).cpu()[ok], st["echelon_inventories"].grad[ok], **tol)
+            torch.testing.assert_close(ref_view(gae, B).cpu()[ok], act["echelons"].grad[:, :, 0][ok], **tol)
+    assert compared >= 2 * B  # saturated softmax heads put many late-period scenarios on the knife edge
+
+
+def check_warehouse_head(be, S, Wn, adj, trans):
+    dev = be.device
+    B, Ww = 37, 3
+    ldb = pad_ld(B)
+    gen = torch.Generator().manual_seed(3)
+    Z = (torch.randn(B, S * Wn + Wn, generator=gen) * 3).requires_grad_(True)
+    wh = (torch.rand(B, Wn, Ww, generator=gen) * 20)
+    wh[0, :, 0] = 0.0  # empty warehouse
+    wh.requires_grad_(True)
+    ub = 123.5
+    adj_t = torch.ones(1, S) if Wn == 1 else torch.tensor(adj, dtype=torch.float32)
+    # oracle arithmetic of neural_networks.py:393-426 on given logits
+    store_logits = Z[:, :S * Wn].view(-1, S, Wn)
+    alloc = torch.zeros_like(store_logits)
+    for w in range(Wn):
+        conn = adj_t[w].nonzero(as_tuple=True)[0]
+        if len(conn) > 0:
+            alloc[:, conn, w] = orc._softmax_share_of_stock(store_logits[:, conn, w], wh[:, w:w + 1], trans)
+    wh_orders = torch.sigmoid(Z[:, S * Wn:]) * torch.tensor([ub])
+    g_so = torch.randn(B, S, Wn, generator=gen)
+    g_wo = torch.randn(B, Wn, generator=gen)
+    ((alloc * g_so).sum() + (wh_orders * g_wo).sum()).backward()
+
+    Zs, whs = to_soa(Z.detach().to(dev), ldb), to_soa(wh.detach().to(dev), ldb)
+    adj_i = adj_t.to(torch.int32).contiguous().to(dev)
+    so, wo = torch.zeros(S, Wn, ldb, device=dev), torch.zeros(Wn, ldb, device=dev)
+    be.head_warehouse_fwd(Zs, whs, adj_i, ub, int(trans), so, wo, S, Wn, Ww, B, ldb)
+    be.sync()
+    torch.testing.assert_close(ref_view(so, B).cpu(), alloc.detach(), rtol=3e-6, atol=1e-6)
+    torch.testing.assert_close(ref_view(wo, B).cpu(), wh_orders.detach(), rtol=3e-6, atol=1e-6)
+    # structurally-zero orders must be EXACT zeros (the env's `!= 0` filter depends on it)
+    assert torch.equal(ref_view(so, B).cpu() == 0, alloc.detach() == 0)
+    dZ = torch.zeros(S * Wn + Wn, ldb, device=dev)
+    gwi = torch.zeros(Wn, Ww, ldb, device=dev)
+    gso_s, gwo_s = to_soa(g_so.to(dev), ldb), to_soa(g_wo.to(dev), ldb)
+    be.head_warehouse_bwd(Zs, whs, adj_i, ub, int(trans), gso_s, gwo_s, dZ, gwi, S, Wn, Ww, B, ldb)
+    be.sync()
+    torch.testing.assert_close(ref_view(dZ, B).cpu(), Z.grad, rtol=3e-5, atol=3e-6)
+    torch.testing.assert_close(ref_view(gwi, B).cpu(), wh.grad, rtol=3e-5, atol=3e-6)
+
+
+def check_softplus_head(be):
+    dev = be.device
+    B, ldb = 50, 64
+    Z = torch.linspace(-30, 30, B).reshape(B, 1).clone().requires_grad_(True)
+    y = F.softplus(Z + 1)
+    g = torch.randn(B, 1)
+    (y * g).sum().backward()
+    out, dZ = torch.zeros(1, ldb, device=dev), torch.zeros(1, ldb, device=dev)
+    Zs, gs = to_soa(Z.detach().to(dev), ldb), to_soa(g.to(dev), ldb)
+    be.head_softplus_fwd(Zs, out, 1, B, ldb)
+    be.head_softplus_bwd(Zs, gs, dZ, 1, B, ldb)
+    be.sync()
+    torch.testing.assert_close(ref_view(out, B).cpu(), y.detach(), rtol=3e-6, atol=1e-7)
+    torch.testing.assert_close(ref_view(dZ, B).cpu(), Z.grad, rtol=3e-6, atol=1e-7)
+
+
+def check_serial_head(be, E):
+    dev = be.device
+    B, Ww, We = 41, 3, 4
+    ldb = pad_ld(B)
+    gen = torch.Generator().manual_seed(5)
+    Z = torch.randn(B, E + 2, generator=gen).requires_grad_(True)
+    wh = (torch.rand(B, 1, Ww, generator=gen) * 9).requires_grad_(True)
+    ech = (torch.rand(B, E, We, generator=gen) * 9).requires_grad_(True)
+    ub = 20.0
+    upstream = torch.concat((torch.tensor([ub]).unsqueeze(1).expand(B, -1), ech[:, :, 0], wh[:, :, 0]), dim=1)
+    alloc = torch.sigmoid(Z) * upstream  # neural_networks.py:335-344
+    g = torch.randn(B, E + 2, generator=gen)
+    (alloc * g).sum().backward()
+    Zs, whs, echs = (to_soa(x.detach().to(dev), ldb) for x in (Z, wh, ech))
+    so, wo, eo = torch.zeros(1, 1, ldb, device=dev), torch.zeros(1, ldb, device=dev), torch.zeros(E, ldb, device=dev)
+    be.head_serial_fwd(Zs, whs, echs, ub, so, wo, eo, E, Ww, We, B, ldb)
+    be.sync()
+    torch.testing.assert_close(ref_view(eo, B).cpu(), alloc.detach()[:, :E], rtol=3e-6, atol=1e-7)
+    torch.testing.assert_close(wo[0, :B].cpu(), alloc.detach()[:, E], rtol=3e-6, atol=1e-7)
+    torch.testing.assert_close(so[0, 0, :B].cpu(), alloc.detach()[:, E + 1], rtol=3e-6, atol=1e-7)
+    dZ, gwi, gei = (torch.zeros(E + 2, ldb, device=dev), torch.zeros(1, Ww, ldb, device=dev),
+                    torch.zeros(E, We, ldb, device=dev))
+    gs = to_soa(g.to(dev), ldb)
+    g_store, g_wh, g_ech = gs[E + 1:], gs[E:E + 1], gs[:E]
+    be.head_serial_bwd(Zs, whs, echs, ub, g_store, g_wh, g_ech, dZ, gwi, gei, E, Ww, We, B, ldb)
+    be.sync()
+    torch.testing.assert_close(ref_view(dZ, B).cpu(), Z.grad, rtol=3e-5, atol=1e-6)
+    torch.testing.assert_close(ref_view(gwi, B).cpu(), wh.grad, rtol=3e-5, atol=1e-6)
+    torch.testing.assert_close(ref_view(gei, B).cpu(), ech.grad, rtol=3e-5, atol=1e-6)
+
+
+WAREHOUSE_HEAD_CASES = [
+    (16, 1, None),
+    (10, 2, [[0, 0, 1, 1, 1, 0, 1, 1, 1, 0], [1, 1, 1, 1, 1, 1, 0, 1, 1, 1]]),
+    (8, 3, [[1, 1, 0, 0, 1, 0, 1, 0], [0, 1, 1, 1, 0, 0, 1, 1], [1, 0, 0, 1, 0, 1, 0, 1]]),
+    (4, 2, [[1, 1, 1, 1], [0, 0, 0, 0]]),  # a warehouse without any connected store
+]

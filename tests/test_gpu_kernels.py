@@ -1,0 +1,210 @@
+"""Parity of every HIP kernel, called through the C ABI (libnic_hip.so), on a real MI355X.
+
+env step / policy heads: the same checks as the host-sim build (golden vectors + oracle autograd);
+policy GEMMs: against float64 torch on the same inputs (FP32 MFMA = exact f32 products, f32 accumulation);
+sampler: moments + sharding invariance (statistical parity with numpy)."""
+import numpy as np
+import pytest
+import torch
+
+import kernel_checks as kc
+from golden_io import case_names
+from neural_inventory_control_amd import _lib, ops
+from neural_inventory_control_amd.layout import pad_ld
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    return kc.HipBackend()
+
+
+def test_library_loaded_and_device_visible():
+    assert _lib.library_built()
+    assert _lib.lib().nic_device_count() >= 1
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_env_forward_matches_golden(be, name):
+    kc.check_env_forward(be, name)
+
+
+@pytest.mark.parametrize("name", case_names())
+@pytest.mark.parametrize("profit", [False, True])
+def test_env_backward_matches_oracle_autograd(be, name, profit):
+    kc.check_env_backward(be, name, profit)
+
+
+@pytest.mark.parametrize("S,Wn,adj", kc.WAREHOUSE_HEAD_CASES)
+@pytest.mark.parametrize("trans", [False, True])
+def test_warehouse_head(be, S, Wn, adj, trans):
+    kc.check_warehouse_head(be, S, Wn, adj, trans)
+
+
+def test_softplus_head(be):
+    kc.check_softplus_head(be)
+
+
+@pytest.mark.parametrize("E", [2, 1, 3])
+def test_serial_head(be, E):
+    kc.check_serial_head(be, E)
+
+
+def test_env_rejects_bad_arguments(be):
+    io = _lib.NicEnvStepIO()
+    assert be.l.nic_env_step_fwd(io, None, None, None, None, None) != 0
+    assert b"n_scenarios" in be.l.nic_last_error() or b"null" in be.l.nic_last_error()
+
+
+# ---- policy GEMMs -------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(512, 51, 1000), (512, 512, 2048 + 37), (17, 512, 777), (32, 4, 100), (1, 32, 130), (64, 64, 64),
+               (200, 100, 300), (195, 393, 520), (4, 32, 4096)]
+
+
+def _rand(shape, gen, dev, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(dev)
+
+
+def _close(got, want64, scale64, what):
+    """|got - want| <= 4e-6 * sum|a||b| (f32 accumulation over K terms) elementwise."""
+    err = (got.double().cpu() - want64).abs()
+    bound = 4e-6 * scale64 + 1e-6
+    bad = err > bound
+    assert not bool(bad.any()), (what, float(err.max()), float(bound.min()), int(bad.sum()))
+
+
+@pytest.mark.parametrize("N,K,B", GEMM_SHAPES)
+@pytest.mark.parametrize("padded_w", [False, True])
+def test_linear_fwd(N, K, B, padded_w):
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(N * 1000 + K)
+    ldb = pad_ld(B)
+    X = _rand((K, ldb), gen, dev)
+    if padded_w:
+        Wfull = torch.zeros(N, (K + 31) // 32 * 32, device=dev)
+        Wfull[:, :K] = _rand((N, K), gen, dev, 0.3)
+        W = Wfull[:, :K]
+    else:
+        W = _rand((N, K), gen, dev, 0.3)
+    bias = _rand((N,), gen, dev)
+    for act in (_lib.NIC_ACT_ELU, _lib.NIC_ACT_NONE):
+        Y = torch.full((N, ldb), float("nan"), device=dev)
+        ops.linear_fwd(W, bias, X, Y, B, act)
+        torch.cuda.synchronize()
+        W64, X64 = W.double().cpu(), X.double().cpu()[:, :B]
+        pre = W64 @ X64 + bias.double().cpu()[:, None]
+        want = torch.where(pre > 0, pre, torch.expm1(pre)) if act == _lib.NIC_ACT_ELU else pre
+        scale = W64.abs() @ X64.abs() + bias.double().cpu().abs()[:, None]
+        _close(Y[:, :B], want, scale, ("fwd", act))
+    Y2 = torch.zeros(N, ldb, device=dev)
+    ops.linear_fwd(W, None, X, Y2, B, _lib.NIC_ACT_NONE)
+    torch.cuda.synchronize()
+    _close(Y2[:, :B], W.double().cpu() @ X.double().cpu()[:, :B], W.double().cpu().abs() @ X.double().cpu()[:, :B].abs(), "nobias")
+
+
+@pytest.mark.parametrize("N,K,B", GEMM_SHAPES)
+def test_linear_dgrad(N, K, B):
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(N * 1000 + K + 1)
+    ldb = pad_ld(B)
+    W = _rand((N, K), gen, dev, 0.3)
+    Wt = W.t().contiguous()
+    dY = _rand((N, ldb), gen, dev)
+    H = _rand((K, ldb), gen, dev)  # "post-activation" of the previous layer (values <= 0 have derivative H + 1)
+    H = torch.where(H > 0, H, torch.expm1(H))
+    base = _rand((K, ldb), gen, dev)
+    W64, dY64, H64 = W.double().cpu(), dY.double().cpu()[:, :B], H.double().cpu()[:, :B]
+    lin = W64.t() @ dY64
+    scale = W64.t().abs() @ dY64.abs()
+    # plain
+    dX = torch.full((K, ldb), float("nan"), device=dev)
+    ops.linear_dgrad(Wt, dY, None, dX, B, _lib.NIC_ACT_NONE, False)
+    torch.cuda.synchronize()
+    _close(dX[:, :B], lin, scale, "dgrad plain")
+    # ELU' from the stored output, accumulate into an existing gradient
+    dX = base.clone()
+    ops.linear_dgrad(Wt, dY, H, dX, B, _lib.NIC_ACT_ELU, True)
+    torch.cuda.synchronize()
+    want = lin * torch.where(H64 > 0, torch.ones_like(H64), H64 + 1) + base.double().cpu()[:, :B]
+    _close(dX[:, :B], want, scale + base.double().cpu()[:, :B].abs(), "dgrad elu acc")
+
+
+@pytest.mark.parametrize("N,K,B", GEMM_SHAPES)
+def test_linear_wgrad_accumulates_over_periods(N, K, B):
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(N * 1000 + K + 2)
+    ldb = pad_ld(B)
+    splits = ops.wgrad_num_splits(N, K, B)
+    assert splits >= 1
+    lds = (K + 1 + 3) // 4 * 4
+    slab = torch.zeros(splits, N, lds, device=dev)
+    want_w = torch.zeros(N, K, dtype=torch.float64)
+    want_b = torch.zeros(N, dtype=torch.float64)
+    scale_w = torch.zeros(N, K, dtype=torch.float64)
+    for period in range(3):
+        dY = _rand((N, ldb), gen, dev)  # padding columns are NOT zero: the kernel must ignore b >= n_scenarios
+        X = _rand((K, ldb), gen, dev)
+        ops.linear_wgrad(dY, X, slab, B)
+        dY64, X64 = dY.double().cpu()[:, :B], X.double().cpu()[:, :B]
+        want_w += dY64 @ X64.t()
+        want_b += dY64.sum(dim=1)
+        scale_w += dY64.abs() @ X64.abs().t()
+    dW = torch.full((N, K), float("nan"), device=dev)
+    db = torch.full((N,), float("nan"), device=dev)
+    ops.wgrad_reduce(slab, dW, db, K, 0.5)
+    torch.cuda.synchronize()
+    _close(dW, 0.5 * want_w, scale_w, "wgrad")
+    _close(db, 0.5 * want_b, torch.full((N,), 3.0 * B), "bgrad")
+    assert float(slab[:, :, K + 1:].abs().sum()) == 0.0
+
+
+# ---- sampler ------------------------------------------------------------------------------------------------------
+
+def test_sampler_normal_moments_and_sharding_invariance():
+    dev = "cuda"
+    S, T, B = 5, 40, 4096
+    mean = torch.tensor([5.0, 3.0, 7.0, 4.0, 6.0])
+    std = torch.tensor([1.5, 1.0, 2.0, 0.8, 1.2])
+    rho = 0.5
+    cov = rho * std[:, None] * std[None, :]
+    cov[range(S), range(S)] = std * std
+    chol = torch.linalg.cholesky(cov.double()).float()
+    ldb = pad_ld(B)
+    out = torch.zeros(T, S, ldb, device=dev)
+    ops.sample_demand(out, T, S, B, 0, 1234, 0, mean.to(dev), chol.to(dev).contiguous(), False)
+    torch.cuda.synchronize()
+    x = out[:, :, :B].permute(1, 0, 2).reshape(S, -1).double().cpu()  # S x (T*B)
+    np.testing.assert_allclose(x.mean(dim=1).numpy(), mean.numpy(), atol=0.02)
+    np.testing.assert_allclose(np.cov(x.numpy()), cov.numpy(), atol=0.05)
+    # independent across periods and scenarios
+    a, b = out[0, 0, :B].double().cpu(), out[1, 0, :B].double().cpu()
+    assert abs(np.corrcoef(a.numpy(), b.numpy())[0, 1]) < 0.06
+    # sharding invariance: two shards with global scenario offsets reproduce the single-GPU traces bit for bit
+    half = B // 2
+    o1 = torch.zeros(T, S, pad_ld(half), device=dev)
+    o2 = torch.zeros(T, S, pad_ld(half), device=dev)
+    ops.sample_demand(o1, T, S, half, 0, 1234, 0, mean.to(dev), chol.to(dev).contiguous(), False)
+    ops.sample_demand(o2, T, S, half, half, 1234, 0, mean.to(dev), chol.to(dev).contiguous(), False)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([o1[:, :, :half], o2[:, :, :half]], dim=2), out[:, :, :B])
+    # clip
+    oc = torch.zeros(T, S, ldb, device=dev)
+    ops.sample_demand(oc, T, S, B, 0, 1234, 0, (mean * 0).to(dev), chol.to(dev).contiguous(), True)
+    torch.cuda.synchronize()
+    assert float(oc.min()) == 0.0
+
+
+def test_sampler_poisson():
+    dev = "cuda"
+    S, T, B = 2, 50, 8192
+    lam = torch.tensor([5.0, 0.7])
+    out = torch.zeros(T, S, pad_ld(B), device=dev)
+    ops.sample_demand(out, T, S, B, 0, 99, 1, lam.to(dev), None, True)
+    torch.cuda.synchronize()
+    x = out[:, :, :B].permute(1, 0, 2).reshape(S, -1).double().cpu()
+    assert torch.equal(x, x.round()) and float(x.min()) >= 0
+    np.testing.assert_allclose(x.mean(dim=1).numpy(), lam.numpy(), rtol=0.01)
+    np.testing.assert_allclose(x.var(dim=1).numpy(), lam.numpy(), rtol=0.03)
+    # P(X = 0) = exp(-lambda)
+    np.testing.assert_allclose((x == 0).double().mean(dim=1).numpy(), np.exp(-lam.numpy()), atol=0.003)

@@ -1,136 +1,38 @@
-"""The per-scenario bodies of the HIP kernels (env_step_body.h, policy_heads_body.h), compiled for the host, against
-the golden vectors (forward) and the oracle's autograd (backward).  This checks the kernels' ARITHMETIC on the CPU
-container; the same checks run through the real HIP library in test_gpu_*.py on the GPU box."""
+"""The per-scenario bodies of the HIP kernels (env_step_body.h, policy_heads_body.h), compiled for the HOST, against
+the golden vectors (forward) and the oracle's autograd (backward).  Checks the kernels' arithmetic on the CPU
+container; the identical checks run through the real HIP library in test_gpu_kernels.py on the GPU box."""
 import pytest
-import torch
 
-import hostsim_util
-from golden_io import Golden, case_names
-from neural_inventory_control_amd import layout
-from neural_inventory_control_amd.layout import EnvProblem, Table, to_soa, ref_view
-from oracle import inventory_oracle as orc
+import kernel_checks as kc
+from golden_io import case_names
 
 
-def _state_soa(st, prob):
-    s = to_soa(st["store_inventories"], prob.ldb)
-    w = to_soa(st["warehouse_inventories"], prob.ldb) if prob.Wn else None
-    e = to_soa(st["echelon_inventories"], prob.ldb) if prob.E else None
-    return s, w, e
-
-
-def _orders_tables(act):
-    return (Table.from_orders(act["stores"]),
-            Table.from_orders(act["warehouses"][:, :, 0]) if "warehouses" in act else None,
-            Table.from_orders(act["echelons"][:, :, 0]) if "echelons" in act else None)
+@pytest.fixture(scope="module")
+def be():
+    return kc.HostSimBackend()
 
 
 @pytest.mark.parametrize("name", case_names())
-def test_env_forward_matches_golden(name):
-    h = hostsim_util.load()
-    g = Golden(name)
-    c = g.fresh_config()
-    data = g.data
-    prob = EnvProblem(c["problem_params"], data, "cpu")
-    B, T = c["n"], c["periods"]
-    rewards = g.tensor("rewards")
-    for t in range(T):
-        s, w, e = _state_soa(g.states(t), prob)
-        act = g.actions(t)
-        ts, tw, te = _orders_tables(act)
-        dem = Table(data["demands"], data["demands"].stride(1), data["demands"].stride(0))
-        dem_t = Table(data["demands"][:, :, t], dem.loc_stride, dem.scn_stride)
-        io = prob.make_io(s, w, e, dem_t, ts, tw, te)
-        so = torch.zeros_like(s)
-        wo = torch.zeros_like(w) if w is not None else None
-        eo = torch.zeros_like(e) if e is not None else None
-        r = torch.zeros(prob.ldb)
-        h.hostsim_env_step_fwd(io, so.data_ptr(), wo.data_ptr() if wo is not None else None,
-                               eo.data_ptr() if eo is not None else None, r.data_ptr())
-        nxt = g.states(t + 1)
-        # integer slot placement and the store pipelines are exact; sums over stores may differ in the last bit
-        assert torch.equal(ref_view(so, B), nxt["store_inventories"]), (t, "stores")
-        if prob.Wn:
-            torch.testing.assert_close(ref_view(wo, B), nxt["warehouse_inventories"], rtol=2e-6, atol=1e-5)
-        if prob.E:
-            torch.testing.assert_close(ref_view(eo, B), nxt["echelon_inventories"], rtol=2e-6, atol=1e-5)
-        torch.testing.assert_close(r[:B], rewards[t], rtol=2e-6, atol=1e-5)
-        assert float(r[B:].abs().sum()) == 0.0
-
-
-def knife_edge_scenarios(st, act):
-    """Scenarios whose warehouse on-hand after shipping (environment.py:249) is within float noise of 0 WITHOUT being
-    structurally 0: the `>= 0` mask of clamp's backward then depends on the summation order of `sum(dim=1)`, which no
-    two implementations share (the reference's own CPU and GPU paths differ there too).  Excluded from gradient
-    comparisons; exact zeros (structural ties) stay in."""
-    B = st["store_inventories"].shape[0]
-    bad = torch.zeros(B, dtype=torch.bool)
-    if "warehouse_inventories" in st:
-        orders = act["stores"].detach().double()
-        after = st["warehouse_inventories"].detach()[:, :, 0].double() - orders.sum(dim=1)
-        scale = orders.abs().sum(dim=1) + 1e-30
-        bad |= ((after.abs() / scale < 1e-6) & ((orders != 0).sum(dim=1) >= 2)).any(dim=1)  # >= 2 addends: order matters
-    return bad
+def test_env_forward_matches_golden(be, name):
+    kc.check_env_forward(be, name)
 
 
 @pytest.mark.parametrize("name", case_names())
 @pytest.mark.parametrize("profit", [False, True])
-def test_env_backward_matches_oracle_autograd(name, profit):
-    h = hostsim_util.load()
-    g = Golden(name)
-    c = g.fresh_config()
-    c["problem_params"]["maximize_profit"] = profit
-    data = g.data
-    prob = EnvProblem(c["problem_params"], data, "cpu")
-    B = c["n"]
-    gen = torch.Generator().manual_seed(7)
-    compared = 0
-    for t in (0, 1, c["periods"] // 2, c["periods"] - 1):
-        st = {k: v.clone().requires_grad_(True) for k, v in g.states(t).items()}
-        act = {k: v.clone().requires_grad_(True) for k, v in g.actions(t).items()}
-        # force a few exact ties / zeros: on-hand == demand, zero orders
-        with torch.no_grad():
-            st["store_inventories"][0, :, 0] = data["demands"][0, :, t]
-            act["stores"][1 % B] = 0.0
-        env = orc.env_reset(c["periods"], c["problem_params"], data, c["observation_params"])
-        env.obs.update(st)
-        env.t = t
-        reward = orc.env_step(env, act)
-        keys = [k for k in ("store_inventories", "warehouse_inventories", "echelon_inventories") if k in st]
-        g_out = {k: torch.randn(env.obs[k].shape, generator=gen) for k in keys}
-        g_r = torch.randn(B, generator=gen)
-        loss = (reward * g_r).sum() + sum((env.obs[k] * g_out[k]).sum() for k in keys)
-        loss.backward()
+def test_env_backward_matches_oracle_autograd(be, name, profit):
+    kc.check_env_backward(be, name, profit)
 
-        s, w, e = _state_soa({k: v.detach() for k, v in st.items()}, prob)
-        ts, tw, te = _orders_tables({k: v.detach() for k, v in act.items()})
-        dem_t = Table(data["demands"][:, :, t], data["demands"].stride(1), data["demands"].stride(0))
-        io = prob.make_io(s, w, e, dem_t, ts, tw, te)
-        gso = to_soa(g_out["store_inventories"], prob.ldb)
-        gwo = to_soa(g_out["warehouse_inventories"], prob.ldb) if prob.Wn else None
-        geo = to_soa(g_out["echelon_inventories"], prob.ldb) if prob.E else None
-        grs = torch.zeros(prob.ldb)
-        grs[:B] = g_r
-        gsi = torch.zeros_like(s)
-        gwi = torch.zeros_like(w) if prob.Wn else None
-        gei = torch.zeros_like(e) if prob.E else None
-        gas = torch.zeros(prob.S, prob.nsup, prob.ldb)
-        gaw = torch.zeros(prob.Wn, prob.ldb) if prob.Wn else None
-        gae = torch.zeros(prob.E, prob.ldb) if prob.E else None
-        p = lambda x: x.data_ptr() if x is not None else None  # noqa: E731
-        h.hostsim_env_step_bwd(io, p(gso), p(gwo), p(geo), layout.Table(grs, 0, 1).t2(), p(gsi), p(gwi), p(gei),
-                               p(gas), p(gaw), p(gae))
-        tol = dict(rtol=1e-5, atol=1e-5)
-        for leaf in list(st.values()) + list(act.values()):
-            if leaf.grad is None:  # e.g. every order is 0 -> the reference skips the put entirely (environment.py:427)
-                leaf.grad = torch.zeros_like(leaf)
-        ok = ~knife_edge_scenarios(st, act)
-        compared += int(ok.sum())
-        torch.testing.assert_close(ref_view(gsi, B)[ok], st["store_inventories"].grad[ok], **tol)
-        torch.testing.assert_close(ref_view(gas, B)[ok], act["stores"].grad[ok], **tol)
-        if prob.Wn:
-            torch.testing.assert_close(ref_view(gwi, B)[ok], st["warehouse_inventories"].grad[ok], **tol)
-            torch.testing.assert_close(ref_view(gaw, B)[ok], act["warehouses"].grad[:, :, 0][ok], **tol)
-        if prob.E:
-            torch.testing.assert_close(ref_view(gei, B)[ok], st["echelon_inventories"].grad[ok], **tol)
-            torch.testing.assert_close(ref_view(gae, B)[ok], act["echelons"].grad[:, :, 0][ok], **tol)
-    assert compared >= 2 * B  # saturated softmax heads put many late-period scenarios on the knife edge
+
+@pytest.mark.parametrize("S,Wn,adj", kc.WAREHOUSE_HEAD_CASES)
+@pytest.mark.parametrize("trans", [False, True])
+def test_warehouse_head(be, S, Wn, adj, trans):
+    kc.check_warehouse_head(be, S, Wn, adj, trans)
+
+
+def test_softplus_head(be):
+    kc.check_softplus_head(be)
+
+
+@pytest.mark.parametrize("E", [2, 1, 3])
+def test_serial_head(be, E):
+    kc.check_serial_head(be, E)

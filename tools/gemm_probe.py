@@ -1,0 +1,50 @@
+"""Micro-benchmark of the policy GEMM kernels + env step at BASELINE cfg3 shapes (HIP events on the current stream)."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from neural_inventory_control_amd import _lib, ops
+from neural_inventory_control_amd.layout import pad_ld
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    dev = "cuda"
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    ldb = pad_ld(B)
+    res = {}
+    for (N, K) in [(512, 512), (512, 51), (17, 512)]:
+        W = torch.randn(N, (K + 31) // 32 * 32, device=dev)[:, :K] * 0.05
+        Wt = torch.randn(K, (N + 31) // 32 * 32, device=dev)[:, :N] * 0.05
+        b = torch.randn(N, device=dev)
+        X = torch.randn(K, ldb, device=dev)
+        Y = torch.zeros(N, ldb, device=dev)
+        dX = torch.zeros(K, ldb, device=dev)
+        flops = 2.0 * N * K * B
+        ms = timeit(lambda: ops.linear_fwd(W, b, X, Y, B, 1))
+        res[f"fwd_{N}x{K}"] = dict(ms=ms, tflops=flops / ms / 1e9)
+        ms = timeit(lambda: ops.linear_dgrad(Wt, Y, X, dX, B, 1, False))
+        res[f"dgrad_{N}x{K}"] = dict(ms=ms, tflops=flops / ms / 1e9)
+        splits = ops.wgrad_num_splits(N, K, B)
+        slab = torch.zeros(splits, N, (K + 4) // 4 * 4, device=dev)
+        ms = timeit(lambda: ops.linear_wgrad(Y, X, slab, B))
+        res[f"wgrad_{N}x{K}"] = dict(ms=ms, tflops=flops / ms / 1e9, splits=splits)
+        # rocBLAS (torch) for orientation only
+        Xr, Wr = torch.randn(B, K, device=dev), torch.randn(N, K, device=dev)
+        ms = timeit(lambda: torch.nn.functional.linear(Xr, Wr))
+        res[f"torch_linear_{N}x{K}"] = dict(ms=ms, tflops=flops / ms / 1e9)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
