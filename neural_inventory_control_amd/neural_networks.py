@@ -1,0 +1,391 @@
+"""Policies of the hot path behind the reference's plugin contract (neural_networks.py:6-427, 1495-1574):
+subclass `MyNeuralNetwork`, implement `forward(observation: dict) -> dict` of 3-D action tensors.
+
+Same constructor arguments, same `state_dict` keys (`net.master.<i>.weight/bias`, so the reference's shipped
+checkpoint loads), same attributes the trainer reads (`trainable`, `gradient_clipping_norm_value`,
+`warehouse_upper_bound`).  What differs is what runs underneath: every Linear(+ELU) is `HipLinear`, an autograd
+function over the FP32-MFMA kernels of csrc/linear_mfma.hip with feature-major activations, and the feasibility
+heads (softmax share of warehouse stock, sigmoid x upstream on-hand, softplus) are the kernels of
+csrc/policy_heads.hip.  `trainer.Trainer` additionally recognises these architectures and runs the whole horizon
+through `rollout.FusedRollout` (no autograd graph at all); the modules below are the general path and the plugin base.
+
+Out of scope this round: GNN, data-driven / quantile / just-in-time policies.
+"""
+import copy
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .layout import pad_ld, ref_view, to_soa
+
+
+def _as_feature_major(x):
+    """logical (B, K) -> 2-D [K][ld] tensor the kernels can read (no copy if `x` already is a feature-major view)."""
+    xt = x.t()
+    if x.is_cuda and xt.stride(1) == 1 and xt.stride(0) % 4 == 0 and xt.stride(0) >= x.shape[0] \
+            and xt.data_ptr() % 16 == 0 and x.dtype == torch.float32:
+        return xt
+    return to_soa(x.float())
+
+
+class _LinearFunction(torch.autograd.Function):
+    """y = act(x @ W^T + b) on the matrix cores; activations stay feature-major between layers."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        if not x.is_cuda:
+            raise _lib.NicUnavailableError("HipLinear needs device tensors (no CPU fallback)")
+        B = x.shape[0]
+        X = _as_feature_major(x)
+        N = weight.shape[0]
+        Y = torch.empty(N, X.stride(0), device=x.device, dtype=torch.float32)
+        if X.stride(0) > B:
+            Y[:, B:].zero_()
+        ops.linear_fwd(weight.detach().contiguous(), None if bias is None else bias.detach(), X, Y, B, act)
+        ctx.act, ctx.B = act, B
+        ctx.save_for_backward(X, Y, weight)
+        ctx.has_bias = bias is not None
+        return ref_view(Y, B)
+
+    @staticmethod
+    def backward(ctx, gy):
+        X, Y, weight = ctx.saved_tensors
+        B, act = ctx.B, ctx.act
+        N, K = weight.shape
+        ld = X.stride(0)
+        if act == _lib.NIC_ACT_ELU:  # dZ = gY * elu'(z), recovered from the output (y > 0 ? 1 : y + 1)
+            yv = ref_view(Y, B)
+            gy = torch.where(yv > 0, gy, gy * (yv + 1))
+        dZ = torch.zeros(N, ld, device=gy.device, dtype=torch.float32)
+        dZ[:, :B] = gy.t()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            splits = max(1, min(ops.wgrad_num_splits(N, K, B), 16))
+            slab = torch.zeros(splits, N, (K + 4) // 4 * 4, device=gy.device)
+            ops.linear_wgrad(dZ, X, slab, B)
+            gw = torch.empty(N, K, device=gy.device)
+            gb = torch.empty(N, device=gy.device)
+            ops.wgrad_reduce(slab, gw, gb, K, 1.0)
+            if not ctx.has_bias:
+                gb = None
+        if ctx.needs_input_grad[0]:
+            dX = torch.zeros(K, ld, device=gy.device)
+            ops.linear_dgrad(weight.detach().t().contiguous(), dZ, None, dX, B, _lib.NIC_ACT_NONE, False)
+            gx = ref_view(dX, B)
+        return gx, gw, gb, None
+
+
+class _HipLinearForward:
+    fused_act = _lib.NIC_ACT_NONE
+
+    def forward(self, x):
+        if x.dim() == 1:  # closed-form policies feed a constant scalar input (neural_networks.py:228 in the reference)
+            return _LinearFunction.apply(x.unsqueeze(0), self.weight, self.bias, self.fused_act).squeeze(0)
+        return _LinearFunction.apply(x, self.weight, self.bias, self.fused_act)
+
+
+class HipLinear(_HipLinearForward, nn.Linear):
+    """nn.Linear whose forward/backward run on csrc/linear_mfma.hip; optionally fuses the following ELU."""
+
+
+class HipLazyLinear(_HipLinearForward, nn.LazyLinear):
+    """LazyLinear (in_features inferred at the first forward, neural_networks.py:88) that becomes a HipLinear.
+    torch binds `forward` before the materialising pre-hook swaps the class, so both classes share one forward."""
+    cls_to_become = HipLinear
+
+
+class _FusedELU(nn.ELU):
+    """Keeps the reference's Sequential indices (activation modules sit at odd positions); the ELU itself was already
+    applied in the epilogue of the preceding HipLinear."""
+
+    def forward(self, x):
+        return x
+
+
+class MyNeuralNetwork(nn.Module):
+    """Plugin base class.  Constructor contract: neural_networks.py:8-58 of the reference."""
+
+    def __init__(self, args, device="cpu"):
+        super().__init__()
+        self.device = device
+        self.trainable = True
+        self.gradient_clipping_norm_value = args.get("gradient_clipping_norm_value", None)
+        self.activation_functions = {
+            "relu": nn.ReLU(), "elu": nn.ELU(), "tanh": nn.Tanh(), "softmax": nn.Softmax(dim=1),
+            "softplus": nn.Softplus(), "sigmoid": nn.Sigmoid(),
+        }
+        self.warehouse_upper_bound = 0
+        self.layers = {}
+        self.nn_args = copy.deepcopy(args)
+        self.net = self.create_module_dict(args)
+        if args["initial_bias"] is not None:
+            for key, val in args["initial_bias"].items():
+                if val is not None:
+                    pos = -2 if args["output_layer_activation"][key] else -1
+                    self.initialize_bias(key, pos, val)
+
+    def forward(self, observation):
+        raise NotImplementedError
+
+    def create_module_dict(self, args):
+        return nn.ModuleDict({
+            key: self.create_sequential_net(key, args["inner_layer_activations"][key], args["output_layer_activation"][key],
+                                            args["neurons_per_hidden_layer"][key], args["output_sizes"][key])
+            for key in args["output_sizes"]})
+
+    def create_sequential_net(self, name, inner_layer_activations, output_layer_activation, neurons_per_hidden_layer,
+                              output_size):
+        """Sequential(LazyLinear, act, ..., Linear[, out_act]) exactly as neural_networks.py:80-106 lays it out."""
+        layers = []
+        fuse = inner_layer_activations == "elu"
+        for width in neurons_per_hidden_layer:
+            lin = HipLazyLinear(width)
+            if fuse:
+                lin.fused_act = _lib.NIC_ACT_ELU
+                layers += [lin, _FusedELU()]
+            else:
+                layers += [lin, self.activation_functions[inner_layer_activations]]
+        if len(neurons_per_hidden_layer) == 0:
+            layers.append(HipLazyLinear(output_size))
+        else:
+            layers.append(HipLinear(neurons_per_hidden_layer[-1], output_size))
+        if output_layer_activation is not None:
+            layers.append(self.activation_functions[output_layer_activation])
+        self.layers[name] = layers
+        return nn.Sequential(*layers)
+
+    def initialize_bias(self, key, pos, value):
+        self.layers[key][pos].bias.data.fill_(value)
+
+    # helpers kept for plugin authors (neural_networks.py:111-193)
+    def apply_proportional_allocation(self, desired_allocations, available_inventory, transshipment=False):
+        if available_inventory.dim() > 1:
+            available_inventory = available_inventory.sum(dim=1)
+        scaling = available_inventory / (desired_allocations.sum(dim=1) + 1e-10)
+        if not transshipment:
+            scaling = torch.clip(scaling, max=1.0)
+        return desired_allocations * scaling[:, None]
+
+    def flatten_then_concatenate_tensors(self, tensor_list, dim=1):
+        return torch.cat([t.flatten(start_dim=dim) for t in tensor_list], dim=dim)
+
+    def concatenate_signal_to_object_state_tensor(self, object_state, signal):
+        return torch.cat((object_state, signal.unsqueeze(1).expand(-1, object_state.size(1), -1)), dim=2)
+
+    def unpack_args(self, args, keys):
+        return [args[k] for k in keys] if len(keys) > 1 else args[keys[0]]
+
+    # ---- description consumed by rollout.FusedRollout -----------------------------------------------------------
+    def master_linears(self):
+        return [m for m in self.net["master"] if isinstance(m, nn.Linear)]
+
+
+# ---- heads as autograd functions over csrc/policy_heads.hip --------------------------------------------------------
+
+class _SoftplusHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        B, rows = z.shape
+        Z = _as_feature_major(z)
+        out = torch.zeros(rows, Z.stride(0), device=z.device)
+        ops.head_softplus_fwd(Z, out, rows, B)
+        ctx.save_for_backward(Z)
+        ctx.B = B
+        return ref_view(out, B)
+
+    @staticmethod
+    def backward(ctx, g):
+        (Z,) = ctx.saved_tensors
+        G = to_soa(g, Z.stride(0))
+        dZ = torch.zeros_like(G)
+        ops.head_softplus_bwd(Z, G, dZ, Z.shape[0], ctx.B)
+        return ref_view(dZ, ctx.B)
+
+
+class _WarehouseHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, wh_inv, adjacency, ub, transshipment, S, Wn):
+        B = z.shape[0]
+        Z = _as_feature_major(z)
+        ld = Z.stride(0)
+        Wh = to_soa(wh_inv, ld)
+        Ww = wh_inv.shape[2]
+        so = torch.zeros(S, Wn, ld, device=z.device)
+        wo = torch.zeros(Wn, ld, device=z.device)
+        ops.head_warehouse_fwd(Z, Wh, adjacency, ub, transshipment, so, wo, S, Wn, Ww, B)
+        ctx.save_for_backward(Z, Wh, adjacency)
+        ctx.meta = (B, ub, transshipment, S, Wn, Ww)
+        return ref_view(so, B), ref_view(wo, B).unsqueeze(2)
+
+    @staticmethod
+    def backward(ctx, g_so, g_wo):
+        Z, Wh, adjacency = ctx.saved_tensors
+        B, ub, trans, S, Wn, Ww = ctx.meta
+        ld = Z.stride(0)
+        Gs, Gw = to_soa(g_so, ld), to_soa(g_wo[:, :, 0], ld)
+        dZ = torch.zeros(S * Wn + Wn, ld, device=Z.device)
+        g_wh = torch.zeros(Wn, Ww, ld, device=Z.device)
+        ops.head_warehouse_bwd(Z, Wh, adjacency, ub, trans, Gs, Gw, dZ, g_wh, S, Wn, Ww, B)
+        return ref_view(dZ, B), ref_view(g_wh, B), None, None, None, None, None
+
+
+class _SerialHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, wh_inv, ech_inv, ub):
+        B = z.shape[0]
+        Z = _as_feature_major(z)
+        ld = Z.stride(0)
+        Wh, Ech = to_soa(wh_inv, ld), to_soa(ech_inv, ld)
+        E, Ww, We = ech_inv.shape[1], wh_inv.shape[2], ech_inv.shape[2]
+        so, wo, eo = (torch.zeros(1, 1, ld, device=z.device), torch.zeros(1, ld, device=z.device),
+                      torch.zeros(E, ld, device=z.device))
+        ops.head_serial_fwd(Z, Wh, Ech, ub, so, wo, eo, E, Ww, We, B)
+        ctx.save_for_backward(Z, Wh, Ech)
+        ctx.meta = (B, ub, E, Ww, We)
+        return ref_view(so, B), ref_view(wo, B).unsqueeze(2), ref_view(eo, B).unsqueeze(2)
+
+    @staticmethod
+    def backward(ctx, g_so, g_wo, g_eo):
+        Z, Wh, Ech = ctx.saved_tensors
+        B, ub, E, Ww, We = ctx.meta
+        ld = Z.stride(0)
+        Gs, Gw, Ge = to_soa(g_so, ld), to_soa(g_wo[:, :, 0], ld), to_soa(g_eo[:, :, 0], ld)
+        dZ = torch.zeros(E + 2, ld, device=Z.device)
+        g_wh, g_ech = torch.zeros(1, Ww, ld, device=Z.device), torch.zeros(E, We, ld, device=Z.device)
+        ops.head_serial_bwd(Z, Wh, Ech, ub, Gs, Gw, Ge, dZ, g_wh, g_ech, E, Ww, We, B)
+        return ref_view(dZ, B), ref_view(g_wh, B), ref_view(g_ech, B), None
+
+
+def _scalar(x):
+    return float(x.reshape(-1)[0]) if torch.is_tensor(x) else float(x)
+
+
+# ---- architectures of the hot path ----------------------------------------------------------------------------------
+
+class VanillaOneStore(MyNeuralNetwork):
+    """neural_networks.py:195-214: MLP over the store pipeline, softplus(x + 1)."""
+
+    def forward(self, observation):
+        x = observation["store_inventories"].flatten(start_dim=1)
+        return {"stores": _SoftplusHead.apply(self.net["master"](x)).unsqueeze(2)}
+
+
+class BaseStock(MyNeuralNetwork):
+    """neural_networks.py:216-229."""
+
+    def forward(self, observation):
+        x = observation["store_inventories"]
+        inv_pos = x.sum(dim=2)
+        level = self.net["master"](torch.tensor([0.0], device=x.device))
+        return {"stores": torch.clip(level - inv_pos, min=0).unsqueeze(2)}
+
+
+class CappedBaseStock(MyNeuralNetwork):
+    """neural_networks.py:296-311."""
+
+    def forward(self, observation):
+        x = observation["store_inventories"]
+        inv_pos = x.sum(dim=2)
+        out = self.net["master"](torch.tensor([0.0], device=x.device))
+        return {"stores": torch.clip(out[0] - inv_pos, min=torch.tensor([0.0], device=x.device), max=out[1]).unsqueeze(2)}
+
+
+class EchelonStock(MyNeuralNetwork):
+    """neural_networks.py:231-294 (locations ordered upstream -> downstream; cumulative softplus base levels)."""
+
+    def forward(self, observation):
+        s_inv, w_inv, e_inv = (observation[k] for k in ("store_inventories", "warehouse_inventories",
+                                                        "echelon_inventories"))
+        E = e_inv.size(1)
+        x = self.activation_functions["softplus"](self.net["master"](torch.tensor([0.0], device=s_inv.device)) + 10.0)
+        levels = torch.cumsum(x, dim=0).flip(dims=[0])
+        pos = torch.concat((e_inv.sum(dim=2), w_inv.sum(dim=2), s_inv.sum(dim=2)), dim=1)
+        upstream = torch.concat((1000000 * torch.ones_like(w_inv[:, :, 0]), e_inv[:, :, 0], w_inv[:, :, 0]), dim=1)
+        want = torch.clip(torch.stack([levels[k] - pos[:, k:].sum(dim=1) for k in range(2 + E)], dim=1), min=0)
+        alloc = torch.minimum(want, upstream)
+        return {"stores": alloc[:, -1:].unsqueeze(2), "warehouses": alloc[:, -2:-1].unsqueeze(2),
+                "echelons": alloc[:, :E].unsqueeze(2)}
+
+
+class VanillaSerial(MyNeuralNetwork):
+    """neural_networks.py:314-355.  The reference wraps the MLP input in torch.tensor(...) (:329), i.e. DETACHES it;
+    replicated so that gradients match."""
+
+    def forward(self, observation):
+        s_inv, w_inv, e_inv = (observation[k] for k in ("store_inventories", "warehouse_inventories",
+                                                        "echelon_inventories"))
+        x = self.flatten_then_concatenate_tensors([s_inv, w_inv, e_inv]).detach()
+        z = self.net["master"](x)
+        so, wo, eo = _SerialHead.apply(z, w_inv, e_inv, _scalar(self.warehouse_upper_bound))
+        return {"stores": so, "warehouses": wo, "echelons": eo}
+
+
+class VanillaWarehouse(MyNeuralNetwork):
+    """neural_networks.py:358-427: one MLP over all pipelines; per warehouse a softmax over its connected stores (+ a
+    constant-1 'keep' logit) times its on-hand stock; sigmoid x upper bound for the warehouses' own orders."""
+
+    def __init__(self, args, scenario=None, device="cpu"):
+        super().__init__(args, device)
+        self.scenario = scenario
+        self.transshipment = args.get("transshipment", False)
+        self._adj_cache = {}
+
+    def adjacency(self, n_stores, n_warehouses, device):
+        key = (n_stores, n_warehouses, str(device))
+        if key not in self._adj_cache:
+            if n_warehouses == 1:
+                adj = torch.ones(1, n_stores, dtype=torch.int32)
+            else:
+                raw = self.scenario.problem_params.get("warehouse_store_adjacency", None) if self.scenario else None
+                if raw is None:
+                    raise ValueError(f"warehouse_store_adjacency matrix required for n_warehouses={n_warehouses}")
+                adj = (torch.tensor(raw, dtype=torch.float32) != 0).to(torch.int32)
+            self._adj_cache[key] = adj.contiguous().to(device)
+        return self._adj_cache[key]
+
+    def forward(self, observation):
+        s_inv, w_inv = observation["store_inventories"], observation["warehouse_inventories"]
+        S, Wn = s_inv.size(1), w_inv.size(1)
+        x = torch.cat((s_inv.flatten(start_dim=1), w_inv.flatten(start_dim=1)), dim=1)
+        z = self.net["master"](x)
+        so, wo = _WarehouseHead.apply(z, w_inv, self.adjacency(S, Wn, z.device), _scalar(self.warehouse_upper_bound),
+                                      bool(self.transshipment), S, Wn)
+        return {"stores": so, "warehouses": wo}
+
+
+class NeuralNetworkCreator:
+    """neural_networks.py:1495-1574."""
+
+    def set_default_output_size(self, module_name, problem_params):
+        S, Wn = problem_params["n_stores"], problem_params["n_warehouses"]
+        master = S * Wn + Wn if Wn > 1 else S + Wn
+        return {"master": master, "store": 1, "warehouse": 1, "context": None}[module_name]
+
+    def get_architecture(self, name):
+        architectures = {
+            "vanilla_one_store": VanillaOneStore, "base_stock": BaseStock, "capped_base_stock": CappedBaseStock,
+            "echelon_stock": EchelonStock, "vanilla_serial": VanillaSerial, "vanilla_warehouse": VanillaWarehouse,
+        }
+        return architectures[name]  # KeyError for unknown names, like the reference (:1536)
+
+    def get_warehouse_upper_bound(self, warehouse_upper_bound_mult, scenario, device="cpu"):
+        mean = scenario.store_params["demand"]["mean"]
+        if type(mean) == float:
+            mean = [mean]
+        return torch.tensor([warehouse_upper_bound_mult * sum(mean)]).float().to(device)
+
+    def create_neural_network(self, scenario, nn_params, device="cpu"):
+        p = copy.deepcopy(nn_params)
+        for key, val in p["output_sizes"].items():
+            if val is None:
+                p["output_sizes"][key] = self.set_default_output_size(key, scenario.problem_params)
+        cls = self.get_architecture(p["name"])
+        if p["name"] in ("vanilla_warehouse",):
+            model = cls(p, scenario, device=device)
+        else:
+            model = cls(p, device=device)
+        if "warehouse_upper_bound_mult" in nn_params.keys():
+            model.warehouse_upper_bound = self.get_warehouse_upper_bound(nn_params["warehouse_upper_bound_mult"], scenario,
+                                                                         device)
+        return model.to(device)

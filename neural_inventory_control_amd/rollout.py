@@ -1,0 +1,269 @@
+"""`FusedRollout`: the unrolled T-period rollout + backward of `Trainer.simulate_batch` / `do_one_epoch`
+(trainer.py:160-216) for the MLP policies, without an autograd graph and without host round-trips.
+
+Per period the engine enqueues, on one HIP stream, the policy GEMMs (csrc/linear_mfma.hip), the feasibility head
+(csrc/policy_heads.hip) and the env step (csrc/env_step.hip); the backward sweep walks the periods in reverse with the
+analytic kernels (env bwd -> head bwd -> wgrad / dgrad per layer), accumulating weight gradients in per-split slabs that
+are reduced once at the end.  Everything a period needs later is kept RESIDENT in HBM in scenario-minor layout:
+
+    states   [T+1][F][ldb]   F = S*Ws + Wn*Ww + E*We   — state_t IS the MLP input X_t (feature order = the reference's
+                                                        cat(flatten(...)) order, neural_networks.py:207,328,380)
+    hidden_l [T][N_l][ldb]   post-ELU activations (only when training; ELU' is recovered from them)
+    logits   [T][N_out][ldb] ; orders [T][S*nsup+Wn+E][ldb] ; rewards [T][ldb] ; demand [T][S][ldb]
+
+(BASELINE cfg3: 65,536 scenarios x T=100 x 3x512 hidden = 40 GB of activations — sized for 288 GB of HBM3E.)
+The host loop issues ~6 launches per period forward and ~11 backward and never synchronises; the only device->host
+transfers are the two scalars the trainer reports.
+"""
+import torch
+
+from . import _lib, ops
+from .layout import EnvProblem, Table, pad_ld
+from .ops import EnvState
+
+_HEADS = {"vanilla_one_store": "softplus", "vanilla_warehouse": "warehouse", "vanilla_serial": "serial"}
+
+
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+class FusedRollout:
+    @staticmethod
+    def supports(model):
+        name = getattr(model, "nn_args", {}).get("name") if hasattr(model, "nn_args") else None
+        if name not in _HEADS or type(model).__name__ not in ("VanillaOneStore", "VanillaWarehouse", "VanillaSerial"):
+            return False
+        a = model.nn_args
+        return (a["inner_layer_activations"]["master"] == "elu" and a["output_layer_activation"]["master"] is None
+                and len(a["neurons_per_hidden_layer"]["master"]) >= 1)
+
+    def __init__(self, model, problem_params, device):
+        _lib.require_device()
+        if not self.supports(model):
+            raise ValueError("FusedRollout handles vanilla_one_store / vanilla_warehouse / vanilla_serial MLP policies")
+        self.model = model
+        self.problem_params = problem_params
+        self.device = torch.device(device)
+        self.head = _HEADS[model.nn_args["name"]]
+        self._key = None
+
+    # ---- buffers ------------------------------------------------------------------------------------------------
+    def _linears(self):
+        lins = self.model.master_linears()
+        if any(isinstance(m.weight, torch.nn.parameter.UninitializedParameter) for m in lins):
+            raise RuntimeError("policy has un-materialised LazyLinear layers; call materialize() or run one forward")
+        return lins
+
+    def materialize(self, in_features):
+        """Materialises LazyLinear layers without a forward pass (same default init as the reference's first call)."""
+        k = in_features
+        for m in self.model.master_linears():
+            if isinstance(m.weight, torch.nn.parameter.UninitializedParameter):
+                m.in_features = k
+                m.weight.materialize((m.out_features, k))
+                if m.bias is not None:
+                    m.bias.materialize((m.out_features,))
+                m.reset_parameters()
+                for hook in ("_initialize_hook", "_load_hook"):  # what LazyModuleMixin._infer_parameters does
+                    if hasattr(m, hook):
+                        getattr(m, hook).remove()
+                        delattr(m, hook)
+                m.__class__ = m.cls_to_become
+            k = m.out_features
+
+    def _setup(self, prob, T, train):
+        key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We)
+        if self._key == key:
+            return
+        dev, ld = self.device, prob.ldb
+        self.F_store, self.F_wh, self.F_ech = prob.S * prob.Ws, prob.Wn * prob.Ww, prob.E * prob.We
+        F = self.F_store + self.F_wh + self.F_ech
+        if self.head == "softplus":
+            F = self.F_store
+        self.F = F
+        self.materialize(F)
+        lins = self._linears()
+        dims = [F] + [m.out_features for m in lins]
+        assert lins[0].in_features == F, (lins[0].in_features, F)
+        self.dims = dims
+        L = len(lins)
+        z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+        self.states = z(T + 1, self.F_store + self.F_wh + self.F_ech, ld)
+        n_ord = prob.S * prob.nsup + prob.Wn + prob.E
+        self.orders = z(T, n_ord, ld)
+        self.rewards = z(T, ld)
+        self.logits = z(T, dims[-1], ld)
+        keep = T if train else 1
+        self.hidden = [z(keep, dims[i + 1], ld) for i in range(L - 1)]
+        # engine copies of the weights: rows padded to a multiple of 32 floats so every A-tile load is a float4
+        self.Wp = [z(dims[i + 1], _pad32(dims[i])) for i in range(L)]
+        self.Wt = [z(dims[i], _pad32(dims[i + 1])) for i in range(L)]
+        if train:
+            self.g_state = [z(self.states.shape[1], ld), z(self.states.shape[1], ld)]
+            self.g_orders = z(n_ord, ld)
+            self.dZ = z(dims[-1], ld)
+            wmax = max(dims[1:-1]) if L > 1 else 1
+            self.dH = [z(wmax, ld), z(wmax, ld)]
+            self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], prob.B) for i in range(L)]
+            self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
+            self.g_reward = z(ld)
+        if self.head == "warehouse":
+            self.adj = self.model.adjacency(prob.S, prob.Wn, dev)
+        self._key = key
+
+    def _views(self, block, prob):
+        """(store, wh, ech) SoA views of one [F][ldb] state block."""
+        a, b = self.F_store, self.F_store + self.F_wh
+        store = block[:a].view(prob.S, prob.Ws, -1)
+        wh = block[a:b].view(prob.Wn, prob.Ww, -1) if prob.Wn else None
+        ech = block[b:].view(prob.E, prob.We, -1) if prob.E else None
+        return EnvState(store, wh, ech)
+
+    def _order_views(self, block, prob):
+        a, b = prob.S * prob.nsup, prob.S * prob.nsup + prob.Wn
+        return (block[:a].view(prob.S, prob.nsup, -1), block[a:b] if prob.Wn else None, block[b:] if prob.E else None)
+
+    def _order_tables(self, block, prob):
+        so, wo, eo = self._order_views(block, prob)
+        ld = prob.ldb
+        return (Table(so, prob.nsup * ld, 1, ld), Table(wo, ld, 1) if wo is not None else None,
+                Table(eo, ld, 1) if eo is not None else None)
+
+    def _ub(self):
+        ub = self.model.warehouse_upper_bound
+        return float(ub.reshape(-1)[0]) if torch.is_tensor(ub) else float(ub)
+
+    # ---- one batch ----------------------------------------------------------------------------------------------
+    def run(self, data, periods, ignore_periods=0, train=True, observation_params=None, demand_soa=None,
+            grad_scale=None, accumulate_grads=False):
+        """Rollout of one batch (and, if `train`, d(mean_loss)/d(theta) into `param.grad`).
+
+        data: the batch dict `Simulator.reset` takes (device tensors).  demand_soa: optional [T][S][ldb] trace already
+        in kernel layout (e.g. from Scenario(sampler='hip')) — skips the transpose of data['demands'].
+        grad_scale: d(loss)/d(reward[b,t]); default 1/(B*T*S) = trainer.py:169.  Multi-GPU callers pass the GLOBAL B.
+        Returns (total, reported) as 0-d device tensors = simulate_batch's return values (trainer.py:216).
+        """
+        dev = self.device
+        prob = EnvProblem(self.problem_params, data, dev)
+        T, B, ld = periods, prob.B, prob.ldb
+        self._setup(prob, T, train)
+        self.prob = prob
+        shift = observation_params["demand"]["period_shift"] if observation_params else 0
+        if demand_soa is None:
+            d = data["demands"]
+            demand_soa = torch.zeros(d.shape[2], d.shape[1], ld, device=dev)
+            demand_soa[:, :, :B] = d.permute(2, 1, 0)
+        self.demand = demand_soa
+        if demand_soa.shape[0] < T + shift:
+            raise ValueError("Current period is greater than the number of periods in the data")
+
+        # engine copies of the weights (tiny) — refreshed every call because the optimizer moves them
+        lins = self._linears()
+        L = len(lins)
+        for i, m in enumerate(lins):
+            self.Wp[i][:, :self.dims[i]].copy_(m.weight.detach())
+            self.Wt[i][:, :self.dims[i + 1]].copy_(m.weight.detach().t())
+        biases = [m.bias.detach() if m.bias is not None else None for m in lins]
+        Wv = [self.Wp[i][:, :self.dims[i]] for i in range(L)]
+        Wtv = [self.Wt[i][:, :self.dims[i + 1]] for i in range(L)]
+
+        # initial state
+        s0 = self._views(self.states[0], prob)
+        s0.store[:, :, :B].copy_(data["initial_inventories"].permute(1, 2, 0))
+        if prob.Wn:
+            s0.wh[:, :, :B].copy_(data["initial_warehouse_inventories"].permute(1, 2, 0))
+        if prob.E:
+            s0.ech[:, :, :B].copy_(data["initial_echelon_inventories"].permute(1, 2, 0))
+
+        ub = self._ub() if self.head != "softplus" else 0.0
+        for t in range(T):
+            st = self._views(self.states[t], prob)
+            x = self.states[t][:self.F]
+            hs = t if train else 0
+            for i in range(L - 1):
+                y = self.hidden[i][hs]
+                ops.linear_fwd(Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)
+                x = y
+            Z = self.logits[t]
+            ops.linear_fwd(Wv[L - 1], biases[L - 1], x, Z, B, _lib.NIC_ACT_NONE)
+            so, wo, eo = self._order_views(self.orders[t], prob)
+            if self.head == "warehouse":
+                ops.head_warehouse_fwd(Z, st.wh, self.adj, ub, bool(self.model.transshipment), so, wo, prob.S, prob.Wn,
+                                       prob.Ww, B)
+            elif self.head == "serial":
+                ops.head_serial_fwd(Z, st.wh, st.ech, ub, so, wo, eo, prob.E, prob.Ww, prob.We, B)
+            else:
+                ops.head_softplus_fwd(Z, so.view(-1, ld), prob.S * prob.nsup, B)
+            ts, tw, te = self._order_tables(self.orders[t], prob)
+            ops.env_step_fwd(prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te,
+                             out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
+
+        total = self.rewards.sum()
+        reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
+        if not train:
+            return total, reported
+
+        # ---- backward sweep -------------------------------------------------------------------------------------
+        if grad_scale is None:
+            grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
+        self.g_reward.zero_()
+        self.g_reward[:B] = grad_scale
+        for s in self.slabs:
+            s.zero_()
+        g_next, g_cur = self.g_state
+        g_next.zero_()
+        detached_input = self.head == "serial"  # the reference detaches VanillaSerial's MLP input (:329)
+        for t in range(T - 1, -1, -1):
+            st = self._views(self.states[t], prob)
+            ts, tw, te = self._order_tables(self.orders[t], prob)
+            gso, gwo, geo = self._order_views(self.g_orders, prob)
+            ops.env_step_bwd(prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te, self._views(g_next, prob),
+                             Table(self.g_reward, 0, 1), g_in=self._views(g_cur, prob), g_orders=(gso, gwo, geo))
+            Z = self.logits[t]
+            gc = self._views(g_cur, prob)
+            if self.head == "warehouse":
+                ops.head_warehouse_bwd(Z, st.wh, self.adj, ub, bool(self.model.transshipment), gso, gwo, self.dZ, gc.wh,
+                                       prob.S, prob.Wn, prob.Ww, B)
+            elif self.head == "serial":
+                ops.head_serial_bwd(Z, st.wh, st.ech, ub, gso, gwo, geo, self.dZ, gc.wh, gc.ech, prob.E, prob.Ww, prob.We, B)
+            else:
+                ops.head_softplus_bwd(Z, gso.view(-1, ld), self.dZ, prob.S * prob.nsup, B)
+            d = self.dZ
+            for i in range(L - 1, -1, -1):
+                x_in = self.hidden[i - 1][t] if i > 0 else self.states[t][:self.F]
+                ops.linear_wgrad(d, x_in, self.slabs[i], B)
+                if i > 0:
+                    dx = self.dH[i & 1][:self.dims[i]]
+                    ops.linear_dgrad(Wtv[i], d, x_in, dx, B, _lib.NIC_ACT_ELU, False)
+                    d = dx
+                elif not detached_input:
+                    ops.linear_dgrad(Wtv[0], d, None, g_cur[:self.F], B, _lib.NIC_ACT_NONE, True)
+            g_next, g_cur = g_cur, g_next
+
+        for i, m in enumerate(lins):
+            gw = torch.empty_like(m.weight)
+            gb = torch.empty_like(m.bias) if m.bias is not None else None
+            ops.wgrad_reduce(self.slabs[i], gw, gb, self.dims[i], 1.0)
+            for p, g in ((m.weight, gw), (m.bias, gb)):
+                if p is None:
+                    continue
+                if accumulate_grads and p.grad is not None:
+                    p.grad.add_(g)
+                else:
+                    p.grad = g
+        return total, reported
+
+    # ---- inspection helpers used by the parity tests --------------------------------------------------------------
+    def per_period_rewards(self):
+        return self.rewards[:, :self.prob.B]
+
+    def final_state(self):
+        from .layout import ref_view
+        st = self._views(self.states[-1], self.prob)
+        out = {"store_inventories": ref_view(st.store, self.prob.B)}
+        if st.wh is not None:
+            out["warehouse_inventories"] = ref_view(st.wh, self.prob.B)
+        if st.ech is not None:
+            out["echelon_inventories"] = ref_view(st.ech, self.prob.B)
+        return out

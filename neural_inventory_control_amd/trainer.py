@@ -1,0 +1,231 @@
+"""`Trainer`: epoch loop, rollout, backward, optimizer step, dev evaluation, best-model tracking, early stopping and
+checkpoints with the reference's signatures and file format (trainer.py:5-324).
+
+`simulate_batch` has two routes with identical return values:
+  * MLP policies the engine knows (`FusedRollout.supports`): the whole horizon forward AND backward runs in HIP kernels
+    with no autograd graph; gradients land in `param.grad` and `do_one_epoch` skips `mean_loss.backward()`.
+  * anything else (closed-form policies, user plugins): the reference's unrolled loop, with `Simulator.step` as one
+    autograd-aware HIP kernel per period.
+Multi-GPU (one process per GPU, scenarios sharded): `do_one_epoch` all-reduces [grads..., total, reported] once per
+optimizer step through `parallel.GradientAllReducer` when torch.distributed is initialised.
+"""
+import copy
+import datetime
+import os
+
+import numpy as np
+import torch
+
+from . import parallel
+from .rollout import FusedRollout
+
+
+class Trainer:
+    def __init__(self, device="cpu"):
+        self.all_train_losses = []
+        self.all_dev_losses = []
+        self.all_test_losses = []
+        self.device = device
+        self.time_stamp = self.get_time_stamp()
+        self.best_performance_data = {"train_loss": np.inf, "dev_loss": np.inf, "last_epoch_saved": -1000,
+                                      "model_params_to_save": None}
+        self.best_epoch = 0
+        self.use_fused_rollout = True
+        self._engines = {}
+        self._fused_grads_ready = False
+
+    def reset(self):
+        self.all_train_losses, self.all_dev_losses, self.all_test_losses = [], [], []
+
+    # ---- training / evaluation loops (trainer.py:29-141) ---------------------------------------------------------
+    def train(self, epochs, loss_function, simulator, model, data_loaders, optimizer, problem_params, observation_params,
+              params_by_dataset, trainer_params):
+        for epoch in range(epochs):
+            _, train_report = self.do_one_epoch(
+                optimizer, data_loaders["train"], loss_function, simulator, model, params_by_dataset["train"]["periods"],
+                problem_params, observation_params, train=True, ignore_periods=params_by_dataset["train"]["ignore_periods"])
+            self.all_train_losses.append(train_report)
+            if epoch % trainer_params["do_dev_every_n_epochs"] == 0:
+                _, dev_report = self.do_one_epoch(
+                    optimizer, data_loaders["dev"], loss_function, simulator, model, params_by_dataset["dev"]["periods"],
+                    problem_params, observation_params, train=False, ignore_periods=params_by_dataset["dev"]["ignore_periods"])
+                self.all_dev_losses.append(dev_report)
+                self.update_best_params_and_save(epoch, train_report, dev_report, trainer_params, model, optimizer)
+                patience = trainer_params.get("early_stopping_patience_epochs", None)
+                if patience is not None and (epoch - self.best_epoch) >= patience:
+                    print(f"\nEarly stopping triggered at epoch {epoch + 1}")
+                    print(f"No improvement for {epoch - self.best_epoch} epochs")
+                    print(f"Best model was at epoch {self.best_epoch + 1} with dev loss: "
+                          f"{self.best_performance_data['dev_loss']}")
+                    break
+            else:
+                dev_report = 0
+                self.all_dev_losses.append(self.all_dev_losses[-1])
+            if epoch % trainer_params["print_results_every_n_epochs"] == 0 and parallel.rank() == 0:
+                print(f"epoch: {epoch + 1}")
+                print(f"Average per-period train loss: {train_report}")
+                print(f"Average per-period dev loss: {dev_report}")
+                print(f"Best per-period dev loss: {self.best_performance_data['dev_loss']}")
+
+    def test(self, loss_function, simulator, model, data_loaders, optimizer, problem_params, observation_params,
+             params_by_dataset, discrete_allocation=False):
+        if model.trainable and self.best_performance_data["model_params_to_save"] is not None:
+            model.load_state_dict(self.best_performance_data["model_params_to_save"])
+        return self.do_one_epoch(
+            optimizer, data_loaders["test"], loss_function, simulator, model, params_by_dataset["test"]["periods"],
+            problem_params, observation_params, train=False, ignore_periods=params_by_dataset["test"]["ignore_periods"],
+            discrete_allocation=discrete_allocation)
+
+    def do_one_epoch(self, optimizer, data_loader, loss_function, simulator, model, periods, problem_params,
+                     observation_params, train=True, ignore_periods=0, discrete_allocation=False):
+        """trainer.py:143-179.  Loss scalars are accumulated on the device and read back ONCE per epoch (the reference
+        calls .item() twice per batch, :166-167)."""
+        epoch_loss = torch.zeros((), device=self.device, dtype=torch.float64)
+        epoch_report = torch.zeros((), device=self.device, dtype=torch.float64)
+        total_samples = len(data_loader.dataset)
+        tracked = periods - ignore_periods
+        world = parallel.world_size()
+        with torch.no_grad() if not train else torch.enable_grad():
+            for data_batch in data_loader:
+                data_batch = self.move_batch_to_device(data_batch)
+                if train:
+                    optimizer.zero_grad()
+                self._fused_grads_ready = False
+                self._train_mode = train and model.trainable
+                # every rank normalises by the GLOBAL batch (trainer.py:169 with B summed over ranks)
+                self._global_batch = getattr(data_loader, "last_global_batch", None) or len(data_batch["demands"]) * world
+                total_reward, reward_to_report = self.simulate_batch(
+                    loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
+                    ignore_periods, discrete_allocation)
+                if train and model.trainable:
+                    if not self._fused_grads_ready:
+                        mean_loss = total_reward / (self._global_batch * periods * problem_params["n_stores"])
+                        mean_loss.backward()
+                    if world > 1:
+                        total_reward, reward_to_report = parallel.GradientAllReducer.get(model).all_reduce(
+                            total_reward.detach(), reward_to_report.detach())
+                    if getattr(model, "gradient_clipping_norm_value", None) is not None:
+                        torch.nn.utils.clip_grad_norm_(model.parameters(), model.gradient_clipping_norm_value)
+                    optimizer.step()
+                elif world > 1:
+                    total_reward, reward_to_report = parallel.all_reduce_scalars(total_reward.detach(),
+                                                                                 reward_to_report.detach())
+                epoch_loss += total_reward.detach()
+                epoch_report += reward_to_report.detach()
+        # in a sharded job `data_loader.dataset` is the GLOBAL dataset (each rank iterates its slice of every batch)
+        n_stores = problem_params["n_stores"]
+        return (epoch_loss.item() / (total_samples * periods * n_stores),
+                epoch_report.item() / (total_samples * tracked * n_stores))
+
+    def simulate_batch(self, loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
+                       ignore_periods=0, discrete_allocation=False):
+        """trainer.py:181-216."""
+        if self.use_fused_rollout and not discrete_allocation and FusedRollout.supports(model) \
+                and self._plain_observation(observation_params):
+            eng = self._engines.get(id(model))
+            if eng is None:
+                eng = self._engines[id(model)] = FusedRollout(model, problem_params, self.device)
+            train = bool(getattr(self, "_train_mode", torch.is_grad_enabled() and model.trainable)) and torch.is_grad_enabled()
+            gb = getattr(self, "_global_batch", len(data_batch["demands"]))
+            total, reported = eng.run(data_batch, periods, ignore_periods, train=train,
+                                      observation_params=observation_params,
+                                      grad_scale=1.0 / (gb * periods * problem_params["n_stores"]))
+            self._fused_grads_ready = train
+            return total, reported
+
+        batch_reward, reward_to_report = 0, 0
+        observation, _ = simulator.reset(periods, problem_params, data_batch, observation_params)
+        for t in range(periods):
+            obs_and_internal = {k: v for k, v in observation.items()}
+            obs_and_internal["internal_data"] = simulator._internal_data
+            action = model(obs_and_internal)
+            if discrete_allocation:
+                action = {k: v.round() for k, v in action.items()}
+            observation, reward, terminated, _, _ = simulator.step(action)
+            total_reward = loss_function(None, action, reward)
+            batch_reward += total_reward
+            if t >= ignore_periods:
+                reward_to_report += total_reward
+            if terminated:
+                break
+        return batch_reward, reward_to_report
+
+    @staticmethod
+    def _plain_observation(observation_params):
+        return (observation_params["demand"]["past_periods"] == 0 and not observation_params["time_features"]
+                and not observation_params["sample_features"])
+
+    # ---- checkpoints (trainer.py:218-276, 300-312): same dict keys, including the reference's mislabeled ones -----
+    def save_model(self, epoch, model, optimizer, trainer_params):
+        path = self.create_many_folders_if_not_exist_and_return_path(trainer_params["base_dir"],
+                                                                     trainer_params["save_model_folders"])
+        torch.save({
+            "epoch": epoch,
+            "model_state_dict": self.best_performance_data["model_params_to_save"],
+            "optimizer_state_dict": optimizer.state_dict(),
+            "best_train_loss": self.best_performance_data["dev_loss"],
+            "best_dev_loss": self.all_train_losses,
+            "all_train_losses": self.all_train_losses,
+            "all_dev_losses": self.all_dev_losses,
+            "all_test_losses": self.all_test_losses,
+            "warehouse_upper_bound": model.warehouse_upper_bound,
+        }, f"{path}/{trainer_params['save_model_filename']}.pt")
+
+    def create_folder_if_not_exists(self, folder):
+        if not os.path.isdir(folder):
+            os.mkdir(folder)
+
+    def create_many_folders_if_not_exist_and_return_path(self, base_dir, intermediate_folder_strings):
+        path = base_dir
+        for s in intermediate_folder_strings:
+            path += f"/{s}"
+            self.create_folder_if_not_exists(path)
+        return path
+
+    def update_best_params_and_save(self, epoch, train_loss, dev_loss, trainer_params, model, optimizer):
+        current = {"train_loss": train_loss, "dev_loss": dev_loss}
+        key = trainer_params["choose_best_model_on"]
+        if current[key] < self.best_performance_data[key]:
+            self.best_performance_data["train_loss"] = train_loss
+            self.best_performance_data["dev_loss"] = dev_loss
+            if model.trainable:
+                self.best_performance_data["model_params_to_save"] = copy.deepcopy(model.state_dict())
+            self.best_performance_data["update"] = True
+            self.best_epoch = epoch
+        if trainer_params["save_model"] and model.trainable and parallel.rank() == 0:
+            if self.best_performance_data["last_epoch_saved"] + trainer_params["epochs_between_save"] <= epoch \
+                    and self.best_performance_data.get("update"):
+                self.best_performance_data["last_epoch_saved"] = epoch
+                self.best_performance_data["update"] = False
+                self.save_model(epoch, model, optimizer, trainer_params)
+
+    def plot_losses(self, ymin=None, ymax=None):
+        import matplotlib.pyplot as plt
+        plt.plot(self.all_train_losses, label="Train loss")
+        plt.plot(self.all_dev_losses, label="Dev loss")
+        plt.legend()
+        if ymin is not None and ymax is not None:
+            plt.ylim(ymin, ymax)
+        plt.xlabel("Epoch")
+        plt.ylabel("Loss")
+        plt.show()
+
+    def move_batch_to_device(self, data_batch):
+        return {k: v.to(self.device) for k, v in data_batch.items()}
+
+    def load_model(self, model, optimizer, model_path):
+        checkpoint = torch.load(model_path, map_location=self.device, weights_only=False)
+        model.load_state_dict(checkpoint["model_state_dict"])
+        optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+        self.all_train_losses = checkpoint["all_train_losses"]
+        self.all_dev_losses = checkpoint["all_dev_losses"]
+        self.all_test_losses = checkpoint["all_test_losses"]
+        model.warehouse_upper_bound = checkpoint["warehouse_upper_bound"]
+        return model, optimizer
+
+    def get_time_stamp(self):
+        return int(datetime.datetime.now().timestamp())
+
+    def get_year_month_day(self):
+        ct = datetime.datetime.now()
+        return f"{ct.year}_{ct.month:02d}_{ct.day:02d}"
