@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: one TRAINING STEP of the differentiable inventory rollout
+(reset + T x (policy forward + env step) + cost reduction + backward through the horizon [+ gradient all-reduce] + Adam)
+on synthetic demand, BASELINE.json's metric: scenario-steps/s = scenarios x n_stores x T / wall-time.
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3]
+
+N = 1: plain process.  N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, one
+rank per GPU; scenarios are sharded (weak scaling: 65,536 scenarios PER GPU for cfg3), one RCCL all-reduce of the flat
+gradient per step.  Rank 0 prints ONE JSON line.  Inputs (demand traces from the HIP Philox sampler, initial state,
+weights) are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X dense FP32 matrix peak (MI355X_MICROARCH.md)
+
+
+def build_case(workload, device, rank, scenarios=None, periods=None):
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from neural_inventory_control_amd.data_handling import Scenario
+    from neural_inventory_control_amd.neural_networks import NeuralNetworkCreator
+    from neural_inventory_control_amd.rollout import FusedRollout
+    setting, policy, n, T, desc = workloads.get(workload)
+    n, T = scenarios or n, periods or T
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"],
+                  setting["echelon_params"], n, obs, setting["seeds"], sampler="hip", device=device,
+                  scenario_offset=rank * n)
+    data = {k: v.to(device) for k, v in sc.get_data().items()}
+    torch.manual_seed(1234)  # identical initial weights on every rank
+    model = NeuralNetworkCreator().create_neural_network(sc, policy, device=device)
+    eng = FusedRollout(model, setting["problem_params"], device)
+    return setting, policy, sc, data, model, eng, n, T, desc
+
+
+def cpu_baseline(workload, sample_scenarios, periods):
+    """The oracle (CPU restatement of the reference path, PyTorch eager) timed on this host's cores: one training step
+    (rollout + backward) of the same workload on a bounded sample of scenarios."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from oracle import inventory_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    setting, policy, _, _, _ = workloads.get(workload)
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    data = orc.generate_scenario_data(periods, setting["problem_params"], setting["store_params"],
+                                      setting["warehouse_params"], setting["echelon_params"], sample_scenarios, obs,
+                                      setting["seeds"])
+    S, Wn, E = (setting["problem_params"][k] for k in ("n_stores", "n_warehouses", "n_extra_echelons"))
+    F = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
+    if policy["name"] != "vanilla_one_store":
+        F += sum(data[k].shape[1] * data[k].shape[2] for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
+                 if k in data)
+    pol = orc.init_policy(policy, setting["problem_params"], F, 1234, setting["store_params"])
+    warm = {k: v[:max(8, sample_scenarios // 16)] for k, v in data.items()}
+    orc.train_step_gradients(pol, min(periods, 10), setting["problem_params"], warm, obs)
+    t0 = time.perf_counter()
+    orc.train_step_gradients(pol, periods, setting["problem_params"], data, obs)
+    dt = time.perf_counter() - t0
+    return {"value": sample_scenarios * S * periods / dt, "unit": "scenario-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU eager restatement of the reference path), 1 training step fwd+bwd, "
+                      f"{sample_scenarios} scenarios x {S} stores x T={periods}, {cores} threads, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--scenarios", type=int, default=None, help="scenarios per GPU (default: the workload's)")
+    ap.add_argument("--periods", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=None)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from neural_inventory_control_amd import _lib, parallel
+    from neural_inventory_control_amd.rollout import KernelTimer
+    rank, world, device = parallel.init_from_env()
+    _lib.require_device()
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, device, rank, args.scenarios, args.periods)
+    S = setting["problem_params"]["n_stores"]
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+    reducer = parallel.GradientAllReducer.get(model) if world > 1 else None
+    global_b = n * world
+    grad_scale = 1.0 / (global_b * T * S)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        total, reported = eng.run(data, T, 0, train=True, observation_params=setting["observation_params"],
+                                  demand_soa=sc.demands_soa, grad_scale=grad_scale)
+        if reducer is not None:
+            total, reported = reducer.all_reduce(total, reported)
+        opt.step()
+        return total
+
+    for _ in range(max(args.warmup, 0)):
+        step()
+    timer = None
+    if not args.no_kernel_timing:
+        timer = eng.timer = KernelTimer()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax)
+    loss = float(last) / (global_b * T * S)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "scenario-steps/sec (scenarios x stores x T) per training step",
+            "value": global_b * S * T * args.steps / dt, "unit": "scenario-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc + "; training step = rollout fwd + bwd + Adam" + (" + RCCL grad all-reduce" if world > 1 else ""),
+                       "name": args.workload, "scenarios_per_gpu": n, "global_scenarios": global_b, "stores": S,
+                       "periods": T, "parallelism": f"scenario-sharded dp{world}",
+                       "mean_cost_per_store_period": loss},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            dims = eng.dims
+            gemm = {}
+            for tag, (cnt, mean_ms) in summ.items():
+                kind, _, shape = tag.partition("_")
+                if kind in ("fwd", "dgrad", "wgrad") and "x" in shape:
+                    N_, K_ = (int(v) for v in shape.split("x"))
+                    flops = 2.0 * N_ * K_ * n
+                    gemm[tag] = {"launches": cnt, "mean_ms": mean_ms, "total_ms_per_step": cnt * mean_ms / args.steps,
+                                 "tflops": flops / mean_ms / 1e9}
+            if gemm:
+                dom = max(gemm, key=lambda k: gemm[k]["total_ms_per_step"])
+                kind, _, shape = dom.partition("_")
+                N_, K_ = (int(v) for v in shape.split("x"))
+                out["roofline"] = {
+                    "bound": "mfma", "achieved": gemm[dom]["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": gemm[dom]["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "kernel": {"fwd": "gemm_wx_kernel<2,2,2,2,EPI_BIAS_ACT>", "dgrad": "gemm_wx_kernel<2,2,2,2,EPI_DGRAD>",
+                               "wgrad": "gemm_wgrad_kernel<2,2,2,2>"}.get(kind, kind) + f" ({dom})",
+                    "algorithmic_flops_per_launch": 2.0 * N_ * K_ * n, "mean_launch_ms": gemm[dom]["mean_ms"],
+                    "launches_timed": gemm[dom]["launches"],
+                }
+                out["kernels"] = {k: {kk: round(vv, 5) if isinstance(vv, float) else vv for kk, vv in v.items()}
+                                  for k, v in sorted(gemm.items())}
+                for tag in ("env_fwd", "env_bwd"):
+                    if tag in summ:
+                        out["kernels"][tag] = {"launches": summ[tag][0], "mean_ms": round(summ[tag][1], 5)}
+        if world == 1 and not args.no_cpu_baseline:
+            sample = args.cpu_sample or {"cfg3": 2048, "cfg5": 512, "cfg2": 16384, "cfg4": 16384, "cfg1": 256}.get(args.workload, 1024)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, min(sample, n), T)
+                out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:  # the baseline must never take the bench line down
+                out["cpu_baseline"] = {"value": None, "unit": "scenario-steps/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,36 @@ def _pad32(n):
     return (n + 31) // 32 * 32
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the stream the kernels are launched on (torch's current
+    stream).  bench.py uses it to report the dominant kernel's average duration over the timed region."""
+
+    def __init__(self, tags=None):
+        self.tags = set(tags) if tags is not None else None
+        self.events = {}
+        self.enabled = True
+
+    def wants(self, tag):
+        return self.enabled and (self.tags is None or tag in self.tags)
+
+    def call(self, tag, fn, *args, **kw):
+        if not self.wants(tag):
+            return fn(*args, **kw)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn(*args, **kw)
+        b.record()
+        self.events.setdefault(tag, []).append((a, b))
+        return out
+
+    def summary(self):
+        """tag -> (launches, mean ms).  Call after torch.cuda.synchronize()."""
+        return {t: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / len(ev)) for t, ev in self.events.items() if ev}
+
+    def reset(self):
+        self.events = {}
+
+
 class FusedRollout:
     @staticmethod
     def supports(model):
@@ -47,6 +77,12 @@ class FusedRollout:
         self.device = torch.device(device)
         self.head = _HEADS[model.nn_args["name"]]
         self._key = None
+        self.timer = None  # KernelTimer or None
+
+    def _k(self, tag, fn, *args, **kw):
+        if self.timer is None:
+            return fn(*args, **kw)
+        return self.timer.call(tag, fn, *args, **kw)
 
     # ---- buffers ------------------------------------------------------------------------------------------------
     def _linears(self):
@@ -183,10 +219,10 @@ class FusedRollout:
             hs = t if train else 0
             for i in range(L - 1):
                 y = self.hidden[i][hs]
-                ops.linear_fwd(Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)
+                self._k(f"fwd_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_fwd, Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)
                 x = y
             Z = self.logits[t]
-            ops.linear_fwd(Wv[L - 1], biases[L - 1], x, Z, B, _lib.NIC_ACT_NONE)
+            self._k(f"fwd_{self.dims[L]}x{self.dims[L - 1]}", ops.linear_fwd, Wv[L - 1], biases[L - 1], x, Z, B, _lib.NIC_ACT_NONE)
             so, wo, eo = self._order_views(self.orders[t], prob)
             if self.head == "warehouse":
                 ops.head_warehouse_fwd(Z, st.wh, self.adj, ub, bool(self.model.transshipment), so, wo, prob.S, prob.Wn,
@@ -196,8 +232,8 @@ class FusedRollout:
             else:
                 ops.head_softplus_fwd(Z, so.view(-1, ld), prob.S * prob.nsup, B)
             ts, tw, te = self._order_tables(self.orders[t], prob)
-            ops.env_step_fwd(prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te,
-                             out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
+            self._k("env_fwd", ops.env_step_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te,
+                    out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
 
         total = self.rewards.sum()
         reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
@@ -218,8 +254,9 @@ class FusedRollout:
             st = self._views(self.states[t], prob)
             ts, tw, te = self._order_tables(self.orders[t], prob)
             gso, gwo, geo = self._order_views(self.g_orders, prob)
-            ops.env_step_bwd(prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te, self._views(g_next, prob),
-                             Table(self.g_reward, 0, 1), g_in=self._views(g_cur, prob), g_orders=(gso, gwo, geo))
+            self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te,
+                    self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=self._views(g_cur, prob),
+                    g_orders=(gso, gwo, geo))
             Z = self.logits[t]
             gc = self._views(g_cur, prob)
             if self.head == "warehouse":
@@ -232,13 +269,15 @@ class FusedRollout:
             d = self.dZ
             for i in range(L - 1, -1, -1):
                 x_in = self.hidden[i - 1][t] if i > 0 else self.states[t][:self.F]
-                ops.linear_wgrad(d, x_in, self.slabs[i], B)
+                self._k(f"wgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad, d, x_in, self.slabs[i], B)
                 if i > 0:
                     dx = self.dH[i & 1][:self.dims[i]]
-                    ops.linear_dgrad(Wtv[i], d, x_in, dx, B, _lib.NIC_ACT_ELU, False)
+                    self._k(f"dgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_dgrad, Wtv[i], d, x_in, dx, B,
+                            _lib.NIC_ACT_ELU, False)
                     d = dx
                 elif not detached_input:
-                    ops.linear_dgrad(Wtv[0], d, None, g_cur[:self.F], B, _lib.NIC_ACT_NONE, True)
+                    self._k(f"dgrad_{self.dims[1]}x{self.dims[0]}", ops.linear_dgrad, Wtv[0], d, None, g_cur[:self.F], B,
+                            _lib.NIC_ACT_NONE, True)
             g_next, g_cur = g_cur, g_next
 
         for i, m in enumerate(lins):

@@ -1,0 +1,112 @@
+"""BASELINE.json's five configurations as setting / policy dicts in the reference's YAML schema (same keys and values
+as its config_files/settings/*.yml and policies_and_hyperparams/*.yml), for bench.py and examples.
+Each call returns fresh deep copies because `Scenario` mutates its inputs."""
+import copy
+
+_SEEDS = {"underage_cost": 28, "holding_cost": 73, "mean": 33, "coef_of_var": 92, "lead_time": 41, "demand": 57,
+          "initial_inventory": 4839}
+
+
+def _const(v):
+    return {"sample_across_stores": False, "vary_across_samples": False, "expand": True, "value": v}
+
+
+def _per_store(lo, hi):
+    return {"sample_across_stores": True, "vary_across_samples": False, "expand": False, "range": [lo, hi]}
+
+
+def _obs(warehouse, moments):
+    feats = {"holding_costs": True, "underage_costs": True, "lead_times": True}
+    if moments:
+        feats.update({"mean": True, "std": True})
+    return {"include_warehouse_inventory": warehouse, "include_static_features": feats,
+            "demand": {"past_periods": 0, "period_shift": 0}, "include_days_to_christmas": False,
+            "time_features": None, "sample_features": None}
+
+
+def _mlp(name, hidden, out=None, ub_mult=None):
+    p = {"name": name, "inner_layer_activations": {"master": "elu"}, "output_layer_activation": {"master": None},
+         "neurons_per_hidden_layer": {"master": list(hidden)}, "output_sizes": {"master": out}, "initial_bias": None}
+    if ub_mult is not None:
+        p["warehouse_upper_bound_mult"] = ub_mult
+    return p
+
+
+def one_store(lost, poisson):
+    demand = ({"sample_across_stores": False, "expand": True, "mean": 5.0, "distribution": "poisson", "clip": True}
+              if poisson else
+              {"sample_across_stores": False, "expand": True, "mean": 5.0, "std": 1.6, "distribution": "normal", "clip": True})
+    return {
+        "seeds": dict(_SEEDS),
+        "problem_params": {"n_stores": 1, "n_warehouses": 0, "n_extra_echelons": 0, "lost_demand": lost,
+                           "maximize_profit": False},
+        "observation_params": _obs(False, False),
+        "store_params": {"demand": demand, "lead_time": _const(4), "holding_cost": _const(1),
+                         "underage_cost": _const(9.0),
+                         "initial_inventory": {"sample": True, "range_mult": [0, 1], "inventory_periods": 4}},
+        "warehouse_params": None, "echelon_params": None,
+    }
+
+
+def one_warehouse(n_stores=16):
+    return {
+        "seeds": dict(_SEEDS),
+        "problem_params": {"n_stores": n_stores, "n_warehouses": 1, "n_extra_echelons": 0, "lost_demand": True,
+                           "maximize_profit": False},
+        "observation_params": _obs(True, True),
+        "store_params": {
+            "demand": {"sample_across_stores": True, "mean_range": [2.5, 7.5], "coef_of_var_range": [0.25, 0.50],
+                       "distribution": "normal", "correlation": 0.5, "clip": True},
+            "lead_time": _per_store(2, 4), "holding_cost": _per_store(0.7, 1.3), "underage_cost": _per_store(6.3, 11.7),
+            "initial_inventory": {"sample": True, "range_mult": [0, 1], "inventory_periods": 3}},
+        "warehouse_params": {"holding_cost": 0.3, "lead_time": 3}, "echelon_params": None,
+    }
+
+
+def serial_system():
+    s = one_store(lost=False, poisson=False)
+    s["store_params"]["demand"]["std"] = 2.0
+    s["problem_params"].update({"n_warehouses": 1, "n_extra_echelons": 2})
+    s["observation_params"] = _obs(True, False)
+    s["warehouse_params"] = {"holding_cost": 0.5, "lead_time": 3}
+    s["echelon_params"] = {"holding_cost": [0.1, 0.2], "lead_time": [2, 4]}
+    return s
+
+
+def many_warehouses(n_stores=64, n_warehouses=3, seed=0):
+    """cfg5: synthetic [Wn][S] adjacency (every store served by 1-2 warehouses) and [S][Wn] lead times in 1..6
+    (0 = not connected), in the format of the reference's many_warehouses_lost_demand.yml:31-34,79-91."""
+    import random
+    rnd = random.Random(seed)
+    adj = [[0] * n_stores for _ in range(n_warehouses)]
+    lead = [[0] * n_warehouses for _ in range(n_stores)]
+    for s in range(n_stores):
+        for w in rnd.sample(range(n_warehouses), rnd.choice([1, 2])):
+            adj[w][s] = 1
+            lead[s][w] = rnd.randint(1, 6)
+    s_ = one_warehouse(n_stores)
+    s_["problem_params"].update({"n_warehouses": n_warehouses, "warehouse_store_adjacency": adj})
+    s_["store_params"]["lead_time"] = _const(lead)
+    s_["warehouse_params"] = {"holding_cost": [0.3, 0.4, 0.2][:n_warehouses], "lead_time": 3,
+                              "edge_cost": [0.5, 1.5, 0.7][:n_warehouses]}
+    return s_
+
+
+WORKLOADS = {
+    # name: (setting builder, policy dict, scenarios per GPU, periods, description)
+    "cfg1": (lambda: one_store(True, True), _mlp("vanilla_one_store", [32, 32, 32], 1), 256, 50,
+             "one_store_lost + vanilla_one_store, 256 scenarios x T=50"),
+    "cfg2": (lambda: one_store(False, False), _mlp("vanilla_one_store", [32, 32, 32], 1), 32768, 100,
+             "one_store_backlogged + vanilla_one_store, 32768 scenarios x T=100"),
+    "cfg3": (lambda: one_warehouse(16), _mlp("vanilla_warehouse", [512, 512, 512], None, 4), 65536, 100,
+             "one_warehouse_lost_demand, 16 stores, 65536 scenarios x T=100, vanilla_warehouse 512x3"),
+    "cfg4": (serial_system, _mlp("vanilla_serial", [32, 32], 4, 4), 16384, 100,
+             "serial_system 4 echelons, 16384 scenarios/GPU x T=100, vanilla_serial"),
+    "cfg5": (lambda: many_warehouses(64, 3), _mlp("vanilla_warehouse", [512, 512, 512], None, 4), 32768, 70,
+             "many_warehouses_lost_demand 3x64 stores, 32768 scenarios/GPU x T=70, vanilla_warehouse 512x3"),
+}
+
+
+def get(name):
+    build, policy, n, T, desc = WORKLOADS[name]
+    return copy.deepcopy(build()), copy.deepcopy(policy), n, T, desc

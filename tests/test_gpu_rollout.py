@@ -23,6 +23,9 @@ from neural_inventory_control_amd.trainer import Trainer
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# state after T periods of a random-init policy in the loop: f32 round-off of the policy GEMMs (different summation order
+# than the CPU reference) is amplified by the recurrence; costs stay within 1e-5, individual pipeline slots within 1e-4
+STATE_TOL = dict(rtol=1e-4, atol=2e-3)
 MLP_CASES = [n for n in case_names() if n.endswith("vanilla")]
 # random-init softmax heads saturate late in the horizon, which puts warehouse on-hand (stock - sum of shares) within
 # float noise of zero: the `>= 0` mask of its holding cost then flips with summation order ("knife
