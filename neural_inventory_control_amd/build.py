@@ -54,6 +54,8 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        import ctypes
+        ctypes.CDLL(OUT)  # fail the build on unresolved symbols
     return OUT
 
 

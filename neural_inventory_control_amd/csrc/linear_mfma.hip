@@ -20,6 +20,8 @@
 //   pipeline: register-staged double buffering — global loads of tile t+1 are issued before the MFMAs of tile t and
 //             written to the other LDS buffer after them; one barrier per k tile.
 // Roofline: MFMA-bound (2*N*K flops per scenario per layer; 128x128x32 tiles read 32 flop/byte from L2).
+#include <stdlib.h>
+
 #include "nic_common.h"
 
 namespace {
@@ -118,6 +120,99 @@ struct CTile {
     }
 };
 
+// ---- branch-free tile loaders (buffer loads: hardware range check returns 0 past num_records) ------------------------
+// The guarded loaders above branch per element and hipcc serialises their loads behind s_waitcnt; in the k loop that
+// stalls every tile.  When the operand rows are 16-byte aligned the tile is fetched with raw buffer loads instead: rows
+// past the end of the matrix are out of range of the descriptor and read as 0.0 without a branch, so the loads of a
+// tile issue back to back.  Columns past K inside an A row read whatever follows (row padding or the next row — finite
+// weights) and are multiplied by B rows that ARE out of range (zero), so no k guard is needed either.
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int64_t n_floats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(n_floats * 4), 0x00020000);
+}
+
+template <int ROWS>
+struct KTileBuf {
+    static constexpr int N4 = ROWS / 32;
+    float4 v[N4];
+    int off[N4];  // byte offsets of this thread's float4s in the current tile
+    __device__ __forceinline__ void init(int64_t ld, int row0, int k0) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < N4; ++i) off[i] = (int)((((int64_t)row0 + (t >> 3) + 32 * i) * ld + k0 + (t & 7) * 4) * 4);
+    }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc) {
+#pragma unroll
+        for (int i = 0; i < N4; ++i) v[i] = buf_load4(rsrc, off[i]);
+    }
+    __device__ __forceinline__ void advance(int tiles = 1) {
+#pragma unroll
+        for (int i = 0; i < N4; ++i) off[i] += tiles * BK * 4;
+    }
+    // wgrad: zero the scenarios at or past b_end; row `ones_row` is a virtual row of ones (bias gradient column)
+    __device__ __forceinline__ void mask_cols(int b0, int b_end, int row0, int ones_row) {
+        const int t = threadIdx.x;
+        const int b = b0 + (t & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < N4; ++i) {
+            const bool one = (row0 + (t >> 3) + 32 * i) == ones_row;
+            float4 x = v[i];
+            x.x = b + 0 < b_end ? (one ? 1.f : x.x) : 0.f;
+            x.y = b + 1 < b_end ? (one ? 1.f : x.y) : 0.f;
+            x.z = b + 2 < b_end ? (one ? 1.f : x.z) : 0.f;
+            x.w = b + 3 < b_end ? (one ? 1.f : x.w) : 0.f;
+            v[i] = x;
+        }
+    }
+    __device__ __forceinline__ void store(float* lds) const {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < N4; ++i)
+            *reinterpret_cast<float4*>(lds + ((t >> 3) + 32 * i) * LDA_S + (t & 7) * 4) = v[i];
+    }
+};
+
+template <int COLS>
+struct CTileBuf {
+    static constexpr int TPR = COLS / 4;
+    static constexpr int RPI = kThreads / TPR;
+    static constexpr int N4 = BK / RPI;
+    float4 v[N4];
+    int off[N4];
+    int step;
+    __device__ __forceinline__ void init(int64_t ld, int c0) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < N4; ++i) off[i] = (int)((((int64_t)(t / TPR) + RPI * i) * ld + c0 + (t % TPR) * 4) * 4);
+        step = (int)(ld * BK * 4);
+    }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc) {
+#pragma unroll
+        for (int i = 0; i < N4; ++i) v[i] = buf_load4(rsrc, off[i]);
+    }
+    __device__ __forceinline__ void advance(int tiles = 1) {
+#pragma unroll
+        for (int i = 0; i < N4; ++i) off[i] += tiles * step;
+    }
+    __device__ __forceinline__ void store(float* lds) const {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < N4; ++i)
+            *reinterpret_cast<float4*>(lds + (t / TPR + RPI * i) * COLS + (t % TPR) * 4) = v[i];
+    }
+};
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2).  Remap the linear workgroup id so that every
+// XCD gets a CONTIGUOUS range of logical tiles: the tiles that share an operand panel (the row tiles of one scenario
+// panel in the wx kernel, the 16 output tiles of one scenario chunk in the wgrad kernel) then run on one XCD at about
+// the same time and the panel is fetched from HBM once instead of once per XCD.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // eight k-contiguous operand values of one lane for k group g (see "k order" above)
 __device__ __forceinline__ void read_frag8(const float* lds_row, int g, int h, float (&f)[8]) {
     const float4 lo = *reinterpret_cast<const float4*>(lds_row + g * 16 + h * 8);
@@ -129,7 +224,7 @@ __device__ __forceinline__ void read_frag8(const float* lds_row, int g, int h, f
 // ---------------------------------------------------------------------------------------------------------------
 // wx kernel: C[M][ncols] = epilogue( A[M][K] * Bm[K][ncols] )
 // ---------------------------------------------------------------------------------------------------------------
-template <int WAVES_M, int WAVES_N, int MT, int NT, int EPI>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int EPI, int BPRE, int FAST, int DBG = 0>
 __global__ __launch_bounds__(kThreads) void gemm_wx_kernel(WxParams p) {
     constexpr int BM = WAVES_M * MT * 32;
     constexpr int BN = WAVES_N * NT * 32;
@@ -139,13 +234,20 @@ __global__ __launch_bounds__(kThreads) void gemm_wx_kernel(WxParams p) {
 
     // row tiles vary fastest so that the workgroups sharing one column panel of Bm are dispatched back to back
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int m0 = (blockIdx.x % tiles_m) * BM;
-    const int c0 = (blockIdx.x / tiles_m) * BN;
+    const int tile = (DBG & 32) ? (int)blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m0 = (tile % tiles_m) * BM;
+    const int c0 = (tile / tiles_m) * BN;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, h = lane >> 5;
     const bool vecA = (p.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+    if constexpr (DBG & 4) {
+        // two co-resident workgroups otherwise run in lockstep (same program, same start): both reach the per-tile
+        // load/barrier bubble together and the matrix pipe idles.  Delay the odd wave slots by half a tile period.
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // HW_REG_HW_ID.wave_id bit 0
+        if (slot) __builtin_amdgcn_s_sleep(78);
+    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -155,21 +257,30 @@ __global__ __launch_bounds__(kThreads) void gemm_wx_kernel(WxParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const int nk = (p.K + BK - 1) / BK;
     KTile<BM> ta;
     CTile<BN> tb;
-    const int nk = (p.K + BK - 1) / BK;
-    ta.load(p.A, p.lda, m0, p.M, 0, p.K, vecA);
-    tb.load(p.Bm, p.ldb, 0, p.K, c0, p.ncols);
-    ta.store(lds);
-    tb.store(lds + BM * LDA_S);
+    KTileBuf<BM> fa;
+    CTileBuf<BN> fb;
+    __amdgpu_buffer_rsrc_t ra, rb;
+    if constexpr (FAST) {
+        ra = make_rsrc(p.A, (int64_t)p.M * p.lda);
+        rb = make_rsrc(p.Bm, (int64_t)p.K * p.ldb);
+        fa.init(p.lda, m0, 0);
+        fb.init(p.ldb, c0);
+        fa.load(ra);
+        fb.load(rb);
+        fa.store(lds);
+        fb.store(lds + BM * LDA_S);
+    } else {
+        ta.load(p.A, p.lda, m0, p.M, 0, p.K, vecA);
+        tb.load(p.Bm, p.ldb, 0, p.K, c0, p.ncols);
+        ta.store(lds);
+        tb.store(lds + BM * LDA_S);
+    }
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            ta.load(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, vecA);
-            tb.load(p.Bm, p.ldb, (kt + 1) * BK, p.K, c0, p.ncols);
-        }
+    auto compute = [&](int cur) {
         const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * LDA_S;
         const float* b_base = lds + cur * STAGE + BM * LDA_S + wn * NT * 32 + li;
 #pragma unroll
@@ -177,26 +288,175 @@ __global__ __launch_bounds__(kThreads) void gemm_wx_kernel(WxParams p) {
             float a[MT][8];
 #pragma unroll
             for (int i = 0; i < MT; ++i) read_frag8(a_base + i * 32 * LDA_S, g, h, a[i]);
+            if constexpr (BPRE) {
+                // all B fragments of the k group are in flight before the first MFMA: the 8*MT*NT MFMAs that follow
+                // (64 cycles each) cover the LDS latency of the next group's reads
+                float b[NT][8];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                float b[NT];
+                for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
+                    for (int j = 0; j < NT; ++j) b[j][kk] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+                if constexpr (BPRE == 2) {
+                    // pin the interleave hipcc otherwise collapses to {ds_read, s_waitcnt lgkmcnt(0), MFMAs}: LDS reads run
+                    // two k steps ahead of the MFMAs that consume them, so their latency hides under 2 x MT*NT MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                    for (int st = 0; st < 7; ++st) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    float b[NT];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) b[j] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j], acc[i][j], 0, 0, 0);
+                }
             }
         }
-        if (kt + 1 < nk) {
-            ta.store(lds + (cur ^ 1) * STAGE);
-            tb.store(lds + (cur ^ 1) * STAGE + BM * LDA_S);
+    };
+
+    if constexpr (FAST && (DBG & 64)) {
+        // two tiles of global loads in flight: tile t+2 is requested before tile t is computed and lands in LDS one
+        // iteration later, so the vmcnt wait in front of the LDS writes has a full tile of slack
+        KTileBuf<BM> fa1 = fa;
+        CTileBuf<BN> fb1 = fb;
+        fa1.advance();
+        fb1.advance();
+        if (nk > 1) {
+            fa1.load(ra);
+            fb1.load(rb);
         }
-        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (kt + 2 < nk) {
+                fa.advance(2);
+                fb.advance(2);
+                fa.load(ra);
+                fb.load(rb);
+            }
+            compute(0);
+            if (kt + 1 < nk) {
+                fa1.store(lds + STAGE);
+                fb1.store(lds + STAGE + BM * LDA_S);
+            }
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            if (kt + 3 < nk) {
+                fa1.advance(2);
+                fb1.advance(2);
+                fa1.load(ra);
+                fb1.load(rb);
+            }
+            compute(1);
+            if (kt + 2 < nk) {
+                fa.store(lds);
+                fb.store(lds + BM * LDA_S);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if ((kt + 1 < nk) && !(DBG & 1)) {
+                if constexpr (FAST) {
+                    if constexpr (!(DBG & 128)) {
+                        fa.advance();
+                        fb.advance();
+                        fa.load(ra);
+                        fb.load(rb);
+                    }
+                } else {
+                    ta.load(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, vecA);
+                    tb.load(p.Bm, p.ldb, (kt + 1) * BK, p.K, c0, p.ncols);
+                }
+            }
+            compute(cur);
+            if ((kt + 1 < nk) && !(DBG & 1)) {
+                if constexpr (FAST) {
+                    if constexpr (DBG & 256) {  // timing-only: loads without the LDS writes
+#pragma unroll
+                        for (int q = 0; q < KTileBuf<BM>::N4; ++q) asm volatile("" ::"v"(fa.v[q].x), "v"(fa.v[q].w));
+#pragma unroll
+                        for (int q = 0; q < CTileBuf<BN>::N4; ++q) asm volatile("" ::"v"(fb.v[q].x), "v"(fb.v[q].w));
+                    } else {
+                        fa.store(lds + (cur ^ 1) * STAGE);
+                        fb.store(lds + (cur ^ 1) * STAGE + BM * LDA_S);
+                    }
+                } else {
+                    ta.store(lds + (cur ^ 1) * STAGE);
+                    tb.store(lds + (cur ^ 1) * STAGE + BM * LDA_S);
+                }
+            }
+            if constexpr (!(DBG & 2)) __syncthreads();
+        }
+    }
+    if constexpr (DBG & 8) {  // timing-only: drop the epilogue but keep the accumulators alive
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
     }
 
     // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if constexpr (FAST && !(DBG & 16) && (BM * (BN + 4) <= 2 * STAGE)) {
+        // A lane owns ONE scenario column of each 32x32 tile, so storing straight from the accumulators costs 16*MT*NT
+        // four-byte store instructions per wave (store-issue bound).  Stage the block tile through the (now dead)
+        // LDS tiles instead and write it out as whole rows: 16 B per lane, 512 contiguous bytes per 32 lanes, a
+        // quarter of the store instructions; the dgrad's Hprev / accumulate reads become float4 loads the same way.
+        constexpr int LDC = BN + 4;
+        float* cs = lds;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    cs[((wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + (wn * NT + j) * 32 + li] = acc[i][j][r];
+        __syncthreads();
+        constexpr int TPR = BN / 4, RPI = kThreads / TPR, ITER = BM / RPI;
+        const int t = threadIdx.x;
+        const int col = c0 + (t % TPR) * 4;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int row_l = t / TPR + RPI * it;
+            const int row = m0 + row_l;
+            if (row >= p.M || col >= p.ncols) continue;
+            float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (t % TPR) * 4);
+            const int64_t off = (int64_t)row * p.ldb + col;
+            if (EPI == EPI_BIAS_ACT) {
+                const float bias = p.bias ? p.bias[row] : 0.f;
+                y.x += bias; y.y += bias; y.z += bias; y.w += bias;
+                if (p.act == NIC_ACT_ELU) { y.x = elu_f(y.x); y.y = elu_f(y.y); y.z = elu_f(y.z); y.w = elu_f(y.w); }
+            } else {
+                if (p.Hprev && p.act == NIC_ACT_ELU) {
+                    const float4 hq = *reinterpret_cast<const float4*>(p.Hprev + off);
+                    y.x *= elu_grad_from_out(hq.x); y.y *= elu_grad_from_out(hq.y);
+                    y.z *= elu_grad_from_out(hq.z); y.w *= elu_grad_from_out(hq.w);
+                }
+                if (p.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(p.C + off);
+                    y.x += o.x; y.y += o.y; y.z += o.z; y.w += o.w;
+                }
+            }
+            *reinterpret_cast<float4*>(p.C + off) = y;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -225,6 +485,157 @@ __global__ __launch_bounds__(kThreads) void gemm_wx_kernel(WxParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// wx kernel, LDS-DMA form (the production path): tiles go HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds`, no VGPR
+// round trip and no ds_write.  Measured on MI355X at 512x512x65536: the register-staged loop spends 13 % of its time
+// in the ds_write_b128 transfer and 5 % in the loads; both disappear here.
+//   A tile [BM][32] floats, UNPADDED (a DMA wave-instruction writes 1 KiB linearly = 8 rows), 16-byte chunks XOR-
+//     swizzled with ((row >> 1) & 7) on the SOURCE address; the ds_read_b128 fragment reads apply the same XOR, which
+//     makes every 16-lane read group hit 16 distinct bank quads (rows r, r+1 differ in the 32-bank half).
+//   B tile [32][BN] floats, linear (row reads by ds_read_b32 are conflict-free as they are).
+//   Rows past the matrix end are out of range of the buffer descriptor: the DMA writes zeros, no branches.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int MT, int NT, int EPI>
+__global__ __launch_bounds__(kThreads) void gemm_wx_dma_kernel(WxParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // LDS address-space pointers only exist in the device pass
+    constexpr int BM = WAVES_M * MT * 32;
+    constexpr int BN = WAVES_N * NT * 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int A_FLOATS = BM * BK, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;
+    constexpr int LDC = BN + 4;
+    constexpr int LDS_FLOATS = (2 * STAGE > BM * LDC) ? 2 * STAGE : BM * LDC;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m0 = (tile % tiles_m) * BM;
+    const int c0 = (tile / tiles_m) * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, h = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, (int64_t)p.M * p.lda);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.Bm, (int64_t)p.K * p.ldb);
+    constexpr int A_INSTR = BM / 32;               // 1-KiB DMA instructions per wave for the A tile (8 rows each)
+    constexpr int B_INSTR = BN / 32;               // ... for the B tile (256/BN rows each)
+    constexpr int B_LPR = BN / 4;                  // lanes per B row
+    int offA[A_INSTR], offB[B_INSTR];
+#pragma unroll
+    for (int q = 0; q < A_INSTR; ++q) {
+        const int row = (wave * A_INSTR + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // LDS position (lane & 7) holds source chunk `chunk`
+        offA[q] = (int)((((int64_t)m0 + row) * p.lda + chunk * 4) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < B_INSTR; ++q) {
+        const int row = (wave * B_INSTR + q) * (64 / B_LPR) + lane / B_LPR;
+        offB[q] = (int)(((int64_t)row * p.ldb + c0 + (lane % B_LPR) * 4) * 4);
+    }
+    const int stepB = (int)(p.ldb * BK * 4);
+    auto issue = [&](int stage) {
+        float* base = lds + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < A_INSTR; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(base + (wave * A_INSTR + q) * 256), 16, offA[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < B_INSTR; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(base + A_FLOATS + (wave * B_INSTR + q) * 256), 16,
+                                                     offB[q], 0, 0, 0);
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int q = 0; q < A_INSTR; ++q) offA[q] += BK * 4;
+#pragma unroll
+        for (int q = 0; q < B_INSTR; ++q) offB[q] += stepB;
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // swizzled chunk positions of this lane's A rows: row = wm*MT*32 + i*32 + li -> ((row >> 1) & 7) == ((li >> 1) & 7)
+    const int sw = (li >> 1) & 7;
+    const int nk = (p.K + BK - 1) / BK;
+    issue(0);
+    __syncthreads();  // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            advance();
+            issue(cur ^ 1);
+        }
+        const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * BK;
+        const float* b_base = lds + cur * STAGE + A_FLOATS + wn * NT * 32 + li;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float a[MT][8];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float4 lo = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
+                const float4 hi = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
+                a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
+                a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                float b[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: stage the block tile through LDS and write whole rows (see gemm_wx_kernel)
+    float* cs = lds;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                cs[((wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + (wn * NT + j) * 32 + li] = acc[i][j][r];
+    __syncthreads();
+    constexpr int TPR = BN / 4, RPI = kThreads / TPR, ITER = BM / RPI;
+    const int t = threadIdx.x;
+    const int col = c0 + (t % TPR) * 4;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int row_l = t / TPR + RPI * it;
+        const int row = m0 + row_l;
+        if (row >= p.M || col >= p.ncols) continue;
+        float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (t % TPR) * 4);
+        const int64_t off = (int64_t)row * p.ldb + col;
+        if (EPI == EPI_BIAS_ACT) {
+            const float bias = p.bias ? p.bias[row] : 0.f;
+            y.x += bias; y.y += bias; y.z += bias; y.w += bias;
+            if (p.act == NIC_ACT_ELU) { y.x = elu_f(y.x); y.y = elu_f(y.y); y.z = elu_f(y.z); y.w = elu_f(y.w); }
+        } else {
+            if (p.Hprev && p.act == NIC_ACT_ELU) {
+                const float4 hq = *reinterpret_cast<const float4*>(p.Hprev + off);
+                y.x *= elu_grad_from_out(hq.x); y.y *= elu_grad_from_out(hq.y);
+                y.z *= elu_grad_from_out(hq.z); y.w *= elu_grad_from_out(hq.w);
+            }
+            if (p.accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(p.C + off);
+                y.x += o.x; y.y += o.y; y.z += o.z; y.w += o.w;
+            }
+        }
+        *reinterpret_cast<float4*>(p.C + off) = y;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // wgrad kernel: slab[split][n][k] += sum_{b in split} dY[n][b] * X[k][b]   (k == K: bias column, X row of ones)
 // ---------------------------------------------------------------------------------------------------------------
 struct WgParams {
@@ -235,16 +646,19 @@ struct WgParams {
     int N, K, nB, chunk;  // chunk = scenarios per split (multiple of 32)
 };
 
-template <int WAVES_M, int WAVES_N, int MT, int NT>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int FAST>
 __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
     constexpr int BM = WAVES_M * MT * 32;
     constexpr int BN = WAVES_N * NT * 32;
     constexpr int STAGE = (BM + BN) * LDA_S;
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
-    const int n0 = blockIdx.y * BM;   // output rows  (features of dY)
-    const int k0 = blockIdx.x * BN;   // output cols  (features of X, plus the bias column K)
-    const int split = blockIdx.z;
+    // 1-D grid, tile index fastest: the tiles of one scenario chunk (split) are contiguous logical ids -> one XCD
+    const int tiles_k = (p.K + 1 + BN - 1) / BN, tiles_n = (p.N + BM - 1) / BM;
+    const int lid = blockIdx.x;  // (an XCD remap of this id measured 15 % SLOWER here: keep dispatch order)
+    const int k0 = (lid % tiles_k) * BN;                  // output cols  (features of X, plus the bias column K)
+    const int n0 = ((lid / tiles_k) % tiles_n) * BM;      // output rows  (features of dY)
+    const int split = lid / (tiles_k * tiles_n);
     const int b_begin = split * p.chunk;
     const int b_end = min(b_begin + p.chunk, p.nB);
 
@@ -271,17 +685,40 @@ __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
                          ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
         KTile<BM> ta;
         KTile<BN> tb;
+        KTileBuf<BM> fa;
+        KTileBuf<BN> fb;
+        __amdgpu_buffer_rsrc_t ra, rb;
         const int nt = (b_end - b_begin + BK - 1) / BK;
-        ta.load(p.dY, p.ldb, n0, p.N, b_begin, b_end, vec);
-        tb.load(p.X, p.ldb, k0, p.K, b_begin, b_end, vec, p.K, b_end);
-        ta.store(lds);
-        tb.store(lds + BM * LDA_S);
+        if constexpr (FAST) {
+            ra = make_rsrc(p.dY, (int64_t)p.N * p.ldb);
+            rb = make_rsrc(p.X, (int64_t)p.K * p.ldb);
+            fa.init(p.ldb, n0, b_begin);
+            fb.init(p.ldb, k0, b_begin);
+            fa.load(ra);
+            fb.load(rb);
+            fa.mask_cols(b_begin, b_end, n0, -1);
+            fb.mask_cols(b_begin, b_end, k0, p.K);
+            fa.store(lds);
+            fb.store(lds + BM * LDA_S);
+        } else {
+            ta.load(p.dY, p.ldb, n0, p.N, b_begin, b_end, vec);
+            tb.load(p.X, p.ldb, k0, p.K, b_begin, b_end, vec, p.K, b_end);
+            ta.store(lds);
+            tb.store(lds + BM * LDA_S);
+        }
         __syncthreads();
         for (int t = 0; t < nt; ++t) {
             const int cur = t & 1;
             if (t + 1 < nt) {
-                ta.load(p.dY, p.ldb, n0, p.N, b_begin + (t + 1) * BK, b_end, vec);
-                tb.load(p.X, p.ldb, k0, p.K, b_begin + (t + 1) * BK, b_end, vec, p.K, b_end);
+                if constexpr (FAST) {
+                    fa.advance();
+                    fb.advance();
+                    fa.load(ra);
+                    fb.load(rb);
+                } else {
+                    ta.load(p.dY, p.ldb, n0, p.N, b_begin + (t + 1) * BK, b_end, vec);
+                    tb.load(p.X, p.ldb, k0, p.K, b_begin + (t + 1) * BK, b_end, vec, p.K, b_end);
+                }
             }
             const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * LDA_S;
             const float* b_base = lds + cur * STAGE + (BM + wn * NT * 32 + li) * LDA_S;
@@ -301,8 +738,15 @@ __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
             }
             if (t + 1 < nt) {
-                ta.store(lds + (cur ^ 1) * STAGE);
-                tb.store(lds + (cur ^ 1) * STAGE + BM * LDA_S);
+                if constexpr (FAST) {
+                    fa.mask_cols(b_begin + (t + 1) * BK, b_end, n0, -1);
+                    fb.mask_cols(b_begin + (t + 1) * BK, b_end, k0, p.K);
+                    fa.store(lds + (cur ^ 1) * STAGE);
+                    fb.store(lds + (cur ^ 1) * STAGE + BM * LDA_S);
+                } else {
+                    ta.store(lds + (cur ^ 1) * STAGE);
+                    tb.store(lds + (cur ^ 1) * STAGE + BM * LDA_S);
+                }
             }
             __syncthreads();
         }
@@ -333,25 +777,88 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int64_t lds_
     else if (db) db[n] = s;
 }
 
-template <int WM, int WN, int MT, int NT, int EPI>
+// fast (buffer-load) path: 16-byte aligned operands, row strides multiples of 4 floats, buffers below 2 GiB
+bool wx_fast_ok(const WxParams& p) {
+    return p.lda % 4 == 0 && p.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(p.Bm) & 15) == 0 && (int64_t)p.M * p.lda < (1ll << 28) &&
+           (int64_t)p.K * p.ldb < (1ll << 28);
+}
+
+int gemm_variant();
+
+template <int WM, int WN, int MT, int NT, int EPI, int BPRE>
 void launch_wx(const WxParams& p, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.ncols + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_wx_kernel<WM, WN, MT, NT, EPI>), dim3(tiles_m * tiles_n), dim3(kThreads), 0, s, p);
+    if constexpr (BN >= 128 && BM * (BN + 4) * 4 <= 80 * 1024) {
+        if (wx_fast_ok(p) && gemm_variant() != 10) {
+            hipLaunchKernelGGL((gemm_wx_dma_kernel<WM, WN, MT, NT, EPI>), dim3(tiles_m * tiles_n), dim3(kThreads), 0, s, p);
+            return;
+        }
+    }
+    if (wx_fast_ok(p))
+        hipLaunchKernelGGL((gemm_wx_kernel<WM, WN, MT, NT, EPI, BPRE, 1>), dim3(tiles_m * tiles_n), dim3(kThreads), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_wx_kernel<WM, WN, MT, NT, EPI, BPRE, 0>), dim3(tiles_m * tiles_n), dim3(kThreads), 0, s, p);
+}
+
+template <int EPI, int DBG>
+void launch_wx_dbg1(const WxParams& p, hipStream_t s) {
+    const int tiles = ((p.M + 127) / 128) * ((p.ncols + 127) / 128);
+    hipLaunchKernelGGL((gemm_wx_kernel<2, 2, 2, 2, EPI, 1, 1, DBG>), dim3(tiles), dim3(kThreads), 0, s, p);
+}
+template <int EPI>
+void launch_wx_dbg(const WxParams& p, hipStream_t s, int dbg) {
+    switch (dbg) {
+        case 1: launch_wx_dbg1<EPI, 1>(p, s); break;    // no loads in the loop
+        case 3: launch_wx_dbg1<EPI, 3>(p, s); break;    // no loads, no barrier
+        case 4: launch_wx_dbg1<EPI, 4>(p, s); break;    // stagger
+        case 16: launch_wx_dbg1<EPI, 16>(p, s); break;  // direct (un-staged) epilogue
+        case 32: launch_wx_dbg1<EPI, 32>(p, s); break;  // no XCD swizzle
+        case 64: launch_wx_dbg1<EPI, 64>(p, s); break;  // two tiles of loads in flight
+        case 128: launch_wx_dbg1<EPI, 128>(p, s); break;  // LDS writes without the global loads (timing only)
+        case 256: launch_wx_dbg1<EPI, 256>(p, s); break;  // global loads without the LDS writes (timing only)
+        default: launch_wx_dbg1<EPI, 0>(p, s); break;
+    }
+}
+
+// NIC_GEMM_VARIANT (debug/tuning only): 0 = default choice below
+int gemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("NIC_GEMM_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 template <int EPI>
 void dispatch_wx(const WxParams& p, hipStream_t s) {
-    if (p.M > 64) launch_wx<2, 2, 2, 2, EPI>(p, s);        // 128 x 128
-    else if (p.M > 32) launch_wx<1, 4, 2, 1, EPI>(p, s);   //  64 x 128
-    else launch_wx<1, 4, 1, 2, EPI>(p, s);                 //  32 x 256
+    const int v = gemm_variant();
+    if (p.M > 64) {
+        if (v == 1) launch_wx<2, 2, 2, 2, EPI, 0>(p, s);        // 128 x 128, B fragments loaded per k step
+        else if (v == 2) launch_wx<2, 2, 2, 4, EPI, 1>(p, s);   // 128 x 256
+        else if (v == 3) launch_wx<2, 2, 4, 2, EPI, 1>(p, s);   // 256 x 128
+        else if (v == 4) launch_wx<4, 1, 1, 4, EPI, 1>(p, s);   // 128 x 128, waves stacked along M (each 32 x 128)
+        else if (v == 5) launch_wx<1, 4, 4, 1, EPI, 1>(p, s);   // 128 x 128, waves side by side along N (each 128 x 32)
+        else if (v == 6) launch_wx<2, 2, 2, 2, EPI, 2>(p, s);   // 128 x 128 with the pinned DS/MFMA interleave
+        else if (v == 7) launch_wx<2, 2, 2, 4, EPI, 2>(p, s);   // 128 x 256 pinned
+        else if (v == 8) launch_wx<2, 2, 4, 2, EPI, 2>(p, s);   // 256 x 128 pinned
+        else if (v >= 20 && v < 400) launch_wx_dbg<EPI>(p, s, v - 20);  // timing experiments (results may be WRONG)
+        else launch_wx<2, 2, 2, 2, EPI, 1>(p, s);               // 128 x 128
+    } else if (p.M > 32) launch_wx<1, 4, 2, 1, EPI, 1>(p, s);   //  64 x 128
+    else launch_wx<1, 4, 1, 2, EPI, 1>(p, s);                   //  32 x 256
 }
 
 template <int WM, int WN, int MT, int NT>
 void launch_wg(const WgParams& p, int n_splits, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-    dim3 grid((p.K + 1 + BN - 1) / BN, (p.N + BM - 1) / BM, n_splits);
-    hipLaunchKernelGGL((gemm_wgrad_kernel<WM, WN, MT, NT>), grid, dim3(kThreads), 0, s, p);
+    dim3 grid(((p.K + 1 + BN - 1) / BN) * ((p.N + BM - 1) / BM) * n_splits);
+    const bool fast = p.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(p.dY) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(p.X) & 15) == 0 && (int64_t)p.N * p.ldb < (1ll << 28) &&
+                      (int64_t)p.K * p.ldb < (1ll << 28);
+    if (fast) hipLaunchKernelGGL((gemm_wgrad_kernel<WM, WN, MT, NT, 1>), grid, dim3(kThreads), 0, s, p);
+    else hipLaunchKernelGGL((gemm_wgrad_kernel<WM, WN, MT, NT, 0>), grid, dim3(kThreads), 0, s, p);
 }
 
 // the tile shape is a function of (N, K) only so that nic_wgrad_num_splits and the launch agree

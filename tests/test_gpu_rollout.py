@@ -92,7 +92,7 @@ def test_fused_rollout_matches_reference(name):
     assert abs(float(reported) - float(g.z["reported"])) <= 1e-5 * abs(float(g.z["reported"]))
     final = eng.final_state()
     for k, v in g.states(c["periods"]).items():
-        torch.testing.assert_close(final[k].cpu(), v, rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(final[k].cpu(), v, **STATE_TOL)
     _check_grads(model, g, GRAD_TOL.get(name, 2e-5))
     # evaluation mode (no activations kept) gives the same costs
     t2, r2 = eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"])
@@ -122,7 +122,7 @@ def test_simulator_autograd_route_matches_reference(name):
     assert abs(float(total) - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
     assert abs(float(reported) - float(g.z["reported"])) <= 1e-5 * abs(float(g.z["reported"]))
     for k, v in g.states(c["periods"]).items():
-        torch.testing.assert_close(sim.observation[k].cpu(), v, rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(sim.observation[k].cpu(), v, **STATE_TOL)
     assert int(sim.observation["current_period"]) == c["periods"]
     _check_grads(model, g, GRAD_TOL.get(name, 2e-5))
 

@@ -1,4 +1,5 @@
-"""Micro-benchmark of the policy GEMM kernels + env step at BASELINE cfg3 shapes (HIP events on the current stream)."""
+"""Micro-benchmark of the policy GEMM kernels at BASELINE cfg3 shapes (HIP events on the current stream).
+NIC_GEMM_VARIANT selects a tuning variant of the wx kernel (see dispatch_wx in csrc/linear_mfma.hip)."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,10 +21,11 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     dev = "cuda"
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    B = int(os.environ.get("PROBE_B", 65536))
+    shapes = [(512, 512)] if os.environ.get("PROBE_MAIN_ONLY") else [(512, 512), (512, 51), (17, 512)]
     ldb = pad_ld(B)
-    res = {}
-    for (N, K) in [(512, 512), (512, 51), (17, 512)]:
+    res = {"variant": os.environ.get("NIC_GEMM_VARIANT", "0")}
+    for (N, K) in shapes:
         W = torch.randn(N, (K + 31) // 32 * 32, device=dev)[:, :K] * 0.05
         Wt = torch.randn(K, (N + 31) // 32 * 32, device=dev)[:, :N] * 0.05
         b = torch.randn(N, device=dev)
@@ -32,18 +34,14 @@ def main():
         dX = torch.zeros(K, ldb, device=dev)
         flops = 2.0 * N * K * B
         ms = timeit(lambda: ops.linear_fwd(W, b, X, Y, B, 1))
-        res[f"fwd_{N}x{K}"] = dict(ms=ms, tflops=flops / ms / 1e9)
+        res[f"fwd_{N}x{K}"] = dict(ms=round(ms, 4), tflops=round(flops / ms / 1e9, 1))
         ms = timeit(lambda: ops.linear_dgrad(Wt, Y, X, dX, B, 1, False))
-        res[f"dgrad_{N}x{K}"] = dict(ms=ms, tflops=flops / ms / 1e9)
+        res[f"dgrad_{N}x{K}"] = dict(ms=round(ms, 4), tflops=round(flops / ms / 1e9, 1))
         splits = ops.wgrad_num_splits(N, K, B)
         slab = torch.zeros(splits, N, (K + 4) // 4 * 4, device=dev)
         ms = timeit(lambda: ops.linear_wgrad(Y, X, slab, B))
-        res[f"wgrad_{N}x{K}"] = dict(ms=ms, tflops=flops / ms / 1e9, splits=splits)
-        # rocBLAS (torch) for orientation only
-        Xr, Wr = torch.randn(B, K, device=dev), torch.randn(N, K, device=dev)
-        ms = timeit(lambda: torch.nn.functional.linear(Xr, Wr))
-        res[f"torch_linear_{N}x{K}"] = dict(ms=ms, tflops=flops / ms / 1e9)
-    print(json.dumps(res, indent=1))
+        res[f"wgrad_{N}x{K}"] = dict(ms=round(ms, 4), tflops=round(flops / ms / 1e9, 1), splits=splits)
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":
