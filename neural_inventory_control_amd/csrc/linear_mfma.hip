@@ -33,6 +33,7 @@ constexpr int LDA_S = 36;    // padded LDS row (floats) for k-contiguous tiles
 constexpr int kThreads = 256;
 
 enum { EPI_BIAS_ACT = 0, EPI_DGRAD = 1 };
+int gemm_variant();
 
 struct WxParams {
     const float* A;      // [M][lda]
@@ -495,14 +496,18 @@ __global__ __launch_bounds__(kThreads) void gemm_wx_kernel(WxParams p) {
 //   Rows past the matrix end are out of range of the buffer descriptor: the DMA writes zeros, no branches.
 // ---------------------------------------------------------------------------------------------------------------
 template <int WAVES_M, int WAVES_N, int MT, int NT, int EPI>
-__global__ __launch_bounds__(kThreads) void gemm_wx_dma_kernel(WxParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // LDS address-space pointers only exist in the device pass
+    constexpr int NW = WAVES_M * WAVES_N, NTHREADS = 64 * NW;
     constexpr int BM = WAVES_M * MT * 32;
     constexpr int BN = WAVES_N * NT * 32;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int A_FLOATS = BM * BK, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;
     constexpr int LDC = BN + 4;
-    constexpr int LDS_FLOATS = (2 * STAGE > BM * LDC) ? 2 * STAGE : BM * LDC;
+    // epilogue staging: the whole C tile if it fits next to nothing else, otherwise one wave-row (MT*32 rows) per pass
+    constexpr int PASSES = (BM * LDC * 4 <= 72 * 1024) ? 1 : WAVES_M;
+    constexpr int PASS_ROWS = BM / PASSES;
+    constexpr int LDS_FLOATS = (2 * STAGE > PASS_ROWS * LDC) ? 2 * STAGE : PASS_ROWS * LDC;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -516,9 +521,10 @@ __global__ __launch_bounds__(kThreads) void gemm_wx_dma_kernel(WxParams p) {
 
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, (int64_t)p.M * p.lda);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.Bm, (int64_t)p.K * p.ldb);
-    constexpr int A_INSTR = BM / 32;               // 1-KiB DMA instructions per wave for the A tile (8 rows each)
-    constexpr int B_INSTR = BN / 32;               // ... for the B tile (256/BN rows each)
+    constexpr int A_INSTR = BM / 8 / NW;           // 1-KiB DMA instructions per wave for the A tile (8 rows each)
+    constexpr int B_INSTR = BN / 8 / NW;           // ... for the B tile (256/BN rows each)
     constexpr int B_LPR = BN / 4;                  // lanes per B row
+    static_assert(A_INSTR >= 1 && B_INSTR >= 1 && B_LPR <= 64, "tile too small for this wave count");
     int offA[A_INSTR], offB[B_INSTR];
 #pragma unroll
     for (int q = 0; q < A_INSTR; ++q) {
@@ -597,40 +603,48 @@ __global__ __launch_bounds__(kThreads) void gemm_wx_dma_kernel(WxParams p) {
 
     // epilogue: stage the block tile through LDS and write whole rows (see gemm_wx_kernel)
     float* cs = lds;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                cs[((wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + (wn * NT + j) * 32 + li] = acc[i][j][r];
-    __syncthreads();
-    constexpr int TPR = BN / 4, RPI = kThreads / TPR, ITER = BM / RPI;
+    constexpr int TPR = BN / 4, RPI = NTHREADS / TPR, ITER = PASS_ROWS / RPI;
+    static_assert(PASS_ROWS % RPI == 0, "pass rows must divide evenly over the threads");
     const int t = threadIdx.x;
     const int col = c0 + (t % TPR) * 4;
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int row_l = t / TPR + RPI * it;
-        const int row = m0 + row_l;
-        if (row >= p.M || col >= p.ncols) continue;
-        float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (t % TPR) * 4);
-        const int64_t off = (int64_t)row * p.ldb + col;
-        if (EPI == EPI_BIAS_ACT) {
-            const float bias = p.bias ? p.bias[row] : 0.f;
-            y.x += bias; y.y += bias; y.z += bias; y.w += bias;
-            if (p.act == NIC_ACT_ELU) { y.x = elu_f(y.x); y.y = elu_f(y.y); y.z = elu_f(y.z); y.w = elu_f(y.w); }
-        } else {
-            if (p.Hprev && p.act == NIC_ACT_ELU) {
-                const float4 hq = *reinterpret_cast<const float4*>(p.Hprev + off);
-                y.x *= elu_grad_from_out(hq.x); y.y *= elu_grad_from_out(hq.y);
-                y.z *= elu_grad_from_out(hq.z); y.w *= elu_grad_from_out(hq.w);
-            }
-            if (p.accumulate) {
-                const float4 o = *reinterpret_cast<const float4*>(p.C + off);
-                y.x += o.x; y.y += o.y; y.z += o.z; y.w += o.w;
-            }
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (PASSES == 1 || wm == pass) {
+            const int wrow = (PASSES == 1) ? wm * MT * 32 : 0;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        cs[(wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + (wn * NT + j) * 32 + li] = acc[i][j][r];
         }
-        *reinterpret_cast<float4*>(p.C + off) = y;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int row_l = t / TPR + RPI * it;
+            const int row = m0 + pass * PASS_ROWS + row_l;
+            if (row >= p.M || col >= p.ncols) continue;
+            float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (t % TPR) * 4);
+            const int64_t off = (int64_t)row * p.ldb + col;
+            if (EPI == EPI_BIAS_ACT) {
+                const float bias = p.bias ? p.bias[row] : 0.f;
+                y.x += bias; y.y += bias; y.z += bias; y.w += bias;
+                if (p.act == NIC_ACT_ELU) { y.x = elu_f(y.x); y.y = elu_f(y.y); y.z = elu_f(y.z); y.w = elu_f(y.w); }
+            } else {
+                if (p.Hprev && p.act == NIC_ACT_ELU) {
+                    const float4 hq = *reinterpret_cast<const float4*>(p.Hprev + off);
+                    y.x *= elu_grad_from_out(hq.x); y.y *= elu_grad_from_out(hq.y);
+                    y.z *= elu_grad_from_out(hq.z); y.w *= elu_grad_from_out(hq.w);
+                }
+                if (p.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(p.C + off);
+                    y.x += o.x; y.y += o.y; y.z += o.z; y.w += o.w;
+                }
+            }
+            *reinterpret_cast<float4*>(p.C + off) = y;
+        }
+        if (pass + 1 < PASSES) __syncthreads();
     }
 #endif
 }
@@ -764,6 +778,183 @@ __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad kernel, LDS-DMA form: both operands are row tiles with the contraction index (scenario) contiguous, so both use
+// the swizzled 1-KiB DMA of the wx kernel's A tile.  Output tile BM x BN of dW for one scenario chunk (split); the tile is
+// ADDED to the split's slab through the LDS-staged epilogue (whole-row float4 read-add-write).  The bias gradient needs
+// no virtual row of ones here: the waves of the first column tile sum the dY fragments they read anyway.
+// Requires n_scenarios % 32 == 0 (no partial k tiles) — the launcher falls back to gemm_wgrad_kernel otherwise.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int MT, int NT>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(WgParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WAVES_M * WAVES_N, NTHREADS = 64 * NW;
+    constexpr int BM = WAVES_M * MT * 32;
+    constexpr int BN = WAVES_N * NT * 32;
+    constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;
+    constexpr int LDC = BN + 4;
+    constexpr int PASSES = (BM * LDC * 4 <= 72 * 1024) ? 1 : WAVES_M;
+    constexpr int PASS_ROWS = BM / PASSES;
+    constexpr int LDS_FLOATS = (2 * STAGE > PASS_ROWS * LDC) ? 2 * STAGE : PASS_ROWS * LDC;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tiles_k = (p.K + BN - 1) / BN, tiles_n = (p.N + BM - 1) / BM;
+    const int lid = blockIdx.x;
+    const int k0 = (lid % tiles_k) * BN;              // output cols (features of X)
+    const int n0 = ((lid / tiles_k) % tiles_n) * BM;  // output rows (features of dY)
+    const int split = lid / (tiles_k * tiles_n);
+    const int b_begin = split * p.chunk;
+    const int b_end = min(b_begin + p.chunk, p.nB);
+    const int nt = (b_end - b_begin) / BK;            // whole tiles only (nB % 32 == 0)
+    if (nt <= 0) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, h = lane >> 5;
+    float* slab = p.slab + (int64_t)split * p.N * p.lds_;
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.dY, (int64_t)p.N * p.ldb);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.X, (int64_t)p.K * p.ldb);
+    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+    int offA[A_INSTR], offB[B_INSTR];
+#pragma unroll
+    for (int q = 0; q < A_INSTR; ++q) {
+        const int row = (wave * A_INSTR + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        offA[q] = (int)((((int64_t)n0 + row) * p.ldb + b_begin + chunk * 4) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < B_INSTR; ++q) {
+        const int row = (wave * B_INSTR + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        offB[q] = (int)((((int64_t)k0 + row) * p.ldb + b_begin + chunk * 4) * 4);
+    }
+    auto issue = [&](int stage) {
+        float* base = lds + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < A_INSTR; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(base + (wave * A_INSTR + q) * 256), 16, offA[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < B_INSTR; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(base + A_FLOATS + (wave * B_INSTR + q) * 256), 16,
+                                                     offB[q], 0, 0, 0);
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int q = 0; q < A_INSTR; ++q) offA[q] += BK * 4;
+#pragma unroll
+        for (int q = 0; q < B_INSTR; ++q) offB[q] += BK * 4;
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float rowsum[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rowsum[i] = 0.f;
+    const bool bias_owner = (k0 == 0) && (wn == 0);  // these waves also produce the bias-gradient column
+
+    const int sw = (li >> 1) & 7;
+    issue(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            advance();
+            issue(cur ^ 1);
+        }
+        const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * BK;
+        const float* b_base = lds + cur * STAGE + A_FLOATS + (wn * NT * 32 + li) * BK;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float a[MT][8], b[NT][8];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float4 lo = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
+                const float4 hi = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
+                a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
+                a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float4 lo = *reinterpret_cast<const float4*>(b_base + j * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
+                const float4 hi = *reinterpret_cast<const float4*>(b_base + j * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
+                b[j][0] = lo.x; b[j][1] = lo.y; b[j][2] = lo.z; b[j][3] = lo.w;
+                b[j][4] = hi.x; b[j][5] = hi.y; b[j][6] = hi.z; b[j][7] = hi.w;
+            }
+            if (bias_owner) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) rowsum[i] += a[i][kk];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // bias gradient: lanes l and l+32 hold the two k halves of row (wm*MT + i)*32 + li
+    if (bias_owner) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const float s = rowsum[i] + __shfl_xor(rowsum[i], 32);
+            const int row = n0 + (wm * MT + i) * 32 + li;
+            if (h == 0 && row < p.N) slab[(int64_t)row * p.lds_ + p.K] += s;
+        }
+    }
+
+    // slab += tile, staged through LDS (whole-row float4 read-add-write)
+    float* cs = lds;
+    constexpr int TPR = BN / 4, RPI = NTHREADS / TPR, ITER = PASS_ROWS / RPI;
+    const int tt = threadIdx.x;
+    const int col = k0 + (tt % TPR) * 4;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (PASSES == 1 || wm == pass) {
+            const int wrow = (PASSES == 1) ? wm * MT * 32 : 0;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        cs[(wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + (wn * NT + j) * 32 + li] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int row_l = tt / TPR + RPI * it;
+            const int row = n0 + pass * PASS_ROWS + row_l;
+            if (row >= p.N || col >= p.K) continue;
+            const float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (tt % TPR) * 4);
+            float* dst = slab + (int64_t)row * p.lds_ + col;
+            if (col + 3 < p.K && (p.lds_ & 3) == 0) {
+                float4 o = *reinterpret_cast<const float4*>(dst);
+                o.x += y.x; o.y += y.y; o.z += y.z; o.w += y.w;
+                *reinterpret_cast<float4*>(dst) = o;
+            } else {
+                dst[0] += y.x;
+                if (col + 1 < p.K) dst[1] += y.y;
+                if (col + 2 < p.K) dst[2] += y.z;
+                if (col + 3 < p.K) dst[3] += y.w;
+            }
+        }
+        if (pass + 1 < PASSES) __syncthreads();
+    }
+#endif
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int64_t lds_, int n_splits, float* __restrict__ dW,
                                     int64_t lddw, float* __restrict__ db, int N, int K, float scale) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -784,18 +975,17 @@ bool wx_fast_ok(const WxParams& p) {
            (int64_t)p.K * p.ldb < (1ll << 28);
 }
 
-int gemm_variant();
+template <int WM, int WN, int MT, int NT, int EPI>
+void launch_wx_dma(const WxParams& p, hipStream_t s) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.ncols + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_wx_dma_kernel<WM, WN, MT, NT, EPI>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), 0, s, p);
+}
 
 template <int WM, int WN, int MT, int NT, int EPI, int BPRE>
 void launch_wx(const WxParams& p, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.ncols + BN - 1) / BN;
-    if constexpr (BN >= 128 && BM * (BN + 4) * 4 <= 80 * 1024) {
-        if (wx_fast_ok(p) && gemm_variant() != 10) {
-            hipLaunchKernelGGL((gemm_wx_dma_kernel<WM, WN, MT, NT, EPI>), dim3(tiles_m * tiles_n), dim3(kThreads), 0, s, p);
-            return;
-        }
-    }
     if (wx_fast_ok(p))
         hipLaunchKernelGGL((gemm_wx_kernel<WM, WN, MT, NT, EPI, BPRE, 1>), dim3(tiles_m * tiles_n), dim3(kThreads), 0, s, p);
     else
@@ -835,15 +1025,20 @@ int gemm_variant() {
 template <int EPI>
 void dispatch_wx(const WxParams& p, hipStream_t s) {
     const int v = gemm_variant();
+    if (wx_fast_ok(p) && v < 10) {
+        // production path: LDS-DMA kernels.  256 x 256 CU-level tiles (8 waves) halve the bytes each CU has to ingest per
+        // flop relative to two co-resident 128 x 128 workgroups; they need >= 256 tiles to fill the chip.
+        const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.ncols + 255) / 256);
+        if (p.M > 128 && tiles256 >= 200 && v != 1) launch_wx_dma<2, 4, 4, 2, EPI>(p, s);   // 256 x 256
+        else if (p.M > 64) launch_wx_dma<2, 2, 2, 2, EPI>(p, s);                              // 128 x 128
+        else if (p.M > 32) launch_wx_dma<1, 4, 2, 1, EPI>(p, s);                              //  64 x 128
+        else launch_wx_dma<1, 4, 1, 2, EPI>(p, s);                                            //  32 x 256
+        return;
+    }
+    // register-staged kernels: unaligned operands (guarded loaders) and the tuning / ablation variants
     if (p.M > 64) {
-        if (v == 1) launch_wx<2, 2, 2, 2, EPI, 0>(p, s);        // 128 x 128, B fragments loaded per k step
-        else if (v == 2) launch_wx<2, 2, 2, 4, EPI, 1>(p, s);   // 128 x 256
-        else if (v == 3) launch_wx<2, 2, 4, 2, EPI, 1>(p, s);   // 256 x 128
-        else if (v == 4) launch_wx<4, 1, 1, 4, EPI, 1>(p, s);   // 128 x 128, waves stacked along M (each 32 x 128)
-        else if (v == 5) launch_wx<1, 4, 4, 1, EPI, 1>(p, s);   // 128 x 128, waves side by side along N (each 128 x 32)
-        else if (v == 6) launch_wx<2, 2, 2, 2, EPI, 2>(p, s);   // 128 x 128 with the pinned DS/MFMA interleave
-        else if (v == 7) launch_wx<2, 2, 2, 4, EPI, 2>(p, s);   // 128 x 256 pinned
-        else if (v == 8) launch_wx<2, 2, 4, 2, EPI, 2>(p, s);   // 256 x 128 pinned
+        if (v == 11) launch_wx<2, 2, 2, 2, EPI, 0>(p, s);       // B fragments loaded per k step
+        else if (v == 12) launch_wx<2, 2, 2, 2, EPI, 2>(p, s);  // pinned DS/MFMA interleave
         else if (v >= 20 && v < 400) launch_wx_dbg<EPI>(p, s, v - 20);  // timing experiments (results may be WRONG)
         else launch_wx<2, 2, 2, 2, EPI, 1>(p, s);               // 128 x 128
     } else if (p.M > 32) launch_wx<1, 4, 2, 1, EPI, 1>(p, s);   //  64 x 128
@@ -866,6 +1061,16 @@ void wgrad_tile(int N, int K, int* bm, int* bn) {
     if (N > 64) { *bm = 128; *bn = (K + 1 > 64) ? 128 : 64; }
     else if (N > 32) { *bm = 64; *bn = 128; }
     else { *bm = 32; *bn = 256; }
+}
+
+// big layers: 256 x 256 LDS-DMA tiles, one workgroup per CU
+bool wgrad_big(int N, int K) { return N >= 192 && K >= 192; }
+
+template <int WM, int WN, int MT, int NT>
+void launch_wg_dma(const WgParams& p, int n_splits, hipStream_t s) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    dim3 grid(((p.K + BN - 1) / BN) * ((p.N + BM - 1) / BM) * n_splits);
+    hipLaunchKernelGGL((gemm_wgrad_dma_kernel<WM, WN, MT, NT>), grid, dim3(64 * WM * WN), 0, s, p);
 }
 
 int require_ld(const char* who, int32_t n_scenarios, int32_t ldb) {
@@ -908,8 +1113,13 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
     if (N <= 0 || K <= 0 || n_scenarios <= 0) return 0;
     int bm, bn;
     wgrad_tile(N, K, &bm, &bn);
-    const int tiles = ((N + bm - 1) / bm) * ((K + 1 + bn - 1) / bn);
-    int splits = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in total
+    int tiles = ((N + bm - 1) / bm) * ((K + 1 + bn - 1) / bn);
+    int target = 1024;                                 // ~4 workgroups per CU in total
+    if (wgrad_big(N, K)) {                             // 256 x 256 tiles, one workgroup per CU, one round
+        tiles = ((N + 255) / 256) * ((K + 255) / 256);
+        target = 256;
+    }
+    int splits = (target + tiles - 1) / tiles;
     const int max_splits = (n_scenarios + 255) / 256;  // at least 256 scenarios (8 k-tiles) per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -928,7 +1138,11 @@ int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds_,
     hipStream_t s = nic::as_stream(stream);
     int bm, bn;
     wgrad_tile(N, K, &bm, &bn);
-    if (bm == 128 && bn == 128) launch_wg<2, 2, 2, 2>(p, n_splits, s);
+    const bool dma_ok = ldb % 4 == 0 && n_scenarios % BK == 0 && lds_ % 4 == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 &&
+                        (int64_t)N * ldb < (1ll << 28) && (int64_t)K * ldb < (1ll << 28);
+    if (wgrad_big(N, K) && dma_ok && gemm_variant() != 2) launch_wg_dma<2, 4, 4, 2>(p, n_splits, s);
+    else if (bm == 128 && bn == 128) launch_wg<2, 2, 2, 2>(p, n_splits, s);
     else if (bm == 128) launch_wg<2, 2, 2, 1>(p, n_splits, s);
     else if (bm == 64) launch_wg<1, 4, 2, 1>(p, n_splits, s);
     else launch_wg<1, 4, 1, 2>(p, n_splits, s);
