@@ -43,6 +43,21 @@ def build_case(workload, device, rank, scenarios=None, periods=None):
     return setting, policy, sc, data, model, eng, n, T, desc
 
 
+def _pmc_traffic(kind, N, K, n_scenarios):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_traffic.json):
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH doubled (gfx950 reports half of a wide coalesced
+    read stream), both x1024 (KiB units).  None if no pass matches this kernel / shape."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            for e in json.load(open(f)):
+                if e["kind"] == kind and e["N"] == N and e["K"] == K and e["n_scenarios"] == n_scenarios:
+                    return {"bytes_per_launch": e["hbm_bytes_per_launch"], "source": os.path.basename(f)}
+        except Exception:
+            pass
+    return None
+
+
 def _pick_threads(avail):
     import torch.nn.functional as F
     x, w = torch.randn(4096, 512), torch.randn(512, 512)
@@ -180,11 +195,15 @@ def main():
                 out["roofline"] = {
                     "bound": "mfma", "achieved": gemm[dom]["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": gemm[dom]["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                    "kernel": {"fwd": "gemm_wx_kernel<2,2,2,2,EPI_BIAS_ACT>", "dgrad": "gemm_wx_kernel<2,2,2,2,EPI_DGRAD>",
-                               "wgrad": "gemm_wgrad_kernel<2,2,2,2>"}.get(kind, kind) + f" ({dom})",
+                    "kernel": {"fwd": "gemm_wx_dma_kernel<2,4,4,2,EPI_BIAS_ACT>", "dgrad": "gemm_wx_dma_kernel<2,4,4,2,EPI_DGRAD>",
+                               "wgrad": "gemm_wgrad_dma_kernel<2,4,4,2>"}.get(kind, kind) + f" ({dom})",
                     "algorithmic_flops_per_launch": 2.0 * N_ * K_ * n, "mean_launch_ms": gemm[dom]["mean_ms"],
                     "launches_timed": gemm[dom]["launches"],
                 }
+                tr = _pmc_traffic(kind, N_, K_, n)
+                if tr is not None:
+                    out["roofline"]["traffic"] = tr["bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = tr["source"]
                 out["kernels"] = {k: {kk: round(vv, 5) if isinstance(vv, float) else vv for kk, vv in v.items()}
                                   for k, v in sorted(gemm.items())}
                 for tag in ("env_fwd", "env_bwd"):

@@ -32,10 +32,12 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
     if world > 1 and not initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or os.environ.get("NIC_DIST_BACKEND")  # e.g. gloo: two ranks sharing ONE GPU in tests
         if backend is None:
             backend = "nccl" if use_cuda else "gloo"
         kwargs = {}
