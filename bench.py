@@ -31,6 +31,8 @@ def build_case(workload, device, rank, scenarios=None, periods=None):
     from neural_inventory_control_amd.neural_networks import NeuralNetworkCreator
     from neural_inventory_control_amd.rollout import FusedRollout
     setting, policy, n, T, desc = workloads.get(workload)
+    if scenarios or periods:
+        desc += f" [overridden: {scenarios or n} scenarios/GPU x T={periods or T}]"
     n, T = scenarios or n, periods or T
     obs = defaultdict(lambda: None, setting["observation_params"])
     sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"],

@@ -658,6 +658,7 @@ struct WgParams {
     float* slab;      // [n_splits][N][lds]
     int64_t lds_, ldb;
     int N, K, nB, chunk;  // chunk = scenarios per split (multiple of 32)
+    int swz;              // XCD-aware tile order (DMA kernel)
 };
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, int FAST>
@@ -800,7 +801,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     const int tiles_k = (p.K + BN - 1) / BN, tiles_n = (p.N + BM - 1) / BM;
-    const int lid = blockIdx.x;
+    // the output tiles of one scenario chunk read the same dY / X rows: keep them on one XCD (shared L2)
+    const int lid = p.swz ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int k0 = (lid % tiles_k) * BN;              // output cols (features of X)
     const int n0 = ((lid / tiles_k) % tiles_n) * BM;  // output rows (features of dY)
     const int split = lid / (tiles_k * tiles_n);
@@ -1134,7 +1136,7 @@ int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds_,
     if (int e = require_ld("nic_linear_wgrad", n_scenarios, ldb)) return e;
     int chunk = (n_scenarios + n_splits - 1) / n_splits;
     chunk = (chunk + BK - 1) / BK * BK;
-    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk};
+    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1};
     hipStream_t s = nic::as_stream(stream);
     int bm, bn;
     wgrad_tile(N, K, &bm, &bn);

@@ -24,6 +24,6 @@ for k, c in res.items():
         entries.append({"kernel": k, "kind": kinds[k], "N": 512, "K": 512, "n_scenarios": B, "FETCH_SIZE_KiB": c["FETCH_SIZE"],
                         "WRITE_SIZE_KiB": c["WRITE_SIZE"], "hbm_bytes_per_launch": hbm,
                         "algorithmic_bytes": {"fwd": 4.0 * (512 * 512 + 2 * 512 * B), "dgrad": 4.0 * (512 * 512 + 3 * 512 * B),
-                                              "wgrad": 4.0 * (2 * 512 * B)}[kinds[k]]})
+                                              "wgrad": 4.0 * (2 * 512 * B) + 2 * 4.0 * 64 * 512 * 516}[kinds[k]]})  # wgrad: + slab read/write (64 splits)
 json.dump(entries, open(out, "w"), indent=1)
 print(json.dumps(entries, indent=1))
