@@ -10,16 +10,22 @@
 // C/D tile (col = lane&31) are read / written as contiguous 128-byte scenario runs, i.e. coalesced with no
 // transposition anywhere between the env-step kernels and the GEMMs.
 //
-// Tiling (256 threads = 4 waves): block tile BM x BN x 32, wave tile (MT*32) x (NT*32) of 32x32x2 MFMAs.
-//   A tile  : LDS [BM][36]  (rows padded by 4 floats: ds_read_b128 of 16 rows then hits 16 distinct bank quads)
-//   B tile  : LDS [32][BN]  for the wx kernel (ds_read_b32: each 32-lane half reads one contiguous row segment)
-//             LDS [BN][36]  for the wgrad kernel (same shape as A: the contraction index is the contiguous one)
+// Production kernels (16-byte aligned operands — everything the rollout engine allocates):
+//   gemm_wx_dma_kernel     forward + dgrad, 256 x 256 x 32 block tile, 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA tiles
+//   gemm_wgrad_dma_kernel  weight gradient, 256 x 256 output tile per scenario chunk, same wave layout
+//   both: tiles go HBM/L2 -> LDS by `buffer_load_dwordx4 ... lds` (no VGPR round trip), double-buffered, one barrier per
+//   k tile; A-style tiles [rows][32] are unpadded with a 16-byte-chunk XOR swizzle applied on the DMA source address
+//   and on the ds_read_b128 fragment reads; the [32][BN] B tile of the wx kernel is linear (ds_read_b32 rows);
+//   epilogues are staged through the dead LDS tiles and leave as whole-row float4 accesses; logical tile order is
+//   XCD-aware.  Smaller shapes (thin first / last layers) use 128x128 / 64x128 / 32x256 instantiations.
 //   k order : within a 16-deep k group, MFMA step kk consumes k = kk (lanes 0-31) and k = 8+kk (lanes 32-63), so a
 //             lane's eight A values of a group are CONTIGUOUS in LDS (two ds_read_b128) — summation order over k is
 //             free because parity is defined to 1e-5, not bitwise, for the policy GEMMs.
-//   pipeline: register-staged double buffering — global loads of tile t+1 are issued before the MFMAs of tile t and
-//             written to the other LDS buffer after them; one barrier per k tile.
-// Roofline: MFMA-bound (2*N*K flops per scenario per layer; 128x128x32 tiles read 32 flop/byte from L2).
+// Fallback kernels (gemm_wx_kernel, gemm_wgrad_kernel): register-staged, per-element guards, for unaligned operands,
+// scenario counts that are not a multiple of 32, and the thin layers of the weight gradient.
+// Roofline: MFMA-bound.  Measured on MI355X (512 x 512 x 65,536): 102-114 TFLOP/s; MFMA pipe 70 % busy at a 2.26 GHz
+// sustained clock (profiles/r01_gemm_pmc_dma256.txt); the remainder is the per-tile DMA wait + barrier (a no-DMA timing
+// build runs 117 TFLOP/s) and the unoverlapped prologue / epilogue of a 1-workgroup-per-CU kernel.
 #include <stdlib.h>
 
 #include "nic_common.h"
@@ -46,6 +52,7 @@ struct WxParams {
     int64_t ldb;
     int act;             // NIC_ACT_*
     int accumulate;      // EPI_DGRAD: C += result
+    int dbg;             // timing experiments only (0 in production)
 };
 
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
@@ -175,36 +182,6 @@ struct KTileBuf {
     }
 };
 
-template <int COLS>
-struct CTileBuf {
-    static constexpr int TPR = COLS / 4;
-    static constexpr int RPI = kThreads / TPR;
-    static constexpr int N4 = BK / RPI;
-    float4 v[N4];
-    int off[N4];
-    int step;
-    __device__ __forceinline__ void init(int64_t ld, int c0) {
-        const int t = threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < N4; ++i) off[i] = (int)((((int64_t)(t / TPR) + RPI * i) * ld + c0 + (t % TPR) * 4) * 4);
-        step = (int)(ld * BK * 4);
-    }
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc) {
-#pragma unroll
-        for (int i = 0; i < N4; ++i) v[i] = buf_load4(rsrc, off[i]);
-    }
-    __device__ __forceinline__ void advance(int tiles = 1) {
-#pragma unroll
-        for (int i = 0; i < N4; ++i) off[i] += tiles * step;
-    }
-    __device__ __forceinline__ void store(float* lds) const {
-        const int t = threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < N4; ++i)
-            *reinterpret_cast<float4*>(lds + (t / TPR + RPI * i) * COLS + (t % TPR) * 4) = v[i];
-    }
-};
-
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private L2).  Remap the linear workgroup id so that every
 // XCD gets a CONTIGUOUS range of logical tiles: the tiles that share an operand panel (the row tiles of one scenario
 // panel in the wx kernel, the 16 output tiles of one scenario chunk in the wgrad kernel) then run on one XCD at about
@@ -223,9 +200,11 @@ __device__ __forceinline__ void read_frag8(const float* lds_row, int g, int h, f
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// wx kernel: C[M][ncols] = epilogue( A[M][K] * Bm[K][ncols] )
+// wx kernel, guarded form: C[M][ncols] = epilogue( A[M][K] * Bm[K][ncols] ) for operands that are NOT 16-byte aligned /
+// row-padded (e.g. an unpadded [N][51] weight handed over by HipLinear).  Register-staged double buffering with
+// per-element guards; correctness path, not the performance path (aligned operands use gemm_wx_dma_kernel below).
 // ---------------------------------------------------------------------------------------------------------------
-template <int WAVES_M, int WAVES_N, int MT, int NT, int EPI, int BPRE, int FAST, int DBG = 0>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int EPI>
 __global__ __launch_bounds__(kThreads) void gemm_wx_kernel(WxParams p) {
     constexpr int BM = WAVES_M * MT * 32;
     constexpr int BN = WAVES_N * NT * 32;
@@ -233,22 +212,13 @@ __global__ __launch_bounds__(kThreads) void gemm_wx_kernel(WxParams p) {
     constexpr int STAGE = BM * LDA_S + BK * BN;  // floats per pipeline stage: A tile then B tile
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
-    // row tiles vary fastest so that the workgroups sharing one column panel of Bm are dispatched back to back
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int tile = (DBG & 32) ? (int)blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
-    const int m0 = (tile % tiles_m) * BM;
-    const int c0 = (tile / tiles_m) * BN;
-
+    const int m0 = (blockIdx.x % tiles_m) * BM;
+    const int c0 = (blockIdx.x / tiles_m) * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, h = lane >> 5;
     const bool vecA = (p.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
-    if constexpr (DBG & 4) {
-        // two co-resident workgroups otherwise run in lockstep (same program, same start): both reach the per-tile
-        // load/barrier bubble together and the matrix pipe idles.  Delay the odd wave slots by half a tile period.
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // HW_REG_HW_ID.wave_id bit 0
-        if (slot) __builtin_amdgcn_s_sleep(78);
-    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -261,27 +231,17 @@ __global__ __launch_bounds__(kThreads) void gemm_wx_kernel(WxParams p) {
     const int nk = (p.K + BK - 1) / BK;
     KTile<BM> ta;
     CTile<BN> tb;
-    KTileBuf<BM> fa;
-    CTileBuf<BN> fb;
-    __amdgpu_buffer_rsrc_t ra, rb;
-    if constexpr (FAST) {
-        ra = make_rsrc(p.A, (int64_t)p.M * p.lda);
-        rb = make_rsrc(p.Bm, (int64_t)p.K * p.ldb);
-        fa.init(p.lda, m0, 0);
-        fb.init(p.ldb, c0);
-        fa.load(ra);
-        fb.load(rb);
-        fa.store(lds);
-        fb.store(lds + BM * LDA_S);
-    } else {
-        ta.load(p.A, p.lda, m0, p.M, 0, p.K, vecA);
-        tb.load(p.Bm, p.ldb, 0, p.K, c0, p.ncols);
-        ta.store(lds);
-        tb.store(lds + BM * LDA_S);
-    }
+    ta.load(p.A, p.lda, m0, p.M, 0, p.K, vecA);
+    tb.load(p.Bm, p.ldb, 0, p.K, c0, p.ncols);
+    ta.store(lds);
+    tb.store(lds + BM * LDA_S);
     __syncthreads();
-
-    auto compute = [&](int cur) {
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            ta.load(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, vecA);
+            tb.load(p.Bm, p.ldb, (kt + 1) * BK, p.K, c0, p.ncols);
+        }
         const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * LDA_S;
         const float* b_base = lds + cur * STAGE + BM * LDA_S + wn * NT * 32 + li;
 #pragma unroll
@@ -289,175 +249,26 @@ __global__ __launch_bounds__(kThreads) void gemm_wx_kernel(WxParams p) {
             float a[MT][8];
 #pragma unroll
             for (int i = 0; i < MT; ++i) read_frag8(a_base + i * 32 * LDA_S, g, h, a[i]);
-            if constexpr (BPRE) {
-                // all B fragments of the k group are in flight before the first MFMA: the 8*MT*NT MFMAs that follow
-                // (64 cycles each) cover the LDS latency of the next group's reads
-                float b[NT][8];
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
+            for (int kk = 0; kk < 8; ++kk) {
+                float b[NT];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) b[j][kk] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
+                for (int j = 0; j < NT; ++j) b[j] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
-                if constexpr (BPRE == 2) {
-                    // pin the interleave hipcc otherwise collapses to {ds_read, s_waitcnt lgkmcnt(0), MFMAs}: LDS reads run
-                    // two k steps ahead of the MFMAs that consume them, so their latency hides under 2 x MT*NT MFMAs
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-                    for (int st = 0; st < 7; ++st) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
-                }
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    float b[NT];
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) b[j] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j], acc[i][j], 0, 0, 0);
-                }
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j], acc[i][j], 0, 0, 0);
             }
         }
-    };
-
-    if constexpr (FAST && (DBG & 64)) {
-        // two tiles of global loads in flight: tile t+2 is requested before tile t is computed and lands in LDS one
-        // iteration later, so the vmcnt wait in front of the LDS writes has a full tile of slack
-        KTileBuf<BM> fa1 = fa;
-        CTileBuf<BN> fb1 = fb;
-        fa1.advance();
-        fb1.advance();
-        if (nk > 1) {
-            fa1.load(ra);
-            fb1.load(rb);
+        if (kt + 1 < nk) {
+            ta.store(lds + (cur ^ 1) * STAGE);
+            tb.store(lds + (cur ^ 1) * STAGE + BM * LDA_S);
         }
-        for (int kt = 0; kt < nk; kt += 2) {
-            if (kt + 2 < nk) {
-                fa.advance(2);
-                fb.advance(2);
-                fa.load(ra);
-                fb.load(rb);
-            }
-            compute(0);
-            if (kt + 1 < nk) {
-                fa1.store(lds + STAGE);
-                fb1.store(lds + STAGE + BM * LDA_S);
-            }
-            __syncthreads();
-            if (kt + 1 >= nk) break;
-            if (kt + 3 < nk) {
-                fa1.advance(2);
-                fb1.advance(2);
-                fa1.load(ra);
-                fb1.load(rb);
-            }
-            compute(1);
-            if (kt + 2 < nk) {
-                fa.store(lds);
-                fb.store(lds + BM * LDA_S);
-            }
-            __syncthreads();
-        }
-    } else {
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if ((kt + 1 < nk) && !(DBG & 1)) {
-                if constexpr (FAST) {
-                    if constexpr (!(DBG & 128)) {
-                        fa.advance();
-                        fb.advance();
-                        fa.load(ra);
-                        fb.load(rb);
-                    }
-                } else {
-                    ta.load(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, vecA);
-                    tb.load(p.Bm, p.ldb, (kt + 1) * BK, p.K, c0, p.ncols);
-                }
-            }
-            compute(cur);
-            if ((kt + 1 < nk) && !(DBG & 1)) {
-                if constexpr (FAST) {
-                    if constexpr (DBG & 256) {  // timing-only: loads without the LDS writes
-#pragma unroll
-                        for (int q = 0; q < KTileBuf<BM>::N4; ++q) asm volatile("" ::"v"(fa.v[q].x), "v"(fa.v[q].w));
-#pragma unroll
-                        for (int q = 0; q < CTileBuf<BN>::N4; ++q) asm volatile("" ::"v"(fb.v[q].x), "v"(fb.v[q].w));
-                    } else {
-                        fa.store(lds + (cur ^ 1) * STAGE);
-                        fb.store(lds + (cur ^ 1) * STAGE + BM * LDA_S);
-                    }
-                } else {
-                    ta.store(lds + (cur ^ 1) * STAGE);
-                    tb.store(lds + (cur ^ 1) * STAGE + BM * LDA_S);
-                }
-            }
-            if constexpr (!(DBG & 2)) __syncthreads();
-        }
-    }
-    if constexpr (DBG & 8) {  // timing-only: drop the epilogue but keep the accumulators alive
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
-
-    // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if constexpr (FAST && !(DBG & 16) && (BM * (BN + 4) <= 2 * STAGE)) {
-        // A lane owns ONE scenario column of each 32x32 tile, so storing straight from the accumulators costs 16*MT*NT
-        // four-byte store instructions per wave (store-issue bound).  Stage the block tile through the (now dead)
-        // LDS tiles instead and write it out as whole rows: 16 B per lane, 512 contiguous bytes per 32 lanes, a
-        // quarter of the store instructions; the dgrad's Hprev / accumulate reads become float4 loads the same way.
-        constexpr int LDC = BN + 4;
-        float* cs = lds;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    cs[((wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + (wn * NT + j) * 32 + li] = acc[i][j][r];
         __syncthreads();
-        constexpr int TPR = BN / 4, RPI = kThreads / TPR, ITER = BM / RPI;
-        const int t = threadIdx.x;
-        const int col = c0 + (t % TPR) * 4;
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int row_l = t / TPR + RPI * it;
-            const int row = m0 + row_l;
-            if (row >= p.M || col >= p.ncols) continue;
-            float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (t % TPR) * 4);
-            const int64_t off = (int64_t)row * p.ldb + col;
-            if (EPI == EPI_BIAS_ACT) {
-                const float bias = p.bias ? p.bias[row] : 0.f;
-                y.x += bias; y.y += bias; y.z += bias; y.w += bias;
-                if (p.act == NIC_ACT_ELU) { y.x = elu_f(y.x); y.y = elu_f(y.y); y.z = elu_f(y.z); y.w = elu_f(y.w); }
-            } else {
-                if (p.Hprev && p.act == NIC_ACT_ELU) {
-                    const float4 hq = *reinterpret_cast<const float4*>(p.Hprev + off);
-                    y.x *= elu_grad_from_out(hq.x); y.y *= elu_grad_from_out(hq.y);
-                    y.z *= elu_grad_from_out(hq.z); y.w *= elu_grad_from_out(hq.w);
-                }
-                if (p.accumulate) {
-                    const float4 o = *reinterpret_cast<const float4*>(p.C + off);
-                    y.x += o.x; y.y += o.y; y.z += o.z; y.w += o.w;
-                }
-            }
-            *reinterpret_cast<float4*>(p.C + off) = y;
-        }
-        return;
     }
+
+    // epilogue straight from the accumulators: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -570,7 +381,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     __syncthreads();  // hipcc drains the DMA (vmcnt(0)) in front of the barrier
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
+        if (kt + 1 < nk && !(p.dbg & 1)) {
             advance();
             issue(cur ^ 1);
         }
@@ -984,37 +795,15 @@ void launch_wx_dma(const WxParams& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_wx_dma_kernel<WM, WN, MT, NT, EPI>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), 0, s, p);
 }
 
-template <int WM, int WN, int MT, int NT, int EPI, int BPRE>
+template <int WM, int WN, int MT, int NT, int EPI>
 void launch_wx(const WxParams& p, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.ncols + BN - 1) / BN;
-    if (wx_fast_ok(p))
-        hipLaunchKernelGGL((gemm_wx_kernel<WM, WN, MT, NT, EPI, BPRE, 1>), dim3(tiles_m * tiles_n), dim3(kThreads), 0, s, p);
-    else
-        hipLaunchKernelGGL((gemm_wx_kernel<WM, WN, MT, NT, EPI, BPRE, 0>), dim3(tiles_m * tiles_n), dim3(kThreads), 0, s, p);
+    hipLaunchKernelGGL((gemm_wx_kernel<WM, WN, MT, NT, EPI>), dim3(tiles_m * tiles_n), dim3(kThreads), 0, s, p);
 }
 
-template <int EPI, int DBG>
-void launch_wx_dbg1(const WxParams& p, hipStream_t s) {
-    const int tiles = ((p.M + 127) / 128) * ((p.ncols + 127) / 128);
-    hipLaunchKernelGGL((gemm_wx_kernel<2, 2, 2, 2, EPI, 1, 1, DBG>), dim3(tiles), dim3(kThreads), 0, s, p);
-}
-template <int EPI>
-void launch_wx_dbg(const WxParams& p, hipStream_t s, int dbg) {
-    switch (dbg) {
-        case 1: launch_wx_dbg1<EPI, 1>(p, s); break;    // no loads in the loop
-        case 3: launch_wx_dbg1<EPI, 3>(p, s); break;    // no loads, no barrier
-        case 4: launch_wx_dbg1<EPI, 4>(p, s); break;    // stagger
-        case 16: launch_wx_dbg1<EPI, 16>(p, s); break;  // direct (un-staged) epilogue
-        case 32: launch_wx_dbg1<EPI, 32>(p, s); break;  // no XCD swizzle
-        case 64: launch_wx_dbg1<EPI, 64>(p, s); break;  // two tiles of loads in flight
-        case 128: launch_wx_dbg1<EPI, 128>(p, s); break;  // LDS writes without the global loads (timing only)
-        case 256: launch_wx_dbg1<EPI, 256>(p, s); break;  // global loads without the LDS writes (timing only)
-        default: launch_wx_dbg1<EPI, 0>(p, s); break;
-    }
-}
-
-// NIC_GEMM_VARIANT (debug/tuning only): 0 = default choice below
+// NIC_GEMM_VARIANT (tuning / A-B only): 1 = 128 x 128 tiles for the big layers, 2 = register-staged wgrad,
+// 3 = wgrad without the XCD tile order, 4 = TIMING ONLY: no DMA inside the k loop (results are wrong)
 int gemm_variant() {
     static int v = -1;
     if (v < 0) {
@@ -1026,25 +815,19 @@ int gemm_variant() {
 
 template <int EPI>
 void dispatch_wx(const WxParams& p, hipStream_t s) {
-    const int v = gemm_variant();
-    if (wx_fast_ok(p) && v < 10) {
+    if (wx_fast_ok(p)) {
         // production path: LDS-DMA kernels.  256 x 256 CU-level tiles (8 waves) halve the bytes each CU has to ingest per
         // flop relative to two co-resident 128 x 128 workgroups; they need >= 256 tiles to fill the chip.
         const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.ncols + 255) / 256);
-        if (p.M > 128 && tiles256 >= 200 && v != 1) launch_wx_dma<2, 4, 4, 2, EPI>(p, s);   // 256 x 256
-        else if (p.M > 64) launch_wx_dma<2, 2, 2, 2, EPI>(p, s);                              // 128 x 128
-        else if (p.M > 32) launch_wx_dma<1, 4, 2, 1, EPI>(p, s);                              //  64 x 128
-        else launch_wx_dma<1, 4, 1, 2, EPI>(p, s);                                            //  32 x 256
+        if (p.M > 128 && tiles256 >= 200 && gemm_variant() != 1) launch_wx_dma<2, 4, 4, 2, EPI>(p, s);   // 256 x 256
+        else if (p.M > 64) launch_wx_dma<2, 2, 2, 2, EPI>(p, s);                                          // 128 x 128
+        else if (p.M > 32) launch_wx_dma<1, 4, 2, 1, EPI>(p, s);                                          //  64 x 128
+        else launch_wx_dma<1, 4, 1, 2, EPI>(p, s);                                                        //  32 x 256
         return;
     }
-    // register-staged kernels: unaligned operands (guarded loaders) and the tuning / ablation variants
-    if (p.M > 64) {
-        if (v == 11) launch_wx<2, 2, 2, 2, EPI, 0>(p, s);       // B fragments loaded per k step
-        else if (v == 12) launch_wx<2, 2, 2, 2, EPI, 2>(p, s);  // pinned DS/MFMA interleave
-        else if (v >= 20 && v < 400) launch_wx_dbg<EPI>(p, s, v - 20);  // timing experiments (results may be WRONG)
-        else launch_wx<2, 2, 2, 2, EPI, 1>(p, s);               // 128 x 128
-    } else if (p.M > 32) launch_wx<1, 4, 2, 1, EPI, 1>(p, s);   //  64 x 128
-    else launch_wx<1, 4, 1, 2, EPI, 1>(p, s);                   //  32 x 256
+    if (p.M > 64) launch_wx<2, 2, 2, 2, EPI>(p, s);        // unaligned operands: guarded register-staged kernels
+    else if (p.M > 32) launch_wx<1, 4, 2, 1, EPI>(p, s);
+    else launch_wx<1, 4, 1, 2, EPI>(p, s);
 }
 
 template <int WM, int WN, int MT, int NT>
@@ -1093,7 +876,7 @@ int nic_linear_fwd(const float* W, int64_t ldw, const float* bias, const float* 
     if (int e = require_ld("nic_linear_fwd", n_scenarios, ldb)) return e;
     NIC_REQUIRE((reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
                 "nic_linear_fwd: X/Y must be 16-byte aligned");
-    WxParams p{W, ldw, X, Y, bias, nullptr, N, K, (n_scenarios + 3) / 4 * 4, ldb, act, 0};
+    WxParams p{W, ldw, X, Y, bias, nullptr, N, K, (n_scenarios + 3) / 4 * 4, ldb, act, 0, gemm_variant() == 4 ? 1 : 0};
     dispatch_wx<EPI_BIAS_ACT>(p, nic::as_stream(stream));
     return nic::check_launch("nic_linear_fwd");
 }
@@ -1106,7 +889,7 @@ int nic_linear_dgrad(const float* Wt, int64_t ldwt, const float* dY, const float
     NIC_REQUIRE((reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(dX) & 15) == 0,
                 "nic_linear_dgrad: dY/dX must be 16-byte aligned");
     // dX[K][b] = Wt[K][N] * dY[N][b]: output rows = K, contraction = N
-    WxParams p{Wt, ldwt, dY, dX, nullptr, Hprev, K, N, (n_scenarios + 3) / 4 * 4, ldb, act_prev, accumulate};
+    WxParams p{Wt, ldwt, dY, dX, nullptr, Hprev, K, N, (n_scenarios + 3) / 4 * 4, ldb, act_prev, accumulate, gemm_variant() == 4 ? 1 : 0};
     dispatch_wx<EPI_DGRAD>(p, nic::as_stream(stream));
     return nic::check_launch("nic_linear_dgrad");
 }
