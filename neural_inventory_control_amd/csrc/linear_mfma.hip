@@ -141,6 +141,32 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int6
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(n_floats * 4), 0x00020000);
 }
 
+// LDS-DMA issued from inline asm.  With the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc cannot prove that the
+// ds_reads of pipeline stage `cur` do not alias the DMA writes into stage `cur ^ 1` (same __shared__ array) and puts an
+// s_waitcnt vmcnt(0) in front of the first fragment read of EVERY tile: the copy it was meant to overlap is waited for
+// before the MFMAs start (measured: 13 % of the kernel).  An asm statement is outside hipcc's vmcnt bookkeeping; the
+// kernels drain the DMA themselves (dma_wait) right before the barrier that publishes the tile.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 make_desc(const float* p, int64_t n_floats) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    u32x4 d;
+    d.x = (unsigned)a;
+    d.y = (unsigned)(a >> 32) & 0xffffu;  // stride 0: raw buffer
+    d.z = (unsigned)(n_floats * 4);       // num_records in bytes: loads past it return 0
+    d.w = 0x00020000u;
+    return d;
+}
+// lds_addr: wave-uniform LDS byte address; lane l's 16 bytes land at lds_addr + 16 * l.  M0 is saved / restored inside the
+// statement (it is compiler-reserved); s_nop 0 covers the SALU-write-M0 -> LDS-DMA hazard.
+__device__ __forceinline__ void dma16(u32x4 desc, int voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(desc), "s"(lds_addr)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int ROWS>
 struct KTileBuf {
     static constexpr int N4 = ROWS / 32;
@@ -330,8 +356,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, h = lane >> 5;
 
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, (int64_t)p.M * p.lda);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.Bm, (int64_t)p.K * p.ldb);
+    const u32x4 ra = make_desc(p.A, (int64_t)p.M * p.lda);
+    const u32x4 rb = make_desc(p.Bm, (int64_t)p.K * p.ldb);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;  // LDS byte address of the staging array
     constexpr int A_INSTR = BM / 8 / NW;           // 1-KiB DMA instructions per wave for the A tile (8 rows each)
     constexpr int B_INSTR = BN / 8 / NW;           // ... for the B tile (256/BN rows each)
     constexpr int B_LPR = BN / 4;                  // lanes per B row
@@ -350,14 +377,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     }
     const int stepB = (int)(p.ldb * BK * 4);
     auto issue = [&](int stage) {
-        float* base = lds + stage * STAGE;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(stage * STAGE) * 4u);
+        const unsigned wbase_a = __builtin_amdgcn_readfirstlane(base + (unsigned)(wave * A_INSTR) * 1024u);
+        const unsigned wbase_b = __builtin_amdgcn_readfirstlane(base + (unsigned)A_FLOATS * 4u + (unsigned)(wave * B_INSTR) * 1024u);
 #pragma unroll
-        for (int q = 0; q < A_INSTR; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(base + (wave * A_INSTR + q) * 256), 16, offA[q], 0, 0, 0);
+        for (int q = 0; q < A_INSTR; ++q) dma16(ra, offA[q], wbase_a + q * 1024u);
 #pragma unroll
-        for (int q = 0; q < B_INSTR; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(base + A_FLOATS + (wave * B_INSTR + q) * 256), 16,
-                                                     offB[q], 0, 0, 0);
+        for (int q = 0; q < B_INSTR; ++q) dma16(rb, offB[q], wbase_b + q * 1024u);
     };
     auto advance = [&]() {
 #pragma unroll
@@ -378,10 +404,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     const int sw = (li >> 1) & 7;
     const int nk = (p.K + BK - 1) / BK;
     issue(0);
-    __syncthreads();  // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+    dma_wait();
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk && !(p.dbg & 1)) {
+        if (kt + 1 < nk && !(p.dbg & 1)) {  // stage cur^1 was last read in tile kt-1; every wave is past that barrier
             advance();
             issue(cur ^ 1);
         }
@@ -409,10 +436,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j], acc[i][j], 0, 0, 0);
             }
         }
+        dma_wait();  // tile kt+1 has landed (this wave's share); the barrier publishes every wave's share
         __syncthreads();
     }
 
-    // epilogue: stage the block tile through LDS and write whole rows (see gemm_wx_kernel)
+    // epilogue: stage the block tile through LDS and write whole rows
     float* cs = lds;
     constexpr int TPR = BN / 4, RPI = NTHREADS / TPR, ITER = PASS_ROWS / RPI;
     static_assert(PASS_ROWS % RPI == 0, "pass rows must divide evenly over the threads");
@@ -627,8 +655,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
     const int li = lane & 31, h = lane >> 5;
     float* slab = p.slab + (int64_t)split * p.N * p.lds_;
 
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.dY, (int64_t)p.N * p.ldb);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.X, (int64_t)p.K * p.ldb);
+    const u32x4 ra = make_desc(p.dY, (int64_t)p.N * p.ldb);
+    const u32x4 rb = make_desc(p.X, (int64_t)p.K * p.ldb);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
     int offA[A_INSTR], offB[B_INSTR];
 #pragma unroll
@@ -644,14 +673,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
         offB[q] = (int)((((int64_t)k0 + row) * p.ldb + b_begin + chunk * 4) * 4);
     }
     auto issue = [&](int stage) {
-        float* base = lds + stage * STAGE;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(stage * STAGE) * 4u);
+        const unsigned wbase_a = __builtin_amdgcn_readfirstlane(base + (unsigned)(wave * A_INSTR) * 1024u);
+        const unsigned wbase_b = __builtin_amdgcn_readfirstlane(base + (unsigned)A_FLOATS * 4u + (unsigned)(wave * B_INSTR) * 1024u);
 #pragma unroll
-        for (int q = 0; q < A_INSTR; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(base + (wave * A_INSTR + q) * 256), 16, offA[q], 0, 0, 0);
+        for (int q = 0; q < A_INSTR; ++q) dma16(ra, offA[q], wbase_a + q * 1024u);
 #pragma unroll
-        for (int q = 0; q < B_INSTR; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(base + A_FLOATS + (wave * B_INSTR + q) * 256), 16,
-                                                     offB[q], 0, 0, 0);
+        for (int q = 0; q < B_INSTR; ++q) dma16(rb, offB[q], wbase_b + q * 1024u);
     };
     auto advance = [&]() {
 #pragma unroll
@@ -674,6 +702,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
 
     const int sw = (li >> 1) & 7;
     issue(0);
+    dma_wait();
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
@@ -714,6 +743,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
         }
+        dma_wait();
         __syncthreads();
     }
 
