@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the launch sequence from a HIP graph (implies --no-kernel-timing)")
     args = ap.parse_args()
 
     from neural_inventory_control_amd import _lib, parallel
@@ -132,6 +133,9 @@ def main():
     setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, device, rank, args.scenarios, args.periods)
     S = setting["problem_params"]["n_stores"]
     opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+    if args.graph:
+        eng.use_graph = True
+        args.no_kernel_timing = True
     reducer = parallel.GradientAllReducer.get(model) if world > 1 else None
     global_b = n * world
     grad_scale = 1.0 / (global_b * T * S)
@@ -145,7 +149,7 @@ def main():
         opt.step()
         return total
 
-    for _ in range(max(args.warmup, 0)):
+    for _ in range(max(args.warmup, 0) + (2 if args.graph else 0)):  # graph mode: eager run + capture run before timing
         step()
     timer = None
     if not args.no_kernel_timing:

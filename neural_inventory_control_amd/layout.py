@@ -118,6 +118,29 @@ class EnvProblem:
         self.ech_holding = Table.from_ref(data.get("echelon_holding_costs") if self.E else None, ld, device)
         self.ech_lead = Table.from_ref(data.get("echelon_lead_times") if self.E else None, ld, device)
 
+    _TABLES = ("underage", "holding", "lead", "wh_holding", "wh_lead", "wh_edge", "ech_holding", "ech_lead")
+
+    def same_layout(self, other):
+        """True if `other` describes the same sizes and every table has the same shape / strides (so a captured launch
+        sequence that points at this object's tables stays valid once their contents are refreshed)."""
+        if (self.B, self.S, self.Wn, self.E, self.Ws, self.Ww, self.We, self.lost_demand, self.maximize_profit) != \
+                (other.B, other.S, other.Wn, other.E, other.Ws, other.Ww, other.We, other.lost_demand, other.maximize_profit):
+            return False
+        for name in self._TABLES:
+            a, b = getattr(self, name), getattr(other, name)
+            if (a.tensor is None) != (b.tensor is None):
+                return False
+            if a.tensor is not None and (a.tensor.shape != b.tensor.shape or
+                                         (a.loc_stride, a.scn_stride, a.sup_stride) != (b.loc_stride, b.scn_stride, b.sup_stride)):
+                return False
+        return True
+
+    def copy_tables_from(self, other):
+        for name in self._TABLES:
+            a, b = getattr(self, name), getattr(other, name)
+            if a.tensor is not None:
+                a.tensor.copy_(b.tensor)
+
     def dims(self):
         return NicEnvDims(self.B, self.ldb, self.S, self.Wn, self.E, self.Ws, self.Ww, self.We,
                           int(self.lost_demand), int(self.maximize_profit))

@@ -78,6 +78,8 @@ class FusedRollout:
         self.head = _HEADS[model.nn_args["name"]]
         self._key = None
         self.timer = None  # KernelTimer or None
+        self.use_graph = False  # replay the launch sequence from a HIP graph (see _replay_or_capture)
+        self._prob = None
 
     def _k(self, tag, fn, *args, **kw):
         if self.timer is None:
@@ -113,6 +115,7 @@ class FusedRollout:
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
+        self._prob = None
         self.F_store, self.F_wh, self.F_ech = prob.S * prob.Ws, prob.Wn * prob.Ww, prob.E * prob.We
         F = self.F_store + self.F_wh + self.F_ech
         if self.head == "softplus":
@@ -144,6 +147,11 @@ class FusedRollout:
             self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], prob.B) for i in range(L)]
             self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
             self.g_reward = z(ld)
+            self.gw = [torch.zeros_like(m.weight) for m in lins]
+            self.gb = [torch.zeros_like(m.bias) if m.bias is not None else None for m in lins]
+        self.demand_buf = None
+        self._graphs = {}      # "fwd"/"bwd" -> torch.cuda.CUDAGraph (HIP graph) of the launch sequence
+        self._eager_runs = 0
         if self.head == "warehouse":
             self.adj = self.model.adjacency(prob.S, prob.Wn, dev)
         self._key = key
@@ -167,8 +175,14 @@ class FusedRollout:
                 Table(eo, ld, 1) if eo is not None else None)
 
     def _ub(self):
+        """Scalar order upper bound of the policy (read back from the device once, not per call / per capture)."""
         ub = self.model.warehouse_upper_bound
-        return float(ub.reshape(-1)[0]) if torch.is_tensor(ub) else float(ub)
+        if not torch.is_tensor(ub):
+            return float(ub)
+        key = (ub.data_ptr(), ub._version)
+        if getattr(self, "_ub_cache", (None, None))[0] != key:
+            self._ub_cache = (key, float(ub.reshape(-1)[0]))
+        return self._ub_cache[1]
 
     # ---- one batch ----------------------------------------------------------------------------------------------
     def run(self, data, periods, ignore_periods=0, train=True, observation_params=None, demand_soa=None,
@@ -184,12 +198,25 @@ class FusedRollout:
         prob = EnvProblem(self.problem_params, data, dev)
         T, B, ld = periods, prob.B, prob.ldb
         self._setup(prob, T, train)
+        if self.use_graph:
+            # a captured graph holds raw pointers: keep the first call's table tensors and refresh their CONTENTS
+            if self._prob is not None and self._prob.same_layout(prob):
+                self._prob.copy_tables_from(prob)
+                prob = self._prob
+            else:
+                self._prob, self._graphs, self._eager_runs = prob, {}, 0
         self.prob = prob
         shift = observation_params["demand"]["period_shift"] if observation_params else 0
         if demand_soa is None:
             d = data["demands"]
             demand_soa = torch.zeros(d.shape[2], d.shape[1], ld, device=dev)
             demand_soa[:, :, :B] = d.permute(2, 1, 0)
+        if self.use_graph:
+            if self.demand_buf is None or self.demand_buf.shape != demand_soa.shape:
+                self.demand_buf, self._graphs, self._eager_runs = torch.empty_like(demand_soa), {}, 0
+            if self.demand_buf.data_ptr() != demand_soa.data_ptr():
+                self.demand_buf.copy_(demand_soa)
+            demand_soa = self.demand_buf
         self.demand = demand_soa
         if demand_soa.shape[0] < T + shift:
             raise ValueError("Current period is greater than the number of periods in the data")
@@ -212,7 +239,54 @@ class FusedRollout:
         if prob.E:
             s0.ech[:, :, :B].copy_(data["initial_echelon_inventories"].permute(1, 2, 0))
 
-        ub = self._ub() if self.head != "softplus" else 0.0
+        self._ub_now = self._ub() if self.head != "softplus" else 0.0
+        self._ctx = (prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa)
+        self._replay_or_capture("fwd", self._launch_forward)
+        total = self.rewards.sum()
+        reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
+        if not train:
+            self._eager_runs += 1
+            return total, reported
+
+        if grad_scale is None:
+            grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
+        self.g_reward.zero_()
+        self.g_reward[:B] = grad_scale
+        for sl in self.slabs:
+            sl.zero_()
+        self.g_state[0].zero_()
+        self._replay_or_capture("bwd", self._launch_backward)
+        self._eager_runs += 1
+        for i, m in enumerate(lins):
+            for p, g in ((m.weight, self.gw[i]), (m.bias, self.gb[i])):
+                if p is None:
+                    continue
+                if accumulate_grads and p.grad is not None and p.grad is not g:
+                    p.grad.add_(g)
+                else:
+                    p.grad = g
+        return total, reported
+
+    # ---- launch sequences (eager, or captured once into a HIP graph and replayed) ---------------------------------
+    def _replay_or_capture(self, name, fn):
+        """`use_graph`: the launch sequence of a rollout is identical from call to call (same buffers, same shapes), so it
+        is captured once into a HIP graph and replayed — this removes the per-launch host cost that bounds the small
+        (32-wide) policies, whose kernels run for a few microseconds each.  The first call always runs eagerly (module
+        loading is not capturable); timers force eager mode."""
+        if not self.use_graph or self.timer is not None or self._eager_runs < 1:
+            return fn()
+        g = self._graphs.get(name)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                fn()
+            self._graphs[name] = g
+        g.replay()
+
+    def _launch_forward(self):
+        prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
+        ub = self._ub_now
         for t in range(T):
             st = self._views(self.states[t], prob)
             x = self.states[t][:self.F]
@@ -235,20 +309,10 @@ class FusedRollout:
             self._k("env_fwd", ops.env_step_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te,
                     out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
 
-        total = self.rewards.sum()
-        reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
-        if not train:
-            return total, reported
-
-        # ---- backward sweep -------------------------------------------------------------------------------------
-        if grad_scale is None:
-            grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
-        self.g_reward.zero_()
-        self.g_reward[:B] = grad_scale
-        for s in self.slabs:
-            s.zero_()
+    def _launch_backward(self):
+        prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
+        ub = self._ub_now
         g_next, g_cur = self.g_state
-        g_next.zero_()
         detached_input = self.head == "serial"  # the reference detaches VanillaSerial's MLP input (:329)
         for t in range(T - 1, -1, -1):
             st = self._views(self.states[t], prob)
@@ -279,19 +343,8 @@ class FusedRollout:
                     self._k(f"dgrad_{self.dims[1]}x{self.dims[0]}", ops.linear_dgrad, Wtv[0], d, None, g_cur[:self.F], B,
                             _lib.NIC_ACT_NONE, True)
             g_next, g_cur = g_cur, g_next
-
-        for i, m in enumerate(lins):
-            gw = torch.empty_like(m.weight)
-            gb = torch.empty_like(m.bias) if m.bias is not None else None
-            ops.wgrad_reduce(self.slabs[i], gw, gb, self.dims[i], 1.0)
-            for p, g in ((m.weight, gw), (m.bias, gb)):
-                if p is None:
-                    continue
-                if accumulate_grads and p.grad is not None:
-                    p.grad.add_(g)
-                else:
-                    p.grad = g
-        return total, reported
+        for i in range(L):
+            ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], self.dims[i], 1.0)
 
     # ---- inspection helpers used by the parity tests --------------------------------------------------------------
     def per_period_rewards(self):

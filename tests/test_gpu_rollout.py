@@ -217,3 +217,42 @@ def test_full_size_properties_cfg3():
         lhs = nx.sum(dim=1)
         rhs = st.sum(dim=1) - sales + recv
         assert float((lhs - rhs).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["cfg2_one_store_backlogged_vanilla", "cfg4_serial_vanilla", "cfg3_one_warehouse_5_vanilla"])
+def test_graph_replay_matches_eager(name):
+    """HIP-graph replay of the launch sequence (use_graph) is bit-identical to eager launches, also after the batch
+    contents change between calls (the captured graph points at engine-owned buffers that are refreshed per call)."""
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    data2 = dict(data)
+    data2["demands"] = (data["demands"] * 1.25 + 0.5).contiguous()
+    data2["initial_inventories"] = (data["initial_inventories"] * 0.5).contiguous()
+    F = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
+    if c["policy"] != "vanilla_one_store":
+        F += sum(int(np.prod(data[k].shape[1:])) for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
+                 if k in data)
+    results = {}
+    for mode in ("eager", "graph"):
+        model = _model(g, c)
+        eng = FusedRollout(model, c["problem_params"], DEV)
+        eng.use_graph = mode == "graph"
+        eng.materialize(F)
+        _load(model, g)
+        out = []
+        for d in (data, data2, data, data2):  # call 1 eager, call 2 captures, calls 3-4 replay
+            total, rep = eng.run(d, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+            torch.cuda.synchronize()
+            out.append((float(total), float(rep), [p.grad.clone() for p in model.parameters()],
+                        eng.per_period_rewards().clone()))
+        results[mode] = out
+        if mode == "graph":
+            assert set(eng._graphs) == {"fwd", "bwd"}
+    for a, b in zip(results["eager"], results["graph"]):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert torch.equal(a[3], b[3])
+        for x, y in zip(a[2], b[2]):
+            assert torch.equal(x, y)
+    assert results["eager"][0][0] != results["eager"][1][0]  # the two batches really differ
+    assert results["eager"][0][0] == results["eager"][2][0]
