@@ -28,6 +28,7 @@ extern "C" {
 
 #define NIC_ABI_VERSION 1
 #define NIC_MAX_SLOTS 16 /* longest supported pipeline (max lead time) */
+#define NIC_MAX_WAREHOUSES 32
 
 /* element (loc, b) of a per-location table lives at p[loc*loc_stride + b*scn_stride]; scn_stride == 0 broadcasts
  * one row to every scenario (the reference's `expand` views, data_handling.py:257-269). */

@@ -1,38 +1,91 @@
 // One period of inventory dynamics on gfx950: forward and analytic backward.
 //
-// Kernel shape: one lane per scenario, 64-lane workgroups (one wavefront each) so that B scenarios spread over
-// B/64 workgroups and the chip's 256 CUs all get work even at B = 32k; every global access of a wave is a
-// contiguous 256-byte row segment of a scenario-minor buffer.  HBM-bound: algorithmic bytes per scenario-period are
-// 4*[2*(S*Ws + Wn*Ww + E*We) + S + (S*max(Wn,1) + Wn + E) + 1] (state read + write, demand, orders, reward).
-// The arithmetic lives in env_step_body.h (shared with the host-side test build).
+// Kernel shape: FOUR lanes per scenario (a "quad": lane q owns stores q, q+4, ... and warehouses q, q+4, ...), laid out
+// as 4 wavefronts x 64 scenarios per workgroup, so every global access of a wave is still a contiguous 256-byte row
+// segment of a scenario-minor buffer while a 64-store scenario is walked by four lanes (one lane per scenario left the
+// chip latency-bound: 0.22 ms for 32k x 64 stores against a 27 us byte floor).  Per-scenario reductions cross the quad
+// through LDS in a fixed order (bit-identical to the single-lane Sum4 order).  HBM-bound: algorithmic bytes per
+// scenario-period are 4*[2*(S*Ws + Wn*Ww + E*We) + S + (S*max(Wn,1) + Wn + E) + 1] (state read + write, demand, orders,
+// reward).  The arithmetic lives in env_step_body.h (shared with the host-side test build).
 #include "env_step_body.h"
 #include "nic_common.h"
 
 namespace {
 
-constexpr int kBlock = 64;
+// Workgroup = 64 scenarios x 4 lanes ("quad") = 4 wavefronts: wave q handles stores s = q, q+4, ... of its 64 scenarios,
+// so a 64-store scenario is walked by four lanes instead of one (B = 32k scenarios alone would give the 1,024 SIMDs half a
+// wave each).  Per-scenario reductions (store costs, what each warehouse ships) go through LDS in the fixed Sum4 order;
+// then lane q handles warehouses w = q, q+4, ... and lane 0 the serial echelon chain.
+constexpr int kLanes = 64;
+constexpr int kChunk = 8;  // warehouses whose shipment partials are exchanged per barrier round
 
 template <int MAXW>
-__global__ __launch_bounds__(kBlock) void env_step_fwd_kernel(NicEnvStepIO io, float* __restrict__ store_out,
-                                                              float* __restrict__ wh_out, float* __restrict__ ech_out,
-                                                              float* __restrict__ reward) {
-    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (b >= io.dims.n_scenarios) return;
-    nic::env_step_fwd_scenario<MAXW>(io, store_out, wh_out, ech_out, reward, b);
+__global__ __launch_bounds__(kLanes * nic::kQuad) void env_step_fwd_kernel(NicEnvStepIO io, float* __restrict__ store_out,
+                                                                            float* __restrict__ wh_out,
+                                                                            float* __restrict__ ech_out,
+                                                                            float* __restrict__ reward) {
+    __shared__ float part[kChunk][nic::kQuad][kLanes];  // shipment partials of one warehouse chunk
+    __shared__ float rq[nic::kQuad][kLanes];            // store-cost partials
+    __shared__ float cw[NIC_MAX_WAREHOUSES][kLanes];    // warehouse costs
+    const int x = threadIdx.x & (kLanes - 1), q = threadIdx.x / kLanes;
+    const int64_t b = (int64_t)blockIdx.x * kLanes + x;
+    const bool live = b < io.dims.n_scenarios;
+    const int Wn = io.dims.n_warehouses;
+
+    rq[q][x] = live ? nic::env_fwd_stores<MAXW>(io, store_out, b, q) : 0.f;
+    for (int wc = 0; wc < Wn; wc += kChunk) {
+        for (int i = 0; i < kChunk && wc + i < Wn; ++i) part[i][q][x] = live ? nic::env_ship_partial(io, wc + i, b, q) : 0.f;
+        __syncthreads();
+        for (int i = q; i < kChunk && wc + i < Wn; i += nic::kQuad) {
+            const float shipped = nic::combine4(part[i][0][x], part[i][1][x], part[i][2][x], part[i][3][x]);
+            cw[wc + i][x] = live ? nic::env_fwd_warehouse<MAXW>(io, wh_out, wc + i, shipped, b) : 0.f;
+        }
+        __syncthreads();
+    }
+    if (Wn == 0) __syncthreads();
+    if (q == 0 && live) {
+        float total = nic::combine4(rq[0][x], rq[1][x], rq[2][x], rq[3][x]);
+        if (Wn > 0) {
+            float r_wh = 0.f;
+            for (int w = 0; w < Wn; ++w) r_wh += cw[w][x];
+            total += r_wh;
+        }
+        if (io.dims.n_echelons > 0) total += nic::env_fwd_echelons<MAXW>(io, ech_out, nic::env_wh_orders_sum(io, b), b);
+        reward[b] = total;
+    }
 }
 
 template <int MAXW>
-__global__ __launch_bounds__(kBlock) void env_step_bwd_kernel(NicEnvStepIO io, const float* __restrict__ g_store_out,
-                                                              const float* __restrict__ g_wh_out,
-                                                              const float* __restrict__ g_ech_out, NicTable2 g_reward,
-                                                              float* __restrict__ g_store_in, float* __restrict__ g_wh_in,
-                                                              float* __restrict__ g_ech_in, float* g_store_orders,
-                                                              float* __restrict__ g_wh_orders,
-                                                              float* __restrict__ g_ech_orders) {
-    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (b >= io.dims.n_scenarios) return;
-    nic::env_step_bwd_scenario<MAXW>(io, g_store_out, g_wh_out, g_ech_out, g_reward, g_store_in, g_wh_in, g_ech_in,
-                                     g_store_orders, g_wh_orders, g_ech_orders, b);
+__global__ __launch_bounds__(kLanes * nic::kQuad) void env_step_bwd_kernel(
+    NicEnvStepIO io, const float* __restrict__ g_store_out, const float* __restrict__ g_wh_out,
+    const float* __restrict__ g_ech_out, NicTable2 g_reward, float* __restrict__ g_store_in, float* __restrict__ g_wh_in,
+    float* __restrict__ g_ech_in, float* __restrict__ g_store_orders, float* __restrict__ g_wh_orders,
+    float* __restrict__ g_ech_orders) {
+    __shared__ float part[kChunk][nic::kQuad][kLanes];
+    __shared__ float gwa[NIC_MAX_WAREHOUSES][kLanes];  // gradient of each warehouse's post-shipping on-hand
+    __shared__ float g2wh[kLanes];                     // d/d(sum_w wh_orders) from the echelon chain
+    const int x = threadIdx.x & (kLanes - 1), q = threadIdx.x / kLanes;
+    const int64_t b = (int64_t)blockIdx.x * kLanes + x;
+    const bool live = b < io.dims.n_scenarios;
+    const int Wn = io.dims.n_warehouses;
+    const float gr = live ? g_reward.p[b * g_reward.scn_stride] : 0.f;
+
+    if (q == 0)
+        g2wh[x] = (live && io.dims.n_echelons > 0) ? nic::env_bwd_echelons<MAXW>(io, g_ech_out, gr, g_ech_in, g_ech_orders, b)
+                                                    : 0.f;
+    for (int wc = 0; wc < Wn; wc += kChunk) {
+        for (int i = 0; i < kChunk && wc + i < Wn; ++i) part[i][q][x] = live ? nic::env_ship_partial(io, wc + i, b, q) : 0.f;
+        __syncthreads();  // also publishes g2wh in the first round
+        for (int i = q; i < kChunk && wc + i < Wn; i += nic::kQuad) {
+            const float shipped = nic::combine4(part[i][0][x], part[i][1][x], part[i][2][x], part[i][3][x]);
+            gwa[wc + i][x] = live ? nic::env_bwd_warehouse<MAXW>(io, g_wh_out, gr, g2wh[x], wc + i, shipped, g_wh_in,
+                                                                 g_wh_orders, b)
+                                  : 0.f;
+        }
+        __syncthreads();
+    }
+    if (live)
+        nic::env_bwd_stores<MAXW>(io, g_store_out, gr, [&](int w) { return gwa[w][x]; }, g_store_in, g_store_orders, b, q);
 }
 
 int validate(const NicEnvStepIO* io, const char* who) {
@@ -41,6 +94,7 @@ int validate(const NicEnvStepIO* io, const char* who) {
     NIC_REQUIRE(d.n_scenarios > 0 && d.ldb >= d.n_scenarios, "%s: bad n_scenarios/ldb (%d/%d)", who, d.n_scenarios, d.ldb);
     NIC_REQUIRE(d.n_stores > 0, "%s: n_stores must be positive", who);
     NIC_REQUIRE(d.n_warehouses >= 0 && d.n_echelons >= 0, "%s: negative location count", who);
+    NIC_REQUIRE(d.n_warehouses <= NIC_MAX_WAREHOUSES, "%s: at most %d warehouses", who, NIC_MAX_WAREHOUSES);
     NIC_REQUIRE(d.store_slots >= 2 && d.store_slots <= NIC_MAX_SLOTS, "%s: store pipeline length %d outside [2,%d]", who,
                 d.store_slots, NIC_MAX_SLOTS);
     NIC_REQUIRE(d.n_warehouses == 0 || (d.warehouse_slots >= 2 && d.warehouse_slots <= NIC_MAX_SLOTS),
@@ -75,7 +129,7 @@ int nic_env_step_fwd(const NicEnvStepIO* io, float* store_inv_out, float* wh_inv
     NIC_REQUIRE(store_inv_out && reward, "nic_env_step_fwd: null output");
     NIC_REQUIRE(d.n_warehouses == 0 || wh_inv_out, "nic_env_step_fwd: null warehouse output");
     NIC_REQUIRE(d.n_echelons == 0 || ech_inv_out, "nic_env_step_fwd: null echelon output");
-    const dim3 grid(nic::ceil_div(d.n_scenarios, kBlock)), block(kBlock);
+    const dim3 grid(nic::ceil_div(d.n_scenarios, kLanes)), block(kLanes * nic::kQuad);
     hipStream_t s = nic::as_stream(stream);
     const int m = max_slots(d);
     if (m <= 4)
@@ -97,7 +151,7 @@ int nic_env_step_bwd(const NicEnvStepIO* io, const float* g_store_out, const flo
     NIC_REQUIRE(g_store_in && g_store_orders, "nic_env_step_bwd: null store gradient output");
     NIC_REQUIRE(d.n_warehouses == 0 || (g_wh_in && g_wh_orders), "nic_env_step_bwd: null warehouse gradient output");
     NIC_REQUIRE(d.n_echelons == 0 || (g_ech_in && g_ech_orders), "nic_env_step_bwd: null echelon gradient output");
-    const dim3 grid(nic::ceil_div(d.n_scenarios, kBlock)), block(kBlock);
+    const dim3 grid(nic::ceil_div(d.n_scenarios, kLanes)), block(kLanes * nic::kQuad);
     hipStream_t s = nic::as_stream(stream);
     const int m = max_slots(d);
 #define NIC_LAUNCH_BWD(MW)                                                                                              \

@@ -27,22 +27,11 @@ NIC_HD float t3(const NicTable3& t, int loc, int sup, int64_t b) {
 }
 NIC_HD float relu(float x) { return x > 0.f ? x : 0.f; }
 
-// Sum over the locations of one scenario with four interleaved accumulators combined as ((a0+a1)+a2)+a3.
-// Four independent chains give the lane ILP; the order also coincides with what the reference's CPU `sum(dim=1)`
-// does for outer-dimension reductions (measured on torch 2.10), which keeps knife-edge `>= 0` masks on the
-// warehouse on-hand (environment.py:249-251) on the reference's side of zero more often than a serial sum.
-struct Sum4 {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    NIC_HD void add(int i, float v) {
-        switch (i & 3) {
-            case 0: a0 += v; break;
-            case 1: a1 += v; break;
-            case 2: a2 += v; break;
-            default: a3 += v; break;
-        }
-    }
-    NIC_HD float total() const { return ((a0 + a1) + a2) + a3; }
-};
+// Sums over the stores of one scenario use four interleaved accumulators (stores s = q mod 4) combined as
+// ((a0+a1)+a2)+a3 ("Sum4 order").  Four independent chains give ILP / let four lanes share the work, and the order
+// coincides with what the reference's CPU `sum(dim=1)` does for outer-dimension reductions (measured on torch 2.10), which
+// keeps knife-edge `>= 0` masks on the warehouse on-hand (environment.py:249-251) on the reference's side of zero more
+// often than a serial sum.
 
 // new[0] = on_hand_after + old[1]; new[k] = old[k+1]; new[W-1] = 0            (environment.py:405-412)
 template <int MAXW>
@@ -84,19 +73,25 @@ NIC_HD float pick(const float (&g)[MAXW], int W, int slot) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Forward of one scenario.  Follows Simulator.step: stores (environment.py:179-234), warehouses (:236-270),
-// echelons (:272-299).
+// One period is split into pieces that FOUR lanes per scenario execute (the "quad": lane q owns stores s = q, q+4, ...)
+// plus per-warehouse and per-scenario pieces.  The pieces are NIC_HD; the device kernels (env_step.hip) run the quad's
+// lanes in four wavefronts of one workgroup and exchange partial sums through LDS, the host-side test build runs the same
+// pieces in a loop.  Partial sums are combined as ((p0+p1)+p2)+p3, i.e. exactly the Sum4 order described above, so splitting the
+// stores over four lanes changes no bit of the result.
+// Follows Simulator.step: stores (environment.py:179-234), warehouses (:236-270), echelons (:272-299).
 // ------------------------------------------------------------------------------------------------------------
+constexpr int kQuad = 4;
+
+NIC_HD float combine4(float p0, float p1, float p2, float p3) { return ((p0 + p1) + p2) + p3; }
+
+// stores s = q, q+4, ...: cost + pipeline update; returns this lane's partial store cost
 template <int MAXW>
-NIC_HD void env_step_fwd_scenario(const NicEnvStepIO& io, float* store_out, float* wh_out, float* ech_out,
-                                  float* reward, int64_t b) {
+NIC_HD float env_fwd_stores(const NicEnvStepIO& io, float* store_out, int64_t b, int q) {
     const NicEnvDims& d = io.dims;
     const int64_t ldb = d.ldb;
     const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
-
-    // ---- stores
-    Sum4 r_store;
-    for (int s = 0; s < d.n_stores; ++s) {
+    float r = 0.f;
+    for (int s = q; s < d.n_stores; s += kQuad) {
         const float* inv = io.store_inv + (int64_t)s * d.store_slots * ldb + b;
         const float on_hand = inv[0];
         const float dem = t2(io.demand, s, b);
@@ -108,7 +103,7 @@ NIC_HD void env_step_fwd_scenario(const NicEnvStepIO& io, float* store_out, floa
         } else {
             c = p * relu(-after) + h * relu(after);  // :198-201
         }
-        r_store.add(s, c);
+        r += c;
         if (d.lost_demand) after = relu(after);  // :204-205
         float nv[MAXW];
         shifted_pipeline<MAXW>(inv, ldb, d.store_slots, after, nv);
@@ -116,46 +111,76 @@ NIC_HD void env_step_fwd_scenario(const NicEnvStepIO& io, float* store_out, floa
             place_order<MAXW>(nv, d.store_slots, t3(io.store_orders, s, w, b), t3(io.lead_times, s, w, b));
         store_pipeline<MAXW>(store_out + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, nv);
     }
-    float total = r_store.total();
+    return r;
+}
 
-    // ---- warehouses: ship whatever the stores ordered (no feasibility clip: :249)
-    float wh_orders_sum = 0.f;
+// this lane's share of what warehouse w ships: sum of the orders of stores s = q, q+4, ...   (:247)
+NIC_HD float env_ship_partial(const NicEnvStepIO& io, int w, int64_t b, int q) {
+    float a = 0.f;
+    for (int s = q; s < io.dims.n_stores; s += kQuad) a += t3(io.store_orders, s, w, b);
+    return a;
+}
+
+// warehouse w: ships `shipped` (no feasibility clip: :249), pays holding (+ edge) cost, updates its pipeline; returns cost
+template <int MAXW>
+NIC_HD float env_fwd_warehouse(const NicEnvStepIO& io, float* wh_out, int w, float shipped, int64_t b) {
+    const NicEnvDims& d = io.dims;
+    const int64_t ldb = d.ldb;
+    const float* inv = io.wh_inv + (int64_t)w * d.warehouse_slots * ldb + b;
+    const float after = inv[0] - shipped;
+    float c = t2(io.wh_holding, w, b) * relu(after);  // :251
+    const float a = t2(io.wh_orders, w, b);
+    if (io.wh_edge_costs.p) c = c + t2(io.wh_edge_costs, w, b) * a;  // :254-259
+    float nv[MAXW];
+    shifted_pipeline<MAXW>(inv, ldb, d.warehouse_slots, after, nv);
+    place_order<MAXW>(nv, d.warehouse_slots, a, t2(io.wh_lead_times, w, b));
+    store_pipeline<MAXW>(wh_out + (int64_t)w * d.warehouse_slots * ldb + b, ldb, d.warehouse_slots, nv);
+    return c;
+}
+
+NIC_HD float env_wh_orders_sum(const NicEnvStepIO& io, int64_t b) {
+    float s = 0.f;
+    for (int w = 0; w < io.dims.n_warehouses; ++w) s += t2(io.wh_orders, w, b);
+    return s;
+}
+
+// extra echelons: echelon e ships what echelon e+1 ordered; the last one feeds the warehouses (:282-285); returns cost
+template <int MAXW>
+NIC_HD float env_fwd_echelons(const NicEnvStepIO& io, float* ech_out, float wh_orders_sum, int64_t b) {
+    const NicEnvDims& d = io.dims;
+    const int64_t ldb = d.ldb;
+    float r_e = 0.f;
+    for (int e = 0; e < d.n_echelons; ++e) {
+        const float ship = (e < d.n_echelons - 1) ? t2(io.ech_orders, e + 1, b) : wh_orders_sum;
+        const float* inv = io.ech_inv + (int64_t)e * d.echelon_slots * ldb + b;
+        const float after = inv[0] - ship;
+        r_e += t2(io.ech_holding, e, b) * relu(after);  // :287
+        float nv[MAXW];
+        shifted_pipeline<MAXW>(inv, ldb, d.echelon_slots, after, nv);
+        place_order<MAXW>(nv, d.echelon_slots, t2(io.ech_orders, e, b), t2(io.ech_lead_times, e, b));
+        store_pipeline<MAXW>(ech_out + (int64_t)e * d.echelon_slots * ldb + b, ldb, d.echelon_slots, nv);
+    }
+    return r_e;
+}
+
+// reference composition of the pieces for one scenario (host-side test build; the device kernels do the same through LDS)
+template <int MAXW>
+NIC_HD void env_step_fwd_scenario(const NicEnvStepIO& io, float* store_out, float* wh_out, float* ech_out,
+                                  float* reward, int64_t b) {
+    const NicEnvDims& d = io.dims;
+    float rq[kQuad];
+    for (int q = 0; q < kQuad; ++q) rq[q] = env_fwd_stores<MAXW>(io, store_out, b, q);
+    float total = combine4(rq[0], rq[1], rq[2], rq[3]);
     if (d.n_warehouses > 0) {
         float r_wh = 0.f;
         for (int w = 0; w < d.n_warehouses; ++w) {
-            Sum4 ship4;
-            for (int s = 0; s < d.n_stores; ++s) ship4.add(s, t3(io.store_orders, s, w, b));  // :247
-            const float shipped = ship4.total();
-            const float* inv = io.wh_inv + (int64_t)w * d.warehouse_slots * ldb + b;
-            const float after = inv[0] - shipped;
-            float c = t2(io.wh_holding, w, b) * relu(after);  // :251
-            const float a = t2(io.wh_orders, w, b);
-            if (io.wh_edge_costs.p) c = c + t2(io.wh_edge_costs, w, b) * a;  // :254-259
-            r_wh += c;
-            wh_orders_sum += a;
-            float nv[MAXW];
-            shifted_pipeline<MAXW>(inv, ldb, d.warehouse_slots, after, nv);
-            place_order<MAXW>(nv, d.warehouse_slots, a, t2(io.wh_lead_times, w, b));
-            store_pipeline<MAXW>(wh_out + (int64_t)w * d.warehouse_slots * ldb + b, ldb, d.warehouse_slots, nv);
+            const float shipped = combine4(env_ship_partial(io, w, b, 0), env_ship_partial(io, w, b, 1),
+                                           env_ship_partial(io, w, b, 2), env_ship_partial(io, w, b, 3));
+            r_wh += env_fwd_warehouse<MAXW>(io, wh_out, w, shipped, b);
         }
         total += r_wh;
     }
-
-    // ---- extra echelons: echelon e ships what echelon e+1 ordered; the last one feeds the warehouses (:282-285)
-    if (d.n_echelons > 0) {
-        float r_e = 0.f;
-        for (int e = 0; e < d.n_echelons; ++e) {
-            const float ship = (e < d.n_echelons - 1) ? t2(io.ech_orders, e + 1, b) : wh_orders_sum;
-            const float* inv = io.ech_inv + (int64_t)e * d.echelon_slots * ldb + b;
-            const float after = inv[0] - ship;
-            r_e += t2(io.ech_holding, e, b) * relu(after);  // :287
-            float nv[MAXW];
-            shifted_pipeline<MAXW>(inv, ldb, d.echelon_slots, after, nv);
-            place_order<MAXW>(nv, d.echelon_slots, t2(io.ech_orders, e, b), t2(io.ech_lead_times, e, b));
-            store_pipeline<MAXW>(ech_out + (int64_t)e * d.echelon_slots * ldb + b, ldb, d.echelon_slots, nv);
-        }
-        total += r_e;
-    }
+    if (d.n_echelons > 0) total += env_fwd_echelons<MAXW>(io, ech_out, env_wh_orders_sum(io, b), b);
     reward[b] = total;
 }
 
@@ -182,88 +207,79 @@ NIC_HD void load_grad(const float* g_out, int64_t ldb, int W, float (&gn)[MAXW])
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Backward of one scenario (what autograd derives for the ops cited above).  Tie rules of torch 2.x:
-// clamp(min=0) passes the gradient where x >= 0; minimum splits it 0.5/0.5 on ties; orders that are exactly 0
-// get no gradient through the pipeline placement but still through the warehouse / echelon outflow sums.
+// Backward pieces (what autograd derives for the ops cited above).  Tie rules of torch 2.x: clamp(min=0) passes the
+// gradient where x >= 0; minimum splits it 0.5/0.5 on ties; orders that are exactly 0 get no gradient through the
+// pipeline placement but still through the warehouse / echelon outflow sums.
 // ------------------------------------------------------------------------------------------------------------
+
+// echelons, most upstream first (their outflow gradient lands on downstream orders); returns d/d(sum_w wh_orders)
 template <int MAXW>
-NIC_HD void env_step_bwd_scenario(const NicEnvStepIO& io, const float* g_store_out, const float* g_wh_out,
-                                  const float* g_ech_out, const NicTable2& g_reward, float* g_store_in,
-                                  float* g_wh_in, float* g_ech_in, float* g_store_orders, float* g_wh_orders,
-                                  float* g_ech_orders, int64_t b) {
+NIC_HD float env_bwd_echelons(const NicEnvStepIO& io, const float* g_ech_out, float gr, float* g_ech_in,
+                              float* g_ech_orders, int64_t b) {
+    const NicEnvDims& d = io.dims;
+    const int64_t ldb = d.ldb;
+    const float wh_orders_sum = env_wh_orders_sum(io, b);
+    float prev_g_after = 0.f;
+    for (int e = 0; e < d.n_echelons; ++e) {
+        const float ship = (e < d.n_echelons - 1) ? t2(io.ech_orders, e + 1, b) : wh_orders_sum;
+        const float* inv = io.ech_inv + (int64_t)e * d.echelon_slots * ldb + b;
+        const float after = inv[0] - ship;
+        float gn[MAXW];
+        load_grad<MAXW>(g_ech_out ? g_ech_out + (int64_t)e * d.echelon_slots * ldb + b : nullptr, ldb, d.echelon_slots, gn);
+        const float a = t2(io.ech_orders, e, b);
+        const float ga = (a != 0.f) ? pick<MAXW>(gn, d.echelon_slots, (int)t2(io.ech_lead_times, e, b) - 1) : 0.f;
+        float g_after = gn[0];
+        if (after >= 0.f) g_after += gr * t2(io.ech_holding, e, b);
+        store_pipeline_grad<MAXW>(g_ech_in + (int64_t)e * d.echelon_slots * ldb + b, ldb, d.echelon_slots, gn, g_after);
+        g_ech_orders[(int64_t)e * ldb + b] = ga - prev_g_after;  // echelon e's own order is shipped by echelon e-1
+        prev_g_after = g_after;
+    }
+    return -prev_g_after;
+}
+
+// warehouse w; returns the gradient w.r.t. its post-shipping on-hand (every store order from it carries -that)
+template <int MAXW>
+NIC_HD float env_bwd_warehouse(const NicEnvStepIO& io, const float* g_wh_out, float gr, float g_to_wh_orders, int w,
+                               float shipped, float* g_wh_in, float* g_wh_orders, int64_t b) {
+    const NicEnvDims& d = io.dims;
+    const int64_t ldb = d.ldb;
+    const float* inv = io.wh_inv + (int64_t)w * d.warehouse_slots * ldb + b;
+    const float after = inv[0] - shipped;
+    float gn[MAXW];
+    load_grad<MAXW>(g_wh_out ? g_wh_out + (int64_t)w * d.warehouse_slots * ldb + b : nullptr, ldb, d.warehouse_slots, gn);
+    const float a = t2(io.wh_orders, w, b);
+    float ga = (a != 0.f) ? pick<MAXW>(gn, d.warehouse_slots, (int)t2(io.wh_lead_times, w, b) - 1) : 0.f;
+    if (io.wh_edge_costs.p) ga += gr * t2(io.wh_edge_costs, w, b);
+    ga += g_to_wh_orders;
+    g_wh_orders[(int64_t)w * ldb + b] = ga;
+    float g_after = gn[0];
+    if (after >= 0.f) g_after += gr * t2(io.wh_holding, w, b);
+    store_pipeline_grad<MAXW>(g_wh_in + (int64_t)w * d.warehouse_slots * ldb + b, ldb, d.warehouse_slots, gn, g_after);
+    return g_after;
+}
+
+// stores s = q, q+4, ...; g_wafter(w) = gradient of warehouse w's post-shipping on-hand (unused when n_warehouses == 0)
+template <int MAXW, typename GWAfter>
+NIC_HD void env_bwd_stores(const NicEnvStepIO& io, const float* g_store_out, float gr, GWAfter g_wafter,
+                           float* g_store_in, float* g_store_orders, int64_t b, int q) {
     const NicEnvDims& d = io.dims;
     const int64_t ldb = d.ldb;
     const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
-    const float gr = g_reward.p[b * g_reward.scn_stride];
-
-    // ---- echelons (most upstream first: their outflow gradient lands on downstream orders)
-    float g_to_wh_orders = 0.f;  // d/d(sum_w wh_orders) coming from the last echelon's outflow
-    if (d.n_echelons > 0) {
-        float wh_orders_sum = 0.f;
-        for (int w = 0; w < d.n_warehouses; ++w) wh_orders_sum += t2(io.wh_orders, w, b);
-        float prev_g_after = 0.f;
-        for (int e = 0; e < d.n_echelons; ++e) {
-            const float ship = (e < d.n_echelons - 1) ? t2(io.ech_orders, e + 1, b) : wh_orders_sum;
-            const float* inv = io.ech_inv + (int64_t)e * d.echelon_slots * ldb + b;
-            const float after = inv[0] - ship;
-            float gn[MAXW];
-            load_grad<MAXW>(g_ech_out ? g_ech_out + (int64_t)e * d.echelon_slots * ldb + b : nullptr, ldb,
-                            d.echelon_slots, gn);
-            const float a = t2(io.ech_orders, e, b);
-            float ga = (a != 0.f) ? pick<MAXW>(gn, d.echelon_slots, (int)t2(io.ech_lead_times, e, b) - 1) : 0.f;
-            float g_after = gn[0];
-            if (after >= 0.f) g_after += gr * t2(io.ech_holding, e, b);
-            store_pipeline_grad<MAXW>(g_ech_in + (int64_t)e * d.echelon_slots * ldb + b, ldb, d.echelon_slots, gn,
-                                      g_after);
-            // echelon e's own order is shipped by echelon e-1
-            g_ech_orders[(int64_t)e * ldb + b] = ga - prev_g_after;
-            prev_g_after = g_after;
-        }
-        g_to_wh_orders = -prev_g_after;
-    }
-
-    // ---- warehouses
-    if (d.n_warehouses > 0) {
-        for (int w = 0; w < d.n_warehouses; ++w) {
-            Sum4 ship4;
-            for (int s = 0; s < d.n_stores; ++s) ship4.add(s, t3(io.store_orders, s, w, b));
-            const float shipped = ship4.total();
-            const float* inv = io.wh_inv + (int64_t)w * d.warehouse_slots * ldb + b;
-            const float after = inv[0] - shipped;
-            float gn[MAXW];
-            load_grad<MAXW>(g_wh_out ? g_wh_out + (int64_t)w * d.warehouse_slots * ldb + b : nullptr, ldb,
-                            d.warehouse_slots, gn);
-            const float a = t2(io.wh_orders, w, b);
-            float ga = (a != 0.f) ? pick<MAXW>(gn, d.warehouse_slots, (int)t2(io.wh_lead_times, w, b) - 1) : 0.f;
-            if (io.wh_edge_costs.p) ga += gr * t2(io.wh_edge_costs, w, b);
-            ga += g_to_wh_orders;
-            g_wh_orders[(int64_t)w * ldb + b] = ga;
-            float g_after = gn[0];
-            if (after >= 0.f) g_after += gr * t2(io.wh_holding, w, b);
-            store_pipeline_grad<MAXW>(g_wh_in + (int64_t)w * d.warehouse_slots * ldb + b, ldb, d.warehouse_slots, gn,
-                                      g_after);
-            // every store order from this warehouse reduces its on-hand stock (no zero filter on this path)
-            for (int s = 0; s < d.n_stores; ++s) g_store_orders[((int64_t)s * nsup + w) * ldb + b] = -g_after;
-        }
-    }
-
-    // ---- stores
-    for (int s = 0; s < d.n_stores; ++s) {
+    for (int s = q; s < d.n_stores; s += kQuad) {
         const float* inv = io.store_inv + (int64_t)s * d.store_slots * ldb + b;
         const float on_hand = inv[0];
         const float dem = t2(io.demand, s, b);
         const float after = on_hand - dem;
         const float p = t2(io.underage, s, b), h = t2(io.holding, s, b);
         float gn[MAXW];
-        load_grad<MAXW>(g_store_out ? g_store_out + (int64_t)s * d.store_slots * ldb + b : nullptr, ldb,
-                        d.store_slots, gn);
+        load_grad<MAXW>(g_store_out ? g_store_out + (int64_t)s * d.store_slots * ldb + b : nullptr, ldb, d.store_slots, gn);
         // through the carried inventory (lost demand clips it at 0: gradient where after >= 0)
         float g_after = gn[0];
         if (d.lost_demand && !(after >= 0.f)) g_after = 0.f;
         float g_on_hand;
         if (d.maximize_profit) {
             if (after >= 0.f) g_after += gr * h;
-            float share = on_hand < dem ? 1.f : (on_hand == dem ? 0.5f : 0.f);  // minimum() tie rule
+            const float share = on_hand < dem ? 1.f : (on_hand == dem ? 0.5f : 0.f);  // minimum() tie rule
             g_on_hand = g_after + gr * (-p) * share;
         } else {
             float gc = 0.f;
@@ -271,16 +287,34 @@ NIC_HD void env_step_bwd_scenario(const NicEnvStepIO& io, const float* g_store_o
             if (after >= 0.f) gc += h;    // d/d(after) of h*clamp(after, 0)
             g_on_hand = g_after + gr * gc;
         }
-        store_pipeline_grad<MAXW>(g_store_in + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, gn,
-                                  g_on_hand);
+        store_pipeline_grad<MAXW>(g_store_in + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, gn, g_on_hand);
         for (int w = 0; w < nsup; ++w) {
             const float a = t3(io.store_orders, s, w, b);
             float ga = (a != 0.f) ? pick<MAXW>(gn, d.store_slots, (int)t3(io.lead_times, s, w, b) - 1) : 0.f;
-            float* dst = g_store_orders + ((int64_t)s * nsup + w) * ldb + b;
-            if (d.n_warehouses > 0) ga += *dst;  // outflow term written in the warehouse pass above
-            *dst = ga;
+            if (d.n_warehouses > 0) ga += -g_wafter(w);  // the outflow sum has no zero filter (:247)
+            g_store_orders[((int64_t)s * nsup + w) * ldb + b] = ga;
         }
     }
+}
+
+// reference composition for one scenario (host-side test build)
+template <int MAXW>
+NIC_HD void env_step_bwd_scenario(const NicEnvStepIO& io, const float* g_store_out, const float* g_wh_out,
+                                  const float* g_ech_out, const NicTable2& g_reward, float* g_store_in,
+                                  float* g_wh_in, float* g_ech_in, float* g_store_orders, float* g_wh_orders,
+                                  float* g_ech_orders, int64_t b) {
+    const NicEnvDims& d = io.dims;
+    const float gr = g_reward.p[b * g_reward.scn_stride];
+    float g_to_wh_orders = 0.f;
+    if (d.n_echelons > 0) g_to_wh_orders = env_bwd_echelons<MAXW>(io, g_ech_out, gr, g_ech_in, g_ech_orders, b);
+    float gwa[NIC_MAX_WAREHOUSES];
+    for (int w = 0; w < d.n_warehouses; ++w) {
+        const float shipped = combine4(env_ship_partial(io, w, b, 0), env_ship_partial(io, w, b, 1),
+                                       env_ship_partial(io, w, b, 2), env_ship_partial(io, w, b, 3));
+        gwa[w] = env_bwd_warehouse<MAXW>(io, g_wh_out, gr, g_to_wh_orders, w, shipped, g_wh_in, g_wh_orders, b);
+    }
+    for (int q = 0; q < kQuad; ++q)
+        env_bwd_stores<MAXW>(io, g_store_out, gr, [&](int w) { return gwa[w]; }, g_store_in, g_store_orders, b, q);
 }
 
 }  // namespace nic

@@ -6,12 +6,15 @@
 namespace {
 constexpr int kBlock = 64;
 
+// grid.y = min(Wn, 4): the warehouses of a scenario are independent, so up to four lanes share one scenario
 __global__ __launch_bounds__(kBlock) void head_warehouse_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ wh_inv,
                                                                     const int32_t* __restrict__ adj, float ub, int trans,
                                                                     float* __restrict__ so, float* __restrict__ wo, int S,
                                                                     int Wn, int Ww, int B, int64_t ldb) {
     const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (b < B) nic::head_warehouse_fwd_scenario(Z, wh_inv, adj, ub, trans, so, wo, S, Wn, Ww, ldb, b);
+    if (b >= B) return;
+    for (int w = blockIdx.y; w < Wn; w += gridDim.y)
+        nic::head_warehouse_fwd_one(Z, wh_inv, adj, ub, trans, so, wo, S, Wn, Ww, ldb, b, w);
 }
 __global__ __launch_bounds__(kBlock) void head_warehouse_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ wh_inv,
                                                                     const int32_t* __restrict__ adj, float ub, int trans,
@@ -19,7 +22,9 @@ __global__ __launch_bounds__(kBlock) void head_warehouse_bwd_kernel(const float*
                                                                     float* __restrict__ dZ, float* g_wh_inv, int S, int Wn,
                                                                     int Ww, int B, int64_t ldb) {
     const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (b < B) nic::head_warehouse_bwd_scenario(Z, wh_inv, adj, ub, trans, gso, gwo, dZ, g_wh_inv, S, Wn, Ww, ldb, b);
+    if (b >= B) return;
+    for (int w = blockIdx.y; w < Wn; w += gridDim.y)
+        nic::head_warehouse_bwd_one(Z, wh_inv, adj, ub, trans, gso, gwo, dZ, g_wh_inv, S, Wn, Ww, ldb, b, w);
 }
 __global__ void head_softplus_fwd_kernel(const float* __restrict__ Z, float* __restrict__ o, int rows, int B, int64_t ldb) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,7 +63,7 @@ int nic_head_warehouse_fwd(const float* Z, const float* wh_inv, const int32_t* a
                            int32_t n_scenarios, int32_t ldb, void* stream) {
     NIC_REQUIRE(Z && wh_inv && adjacency && store_orders && wh_orders, "nic_head_warehouse_fwd: null buffer");
     NIC_REQUIRE(S > 0 && Wn > 0 && Ww > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_warehouse_fwd: bad sizes");
-    hipLaunchKernelGGL(head_warehouse_fwd_kernel, dim3(nic::ceil_div(n_scenarios, kBlock)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(head_warehouse_fwd_kernel, dim3(nic::ceil_div(n_scenarios, kBlock), Wn < 4 ? Wn : 4), dim3(kBlock), 0,
                        nic::as_stream(stream), Z, wh_inv, adjacency, upper_bound, transshipment, store_orders, wh_orders, S,
                        Wn, Ww, n_scenarios, (int64_t)ldb);
     return nic::check_launch("nic_head_warehouse_fwd");
@@ -71,7 +76,7 @@ int nic_head_warehouse_bwd(const float* Z, const float* wh_inv, const int32_t* a
     NIC_REQUIRE(Z && wh_inv && adjacency && g_store_orders && g_wh_orders && dZ && g_wh_inv,
                 "nic_head_warehouse_bwd: null buffer");
     NIC_REQUIRE(S > 0 && Wn > 0 && Ww > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_warehouse_bwd: bad sizes");
-    hipLaunchKernelGGL(head_warehouse_bwd_kernel, dim3(nic::ceil_div(n_scenarios, kBlock)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(head_warehouse_bwd_kernel, dim3(nic::ceil_div(n_scenarios, kBlock), Wn < 4 ? Wn : 4), dim3(kBlock), 0,
                        nic::as_stream(stream), Z, wh_inv, adjacency, upper_bound, transshipment, g_store_orders, g_wh_orders,
                        dZ, g_wh_inv, S, Wn, Ww, n_scenarios, (int64_t)ldb);
     return nic::check_launch("nic_head_warehouse_bwd");
