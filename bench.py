@@ -212,9 +212,22 @@ def main():
                     out["roofline"]["traffic_source"] = tr["source"]
                 out["kernels"] = {k: {kk: round(vv, 5) if isinstance(vv, float) else vv for kk, vv in v.items()}
                                   for k, v in sorted(gemm.items())}
+                pp = setting["problem_params"]
+                Wn_, E_ = pp["n_warehouses"], pp["n_extra_echelons"]
+                Ws_ = data["initial_inventories"].shape[2]
+                Ww_ = data["initial_warehouse_inventories"].shape[2] if Wn_ else 0
+                We_ = data["initial_echelon_inventories"].shape[2] if E_ else 0
+                # state read + write, demand, orders, reward (static tables amortised over T)
+                env_bytes = 4.0 * (2 * (S * Ws_ + Wn_ * Ww_ + E_ * We_) + S + (S * max(Wn_, 1) + Wn_ + E_) + 1) * n
                 for tag in ("env_fwd", "env_bwd"):
                     if tag in summ:
                         out["kernels"][tag] = {"launches": summ[tag][0], "mean_ms": round(summ[tag][1], 5)}
+                if "env_fwd" in summ:
+                    gbs = env_bytes / (summ["env_fwd"][1] * 1e-3) / 1e9
+                    out["roofline_env_step"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                                                "frac": gbs / 8000.0, "kernel": "env_step_fwd_kernel",
+                                                "algorithmic_bytes_per_launch": env_bytes,
+                                                "mean_launch_ms": summ["env_fwd"][1]}
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or {"cfg3": 4096, "cfg5": 1024, "cfg2": 32768, "cfg4": 16384, "cfg1": 256}.get(args.workload, 1024)
             try:
