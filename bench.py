@@ -219,7 +219,7 @@ def main():
                 We_ = data["initial_echelon_inventories"].shape[2] if E_ else 0
                 # state read + write, demand, orders, reward (static tables amortised over T)
                 env_bytes = 4.0 * (2 * (S * Ws_ + Wn_ * Ww_ + E_ * We_) + S + (S * max(Wn_, 1) + Wn_ + E_) + 1) * n
-                for tag in ("env_fwd", "env_bwd"):
+                for tag in ("env_fwd", "env_bwd", "small_rollout_fwd", "small_rollout_bwd"):
                     if tag in summ:
                         out["kernels"][tag] = {"launches": summ[tag][0], "mean_ms": round(summ[tag][1], 5)}
                 if "env_fwd" in summ:

@@ -168,6 +168,41 @@ int nic_head_serial_bwd(const float* Z, const float* wh_inv, const float* ech_in
                         float* dZ, float* g_wh_inv, float* g_ech_inv, int32_t E, int32_t Ww, int32_t We,
                         int32_t n_scenarios, int32_t ldb, void* stream);
 
+/* ---- whole-horizon rollout of the small policies --------------------------------------------------------------
+ * One kernel runs ALL T periods of Trainer.simulate_batch (trainer.py:190-213) for the one-store chain settings
+ * (one_store_lost / one_store_backlogged / serial_system: S = 1, Wn <= 1, E <= 3) with a 32-wide MLP policy:
+ * vanilla_one_store (neural_networks.py:195-214, head 0) or vanilla_serial (:314-355, head 1).  One lane = one scenario;
+ * pipeline slots and activations stay in registers across the horizon.  The state block is [F][ldb] in the reference's
+ * cat(flatten(...)) order: store slots, then warehouse slots, then echelon slots. */
+#define NIC_SR_MAX_INPUTS 16  /* F  = Ws + Wn*Ww + E*We */
+#define NIC_SR_HIDDEN 32      /* width of every hidden layer */
+#define NIC_SR_MAX_OUTPUTS 8
+typedef struct NicSmallRolloutDesc {
+    int32_t n_scenarios, ldb, T, t0;       /* t0 = observation_params['demand']['period_shift'] */
+    int32_t F, n_hidden, n_out, head;      /* n_hidden in 1..3; head 0: softplus(z+1), 1: sigmoid(z) * upstream on-hand */
+    int32_t Ws, Wn, Ww, E, We;
+    int32_t lost_demand, maximize_profit;
+    int32_t detach_input;                  /* 1: no gradient through the MLP input (vanilla_serial, :329) */
+    float upper_bound;                     /* model.warehouse_upper_bound (head 1) */
+    const float* weights;                  /* packed: [W1 32xF][b1 32] [W_l 32x32][b_l 32]... [Wout n_out x 32][bout n_out] */
+    const float* demand;                   /* [T_total][ldb] */
+    const float* state0;                   /* [F][ldb] */
+    NicTable2 underage, holding, lead;     /* store tables (loc index 0) */
+    NicTable2 wh_holding, wh_lead, wh_edge;
+    NicTable2 ech_holding, ech_lead;       /* (e, b) */
+} NicSmallRolloutDesc;
+
+/* Forward: rewards [T][ldb] (per-period per-scenario cost), state_final [F][ldb].  When states_hist != NULL the
+ * activations the backward needs are stored, every row contiguous over (t, b): states_hist [F][T][ldb],
+ * hidden_hist [32*n_hidden][T][ldb] (post-ELU), logits_hist [n_out][T][ldb]. */
+int nic_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* state_final, float* states_hist,
+                          float* hidden_hist, float* logits_hist, void* stream);
+/* Backward sweep over the stored activations: g_reward (b) = d loss / d reward[b, t] (same for every t).  Emits the
+ * pre-activation gradients dz_hidden [32*n_hidden][T][ldb] and dz_out [n_out][T][ldb]; the weight gradients are then
+ * nic_linear_wgrad contractions over n_scenarios = T*ldb with ldb = T*ldb (layer l: dY = its dz rows, X = its input rows). */
+int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
+                          const float* logits_hist, NicTable2 g_reward, float* dz_hidden, float* dz_out, void* stream);
+
 /* ---- batched demand sampler -------------------------------------------------------------------------------
  * Replaces Scenario.generate_normal_demand / generate_poisson_demand (data_handling.py:178-211) for synthetic
  * throughput runs: counter-based Philox4x32-10 keyed by (seed, global scenario index, period), so results do not

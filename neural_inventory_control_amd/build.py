@@ -17,8 +17,9 @@ SOURCES = [
     ("policy_heads.hip", ["-ffp-contract=off"]),
     ("linear_mfma.hip", []),
     ("sampler.hip", []),
+    ("small_rollout.hip", ["-ffp-contract=off"]),
 ]
-HEADERS = ["nic_common.h", "env_step_body.h", "policy_heads_body.h", os.path.join("..", "..", "include", "nic_rollout.h")]
+HEADERS = ["nic_common.h", "env_step_body.h", "policy_heads_body.h", "small_rollout_body.h", os.path.join("..", "..", "include", "nic_rollout.h")]
 ARCH = "gfx950"
 
 

@@ -18,6 +18,7 @@ transfers are the two scalars the trainer reports.
 import torch
 
 from . import _lib, ops
+from . import small_rollout as sr
 from .layout import EnvProblem, Table, pad_ld
 from .ops import EnvState
 
@@ -79,6 +80,8 @@ class FusedRollout:
         self._key = None
         self.timer = None  # KernelTimer or None
         self.use_graph = False  # replay the launch sequence from a HIP graph (see _replay_or_capture)
+        self.use_small = True   # whole-horizon kernels for the small one-store-chain policies (small_rollout.py)
+        self.small = None       # SmallRolloutPlan when the current shapes take that route
         self._prob = None
 
     def _k(self, tag, fn, *args, **kw):
@@ -128,6 +131,25 @@ class FusedRollout:
         self.dims = dims
         L = len(lins)
         z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+        self.small = None
+        if self.use_small and all(m.bias is not None for m in lins) and sr.SmallRolloutPlan.supports(prob, self.head, dims):
+            # ---- whole-horizon route: one forward kernel, one backward kernel, one wgrad GEMM per layer ------------------
+            plan = self.small = sr.SmallRolloutPlan(prob, self.head, dims)
+            nh, no = plan.n_hidden, plan.n_out
+            self.rewards = z(T, ld)
+            self.sr_final = z(F, ld)
+            self.sr_state0 = z(F, ld)
+            self.sr_weights = z(sr.packed_weight_count(F, nh, no))
+            if train:
+                self.sr_states, self.sr_hidden, self.sr_logits = z(F, T, ld), z(nh * sr.H, T, ld), z(no, T, ld)
+                self.sr_dzh, self.sr_dzo = z(nh * sr.H, T, ld), z(no, T, ld)
+                self.g_reward = z(ld)
+                self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], T * ld) for i in range(L)]
+                self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
+                self.gw = [torch.zeros_like(m.weight) for m in lins]
+                self.gb = [torch.zeros_like(m.bias) for m in lins]
+            self._key = key
+            return
         self.states = z(T + 1, self.F_store + self.F_wh + self.F_ech, ld)
         n_ord = prob.S * prob.nsup + prob.Wn + prob.E
         self.orders = z(T, n_ord, ld)
@@ -221,6 +243,10 @@ class FusedRollout:
         if demand_soa.shape[0] < T + shift:
             raise ValueError("Current period is greater than the number of periods in the data")
 
+        if self.small is not None:
+            return self._run_small(data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale,
+                                   accumulate_grads)
+
         # engine copies of the weights (tiny) — refreshed every call because the optimizer moves them
         lins = self._linears()
         L = len(lins)
@@ -261,6 +287,45 @@ class FusedRollout:
             for p, g in ((m.weight, self.gw[i]), (m.bias, self.gb[i])):
                 if p is None:
                     continue
+                if accumulate_grads and p.grad is not None and p.grad is not g:
+                    p.grad.add_(g)
+                else:
+                    p.grad = g
+        return total, reported
+
+    # ---- whole-horizon route for the small policies -------------------------------------------------------------------
+    def _run_small(self, data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale, accumulate_grads):
+        plan, lins = self.small, self._linears()
+        sr.pack_weights(lins, self.sr_weights)
+        s0 = self._views(self.sr_state0, prob)
+        s0.store[:, :, :B].copy_(data["initial_inventories"].permute(1, 2, 0))
+        if prob.Wn:
+            s0.wh[:, :, :B].copy_(data["initial_warehouse_inventories"].permute(1, 2, 0))
+        if prob.E:
+            s0.ech[:, :, :B].copy_(data["initial_echelon_inventories"].permute(1, 2, 0))
+        ub = self._ub() if self.head != "softplus" else 0.0
+        desc = plan.desc(T, shift, self.sr_weights, demand_soa, self.sr_state0, ub)
+        hist = (self.sr_states, self.sr_hidden, self.sr_logits) if train else (None, None, None)
+        self._k("small_rollout_fwd", sr.small_rollout_fwd, desc, self.rewards, self.sr_final, *hist)
+        total = self.rewards.sum()
+        reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
+        if not train:
+            return total, reported
+        if grad_scale is None:
+            grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
+        self.g_reward.zero_()
+        self.g_reward[:B] = grad_scale
+        self._k("small_rollout_bwd", sr.small_rollout_bwd, desc, *hist, Table(self.g_reward, 0, 1), self.sr_dzh, self.sr_dzo)
+        # weight gradients: contraction over (period, scenario) = T*ld columns; padding columns of dZ are zero
+        n_cols, nh = T * ld, plan.n_hidden
+        inputs = [self.sr_states] + [self.sr_hidden[sr.H * l:sr.H * (l + 1)] for l in range(nh)]
+        dzs = [self.sr_dzh[sr.H * l:sr.H * (l + 1)] for l in range(nh)] + [self.sr_dzo]
+        for i, m in enumerate(lins):
+            self.slabs[i].zero_()
+            dy, x = dzs[i].reshape(dzs[i].shape[0], n_cols), inputs[i].reshape(inputs[i].shape[0], n_cols)
+            self._k(f"wgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad, dy, x, self.slabs[i], n_cols)
+            ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], self.dims[i], 1.0)
+            for p, g in ((m.weight, self.gw[i]), (m.bias, self.gb[i])):
                 if accumulate_grads and p.grad is not None and p.grad is not g:
                     p.grad.add_(g)
                 else:
@@ -352,7 +417,7 @@ class FusedRollout:
 
     def final_state(self):
         from .layout import ref_view
-        st = self._views(self.states[-1], self.prob)
+        st = self._views(self.sr_final if self.small is not None else self.states[-1], self.prob)
         out = {"store_inventories": ref_view(st.store, self.prob.B)}
         if st.wh is not None:
             out["warehouse_inventories"] = ref_view(st.wh, self.prob.B)

@@ -3,6 +3,7 @@
 // product library; the product has no CPU path.
 #include "../../neural_inventory_control_amd/csrc/env_step_body.h"
 #include "../../neural_inventory_control_amd/csrc/policy_heads_body.h"
+#include "../../neural_inventory_control_amd/csrc/small_rollout_body.h"
 
 template <int MAXW>
 static void fwd_all(const NicEnvStepIO& io, float* so, float* wo, float* eo, float* r) {
@@ -58,6 +59,24 @@ int hostsim_head_serial_bwd(const float* Z, const float* wh_inv, const float* ec
                             int32_t Ww, int32_t We, int32_t B, int32_t ldb) {
     for (int64_t b = 0; b < B; ++b)
         nic::head_serial_bwd_scenario(Z, wh_inv, ech_inv, ub, gso, gwo, geo, dZ, gwi, gei, E, Ww, We, ldb, b);
+    return 0;
+}
+int hostsim_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* state_final, float* states_hist,
+                              float* hidden_hist, float* logits_hist) {
+    for (int64_t b = 0; b < d->n_scenarios; ++b) {
+        if (d->n_hidden == 1) nic::small_rollout_fwd_scenario<1>(*d, rewards, state_final, states_hist, hidden_hist, logits_hist, b);
+        else if (d->n_hidden == 2) nic::small_rollout_fwd_scenario<2>(*d, rewards, state_final, states_hist, hidden_hist, logits_hist, b);
+        else nic::small_rollout_fwd_scenario<3>(*d, rewards, state_final, states_hist, hidden_hist, logits_hist, b);
+    }
+    return 0;
+}
+int hostsim_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
+                              const float* logits_hist, NicTable2 g_reward, float* dz_hidden, float* dz_out) {
+    for (int64_t b = 0; b < d->n_scenarios; ++b) {
+        if (d->n_hidden == 1) nic::small_rollout_bwd_scenario<1>(*d, states_hist, hidden_hist, logits_hist, g_reward, dz_hidden, dz_out, b);
+        else if (d->n_hidden == 2) nic::small_rollout_bwd_scenario<2>(*d, states_hist, hidden_hist, logits_hist, g_reward, dz_hidden, dz_out, b);
+        else nic::small_rollout_bwd_scenario<3>(*d, states_hist, hidden_hist, logits_hist, g_reward, dz_hidden, dz_out, b);
+    }
     return 0;
 }
 }

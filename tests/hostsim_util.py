@@ -18,7 +18,7 @@ def load():
         return _h
     os.makedirs(OUT_DIR, exist_ok=True)
     deps = [SRC] + [os.path.join(HERE, "..", "neural_inventory_control_amd", "csrc", f)
-                    for f in ("env_step_body.h", "policy_heads_body.h")] + [os.path.join(HERE, "..", "include", "nic_rollout.h")]
+                    for f in ("env_step_body.h", "policy_heads_body.h", "small_rollout_body.h")] + [os.path.join(HERE, "..", "include", "nic_rollout.h")]
     if not os.path.isfile(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", OUT])
     h = C.CDLL(OUT)
@@ -32,5 +32,8 @@ def load():
     h.hostsim_head_softplus_bwd.argtypes = [vp, vp, vp, i32, i32, i32]
     h.hostsim_head_serial_fwd.argtypes = [vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32]
     h.hostsim_head_serial_bwd.argtypes = [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32]
+    SRP = C.POINTER(_lib.NicSmallRolloutDesc)
+    h.hostsim_small_rollout_fwd.argtypes = [SRP, vp, vp, vp, vp, vp]
+    h.hostsim_small_rollout_bwd.argtypes = [SRP, vp, vp, vp, _lib.NicTable2, vp, vp]
     _h = h
     return h

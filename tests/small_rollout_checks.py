@@ -1,0 +1,81 @@
+"""Parity of the whole-horizon small-policy rollout (small_rollout_body.h) against the reference's golden vectors:
+per-period rewards, final state and d(mean_loss)/d(theta).  Backend-agnostic like kernel_checks.py: the host build of
+the bodies (CPU suite) and the HIP kernels through the C ABI (GPU suite) run the same check."""
+import numpy as np
+import torch
+
+from golden_io import Golden
+from neural_inventory_control_amd import _lib, small_rollout as sr
+from neural_inventory_control_amd.layout import EnvProblem, Table, pad_ld, to_soa
+
+SMALL_CASES = ["cfg1_one_store_lost_vanilla", "cfg2_one_store_backlogged_vanilla", "cfg4_serial_vanilla"]
+P = lambda x: x.data_ptr() if x is not None else None  # noqa: E731
+
+
+class _Lin:
+    def __init__(self, w, b):
+        self.weight, self.bias = w, b
+
+
+def run_case(name, fwd, bwd, dev, sync=lambda: None, profit=False):
+    """fwd(desc, rewards, state_final, states_hist, hidden_hist, logits_hist); bwd(desc, sh, hh, lh, g_reward(NicTable2), dzh, dzo)"""
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(dev) for k, v in g.data.items()}
+    prob = EnvProblem(c["problem_params"], data, dev)
+    head = "softplus" if c["policy"] == "vanilla_one_store" else "serial"
+    params = g.params
+    idx = sorted({int(k.split(".")[2]) for k in params})
+    lins = [_Lin(params[f"net.master.{i}.weight"].to(dev), params[f"net.master.{i}.bias"].to(dev)) for i in idx]
+    dims = [lins[0].weight.shape[1]] + [m.weight.shape[0] for m in lins]
+    assert sr.SmallRolloutPlan.supports(prob, head, dims), (name, dims)
+    plan = sr.SmallRolloutPlan(prob, head, dims)
+    T, B, ld, F = c["periods"], c["n"], prob.ldb, plan.F
+    weights = sr.pack_weights(lins)
+    assert weights.numel() == sr.packed_weight_count(F, plan.n_hidden, plan.n_out)
+    demand = torch.zeros(data["demands"].shape[2], 1, ld, device=dev)
+    demand[:, :, :B] = data["demands"].permute(2, 1, 0)
+    parts = [to_soa(data["initial_inventories"], ld).reshape(-1, ld)]
+    if prob.Wn:
+        parts.append(to_soa(data["initial_warehouse_inventories"], ld).reshape(-1, ld))
+    if prob.E:
+        parts.append(to_soa(data["initial_echelon_inventories"], ld).reshape(-1, ld))
+    state0 = torch.cat(parts).contiguous()
+    ub = float(g.z["warehouse_upper_bound"][0])
+    desc = plan.desc(T, 0, weights, demand, state0, ub)
+    z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    rewards, final = z(T, ld), z(F, ld)
+    sh, hh, lh = z(F, T, ld), z(plan.n_hidden * 32, T, ld), z(plan.n_out, T, ld)
+    fwd(desc, rewards, final, sh, hh, lh)
+    sync()
+    ref_r = g.tensor("rewards")
+    torch.testing.assert_close(rewards[:, :B].cpu(), ref_r, rtol=1e-5, atol=1e-4)
+    tot_b, ref_b = rewards[:, :B].double().sum(dim=0).cpu(), ref_r.double().sum(dim=0)
+    assert float(((tot_b - ref_b).abs() / ref_b.abs().clamp_min(1e-9)).max()) <= 1e-5
+    fin = g.states(T)
+    want = [fin["store_inventories"].reshape(B, -1)]
+    if prob.Wn:
+        want.append(fin["warehouse_inventories"].reshape(B, -1))
+    if prob.E:
+        want.append(fin["echelon_inventories"].reshape(B, -1))
+    torch.testing.assert_close(final[:, :B].t().cpu(), torch.cat(want, dim=1), rtol=1e-4, atol=2e-3)
+    assert float(rewards[:, B:].abs().sum()) == 0.0
+
+    # backward: dZ of every layer, then the weight gradients as contractions over (t, b)
+    gr = z(ld)
+    gr[:B] = 1.0 / (B * T * c["problem_params"]["n_stores"])
+    dzh, dzo = z(plan.n_hidden * 32, T, ld), z(plan.n_out, T, ld)
+    bwd(desc, sh, hh, lh, Table(gr, 0, 1).t2(), dzh, dzo)
+    sync()
+    ref = g.grads
+    inputs = [sh] + [hh[32 * l:32 * (l + 1)] for l in range(plan.n_hidden)]
+    dzs = [dzh[32 * l:32 * (l + 1)] for l in range(plan.n_hidden)] + [dzo]
+    worst = 0.0
+    for li, i in enumerate(idx):
+        dz, x = dzs[li].double().reshape(dzs[li].shape[0], -1).cpu(), inputs[li].double().reshape(inputs[li].shape[0], -1).cpu()
+        gw, gb = dz @ x.t(), dz.sum(dim=1)
+        for got, key in ((gw, f"net.master.{i}.weight"), (gb, f"net.master.{i}.bias")):
+            rel = float((got - ref[key].double()).norm() / (ref[key].double().norm() + 1e-30))
+            worst = max(worst, rel)
+            assert rel <= 2e-5, (key, rel)
+    return dict(desc=desc, plan=plan, rewards=rewards, sh=sh, hh=hh, lh=lh, dzh=dzh, dzo=dzo, worst=worst)

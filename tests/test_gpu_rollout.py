@@ -238,6 +238,7 @@ def test_graph_replay_matches_eager(name):
         model = _model(g, c)
         eng = FusedRollout(model, c["problem_params"], DEV)
         eng.use_graph = mode == "graph"
+        eng.use_small = False  # the whole-horizon route is three launches; graphs matter for the per-period route
         eng.materialize(F)
         _load(model, g)
         out = []
@@ -295,3 +296,47 @@ def test_trainer_train_loop_checkpoint_and_test(tmp_path):
         assert torch.equal(v, best[k])
     _, rep = tr.test(PolicyLoss(), sim, model, loaders, opt, setting["problem_params"], obs, pbd)
     assert abs(rep - tr.best_performance_data["dev_loss"]) < 1e-4 * abs(rep)
+
+
+@pytest.mark.parametrize("name", ["cfg1_one_store_lost_vanilla", "cfg2_one_store_backlogged_vanilla", "cfg4_serial_vanilla"])
+def test_small_rollout_kernels_match_reference(name):
+    """Whole-horizon kernels (nic_small_rollout_fwd/bwd through the C ABI) against the reference's golden vectors."""
+    import small_rollout_checks as src
+    from neural_inventory_control_amd import small_rollout as sr
+    out = src.run_case(name, sr.small_rollout_fwd,
+                       lambda d, sh, hh, lh, gr, dzh, dzo: _lib.check(_lib.lib().nic_small_rollout_bwd(
+                           d, sh.data_ptr(), hh.data_ptr(), lh.data_ptr(), gr, dzh.data_ptr(), dzo.data_ptr(),
+                           _lib.current_stream())),
+                       DEV, sync=torch.cuda.synchronize)
+    assert out["worst"] <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["cfg2_one_store_backlogged_vanilla", "cfg4_serial_vanilla"])
+def test_small_route_equals_per_period_route(name):
+    """FusedRollout takes the whole-horizon route for these policies; it must agree with its own per-period route."""
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    F = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
+    if c["policy"] != "vanilla_one_store":
+        F += sum(int(np.prod(data[k].shape[1:])) for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
+                 if k in data)
+    res = {}
+    for small in (True, False):
+        model = _model(g, c)
+        eng = FusedRollout(model, c["problem_params"], DEV)
+        eng.use_small = small
+        eng.materialize(F)
+        _load(model, g)
+        total, rep = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+        torch.cuda.synchronize()
+        assert (eng.small is not None) == small
+        res[small] = (float(total), float(rep), eng.per_period_rewards().clone(), [p.grad.clone() for p in model.parameters()],
+                      {k: v.clone() for k, v in eng.final_state().items()})
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 2e-6 * abs(b[1])
+    torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-4)
+    for x, y in zip(a[3], b[3]):
+        assert float((x - y).norm() / (y.norm() + 1e-30)) < 2e-5
+    for k in b[4]:
+        torch.testing.assert_close(a[4][k], b[4][k], **STATE_TOL)
