@@ -1018,8 +1018,8 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
         target = 256;
     }
     if (N <= 32 && K <= 32) {  // wgrad_small_kernel: one split per wave (multiple of 4), >= 512 columns each
-        int sp = (int)(((int64_t)n_scenarios + 511) / 512);
-        if (sp > 4096) sp = 4096;
+        int sp = (int)(((int64_t)n_scenarios + 2047) / 2048);
+        if (sp > 1024) sp = 1024;  // one wave per SIMD
         return (sp + 3) / 4 * 4;
     }
     int splits = (target + tiles - 1) / tiles;
@@ -1056,13 +1056,35 @@ int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds_,
     return nic::check_launch("nic_linear_wgrad");
 }
 
+// many splits, few outputs (the small layers): one wavefront per output element, lanes stride over the splits
+__global__ void wgrad_reduce_wide_kernel(const float* __restrict__ slab, int64_t lds_, int n_splits, float* __restrict__ dW,
+                                         int64_t lddw, float* __restrict__ db, int N, int K, float scale) {
+    const int64_t idx = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (idx >= (int64_t)N * (K + 1)) return;
+    const int n = (int)(idx / (K + 1)), k = (int)(idx % (K + 1));
+    float s = 0.f;
+    for (int sp = lane; sp < n_splits; sp += 64) s += slab[((int64_t)sp * N + n) * lds_ + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        s *= scale;
+        if (k < K) dW[(int64_t)n * lddw + k] = s;
+        else if (db) db[n] = s;
+    }
+}
+
 int nic_wgrad_reduce(const float* slab, int64_t lds_, int32_t n_splits, float* dW, int64_t lddw, float* db, int32_t N,
                      int32_t K, float scale, void* stream) {
     NIC_REQUIRE(slab && dW, "nic_wgrad_reduce: null buffer");
     NIC_REQUIRE(N > 0 && K > 0 && lds_ >= K + 1 && lddw >= K && n_splits >= 1, "nic_wgrad_reduce: bad sizes");
     const int64_t total = (int64_t)N * (K + 1);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nic::ceil_div(total, 256)), dim3(256), 0, nic::as_stream(stream), slab, lds_,
-                       n_splits, dW, lddw, db, N, K, scale);
+    if (n_splits >= 128 && total <= 65536)
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(nic::ceil_div(total, 4)), dim3(256), 0, nic::as_stream(stream), slab,
+                           lds_, n_splits, dW, lddw, db, N, K, scale);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nic::ceil_div(total, 256)), dim3(256), 0, nic::as_stream(stream), slab, lds_,
+                           n_splits, dW, lddw, db, N, K, scale);
     return nic::check_launch("nic_wgrad_reduce");
 }
 }

@@ -82,6 +82,7 @@ class FusedRollout:
         self.use_graph = False  # replay the launch sequence from a HIP graph (see _replay_or_capture)
         self.use_small = True   # whole-horizon kernels for the small one-store-chain policies (small_rollout.py)
         self.small = None       # SmallRolloutPlan when the current shapes take that route
+        self._prob_cache = {}
         self._prob = None
 
     def _k(self, tag, fn, *args, **kw):
@@ -217,7 +218,7 @@ class FusedRollout:
         Returns (total, reported) as 0-d device tensors = simulate_batch's return values (trainer.py:216).
         """
         dev = self.device
-        prob = EnvProblem(self.problem_params, data, dev)
+        prob = self._problem_for(data)
         T, B, ld = periods, prob.B, prob.ldb
         self._setup(prob, T, train)
         if self.use_graph:
@@ -292,6 +293,23 @@ class FusedRollout:
                 else:
                     p.grad = g
         return total, reported
+
+    _STATIC_KEYS = ("underage_costs", "holding_costs", "lead_times", "warehouse_holding_costs", "warehouse_lead_times",
+                    "warehouse_edge_costs", "echelon_holding_costs", "echelon_lead_times", "initial_inventories",
+                    "initial_warehouse_inventories", "initial_echelon_inventories")
+
+    def _problem_for(self, data):
+        """EnvProblem of a batch.  Building one compacts the static tables and checks them for scenario-uniformity, which
+        reads a flag back from the device (a sync); batches that present the SAME tensors again (same storage, shape and
+        in-place version — e.g. every step of a benchmark, or the fixed batches of an un-shuffled loader) reuse it."""
+        key = tuple((k, data[k].data_ptr(), tuple(data[k].shape), tuple(data[k].stride()), data[k]._version)
+                    for k in self._STATIC_KEYS if k in data and data[k] is not None)
+        hit = self._prob_cache.get(key)
+        if hit is None:
+            if len(self._prob_cache) >= 16:
+                self._prob_cache.pop(next(iter(self._prob_cache)))
+            hit = self._prob_cache[key] = EnvProblem(self.problem_params, data, self.device)
+        return hit
 
     # ---- whole-horizon route for the small policies -------------------------------------------------------------------
     def _run_small(self, data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale, accumulate_grads):
