@@ -4,6 +4,8 @@
 // (wave-uniform) weight reads invariant and issues them on the scalar path (s_load) instead of 64-lane vector loads.
 // VALU-bound: ~2 * params FMAs per scenario-period forward; HBM traffic is 4 B (demand) + 4 B (reward) per scenario-period
 // plus, when training, the stored activations (4 * (F + 32 * n_hidden + n_out) B).
+#include <stdlib.h>
+
 #include "nic_common.h"
 #include "small_rollout_body.h"
 
@@ -54,6 +56,129 @@ __global__ __launch_bounds__(kBlock) void small_rollout_bwd_kernel(NicSmallRollo
     nic::small_rollout_bwd_scenario<NL>(d, states_hist, hidden_hist, logits_hist, g_reward, dz_hidden, dz_out, b);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MFMA form of the whole-horizon FORWARD: one wavefront = 32 scenarios; the 32-wide layers run on the matrix cores with
+// the weights RESIDENT IN VGPRs for the whole horizon (no per-period weight traffic at all — the per-lane VALU form above
+// re-reads ~2.3k weights from LDS every period and is bound by that latency).
+//   layer output D[neuron i][scenario j] = sum_k W[i][k] H[k][j]:  A = W (lane l holds A[i = l&31][kk = l>>5]),
+//   B = activations (lane l holds B[kk = l>>5][j = l&31]), C/D: lane (j, h) holds rows row(r, h) = (r&3) + 8(r>>2) + 4h.
+//   MFMA step s of the NEXT layer is defined to contract over k = row(s, h): its B operand is then exactly register s of
+//   the previous layer's accumulator — no data movement between layers; the A fragments are loaded in that k order once.
+//   The bias is the initial accumulator.  Both halves of the wave carry the same 32 scenarios (different neuron rows), so
+//   the per-scenario state and the env step are simply replicated in both halves.
+// ---------------------------------------------------------------------------------------------------------------
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int NL>
+__global__ __launch_bounds__(64) void small_rollout_fwd_mfma_kernel(NicSmallRolloutDesc d, const float* __restrict__ weights,
+                                                                    const float* __restrict__ demand,
+                                                                    const float* __restrict__ state0, float* __restrict__ rewards,
+                                                                    float* __restrict__ state_final, float* __restrict__ states_hist,
+                                                                    float* __restrict__ hidden_hist, float* __restrict__ logits_hist) {
+    using namespace nic;
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int64_t b_raw = (int64_t)blockIdx.x * 32 + j;
+    const bool live = b_raw < d.n_scenarios;
+    const int64_t b = live ? b_raw : 0;  // dead lanes shadow scenario 0 (they take part in the MFMAs but never store)
+    const int64_t ldb = d.ldb, tl = (int64_t)d.T * ldb;
+    d.weights = weights;
+    d.demand = demand;
+    d.state0 = state0;
+
+    // ---- weight fragments, resident for the whole horizon
+    const int i = j;  // A-operand row owned by this lane
+    float aW1[8], cB[NL + 1][16];
+    float aWh[(NL > 1 ? NL - 1 : 1)][16], aWo[16];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) aW1[s] = (2 * s + h < d.F) ? weights[i * d.F + 2 * s + h] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cB[0][r] = weights[SR_H * d.F + crow(r, h)];
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        const float* Wl = weights + sr_hidden_offset(d, l);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) aWh[l - 1][s] = Wl[i * SR_H + crow(s, h)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cB[l][r] = Wl[SR_H * SR_H + crow(r, h)];
+    }
+    {
+        const float* Wo = weights + sr_out_offset(d);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) aWo[s] = (i < d.n_out) ? Wo[i * SR_H + crow(s, h)] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cB[NL][r] = (crow(r, h) < d.n_out) ? Wo[d.n_out * SR_H + crow(r, h)] : 0.f;
+    }
+
+    const SrStatics c = sr_load_statics(d, b);
+    float st[SR_MAXF];
+#pragma unroll
+    for (int k = 0; k < SR_MAXF; ++k) st[k] = k < d.F ? state0[(int64_t)k * ldb + b] : 0.f;
+
+    for (int t = 0; t < d.T; ++t) {
+        f32x16 acc;
+        float hcur[16];
+        // layer 1: contraction over the state slots, k = 2s + h
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = cB[0][r];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aW1[s], h ? st[2 * s + 1] : st[2 * s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hcur[r] = elu1(acc[r]);
+        if (states_hist && live) {
+            if (h == 0) {
+#pragma unroll
+                for (int k = 0; k < SR_MAXF; ++k)
+                    if (k < d.F) states_hist[k * tl + t * ldb + b] = st[k];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hidden_hist[(int64_t)crow(r, h) * tl + t * ldb + b] = hcur[r];
+        }
+#pragma unroll
+        for (int l = 1; l < NL; ++l) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = cB[l][r];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aWh[l - 1][s], hcur[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hcur[r] = elu1(acc[r]);
+            if (states_hist && live) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hidden_hist[(int64_t)(l * SR_H + crow(r, h)) * tl + t * ldb + b] = hcur[r];
+            }
+        }
+        // output layer: rows 0..3 land in half 0 (registers 0..3), rows 4..7 in half 1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = cB[NL][r];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aWo[s], hcur[s], acc, 0, 0, 0);
+        float z[SR_MAXOUT];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const float mine = acc[n], other = __shfl_xor(mine, 32);
+            z[n] = h == 0 ? mine : other;
+            z[n + 4] = h == 0 ? other : mine;
+        }
+        if (logits_hist && live && h == 0) {
+#pragma unroll
+            for (int n = 0; n < SR_MAXOUT; ++n)
+                if (n < d.n_out) logits_hist[n * tl + t * ldb + b] = z[n];
+        }
+        const SrOrders o = sr_head(d, z, st);
+        float nx[SR_MAXF];
+        const float dem = demand[(int64_t)(t + d.t0) * ldb + b];
+        const float cost = sr_env_fwd(d, c, st, nx, dem, o);
+        if (live && h == 0) rewards[(int64_t)t * ldb + b] = cost;
+#pragma unroll
+        for (int k = 0; k < SR_MAXF; ++k) st[k] = nx[k];
+    }
+    if (live && h == 0) {
+#pragma unroll
+        for (int k = 0; k < SR_MAXF; ++k)
+            if (k < d.F) state_final[(int64_t)k * ldb + b] = st[k];
+    }
+}
+
 int validate(const NicSmallRolloutDesc* d, const char* who) {
     NIC_REQUIRE(d != nullptr, "%s: null descriptor", who);
     NIC_REQUIRE(d->n_scenarios > 0 && d->ldb >= d->n_scenarios && d->T > 0 && d->t0 >= 0, "%s: bad sizes", who);
@@ -78,8 +203,20 @@ int nic_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* s
     if (int e = validate(d, "nic_small_rollout_fwd")) return e;
     NIC_REQUIRE(d->state0 && rewards && state_final, "nic_small_rollout_fwd: null buffer");
     NIC_REQUIRE(!states_hist || (hidden_hist && logits_hist), "nic_small_rollout_fwd: incomplete history buffers");
-    const dim3 grid(nic::ceil_div(d->n_scenarios, kBlock)), block(kBlock);
     hipStream_t s = nic::as_stream(stream);
+    static const int variant = getenv("NIC_SMALL_VARIANT") ? atoi(getenv("NIC_SMALL_VARIANT")) : 0;
+    if (variant != 1) {  // matrix-core form: 32 scenarios per wavefront
+        const dim3 g32(nic::ceil_div(d->n_scenarios, 32)), b64(64);
+#define NIC_SR_FWD_MFMA(NL)                                                                                                \
+    hipLaunchKernelGGL(small_rollout_fwd_mfma_kernel<NL>, g32, b64, 0, s, *d, d->weights, d->demand, d->state0, rewards,  \
+                       state_final, states_hist, hidden_hist, logits_hist)
+        if (d->n_hidden == 1) NIC_SR_FWD_MFMA(1);
+        else if (d->n_hidden == 2) NIC_SR_FWD_MFMA(2);
+        else NIC_SR_FWD_MFMA(3);
+#undef NIC_SR_FWD_MFMA
+        return nic::check_launch("nic_small_rollout_fwd");
+    }
+    const dim3 grid(nic::ceil_div(d->n_scenarios, kBlock)), block(kBlock);
 #define NIC_SR_FWD(NL)                                                                                                     \
     hipLaunchKernelGGL(small_rollout_fwd_kernel<NL>, grid, block, 0, s, *d, d->weights, d->demand, d->state0, rewards,    \
                        state_final, states_hist, hidden_hist, logits_hist)
