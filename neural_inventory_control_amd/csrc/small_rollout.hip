@@ -179,6 +179,135 @@ __global__ __launch_bounds__(64) void small_rollout_fwd_mfma_kernel(NicSmallRoll
     }
 }
 
+// MFMA form of the whole-horizon BACKWARD sweep: same wave shape as the forward.  The transposed weights are the resident
+// A fragments (dH_{l-1} = W_l^T dZ_l), contraction order over neurons n = crow(s, h) so the previous layer's dZ accumulator
+// registers are again the B operands as they stand.  elu'(H) comes from the stored activations, read in the C layout the
+// forward wrote them in.  Emits the same dZ history as the per-lane form for the weight-gradient GEMMs.
+template <int NL>
+__global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRolloutDesc d, const float* __restrict__ weights,
+                                                                    const float* __restrict__ demand,
+                                                                    const float* __restrict__ states_hist,
+                                                                    const float* __restrict__ hidden_hist,
+                                                                    const float* __restrict__ logits_hist, NicTable2 g_reward,
+                                                                    float* __restrict__ dz_hidden, float* __restrict__ dz_out) {
+    using namespace nic;
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int64_t b_raw = (int64_t)blockIdx.x * 32 + j;
+    const bool live = b_raw < d.n_scenarios;
+    const int64_t b = live ? b_raw : 0;
+    const int64_t ldb = d.ldb, tl = (int64_t)d.T * ldb;
+    d.weights = weights;
+    d.demand = demand;
+
+    const int i = j;  // A-operand row: the INPUT feature of the layer being back-propagated through
+    float aWoT[4], aWhT[(NL > 1 ? NL - 1 : 1)][16], aW1T[16];
+    {
+        const float* Wo = weights + sr_out_offset(d);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) aWoT[s] = (2 * s + h < d.n_out) ? Wo[(2 * s + h) * SR_H + i] : 0.f;
+    }
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        const float* Wl = weights + sr_hidden_offset(d, l);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) aWhT[l - 1][s] = Wl[crow(s, h) * SR_H + i];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) aW1T[s] = (i < d.F) ? weights[crow(s, h) * d.F + i] : 0.f;
+
+    const SrStatics c = sr_load_statics(d, b);
+    const float gr = g_reward.p[b * g_reward.scn_stride];
+    float gn[SR_MAXF];
+#pragma unroll
+    for (int k = 0; k < SR_MAXF; ++k) gn[k] = 0.f;
+
+    // The sweep is a chain of dependent HBM round trips if each period loads its own history (one wavefront per SIMD: nothing
+    // else to switch to), so period t-1's history is fetched into registers while period t is computed.
+    float st[SR_MAXF], z[SR_MAXOUT], dem, hh[NL][16];
+    float st_n[SR_MAXF], z_n[SR_MAXOUT], dem_n, hh_n[NL][16];
+    auto fetch = [&](int t, float (&fs)[SR_MAXF], float (&fz)[SR_MAXOUT], float& fd, float (&fh)[NL][16]) {
+        const int64_t at = (int64_t)t * ldb + b;
+#pragma unroll
+        for (int k = 0; k < SR_MAXF; ++k) fs[k] = k < d.F ? states_hist[k * tl + at] : 0.f;
+#pragma unroll
+        for (int n = 0; n < SR_MAXOUT; ++n) fz[n] = n < d.n_out ? logits_hist[n * tl + at] : 0.f;
+        fd = demand[(int64_t)(t + d.t0) * ldb + b];
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fh[l][r] = hidden_hist[(int64_t)(l * SR_H + crow(r, h)) * tl + at];
+    };
+    fetch(d.T - 1, st, z, dem, hh);
+    for (int t = d.T - 1; t >= 0; --t) {
+        const int64_t at = (int64_t)t * ldb + b;
+        fetch(t > 0 ? t - 1 : 0, st_n, z_n, dem_n, hh_n);
+        const SrOrders o = sr_head(d, z, st);
+        float go[SR_MAXF], dz[SR_MAXOUT];
+        const SrOrders g = sr_env_bwd(d, c, st, gn, go, dem, o, gr);
+        sr_head_bwd(d, z, st, g, dz, go);
+        if (live && h == 0) {
+#pragma unroll
+            for (int n = 0; n < SR_MAXOUT; ++n)
+                if (n < d.n_out) dz_out[n * tl + at] = dz[n];
+        }
+        // output layer -> last hidden layer: contraction over the n_out logits, n = 2s + h
+        f32x16 acc;
+        float dh[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aWoT[s], h ? dz[2 * s + 1] : dz[2 * s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            dh[r] = acc[r] * elu1_grad_from_out(hh[NL - 1][r]);
+#pragma unroll
+        for (int l = NL - 1; l >= 1; --l) {
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dz_hidden[(int64_t)(l * SR_H + crow(r, h)) * tl + at] = dh[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aWhT[l - 1][s], dh[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dh[r] = acc[r] * elu1_grad_from_out(hh[l - 1][r]);
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz_hidden[(int64_t)crow(r, h) * tl + at] = dh[r];
+        }
+        // first layer -> state (the reference detaches vanilla_serial's MLP input, neural_networks.py:329)
+        if (!d.detach_input) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aW1T[s], dh[s], acc, 0, 0, 0);
+            // state rows 0..15 live in registers 0..7: half 0 holds rows 0-3, 8-11; half 1 rows 4-7, 12-15
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float mine = acc[r], other = __shfl_xor(mine, 32);
+                const int lo = (r & 3) + 8 * (r >> 2);  // row held by half 0 in register r; half 1 holds lo + 4
+                go[lo] += h == 0 ? mine : other;
+                go[lo + 4] += h == 0 ? other : mine;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SR_MAXF; ++k) {
+            gn[k] = go[k];
+            st[k] = st_n[k];
+        }
+#pragma unroll
+        for (int n = 0; n < SR_MAXOUT; ++n) z[n] = z_n[n];
+        dem = dem_n;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hh[l][r] = hh_n[l][r];
+    }
+}
+
 int validate(const NicSmallRolloutDesc* d, const char* who) {
     NIC_REQUIRE(d != nullptr, "%s: null descriptor", who);
     NIC_REQUIRE(d->n_scenarios > 0 && d->ldb >= d->n_scenarios && d->T > 0 && d->t0 >= 0, "%s: bad sizes", who);
@@ -232,8 +361,20 @@ int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist
     if (int e = validate(d, "nic_small_rollout_bwd")) return e;
     NIC_REQUIRE(states_hist && hidden_hist && logits_hist && g_reward.p && dz_hidden && dz_out,
                 "nic_small_rollout_bwd: null buffer");
-    const dim3 grid(nic::ceil_div(d->n_scenarios, kBlock)), block(kBlock);
     hipStream_t s = nic::as_stream(stream);
+    static const int variant = getenv("NIC_SMALL_VARIANT") ? atoi(getenv("NIC_SMALL_VARIANT")) : 0;
+    if (variant != 1) {
+        const dim3 g32(nic::ceil_div(d->n_scenarios, 32)), b64(64);
+#define NIC_SR_BWD_MFMA(NL)                                                                                                \
+    hipLaunchKernelGGL(small_rollout_bwd_mfma_kernel<NL>, g32, b64, 0, s, *d, d->weights, d->demand, states_hist,         \
+                       hidden_hist, logits_hist, g_reward, dz_hidden, dz_out)
+        if (d->n_hidden == 1) NIC_SR_BWD_MFMA(1);
+        else if (d->n_hidden == 2) NIC_SR_BWD_MFMA(2);
+        else NIC_SR_BWD_MFMA(3);
+#undef NIC_SR_BWD_MFMA
+        return nic::check_launch("nic_small_rollout_bwd");
+    }
+    const dim3 grid(nic::ceil_div(d->n_scenarios, kBlock)), block(kBlock);
 #define NIC_SR_BWD(NL)                                                                                                     \
     hipLaunchKernelGGL(small_rollout_bwd_kernel<NL>, grid, block, 0, s, *d, d->weights, d->demand, states_hist,           \
                        hidden_hist, logits_hist, g_reward, dz_hidden, dz_out)
