@@ -222,6 +222,12 @@ def main():
                 for tag in ("env_fwd", "env_bwd", "small_rollout_fwd", "small_rollout_bwd"):
                     if tag in summ:
                         out["kernels"][tag] = {"launches": summ[tag][0], "mean_ms": round(summ[tag][1], 5)}
+                for tag, (cnt, mean_ms) in summ.items():  # fused thin-layer backward: HBM-bound, X in + dX out
+                    if tag.startswith("bwd_thin_"):
+                        N_t, K_t = (int(v) for v in tag[len("bwd_thin_"):].split("x"))
+                        out["kernels"][tag] = {"launches": cnt, "mean_ms": round(mean_ms, 5),
+                                               "total_ms_per_step": round(cnt * mean_ms / args.steps, 5),
+                                               "gb_per_s": round(2.0 * K_t * n * 4 / (mean_ms * 1e-3) / 1e9, 1)}
                 if "env_fwd" in summ:
                     gbs = env_bytes / (summ["env_fwd"][1] * 1e-3) / 1e9
                     out["roofline_env_step"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",

@@ -128,6 +128,14 @@ int nic_linear_dgrad(const float* Wt, int64_t ldwt, const float* dY, const float
 int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios);
 int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds, int32_t N, int32_t K,
                      int32_t n_scenarios, int32_t ldb, int32_t n_splits, void* stream);
+/* Fused backward of a thin layer (N <= NIC_THIN_MAX_ROWS output rows, K % 32 == 0: the logits layer of the policy
+ * MLPs): one pass over X computes what nic_linear_dgrad (dX = act'(X) * W^T dY, no accumulate) and nic_linear_wgrad
+ * (slab += dY X^T per split, bias column K) compute with two.  W is the layer's weight [N][ldw] (NOT transposed);
+ * n_splits as for nic_linear_wgrad (any value >= 1 is accepted; the slab must have that many splits). */
+#define NIC_THIN_MAX_ROWS 32
+int nic_linear_bwd_thin(const float* W, int64_t ldw, const float* dY, const float* X, float* dX, float* slab,
+                        int64_t lds, int32_t N, int32_t K, int32_t n_scenarios, int32_t ldb, int32_t act_prev,
+                        int32_t n_splits, void* stream);
 /* dW[n][k] = scale * sum_split slab[split][n][k] (k < K), db[n] = scale * sum_split slab[split][n][K] */
 int nic_wgrad_reduce(const float* slab, int64_t lds, int32_t n_splits, float* dW, int64_t lddw, float* db,
                      int32_t N, int32_t K, float scale, void* stream);

@@ -57,6 +57,7 @@ class NicSmallRolloutDesc(C.Structure):
 
 
 NIC_SR_MAX_INPUTS, NIC_SR_HIDDEN, NIC_SR_MAX_OUTPUTS = 16, 32, 8
+NIC_THIN_MAX_ROWS = 32
 _vp, _i32, _i64, _f32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 _IOP = C.POINTER(NicEnvStepIO)
 
@@ -71,6 +72,7 @@ PROTOTYPES = {
     "nic_linear_dgrad": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_wgrad_num_splits": (C.c_int, [_i32, _i32, _i32]),
     "nic_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "nic_linear_bwd_thin": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_wgrad_reduce": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _f32, _vp]),
     "nic_head_warehouse_fwd": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_head_warehouse_bwd": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,

@@ -95,6 +95,20 @@ def linear_wgrad(dY, X, slab, n_scenarios):
     return slab
 
 
+def linear_bwd_thin_ok(N, K):
+    """shapes nic_linear_bwd_thin takes (the logits layer of the policy MLPs)"""
+    return N <= _lib.NIC_THIN_MAX_ROWS and K >= 32 and K % 32 == 0
+
+
+def linear_bwd_thin(W, dY, X, dX, slab, n_scenarios, act_prev):
+    """One pass over X: dX = act'(X) * W^T dY  and  slab[split] += dY X^T (column K = bias gradient)."""
+    _dev(dY)
+    N, K = dY.shape[0], X.shape[0]
+    check(lib().nic_linear_bwd_thin(ptr(W), W.stride(0), ptr(dY), ptr(X), ptr(dX), ptr(slab), slab.stride(1), N, K,
+                                    n_scenarios, dY.stride(0), int(act_prev), slab.shape[0], current_stream()))
+    return dX
+
+
 def wgrad_reduce(slab, dW, db, K, scale=1.0):
     N = dW.shape[0]
     check(lib().nic_wgrad_reduce(ptr(slab), slab.stride(1), slab.shape[0], ptr(dW), dW.stride(0), ptr(db), N, K,

@@ -81,6 +81,7 @@ class FusedRollout:
         self.timer = None  # KernelTimer or None
         self.use_graph = False  # replay the launch sequence from a HIP graph (see _replay_or_capture)
         self.use_small = True   # whole-horizon kernels for the small one-store-chain policies (small_rollout.py)
+        self.use_thin = True    # fused backward of thin (<= 32 rows) output layers (csrc/thin_layer.hip)
         self.small = None       # SmallRolloutPlan when the current shapes take that route
         self._prob_cache = {}
         self._prob = None
@@ -282,6 +283,11 @@ class FusedRollout:
         for sl in self.slabs:
             sl.zero_()
         self.g_state[0].zero_()
+        # layers whose backward is ONE fused pass over their input (nic_linear_bwd_thin): thin output, not the first
+        thin = [i > 0 and self.use_thin and ops.linear_bwd_thin_ok(self.dims[i + 1], self.dims[i]) for i in range(len(lins))]
+        if thin != getattr(self, "_thin", None):
+            self._thin = thin
+            self._graphs.pop("bwd", None)  # a captured launch sequence no longer applies
         self._replay_or_capture("bwd", self._launch_backward)
         self._eager_runs += 1
         for i, m in enumerate(lins):
@@ -416,6 +422,13 @@ class FusedRollout:
             d = self.dZ
             for i in range(L - 1, -1, -1):
                 x_in = self.hidden[i - 1][t] if i > 0 else self.states[t][:self.F]
+                if i > 0 and self._thin[i]:
+                    # thin (logits) layer: weight gradient and input gradient in ONE pass over the layer's input
+                    dx = self.dH[i & 1][:self.dims[i]]
+                    self._k(f"bwd_thin_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_bwd_thin, Wv[i], d, x_in, dx,
+                            self.slabs[i], B, _lib.NIC_ACT_ELU)
+                    d = dx
+                    continue
                 self._k(f"wgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad, d, x_in, self.slabs[i], B)
                 if i > 0:
                     dx = self.dH[i & 1][:self.dims[i]]

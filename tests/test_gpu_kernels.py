@@ -161,6 +161,61 @@ def test_linear_wgrad_accumulates_over_periods(N, K, B):
     assert float(slab[:, :, K + 1:].abs().sum()) == 0.0
 
 
+THIN_SHAPES = [(17, 512, 777), (17, 512, 4096), (5, 128, 130), (32, 256, 1000), (1, 32, 64), (18, 96, 2049), (9, 64, 63)]
+
+
+@pytest.mark.parametrize("N,K,B", THIN_SHAPES)
+@pytest.mark.parametrize("splits", [None, 3])
+def test_linear_bwd_thin_matches_dgrad_plus_wgrad(N, K, B, splits):
+    """nic_linear_bwd_thin = nic_linear_dgrad (ELU' of the layer below) + nic_linear_wgrad in one pass over X."""
+    dev = "cuda"
+    assert ops.linear_bwd_thin_ok(N, K)
+    gen = torch.Generator().manual_seed(N * 1000 + K + 7)
+    ldb = pad_ld(B)
+    W = torch.zeros(N, K + 8, device=dev)[:, :K]  # padded leading dimension, as HipLinear stores its weights
+    W.copy_(_rand((N, K), gen, dev, 0.3))
+    n_splits = splits or ops.wgrad_num_splits(N, K, B)
+    lds = (K + 1 + 3) // 4 * 4
+    slab = torch.zeros(n_splits, N, lds, device=dev)
+    want_w = torch.zeros(N, K, dtype=torch.float64)
+    want_b = torch.zeros(N, dtype=torch.float64)
+    scale_w = torch.zeros(N, K, dtype=torch.float64)
+    W64 = W.double().cpu()
+    for period in range(3):
+        act = _lib.NIC_ACT_ELU if period != 1 else _lib.NIC_ACT_NONE
+        dY = _rand((N, ldb), gen, dev)  # padding columns are NOT zero: the kernel must ignore b >= n_scenarios
+        H = _rand((K, ldb), gen, dev)
+        H = torch.where(H > 0, H, torch.expm1(H))
+        dX = torch.full((K, ldb), float("nan"), device=dev)
+        ops.linear_bwd_thin(W, dY, H, dX, slab, B, act)
+        torch.cuda.synchronize()
+        dY64, H64 = dY.double().cpu()[:, :B], H.double().cpu()[:, :B]
+        lin = W64.t() @ dY64
+        if act == _lib.NIC_ACT_ELU:
+            lin = lin * torch.where(H64 > 0, torch.ones_like(H64), H64 + 1)
+        _close(dX[:, :B], lin, W64.t().abs() @ dY64.abs(), f"thin dgrad period {period}")
+        want_w += dY64 @ H64.t()
+        want_b += dY64.sum(dim=1)
+        scale_w += dY64.abs() @ H64.abs().t()
+    dW = torch.full((N, K), float("nan"), device=dev)
+    db = torch.full((N,), float("nan"), device=dev)
+    ops.wgrad_reduce(slab, dW, db, K, 0.5)
+    torch.cuda.synchronize()
+    _close(dW, 0.5 * want_w, scale_w, "thin wgrad")
+    _close(db, 0.5 * want_b, torch.full((N,), 3.0 * B), "thin bgrad")
+    assert float(slab[:, :, K + 1:].abs().sum()) == 0.0
+
+
+def test_linear_bwd_thin_rejects_bad_shapes():
+    dev = "cuda"
+    z = torch.zeros(64, 64, device=dev)
+    slab = torch.zeros(1, 64, 68, device=dev)
+    with pytest.raises(_lib.NicError):
+        ops.linear_bwd_thin(z[:40, :48], z[:40], z[:48], z[:48].clone(), slab, 64, _lib.NIC_ACT_ELU)   # N > 32
+    with pytest.raises(_lib.NicError):
+        ops.linear_bwd_thin(z[:8, :48], z[:8], z[:48], z[:48].clone(), slab, 64, _lib.NIC_ACT_ELU)     # K % 32 != 0
+
+
 # ---- sampler ------------------------------------------------------------------------------------------------------
 
 def test_sampler_normal_moments_and_sharding_invariance():

@@ -340,3 +340,27 @@ def test_small_route_equals_per_period_route(name):
         assert float((x - y).norm() / (y.norm() + 1e-30)) < 2e-5
     for k in b[4]:
         torch.testing.assert_close(a[4][k], b[4][k], **STATE_TOL)
+
+
+@pytest.mark.parametrize("name", ["cfg3_one_warehouse_16_vanilla", "cfg5_many_warehouses_2x10_vanilla"])
+def test_fused_thin_layer_backward_equals_separate_gemms(name):
+    """The logits layer's backward runs as one fused pass (nic_linear_bwd_thin); switching it off must give the same
+    gradients through nic_linear_wgrad + nic_linear_dgrad."""
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    F = sum(int(np.prod(data[k].shape[1:])) for k in ("initial_inventories", "initial_warehouse_inventories") if k in data)
+    res = {}
+    for thin in (True, False):
+        model = _model(g, c)
+        eng = FusedRollout(model, c["problem_params"], DEV)
+        eng.use_thin = thin
+        eng.materialize(F)
+        _load(model, g)
+        total, _ = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+        torch.cuda.synchronize()
+        assert any(eng._thin) == thin
+        res[thin] = (float(total), [p.grad.clone() for p in model.parameters()])
+    assert res[True][0] == res[False][0]
+    for x, y in zip(res[True][1], res[False][1]):
+        assert float((x - y).norm() / (y.norm() + 1e-30)) < 2e-5
