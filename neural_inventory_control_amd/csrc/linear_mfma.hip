@@ -1032,6 +1032,12 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
         if (sp > 1024) sp = 1024;  // one wave per SIMD
         return (sp + 3) / 4 * 4;
     }
+    if (N <= NIC_THIN_MAX_ROWS && K % 32 == 0) {  // nic_linear_bwd_thin: one wave per (split, 32-row chunk), 2 waves per SIMD
+        int sp = 2048 / (K / 32);
+        const int cap = (n_scenarios + 63) / 64;  // at least one 64-scenario block per split
+        if (sp > cap) sp = cap;
+        return sp < 1 ? 1 : sp;
+    }
     int splits = (target + tiles - 1) / tiles;
     const int max_splits = (n_scenarios + 255) / 256;  // at least 256 scenarios (8 k-tiles) per split
     if (splits > max_splits) splits = max_splits;

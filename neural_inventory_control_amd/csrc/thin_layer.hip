@@ -7,9 +7,12 @@
 // Reference: the logits layer of MyNeuralNetwork.forward (neural_networks.py:80-106) under autograd (addmm backward +
 // elu_backward of the layer below).
 //
-// One wavefront (= one workgroup, no barriers across waves) owns a scenario range x a group of KG row chunks (64 rows of
-// X); registers are kept under 256 so that two such waves share a SIMD and hide each other's LDS/HBM latency.  Per 64-scenario block and 32-row chunk the X tile is staged in LDS once and used three ways: as the B operand of
-// the weight-gradient MFMAs (lane = row k, float4 over scenarios), and row-wise as elu'(X) for the dX tile.
+// One wavefront (= one workgroup, no barriers across waves) owns a scenario range x KG 32-row chunks of X (KG = 1: two
+// chunks per wave measured slower - hipcc hoists every fragment read of the unrolled body and spills); registers stay under
+// 256 so that two such waves share a SIMD and hide each other's LDS/HBM latency.  Per 64-scenario block the X tile is
+// staged in LDS once and used two ways: as the B operand of the weight-gradient MFMAs (lane = row k, float4 over
+// scenarios), and row-wise as elu'(X) for the dX tile.  The next X tile and dY tile are fetched into registers while the
+// current block is computed.
 //   wgrad  D[n][k]   += sum_b dY[n][b] X[k][b]   : A = dY tile (lane i = n), B = X tile (lane j = k); contraction index
 //                                                  of MFMA step (q, e) and lane half h is b = 8q + 4h + e (b128 LDS reads)
 //   dgrad  D[k][b]    = sum_n W[n][k] dY[n][b]   : A = W^T chunk (lane i = k, resident in VGPRs), B = dY tile (lane j = b)
@@ -23,7 +26,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int CB = 64;        // scenarios per block
 constexpr int LD = CB + 4;    // LDS row stride (floats): 16-byte aligned rows, conflict-free b128 reads down a column of rows
-constexpr int KG = 2;         // 32-row chunks per wavefront
+constexpr int KG = 1;         // 32-row chunks per wavefront
 
 struct ThinParams {
     const float* W;   // [N][ldw]
@@ -39,20 +42,26 @@ struct ThinParams {
 
 __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
-// 4 scenarios col .. col+3 of one row, zero beyond the last scenario (rows are 16-byte aligned and ldb % 4 == 0, so the
-// load itself never leaves the row)
-__device__ __forceinline__ float4 load4_masked(const float* row, int col, int nB) {
-    if (col >= nB) return make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 v = *reinterpret_cast<const float4*>(row + col);
-    if (col + 3 >= nB) {
-        if (col + 1 >= nB) v.y = 0.f;
-        if (col + 2 >= nB) v.z = 0.f;
-        v.w = 0.f;
-    }
+// zero the scenarios >= nB of a float4 that starts at scenario `col` (select, no branch: the caller applies it when the value
+// is consumed, so the load itself stays an unconditional, early-issued global_load_dwordx4)
+__device__ __forceinline__ float4 mask4(float4 v, int col, int nB) {
+    v.x = col < nB ? v.x : 0.f;
+    v.y = col + 1 < nB ? v.y : 0.f;
+    v.z = col + 2 < nB ? v.z : 0.f;
+    v.w = col + 3 < nB ? v.w : 0.f;
     return v;
 }
 
-template <int NS>  // MFMA steps over the N output rows (2 rows per step)
+// Ordering point for LDS traffic inside a ONE-wave workgroup.  __syncthreads() would also wait for every outstanding global
+// load and STORE (s_waitcnt vmcnt(0)), i.e. drain the dX stores of a chunk before the next chunk may start; the LDS queue of
+// a wave is in order, so all that is needed is that the compiler keeps LDS writes and reads on their side of this point.
+__device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// NS = MFMA steps over the N output rows (2 rows per step).  FULL: ldb % 64 == 0 and K % 64 == 0 — every wave has KG whole
+// chunks and stores its dX tile unconditionally (the padding scenarios nB..ldb receive exact zeros: their dY is masked), so
+// the chunk body is straight-line code and hipcc's s_waitcnt counts stay exact: the wait for a prefetched tile does not
+// also drain the dX stores issued after it.  Otherwise every chunk / store is guarded.
+template <int NS, bool FULL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void thin_bwd_kernel(ThinParams p) {
     __shared__ __attribute__((aligned(16))) float lds_dy[2 * NS * LD];
     __shared__ __attribute__((aligned(16))) float lds_x[32 * LD];
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void th
     // its dY tile in that L2
     const int split = blockIdx.x % p.n_splits, kg = blockIdx.x / p.n_splits;
     const int k_base = kg * 32 * KG;
-    const int n_chunks = min(KG, (p.K - k_base) / 32);
+    const int n_chunks = FULL ? KG : min(KG, (p.K - k_base) / 32);
     // (splits that interleave their 64-scenario blocks, so that concurrent waves read neighbouring pieces of each row,
     // measured 20 % slower than contiguous ranges)
     const int col_lo = split * p.chunk, col_hi = min(col_lo + p.chunk, p.nB);
@@ -90,29 +99,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void th
     const int ldb32 = (int)p.ldb;
     // staging map of a [32][64] tile: lane -> row (lane >> 4) + 4q, columns (lane & 15) * 4 .. +3
     const int srow = lane >> 4, scol = (lane & 15) * 4;
+    // the column is clamped into the row (ldb % 4 == 0), so the loads are unconditional; what lies beyond the last scenario
+    // (always a clamped or padding column) is masked when the tile is written to LDS
+    // addresses are (uniform base: SGPR arithmetic) + (one per-lane 32-bit offset), so the unrolled body keeps ONE address
+    // register per access pattern instead of one per access (K * ldb < 2^31 is checked by the launcher)
+    const int lane_ld = srow * ldb32 + scol;
+    const int lane_st = 4 * h * ldb32 + li;   // dX stores: row (uniform) + 4h, scenario li  // staging loads: row srow (+ 4q uniform), columns scol..scol+3
     auto load_x = [&](int col0, int c, float4 (&v)[8]) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            // 32-bit element offsets from one uniform base (K * ldb < 2^31 is checked by the launcher): one VGPR per address
-            v[q] = (c < n_chunks) ? load4_masked(xg + (c * 32 + srow + 4 * q) * ldb32, col0 + scol, p.nB)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* rowbase = xg + (c * 32 + 4 * q) * ldb32 + col0;  // uniform
+            v[q] = FULL ? *reinterpret_cast<const float4*>(rowbase + lane_ld)
+                        : *reinterpret_cast<const float4*>(rowbase + srow * ldb32 + min(scol, ldb32 - 4 - col0));
         }
     };
 
-    float4 xv[8];
+    constexpr int DQ = (2 * NS + 3) / 4;  // float4 loads per lane that cover the 2 NS staged dY rows
+    auto load_dy = [&](int col0, float4 (&v)[DQ]) {
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) {
+            if (FULL && 4 * q + 3 < p.N) {  // (uniform) all four rows of this step exist
+                v[q] = *reinterpret_cast<const float4*>(p.dY + 4 * q * ldb32 + col0 + lane_ld);
+            } else {
+                const int n = min(srow + 4 * q, p.N - 1);  // rows N .. 2 NS - 1 are zero padding (masked at the LDS write)
+                v[q] = *reinterpret_cast<const float4*>(p.dY + n * ldb32 + min(col0 + scol, ldb32 - 4));
+            }
+        }
+    };
+    const bool act_elu = p.act_prev == NIC_ACT_ELU;
+
+    float4 xv[8], dyv[DQ];
+    load_dy(col_lo, dyv);
     load_x(col_lo, 0, xv);
     for (int col0 = col_lo; col0 < col_hi; col0 += CB) {
-        // ---- dY tile of this block: rows >= N and columns >= nB are zero
-        __syncthreads();  // previous block's reads of lds_dy are done
+        // ---- dY tile of this block (fetched during the previous block): rows >= N and columns >= nB are zero
+        lds_order();  // previous block's reads of lds_dy are done
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < DQ; ++q) {
             const int n = srow + 4 * q;
             if (n < 2 * NS) {
-                const float4 v = (n < p.N) ? load4_masked(p.dY + n * ldb32, col0 + scol, p.nB) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v = mask4(dyv[q], col0 + scol, p.nB);
+                if (n >= p.N) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(lds_dy + n * LD + scol) = v;
             }
         }
-        __syncthreads();
+        lds_order();
         // the bias gradient rides on the first row group: lane (i = n, h) sums its 32 scenarios of the block
         const bool arow = li < 2 * NS;  // dY rows staged in LDS
         if (kg == 0 && arow) {
@@ -125,16 +156,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void th
 
 #pragma unroll
         for (int c = 0; c < KG; ++c) {
-            if (c >= n_chunks) break;
+            if (!FULL && c >= n_chunks) break;
             // ---- X chunk: registers (fetched one chunk ahead) -> LDS
-            __syncthreads();  // previous chunk's reads of lds_x are done
+            lds_order();  // previous chunk's reads of lds_x are done
 #pragma unroll
-            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(lds_x + (srow + 4 * q) * LD + scol) = xv[q];
-            __syncthreads();
-            {  // fetch the next chunk (or the first chunk of the next block) while this one is computed
-                const int cn = (c + 1 < n_chunks) ? c + 1 : 0;
-                const int coln = (c + 1 < n_chunks) ? col0 : col0 + CB;
-                if (coln < col_hi) load_x(coln, cn, xv);
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(lds_x + (srow + 4 * q) * LD + scol) = mask4(xv[q], col0 + scol, p.nB);
+            lds_order();
+            {  // fetch the next chunk (or the first chunk and the dY tile of the next block) while this one is computed
+                const bool last = FULL ? c + 1 == KG : c + 1 >= n_chunks;
+                const int coln = last ? col0 + CB : col0;
+                if (coln < col_hi) {
+                    load_x(coln, last ? 0 : c + 1, xv);
+                    if (last) load_dy(coln, dyv);
+                }
             }
             // ---- weight gradient: 32 MFMA steps over the 64 scenarios of the block
 #pragma unroll
@@ -158,13 +192,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void th
                 for (int s = 0; s < NS; ++s)  // B operand: lane (j = scenario, h) holds dY[2s + h][cb*32 + j]
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aW[c][s], lds_dy[(2 * s + h) * LD + cb * 32 + li], acc, 0, 0, 0);
                 const int col = col0 + cb * 32 + li;
-                if (col < p.nB) {
+                if (FULL || col < p.nB) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int kl = crow(r, h);
-                        float y = acc[r];
-                        if (p.act_prev == NIC_ACT_ELU) y *= elu_grad_from_out(lds_x[kl * LD + cb * 32 + li]);
-                        dxg[(c * 32 + kl) * ldb32 + col] = y;
+                        const int ku = (r & 3) + 8 * (r >> 2);  // uniform part of the row; the lane half adds 4h
+                        const float g = elu_grad_from_out(lds_x[(ku + 4 * h) * LD + cb * 32 + li]);
+                        float* rowbase = dxg + (c * 32 + ku) * ldb32 + col0 + cb * 32;  // uniform
+                        rowbase[lane_st] = acc[r] * (act_elu ? g : 1.f);
                     }
                 }
             }
@@ -176,7 +210,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void th
     float* slab = p.slab + (int64_t)split * p.N * p.lds_;
 #pragma unroll
     for (int c = 0; c < KG; ++c) {
-        if (c >= n_chunks) break;
+        if (!FULL && c >= n_chunks) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = crow(r, h);
@@ -214,9 +248,16 @@ int nic_linear_bwd_thin(const float* W, int64_t ldw, const float* dY, const floa
     const dim3 grid(n_kg * n_splits), block(64);
     hipStream_t s = nic::as_stream(stream);
     const int steps = (N + 1) / 2;
-    if (steps <= 4) hipLaunchKernelGGL(thin_bwd_kernel<4>, grid, block, 0, s, p);
-    else if (steps <= 9) hipLaunchKernelGGL(thin_bwd_kernel<9>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(thin_bwd_kernel<16>, grid, block, 0, s, p);
+    const bool full = ldb % CB == 0 && K % (32 * KG) == 0;
+#define NIC_THIN_LAUNCH(NS_)                                                                    \
+    do {                                                                                        \
+        if (full) hipLaunchKernelGGL((thin_bwd_kernel<NS_, true>), grid, block, 0, s, p);       \
+        else hipLaunchKernelGGL((thin_bwd_kernel<NS_, false>), grid, block, 0, s, p);           \
+    } while (0)
+    if (steps <= 4) NIC_THIN_LAUNCH(4);
+    else if (steps <= 9) NIC_THIN_LAUNCH(9);
+    else NIC_THIN_LAUNCH(16);
+#undef NIC_THIN_LAUNCH
     return nic::check_launch("nic_linear_bwd_thin");
 }
 

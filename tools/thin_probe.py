@@ -17,7 +17,7 @@ def main():
     H = torch.where(H > 0, H, torch.expm1(H))
     dX = torch.zeros(K, ldb, device=dev)
     res = {}
-    for splits in (ops.wgrad_num_splits(N, K, B), 128, 512, 1024):
+    for splits in (ops.wgrad_num_splits(N, K, B), 64, 96, 128, 192, 384):
         slab = torch.zeros(splits, N, (K + 4) // 4 * 4, device=dev)
         ms = timeit(lambda: ops.linear_bwd_thin(W, dY, H, dX, slab, B, _lib.NIC_ACT_ELU))
         res[f"thin_splits{splits}"] = round(ms, 4)
