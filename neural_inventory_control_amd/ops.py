@@ -16,6 +16,11 @@ def _dev(t):
     return t
 
 
+def _ld(m):
+    """leading dimension of a row-major matrix (torch reports an arbitrary stride for a dimension of size 1)"""
+    return m.stride(0) if m.shape[0] > 1 else max(m.stride(0), m.shape[1])
+
+
 class EnvState:
     """The three pipelines of one period in SoA layout: store [S][Ws][ldb], wh [Wn][Ww][ldb], ech [E][We][ldb]."""
     __slots__ = ("store", "wh", "ech")
@@ -68,7 +73,7 @@ def linear_fwd(W, bias, X, Y, n_scenarios, act):
     """Y[N][ldb] = act(W[N][K(ldw)] @ X[K][ldb] + bias)."""
     _dev(X)
     N, K = W.shape[0], X.shape[0]
-    check(lib().nic_linear_fwd(ptr(W), W.stride(0), ptr(bias), ptr(X), ptr(Y), N, K, n_scenarios, X.stride(0), act,
+    check(lib().nic_linear_fwd(ptr(W), _ld(W), ptr(bias), ptr(X), ptr(Y), N, K, n_scenarios, X.stride(0), act,
                                current_stream()))
     return Y
 
@@ -77,7 +82,7 @@ def linear_dgrad(Wt, dY, Hprev, dX, n_scenarios, act_prev, accumulate):
     """dX[K][ldb] (+)= (Wt[K][N(ldwt)] @ dY[N][ldb]) * act'(Hprev)."""
     _dev(dY)
     K, N = dX.shape[0], dY.shape[0]
-    check(lib().nic_linear_dgrad(ptr(Wt), Wt.stride(0), ptr(dY), ptr(Hprev), ptr(dX), N, K, n_scenarios, dY.stride(0),
+    check(lib().nic_linear_dgrad(ptr(Wt), _ld(Wt), ptr(dY), ptr(Hprev), ptr(dX), N, K, n_scenarios, dY.stride(0),
                                  act_prev, int(accumulate), current_stream()))
     return dX
 
@@ -104,14 +109,14 @@ def linear_bwd_thin(W, dY, X, dX, slab, n_scenarios, act_prev):
     """One pass over X: dX = act'(X) * W^T dY  and  slab[split] += dY X^T (column K = bias gradient)."""
     _dev(dY)
     N, K = dY.shape[0], X.shape[0]
-    check(lib().nic_linear_bwd_thin(ptr(W), W.stride(0), ptr(dY), ptr(X), ptr(dX), ptr(slab), slab.stride(1), N, K,
+    check(lib().nic_linear_bwd_thin(ptr(W), _ld(W), ptr(dY), ptr(X), ptr(dX), ptr(slab), slab.stride(1), N, K,
                                     n_scenarios, dY.stride(0), int(act_prev), slab.shape[0], current_stream()))
     return dX
 
 
 def wgrad_reduce(slab, dW, db, K, scale=1.0):
     N = dW.shape[0]
-    check(lib().nic_wgrad_reduce(ptr(slab), slab.stride(1), slab.shape[0], ptr(dW), dW.stride(0), ptr(db), N, K,
+    check(lib().nic_wgrad_reduce(ptr(slab), slab.stride(1), slab.shape[0], ptr(dW), _ld(dW), ptr(db), N, K,
                                  float(scale), current_stream()))
 
 
