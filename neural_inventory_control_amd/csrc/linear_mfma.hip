@@ -413,10 +413,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     // swizzled chunk positions of this lane's A rows: row = wm*MT*32 + i*32 + li -> ((row >> 1) & 7) == ((li >> 1) & 7)
     const int sw = (li >> 1) & 7;
     const int nk = (p.K + BK - 1) / BK;
-    issue(0);
-    dma_wait();
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    // epilogue geometry (needed here already: the dgrad epilogue's Hprev rows are fetched during the last k tiles)
+    constexpr int TPR = BN / 4, RPI = NTHREADS / TPR, ITER = PASS_ROWS / RPI;
+    static_assert(PASS_ROWS % RPI == 0, "pass rows must divide evenly over the threads");
+    const int t = threadIdx.x;
+    const int col = c0 + (t % TPR) * 4;
+    // EPI_DGRAD multiplies the tile by act'(Hprev): read in the epilogue, those 256 KB per workgroup arrive as one burst from
+    // every CU at once, on top of the write burst.  The kernel has ~80 free VGPRs, so the rows of the first pass are fetched
+    // into registers during the last PFT k tiles (each batch completes under that tile's MFMAs, before its dma_wait), and
+    // the rows of the second pass are fetched into the same registers as the first pass consumes them.
+    constexpr int PFT = 4;
+    static_assert(ITER % PFT == 0, "prefetch batches must divide the pass");
+    float4 hq[ITER];  // (dead in the forward instantiation)
+    const bool pf_on = EPI == EPI_DGRAD && p.Hprev != nullptr && p.act == NIC_ACT_ELU && nk >= PFT && !p.accumulate;
+    auto load_h = [&](int pass, int it) {
+        const int row = m0 + pass * PASS_ROWS + t / TPR + RPI * it;
+        return (row < p.M && col < p.ncols) ? *reinterpret_cast<const float4*>(p.Hprev + (int64_t)row * p.ldb + col)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    auto ktile = [&](int kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk && !(p.dbg & 1)) {  // stage cur^1 was last read in tile kt-1; every wave is past that barrier
             advance();
@@ -448,14 +464,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
         }
         dma_wait();  // tile kt+1 has landed (this wave's share); the barrier publishes every wave's share
         __syncthreads();
+    };
+    issue(0);
+    dma_wait();
+    __syncthreads();
+    const int nk_plain = pf_on ? nk - PFT : nk;
+    for (int kt = 0; kt < nk_plain; ++kt) ktile(kt);
+    if constexpr (EPI == EPI_DGRAD) {
+        if (pf_on) {
+#pragma unroll
+            for (int b = 0; b < PFT; ++b) {
+#pragma unroll
+                for (int q = 0; q < ITER / PFT; ++q) hq[b * (ITER / PFT) + q] = load_h(0, b * (ITER / PFT) + q);
+                ktile(nk_plain + b);
+            }
+        }
     }
 
     // epilogue: stage the block tile through LDS and write whole rows
     float* cs = lds;
-    constexpr int TPR = BN / 4, RPI = NTHREADS / TPR, ITER = PASS_ROWS / RPI;
-    static_assert(PASS_ROWS % RPI == 0, "pass rows must divide evenly over the threads");
-    const int t = threadIdx.x;
-    const int col = c0 + (t % TPR) * 4;
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         if (PASSES == 1 || wm == pass) {
@@ -482,9 +509,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
                 if (p.act == NIC_ACT_ELU) { y.x = elu_f(y.x); y.y = elu_f(y.y); y.z = elu_f(y.z); y.w = elu_f(y.w); }
             } else {
                 if (p.Hprev && p.act == NIC_ACT_ELU) {
-                    const float4 hq = *reinterpret_cast<const float4*>(p.Hprev + off);
-                    y.x *= elu_grad_from_out(hq.x); y.y *= elu_grad_from_out(hq.y);
-                    y.z *= elu_grad_from_out(hq.z); y.w *= elu_grad_from_out(hq.w);
+                    const float4 hv = pf_on ? hq[it] : *reinterpret_cast<const float4*>(p.Hprev + off);
+                    y.x *= elu_grad_from_out(hv.x); y.y *= elu_grad_from_out(hv.y);
+                    y.z *= elu_grad_from_out(hv.z); y.w *= elu_grad_from_out(hv.w);
+                    if (pf_on && pass + 1 < PASSES) hq[it] = load_h(pass + 1, it);  // next pass's row into the freed register
                 }
                 if (p.accumulate) {
                     const float4 o = *reinterpret_cast<const float4*>(p.C + off);
