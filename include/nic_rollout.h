@@ -128,6 +128,14 @@ int nic_linear_dgrad(const float* Wt, int64_t ldwt, const float* dY, const float
 int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios);
 int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds, int32_t N, int32_t K,
                      int32_t n_scenarios, int32_t ldb, int32_t n_splits, void* stream);
+/* The same contraction over n_periods operand pairs (dY + t * period_stride_dy, X + t * period_stride_x; strides in
+ * elements, multiples of 4) in ONE launch: the backward sweep of a rollout keeps every period's dY resident ([T][N][ldb],
+ * HBM is sized for it) and contracts weight gradients once per training step instead of once per period — one slab
+ * read-modify-write instead of T, no per-period pipeline fill/drain.  Shapes the LDS-DMA kernel does not take are
+ * served by one nic_linear_wgrad launch per period (same result). */
+int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64_t lds, int32_t N, int32_t K,
+                             int32_t n_scenarios, int32_t ldb, int32_t n_splits, int32_t n_periods,
+                             int64_t period_stride_dy, int64_t period_stride_x, void* stream);
 /* Fused backward of a thin layer (N <= NIC_THIN_MAX_ROWS output rows, K % 32 == 0: the logits layer of the policy
  * MLPs): one pass over X computes what nic_linear_dgrad (dX = act'(X) * W^T dY, no accumulate) and nic_linear_wgrad
  * (slab += dY X^T per split, bias column K) compute with two.  W is the layer's weight [N][ldw] (NOT transposed);

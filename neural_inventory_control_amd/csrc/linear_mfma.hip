@@ -536,6 +536,10 @@ struct WgParams {
     int64_t lds_, ldb;
     int N, K, nB, chunk;  // chunk = scenarios per split (multiple of 32)
     int swz;              // XCD-aware tile order (DMA kernel)
+    // periods (DMA kernel): the contraction runs over n_periods operand pairs dY + t * pstride_dy, X + t * pstride_x (elements)
+    // with the same scenario split in each — one launch for the whole backward sweep of a rollout
+    int n_periods;
+    int64_t pstride_dy, pstride_x;
 };
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, int FAST>
@@ -693,8 +697,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
     const int li = lane & 31, h = lane >> 5;
     float* slab = p.slab + (int64_t)split * p.N * p.lds_;
 
-    const u32x4 ra = make_desc(p.dY, (int64_t)p.N * p.ldb);
-    const u32x4 rb = make_desc(p.X, (int64_t)p.K * p.ldb);
+    u32x4 ra = make_desc(p.dY, (int64_t)p.N * p.ldb);
+    u32x4 rb = make_desc(p.X, (int64_t)p.K * p.ldb);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
     int offA[A_INSTR], offB[B_INSTR];
@@ -742,10 +746,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
     issue(0);
     dma_wait();
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
+    // flat sequence of (period, k tile): the copy of the next tile crosses period boundaries by moving the two buffer
+    // descriptors to the next period's operands and rewinding the offsets, so the pipeline never drains
+    const int total = nt * p.n_periods;
+    int t_in = 0, period = 0;
+    for (int t = 0; t < total; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) {
-            advance();
+        if (t + 1 < total) {
+            if (++t_in == nt) {
+                t_in = 0;
+                ++period;
+                ra = make_desc(p.dY + period * p.pstride_dy, (int64_t)p.N * p.ldb);
+                rb = make_desc(p.X + period * p.pstride_x, (int64_t)p.K * p.ldb);
+#pragma unroll
+                for (int q = 0; q < A_INSTR; ++q) offA[q] -= (nt - 1) * BK * 4;
+#pragma unroll
+                for (int q = 0; q < B_INSTR; ++q) offB[q] -= (nt - 1) * BK * 4;
+            } else {
+                advance();
+            }
             issue(cur ^ 1);
         }
         const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * BK;
@@ -1081,7 +1100,7 @@ int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds_,
     if (int e = require_ld("nic_linear_wgrad", n_scenarios, ldb)) return e;
     int chunk = (n_scenarios + n_splits - 1) / n_splits;
     chunk = (chunk + BK - 1) / BK * BK;
-    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1};
+    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, 1, 0, 0};
     hipStream_t s = nic::as_stream(stream);
     int bm, bn;
     wgrad_tile(N, K, &bm, &bn);
@@ -1098,6 +1117,32 @@ int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds_,
     else if (bm == 64) launch_wg<1, 4, 2, 1>(p, n_splits, s);
     else launch_wg<1, 4, 1, 2>(p, n_splits, s);
     return nic::check_launch("nic_linear_wgrad");
+}
+
+int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64_t lds_, int32_t N, int32_t K,
+                             int32_t n_scenarios, int32_t ldb, int32_t n_splits, int32_t n_periods, int64_t period_stride_dy,
+                             int64_t period_stride_x, void* stream) {
+    NIC_REQUIRE(n_periods >= 1, "nic_linear_wgrad_periods: n_periods must be >= 1");
+    NIC_REQUIRE(period_stride_dy % 4 == 0 && period_stride_x % 4 == 0,
+                "nic_linear_wgrad_periods: period strides must be multiples of 4 elements (16-byte aligned operands)");
+    const bool dma_ok = dY && X && slab && N > 0 && K > 0 && lds_ >= K + 1 && n_splits >= 1 && n_scenarios > 0 && ldb >= n_scenarios &&
+                        wgrad_big(N, K) && gemm_variant() != 2 && ldb % 4 == 0 && n_scenarios % BK == 0 && lds_ % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (int64_t)N * ldb < (1ll << 28) &&
+                        (int64_t)K * ldb < (1ll << 28);
+    if (!dma_ok) {  // any other shape: one launch per period (also validates the arguments)
+        for (int t = 0; t < n_periods; ++t)
+            if (int e = nic_linear_wgrad(dY + t * period_stride_dy, X + t * period_stride_x, slab, lds_, N, K, n_scenarios, ldb,
+                                         n_splits, stream))
+                return e;
+        return 0;
+    }
+    int chunk = (n_scenarios + n_splits - 1) / n_splits;
+    chunk = (chunk + BK - 1) / BK * BK;
+    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, period_stride_dy,
+               period_stride_x};
+    launch_wg_dma<2, 4, 4, 2>(p, n_splits, nic::as_stream(stream));
+    return nic::check_launch("nic_linear_wgrad_periods");
 }
 
 // many splits, few outputs (the small layers): one wavefront per output element, lanes stride over the splits

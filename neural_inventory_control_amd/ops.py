@@ -100,6 +100,17 @@ def linear_wgrad(dY, X, slab, n_scenarios):
     return slab
 
 
+def linear_wgrad_periods(dY, X, slab, n_scenarios):
+    """dY [T][N][ldb], X [T'][K'][ldb] views (period = leading dimension; only the strides and the first K rows of X's
+    periods matter): slab += sum_t per-split dY[t] X[t]^T in one launch."""
+    _dev(dY)
+    T, N, K = dY.shape[0], dY.shape[1], X.shape[1]
+    assert X.shape[0] == T and dY.stride(1) == X.stride(1) and dY.stride(2) == 1 and X.stride(2) == 1
+    check(lib().nic_linear_wgrad_periods(ptr(dY), ptr(X), ptr(slab), slab.stride(1), N, K, n_scenarios, dY.stride(1),
+                                         slab.shape[0], T, dY.stride(0), X.stride(0), current_stream()))
+    return slab
+
+
 def linear_bwd_thin_ok(N, K):
     """shapes nic_linear_bwd_thin takes (the logits layer of the policy MLPs)"""
     return N <= _lib.NIC_THIN_MAX_ROWS and K >= 32 and K % 32 == 0

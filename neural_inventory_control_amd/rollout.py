@@ -91,6 +91,7 @@ class FusedRollout:
         self.use_graph = False  # replay the launch sequence from a HIP graph (see _replay_or_capture)
         self.use_small = True   # whole-horizon kernels for the small one-store-chain policies (small_rollout.py)
         self.use_thin = True    # fused backward of thin (<= 32 rows) output layers (csrc/thin_layer.hip)
+        self.batch_wgrad = True  # hidden-layer weight gradients contracted over all periods in one launch
         self.small = None       # SmallRolloutPlan when the current shapes take that route
         self._prob_cache = {}
         self._prob = None
@@ -125,7 +126,7 @@ class FusedRollout:
             k = m.out_features
 
     def _setup(self, prob, T, train):
-        key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We)
+        key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
@@ -177,6 +178,10 @@ class FusedRollout:
             self.dZ = z(dims[-1], ld)
             wmax = max(dims[1:-1]) if L > 1 else 1
             self.dH = [z(wmax, ld), z(wmax, ld)]
+            # pre-activation gradients of the hidden layers for EVERY period ([T][N_l][ldb], 13.4 GB per 512-wide layer at
+            # BASELINE cfg3 — HBM is sized for it): their weight gradients are contracted once per training step over
+            # (period x scenario) instead of once per period (see _launch_backward)
+            self.dZhist = [z(T, dims[i + 1], ld) for i in range(L - 1)] if self.batch_wgrad else None
             self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], prob.B) for i in range(L)]
             self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
             self.g_reward = z(ld)
@@ -429,18 +434,21 @@ class FusedRollout:
             else:
                 ops.head_softplus_bwd(Z, gso.view(-1, ld), self.dZ, prob.S * prob.nsup, B)
             d = self.dZ
+            hist = self.dZhist
             for i in range(L - 1, -1, -1):
                 x_in = self.hidden[i - 1][t] if i > 0 else self.states[t][:self.F]
+                # gradient wrt the previous layer's pre-activation output: kept for every period when its weight gradient
+                # is contracted at the end of the sweep, else a ping-pong scratch buffer
+                dx = (hist[i - 1][t] if hist is not None else self.dH[i & 1][:self.dims[i]]) if i > 0 else None
                 if i > 0 and self._thin[i]:
                     # thin (logits) layer: weight gradient and input gradient in ONE pass over the layer's input
-                    dx = self.dH[i & 1][:self.dims[i]]
                     self._k(f"bwd_thin_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_bwd_thin, Wv[i], d, x_in, dx,
                             self.slabs[i], B, _lib.NIC_ACT_ELU)
                     d = dx
                     continue
-                self._k(f"wgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad, d, x_in, self.slabs[i], B)
+                if hist is None or i == L - 1:  # (hidden layers: contracted over all periods after the sweep)
+                    self._k(f"wgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad, d, x_in, self.slabs[i], B)
                 if i > 0:
-                    dx = self.dH[i & 1][:self.dims[i]]
                     self._k(f"dgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_dgrad, Wtv[i], d, x_in, dx, B,
                             _lib.NIC_ACT_ELU, False)
                     d = dx
@@ -448,6 +456,14 @@ class FusedRollout:
                     self._k(f"dgrad_{self.dims[1]}x{self.dims[0]}", ops.linear_dgrad, Wtv[0], d, None, g_cur[:self.F], B,
                             _lib.NIC_ACT_NONE, True)
             g_next, g_cur = g_cur, g_next
+        if self.dZhist is not None:
+            # hidden layers: dW_i = sum over (period, scenario) of dZ_i X_i^T in one launch each
+            for i in range(L - 1):
+                if i > 0 and self._thin[i]:
+                    continue  # its weight gradient came out of the fused thin-layer backward, period by period
+                x_hist = self.hidden[i - 1] if i > 0 else self.states[:T, :self.F]
+                self._k(f"wgradT_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad_periods, self.dZhist[i], x_hist,
+                        self.slabs[i], B)
         for i in range(L):
             ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], self.dims[i], 1.0)
 

@@ -218,6 +218,36 @@ def test_linear_bwd_thin_rejects_bad_shapes():
         ops.linear_bwd_thin(z[:8, :48], z[:8], z[:48], z[:48].clone(), slab, 64, _lib.NIC_ACT_ELU)     # K % 32 != 0
 
 
+@pytest.mark.parametrize("N,K,B,T", [(512, 512, 2048, 3), (256, 200, 1024, 4), (300, 512, 1056, 2), (64, 33, 100, 3)])
+def test_linear_wgrad_periods_equals_per_period_launches(N, K, B, T):
+    """One launch contracting over T operand pairs == T nic_linear_wgrad launches (LDS-DMA shapes and fallback shapes)."""
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(N + K + T)
+    ldb = pad_ld(B)
+    splits = ops.wgrad_num_splits(N, K, B)
+    lds = (K + 1 + 3) // 4 * 4
+    dY = _rand((T, N, ldb), gen, dev)
+    Xfull = _rand((T + 1, K + 5, ldb), gen, dev)  # periods are slices of a larger history block, as in the rollout
+    X = Xfull[:T, :K]
+    want_w = torch.zeros(N, K, dtype=torch.float64)
+    want_b = torch.zeros(N, dtype=torch.float64)
+    scale_w = torch.zeros(N, K, dtype=torch.float64)
+    for t in range(T):
+        dY64, X64 = dY[t].double().cpu()[:, :B], X[t].double().cpu()[:, :B]
+        want_w += dY64 @ X64.t()
+        want_b += dY64.sum(dim=1)
+        scale_w += dY64.abs() @ X64.abs().t()
+    slab = torch.zeros(splits, N, lds, device=dev)
+    ops.linear_wgrad_periods(dY, X, slab, B)
+    ops.linear_wgrad_periods(dY, X, slab, B)  # accumulates
+    dW = torch.full((N, K), float("nan"), device=dev)
+    db = torch.full((N,), float("nan"), device=dev)
+    ops.wgrad_reduce(slab, dW, db, K, 0.5)
+    torch.cuda.synchronize()
+    _close(dW, want_w, 2 * scale_w, "wgrad periods")
+    _close(db, want_b, torch.full((N,), 2.0 * T * B), "bgrad periods")
+
+
 # ---- sampler ------------------------------------------------------------------------------------------------------
 
 def test_sampler_normal_moments_and_sharding_invariance():

@@ -364,3 +364,27 @@ def test_fused_thin_layer_backward_equals_separate_gemms(name):
     assert res[True][0] == res[False][0]
     for x, y in zip(res[True][1], res[False][1]):
         assert float((x - y).norm() / (y.norm() + 1e-30)) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["cfg3_one_warehouse_16_vanilla", "cfg5_many_warehouses_3x8_vanilla"])
+def test_batched_weight_gradients_equal_per_period_contraction(name):
+    """Hidden-layer weight gradients are contracted over all periods in one launch (nic_linear_wgrad_periods); with that
+    switched off the engine accumulates them period by period — same gradients."""
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    F = sum(int(np.prod(data[k].shape[1:])) for k in ("initial_inventories", "initial_warehouse_inventories") if k in data)
+    res = {}
+    for batched in (True, False):
+        model = _model(g, c)
+        eng = FusedRollout(model, c["problem_params"], DEV)
+        eng.batch_wgrad = batched
+        eng.materialize(F)
+        _load(model, g)
+        total, _ = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+        torch.cuda.synchronize()
+        assert (eng.dZhist is not None) == batched
+        res[batched] = (float(total), [p.grad.clone() for p in model.parameters()])
+    assert res[True][0] == res[False][0]
+    for x, y in zip(res[True][1], res[False][1]):
+        assert float((x - y).norm() / (y.norm() + 1e-30)) < 2e-5
