@@ -576,9 +576,13 @@ __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
                 acc[i][j][r] = (row < p.N && col <= p.K) ? slab[(int64_t)row * p.lds_ + col] : 0.f;
             }
 
-    if (b_begin < b_end) {
-        const bool vec = (p.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.dY) & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+    // periods: the accumulators persist over n_periods operand pairs (one slab read-modify-write per launch)
+    for (int period = 0; period < p.n_periods && b_begin < b_end; ++period) {
+        const float* dYp = p.dY + period * p.pstride_dy;
+        const float* Xp = p.X + period * p.pstride_x;
+        if (period > 0) __syncthreads();  // the previous period's last tile has been read by every wave
+        const bool vec = (p.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(dYp) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(Xp) & 15) == 0);
         KTile<BM> ta;
         KTile<BN> tb;
         KTileBuf<BM> fa;
@@ -586,8 +590,8 @@ __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
         __amdgpu_buffer_rsrc_t ra, rb;
         const int nt = (b_end - b_begin + BK - 1) / BK;
         if constexpr (FAST) {
-            ra = make_rsrc(p.dY, (int64_t)p.N * p.ldb);
-            rb = make_rsrc(p.X, (int64_t)p.K * p.ldb);
+            ra = make_rsrc(dYp, (int64_t)p.N * p.ldb);
+            rb = make_rsrc(Xp, (int64_t)p.K * p.ldb);
             fa.init(p.ldb, n0, b_begin);
             fb.init(p.ldb, k0, b_begin);
             fa.load(ra);
@@ -597,8 +601,8 @@ __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
             fa.store(lds);
             fb.store(lds + BM * LDA_S);
         } else {
-            ta.load(p.dY, p.ldb, n0, p.N, b_begin, b_end, vec);
-            tb.load(p.X, p.ldb, k0, p.K, b_begin, b_end, vec, p.K, b_end);
+            ta.load(dYp, p.ldb, n0, p.N, b_begin, b_end, vec);
+            tb.load(Xp, p.ldb, k0, p.K, b_begin, b_end, vec, p.K, b_end);
             ta.store(lds);
             tb.store(lds + BM * LDA_S);
         }
@@ -612,8 +616,8 @@ __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
                     fa.load(ra);
                     fb.load(rb);
                 } else {
-                    ta.load(p.dY, p.ldb, n0, p.N, b_begin + (t + 1) * BK, b_end, vec);
-                    tb.load(p.X, p.ldb, k0, p.K, b_begin + (t + 1) * BK, b_end, vec, p.K, b_end);
+                    ta.load(dYp, p.ldb, n0, p.N, b_begin + (t + 1) * BK, b_end, vec);
+                    tb.load(Xp, p.ldb, k0, p.K, b_begin + (t + 1) * BK, b_end, vec, p.K, b_end);
                 }
             }
             const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * LDA_S;
@@ -1092,31 +1096,38 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
     return splits;
 }
 
-int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds_, int32_t N, int32_t K, int32_t n_scenarios,
-                     int32_t ldb, int32_t n_splits, void* stream) {
-    NIC_REQUIRE(dY && X && slab, "nic_linear_wgrad: null buffer");
-    NIC_REQUIRE(N > 0 && K > 0 && lds_ >= K + 1, "nic_linear_wgrad: bad N/K/lds (%d/%d/%lld)", N, K, (long long)lds_);
-    NIC_REQUIRE(n_splits >= 1, "nic_linear_wgrad: n_splits must be >= 1");
-    if (int e = require_ld("nic_linear_wgrad", n_scenarios, ldb)) return e;
+// argument checks + dispatch shared by nic_linear_wgrad (one period) and nic_linear_wgrad_periods
+static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t lds_, int32_t N, int32_t K, int32_t n_scenarios,
+                         int32_t ldb, int32_t n_splits, int32_t n_periods, int64_t pstride_dy, int64_t pstride_x, void* stream,
+                         const char* who) {
+    NIC_REQUIRE(dY && X && slab, "%s: null buffer", who);
+    NIC_REQUIRE(N > 0 && K > 0 && lds_ >= K + 1, "%s: bad N/K/lds (%d/%d/%lld)", who, N, K, (long long)lds_);
+    NIC_REQUIRE(n_splits >= 1, "%s: n_splits must be >= 1", who);
+    if (int e = require_ld(who, n_scenarios, ldb)) return e;
     int chunk = (n_scenarios + n_splits - 1) / n_splits;
     chunk = (chunk + BK - 1) / BK * BK;
-    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, 1, 0, 0};
+    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, pstride_dy, pstride_x};
     hipStream_t s = nic::as_stream(stream);
     int bm, bn;
     wgrad_tile(N, K, &bm, &bn);
     const bool dma_ok = ldb % 4 == 0 && n_scenarios % BK == 0 && lds_ % 4 == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 &&
                         (int64_t)N * ldb < (1ll << 28) && (int64_t)K * ldb < (1ll << 28);
-    const bool small_ok = N <= 32 && K <= 32 && n_splits % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0 &&
-                          (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (int64_t)N * ldb < (1ll << 28) &&
-                          (int64_t)K * ldb < (1ll << 28);
+    const bool small_ok = n_periods == 1 && N <= 32 && K <= 32 && n_splits % 4 == 0 && ldb % 4 == 0 &&
+                          (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+                          (int64_t)N * ldb < (1ll << 28) && (int64_t)K * ldb < (1ll << 28);
     if (small_ok) hipLaunchKernelGGL(wgrad_small_kernel, dim3(n_splits / 4), dim3(kThreads), 0, s, p);
     else if (wgrad_big(N, K) && dma_ok && gemm_variant() != 2) launch_wg_dma<2, 4, 4, 2>(p, n_splits, s);
     else if (bm == 128 && bn == 128) launch_wg<2, 2, 2, 2>(p, n_splits, s);
     else if (bm == 128) launch_wg<2, 2, 2, 1>(p, n_splits, s);
     else if (bm == 64) launch_wg<1, 4, 2, 1>(p, n_splits, s);
     else launch_wg<1, 4, 1, 2>(p, n_splits, s);
-    return nic::check_launch("nic_linear_wgrad");
+    return nic::check_launch(who);
+}
+
+int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds_, int32_t N, int32_t K, int32_t n_scenarios,
+                     int32_t ldb, int32_t n_splits, void* stream) {
+    return wgrad_generic(dY, X, slab, lds_, N, K, n_scenarios, ldb, n_splits, 1, 0, 0, stream, "nic_linear_wgrad");
 }
 
 int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64_t lds_, int32_t N, int32_t K,
@@ -1130,12 +1141,17 @@ int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64
                         (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (int64_t)N * ldb < (1ll << 28) &&
                         (int64_t)K * ldb < (1ll << 28);
-    if (!dma_ok) {  // any other shape: one launch per period (also validates the arguments)
-        for (int t = 0; t < n_periods; ++t)
-            if (int e = nic_linear_wgrad(dY + t * period_stride_dy, X + t * period_stride_x, slab, lds_, N, K, n_scenarios, ldb,
-                                         n_splits, stream))
-                return e;
-        return 0;
+    if (!dma_ok) {  // other shapes: the register-staged kernels loop over the periods themselves; tiny layers one launch each
+        const bool small = N <= 32 && K <= 32;
+        if (small || n_periods == 1) {
+            for (int t = 0; t < n_periods; ++t)
+                if (int e = nic_linear_wgrad(dY + t * period_stride_dy, X + t * period_stride_x, slab, lds_, N, K, n_scenarios,
+                                             ldb, n_splits, stream))
+                    return e;
+            return 0;
+        }
+        return wgrad_generic(dY, X, slab, lds_, N, K, n_scenarios, ldb, n_splits, n_periods, period_stride_dy, period_stride_x,
+                             stream, "nic_linear_wgrad_periods");
     }
     int chunk = (n_scenarios + n_splits - 1) / n_splits;
     chunk = (chunk + BK - 1) / BK * BK;

@@ -126,7 +126,7 @@ class FusedRollout:
             k = m.out_features
 
     def _setup(self, prob, T, train):
-        key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad)
+        key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
@@ -182,6 +182,9 @@ class FusedRollout:
             # BASELINE cfg3 — HBM is sized for it): their weight gradients are contracted once per training step over
             # (period x scenario) instead of once per period (see _launch_backward)
             self.dZhist = [z(T, dims[i + 1], ld) for i in range(L - 1)] if self.batch_wgrad else None
+            # ... and the logits gradient too, unless the logits layer takes the fused thin-layer backward (per period)
+            thin_last = L > 1 and self.use_thin and ops.linear_bwd_thin_ok(dims[L], dims[L - 1])
+            self.dZlast_hist = z(T, dims[-1], ld) if self.batch_wgrad and not thin_last else None
             self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], prob.B) for i in range(L)]
             self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
             self.g_reward = z(ld)
@@ -426,15 +429,16 @@ class FusedRollout:
                     g_orders=(gso, gwo, geo))
             Z = self.logits[t]
             gc = self._views(g_cur, prob)
+            hist, last_hist = self.dZhist, self.dZlast_hist
+            dZ = last_hist[t] if last_hist is not None else self.dZ
             if self.head == "warehouse":
-                ops.head_warehouse_bwd(Z, st.wh, self.adj, ub, bool(self.model.transshipment), gso, gwo, self.dZ, gc.wh,
+                ops.head_warehouse_bwd(Z, st.wh, self.adj, ub, bool(self.model.transshipment), gso, gwo, dZ, gc.wh,
                                        prob.S, prob.Wn, prob.Ww, B)
             elif self.head == "serial":
-                ops.head_serial_bwd(Z, st.wh, st.ech, ub, gso, gwo, geo, self.dZ, gc.wh, gc.ech, prob.E, prob.Ww, prob.We, B)
+                ops.head_serial_bwd(Z, st.wh, st.ech, ub, gso, gwo, geo, dZ, gc.wh, gc.ech, prob.E, prob.Ww, prob.We, B)
             else:
-                ops.head_softplus_bwd(Z, gso.view(-1, ld), self.dZ, prob.S * prob.nsup, B)
-            d = self.dZ
-            hist = self.dZhist
+                ops.head_softplus_bwd(Z, gso.view(-1, ld), dZ, prob.S * prob.nsup, B)
+            d = dZ
             for i in range(L - 1, -1, -1):
                 x_in = self.hidden[i - 1][t] if i > 0 else self.states[t][:self.F]
                 # gradient wrt the previous layer's pre-activation output: kept for every period when its weight gradient
@@ -446,7 +450,7 @@ class FusedRollout:
                             self.slabs[i], B, _lib.NIC_ACT_ELU)
                     d = dx
                     continue
-                if hist is None or i == L - 1:  # (hidden layers: contracted over all periods after the sweep)
+                if hist is None or (i == L - 1 and last_hist is None):  # (else: contracted over all periods after the sweep)
                     self._k(f"wgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad, d, x_in, self.slabs[i], B)
                 if i > 0:
                     self._k(f"dgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_dgrad, Wtv[i], d, x_in, dx, B,
@@ -458,11 +462,12 @@ class FusedRollout:
             g_next, g_cur = g_cur, g_next
         if self.dZhist is not None:
             # hidden layers: dW_i = sum over (period, scenario) of dZ_i X_i^T in one launch each
-            for i in range(L - 1):
-                if i > 0 and self._thin[i]:
-                    continue  # its weight gradient came out of the fused thin-layer backward, period by period
+            for i in range(L):
+                if (i > 0 and self._thin[i]) or (i == L - 1 and self.dZlast_hist is None):
+                    continue  # its weight gradient was accumulated period by period (fused thin-layer backward / no history)
                 x_hist = self.hidden[i - 1] if i > 0 else self.states[:T, :self.F]
-                self._k(f"wgradT_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad_periods, self.dZhist[i], x_hist,
+                dz_hist = self.dZhist[i] if i < L - 1 else self.dZlast_hist
+                self._k(f"wgradT_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad_periods, dz_hist, x_hist,
                         self.slabs[i], B)
         for i in range(L):
             ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], self.dims[i], 1.0)
