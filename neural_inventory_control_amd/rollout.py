@@ -181,10 +181,14 @@ class FusedRollout:
             # pre-activation gradients of the hidden layers for EVERY period ([T][N_l][ldb], 13.4 GB per 512-wide layer at
             # BASELINE cfg3 — HBM is sized for it): their weight gradients are contracted once per training step over
             # (period x scenario) instead of once per period (see _launch_backward)
-            self.dZhist = [z(T, dims[i + 1], ld) for i in range(L - 1)] if self.batch_wgrad else None
+            hist_bytes = 4 * T * ld * sum(dims[1:])
+            free_bytes = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 0
+            # not enough HBM left for the gradient history -> accumulate weight gradients period by period
+            batch = self.batch_wgrad and hist_bytes <= 0.6 * free_bytes
+            self.dZhist = [z(T, dims[i + 1], ld) for i in range(L - 1)] if batch else None
             # ... and the logits gradient too, unless the logits layer takes the fused thin-layer backward (per period)
             thin_last = L > 1 and self.use_thin and ops.linear_bwd_thin_ok(dims[L], dims[L - 1])
-            self.dZlast_hist = z(T, dims[-1], ld) if self.batch_wgrad and not thin_last else None
+            self.dZlast_hist = z(T, dims[-1], ld) if batch and not thin_last else None
             self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], prob.B) for i in range(L)]
             self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
             self.g_reward = z(ld)
