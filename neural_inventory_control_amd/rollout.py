@@ -131,6 +131,9 @@ class FusedRollout:
             return
         dev, ld = self.device, prob.ldb
         self._prob = None
+        for name in ("states", "orders", "logits", "hidden", "dZhist", "dZlast_hist", "dH", "slabs", "sr_states", "sr_hidden",
+                     "sr_logits", "sr_dzh", "sr_dzo"):
+            setattr(self, name, None)  # release the previous shapes' buffers before sizing the new ones
         self.F_store, self.F_wh, self.F_ech = prob.S * prob.Ws, prob.Wn * prob.Ww, prob.E * prob.We
         F = self.F_store + self.F_wh + self.F_ech
         if self.head == "softplus":
@@ -182,7 +185,9 @@ class FusedRollout:
             # BASELINE cfg3 — HBM is sized for it): their weight gradients are contracted once per training step over
             # (period x scenario) instead of once per period (see _launch_backward)
             hist_bytes = 4 * T * ld * sum(dims[1:])
-            free_bytes = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 0
+            # free HBM = what the driver reports + what torch's caching allocator holds but is not using
+            free_bytes = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                          if dev.type == "cuda" else 0)
             # not enough HBM left for the gradient history -> accumulate weight gradients period by period
             batch = self.batch_wgrad and hist_bytes <= 0.6 * free_bytes
             self.dZhist = [z(T, dims[i + 1], ld) for i in range(L - 1)] if batch else None
