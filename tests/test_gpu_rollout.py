@@ -388,3 +388,41 @@ def test_batched_weight_gradients_equal_per_period_contraction(name):
     assert res[True][0] == res[False][0]
     for x, y in zip(res[True][1], res[False][1]):
         assert float((x - y).norm() / (y.norm() + 1e-30)) < 2e-5
+
+
+@pytest.mark.parametrize("name,B", [("cfg3_one_warehouse_16_vanilla", 333), ("cfg1_one_store_lost_vanilla", 201),
+                                     ("cfg4_serial_vanilla", 130), ("cfg5_many_warehouses_2x10_vanilla", 77)])
+def test_ragged_multi_block_batch_matches_oracle(name, B):
+    """Batch sizes that are neither a multiple of 4 nor of the 64-scenario block (several blocks + a ragged tail), fresh
+    random demands: per-scenario costs, totals and gradients of the HIP engine against the CPU oracle on the same inputs."""
+    from oracle import inventory_oracle as orc
+    g = Golden(name)
+    c = g.fresh_config()
+    n = c["n"]
+    reps = B // n + 1
+    gen = torch.Generator(device="cpu").manual_seed(B)
+    data = {k: v.repeat(*([reps] + [1] * (v.dim() - 1)))[:B].contiguous() for k, v in g.data.items()}
+    d = data["demands"]
+    data["demands"] = (d * (0.5 + torch.rand(d.shape, generator=gen))).contiguous()
+    model = _model(g, c)
+    eng = FusedRollout(model, c["problem_params"], DEV)
+    F = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
+    if c["policy"] != "vanilla_one_store":
+        F += sum(int(np.prod(data[k].shape[1:])) for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
+                 if k in data)
+    eng.materialize(F)
+    _load(model, g)
+    total, reported = eng.run({k: v.to(DEV) for k, v in data.items()}, c["periods"], c["ignore"], train=True,
+                              observation_params=c["observation_params"])
+    torch.cuda.synchronize()
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"], g.tensor("warehouse_upper_bound"))
+    res, _, grads = orc.train_step_gradients(pol, c["periods"], c["problem_params"], data, c["observation_params"],
+                                             c["ignore"])
+    assert abs(float(total) - float(res.total)) <= 1e-5 * abs(float(res.total))
+    assert abs(float(reported) - float(res.reported)) <= 1e-5 * abs(float(res.reported))
+    tot_b = eng.per_period_rewards().sum(dim=0).cpu()
+    ref_b = res.per_period.sum(dim=0)
+    assert float(((tot_b - ref_b).abs() / ref_b.abs().clamp_min(1e-9)).max()) <= 1e-5
+    tol = max(GRAD_TOL.get(name, 2e-5), 1e-4)  # fresh demands may put a few more scenarios on a clamp knife edge
+    for p, ref in zip(model.parameters(), grads):
+        assert float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30)) <= tol
