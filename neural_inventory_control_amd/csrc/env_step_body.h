@@ -84,6 +84,31 @@ constexpr int kQuad = 4;
 
 NIC_HD float combine4(float p0, float p1, float p2, float p3) { return ((p0 + p1) + p2) + p3; }
 
+// Stores are processed kStoreBatch at a time in three phases (all loads, arithmetic + order placement, all stores): a lane
+// then has kStoreBatch x (slots + 3) independent loads in flight instead of one store's worth, which is what this
+// latency-bound kernel lacked (one wave per SIMD or two at B = 32k: 1.7 TB/s).  Reading store s + 4 before store s is
+// written is also valid for in-place updates (different rows).  The arithmetic and its order are unchanged.
+constexpr int kStoreBatch = 4;
+constexpr int kSupBatch = 3;  // suppliers per store whose order / lead time are fetched in the load phase
+
+template <int MAXW>
+NIC_HD void load_pipeline(const float* slots, int64_t ldb, int W, float (&old)[MAXW]) {
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) old[k] = k < W ? slots[(int64_t)k * ldb] : 0.f;
+}
+
+// shifted_pipeline on already loaded slots
+template <int MAXW>
+NIC_HD void shift_loaded(const float (&old)[MAXW], int W, float on_hand_after, float (&nv)[MAXW]) {
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) {
+        float v = 0.f;
+        if (k == 0) v = on_hand_after + (MAXW > 1 ? old[1] : 0.f);
+        else if (k < W - 1) v = old[k + 1 < MAXW ? k + 1 : k];
+        nv[k] = v;
+    }
+}
+
 // stores s = q, q+4, ...: cost + pipeline update; returns this lane's partial store cost
 template <int MAXW>
 NIC_HD float env_fwd_stores(const NicEnvStepIO& io, float* store_out, int64_t b, int q) {
@@ -91,25 +116,53 @@ NIC_HD float env_fwd_stores(const NicEnvStepIO& io, float* store_out, int64_t b,
     const int64_t ldb = d.ldb;
     const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
     float r = 0.f;
-    for (int s = q; s < d.n_stores; s += kQuad) {
-        const float* inv = io.store_inv + (int64_t)s * d.store_slots * ldb + b;
-        const float on_hand = inv[0];
-        const float dem = t2(io.demand, s, b);
-        float after = on_hand - dem;
-        const float p = t2(io.underage, s, b), h = t2(io.holding, s, b);
-        float c;
-        if (d.maximize_profit) {
-            c = (-p) * (on_hand < dem ? on_hand : dem) + h * relu(after);  // :191-194
-        } else {
-            c = p * relu(-after) + h * relu(after);  // :198-201
+    for (int s0 = q; s0 < d.n_stores; s0 += kQuad * kStoreBatch) {
+        float old[kStoreBatch][MAXW], nv[kStoreBatch][MAXW], dem[kStoreBatch], p[kStoreBatch], h[kStoreBatch];
+        float ord[kStoreBatch][kSupBatch], lead[kStoreBatch][kSupBatch];  // (suppliers beyond kSupBatch are read in phase 2)
+#pragma unroll
+        for (int u = 0; u < kStoreBatch; ++u) {
+            const int s = s0 + u * kQuad;
+            if (s < d.n_stores) {
+                load_pipeline<MAXW>(io.store_inv + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, old[u]);
+                dem[u] = t2(io.demand, s, b);
+                p[u] = t2(io.underage, s, b);
+                h[u] = t2(io.holding, s, b);
+#pragma unroll
+                for (int w = 0; w < kSupBatch; ++w) {
+                    if (w < nsup) {
+                        ord[u][w] = t3(io.store_orders, s, w, b);
+                        lead[u][w] = t3(io.lead_times, s, w, b);
+                    }
+                }
+            }
         }
-        r += c;
-        if (d.lost_demand) after = relu(after);  // :204-205
-        float nv[MAXW];
-        shifted_pipeline<MAXW>(inv, ldb, d.store_slots, after, nv);
-        for (int w = 0; w < nsup; ++w)
-            place_order<MAXW>(nv, d.store_slots, t3(io.store_orders, s, w, b), t3(io.lead_times, s, w, b));
-        store_pipeline<MAXW>(store_out + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, nv);
+#pragma unroll
+        for (int u = 0; u < kStoreBatch; ++u) {
+            const int s = s0 + u * kQuad;
+            if (s < d.n_stores) {
+                const float on_hand = old[u][0];
+                float after = on_hand - dem[u];
+                float c;
+                if (d.maximize_profit) {
+                    c = (-p[u]) * (on_hand < dem[u] ? on_hand : dem[u]) + h[u] * relu(after);  // :191-194
+                } else {
+                    c = p[u] * relu(-after) + h[u] * relu(after);  // :198-201
+                }
+                r += c;
+                if (d.lost_demand) after = relu(after);  // :204-205
+                shift_loaded<MAXW>(old[u], d.store_slots, after, nv[u]);
+#pragma unroll
+                for (int w = 0; w < kSupBatch; ++w)
+                    if (w < nsup) place_order<MAXW>(nv[u], d.store_slots, ord[u][w], lead[u][w]);
+                for (int w = kSupBatch; w < nsup; ++w)
+                    place_order<MAXW>(nv[u], d.store_slots, t3(io.store_orders, s, w, b), t3(io.lead_times, s, w, b));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kStoreBatch; ++u) {
+            const int s = s0 + u * kQuad;
+            if (s < d.n_stores) store_pipeline<MAXW>(store_out + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, nv[u]);
+        }
     }
     return r;
 }
@@ -265,34 +318,63 @@ NIC_HD void env_bwd_stores(const NicEnvStepIO& io, const float* g_store_out, flo
     const NicEnvDims& d = io.dims;
     const int64_t ldb = d.ldb;
     const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
-    for (int s = q; s < d.n_stores; s += kQuad) {
-        const float* inv = io.store_inv + (int64_t)s * d.store_slots * ldb + b;
-        const float on_hand = inv[0];
-        const float dem = t2(io.demand, s, b);
-        const float after = on_hand - dem;
-        const float p = t2(io.underage, s, b), h = t2(io.holding, s, b);
-        float gn[MAXW];
-        load_grad<MAXW>(g_store_out ? g_store_out + (int64_t)s * d.store_slots * ldb + b : nullptr, ldb, d.store_slots, gn);
-        // through the carried inventory (lost demand clips it at 0: gradient where after >= 0)
-        float g_after = gn[0];
-        if (d.lost_demand && !(after >= 0.f)) g_after = 0.f;
-        float g_on_hand;
-        if (d.maximize_profit) {
-            if (after >= 0.f) g_after += gr * h;
-            const float share = on_hand < dem ? 1.f : (on_hand == dem ? 0.5f : 0.f);  // minimum() tie rule
-            g_on_hand = g_after + gr * (-p) * share;
-        } else {
-            float gc = 0.f;
-            if (-after >= 0.f) gc += -p;  // d/d(after) of p*clamp(-after, 0)
-            if (after >= 0.f) gc += h;    // d/d(after) of h*clamp(after, 0)
-            g_on_hand = g_after + gr * gc;
+    // same three-phase batching as env_fwd_stores
+    for (int s0 = q; s0 < d.n_stores; s0 += kQuad * kStoreBatch) {
+        float gn[kStoreBatch][MAXW], on_hand[kStoreBatch], dem[kStoreBatch], p[kStoreBatch], h[kStoreBatch];
+        float ord[kStoreBatch][kSupBatch], lead[kStoreBatch][kSupBatch];
+#pragma unroll
+        for (int u = 0; u < kStoreBatch; ++u) {
+            const int s = s0 + u * kQuad;
+            if (s < d.n_stores) {
+                on_hand[u] = io.store_inv[(int64_t)s * d.store_slots * ldb + b];
+                dem[u] = t2(io.demand, s, b);
+                p[u] = t2(io.underage, s, b);
+                h[u] = t2(io.holding, s, b);
+#pragma unroll
+                for (int w = 0; w < kSupBatch; ++w) {
+                    if (w < nsup) {
+                        ord[u][w] = t3(io.store_orders, s, w, b);
+                        lead[u][w] = t3(io.lead_times, s, w, b);
+                    }
+                }
+                load_grad<MAXW>(g_store_out ? g_store_out + (int64_t)s * d.store_slots * ldb + b : nullptr, ldb, d.store_slots,
+                                gn[u]);
+            }
         }
-        store_pipeline_grad<MAXW>(g_store_in + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, gn, g_on_hand);
-        for (int w = 0; w < nsup; ++w) {
-            const float a = t3(io.store_orders, s, w, b);
-            float ga = (a != 0.f) ? pick<MAXW>(gn, d.store_slots, (int)t3(io.lead_times, s, w, b) - 1) : 0.f;
-            if (d.n_warehouses > 0) ga += -g_wafter(w);  // the outflow sum has no zero filter (:247)
-            g_store_orders[((int64_t)s * nsup + w) * ldb + b] = ga;
+#pragma unroll
+        for (int u = 0; u < kStoreBatch; ++u) {
+            const int s = s0 + u * kQuad;
+            if (s >= d.n_stores) continue;
+            const float after = on_hand[u] - dem[u];
+            // through the carried inventory (lost demand clips it at 0: gradient where after >= 0)
+            float g_after = gn[u][0];
+            if (d.lost_demand && !(after >= 0.f)) g_after = 0.f;
+            float g_on_hand;
+            if (d.maximize_profit) {
+                if (after >= 0.f) g_after += gr * h[u];
+                const float share = on_hand[u] < dem[u] ? 1.f : (on_hand[u] == dem[u] ? 0.5f : 0.f);  // minimum() tie rule
+                g_on_hand = g_after + gr * (-p[u]) * share;
+            } else {
+                float gc = 0.f;
+                if (-after >= 0.f) gc += -p[u];  // d/d(after) of p*clamp(-after, 0)
+                if (after >= 0.f) gc += h[u];    // d/d(after) of h*clamp(after, 0)
+                g_on_hand = g_after + gr * gc;
+            }
+            store_pipeline_grad<MAXW>(g_store_in + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, gn[u], g_on_hand);
+#pragma unroll
+            for (int w = 0; w < kSupBatch; ++w) {
+                if (w < nsup) {
+                    float ga = (ord[u][w] != 0.f) ? pick<MAXW>(gn[u], d.store_slots, (int)lead[u][w] - 1) : 0.f;
+                    if (d.n_warehouses > 0) ga += -g_wafter(w);  // the outflow sum has no zero filter (:247)
+                    g_store_orders[((int64_t)s * nsup + w) * ldb + b] = ga;
+                }
+            }
+            for (int w = kSupBatch; w < nsup; ++w) {
+                const float a = t3(io.store_orders, s, w, b);
+                float ga = (a != 0.f) ? pick<MAXW>(gn[u], d.store_slots, (int)t3(io.lead_times, s, w, b) - 1) : 0.f;
+                if (d.n_warehouses > 0) ga += -g_wafter(w);
+                g_store_orders[((int64_t)s * nsup + w) * ldb + b] = ga;
+            }
         }
     }
 }

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     // every CU at once, on top of the write burst.  The kernel has ~80 free VGPRs, so the rows of the first pass are fetched
     // into registers during the last PFT k tiles (each batch completes under that tile's MFMAs, before its dma_wait), and
     // the rows of the second pass are fetched into the same registers as the first pass consumes them.
-    constexpr int PFT = 4;
+    constexpr int PFT = 8;
     static_assert(ITER % PFT == 0, "prefetch batches must divide the pass");
     float4 hq[ITER];  // (dead in the forward instantiation)
     const bool pf_on = EPI == EPI_DGRAD && p.Hprev != nullptr && p.act == NIC_ACT_ELU && nk >= PFT && !p.accumulate;
