@@ -25,28 +25,68 @@ NIC_HD float softplus1_grad(float z) {
 
 // vanilla_warehouse head.  neural_networks.py:393-426 + apply_softmax_feasibility_function :140-166.
 //   Z rows: s*Wn + w (store s <- warehouse w), then S*Wn + w (warehouse w's own order logit)
+// Store loops run in batches of kHeadBatch with the loads of a batch issued before its arithmetic (one lane walks up to
+// S stores three times: with one load in flight at a time the kernel was pure latency).  Loads are unconditional (the
+// adjacency only selects which values are used), the arithmetic and its order are unchanged.
+constexpr int kHeadBatch = 8;
+
 NIC_HD void head_warehouse_fwd_one(const float* Z, const float* wh_inv, const int32_t* adj, float ub, int transshipment,
                                    float* store_orders, float* wh_orders, int S, int Wn, int Ww, int64_t ldb, int64_t b,
                                    int w) {
     const float stock = wh_inv[(int64_t)w * Ww * ldb + b];  // on-hand slot of warehouse w (:146)
+    const float* Zw = Z + (int64_t)w * ldb + b;             // row s*Wn + w  ->  Zw[s * Wn * ldb]
+    const int64_t rs = (int64_t)Wn * ldb;
+    const int32_t* aw = adj + w * S;
     // pass 1: max over connected logits (and the constant-1 'keep' logit unless transshipment)
     float m = transshipment ? -INFINITY : 1.f;
     int n_conn = 0;
-    for (int s = 0; s < S; ++s)
-        if (adj[w * S + s]) {
-            const float z = Z[((int64_t)s * Wn + w) * ldb + b];
-            m = z > m ? z : m;
-            ++n_conn;
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch];
+        int a[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            a[u] = s0 + u < S ? aw[s] : 0;
         }
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (a[u]) {
+                m = z[u] > m ? z[u] : m;
+                ++n_conn;
+            }
+    }
     // pass 2: denominator
     float denom = transshipment ? 0.f : expf(1.f - m);
-    for (int s = 0; s < S; ++s)
-        if (adj[w * S + s]) denom += expf(Z[((int64_t)s * Wn + w) * ldb + b] - m);
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch];
+        int a[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            a[u] = s0 + u < S ? aw[s] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (a[u]) denom += expf(z[u] - m);
+    }
     // pass 3: shares of the on-hand stock
-    for (int s = 0; s < S; ++s) {
-        float o = 0.f;
-        if (adj[w * S + s] && n_conn > 0) o = (expf(Z[((int64_t)s * Wn + w) * ldb + b] - m) / denom) * stock;
-        store_orders[((int64_t)s * Wn + w) * ldb + b] = o;
+    float* ow = store_orders + (int64_t)w * ldb + b;
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch], o[kHeadBatch];
+        int a[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            a[u] = s0 + u < S ? aw[s] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) o[u] = (a[u] && n_conn > 0) ? (expf(z[u] - m) / denom) * stock : 0.f;
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (s0 + u < S) ow[(s0 + u) * rs] = o[u];
     }
     wh_orders[(int64_t)w * ldb + b] = sigmoidf_(Z[((int64_t)S * Wn + w) * ldb + b]) * ub;  // :422
 }
@@ -63,33 +103,81 @@ NIC_HD void head_warehouse_bwd_one(const float* Z, const float* wh_inv, const in
                                    const float* g_store_orders, const float* g_wh_orders, float* dZ, float* g_wh_inv, int S,
                                    int Wn, int Ww, int64_t ldb, int64_t b, int w) {
     const float stock = wh_inv[(int64_t)w * Ww * ldb + b];
+    const float* Zw = Z + (int64_t)w * ldb + b;
+    const float* gw = g_store_orders + (int64_t)w * ldb + b;
+    const int64_t rs = (int64_t)Wn * ldb;
+    const int32_t* aw = adj + w * S;
     float m = transshipment ? -INFINITY : 1.f;
-    for (int s = 0; s < S; ++s)
-        if (adj[w * S + s]) {
-            const float z = Z[((int64_t)s * Wn + w) * ldb + b];
-            m = z > m ? z : m;
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch];
+        int a[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            a[u] = s0 + u < S ? aw[s] : 0;
         }
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (a[u]) m = z[u] > m ? z[u] : m;
+    }
     float denom = transshipment ? 0.f : expf(1.f - m);
-    for (int s = 0; s < S; ++s)
-        if (adj[w * S + s]) denom += expf(Z[((int64_t)s * Wn + w) * ldb + b] - m);
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch];
+        int a[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            a[u] = s0 + u < S ? aw[s] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (a[u]) denom += expf(z[u] - m);
+    }
     // order_s = y_s * stock;  g_y_s = g_order_s * stock;  g_stock = sum_s g_order_s * y_s
     // softmax backward: dz_s = y_s * (g_y_s - sum_j y_j g_y_j)   (the keep column has g_y = 0)
     float dot = 0.f, g_stock = 0.f;
-    for (int s = 0; s < S; ++s)
-        if (adj[w * S + s]) {
-            const float y = expf(Z[((int64_t)s * Wn + w) * ldb + b] - m) / denom;
-            const float go = g_store_orders[((int64_t)s * Wn + w) * ldb + b];
-            dot += y * (go * stock);
-            g_stock += go * y;
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch], go[kHeadBatch];
+        int a[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            go[u] = gw[s * rs];
+            a[u] = s0 + u < S ? aw[s] : 0;
         }
-    for (int s = 0; s < S; ++s) {
-        float dz = 0.f;
-        if (adj[w * S + s]) {
-            const float y = expf(Z[((int64_t)s * Wn + w) * ldb + b] - m) / denom;
-            const float go = g_store_orders[((int64_t)s * Wn + w) * ldb + b];
-            dz = y * (go * stock - dot);
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (a[u]) {
+                const float y = expf(z[u] - m) / denom;
+                dot += y * (go[u] * stock);
+                g_stock += go[u] * y;
+            }
+    }
+    float* dw = dZ + (int64_t)w * ldb + b;
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch], go[kHeadBatch], dz[kHeadBatch];
+        int a[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            go[u] = gw[s * rs];
+            a[u] = s0 + u < S ? aw[s] : 0;
         }
-        dZ[((int64_t)s * Wn + w) * ldb + b] = dz;
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            dz[u] = 0.f;
+            if (a[u]) {
+                const float y = expf(z[u] - m) / denom;
+                dz[u] = y * (go[u] * stock - dot);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (s0 + u < S) dw[(s0 + u) * rs] = dz[u];
     }
     g_wh_inv[(int64_t)w * Ww * ldb + b] += g_stock;
     const float sg = sigmoidf_(Z[((int64_t)S * Wn + w) * ldb + b]);
