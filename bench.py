@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--timing-stride", type=int, default=5,
                     help="bracket every n-th launch of each kernel class with HIP events (1 = all; each pair costs ~5 us)")
     ap.add_argument("--graph", action="store_true", help="replay the launch sequence from a HIP graph (implies --no-kernel-timing)")
+    ap.add_argument("--eval", action="store_true",
+                    help="SURVEY 8(f2): time the forward-only evaluation pass (Trainer.test: no gradients, discrete allocation "
+                         "for Poisson demand) instead of a training step; use with --periods 5000 for the reference's test horizon")
     args = ap.parse_args()
 
     from neural_inventory_control_amd import _lib, parallel
@@ -142,7 +145,17 @@ def main():
     global_b = n * world
     grad_scale = 1.0 / (global_b * T * S)
 
+    discrete = bool(args.eval) and setting["store_params"]["demand"].get("distribution") == "poisson"
+
+    def eval_step():
+        with torch.no_grad():
+            total, _ = eng.run(data, T, 0, train=False, observation_params=setting["observation_params"],
+                               demand_soa=sc.demands_soa, discrete_allocation=discrete)
+        return total
+
     def step():
+        if args.eval:
+            return eval_step()
         opt.zero_grad(set_to_none=True)
         total, reported = eng.run(data, T, 0, train=True, observation_params=setting["observation_params"],
                                   demand_soa=sc.demands_soa, grad_scale=grad_scale)
@@ -176,11 +189,13 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         out = {
-            "metric": "scenario-steps/sec (scenarios x stores x T) per training step",
+            "metric": "scenario-steps/sec (scenarios x stores x T) per " + ("evaluation pass" if args.eval else "training step"),
             "value": global_b * S * T * args.steps / dt, "unit": "scenario-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc + "; training step = rollout fwd + bwd + Adam" + (" + RCCL grad all-reduce" if world > 1 else ""),
+            "config": {"workload": desc + ("; evaluation pass = forward rollout only" + (", discrete allocation" if discrete else "")
+                                           if args.eval else
+                                           "; training step = rollout fwd + bwd + Adam" + (" + RCCL grad all-reduce" if world > 1 else "")),
                        "name": args.workload, "scenarios_per_gpu": n, "global_scenarios": global_b, "stores": S,
                        "periods": T, "parallelism": f"scenario-sharded dp{world}",
                        "mean_cost_per_store_period": loss},
@@ -238,7 +253,7 @@ def main():
                                                 "frac": gbs / 8000.0, "kernel": "env_step_fwd_kernel",
                                                 "algorithmic_bytes_per_launch": env_bytes,
                                                 "mean_launch_ms": summ["env_fwd"][1]}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.eval:
             sample = args.cpu_sample or {"cfg3": 4096, "cfg5": 1024, "cfg2": 32768, "cfg4": 16384, "cfg1": 256}.get(args.workload, 1024)
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, min(sample, n), T)

@@ -136,6 +136,10 @@ int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds, 
 int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64_t lds, int32_t N, int32_t K,
                              int32_t n_scenarios, int32_t ldb, int32_t n_splits, int32_t n_periods,
                              int64_t period_stride_dy, int64_t period_stride_x, void* stream);
+/* x[r][b] = rint(x[r][b]) (round half to even = torch.round) over rows x n_scenarios of a scenario-minor block: the
+ * reference's discrete allocation `action.round()` (trainer.py:201-202) between the policy head and the env step. */
+int nic_round_orders(float* x, int32_t rows, int32_t n_scenarios, int32_t ldb, void* stream);
+
 /* Fused backward of a thin layer (N <= NIC_THIN_MAX_ROWS output rows, K % 32 == 0: the logits layer of the policy
  * MLPs): one pass over X computes what nic_linear_dgrad (dX = act'(X) * W^T dY, no accumulate) and nic_linear_wgrad
  * (slab += dY X^T per split, bias column K) compute with two.  W is the layer's weight [N][ldw] (NOT transposed);
@@ -199,6 +203,8 @@ typedef struct NicSmallRolloutDesc {
     int32_t Ws, Wn, Ww, E, We;
     int32_t lost_demand, maximize_profit;
     int32_t detach_input;                  /* 1: no gradient through the MLP input (vanilla_serial, :329) */
+    int32_t round_orders;                  /* 1: orders rounded half-to-even before the env step (discrete allocation,
+                                              trainer.py:201-202); forward / evaluation only */
     float upper_bound;                     /* model.warehouse_upper_bound (head 1) */
     const float* weights;                  /* packed: [W1 32xF][b1 32] [W_l 32x32][b_l 32]... [Wout n_out x 32][bout n_out] */
     const float* demand;                   /* [T_total][ldb] */

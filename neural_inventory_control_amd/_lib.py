@@ -50,7 +50,7 @@ class NicEnvStepIO(C.Structure):
 class NicSmallRolloutDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in (
         "n_scenarios", "ldb", "T", "t0", "F", "n_hidden", "n_out", "head", "Ws", "Wn", "Ww", "E", "We", "lost_demand",
-        "maximize_profit", "detach_input")] + [("upper_bound", C.c_float), ("weights", C.c_void_p), ("demand", C.c_void_p),
+        "maximize_profit", "detach_input", "round_orders")] + [("upper_bound", C.c_float), ("weights", C.c_void_p), ("demand", C.c_void_p),
                                                ("state0", C.c_void_p)]
                 + [(n, NicTable2) for n in ("underage", "holding", "lead", "wh_holding", "wh_lead", "wh_edge",
                                             "ech_holding", "ech_lead")])
@@ -85,6 +85,7 @@ PROTOTYPES = {
                                       _i32, _vp]),
     "nic_small_rollout_fwd": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_small_rollout_bwd": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, NicTable2, _vp, _vp, _vp]),
+    "nic_round_orders": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "nic_sample_demand": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i64, _u64, _i32, _vp, _vp, _i32, _vp]),
     "nic_axpy": (C.c_int, [_vp, _vp, _f32, _i64, _vp]),
 }

@@ -54,9 +54,21 @@ __global__ __launch_bounds__(kBlock) void head_serial_bwd_kernel(const float* __
     const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (b < B) nic::head_serial_bwd_scenario(Z, wh_inv, ech_inv, ub, gso, gwo, geo, dZ, g_wh_inv, g_ech_inv, E, Ww, We, ldb, b);
 }
+__global__ void round_orders_kernel(float* __restrict__ x, int rows, int B, int64_t ldb) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B)
+        for (int r = blockIdx.y; r < rows; r += gridDim.y) x[r * ldb + b] = rintf(x[r * ldb + b]);
+}
 }  // namespace
 
 extern "C" {
+
+int nic_round_orders(float* x, int32_t rows, int32_t n_scenarios, int32_t ldb, void* stream) {
+    NIC_REQUIRE(x && rows > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_round_orders: bad arguments");
+    hipLaunchKernelGGL(round_orders_kernel, dim3(nic::ceil_div(n_scenarios, 256), rows < 64 ? rows : 64), dim3(256), 0,
+                       nic::as_stream(stream), x, rows, n_scenarios, (int64_t)ldb);
+    return nic::check_launch("nic_round_orders");
+}
 
 int nic_head_warehouse_fwd(const float* Z, const float* wh_inv, const int32_t* adjacency, float upper_bound,
                            int32_t transshipment, float* store_orders, float* wh_orders, int32_t S, int32_t Wn, int32_t Ww,

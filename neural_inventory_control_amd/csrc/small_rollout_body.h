@@ -116,6 +116,7 @@ NIC_HD SrOrders sr_head(const NicSmallRolloutDesc& d, const float (&z)[SR_MAXOUT
     for (int e = 0; e < SR_MAXE; ++e) o.ech[e] = 0.f;
     if (d.head == 0) {
         o.store = softplus1_fwd(z[0]);  // neural_networks.py:211-212
+        if (d.round_orders) o.store = rintf(o.store);  // trainer.py:201-202
         return o;
     }
     // serial (:335-349): rows [echelons..., warehouse, store]; row j = sigmoid(z_j) * upstream_j,
@@ -134,6 +135,12 @@ NIC_HD SrOrders sr_head(const NicSmallRolloutDesc& d, const float (&z)[SR_MAXOUT
             else if (j == d.E) o.wh = a;
             else o.store = a;
         }
+    }
+    if (d.round_orders) {  // discrete allocation (trainer.py:201-202): torch.round = round half to even
+        o.store = rintf(o.store);
+        o.wh = rintf(o.wh);
+#pragma unroll
+        for (int e = 0; e < SR_MAXE; ++e) o.ech[e] = rintf(o.ech[e]);
     }
     return o;
 }

@@ -133,6 +133,12 @@ def wgrad_reduce(slab, dW, db, K, scale=1.0):
 
 # ---- policy heads ----------------------------------------------------------------------------------------------
 
+def round_orders(block, B):
+    """in-place torch.round (half to even) of a [rows][ldb] order block: discrete allocation (trainer.py:201-202)"""
+    _dev(block)
+    check(lib().nic_round_orders(ptr(block), block.shape[0], B, block.stride(0), current_stream()))
+
+
 def head_warehouse_fwd(Z, wh_inv, adjacency, ub, transshipment, store_orders, wh_orders, S, Wn, Ww, B):
     _dev(Z)
     check(lib().nic_head_warehouse_fwd(ptr(Z), ptr(wh_inv), ptr(adjacency), float(ub), int(transshipment),

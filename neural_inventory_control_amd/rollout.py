@@ -92,6 +92,7 @@ class FusedRollout:
         self.use_small = True   # whole-horizon kernels for the small one-store-chain policies (small_rollout.py)
         self.use_thin = True    # fused backward of thin (<= 32 rows) output layers (csrc/thin_layer.hip)
         self.batch_wgrad = True  # hidden-layer weight gradients contracted over all periods in one launch
+        self.eval_history = None  # evaluation keeps per-period states/orders/logits: None = while small, True / False = forced
         self.small = None       # SmallRolloutPlan when the current shapes take that route
         self._prob_cache = {}
         self._prob = None
@@ -126,7 +127,8 @@ class FusedRollout:
             k = m.out_features
 
     def _setup(self, prob, T, train):
-        key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin)
+        key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin,
+               self.eval_history)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
@@ -165,11 +167,18 @@ class FusedRollout:
                 self.gb = [torch.zeros_like(m.bias) for m in lins]
             self._key = key
             return
-        self.states = z(T + 1, self.F_store + self.F_wh + self.F_ech, ld)
         n_ord = prob.S * prob.nsup + prob.Wn + prob.E
-        self.orders = z(T, n_ord, ld)
+        f_tot = self.F_store + self.F_wh + self.F_ech
+        # evaluation keeps the state / order / logit history only while it is small (tests and short horizons read it);
+        # a long-horizon evaluation (test periods: 5000) rolls through two state blocks and one order / logit block
+        free_now = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                    if dev.type == "cuda" else 0)
+        auto = 4 * (T + 1) * ld * (f_tot + n_ord + dims[-1]) <= 0.1 * free_now
+        self._hist = bool(train) or (auto if self.eval_history is None else bool(self.eval_history))
+        self.states = z(T + 1 if self._hist else 2, f_tot, ld)
+        self.orders = z(T if self._hist else 1, n_ord, ld)
         self.rewards = z(T, ld)
-        self.logits = z(T, dims[-1], ld)
+        self.logits = z(T if self._hist else 1, dims[-1], ld)
         keep = T if train else 1
         self.hidden = [z(keep, dims[i + 1], ld) for i in range(L - 1)]
         # engine copies of the weights: rows padded to a multiple of 32 floats so every A-tile load is a float4
@@ -236,14 +245,20 @@ class FusedRollout:
 
     # ---- one batch ----------------------------------------------------------------------------------------------
     def run(self, data, periods, ignore_periods=0, train=True, observation_params=None, demand_soa=None,
-            grad_scale=None, accumulate_grads=False):
+            grad_scale=None, accumulate_grads=False, discrete_allocation=False):
         """Rollout of one batch (and, if `train`, d(mean_loss)/d(theta) into `param.grad`).
 
         data: the batch dict `Simulator.reset` takes (device tensors).  demand_soa: optional [T][S][ldb] trace already
         in kernel layout (e.g. from Scenario(sampler='hip')) — skips the transpose of data['demands'].
         grad_scale: d(loss)/d(reward[b,t]); default 1/(B*T*S) = trainer.py:169.  Multi-GPU callers pass the GLOBAL B.
+        discrete_allocation: orders rounded half-to-even between head and env step (trainer.py:201-202); evaluation only
+        (torch.round has zero gradient, so a training step with it goes through the generic route).
         Returns (total, reported) as 0-d device tensors = simulate_batch's return values (trainer.py:216).
         """
+        if discrete_allocation and train:
+            raise ValueError("discrete_allocation is an evaluation-time option of the fused rollout")
+        self._round = bool(discrete_allocation)
+        self._T_last = periods
         dev = self.device
         prob = self._problem_for(data)
         T, B, ld = periods, prob.B, prob.ldb
@@ -354,7 +369,7 @@ class FusedRollout:
         if prob.E:
             s0.ech[:, :, :B].copy_(data["initial_echelon_inventories"].permute(1, 2, 0))
         ub = self._ub() if self.head != "softplus" else 0.0
-        desc = plan.desc(T, shift, self.sr_weights, demand_soa, self.sr_state0, ub)
+        desc = plan.desc(T, shift, self.sr_weights, demand_soa, self.sr_state0, ub, round_orders=self._round)
         hist = (self.sr_states, self.sr_hidden, self.sr_logits) if train else (None, None, None)
         self._k("small_rollout_fwd", sr.small_rollout_fwd, desc, self.rewards, self.sr_final, *hist)
         total = self.rewards.sum()
@@ -402,17 +417,19 @@ class FusedRollout:
     def _launch_forward(self):
         prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
         ub = self._ub_now
+        hist = self._hist
         for t in range(T):
-            st = self._views(self.states[t], prob)
-            x = self.states[t][:self.F]
+            cur, nxt, row = (t, t + 1, t) if hist else (t & 1, (t + 1) & 1, 0)
+            st = self._views(self.states[cur], prob)
+            x = self.states[cur][:self.F]
             hs = t if train else 0
             for i in range(L - 1):
                 y = self.hidden[i][hs]
                 self._k(f"fwd_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_fwd, Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)
                 x = y
-            Z = self.logits[t]
+            Z = self.logits[row]
             self._k(f"fwd_{self.dims[L]}x{self.dims[L - 1]}", ops.linear_fwd, Wv[L - 1], biases[L - 1], x, Z, B, _lib.NIC_ACT_NONE)
-            so, wo, eo = self._order_views(self.orders[t], prob)
+            so, wo, eo = self._order_views(self.orders[row], prob)
             if self.head == "warehouse":
                 ops.head_warehouse_fwd(Z, st.wh, self.adj, ub, bool(self.model.transshipment), so, wo, prob.S, prob.Wn,
                                        prob.Ww, B)
@@ -420,9 +437,11 @@ class FusedRollout:
                 ops.head_serial_fwd(Z, st.wh, st.ech, ub, so, wo, eo, prob.E, prob.Ww, prob.We, B)
             else:
                 ops.head_softplus_fwd(Z, so.view(-1, ld), prob.S * prob.nsup, B)
-            ts, tw, te = self._order_tables(self.orders[t], prob)
+            if self._round:
+                ops.round_orders(self.orders[row], B)  # discrete allocation (trainer.py:201-202)
+            ts, tw, te = self._order_tables(self.orders[row], prob)
             self._k("env_fwd", ops.env_step_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te,
-                    out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
+                    out=self._views(self.states[nxt], prob), reward=self.rewards[t])
 
     def _launch_backward(self):
         prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
@@ -487,7 +506,11 @@ class FusedRollout:
 
     def final_state(self):
         from .layout import ref_view
-        st = self._views(self.sr_final if self.small is not None else self.states[-1], self.prob)
+        if self.small is not None:
+            last = self.sr_final
+        else:  # history: block T; rolling evaluation: block T & 1
+            last = self.states[-1] if self._hist else self.states[self._T_last & 1]
+        st = self._views(last, self.prob)
         out = {"store_inventories": ref_view(st.store, self.prob.B)}
         if st.wh is not None:
             out["warehouse_inventories"] = ref_view(st.wh, self.prob.B)

@@ -60,7 +60,7 @@ class SmallRolloutPlan:
                 and 1 <= n_hidden <= 3 and all(w == H for w in dims[1:-1]) and dims[-1] <= _lib.NIC_SR_MAX_OUTPUTS
                 and (head != "softplus" or dims[-1] == 1) and (head != "serial" or dims[-1] == prob.E + 2))
 
-    def desc(self, T, t0, weights, demand_soa, state0, upper_bound):
+    def desc(self, T, t0, weights, demand_soa, state0, upper_bound, round_orders=False):
         """demand_soa: [T_total][1][ldb]; state0: [F][ldb]."""
         p = self.prob
         d = NicSmallRolloutDesc()
@@ -70,6 +70,7 @@ class SmallRolloutPlan:
         d.Ws, d.Wn, d.Ww, d.E, d.We = p.Ws, p.Wn, p.Ww, p.E, p.We
         d.lost_demand, d.maximize_profit = int(p.lost_demand), int(p.maximize_profit)
         d.detach_input = int(self.head == "serial")
+        d.round_orders = int(bool(round_orders))
         d.upper_bound = float(upper_bound)
         d.weights, d.demand, d.state0 = weights.data_ptr(), demand_soa.data_ptr(), state0.data_ptr()
         d.underage, d.holding = p.underage.t2(), p.holding.t2()

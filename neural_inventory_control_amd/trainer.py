@@ -120,16 +120,18 @@ class Trainer:
     def simulate_batch(self, loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
                        ignore_periods=0, discrete_allocation=False):
         """trainer.py:181-216."""
-        if self.use_fused_rollout and not discrete_allocation and FusedRollout.supports(model) \
+        train = bool(getattr(self, "_train_mode", torch.is_grad_enabled() and model.trainable)) and torch.is_grad_enabled()
+        # (rounded actions have zero gradient: a training step with discrete allocation keeps the reference's generic route)
+        if self.use_fused_rollout and not (discrete_allocation and train) and FusedRollout.supports(model) \
                 and self._plain_observation(observation_params):
             eng = self._engines.get(id(model))
             if eng is None:
                 eng = self._engines[id(model)] = FusedRollout(model, problem_params, self.device)
-            train = bool(getattr(self, "_train_mode", torch.is_grad_enabled() and model.trainable)) and torch.is_grad_enabled()
             gb = getattr(self, "_global_batch", len(data_batch["demands"]))
             total, reported = eng.run(data_batch, periods, ignore_periods, train=train,
                                       observation_params=observation_params,
-                                      grad_scale=1.0 / (gb * periods * problem_params["n_stores"]))
+                                      grad_scale=1.0 / (gb * periods * problem_params["n_stores"]),
+                                      discrete_allocation=discrete_allocation)
             self._fused_grads_ready = train
             return total, reported
 

@@ -426,3 +426,73 @@ def test_ragged_multi_block_batch_matches_oracle(name, B):
     tol = max(GRAD_TOL.get(name, 2e-5), 1e-4)  # fresh demands may put a few more scenarios on a clamp knife edge
     for p, ref in zip(model.parameters(), grads):
         assert float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30)) <= tol
+
+
+# ---- evaluation (Trainer.test): forward only, discrete allocation, long horizons -----------------------
+
+@pytest.mark.parametrize("name", ["cfg1_one_store_lost_vanilla", "cfg4_serial_vanilla", "cfg3_one_warehouse_16_vanilla",
+                                  "cfg5_many_warehouses_2x10_vanilla"])
+@pytest.mark.parametrize("rolling", [False, True])
+def test_discrete_allocation_evaluation_matches_oracle(name, rolling):
+    """`Trainer.test` with discrete allocation (trainer.py:201-202: actions rounded half to even before the env step), with
+    the per-period history kept and with the rolling two-block state buffer a long-horizon evaluation uses."""
+    from oracle import inventory_oracle as orc
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    model = _model(g, c)
+    eng = FusedRollout(model, c["problem_params"], DEV)
+    eng.eval_history = not rolling
+    F = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
+    if c["policy"] != "vanilla_one_store":
+        F += sum(int(np.prod(data[k].shape[1:])) for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
+                 if k in data)
+    eng.materialize(F)
+    _load(model, g)
+    with torch.no_grad():
+        total, reported = eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"],
+                                  discrete_allocation=True)
+    torch.cuda.synchronize()
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"], g.tensor("warehouse_upper_bound"))
+    with torch.no_grad():
+        res = orc.rollout(pol, c["periods"], c["problem_params"], g.data, c["observation_params"], c["ignore"],
+                          discrete_allocation=True)
+    assert abs(float(total) - float(res.total)) <= 1e-5 * abs(float(res.total))
+    assert abs(float(reported) - float(res.reported)) <= 1e-5 * abs(float(res.reported))
+    torch.testing.assert_close(eng.per_period_rewards().cpu(), res.per_period, rtol=1e-5, atol=1e-4)
+    final = eng.final_state()
+    for k, v in res.final_obs.items():
+        if k in final:
+            torch.testing.assert_close(final[k].cpu(), v, **STATE_TOL)
+    # rounding changes the trajectory: the continuous evaluation gives a different cost
+    t_cont, _ = eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"])
+    assert float(t_cont) != float(total)
+    with pytest.raises(ValueError):
+        eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"],
+                discrete_allocation=True)
+
+
+def test_long_horizon_evaluation_matches_oracle():
+    """one_store_lost + vanilla_one_store, Poisson demand, discrete allocation, T = 5000 periods (the reference's test
+    horizon, one_store_lost.yml:43-44) on 256 scenarios: whole-horizon kernel against the oracle's period loop."""
+    from oracle import inventory_oracle as orc
+    g = Golden("cfg1_one_store_lost_vanilla")
+    c = g.fresh_config()
+    B, T, ignore = 256, 5000, 3000
+    gen = torch.Generator().manual_seed(7)
+    data = {k: v.repeat(*([B // c["n"] + 1] + [1] * (v.dim() - 1)))[:B].contiguous() for k, v in g.data.items()}
+    data["demands"] = torch.poisson(torch.full((B, 1, T), 5.0), generator=gen)
+    model = _model(g, c)
+    eng = FusedRollout(model, c["problem_params"], DEV)
+    eng.materialize(data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2])
+    _load(model, g)
+    with torch.no_grad():
+        total, reported = eng.run({k: v.to(DEV) for k, v in data.items()}, T, ignore, train=False,
+                                  observation_params=c["observation_params"], discrete_allocation=True)
+        pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"], g.tensor("warehouse_upper_bound"))
+        res = orc.rollout(pol, T, c["problem_params"], data, c["observation_params"], ignore, discrete_allocation=True)
+    # a rounding knife edge (x.5 +- 1 ulp) may differ in a handful of the 1.28 M actions: compare aggregate costs
+    assert abs(float(total) - float(res.total)) <= 1e-5 * abs(float(res.total))
+    assert abs(float(reported) - float(res.reported)) <= 1e-5 * abs(float(res.reported))
+    per_scn = (eng.per_period_rewards().sum(dim=0).cpu() - res.per_period.sum(dim=0)).abs() / res.per_period.sum(dim=0)
+    assert float((per_scn <= 1e-5).float().mean()) >= 0.99
