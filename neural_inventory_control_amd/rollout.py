@@ -113,12 +113,18 @@ class FusedRollout:
         """Materialises LazyLinear layers without a forward pass (same default init as the reference's first call)."""
         k = in_features
         for m in self.model.master_linears():
-            if isinstance(m.weight, torch.nn.parameter.UninitializedParameter):
+            fresh = isinstance(m.weight, torch.nn.parameter.UninitializedParameter)
+            if fresh:
                 m.in_features = k
                 m.weight.materialize((m.out_features, k))
                 if m.bias is not None:
                     m.bias.materialize((m.out_features,))
                 m.reset_parameters()
+            elif hasattr(m, "cls_to_become") and m.cls_to_become is not None:
+                # a lazy layer whose parameters came from load_state_dict (checkpoint loaded into a fresh model): the
+                # tensors exist, but the module still reports in_features = 0 and is still the lazy class
+                m.in_features = m.weight.shape[1]
+            if fresh or (hasattr(m, "cls_to_become") and m.cls_to_become is not None):
                 for hook in ("_initialize_hook", "_load_hook"):  # what LazyModuleMixin._infer_parameters does
                     if hasattr(m, hook):
                         getattr(m, hook).remove()

@@ -124,9 +124,11 @@ class Trainer:
         # (rounded actions have zero gradient: a training step with discrete allocation keeps the reference's generic route)
         if self.use_fused_rollout and not (discrete_allocation and train) and FusedRollout.supports(model) \
                 and self._plain_observation(observation_params):
-            eng = self._engines.get(id(model))
+            # one engine per (policy, training / evaluation): an epoch alternates a training pass and a dev pass with
+            # different horizons and buffer needs, and re-sizing one engine back and forth would reallocate tens of GB
+            eng = self._engines.get((id(model), train))
             if eng is None:
-                eng = self._engines[id(model)] = FusedRollout(model, problem_params, self.device)
+                eng = self._engines[(id(model), train)] = FusedRollout(model, problem_params, self.device)
             gb = getattr(self, "_global_batch", len(data_batch["demands"]))
             total, reported = eng.run(data_batch, periods, ignore_periods, train=train,
                                       observation_params=observation_params,

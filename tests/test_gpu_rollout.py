@@ -496,3 +496,50 @@ def test_long_horizon_evaluation_matches_oracle():
     assert abs(float(reported) - float(res.reported)) <= 1e-5 * abs(float(res.reported))
     per_scn = (eng.per_period_rewards().sum(dim=0).cpu() - res.per_period.sum(dim=0)).abs() / res.per_period.sum(dim=0)
     assert float((per_scn <= 1e-5).float().mean()) >= 0.99
+
+
+def _one_store_yaml_dicts(tmp_path):
+    """A full pair of config dicts in the reference's YAML schema (settings/one_store_lost.yml +
+    policies_and_hyperparams/vanilla_one_store.yml shape), scaled down."""
+    from neural_inventory_control_amd import workloads
+    setting, policy, _, _, _ = workloads.get("cfg1")
+    setting = dict(setting)
+    setting["test_seeds"] = {k: v + 1 for k, v in setting["seeds"].items()}
+    setting["params_by_dataset"] = {"train": {"n_samples": 256, "batch_size": 128, "periods": 20, "ignore_periods": 4},
+                                    "dev": {"n_samples": 128, "batch_size": 128, "periods": 20, "ignore_periods": 4},
+                                    "test": {"n_samples": 128, "batch_size": 128, "periods": 60, "ignore_periods": 20}}
+    setting["sample_data_params"] = {"split_by_period": False}
+    hyper = {"trainer_params": {"epochs": 3, "do_dev_every_n_epochs": 1, "print_results_every_n_epochs": 100,
+                                "save_model": True, "epochs_between_save": 1, "choose_best_model_on": "dev_loss",
+                                "load_previous_model": False, "load_model_path": "", "base_dir": str(tmp_path)},
+             "optimizer_params": {"learning_rate": 0.01}, "nn_params": policy}
+    return setting, hyper
+
+
+def test_main_run_driver_trains_tests_and_saves(tmp_path, capsys):
+    """The reference's `main_run.py train <setting> <hyperparams>` flow through the thin driver: datasets -> device batches
+    -> policy -> Trainer.train (dev pass, best-model copy, checkpoint) -> Trainer.test with discrete allocation (Poisson)."""
+    import glob
+    import yaml
+    from neural_inventory_control_amd import main_run
+    setting, hyper = _one_store_yaml_dicts(tmp_path)
+    (tmp_path / "settings").mkdir()
+    (tmp_path / "policies_and_hyperparams").mkdir()
+    (tmp_path / "settings" / "tiny_one_store.yml").write_text(yaml.safe_dump(setting))
+    (tmp_path / "policies_and_hyperparams" / "tiny_vanilla.yml").write_text(yaml.safe_dump(hyper))
+    main_run.main(["train", "tiny_one_store", "tiny_vanilla", "--config-dir", str(tmp_path)])
+    out = capsys.readouterr().out
+    assert "Average per-period test loss:" in out
+    loss = float(out.strip().split("Average per-period test loss:")[-1])
+    assert 0.0 < loss < 1e4  # (three epochs on 256 scenarios: only sanity, the policy has barely moved)
+    saved = glob.glob(str(tmp_path / "*" / "vanilla_one_store" / "*.pt"))
+    assert len(saved) == 1
+    ck = torch.load(saved[0], map_location="cpu", weights_only=False)
+    assert {"model_state_dict", "optimizer_state_dict", "all_dev_losses", "warehouse_upper_bound"} <= set(ck)
+    assert len(ck["all_dev_losses"]) == 3
+    # `test` mode from the saved checkpoint reproduces a finite loss through the fused evaluation path
+    hyper["trainer_params"].update(load_previous_model=True, load_model_path=saved[0])
+    rep = main_run.run("test", setting, hyper)
+    assert abs(rep - loss) <= 1e-6 * loss  # same best-dev parameters, same test set
+    with pytest.raises(ValueError):
+        main_run.run("deploy", setting, hyper)

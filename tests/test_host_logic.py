@@ -135,3 +135,14 @@ def test_no_cpu_fallback():
         ops.linear_fwd(torch.zeros(4, 4), None, torch.zeros(4, 64), torch.zeros(4, 64), 4, 0)
     with pytest.raises(_lib.NicUnavailableError):
         _lib.load_library("/nonexistent/libnic_hip.so")
+
+
+def test_main_run_cli_surface():
+    """The driver keeps the reference's positional arguments (main_run.py:7-19) and rejects real-data settings it cannot
+    serve; nothing here touches the GPU."""
+    from neural_inventory_control_amd import main_run
+    with pytest.raises(SystemExit):
+        main_run.main(["deploy"])
+    with pytest.raises(FileNotFoundError):
+        main_run.main(["train", "no_such_setting", "no_such_policy", "--config-dir", "/nonexistent"])
+    assert main_run.SETTING_KEYS[0] == "seeds" and "nn_params" in main_run.HYPERPARAM_KEYS
