@@ -74,3 +74,32 @@ def test_profit_objective(name):
                                   "cfg5_many_warehouses_2x10_vanilla"])
 def test_discrete_allocation(name):
     _run_both(CASES[name], n=21, periods=7, ignore=0, torch_seed=6, discrete=True)
+
+
+# ---- the reference's own YAML files drive this package unchanged (the config schema is the API) ----------------------
+
+_DRIVER_PAIRS = [("one_store_lost", "vanilla_one_store"), ("one_store_backlogged", "vanilla_one_store"),
+                 ("one_store_backlogged", "base_stock"), ("one_store_backlogged", "capped_base_stock"),
+                 ("one_warehouse_lost_demand", "vanilla_warehouse"), ("many_warehouses_lost_demand", "vanilla_warehouse"),
+                 ("serial_system", "vanilla_serial"), ("serial_system", "echelon_stock"),
+                 ("transshipment_backlogged", "vanilla_transshipment")]
+
+
+@pytest.mark.parametrize("setting,policy", _DRIVER_PAIRS)
+def test_driver_builds_from_reference_config_files(setting, policy):
+    """`main_run.build` on the reference's config_files (sample counts shrunk): scenario, datasets, loaders, policy,
+    optimizer and trainer parameters are all constructed from the YAML exactly as the reference's main_run.py reads them."""
+    import yaml
+    from neural_inventory_control_amd import main_run
+    import os
+    cfg = os.path.join(rh.REFERENCE_ROOT, "config_files")
+    cs = yaml.safe_load(open(f"{cfg}/settings/{setting}.yml"))
+    ch = yaml.safe_load(open(f"{cfg}/policies_and_hyperparams/{policy}.yml"))
+    for k in cs["params_by_dataset"]:
+        cs["params_by_dataset"][k].update(n_samples=64, batch_size=32, periods=min(cs["params_by_dataset"][k]["periods"], 30))
+    c = main_run.build(cs, ch, "cpu")
+    assert len(c["data_loaders"]["train"].dataset) == 64 and len(c["data_loaders"]["test"].dataset) == 64
+    assert type(c["model"]).__name__ in ("VanillaOneStore", "BaseStock", "CappedBaseStock", "VanillaWarehouse",
+                                         "VanillaSerial", "EchelonStock")
+    batch = next(iter(c["data_loaders"]["dev"]))
+    assert batch["demands"].shape[0] == 32 and batch["demands"].shape[1] == cs["problem_params"]["n_stores"]
