@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     // every CU at once, on top of the write burst.  The kernel has ~80 free VGPRs, so the rows of the first pass are fetched
     // into registers during the last PFT k tiles (each batch completes under that tile's MFMAs, before its dma_wait), and
     // the rows of the second pass are fetched into the same registers as the first pass consumes them.
-    constexpr int PFT = 8;
+    constexpr int PFT = 4;
     static_assert(ITER % PFT == 0, "prefetch batches must divide the pass");
     float4 hq[ITER];  // (dead in the forward instantiation)
     const bool pf_on = EPI == EPI_DGRAD && p.Hprev != nullptr && p.act == NIC_ACT_ELU && nk >= PFT && !p.accumulate;
@@ -483,6 +483,57 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
 
     // epilogue: stage the block tile through LDS and write whole rows
     float* cs = lds;
+    // Production case first (whole tile inside the matrix; forward: bias + ELU, dgrad: prefetched Hprev): straight-line row
+    // loop, no per-row guards or option branches, so hipcc hoists the bias loads and keeps exact s_waitcnt counts — the
+    // refill loads and the stores of one row do not stall the next row.
+    const bool full_tile = m0 + BM <= p.M && c0 + BN <= p.ncols;
+    const bool fast_epi = full_tile && (EPI == EPI_DGRAD ? pf_on : (p.bias != nullptr && p.act == NIC_ACT_ELU));
+    if (fast_epi) {
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+            if (PASSES == 1 || wm == pass) {
+                const int wrow = (PASSES == 1) ? wm * MT * 32 : 0;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            cs[(wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + (wn * NT + j) * 32 + li] = acc[i][j][r];
+            }
+            __syncthreads();
+            const int row0 = m0 + pass * PASS_ROWS + t / TPR;
+            float bias_r[ITER];
+            if (EPI == EPI_BIAS_ACT) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) bias_r[it] = p.bias[row0 + RPI * it];
+            }
+            // 32-bit element offset, advanced row group by row group (M * ldb < 2^28 on this path): one address register
+            int off = row0 * (int)p.ldb + col;
+            const int off_step = RPI * (int)p.ldb, off_pass = PASS_ROWS * (int)p.ldb;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it, off += off_step) {
+                const int row_l = t / TPR + RPI * it;
+                float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (t % TPR) * 4);
+                if (EPI == EPI_BIAS_ACT) {
+                    y.x = elu_f(y.x + bias_r[it]); y.y = elu_f(y.y + bias_r[it]);
+                    y.z = elu_f(y.z + bias_r[it]); y.w = elu_f(y.w + bias_r[it]);
+                } else {
+                    const float4 hv = hq[it];
+                    y.x *= elu_grad_from_out(hv.x); y.y *= elu_grad_from_out(hv.y);
+                    y.z *= elu_grad_from_out(hv.z); y.w *= elu_grad_from_out(hv.w);
+                    if (pass + 1 < PASSES)  // next pass's row into the freed register
+                        hq[it] = *reinterpret_cast<const float4*>(p.Hprev + off + off_pass);
+                }
+                *reinterpret_cast<float4*>(p.C + off) = y;
+                // keep the scheduler from hoisting all 16 staged rows (64 VGPRs on top of 128 accumulators + 64 Hprev
+                // registers spills): rows are scheduled in groups of four
+                if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (pass + 1 < PASSES) __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         if (PASSES == 1 || wm == pass) {
