@@ -115,6 +115,10 @@ __global__ __launch_bounds__(64) void small_rollout_fwd_mfma_kernel(NicSmallRoll
 #pragma unroll
     for (int k = 0; k < SR_MAXF; ++k) st[k] = k < d.F ? state0[(int64_t)k * ldb + b] : 0.f;
 
+    // the demand of period t+1 is fetched at the END of period t, after that period's stores: s_waitcnt counts in issue
+    // order, so a load issued before the (conditional) stores of a period could only be waited for together with them,
+    // and a load issued right before its use exposes its whole latency every period
+    float dem = demand[(int64_t)d.t0 * ldb + b];
     for (int t = 0; t < d.T; ++t) {
         f32x16 acc;
         float hcur[16];
@@ -166,9 +170,9 @@ __global__ __launch_bounds__(64) void small_rollout_fwd_mfma_kernel(NicSmallRoll
         }
         const SrOrders o = sr_head(d, z, st);
         float nx[SR_MAXF];
-        const float dem = demand[(int64_t)(t + d.t0) * ldb + b];
         const float cost = sr_env_fwd(d, c, st, nx, dem, o);
         if (live && h == 0) rewards[(int64_t)t * ldb + b] = cost;
+        dem = demand[(int64_t)(t + 1 < d.T ? t + 1 + d.t0 : t + d.t0) * ldb + b];
 #pragma unroll
         for (int k = 0; k < SR_MAXF; ++k) st[k] = nx[k];
     }
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     const int64_t b_raw = (int64_t)blockIdx.x * 32 + j;
     const bool live = b_raw < d.n_scenarios;
-    const int64_t b = live ? b_raw : 0;
+    const int64_t b = live ? b_raw : 0;  // dead lanes shadow scenario 0: they compute (and, where stores are unconditional, write) exactly what its own lane does
     const int64_t ldb = d.ldb, tl = (int64_t)d.T * ldb;
     d.weights = weights;
     d.demand = demand;
@@ -225,12 +229,22 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
     // else to switch to), so period t-1's history is fetched into registers while period t is computed.
     float st[SR_MAXF], z[SR_MAXOUT], dem, hh[NL][16];
     float st_n[SR_MAXF], z_n[SR_MAXOUT], dem_n, hh_n[NL][16];
+    // every load of a fetch is unconditional (rows beyond F / n_out re-read the last valid row and are zeroed by a select) and
+    // the fetch sits AFTER the period's only conditional stores (dz_out), followed by unconditional dz_hidden stores: the
+    // number of memory operations issued after it is then a compile-time constant and the wait for it at the top of the
+    // next period (s_waitcnt vmcnt(N), issue order) does not also wait for those stores to complete
     auto fetch = [&](int t, float (&fs)[SR_MAXF], float (&fz)[SR_MAXOUT], float& fd, float (&fh)[NL][16]) {
         const int64_t at = (int64_t)t * ldb + b;
 #pragma unroll
-        for (int k = 0; k < SR_MAXF; ++k) fs[k] = k < d.F ? states_hist[k * tl + at] : 0.f;
+        for (int k = 0; k < SR_MAXF; ++k) {
+            const float v = states_hist[(k < d.F ? k : d.F - 1) * tl + at];
+            fs[k] = k < d.F ? v : 0.f;
+        }
 #pragma unroll
-        for (int n = 0; n < SR_MAXOUT; ++n) fz[n] = n < d.n_out ? logits_hist[n * tl + at] : 0.f;
+        for (int n = 0; n < SR_MAXOUT; ++n) {
+            const float v = logits_hist[(n < d.n_out ? n : d.n_out - 1) * tl + at];
+            fz[n] = n < d.n_out ? v : 0.f;
+        }
         fd = demand[(int64_t)(t + d.t0) * ldb + b];
 #pragma unroll
         for (int l = 0; l < NL; ++l)
@@ -240,7 +254,6 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
     fetch(d.T - 1, st, z, dem, hh);
     for (int t = d.T - 1; t >= 0; --t) {
         const int64_t at = (int64_t)t * ldb + b;
-        fetch(t > 0 ? t - 1 : 0, st_n, z_n, dem_n, hh_n);
         const SrOrders o = sr_head(d, z, st);
         float go[SR_MAXF], dz[SR_MAXOUT];
         const SrOrders g = sr_env_bwd(d, c, st, gn, go, dem, o, gr);
@@ -250,6 +263,7 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
             for (int n = 0; n < SR_MAXOUT; ++n)
                 if (n < d.n_out) dz_out[n * tl + at] = dz[n];
         }
+        fetch(t > 0 ? t - 1 : 0, st_n, z_n, dem_n, hh_n);
         // output layer -> last hidden layer: contraction over the n_out logits, n = 2s + h
         f32x16 acc;
         float dh[16];
@@ -262,10 +276,8 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
             dh[r] = acc[r] * elu1_grad_from_out(hh[NL - 1][r]);
 #pragma unroll
         for (int l = NL - 1; l >= 1; --l) {
-            if (live) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dz_hidden[(int64_t)(l * SR_H + crow(r, h)) * tl + at] = dh[r];
-            }
+            for (int r = 0; r < 16; ++r) dz_hidden[(int64_t)(l * SR_H + crow(r, h)) * tl + at] = dh[r];  // (dead lanes: see b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
@@ -274,10 +286,8 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
             for (int r = 0; r < 16; ++r)
                 dh[r] = acc[r] * elu1_grad_from_out(hh[l - 1][r]);
         }
-        if (live) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dz_hidden[(int64_t)crow(r, h) * tl + at] = dh[r];
-        }
+        for (int r = 0; r < 16; ++r) dz_hidden[(int64_t)crow(r, h) * tl + at] = dh[r];
         // first layer -> state (the reference detaches vanilla_serial's MLP input, neural_networks.py:329)
         if (!d.detach_input) {
 #pragma unroll
