@@ -45,6 +45,11 @@ CASES = {
                                        "value": [[2, 0, 3], [1, 4, 0], [0, 2, 0], [0, 6, 1],
                                                  [3, 0, 0], [0, 0, 2], [5, 2, 0], [0, 1, 3]]}},
         warehouse_overrides={"holding_cost": [0.3, 0.4, 0.2], "lead_time": 3, "edge_cost": [0.5, 1.5, 0.7]}),
+    # the reference's transshipment setting (backlogged demand, warehouse that cannot hold stock: the softmax head has no
+    # 'keep' column) + its vanilla_transshipment policy file (VanillaWarehouse with transshipment: True)
+    "x_transshipment_backlogged_vanilla": dict(
+        setting="transshipment_backlogged", policy="vanilla_transshipment", n=24, periods=12, ignore=4, torch_seed=21,
+        hidden=[32, 32]),
 }
 
 
