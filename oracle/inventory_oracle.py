@@ -315,6 +315,8 @@ class OraclePolicy:
 def policy_from_state_dict(nn_params, state_dict, problem_params=None, warehouse_upper_bound=None):
     """Builds an OraclePolicy from reference-format keys `net.master.<i>.weight/bias`
     (layout produced by neural_networks.py:80-106)."""
+    if nn_params["name"] == "gnn":
+        return gnn_from_state_dict(nn_params, state_dict, problem_params)
     idx = sorted({int(k.split(".")[2]) for k in state_dict if k.startswith("net.master.")})
     layers = [(state_dict[f"net.master.{i}.weight"].detach().clone().float().requires_grad_(True),
                state_dict[f"net.master.{i}.bias"].detach().clone().float().requires_grad_(True)) for i in idx]
@@ -397,6 +399,8 @@ def _softmax_share_of_stock(logits, warehouse_pipeline, transshipment):
 def policy_act(pol: OraclePolicy, obs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Forward of the in-scope architectures; action tensors are always 3-D."""
     name = pol.name
+    if name == "gnn":
+        return gnn_act(pol, obs)
     if name == "vanilla_one_store":  # neural_networks.py:200-214
         x = obs["store_inventories"].flatten(start_dim=1)
         x = F.softplus(_mlp(pol, x) + 1)
@@ -471,6 +475,230 @@ class RolloutResult:
     reported: torch.Tensor         # same from t >= ignore_periods               trainer.py:209-210
     per_period: torch.Tensor       # (T, B) detached rewards
     final_obs: Dict[str, torch.Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# GNN policy.  neural_networks.py:742-1492: message passing over the supply graph.
+# Restated with the reference's node / edge ORDER and the same sequence of additions, so that results are
+# bit-equal: nodes = [echelons..., warehouses..., stores...]; edges = [internal (adjacency.nonzero() order =
+# source-major), supplier edges, demand edges, self-loops of nodes that supply others (absent under transshipment)].
+# --------------------------------------------------------------------------------------
+
+GNN_MODULES = ("initial_node", "initial_edge", "node_update", "edge_update", "output")
+
+
+@dataclass
+class OracleGNNPolicy:
+    name: str
+    modules: Dict[str, List[Tuple[torch.Tensor, torch.Tensor]]]
+    inner_activation: Dict[str, Optional[str]]
+    output_activation: Dict[str, Optional[str]]
+    problem_params: Dict
+    transshipment: bool = False
+    keys: Optional[List[str]] = None  # state-dict keys in parameters() order
+    warehouse_upper_bound: Optional[torch.Tensor] = None
+
+    def parameters(self):
+        return [t for m in GNN_MODULES for wb in self.modules[m] for t in wb]
+
+    def param_keys(self):
+        return list(self.keys)
+
+
+def gnn_from_state_dict(nn_params, state_dict, problem_params):
+    modules, keys = {}, []
+    for m in GNN_MODULES:
+        idx = sorted({int(k.split(".")[2]) for k in state_dict if k.startswith(f"net.{m}.")})
+        modules[m] = []
+        for i in idx:
+            w = state_dict[f"net.{m}.{i}.weight"].detach().clone().float().requires_grad_(True)
+            b = state_dict[f"net.{m}.{i}.bias"].detach().clone().float().requires_grad_(True)
+            modules[m].append((w, b))
+            keys += [f"net.{m}.{i}.weight", f"net.{m}.{i}.bias"]
+    return OracleGNNPolicy(name="gnn", modules=modules, inner_activation=dict(nn_params["inner_layer_activations"]),
+                           output_activation=dict(nn_params["output_layer_activation"]),
+                           problem_params=dict(problem_params), transshipment=nn_params.get("transshipment", False),
+                           keys=keys)
+
+
+def _gnn_mlp(pol, key, x):
+    layers = pol.modules[key]
+    for i, (w, b) in enumerate(layers):
+        x = F.linear(x, w, b)
+        if i < len(layers) - 1:
+            x = _ACT[pol.inner_activation[key]](x)
+    if pol.output_activation[key] is not None:
+        x = _ACT[pol.output_activation[key]](x)
+    return x
+
+
+def gnn_graph(problem_params, obs, transshipment):
+    """Static structure of the supply graph (:757-944, :945-1062): edge lists, lead times, output mapping."""
+    S, Wn, E = problem_params["n_stores"], problem_params["n_warehouses"], problem_params["n_extra_echelons"]
+    n_nodes = E + Wn + S
+    internal, lead = [], []
+    if E > 0:  # serial: echelon 0 -> ... -> echelon E-1 -> warehouse -> store (one warehouse, one store)
+        for i in range(E - 1):
+            internal.append((i, i + 1))
+            lead.append(obs["echelon_lead_times"][0, i + 1])
+        internal.append((E - 1, E))
+        lead.append(obs["warehouse_lead_times"][0, 0])
+        internal.append((E, E + Wn))
+        lead.append(obs["lead_times"][0, 0, 0])
+        suppliers, demand_nodes = [0], [E + Wn]
+        supplier_lead = [obs["echelon_lead_times"][0, 0]]
+    else:
+        if Wn == 1:
+            conn = [[1] * S]
+        else:
+            conn = problem_params["warehouse_store_adjacency"]
+        for w in range(Wn):
+            for st in range(S):
+                if conn[w][st]:
+                    internal.append((w, Wn + st))
+                    lead.append(obs["lead_times"][0][st, w])  # sample 0's lead times stand for the batch (:984)
+        suppliers, demand_nodes = list(range(Wn)), list(range(Wn, Wn + S))
+        supplier_lead = [obs["warehouse_lead_times"][0, w] for w in range(Wn)]
+    out_deg = [0] * n_nodes
+    in_deg = [0] * n_nodes
+    for (a, b) in internal:
+        out_deg[a] += 1
+        in_deg[b] += 1
+    supplying = [] if transshipment else [n for n in range(n_nodes) if out_deg[n] > 0]
+    n_int, n_sup, n_dem = len(internal), len(suppliers), len(demand_nodes)
+    # output mapping (:1010-1062)
+    if E > 0:
+        mapping = {"stores": [[n_int - 1]], "warehouses": [[n_int - 2]],
+                   "echelons": [[n_int]] + [[i - 1] for i in range(1, E)]}
+    else:
+        stores = [[] for _ in range(S)]
+        for i, (a, b) in enumerate(internal):
+            stores[b - Wn].append(i)  # the j-th CONNECTED edge of a store becomes its column j (:1423-1428)
+        mapping = {"stores": stores, "warehouses": [[n_int + w] for w in range(Wn)]}
+    # degrees used for the normalisation (:1275-1296)
+    for n in suppliers:
+        in_deg[n] += 1
+    for n in demand_nodes:
+        out_deg[n] += 1
+    for n in supplying:
+        in_deg[n] += 1
+        out_deg[n] += 1
+    return dict(n_nodes=n_nodes, internal=internal, lead=lead, suppliers=suppliers, supplier_lead=supplier_lead,
+                demand_nodes=demand_nodes, supplying=supplying, mapping=mapping,
+                in_deg=[d if d > 0 else 1 for d in in_deg], out_deg=[d if d > 0 else 1 for d in out_deg],
+                num_message_passing=(E + 1) if E > 0 else 1)
+
+
+def _gnn_node_features(problem_params, obs):
+    """[inventory slots padded to the longest pipeline | static features padded to the longest list] per node (:846-905)."""
+    E = problem_params["n_extra_echelons"]
+    feats, inv_lens = [], []
+    if E > 0:
+        feats.append(torch.cat([obs["echelon_inventories"], obs["echelon_holding_costs"].unsqueeze(-1)], dim=-1))
+        inv_lens.append(obs["echelon_inventories"].size(-1))
+    wl = [obs["warehouse_inventories"], obs["warehouse_holding_costs"].unsqueeze(-1)]
+    if obs.get("warehouse_edge_costs") is not None:
+        wl.append(obs["warehouse_edge_costs"].unsqueeze(-1))
+    feats.append(torch.cat(wl, dim=-1))
+    inv_lens.append(obs["warehouse_inventories"].size(-1))
+    sl = [obs["store_inventories"], obs["holding_costs"].unsqueeze(-1), obs["underage_costs"].unsqueeze(-1),
+          obs["mean"].unsqueeze(-1), obs["std"].unsqueeze(-1)]  # KeyError without mean/std, like the reference (:888)
+    feats.append(torch.cat(sl, dim=-1))
+    inv_lens.append(obs["store_inventories"].size(-1))
+    max_inv = max(inv_lens)
+    max_st = max(f.size(-1) - n for f, n in zip(feats, inv_lens))
+    padded = []
+    for f, n in zip(feats, inv_lens):
+        inv, st = f[:, :, :n], f[:, :, n:]
+        padded.append(torch.cat([F.pad(inv, (0, max_inv - n)), F.pad(st, (0, max_st - (f.size(2) - n)))], dim=2))
+    return torch.cat(padded, dim=1)
+
+
+def _gnn_node_inventories(problem_params, obs):
+    parts = []
+    if problem_params["n_extra_echelons"] > 0:
+        parts.append(obs["echelon_inventories"][:, :, 0])
+    if problem_params["n_warehouses"] > 0:
+        parts.append(obs["warehouse_inventories"][:, :, 0])
+    parts.append(obs["store_inventories"][:, :, 0])
+    return torch.cat(parts, dim=1)
+
+
+def _gnn_edge_endpoints(g, nodes):
+    """(source features, target features) of every edge in edge order; virtual supplier / customer ends are zeros."""
+    B, D = nodes.size(0), nodes.size(-1)
+    src_i = [a for a, _ in g["internal"]]
+    tgt_i = [b for _, b in g["internal"]]
+    srcs = [nodes[:, src_i], torch.zeros(B, len(g["suppliers"]), D), nodes[:, g["demand_nodes"]]]
+    tgts = [nodes[:, tgt_i], nodes[:, g["suppliers"]], torch.zeros(B, len(g["demand_nodes"]), D)]
+    if g["supplying"]:
+        srcs.append(nodes[:, g["supplying"]])
+        tgts.append(nodes[:, g["supplying"]])
+    return torch.cat(srcs, dim=1), torch.cat(tgts, dim=1)
+
+
+def gnn_act(pol: OracleGNNPolicy, obs):
+    """GNN.forward (:1367-1392)."""
+    prob = pol.problem_params
+    g = gnn_graph(prob, obs, pol.transshipment)
+    B = obs["store_inventories"].size(0)
+    nodes = _gnn_mlp(pol, "initial_node", _gnn_node_features(prob, obs))
+    # initial edge features: [source node | target node | lead time] (:1105-1192)
+    src, tgt = _gnn_edge_endpoints(g, nodes)
+    lt = torch.stack([torch.as_tensor(v, dtype=torch.float32) for v in g["lead"] + g["supplier_lead"]]
+                     + [torch.tensor(0.0)] * (len(g["demand_nodes"]) + len(g["supplying"])))
+    edges = _gnn_mlp(pol, "initial_edge", torch.cat([src, tgt, lt.view(1, -1, 1).expand(B, -1, -1)], dim=-1))
+    n_int, n_sup, n_dem = len(g["internal"]), len(g["suppliers"]), len(g["demand_nodes"])
+    in_norm = torch.sqrt(torch.tensor(g["in_deg"], dtype=torch.float32)).view(1, -1, 1)
+    out_norm = torch.sqrt(torch.tensor(g["out_deg"], dtype=torch.float32)).view(1, -1, 1)
+    for _ in range(g["num_message_passing"]):
+        incoming = torch.zeros(B, g["n_nodes"], edges.size(-1))
+        outgoing = torch.zeros(B, g["n_nodes"], edges.size(-1))
+        for i, (a, b) in enumerate(g["internal"]):  # same order of += as :1230-1235
+            incoming[:, b] += edges[:, i]
+            outgoing[:, a] += edges[:, i]
+        for i, n in enumerate(g["suppliers"]):
+            incoming[:, n] += edges[:, n_int + i]
+        for i, n in enumerate(g["demand_nodes"]):
+            outgoing[:, n] += edges[:, n_int + n_sup + i]
+        for i, n in enumerate(g["supplying"]):
+            incoming[:, n] += edges[:, n_int + n_sup + n_dem + i]
+            outgoing[:, n] += edges[:, n_int + n_sup + n_dem + i]
+        incoming = incoming / in_norm
+        outgoing = outgoing / out_norm
+        nodes = nodes + _gnn_mlp(pol, "node_update", torch.cat([nodes, incoming, outgoing], dim=-1))
+        src, tgt = _gnn_edge_endpoints(g, nodes)
+        edges = edges + _gnn_mlp(pol, "edge_update", torch.cat([edges, src, tgt], dim=-1))
+    out = _gnn_mlp(pol, "output", edges).squeeze(-1)
+    # proportional allocation per supplying node over its outgoing internal edges (+ its self-loop) (:1435-1492, :111-138)
+    alloc = out.clone()
+    inv = _gnn_node_inventories(prob, obs)
+    node_edges = {n: [] for n in range(g["n_nodes"])}
+    for i, (a, _) in enumerate(g["internal"]):
+        node_edges[a].append(i)
+    for i, n in enumerate(g["supplying"]):
+        node_edges[n].append(n_int + n_sup + n_dem + i)
+    for n, idxs in node_edges.items():
+        if not idxs:
+            continue
+        desired = torch.stack([out[:, i] for i in idxs], dim=1)
+        scale = inv[:, n] / (desired.sum(dim=1) + 1e-10)
+        if not pol.transshipment:
+            scale = torch.clip(scale, max=1.0)
+        scaled = desired * scale[:, None]
+        for j, i in enumerate(idxs):
+            alloc[:, i] = scaled[:, j]
+    res = {}
+    for kind, rows in g["mapping"].items():
+        if not rows:
+            continue
+        n_cols = max(len(r) for r in rows)
+        t = torch.zeros(B, len(rows), n_cols)
+        for r, row in enumerate(rows):
+            for j, e in enumerate(row):
+                t[:, r, j] = alloc[:, e]
+        res[kind] = t
+    return res
 
 
 def rollout(pol: OraclePolicy, periods, problem_params, data, observation_params,

@@ -50,6 +50,12 @@ CASES = {
     "x_transshipment_backlogged_vanilla": dict(
         setting="transshipment_backlogged", policy="vanilla_transshipment", n=24, periods=12, ignore=4, torch_seed=21,
         hidden=[32, 32]),
+    # the GNN policy (gnn.yml) on the one-warehouse setting, 3 stores (shipped) and 16 stores (cfg3's graph)
+    "f1_one_warehouse_gnn": dict(
+        setting="one_warehouse_lost_demand", policy="gnn", n=16, periods=8, ignore=3, torch_seed=22),
+    "f1_one_warehouse_16_gnn": dict(
+        setting="one_warehouse_lost_demand", policy="gnn", n=12, periods=6, ignore=2, torch_seed=23,
+        problem_overrides={"n_stores": 16}),
 }
 
 

@@ -53,6 +53,8 @@ def _run_both(case, n, periods, ignore, torch_seed, maximize_profit=False, discr
     for (k, p), mine in zip(model.named_parameters(), pol.parameters()):
         if p.grad is None:
             assert mine.grad is None or float(mine.grad.abs().max()) == 0.0
+        elif hasattr(pol, "param_keys"):  # GNN: forward bit-equal, gradients to ~1 ulp (see test_oracle_golden.py)
+            assert float((p.grad - mine.grad).norm() / (p.grad.norm() + 1e-30)) < 1e-6, k
         else:
             assert torch.equal(p.grad, mine.grad), k
     for k in ("store_inventories", "warehouse_inventories", "echelon_inventories"):
