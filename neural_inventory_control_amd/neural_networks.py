@@ -14,6 +14,7 @@ Out of scope this round: GNN, data-driven / quantile / just-i
 import copy
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import _lib, ops
@@ -82,6 +83,10 @@ class _HipLinearForward:
     def forward(self, x):
         if x.dim() == 1:  # closed-form policies feed a constant scalar input (neural_networks.py:228 in the reference)
             return _LinearFunction.apply(x.unsqueeze(0), self.weight, self.bias, self.fused_act).squeeze(0)
+        if x.dim() > 2:  # (batch, nodes-or-edges, features): every leading index is one GEMM column (GNN policy)
+            lead = x.shape[:-1]
+            y = _LinearFunction.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias, self.fused_act)
+            return y.reshape(*lead, y.shape[-1])
         return _LinearFunction.apply(x, self.weight, self.bias, self.fused_act)
 
 
@@ -354,6 +359,186 @@ class VanillaWarehouse(MyNeuralNetwork):
         return {"stores": so, "warehouses": wo}
 
 
+
+class GNN(MyNeuralNetwork):
+    """Message-passing policy over the supply graph (neural_networks.py:742-1492 of the reference): nodes =
+    [echelons..., warehouses..., stores...], edges = [internal (source-major), supplier, demand, self-loops of supplying
+    nodes]; five small MLPs (`gnn.yml`): initial_node, initial_edge, node_update, edge_update, output.
+
+    Re-designed for the device rather than translated: the graph is static, so it is compiled ONCE into index tensors and
+    two dense normalised incidence matrices; message aggregation, the proportional allocation and the scatter of edge
+    outputs into the action tensors are then batched gathers / small matmuls over (batch, edge) instead of the reference's
+    Python loops over edges and nodes, and every MLP runs on the matrix cores (`HipLinear`, all nodes / edges of all
+    scenarios as GEMM columns).  Sums over a node's edges therefore associate differently from the reference's sequential
+    `+=` (costs agree to ~1e-6 relative; the oracle keeps the reference's order bit for bit)."""
+
+    def __init__(self, args, scenario, device="cpu"):
+        super().__init__(args, device)
+        self.scenario = scenario
+        self.transshipment = args.get("transshipment", False)
+        self._graph = None
+
+    # ---- static structure ----------------------------------------------------------------------------------------
+    def _compile_graph(self, observation):
+        prob = self.scenario.problem_params
+        S, Wn, E = prob.get("n_stores", 0), prob.get("n_warehouses", 0), prob.get("n_extra_echelons", 0)
+        dev = observation["store_inventories"].device
+        n_nodes = E + Wn + S
+        internal, lead = [], []
+        if E > 0:  # serial system: echelons -> warehouse -> store
+            for i in range(E - 1):
+                internal.append((i, i + 1))
+                lead.append(float(observation["echelon_lead_times"][0, i + 1]))
+            internal.append((E - 1, E))
+            lead.append(float(observation["warehouse_lead_times"][0, 0]))
+            internal.append((E, E + Wn))
+            lead.append(float(observation["lead_times"][0, 0, 0]))
+            suppliers, customers = [0], [E + Wn]
+            sup_lead = [float(observation["echelon_lead_times"][0, 0])]
+        else:
+            if Wn == 1:
+                conn = [[1] * S]
+            else:
+                conn = prob.get("warehouse_store_adjacency")
+                if conn is None:
+                    raise ValueError(f"Multiple warehouses ({Wn}) detected but no 'warehouse_store_adjacency' matrix found "
+                                     "in problem_params. Please specify which stores connect to which warehouses.")
+            lt0 = observation["lead_times"][0].tolist()  # sample 0's lead times stand for the batch, as upstream (:984)
+            for w in range(Wn):
+                for st in range(S):
+                    if conn[w][st]:
+                        internal.append((w, Wn + st))
+                        lead.append(float(lt0[st][w]))
+            suppliers, customers = list(range(Wn)), list(range(Wn, Wn + S))
+            sup_lead = [float(observation["warehouse_lead_times"][0, w]) for w in range(Wn)]
+        out_deg, in_deg = [0] * n_nodes, [0] * n_nodes
+        for a, b in internal:
+            out_deg[a] += 1
+            in_deg[b] += 1
+        supplying = [] if self.transshipment else [n for n in range(n_nodes) if out_deg[n] > 0]
+        n_int, n_sup, n_dem, n_self = len(internal), len(suppliers), len(customers), len(supplying)
+        n_edges = n_int + n_sup + n_dem + n_self
+        # edge endpoints: index n_nodes = the virtual (all-zero) supplier / customer node
+        src = [a for a, _ in internal] + [n_nodes] * n_sup + customers + supplying
+        tgt = [b for _, b in internal] + suppliers + [n_nodes] * n_dem + supplying
+        for n in suppliers:
+            in_deg[n] += 1
+        for n in customers:
+            out_deg[n] += 1
+        for n in supplying:
+            in_deg[n] += 1
+            out_deg[n] += 1
+        a_in = torch.zeros(n_nodes, n_edges)
+        a_out = torch.zeros(n_nodes, n_edges)
+        for e in range(n_edges):
+            if tgt[e] < n_nodes and not (n_int + n_sup <= e < n_int + n_sup + n_dem):
+                a_in[tgt[e], e] = 1.0 / max(in_deg[tgt[e]], 1) ** 0.5
+            if src[e] < n_nodes and not (n_int <= e < n_int + n_sup):
+                a_out[src[e], e] = 1.0 / max(out_deg[src[e]], 1) ** 0.5
+        # proportional allocation groups: a supplying node's outgoing internal edges + its self-loop
+        group_of_edge = [-1] * n_edges
+        group_nodes = []
+        for n in range(n_nodes):
+            members = [i for i, (a, _) in enumerate(internal) if a == n]
+            if n in supplying:
+                members.append(n_int + n_sup + n_dem + supplying.index(n))
+            if members:
+                for e in members:
+                    group_of_edge[e] = len(group_nodes)
+                group_nodes.append(n)
+        member = torch.zeros(len(group_nodes), n_edges)
+        for e, gi in enumerate(group_of_edge):
+            if gi >= 0:
+                member[gi, e] = 1.0
+        # action layout: edge index per (row, column), n_edges = "no edge" (reads a zero column)
+        if E > 0:
+            mapping = {"stores": [[n_int - 1]], "warehouses": [[n_int - 2]],
+                       "echelons": [[n_int]] + [[i - 1] for i in range(1, E)]}
+        else:
+            rows = [[] for _ in range(S)]
+            for i, (_, b) in enumerate(internal):
+                rows[b - Wn].append(i)  # the j-th CONNECTED edge of a store is its column j, as upstream (:1423-1428)
+            mapping = {"stores": rows, "warehouses": [[n_int + w] for w in range(Wn)]}
+        gather = {}
+        for kind, rows in mapping.items():
+            if rows:
+                width = max(len(r) for r in rows)
+                gather[kind] = torch.tensor([r + [n_edges] * (width - len(r)) for r in rows], dtype=torch.long, device=dev)
+        self._graph = dict(
+            n_nodes=n_nodes, n_edges=n_edges, E=E, Wn=Wn, S=S,
+            src=torch.tensor(src, dtype=torch.long, device=dev), tgt=torch.tensor(tgt, dtype=torch.long, device=dev),
+            lead=torch.tensor(lead + sup_lead + [0.0] * (n_dem + n_self), device=dev).view(1, -1, 1),
+            a_in=a_in.to(dev), a_out=a_out.to(dev), member=member.to(dev),
+            group_nodes=torch.tensor(group_nodes, dtype=torch.long, device=dev), gather=gather,
+            steps=(E + 1) if E > 0 else 1, device=dev)
+        return self._graph
+
+    # ---- per-call features ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _node_features(observation, E):
+        feats, inv_lens = [], []
+        if E > 0:
+            feats.append(torch.cat([observation["echelon_inventories"],
+                                    observation["echelon_holding_costs"].unsqueeze(-1)], dim=-1))
+            inv_lens.append(observation["echelon_inventories"].size(-1))
+        wl = [observation["warehouse_inventories"], observation["warehouse_holding_costs"].unsqueeze(-1)]
+        if observation.get("warehouse_edge_costs") is not None:
+            wl.append(observation["warehouse_edge_costs"].unsqueeze(-1))
+        feats.append(torch.cat(wl, dim=-1))
+        inv_lens.append(observation["warehouse_inventories"].size(-1))
+        sl = [observation["store_inventories"], observation["holding_costs"].unsqueeze(-1),
+              observation["underage_costs"].unsqueeze(-1)]
+        if "past_demands" in observation:
+            sl.append(observation["past_demands"])
+            if "days_from_christmas" in observation:
+                sl.append(observation["days_from_christmas"].unsqueeze(-1))
+        else:
+            sl += [observation["mean"].unsqueeze(-1), observation["std"].unsqueeze(-1)]  # KeyError like upstream (:888)
+        feats.append(torch.cat(sl, dim=-1))
+        inv_lens.append(observation["store_inventories"].size(-1))
+        max_inv = max(inv_lens)
+        max_st = max(f.size(-1) - n for f, n in zip(feats, inv_lens))
+        padded = [torch.cat([F.pad(f[:, :, :n], (0, max_inv - n)), F.pad(f[:, :, n:], (0, max_st - (f.size(2) - n)))], dim=2)
+                  for f, n in zip(feats, inv_lens)]
+        return torch.cat(padded, dim=1)
+
+    def forward(self, observation):
+        g = self._graph
+        if g is None or g["device"] != observation["store_inventories"].device:
+            g = self._compile_graph(observation)
+        B = observation["store_inventories"].size(0)
+        nodes = self.net["initial_node"](self._node_features(observation, g["E"]))
+
+        def endpoints(nd):  # (source, target) features of every edge; index n_nodes selects the zero row
+            ext = torch.cat([nd, nd.new_zeros(B, 1, nd.size(-1))], dim=1)
+            return ext[:, g["src"]], ext[:, g["tgt"]]
+
+        s_f, t_f = endpoints(nodes)
+        edges = self.net["initial_edge"](torch.cat([s_f, t_f, g["lead"].expand(B, -1, -1)], dim=-1))
+        for _ in range(g["steps"]):
+            incoming = torch.matmul(g["a_in"], edges)    # [n_nodes, n_edges] x [B, n_edges, D]
+            outgoing = torch.matmul(g["a_out"], edges)
+            nodes = nodes + self.net["node_update"](torch.cat([nodes, incoming, outgoing], dim=-1))
+            s_f, t_f = endpoints(nodes)
+            edges = edges + self.net["edge_update"](torch.cat([edges, s_f, t_f], dim=-1))
+        out = self.net["output"](edges).squeeze(-1)  # desired quantity per edge
+        # proportional allocation: scale a node's outgoing edges (and its self-loop) to its on-hand stock
+        parts = []
+        if g["E"] > 0:
+            parts.append(observation["echelon_inventories"][:, :, 0])
+        if g["Wn"] > 0:
+            parts.append(observation["warehouse_inventories"][:, :, 0])
+        parts.append(observation["store_inventories"][:, :, 0])
+        on_hand = torch.cat(parts, dim=1)[:, g["group_nodes"]]                 # [B, groups]
+        scale = on_hand / (torch.matmul(out, g["member"].t()) + 1e-10)
+        if not self.transshipment:
+            scale = torch.clip(scale, max=1.0)
+        in_group = g["member"].sum(dim=0)                                      # 1 for edges that belong to a group
+        alloc = out * (torch.matmul(scale, g["member"]) + (1.0 - in_group))
+        ext = torch.cat([alloc, alloc.new_zeros(B, 1)], dim=1)
+        return {kind: ext[:, idx] for kind, idx in g["gather"].items()}
+
+
 class NeuralNetworkCreator:
     """neural_networks.py:1495-1574."""
 
@@ -366,6 +551,7 @@ class NeuralNetworkCreator:
         architectures = {
             "vanilla_one_store": VanillaOneStore, "base_stock": BaseStock, "capped_base_stock": CappedBaseStock,
             "echelon_stock": EchelonStock, "vanilla_serial": VanillaSerial, "vanilla_warehouse": VanillaWarehouse,
+            "gnn": GNN,
         }
         return architectures[name]  # KeyError for unknown names, like the reference (:1536)
 
@@ -381,7 +567,7 @@ class NeuralNetworkCreator:
             if val is None:
                 p["output_sizes"][key] = self.set_default_output_size(key, scenario.problem_params)
         cls = self.get_architecture(p["name"])
-        if p["name"] in ("vanilla_warehouse",):
+        if p["name"] in ("vanilla_warehouse", "gnn"):
             model = cls(p, scenario, device=device)
         else:
             model = cls(p, device=device)

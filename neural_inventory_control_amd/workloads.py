@@ -92,6 +92,17 @@ def many_warehouses(n_stores=64, n_warehouses=3, seed=0):
     return s_
 
 
+def gnn_policy():
+    """gnn.yml of the reference: five 32-wide MLPs (elu inside; softplus on the per-edge output, bias 5.0)."""
+    mods = ("initial_node", "initial_edge", "node_update", "edge_update", "output")
+    return {"name": "gnn",
+            "inner_layer_activations": {m: "elu" for m in mods},
+            "output_layer_activation": {**{m: "elu" for m in mods}, "output": "softplus"},
+            "neurons_per_hidden_layer": {m: [32, 32] for m in mods},
+            "output_sizes": {**{m: 32 for m in mods}, "output": 1},
+            "initial_bias": {"output": 5.0}, "gradient_clipping_norm_value": 1.0}
+
+
 WORKLOADS = {
     # name: (setting builder, policy dict, scenarios per GPU, periods, description)
     "cfg1": (lambda: one_store(True, True), _mlp("vanilla_one_store", [32, 32, 32], 1), 256, 50,
@@ -104,6 +115,9 @@ WORKLOADS = {
              "serial_system 4 echelons, 16384 scenarios/GPU x T=100, vanilla_serial"),
     "cfg5": (lambda: many_warehouses(64, 3), _mlp("vanilla_warehouse", [512, 512, 512], None, 4), 32768, 70,
              "many_warehouses_lost_demand 3x64 stores, 32768 scenarios/GPU x T=70, vanilla_warehouse 512x3"),
+    # the GNN policy on cfg3's graph (generic route: Simulator.step + autograd, MLPs on the matrix cores)
+    "gnn": (lambda: one_warehouse(16), gnn_policy(), 8192, 50,
+            "one_warehouse_lost_demand, 16 stores, 8192 scenarios x T=50, gnn (5 x 32-wide MLPs, 1 message-passing step)"),
 }
 
 

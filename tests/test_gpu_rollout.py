@@ -31,7 +31,9 @@ MLP_CASES = [n for n in case_names() if n.endswith("vanilla")]
 # float noise of zero: the `>= 0` mask of its holding cost then flips with summation order ("knife
 # edges").  Gradients of those configurations are compared with a looser bound; costs are unaffected.
 GRAD_TOL = {"cfg5_many_warehouses_2x10_vanilla": 5e-3, "cfg5_many_warehouses_3x8_vanilla": 5e-3,
-            "cfg3_one_warehouse_16_vanilla": 2e-4, "cfg3_one_warehouse_5_vanilla": 2e-4}
+            "cfg3_one_warehouse_16_vanilla": 2e-4, "cfg3_one_warehouse_5_vanilla": 2e-4,
+            # GNN: batched incidence-matrix aggregation associates sums differently from upstream's edge loops
+            "f1_one_warehouse_gnn": 2e-4, "f1_one_warehouse_16_gnn": 2e-4}
 
 
 def _model(g, c, scenario=None):

@@ -146,3 +146,22 @@ def test_main_run_cli_surface():
     with pytest.raises(FileNotFoundError):
         main_run.main(["train", "no_such_setting", "no_such_policy", "--config-dir", "/nonexistent"])
     assert main_run.SETTING_KEYS[0] == "seeds" and "nn_params" in main_run.HYPERPARAM_KEYS
+
+
+def test_factory_builds_gnn_policy_with_reference_state_dict_keys():
+    """`gnn` in the factory registry (neural_networks.py:1519-1536): five named MLPs, bias 5.0 on the output layer, and the
+    reference's state-dict key layout (checkpoints interchange)."""
+    from neural_inventory_control_amd import workloads
+    from neural_inventory_control_amd.neural_networks import GNN, NeuralNetworkCreator
+    setting, policy, _, _, _ = workloads.get("gnn")
+
+    class _Sc:
+        problem_params = setting["problem_params"]
+        store_params = {"demand": {"mean": [5.0] * 16}}
+    model = NeuralNetworkCreator().create_neural_network(_Sc(), policy, device="cpu")
+    assert isinstance(model, GNN) and model.gradient_clipping_norm_value == 1.0
+    assert list(model.net.keys()) == ["initial_node", "initial_edge", "node_update", "edge_update", "output"]
+    out_last = [m for m in model.net["output"] if hasattr(m, "bias")][-1]
+    assert float(out_last.bias.detach()[0]) == 5.0
+    keys = [k for k, _ in model.named_parameters() if "UninitializedParameter" not in k]
+    assert "net.output.4.bias" in keys and "net.initial_node.0.weight" in keys
