@@ -84,7 +84,7 @@ _DRIVER_PAIRS = [("one_store_lost", "vanilla_one_store"), ("one_store_backlogged
                  ("one_store_backlogged", "base_stock"), ("one_store_backlogged", "capped_base_stock"),
                  ("one_warehouse_lost_demand", "vanilla_warehouse"), ("many_warehouses_lost_demand", "vanilla_warehouse"),
                  ("serial_system", "vanilla_serial"), ("serial_system", "echelon_stock"),
-                 ("transshipment_backlogged", "vanilla_transshipment")]
+                 ("transshipment_backlogged", "vanilla_transshipment"), ("one_warehouse_lost_demand", "gnn")]
 
 
 @pytest.mark.parametrize("setting,policy", _DRIVER_PAIRS)
@@ -102,6 +102,6 @@ def test_driver_builds_from_reference_config_files(setting, policy):
     c = main_run.build(cs, ch, "cpu")
     assert len(c["data_loaders"]["train"].dataset) == 64 and len(c["data_loaders"]["test"].dataset) == 64
     assert type(c["model"]).__name__ in ("VanillaOneStore", "BaseStock", "CappedBaseStock", "VanillaWarehouse",
-                                         "VanillaSerial", "EchelonStock")
+                                         "VanillaSerial", "EchelonStock", "GNN")
     batch = next(iter(c["data_loaders"]["dev"]))
     assert batch["demands"].shape[0] == 32 and batch["demands"].shape[1] == cs["problem_params"]["n_stores"]
