@@ -160,11 +160,18 @@ def main():
         sim, tr, loss_fn = Simulator(device=device), Trainer(device=device), PolicyLoss()
         args.no_kernel_timing = True
 
+        tr._global_batch = global_b
+
         def generic_step():
-            opt.zero_grad(set_to_none=True)
-            total, _ = tr.simulate_batch(loss_fn, sim, model, T, setting["problem_params"], data,
-                                         setting["observation_params"], 0, False)
-            (total * grad_scale).backward()
+            if args.graph:  # whole training step (all periods + autograd sweep) replayed from one HIP graph
+                opt.zero_grad(set_to_none=False)
+                total, _ = tr._graphed_generic_step(loss_fn, sim, model, T, setting["problem_params"], data,
+                                                    setting["observation_params"], 0)
+            else:
+                opt.zero_grad(set_to_none=True)
+                total, _ = tr.simulate_batch(loss_fn, sim, model, T, setting["problem_params"], data,
+                                             setting["observation_params"], 0, False)
+                (total * grad_scale).backward()
             if reducer is not None:
                 total, _ = reducer.all_reduce(total.detach(), total.detach())
             clip = getattr(model, "gradient_clipping_norm_value", None)

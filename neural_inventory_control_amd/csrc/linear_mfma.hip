@@ -916,14 +916,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
 // waves per workgroup (wave-private LDS tiles, no workgroup barrier).  HBM-bound by construction: every dY / X element is
 // read exactly once (8 KiB per 16 MFMAs).  slab split index = global wave id; bias column from the dY fragment sums.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void wgrad_small_kernel(WgParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 32 * LDA_S];  // per wave: A tile then B tile, [32][36]
+// KC = 32-column chunks of the output (K <= 32 KC input features of X): one accumulator and one wave-private B tile each
+template <int KC>
+__global__ __launch_bounds__(kThreads) void wgrad_small_kernel(WgParams p, int n_splits) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * (1 + KC) * 32 * LDA_S];  // per wave: A tile then KC B tiles, [32][36]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int split = blockIdx.x * 4 + wave;
+    if (split >= n_splits) return;  // (tiles are wave-private: no workgroup barrier below)
     const int b_begin = split * p.chunk;
     const int b_end = min(b_begin + p.chunk, p.nB);
-    float* As = lds + wave * (2 * 32 * LDA_S);
+    float* As = lds + wave * ((1 + KC) * 32 * LDA_S);
     float* Bs = As + 32 * LDA_S;
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.dY, (int64_t)p.N * p.ldb);  // rows >= N / K read as zeros
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.X, (int64_t)p.K * p.ldb);
@@ -931,64 +934,86 @@ __global__ __launch_bounds__(kThreads) void wgrad_small_kernel(WgParams p) {
     int off[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) off[q] = (int)((((int64_t)(lane >> 3) + 8 * q) * p.ldb + b_begin + (lane & 7) * 4) * 4);
+    const int chunk_step = (int)(32 * p.ldb * 4);  // byte offset between two 32-row chunks of X
 
-    f32x16 acc;
+    f32x16 acc[KC];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     float rowsum = 0.f;
-    float4 va[4], vb[4];
+    float4 va[4], vb[KC][4];
     const int nt = (b_end - b_begin + BK - 1) / BK;
     if (nt > 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             va[q] = buf_load4(ra, off[q]);
-            vb[q] = buf_load4(rb, off[q]);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) vb[c][q] = buf_load4(rb, off[q] + c * chunk_step);
         }
     }
     for (int t = 0; t < nt; ++t) {
         // columns at or past b_end contribute nothing (only the last tile of the last split can be partial)
-        const int c = b_begin + t * BK + (lane & 7) * 4;
+        const int cc = b_begin + t * BK + (lane & 7) * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 x = va[q], y = vb[q];
-            if (c + 3 >= b_end) {
-                if (c + 0 >= b_end) x.x = y.x = 0.f;
-                if (c + 1 >= b_end) x.y = y.y = 0.f;
-                if (c + 2 >= b_end) x.z = y.z = 0.f;
-                if (c + 3 >= b_end) x.w = y.w = 0.f;
+            float4 x = va[q];
+            const bool tail = cc + 3 >= b_end;
+            if (tail) {
+                if (cc + 0 >= b_end) x.x = 0.f;
+                if (cc + 1 >= b_end) x.y = 0.f;
+                if (cc + 2 >= b_end) x.z = 0.f;
+                if (cc + 3 >= b_end) x.w = 0.f;
             }
             *reinterpret_cast<float4*>(As + ((lane >> 3) + 8 * q) * LDA_S + (lane & 7) * 4) = x;
-            *reinterpret_cast<float4*>(Bs + ((lane >> 3) + 8 * q) * LDA_S + (lane & 7) * 4) = y;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                float4 y = vb[c][q];
+                if (tail) {
+                    if (cc + 0 >= b_end) y.x = 0.f;
+                    if (cc + 1 >= b_end) y.y = 0.f;
+                    if (cc + 2 >= b_end) y.z = 0.f;
+                    if (cc + 3 >= b_end) y.w = 0.f;
+                }
+                *reinterpret_cast<float4*>(Bs + c * 32 * LDA_S + ((lane >> 3) + 8 * q) * LDA_S + (lane & 7) * 4) = y;
+            }
         }
         if (t + 1 < nt) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 off[q] += BK * 4;
                 va[q] = buf_load4(ra, off[q]);
-                vb[q] = buf_load4(rb, off[q]);
+#pragma unroll
+                for (int c = 0; c < KC; ++c) vb[c][q] = buf_load4(rb, off[q] + c * chunk_step);
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (tiles are wave-private)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            float a[8], b[8];
+            float a[8];
             read_frag8(As + li * LDA_S, g, h, a);
-            read_frag8(Bs + li * LDA_S, g, h, b);
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                rowsum += a[kk];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+            for (int kk = 0; kk < 8; ++kk) rowsum += a[kk];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                float b[8];
+                read_frag8(Bs + c * 32 * LDA_S + li * LDA_S, g, h, b);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc[c], 0, 0, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();  // fragment reads done before the next tile overwrites the LDS tiles
     }
     float* slab = p.slab + (int64_t)split * p.N * p.lds_;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < p.N && li < p.K) slab[(int64_t)row * p.lds_ + li] += acc[r];
-    }
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int col = c * 32 + li;
+            if (row < p.N && col < p.K) slab[(int64_t)row * p.lds_ + col] += acc[c][r];
+        }
     const float s = rowsum + __shfl_xor(rowsum, 32);
     if (h == 0 && li < p.N) slab[(int64_t)li * p.lds_ + p.K] += s;
 }
@@ -1129,7 +1154,7 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
         tiles = ((N + 255) / 256) * ((K + 255) / 256);
         target = 256;
     }
-    if (N <= 32 && K <= 32) {  // wgrad_small_kernel: one split per wave (multiple of 4), >= 512 columns each
+    if (N <= 32 && (K <= 32 || (K <= 128 && K % 32 != 0))) {  // wgrad_small_kernel: one split per wave, >= 2048 columns each
         int sp = (int)(((int64_t)n_scenarios + 2047) / 2048);
         if (sp > 1024) sp = 1024;  // one wave per SIMD
         return (sp + 3) / 4 * 4;
@@ -1164,10 +1189,16 @@ static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t l
     const bool dma_ok = ldb % 4 == 0 && n_scenarios % BK == 0 && lds_ % 4 == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 &&
                         (int64_t)N * ldb < (1ll << 28) && (int64_t)K * ldb < (1ll << 28);
-    const bool small_ok = n_periods == 1 && N <= 32 && K <= 32 && n_splits % 4 == 0 && ldb % 4 == 0 &&
+    const bool small_ok = n_periods == 1 && N <= 32 && K <= 128 && ldb % 4 == 0 &&
                           (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                           (int64_t)N * ldb < (1ll << 28) && (int64_t)K * ldb < (1ll << 28);
-    if (small_ok) hipLaunchKernelGGL(wgrad_small_kernel, dim3(n_splits / 4), dim3(kThreads), 0, s, p);
+    if (small_ok) {  // thin output (<= 32 rows), up to 128 input features: one wave per split, 1..4 accumulators
+        const dim3 g((n_splits + 3) / 4), b(kThreads);
+        if (K <= 32) hipLaunchKernelGGL(wgrad_small_kernel<1>, g, b, 0, s, p, n_splits);
+        else if (K <= 64) hipLaunchKernelGGL(wgrad_small_kernel<2>, g, b, 0, s, p, n_splits);
+        else if (K <= 96) hipLaunchKernelGGL(wgrad_small_kernel<3>, g, b, 0, s, p, n_splits);
+        else hipLaunchKernelGGL(wgrad_small_kernel<4>, g, b, 0, s, p, n_splits);
+    }
     else if (wgrad_big(N, K) && dma_ok && gemm_variant() != 2) launch_wg_dma<2, 4, 4, 2>(p, n_splits, s);
     else if (bm == 128 && bn == 128) launch_wg<2, 2, 2, 2>(p, n_splits, s);
     else if (bm == 128) launch_wg<2, 2, 2, 1>(p, n_splits, s);

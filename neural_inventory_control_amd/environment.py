@@ -96,7 +96,7 @@ class Simulator:
         if observation_params["sample_features"] is not None:
             self._internal_data.update({k: data[k] for k in observation_params["sample_features"]})
 
-        prob = EnvProblem(problem_params, data, dev)
+        prob = self._problem_for(problem_params, data, dev)
         self._prob = prob
         # demand trace in [T][S][ldb]: the per-period read of the kernel is then one contiguous (S x ldb) panel instead
         # of the reference's stride-T gather (environment.py:177)
@@ -134,6 +134,25 @@ class Simulator:
         self.observation = obs
         self.maximize_profit = problem_params["maximize_profit"]
         return self.observation, None
+
+    _STATIC_KEYS = ("underage_costs", "holding_costs", "lead_times", "warehouse_holding_costs", "warehouse_lead_times",
+                    "warehouse_edge_costs", "echelon_holding_costs", "echelon_lead_times")
+
+    def _problem_for(self, problem_params, data, dev):
+        """EnvProblem of a batch.  Building one checks the static tables for scenario-uniformity, which reads a flag back
+        from the device; batches that present the SAME tensors again (same storage, shape, in-place version — the static
+        input buffers of a captured training step, or the fixed batches of an un-shuffled loader) reuse it, so a rollout
+        contains no host sync at all (a requirement for capturing it into a HIP graph)."""
+        key = (id(problem_params),) + tuple(
+            (k, data[k].data_ptr(), tuple(data[k].shape), tuple(data[k].stride()), data[k]._version)
+            for k in self._STATIC_KEYS if data.get(k) is not None)
+        cache = self.__dict__.setdefault("_prob_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 16:
+                cache.pop(next(iter(cache)))
+            hit = cache[key] = EnvProblem(problem_params, data, dev)
+        return hit
 
     # ---- step (environment.py:110-169) ------------------------------------------------------------------------
     def step(self, action):

@@ -62,8 +62,11 @@ class _LinearFunction(torch.autograd.Function):
         dZ[:, :B] = gy.t()
         gx = gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            splits = max(1, min(ops.wgrad_num_splits(N, K, B), 16))
-            slab = torch.zeros(splits, N, (K + 4) // 4 * 4, device=gy.device)
+            lds = (K + 4) // 4 * 4
+            # the split count the kernels want for this shape (a GNN layer sees batch x edges = 10^5..10^6 columns: clamping
+            # it left 4 workgroups on the chip), bounded only by 64 MB of slab
+            splits = max(1, min(ops.wgrad_num_splits(N, K, B), (64 << 20) // (N * lds * 4)))
+            slab = torch.zeros(splits, N, lds, device=gy.device)
             ops.linear_wgrad(dZ, X, slab, B)
             gw = torch.empty(N, K, device=gy.device)
             gb = torch.empty(N, device=gy.device)
@@ -282,7 +285,7 @@ class BaseStock(MyNeuralNetwork):
     def forward(self, observation):
         x = observation["store_inventories"]
         inv_pos = x.sum(dim=2)
-        level = self.net["master"](torch.tensor([0.0], device=x.device))
+        level = self.net["master"](torch.zeros(1, device=x.device))
         return {"stores": torch.clip(level - inv_pos, min=0).unsqueeze(2)}
 
 
@@ -292,8 +295,8 @@ class CappedBaseStock(MyNeuralNetwork):
     def forward(self, observation):
         x = observation["store_inventories"]
         inv_pos = x.sum(dim=2)
-        out = self.net["master"](torch.tensor([0.0], device=x.device))
-        return {"stores": torch.clip(out[0] - inv_pos, min=torch.tensor([0.0], device=x.device), max=out[1]).unsqueeze(2)}
+        out = self.net["master"](torch.zeros(1, device=x.device))
+        return {"stores": torch.clip(out[0] - inv_pos, min=torch.zeros(1, device=x.device), max=out[1]).unsqueeze(2)}
 
 
 class EchelonStock(MyNeuralNetwork):
@@ -303,7 +306,7 @@ class EchelonStock(MyNeuralNetwork):
         s_inv, w_inv, e_inv = (observation[k] for k in ("store_inventories", "warehouse_inventories",
                                                         "echelon_inventories"))
         E = e_inv.size(1)
-        x = self.activation_functions["softplus"](self.net["master"](torch.tensor([0.0], device=s_inv.device)) + 10.0)
+        x = self.activation_functions["softplus"](self.net["master"](torch.zeros(1, device=s_inv.device)) + 10.0)
         levels = torch.cumsum(x, dim=0).flip(dims=[0])
         pos = torch.concat((e_inv.sum(dim=2), w_inv.sum(dim=2), s_inv.sum(dim=2)), dim=1)
         upstream = torch.concat((1000000 * torch.ones_like(w_inv[:, :, 0]), e_inv[:, :, 0], w_inv[:, :, 0]), dim=1)

@@ -31,7 +31,12 @@ class Trainer:
                                       "model_params_to_save": None}
         self.best_epoch = 0
         self.use_fused_rollout = True
+        # generic route (policies the fused engine does not take: GNN, closed-form, user plugins): capture the whole training
+        # step of a batch shape - every period's policy + env-step launches and the autograd sweep - into ONE HIP graph and
+        # replay it; the per-period kernels of these policies run for microseconds, so the step is launch-bound
+        self.use_step_graph = False
         self._engines = {}
+        self._step_graphs = {}
         self._fused_grads_ready = False
 
     def reset(self):
@@ -88,15 +93,25 @@ class Trainer:
         with torch.no_grad() if not train else torch.enable_grad():
             for data_batch in data_loader:
                 data_batch = self.move_batch_to_device(data_batch)
-                if train:
+                if train and not self.use_step_graph:
                     optimizer.zero_grad()
+                elif train:
+                    optimizer.zero_grad(set_to_none=False)  # captured steps accumulate into fixed .grad tensors
                 self._fused_grads_ready = False
                 self._train_mode = train and model.trainable
                 # every rank normalises by the GLOBAL batch (trainer.py:169 with B summed over ranks)
                 self._global_batch = getattr(data_loader, "last_global_batch", None) or len(data_batch["demands"]) * world
-                total_reward, reward_to_report = self.simulate_batch(
-                    loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
-                    ignore_periods, discrete_allocation)
+                graphed = (train and model.trainable and self.use_step_graph and not discrete_allocation
+                           and not (self.use_fused_rollout and FusedRollout.supports(model)
+                                    and self._plain_observation(observation_params)))
+                if graphed:
+                    total_reward, reward_to_report = self._graphed_generic_step(
+                        loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
+                        ignore_periods)
+                else:
+                    total_reward, reward_to_report = self.simulate_batch(
+                        loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
+                        ignore_periods, discrete_allocation)
                 if train and model.trainable:
                     if not self._fused_grads_ready:
                         mean_loss = total_reward / (self._global_batch * periods * problem_params["n_stores"])
@@ -153,6 +168,52 @@ class Trainer:
             if terminated:
                 break
         return batch_reward, reward_to_report
+
+    def _graphed_generic_step(self, loss_function, simulator, model, periods, problem_params, data_batch,
+                              observation_params, ignore_periods):
+        """Forward + backward of one batch on the generic route, replayed from a HIP graph.  First call with a batch shape:
+        eager (materialises lazy layers, compiles static policy state); second call: captured with the batch copied into
+        static input tensors and gradients accumulating into static `.grad` tensors; afterwards: copy + replay."""
+        key = (id(model), periods, ignore_periods,
+               tuple((k, tuple(v.shape)) for k, v in sorted(data_batch.items()) if torch.is_tensor(v)))
+        st = self._step_graphs.get(key)
+        scale = 1.0 / (self._global_batch * periods * problem_params["n_stores"])
+        if st is None:  # eager warm-up run
+            self._step_graphs[key] = {"static": None}
+            total, rep = self.simulate_batch(loss_function, simulator, model, periods, problem_params, data_batch,
+                                             observation_params, ignore_periods, False)
+            (total * scale).backward()
+            self._fused_grads_ready = True
+            return total.detach(), rep.detach() if torch.is_tensor(rep) else rep
+        params = [p for p in model.parameters() if p.requires_grad]
+        if st["static"] is None:
+            static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_batch.items()}
+            for p in params:
+                p.grad = torch.zeros_like(p)
+            stream = torch.cuda.Stream()
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):  # one more eager run on the side stream (allocator / autograd warm-up)
+                total, rep = self.simulate_batch(loss_function, simulator, model, periods, problem_params, static,
+                                                 observation_params, ignore_periods, False)
+                (total * scale).backward()
+            torch.cuda.current_stream().wait_stream(stream)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for p in params:
+                    p.grad.zero_()
+                total, rep = self.simulate_batch(loss_function, simulator, model, periods, problem_params, static,
+                                                 observation_params, ignore_periods, False)
+                (total * scale).backward()
+                out_total, out_rep = total.detach(), (rep.detach() if torch.is_tensor(rep) else rep)
+            st.update(static=static, graph=graph, total=out_total, rep=out_rep, scale=scale)
+        if st["scale"] != scale:
+            raise RuntimeError("captured training step: the global batch size changed; disable use_step_graph")
+        for k, v in data_batch.items():
+            if torch.is_tensor(v):
+                st["static"][k].copy_(v)
+        st["graph"].replay()
+        self._fused_grads_ready = True
+        return st["total"], st["rep"]
 
     @staticmethod
     def _plain_observation(observation_params):

@@ -63,7 +63,9 @@ GEMM_SHAPES = [(512, 51, 1000), (512, 512, 2048 + 37), (17, 512, 777), (32, 4, 1
                # multiples of 32 scenarios, wide layers: the 256 x 256 LDS-DMA kernels (8 waves, two-pass epilogue)
                (512, 512, 4096), (256, 200, 2048), (300, 512, 1024), (512, 256, 8192),
                # short contraction, >= 64 output rows: the streamed first-layer forward of thin_layer.hip
-               (512, 51, 4096), (128, 7, 777), (96, 64, 2048), (64, 1, 100), (192, 33, 96)]
+               (512, 51, 4096), (128, 7, 777), (96, 64, 2048), (64, 1, 100), (192, 33, 96),
+               # thin outputs with up to 128 input features (GNN layers): multi-accumulator wgrad_small_kernel
+               (32, 65, 4096), (17, 96, 1000), (32, 128, 2049), (5, 40, 300)]
 
 
 def _rand(shape, gen, dev, scale=1.0):
