@@ -131,7 +131,8 @@ int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds, 
 /* The same contraction over n_periods operand pairs (dY + t * period_stride_dy, X + t * period_stride_x; strides in
  * elements, multiples of 4) in ONE launch: the backward sweep of a rollout keeps every period's dY resident ([T][N][ldb],
  * HBM is sized for it) and contracts weight gradients once per training step instead of once per period — one slab
- * read-modify-write instead of T, no per-period pipeline fill/drain.  Shapes the LDS-DMA kernel does not take are
+ * read-modify-write instead of T, no per-period pipeline fill/drain.  Periods are accumulated last first (autograd's
+ * order; partial sums are added to the slab every ~8k terms).  Shapes the LDS-DMA kernel does not take are
  * served by one nic_linear_wgrad launch per period (same result). */
 int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64_t lds, int32_t N, int32_t K,
                              int32_t n_scenarios, int32_t ldb, int32_t n_splits, int32_t n_periods,

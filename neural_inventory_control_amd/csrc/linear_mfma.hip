@@ -591,6 +591,10 @@ struct WgParams {
     // with the same scenario split in each — one launch for the whole backward sweep of a rollout
     int n_periods;
     int64_t pstride_dy, pstride_x;
+    // the register accumulators are added to the slab and cleared every `flush_periods` periods: an fp32 sum of 10^5
+    // terms in one register drifts to ~5e-5 relative (measured against the fp32 CPU reference at T = 100 x 1,024 scenarios
+    // per split); 8k-term partial sums keep the weight gradients at the per-period accuracy
+    int flush_periods;
 };
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, int FAST>
@@ -804,22 +808,86 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
     // flat sequence of (period, k tile): the copy of the next tile crosses period boundaries by moving the two buffer
     // descriptors to the next period's operands and rewinding the offsets, so the pipeline never drains
     const int total = nt * p.n_periods;
+    const int group = nt * (p.flush_periods > 0 ? p.flush_periods : p.n_periods);  // tiles between two slab updates
     int t_in = 0, period = 0;
+    auto next_tile = [&]() {  // moves descriptors / offsets to tile t+1 (possibly the first tile of the next period)
+        if (++t_in == nt) {
+            t_in = 0;
+            ++period;
+            ra = make_desc(p.dY + period * p.pstride_dy, (int64_t)p.N * p.ldb);
+            rb = make_desc(p.X + period * p.pstride_x, (int64_t)p.K * p.ldb);
+#pragma unroll
+            for (int q = 0; q < A_INSTR; ++q) offA[q] -= (nt - 1) * BK * 4;
+#pragma unroll
+            for (int q = 0; q < B_INSTR; ++q) offB[q] -= (nt - 1) * BK * 4;
+        } else {
+            advance();
+        }
+    };
+    constexpr int TPR = BN / 4, RPI = NTHREADS / TPR, ITER = PASS_ROWS / RPI;
+    const int tt = threadIdx.x;
+    const int col = k0 + (tt % TPR) * 4;
+    float* cs = lds;
+    auto flush = [&]() {  // slab += accumulators (all waves; uses the whole staging area, so no copy may be in flight)
+    // bias gradient: lanes l and l+32 hold the two k halves of row (wm*MT + i)*32 + li
+        if (bias_owner) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float s = rowsum[i] + __shfl_xor(rowsum[i], 32);
+                const int row = n0 + (wm * MT + i) * 32 + li;
+                if (h == 0 && row < p.N) slab[(int64_t)row * p.lds_ + p.K] += s;
+            }
+        }
+
+        // slab += tile, staged through LDS (whole-row float4 read-add-write)
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+            if (PASSES == 1 || wm == pass) {
+                const int wrow = (PASSES == 1) ? wm * MT * 32 : 0;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            cs[(wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + (wn * NT + j) * 32 + li] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int row_l = tt / TPR + RPI * it;
+                const int row = n0 + pass * PASS_ROWS + row_l;
+                if (row >= p.N || col >= p.K) continue;
+                const float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (tt % TPR) * 4);
+                float* dst = slab + (int64_t)row * p.lds_ + col;
+                if (col + 3 < p.K && (p.lds_ & 3) == 0) {
+                    float4 o = *reinterpret_cast<const float4*>(dst);
+                    o.x += y.x; o.y += y.y; o.z += y.z; o.w += y.w;
+                    *reinterpret_cast<float4*>(dst) = o;
+                } else {
+                    dst[0] += y.x;
+                    if (col + 1 < p.K) dst[1] += y.y;
+                    if (col + 2 < p.K) dst[2] += y.z;
+                    if (col + 3 < p.K) dst[3] += y.w;
+                }
+            }
+            if (pass + 1 < PASSES) __syncthreads();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            rowsum[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    };
     for (int t = 0; t < total; ++t) {
         const int cur = t & 1;
-        if (t + 1 < total) {
-            if (++t_in == nt) {
-                t_in = 0;
-                ++period;
-                ra = make_desc(p.dY + period * p.pstride_dy, (int64_t)p.N * p.ldb);
-                rb = make_desc(p.X + period * p.pstride_x, (int64_t)p.K * p.ldb);
-#pragma unroll
-                for (int q = 0; q < A_INSTR; ++q) offA[q] -= (nt - 1) * BK * 4;
-#pragma unroll
-                for (int q = 0; q < B_INSTR; ++q) offB[q] -= (nt - 1) * BK * 4;
-            } else {
-                advance();
-            }
+        const bool boundary = (t + 1) % group == 0 || t + 1 == total;  // this tile ends an accumulation group
+        if (!boundary) {
+            next_tile();
             issue(cur ^ 1);
         }
         const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * BK;
@@ -857,55 +925,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
         }
         dma_wait();
         __syncthreads();
-    }
-
-    // bias gradient: lanes l and l+32 hold the two k halves of row (wm*MT + i)*32 + li
-    if (bias_owner) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const float s = rowsum[i] + __shfl_xor(rowsum[i], 32);
-            const int row = n0 + (wm * MT + i) * 32 + li;
-            if (h == 0 && row < p.N) slab[(int64_t)row * p.lds_ + p.K] += s;
-        }
-    }
-
-    // slab += tile, staged through LDS (whole-row float4 read-add-write)
-    float* cs = lds;
-    constexpr int TPR = BN / 4, RPI = NTHREADS / TPR, ITER = PASS_ROWS / RPI;
-    const int tt = threadIdx.x;
-    const int col = k0 + (tt % TPR) * 4;
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        if (PASSES == 1 || wm == pass) {
-            const int wrow = (PASSES == 1) ? wm * MT * 32 : 0;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        cs[(wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + (wn * NT + j) * 32 + li] = acc[i][j][r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int row_l = tt / TPR + RPI * it;
-            const int row = n0 + pass * PASS_ROWS + row_l;
-            if (row >= p.N || col >= p.K) continue;
-            const float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (tt % TPR) * 4);
-            float* dst = slab + (int64_t)row * p.lds_ + col;
-            if (col + 3 < p.K && (p.lds_ & 3) == 0) {
-                float4 o = *reinterpret_cast<const float4*>(dst);
-                o.x += y.x; o.y += y.y; o.z += y.z; o.w += y.w;
-                *reinterpret_cast<float4*>(dst) = o;
-            } else {
-                dst[0] += y.x;
-                if (col + 1 < p.K) dst[1] += y.y;
-                if (col + 2 < p.K) dst[2] += y.z;
-                if (col + 3 < p.K) dst[3] += y.w;
+        if (boundary) {
+            flush();
+            if (t + 1 < total) {  // re-prime the pipeline after the slab update
+                next_tile();
+                issue(cur ^ 1);
+                dma_wait();
+                __syncthreads();
             }
         }
-        if (pass + 1 < PASSES) __syncthreads();
     }
 #endif
 }
@@ -1182,7 +1210,7 @@ static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t l
     if (int e = require_ld(who, n_scenarios, ldb)) return e;
     int chunk = (n_scenarios + n_splits - 1) / n_splits;
     chunk = (chunk + BK - 1) / BK * BK;
-    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, pstride_dy, pstride_x};
+    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, pstride_dy, pstride_x, 0};
     hipStream_t s = nic::as_stream(stream);
     int bm, bn;
     wgrad_tile(N, K, &bm, &bn);
@@ -1216,6 +1244,16 @@ int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64
                              int32_t n_scenarios, int32_t ldb, int32_t n_splits, int32_t n_periods, int64_t period_stride_dy,
                              int64_t period_stride_x, void* stream) {
     NIC_REQUIRE(n_periods >= 1, "nic_linear_wgrad_periods: n_periods must be >= 1");
+    // Periods are accumulated LAST FIRST, the order autograd accumulates them in the reference: pre-activation gradients grow
+    // towards the start of the horizon (each period adds the costs it influences later), so this sums the small terms
+    // before the large ones.  Measured at 512x3, T = 100: bias-gradient error against an fp64 evaluation 2.9e-5 in
+    // ascending order, 1e-6 descending.
+    if (n_periods > 1) {
+        dY += (int64_t)(n_periods - 1) * period_stride_dy;
+        X += (int64_t)(n_periods - 1) * period_stride_x;
+        period_stride_dy = -period_stride_dy;
+        period_stride_x = -period_stride_x;
+    }
     NIC_REQUIRE(period_stride_dy % 4 == 0 && period_stride_x % 4 == 0,
                 "nic_linear_wgrad_periods: period strides must be multiples of 4 elements (16-byte aligned operands)");
     const bool dma_ok = dY && X && slab && N > 0 && K > 0 && lds_ >= K + 1 && n_splits >= 1 && n_scenarios > 0 && ldb >= n_scenarios &&
@@ -1232,13 +1270,23 @@ int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64
                     return e;
             return 0;
         }
-        return wgrad_generic(dY, X, slab, lds_, N, K, n_scenarios, ldb, n_splits, n_periods, period_stride_dy, period_stride_x,
-                             stream, "nic_linear_wgrad_periods");
+        // register-staged kernels: a launch per group of periods, so that no accumulator sums more than ~8k terms
+        // before it is added to the slab (see WgParams::flush_periods)
+        int chunk_g = (n_scenarios + n_splits - 1) / n_splits;
+        const int group = 8192 / (chunk_g > 0 ? chunk_g : 1) > 0 ? 8192 / (chunk_g > 0 ? chunk_g : 1) : 1;
+        for (int t = 0; t < n_periods; t += group) {
+            const int n = n_periods - t < group ? n_periods - t : group;
+            if (int e = wgrad_generic(dY + t * period_stride_dy, X + t * period_stride_x, slab, lds_, N, K, n_scenarios, ldb,
+                                      n_splits, n, period_stride_dy, period_stride_x, stream, "nic_linear_wgrad_periods"))
+                return e;
+        }
+        return 0;
     }
     int chunk = (n_scenarios + n_splits - 1) / n_splits;
     chunk = (chunk + BK - 1) / BK * BK;
+    const int flush = 8192 / chunk > 0 ? 8192 / chunk : 1;
     WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, period_stride_dy,
-               period_stride_x};
+               period_stride_x, flush};
     launch_wg_dma<2, 4, 4, 2>(p, n_splits, nic::as_stream(stream));
     return nic::check_launch("nic_linear_wgrad_periods");
 }

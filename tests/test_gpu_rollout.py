@@ -602,3 +602,47 @@ def test_captured_generic_training_step_matches_eager(name):
         assert len(ge) == len(gg)
         for a, b2 in zip(ge, gg):
             assert float((a - b2).norm()) <= 1e-5 * float(a.norm()) + 1e-12
+
+
+def test_gradient_parity_at_benchmark_width_and_horizon():
+    """BASELINE cfg3's network (512 x 3) and horizon (T = 100) on 2,048 scenarios: the HIP engine's training step — weight
+    gradients contracted over all 100 periods x 2,048 scenarios in one fp32 accumulation — against the CPU oracle's autograd
+    on identical inputs and weights.  Bars: per-scenario total cost 1e-5 relative (north star); gradients 1e-4 relative L2
+    per tensor (the two sides sum ~200k fp32 terms per weight in different orders)."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from neural_inventory_control_amd.neural_networks import NeuralNetworkCreator
+    from oracle import inventory_oracle as orc
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    setting, policy, _, _, _ = workloads.get("cfg3")
+    B, T = 2048, 100
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    data = orc.generate_scenario_data(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"],
+                                      setting["echelon_params"], B, obs, setting["seeds"])
+    F = 16 * data["initial_inventories"].shape[2] + data["initial_warehouse_inventories"].shape[2]
+    pol = orc.init_policy(policy, setting["problem_params"], F, 4321, setting["store_params"])
+    res, _, grads = orc.train_step_gradients(pol, T, setting["problem_params"], data, obs)
+
+    class _Sc:
+        problem_params = setting["problem_params"]
+        store_params = setting["store_params"]
+    model = NeuralNetworkCreator().create_neural_network(_Sc(), policy, device=DEV)
+    eng = FusedRollout(model, setting["problem_params"], DEV)
+    eng.materialize(F)
+    with torch.no_grad():
+        for m, (w, b) in zip(model.master_linears(), pol.layers):
+            m.weight.copy_(w.detach())
+            m.bias.copy_(b.detach())
+    model.warehouse_upper_bound = pol.warehouse_upper_bound.to(DEV)
+    total, _ = eng.run({k: v.to(DEV) for k, v in data.items()}, T, 0, train=True, observation_params=obs)
+    torch.cuda.synchronize()
+    assert eng.dZhist is not None  # the all-period weight-gradient route
+    assert abs(float(total) - float(res.total)) <= 1e-5 * abs(float(res.total))
+    per_scn = eng.per_period_rewards().sum(dim=0).cpu()
+    ref_scn = res.per_period.sum(dim=0)
+    assert float(((per_scn - ref_scn).abs() / ref_scn.abs().clamp_min(1e-9)).max()) <= 1e-5
+    worst = 0.0
+    for p, ref in zip(model.parameters(), grads):
+        worst = max(worst, float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30)))
+    print(f"worst relative gradient error at 512x3, T=100, B=2048: {worst:.2e}")
+    assert worst <= 1e-4, worst
