@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--timing-stride", type=int, default=5,
+    ap.add_argument("--timing-stride", type=int, default=10,
                     help="bracket every n-th launch of each kernel class with HIP events (1 = all; each pair costs ~5 us)")
     ap.add_argument("--graph", action="store_true", help="replay the launch sequence from a HIP graph (implies --no-kernel-timing)")
     ap.add_argument("--eval", action="store_true",
