@@ -67,6 +67,8 @@ def build(config_setting, config_hyperparams, device, rank=0, world_size=1):
     optimizer = torch.optim.Adam(model.parameters(), lr=optimizer_params["learning_rate"])
     trainer = Trainer(device=device)
     trainer_params = dict(trainer_params)
+    # optional extension key: replay each generic-route training step from one HIP graph (Trainer.use_step_graph)
+    trainer.use_step_graph = bool(trainer_params.get("use_step_graph", False))
     trainer_params["base_dir"] = trainer_params.get("base_dir", "saved_models")
     trainer_params["save_model_folders"] = [trainer.get_year_month_day(), nn_params["name"]]
     trainer_params["save_model_filename"] = trainer.get_time_stamp()

@@ -115,6 +115,12 @@ WORKLOADS = {
              "serial_system 4 echelons, 16384 scenarios/GPU x T=100, vanilla_serial"),
     "cfg5": (lambda: many_warehouses(64, 3), _mlp("vanilla_warehouse", [512, 512, 512], None, 4), 32768, 70,
              "many_warehouses_lost_demand 3x64 stores, 32768 scenarios/GPU x T=70, vanilla_warehouse 512x3"),
+    # closed-form policy on the generic route (base_stock.yml): one trainable level, everything else arithmetic
+    "base_stock": (lambda: one_store(False, False),
+                   {"name": "base_stock", "inner_layer_activations": {"master": None},
+                    "output_layer_activation": {"master": "softplus"}, "neurons_per_hidden_layer": {"master": []},
+                    "output_sizes": {"master": 1}, "initial_bias": {"master": 10.0}}, 32768, 100,
+                   "one_store_backlogged + base_stock, 32768 scenarios x T=100 (generic route: Simulator.step + autograd)"),
     # the GNN policy on cfg3's graph (generic route: Simulator.step + autograd, MLPs on the matrix cores)
     "gnn": (lambda: one_warehouse(16), gnn_policy(), 8192, 50,
             "one_warehouse_lost_demand, 16 stores, 8192 scenarios x T=50, gnn (5 x 32-wide MLPs, 1 message-passing step)"),
