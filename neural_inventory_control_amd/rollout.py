@@ -412,9 +412,9 @@ class FusedRollout:
         if not self.use_graph or self.timer is not None or self._eager_runs < 1:
             return fn()
         variant = (self._round, self._ctx[4])  # options baked into the captured launch sequence (rounding, demand shift)
-        if self._graphs.get("_variant", variant) != variant:
+        if getattr(self, "_graph_variant", variant) != variant:
             self._graphs = {}
-        self._graphs["_variant"] = variant
+        self._graph_variant = variant
         g = self._graphs.get(name)
         if g is None:
             g = torch.cuda.CUDAGraph()
