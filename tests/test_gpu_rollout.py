@@ -14,7 +14,7 @@ import torch
 
 from golden_io import Golden, case_names
 from neural_inventory_control_amd import _lib
-from neural_inventory_control_amd.data_handling import DatasetCreator, DeviceBatches, Scenario
+from neural_inventory_control_amd.data_handling import DatasetCreator, DeviceBatches, MyDataset, Scenario
 from neural_inventory_control_amd.environment import Simulator
 from neural_inventory_control_amd.loss_functions import PolicyLoss
 from neural_inventory_control_amd.neural_networks import NeuralNetworkCreator
@@ -646,3 +646,40 @@ def test_gradient_parity_at_benchmark_width_and_horizon():
         worst = max(worst, float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30)))
     print(f"worst relative gradient error at 512x3, T=100, B=2048: {worst:.2e}")
     assert worst <= 1e-4, worst
+
+
+def test_trainer_epochs_with_step_graph_match_eager_training():
+    """Three epochs of `Trainer.do_one_epoch` on a closed-form policy (generic route), eager vs `use_step_graph`: the same
+    per-epoch losses and the same parameters after Adam."""
+    from neural_inventory_control_amd.environment import Simulator
+    from neural_inventory_control_amd.loss_functions import PolicyLoss
+    from neural_inventory_control_amd.trainer import Trainer
+    g = Golden("cfg2_one_store_backlogged_base_stock")
+    c = g.fresh_config()
+    ds = MyDataset(c["n"], {k: v.clone() for k, v in g.data.items()})
+
+    def train(graph):
+        torch.manual_seed(0)
+        model = _model(g, c)
+        sim = Simulator(device=DEV)
+        with torch.no_grad():
+            obs0, _ = sim.reset(c["periods"], c["problem_params"], {k: v.to(DEV) for k, v in g.data.items()},
+                                c["observation_params"])
+            o = dict(obs0)
+            o["internal_data"] = sim._internal_data
+            model(o)
+        _load(model, g)
+        opt = torch.optim.Adam(model.parameters(), lr=0.05)
+        tr = Trainer(device=DEV)
+        tr.use_step_graph = graph
+        loader = DeviceBatches(ds, 20, shuffle=False, device=DEV)
+        losses = [tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, c["periods"], c["problem_params"],
+                                  c["observation_params"], train=True, ignore_periods=c["ignore"])[1] for _ in range(3)]
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    (le, pe), (lg, pg) = train(False), train(True)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 1e-6 * abs(a)
+    for a, b in zip(pe, pg):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    assert le[-1] < le[0]  # and it learns
