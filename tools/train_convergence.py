@@ -1,0 +1,58 @@
+"""End-to-end convergence check on the MI355X: the reference's headline experiment for the one-store lost-sales setting
+(settings/one_store_lost.yml + policies_and_hyperparams/vanilla_one_store.yml: 32,768 train / dev scenarios, batch 8,192,
+T = 50 / 100, Adam lr 0.003), driven through `main_run.run`.  The reference ships the result of exactly this run as
+saved_models/2024_04_23/vanilla_one_store/1713902211.pt: best dev loss 6.854 at epoch 397 — the dev loss here should land
+in the same place (the demand traces are the same numpy stream: the dev set is bit-identical)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from neural_inventory_control_amd import main_run, workloads  # noqa: E402
+
+
+def configs(epochs):
+    setting, policy, _, _, _ = workloads.get("cfg1")
+    setting["test_seeds"] = {"underage_cost": 36, "holding_cost": 81, "mean": 41, "coef_of_var": 100, "lead_time": 49,
+                             "demand": 65, "initial_inventory": 4847}
+    setting["sample_data_params"] = {"split_by_period": False}
+    setting["params_by_dataset"] = {
+        "train": {"n_samples": 32768, "batch_size": 8192, "periods": 50, "ignore_periods": 30},
+        "dev": {"n_samples": 32768, "batch_size": 32768, "periods": 100, "ignore_periods": 60},
+        "test": {"n_samples": 32768, "batch_size": 32768, "periods": 5000, "ignore_periods": 3000}}
+    hyper = {"trainer_params": {"epochs": epochs, "do_dev_every_n_epochs": 10, "early_stopping_patience_epochs": 500,
+                                "print_results_every_n_epochs": 50, "save_model": False, "load_previous_model": False,
+                                "load_model_path": None, "choose_best_model_on": "dev_loss", "epochs_between_save": 10},
+             "optimizer_params": {"learning_rate": 0.003}, "nn_params": policy}
+    return setting, hyper
+
+
+def main():
+    epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    setting, hyper = configs(epochs)
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    c = main_run.build(setting, hyper, "cuda:0")
+    t_build = time.perf_counter() - t0
+    tr = c["trainer"]
+    t0 = time.perf_counter()
+    tr.train(epochs, c["loss_function"], c["simulator"], c["model"], c["data_loaders"], c["optimizer"], c["problem_params"],
+             c["observation_params"], c["params_by_dataset"], c["trainer_params"])
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, test_loss = tr.test(c["loss_function"], c["simulator"], c["model"], c["data_loaders"], c["optimizer"],
+                           c["problem_params"], c["observation_params"], c["params_by_dataset"], discrete_allocation=True)
+    torch.cuda.synchronize()
+    t_test = time.perf_counter() - t0
+    print(json.dumps({"epochs": epochs, "best_dev_loss": tr.best_performance_data["dev_loss"], "best_epoch": tr.best_epoch + 1,
+                      "test_loss_T5000_discrete": test_loss, "reference_checkpoint_best_dev_loss": 6.854347610473633,
+                      "seconds": {"build_datasets": round(t_build, 2), "train": round(t_train, 2), "test": round(t_test, 2)},
+                      "dev_losses_every_10_epochs": [round(x, 4) for x in tr.all_dev_losses[::10]][:60]}))
+
+
+if __name__ == "__main__":
+    main()
