@@ -1,0 +1,31 @@
+"""Scenario-sharded training on the device: two ranks (sharing the one GPU of the test box; collectives over gloo, kernels
+on HIP) must train to the same parameters as one process — DeviceBatches slices every global batch by rank, each rank
+scales by the GLOBAL batch, one flat all-reduce per optimizer step.  The CPU suite covers the collective and
+sharding logic (test_distributed_gloo.py); this covers it around the real kernels."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(cmd, extra_env=None):
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=os.path.dirname(HERE))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("DDP_RESULT ")][-1]
+    return json.loads(line[len("DDP_RESULT "):])
+
+
+def test_two_rank_training_equals_single_process():
+    helper = os.path.join(HERE, "ddp_helper.py")
+    single = _run([sys.executable, helper])
+    double = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                   "127.0.0.1", "--master-port", "29541", helper], {"NIC_DIST_BACKEND": "gloo"})
+    assert single["world"] == 1 and double["world"] == 2
+    assert abs(single["test_loss"] - double["test_loss"]) <= 1e-6 * abs(single["test_loss"]), (single, double)
