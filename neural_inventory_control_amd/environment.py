@@ -12,7 +12,7 @@ Differences that are deliberate and invisible to callers:
 import torch
 
 from . import _lib, ops
-from .layout import EnvProblem, Table, pad_ld, ref_view, to_soa
+from .layout import EnvProblem, ProblemCache, Table, pad_ld, ref_view, to_soa
 from .ops import EnvState
 
 
@@ -135,24 +135,12 @@ class Simulator:
         self.maximize_profit = problem_params["maximize_profit"]
         return self.observation, None
 
-    _STATIC_KEYS = ("underage_costs", "holding_costs", "lead_times", "warehouse_holding_costs", "warehouse_lead_times",
-                    "warehouse_edge_costs", "echelon_holding_costs", "echelon_lead_times")
-
     def _problem_for(self, problem_params, data, dev):
-        """EnvProblem of a batch.  Building one checks the static tables for scenario-uniformity, which reads a flag back
-        from the device; batches that present the SAME tensors again (same storage, shape, in-place version — the static
-        input buffers of a captured training step, or the fixed batches of an un-shuffled loader) reuse it, so a rollout
-        contains no host sync at all (a requirement for capturing it into a HIP graph)."""
-        key = (id(problem_params),) + tuple(
-            (k, data[k].data_ptr(), tuple(data[k].shape), tuple(data[k].stride()), data[k]._version)
-            for k in self._STATIC_KEYS if data.get(k) is not None)
-        cache = self.__dict__.setdefault("_prob_cache", {})
-        hit = cache.get(key)
-        if hit is None:
-            if len(cache) >= 16:
-                cache.pop(next(iter(cache)))
-            hit = cache[key] = EnvProblem(problem_params, data, dev)
-        return hit
+        """EnvProblem of a batch, cached per presented tensors (layout.ProblemCache: entries pin the tensors they were
+        keyed on), so a rollout over a batch seen before contains no host sync at all - a requirement for capturing it
+        into a HIP graph."""
+        cache = self.__dict__.setdefault("_prob_cache", ProblemCache())
+        return cache.get(problem_params, data, dev)
 
     # ---- step (environment.py:110-169) ------------------------------------------------------------------------
     def step(self, action):

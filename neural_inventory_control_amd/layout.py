@@ -158,3 +158,36 @@ class EnvProblem:
         io.wh_holding, io.wh_lead_times, io.wh_edge_costs = self.wh_holding.t2(), self.wh_lead.t2(), self.wh_edge.t2()
         io.ech_holding, io.ech_lead_times = self.ech_holding.t2(), self.ech_lead.t2()
         return io
+
+
+class ProblemCache:
+    """`EnvProblem`s of recently seen batches.  Building one compacts the static tables and checks them for
+    scenario-uniformity, which reads a flag back from the device (a sync); a batch that presents the SAME tensors again
+    (same storage, shape, strides and in-place version - every step of a benchmark, the fixed batches of an un-shuffled
+    loader, the static inputs of a captured training step) reuses its entry, so a rollout contains no host sync.
+
+    Each entry keeps STRONG references to the tensors its key was computed from: as long as the entry lives their storage
+    cannot be freed and handed to a later batch with the same address and version (which would be a false hit running the
+    step with another batch's cost / lead-time tables)."""
+
+    STATIC_KEYS = ("underage_costs", "holding_costs", "lead_times", "warehouse_holding_costs", "warehouse_lead_times",
+                   "warehouse_edge_costs", "echelon_holding_costs", "echelon_lead_times", "initial_inventories",
+                   "initial_warehouse_inventories", "initial_echelon_inventories")
+
+    def __init__(self, capacity=16):
+        self.capacity = capacity
+        self._entries = {}
+
+    def get(self, problem_params, data, device):
+        tensors = [(k, data[k]) for k in self.STATIC_KEYS if data.get(k) is not None]
+        # the initial pipelines only contribute their SHAPES to an EnvProblem (their values are re-read every reset)
+        key = (id(problem_params), bool(problem_params["lost_demand"]), bool(problem_params["maximize_profit"])) + tuple(
+            (k, tuple(t.shape)) if k.startswith("initial_") else (k, t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version)
+            for k, t in tensors)
+        hit = self._entries.get(key)
+        if hit is None:
+            if len(self._entries) >= self.capacity:
+                self._entries.pop(next(iter(self._entries)))
+            prob = EnvProblem(problem_params, data, device)
+            hit = self._entries[key] = (prob, [t for k, t in tensors if not k.startswith("initial_")], problem_params)
+        return hit[0]

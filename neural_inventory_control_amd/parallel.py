@@ -64,13 +64,13 @@ def all_reduce_scalars(*scalars):
 
 class GradientAllReducer:
     """Flat-buffer SUM all-reduce of every parameter gradient plus trailing scalars, once per optimizer step."""
-    _cache = {}
-
     @classmethod
     def get(cls, model):
-        r = cls._cache.get(id(model))
+        """One reducer per model, stored ON the model (a table keyed by id(model) would outlive the model and could hand a
+        new model at the same address another model's parameter list)."""
+        r = model.__dict__.get("_nic_grad_reducer")
         if r is None:
-            r = cls._cache[id(model)] = cls(model)
+            r = model.__dict__["_nic_grad_reducer"] = cls(model)
         return r
 
     def __init__(self, model):

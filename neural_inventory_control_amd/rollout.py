@@ -19,7 +19,7 @@ import torch
 
 from . import _lib, ops
 from . import small_rollout as sr
-from .layout import EnvProblem, Table, pad_ld
+from .layout import EnvProblem, ProblemCache, Table, pad_ld
 from .ops import EnvState
 
 _HEADS = {"vanilla_one_store": "softplus", "vanilla_warehouse": "warehouse", "vanilla_serial": "serial"}
@@ -94,7 +94,7 @@ class FusedRollout:
         self.batch_wgrad = True  # hidden-layer weight gradients contracted over all periods in one launch
         self.eval_history = None  # evaluation keeps per-period states/orders/logits: None = while small, True / False = forced
         self.small = None       # SmallRolloutPlan when the current shapes take that route
-        self._prob_cache = {}
+        self._prob_cache = ProblemCache()
         self._prob = None
 
     def _k(self, tag, fn, *args, **kw):
@@ -251,7 +251,7 @@ class FusedRollout:
 
     # ---- one batch ----------------------------------------------------------------------------------------------
     def run(self, data, periods, ignore_periods=0, train=True, observation_params=None, demand_soa=None,
-            grad_scale=None, accumulate_grads=False, discrete_allocation=False):
+            grad_scale=None, accumulate_grads=False, discrete_allocation=False, assign_grads=True):
         """Rollout of one batch (and, if `train`, d(mean_loss)/d(theta) into `param.grad`).
 
         data: the batch dict `Simulator.reset` takes (device tensors).  demand_soa: optional [T][S][ldb] trace already
@@ -259,6 +259,7 @@ class FusedRollout:
         grad_scale: d(loss)/d(reward[b,t]); default 1/(B*T*S) = trainer.py:169.  Multi-GPU callers pass the GLOBAL B.
         discrete_allocation: orders rounded half-to-even between head and env step (trainer.py:201-202); evaluation only
         (torch.round has zero gradient, so a training step with it goes through the generic route).
+        assign_grads=False leaves `param.grad` alone; the gradients are then read with `param_grads()`.
         Returns (total, reported) as 0-d device tensors = simulate_batch's return values (trainer.py:216).
         """
         if discrete_allocation and train:
@@ -294,7 +295,7 @@ class FusedRollout:
 
         if self.small is not None:
             return self._run_small(data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale,
-                                   accumulate_grads)
+                                   accumulate_grads, assign_grads)
 
         # engine copies of the weights (tiny) — refreshed every call because the optimizer moves them
         lins = self._linears()
@@ -337,35 +338,33 @@ class FusedRollout:
             self._graphs.pop("bwd", None)  # a captured launch sequence no longer applies
         self._replay_or_capture("bwd", self._launch_backward)
         self._eager_runs += 1
-        for i, m in enumerate(lins):
-            for p, g in ((m.weight, self.gw[i]), (m.bias, self.gb[i])):
-                if p is None:
-                    continue
-                if accumulate_grads and p.grad is not None and p.grad is not g:
-                    p.grad.add_(g)
-                else:
-                    p.grad = g
+        if assign_grads:
+            self._assign_grads(accumulate_grads)
         return total, reported
 
-    _STATIC_KEYS = ("underage_costs", "holding_costs", "lead_times", "warehouse_holding_costs", "warehouse_lead_times",
-                    "warehouse_edge_costs", "echelon_holding_costs", "echelon_lead_times", "initial_inventories",
-                    "initial_warehouse_inventories", "initial_echelon_inventories")
+    def param_grads(self):
+        """[(parameter, gradient buffer of the last training run)] - engine-owned buffers, overwritten by the next run."""
+        out = []
+        for i, m in enumerate(self._linears()):
+            out.append((m.weight, self.gw[i]))
+            if m.bias is not None:
+                out.append((m.bias, self.gb[i]))
+        return out
+
+    def _assign_grads(self, accumulate):
+        for p, g in self.param_grads():
+            if accumulate and p.grad is not None and p.grad is not g:
+                p.grad.add_(g)
+            else:
+                p.grad = g
 
     def _problem_for(self, data):
-        """EnvProblem of a batch.  Building one compacts the static tables and checks them for scenario-uniformity, which
-        reads a flag back from the device (a sync); batches that present the SAME tensors again (same storage, shape and
-        in-place version — e.g. every step of a benchmark, or the fixed batches of an un-shuffled loader) reuse it."""
-        key = tuple((k, data[k].data_ptr(), tuple(data[k].shape), tuple(data[k].stride()), data[k]._version)
-                    for k in self._STATIC_KEYS if k in data and data[k] is not None)
-        hit = self._prob_cache.get(key)
-        if hit is None:
-            if len(self._prob_cache) >= 16:
-                self._prob_cache.pop(next(iter(self._prob_cache)))
-            hit = self._prob_cache[key] = EnvProblem(self.problem_params, data, self.device)
-        return hit
+        """EnvProblem of a batch (cached per presented tensors, see layout.ProblemCache)."""
+        return self._prob_cache.get(self.problem_params, data, self.device)
 
     # ---- whole-horizon route for the small policies -------------------------------------------------------------------
-    def _run_small(self, data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale, accumulate_grads):
+    def _run_small(self, data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale, accumulate_grads,
+                   assign_grads=True):
         plan, lins = self.small, self._linears()
         sr.pack_weights(lins, self.sr_weights)
         s0 = self._views(self.sr_state0, prob)
@@ -375,7 +374,7 @@ class FusedRollout:
         if prob.E:
             s0.ech[:, :, :B].copy_(data["initial_echelon_inventories"].permute(1, 2, 0))
         ub = self._ub() if self.head != "softplus" else 0.0
-        desc = plan.desc(T, shift, self.sr_weights, demand_soa, self.sr_state0, ub, round_orders=self._round)
+        desc = plan.desc(T, shift, self.sr_weights, demand_soa, self.sr_state0, ub, round_orders=self._round, prob=prob)
         hist = (self.sr_states, self.sr_hidden, self.sr_logits) if train else (None, None, None)
         self._k("small_rollout_fwd", sr.small_rollout_fwd, desc, self.rewards, self.sr_final, *hist)
         total = self.rewards.sum()
@@ -396,11 +395,8 @@ class FusedRollout:
             dy, x = dzs[i].reshape(dzs[i].shape[0], n_cols), inputs[i].reshape(inputs[i].shape[0], n_cols)
             self._k(f"wgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad, dy, x, self.slabs[i], n_cols)
             ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], self.dims[i], 1.0)
-            for p, g in ((m.weight, self.gw[i]), (m.bias, self.gb[i])):
-                if accumulate_grads and p.grad is not None and p.grad is not g:
-                    p.grad.add_(g)
-                else:
-                    p.grad = g
+        if assign_grads:
+            self._assign_grads(accumulate_grads)
         return total, reported
 
     # ---- launch sequences (eager, or captured once into a HIP graph and replayed) ---------------------------------

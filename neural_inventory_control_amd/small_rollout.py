@@ -60,9 +60,10 @@ class SmallRolloutPlan:
                 and 1 <= n_hidden <= 3 and all(w == H for w in dims[1:-1]) and dims[-1] <= _lib.NIC_SR_MAX_OUTPUTS
                 and (head != "softplus" or dims[-1] == 1) and (head != "serial" or dims[-1] == prob.E + 2))
 
-    def desc(self, T, t0, weights, demand_soa, state0, upper_bound, round_orders=False):
-        """demand_soa: [T_total][1][ldb]; state0: [F][ldb]."""
-        p = self.prob
+    def desc(self, T, t0, weights, demand_soa, state0, upper_bound, round_orders=False, prob=None):
+        """demand_soa: [T_total][1][ldb]; state0: [F][ldb]; prob: the CURRENT batch's EnvProblem (same shapes as the
+        plan's; its cost / lead-time tables are the ones the kernels read)."""
+        p = prob if prob is not None else self.prob
         d = NicSmallRolloutDesc()
         d.n_scenarios, d.ldb, d.T, d.t0 = p.B, p.ldb, T, t0
         d.F, d.n_hidden, d.n_out = self.F, self.n_hidden, self.n_out
@@ -78,7 +79,7 @@ class SmallRolloutPlan:
         d.lead = NicTable2(_lib.ptr(lead.tensor), lead.loc_stride, lead.scn_stride)
         d.wh_holding, d.wh_lead, d.wh_edge = p.wh_holding.t2(), p.wh_lead.t2(), p.wh_edge.t2()
         d.ech_holding, d.ech_lead = p.ech_holding.t2(), p.ech_lead.t2()
-        self._keep = (weights, demand_soa, state0)
+        self._keep = (weights, demand_soa, state0, p)
         return d
 
 

@@ -17,7 +17,23 @@ import numpy as np
 import torch
 
 from . import parallel
+from .loss_functions import PolicyLoss
 from .rollout import FusedRollout
+
+
+class _FusedTotal(torch.autograd.Function):
+    """Makes the fused rollout's total cost a differentiable function of the policy parameters for callers that use the
+    reference idiom `total, _ = trainer.simulate_batch(...); (total / n).backward()` (trainer.py:160-173): the engine has
+    already computed d(total)/d(theta) in its own backward sweep; autograd only scales and accumulates it."""
+
+    @staticmethod
+    def forward(ctx, total, n_params, *grads_and_params):
+        ctx.save_for_backward(*grads_and_params[:n_params])
+        return total.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + (None,) * len(ctx.saved_tensors) + tuple(g * d for d in ctx.saved_tensors)
 
 
 class Trainer:
@@ -98,23 +114,23 @@ class Trainer:
                 elif train:
                     optimizer.zero_grad(set_to_none=False)  # captured steps accumulate into fixed .grad tensors
                 self._fused_grads_ready = False
-                self._train_mode = train and model.trainable
+                train_now = bool(train and model.trainable)
                 # every rank normalises by the GLOBAL batch (trainer.py:169 with B summed over ranks)
-                self._global_batch = getattr(data_loader, "last_global_batch", None) or len(data_batch["demands"]) * world
+                global_batch = getattr(data_loader, "last_global_batch", None) or len(data_batch["demands"]) * world
                 graphed = (train and model.trainable and self.use_step_graph and not discrete_allocation
                            and not (self.use_fused_rollout and FusedRollout.supports(model)
                                     and self._plain_observation(observation_params)))
                 if graphed:
                     total_reward, reward_to_report = self._graphed_generic_step(
                         loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
-                        ignore_periods)
+                        ignore_periods, global_batch=global_batch)
                 else:
                     total_reward, reward_to_report = self.simulate_batch(
                         loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
-                        ignore_periods, discrete_allocation)
+                        ignore_periods, discrete_allocation, train=train_now, global_batch=global_batch)
                 if train and model.trainable:
                     if not self._fused_grads_ready:
-                        mean_loss = total_reward / (self._global_batch * periods * problem_params["n_stores"])
+                        mean_loss = total_reward / (global_batch * periods * problem_params["n_stores"])
                         mean_loss.backward()
                     if world > 1:
                         total_reward, reward_to_report = parallel.GradientAllReducer.get(model).all_reduce(
@@ -133,18 +149,31 @@ class Trainer:
                 epoch_report.item() / (total_samples * tracked * n_stores))
 
     def simulate_batch(self, loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
-                       ignore_periods=0, discrete_allocation=False):
-        """trainer.py:181-216."""
-        train = bool(getattr(self, "_train_mode", torch.is_grad_enabled() and model.trainable)) and torch.is_grad_enabled()
-        # (rounded actions have zero gradient: a training step with discrete allocation keeps the reference's generic route)
+                       ignore_periods=0, discrete_allocation=False, *, train=None, global_batch=None):
+        """trainer.py:181-216.  `train` / `global_batch` are passed by `do_one_epoch` (the engine then writes
+        d(mean_loss)/d(theta) straight into `param.grad`).  A DIRECT call (the reference's public API, e.g. from a notebook)
+        leaves them None: gradients are wanted iff autograd is recording and the policy is trainable, and the returned total
+        is a differentiable function of the parameters, so `(total / n).backward()` works as it does upstream."""
+        direct = train is None
+        if direct:
+            train = torch.is_grad_enabled() and bool(getattr(model, "trainable", True))
+        train = bool(train) and torch.is_grad_enabled()
+        # (rounded actions have zero gradient: a training step with discrete allocation keeps the reference's generic route;
+        # a custom loss module is honoured by the generic route - the fused engine implements PolicyLoss = reward.sum())
         if self.use_fused_rollout and not (discrete_allocation and train) and FusedRollout.supports(model) \
-                and self._plain_observation(observation_params):
+                and isinstance(loss_function, PolicyLoss) and self._plain_observation(observation_params):
             # one engine per (policy, training / evaluation): an epoch alternates a training pass and a dev pass with
             # different horizons and buffer needs, and re-sizing one engine back and forth would reallocate tens of GB
             eng = self._engines.get((id(model), train))
-            if eng is None:
+            if eng is None or eng.model is not model:  # (the engine holds the model, so its id cannot be recycled)
                 eng = self._engines[(id(model), train)] = FusedRollout(model, problem_params, self.device)
-            gb = getattr(self, "_global_batch", len(data_batch["demands"]))
+            if direct and train:
+                total, reported = eng.run(data_batch, periods, ignore_periods, train=True,
+                                          observation_params=observation_params, grad_scale=1.0, assign_grads=False)
+                pg = eng.param_grads()
+                total = _FusedTotal.apply(total, len(pg), *[g.clone() for _, g in pg], *[p for p, _ in pg])
+                return total, reported
+            gb = global_batch if global_batch is not None else len(data_batch["demands"])
             total, reported = eng.run(data_batch, periods, ignore_periods, train=train,
                                       observation_params=observation_params,
                                       grad_scale=1.0 / (gb * periods * problem_params["n_stores"]),
@@ -170,18 +199,22 @@ class Trainer:
         return batch_reward, reward_to_report
 
     def _graphed_generic_step(self, loss_function, simulator, model, periods, problem_params, data_batch,
-                              observation_params, ignore_periods):
+                              observation_params, ignore_periods, global_batch=None):
         """Forward + backward of one batch on the generic route, replayed from a HIP graph.  First call with a batch shape:
         eager (materialises lazy layers, compiles static policy state); second call: captured with the batch copied into
         static input tensors and gradients accumulating into static `.grad` tensors; afterwards: copy + replay."""
         key = (id(model), periods, ignore_periods,
                tuple((k, tuple(v.shape)) for k, v in sorted(data_batch.items()) if torch.is_tensor(v)))
         st = self._step_graphs.get(key)
-        scale = 1.0 / (self._global_batch * periods * problem_params["n_stores"])
+        if st is not None and st["model"] is not model:  # id(model) recycled after a garbage collection
+            st = None
+        if global_batch is None:
+            global_batch = getattr(self, "_global_batch", None) or len(data_batch["demands"])
+        scale = 1.0 / (global_batch * periods * problem_params["n_stores"])
         if st is None:  # eager warm-up run
-            self._step_graphs[key] = {"static": None}
+            self._step_graphs[key] = {"static": None, "model": model}
             total, rep = self.simulate_batch(loss_function, simulator, model, periods, problem_params, data_batch,
-                                             observation_params, ignore_periods, False)
+                                             observation_params, ignore_periods, False, train=True)
             (total * scale).backward()
             self._fused_grads_ready = True
             return total.detach(), rep.detach() if torch.is_tensor(rep) else rep
@@ -194,7 +227,7 @@ class Trainer:
             stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stream):  # one more eager run on the side stream (allocator / autograd warm-up)
                 total, rep = self.simulate_batch(loss_function, simulator, model, periods, problem_params, static,
-                                                 observation_params, ignore_periods, False)
+                                                 observation_params, ignore_periods, False, train=True)
                 (total * scale).backward()
             torch.cuda.current_stream().wait_stream(stream)
             graph = torch.cuda.CUDAGraph()
@@ -202,12 +235,23 @@ class Trainer:
                 for p in params:
                     p.grad.zero_()
                 total, rep = self.simulate_batch(loss_function, simulator, model, periods, problem_params, static,
-                                                 observation_params, ignore_periods, False)
+                                                 observation_params, ignore_periods, False, train=True)
                 (total * scale).backward()
                 out_total, out_rep = total.detach(), (rep.detach() if torch.is_tensor(rep) else rep)
-            st.update(static=static, graph=graph, total=out_total, rep=out_rep, scale=scale)
+            # the captured env-step launches read the compact cost / lead-time tables of THIS EnvProblem (built from
+            # `static` at capture time), not `static` itself: they are refreshed from every incoming batch below
+            st.update(static=static, graph=graph, total=out_total, rep=out_rep, scale=scale, prob=simulator._prob)
         if st["scale"] != scale:
             raise RuntimeError("captured training step: the global batch size changed; disable use_step_graph")
+        incoming = simulator._problem_for(problem_params, {k: v for k, v in data_batch.items() if torch.is_tensor(v)},
+                                          torch.device(self.device))
+        if incoming is not st["prob"]:
+            if not st["prob"].same_layout(incoming):
+                # e.g. the captured batch had scenario-uniform tables and this one varies across samples: re-capture
+                del self._step_graphs[key]
+                return self._graphed_generic_step(loss_function, simulator, model, periods, problem_params, data_batch,
+                                                  observation_params, ignore_periods, global_batch=global_batch)
+            st["prob"].copy_tables_from(incoming)
         for k, v in data_batch.items():
             if torch.is_tensor(v):
                 st["static"][k].copy_(v)

@@ -312,14 +312,17 @@ class OraclePolicy:
         return [t for wb in self.layers for t in wb]
 
 
-def policy_from_state_dict(nn_params, state_dict, problem_params=None, warehouse_upper_bound=None):
+def policy_from_state_dict(nn_params, state_dict, problem_params=None, warehouse_upper_bound=None, dtype=torch.float32):
     """Builds an OraclePolicy from reference-format keys `net.master.<i>.weight/bias`
-    (layout produced by neural_networks.py:80-106)."""
+    (layout produced by neural_networks.py:80-106).  dtype=torch.float64 (with float64 data) gives the fp64 REFEREE the
+    gradient-parity tests measure both the reference's float32 arithmetic and the HIP engine against."""
     if nn_params["name"] == "gnn":
         return gnn_from_state_dict(nn_params, state_dict, problem_params)
     idx = sorted({int(k.split(".")[2]) for k in state_dict if k.startswith("net.master.")})
-    layers = [(state_dict[f"net.master.{i}.weight"].detach().clone().float().requires_grad_(True),
-               state_dict[f"net.master.{i}.bias"].detach().clone().float().requires_grad_(True)) for i in idx]
+    layers = [(state_dict[f"net.master.{i}.weight"].detach().clone().to(dtype).requires_grad_(True),
+               state_dict[f"net.master.{i}.bias"].detach().clone().to(dtype).requires_grad_(True)) for i in idx]
+    if warehouse_upper_bound is not None:
+        warehouse_upper_bound = warehouse_upper_bound.to(dtype)
     return OraclePolicy(
         name=nn_params["name"], layers=layers,
         inner_activation=nn_params["inner_layer_activations"]["master"],
@@ -371,6 +374,11 @@ def init_policy(nn_params, problem_params, in_features, generator_seed, store_pa
                         problem_params.get("warehouse_store_adjacency"), nn_params.get("transshipment", False))
 
 
+def _zero_input(pol: OraclePolicy):
+    """The constant scalar 0 the closed-form policies feed their one-layer 'net' (neural_networks.py:228)."""
+    return torch.zeros(1, dtype=pol.layers[0][0].dtype)
+
+
 def _mlp(pol: OraclePolicy, x):
     """Sequential(Linear, act, ..., Linear[, out_act]).  neural_networks.py:80-106."""
     n = len(pol.layers)
@@ -408,18 +416,18 @@ def policy_act(pol: OraclePolicy, obs: Dict[str, torch.Tensor]) -> Dict[str, tor
 
     if name == "base_stock":  # :221-229
         pos = obs["store_inventories"].sum(dim=2)
-        level = _mlp(pol, torch.tensor([0.0]))
+        level = _mlp(pol, _zero_input(pol))
         return {"stores": torch.clip(level - pos, min=0).unsqueeze(2)}
 
     if name == "capped_base_stock":  # :301-311
         pos = obs["store_inventories"].sum(dim=2)
-        out = _mlp(pol, torch.tensor([0.0]))
-        return {"stores": torch.clip(out[0] - pos, min=torch.tensor([0.0]), max=out[1]).unsqueeze(2)}
+        out = _mlp(pol, _zero_input(pol))
+        return {"stores": torch.clip(out[0] - pos, min=_zero_input(pol), max=out[1]).unsqueeze(2)}
 
     if name == "echelon_stock":  # :236-294
         s_inv, w_inv, e_inv = obs["store_inventories"], obs["warehouse_inventories"], obs["echelon_inventories"]
         E = e_inv.size(1)
-        x = F.softplus(_mlp(pol, torch.tensor([0.0])) + 10.0)
+        x = F.softplus(_mlp(pol, _zero_input(pol)) + 10.0)
         levels = torch.cumsum(x, dim=0).flip(dims=[0])
         pos = torch.concat((e_inv.sum(dim=2), w_inv.sum(dim=2), s_inv.sum(dim=2)), dim=1)
         upstream = torch.concat((1000000 * torch.ones_like(w_inv[:, :, 0]), e_inv[:, :, 0], w_inv[:, :, 0]), dim=1)

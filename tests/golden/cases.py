@@ -5,6 +5,22 @@ Each case names a reference setting + policy YAML, the overrides applied to them
 five configurations scaled down to sizes the CPU finishes in well under a second.
 """
 
+
+def _cfg5_3x64():
+    """BASELINE cfg5's real topology: the [3][64] adjacency and [64][3] lead-time matrix (lead times 1..6, 0 = not
+    connected) that bench.py's `cfg5` workload uses (`workloads.many_warehouses(64, 3)`), in the reference's YAML format."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from neural_inventory_control_amd import workloads
+    s = workloads.many_warehouses(64, 3)
+    return s["problem_params"]["warehouse_store_adjacency"], s["store_params"]["lead_time"]["value"]
+
+
+_ADJ64, _LEAD64 = _cfg5_3x64()
+
 CASES = {
     # cfg1: one_store_lost + vanilla_one_store (Poisson demand, lost sales)
     "cfg1_one_store_lost_vanilla": dict(
@@ -44,6 +60,15 @@ CASES = {
         store_overrides={"lead_time": {"sample_across_stores": False, "vary_across_samples": False, "expand": True,
                                        "value": [[2, 0, 3], [1, 4, 0], [0, 2, 0], [0, 6, 1],
                                                  [3, 0, 0], [0, 0, 2], [5, 2, 0], [0, 1, 3]]}},
+        warehouse_overrides={"holding_cost": [0.3, 0.4, 0.2], "lead_time": 3, "edge_cost": [0.5, 1.5, 0.7]}),
+    # cfg5 at its REAL topology: 3 warehouses x 64 stores (16 stores per lane of the env / head kernels' quad walk, Ws = 6,
+    # the 3-warehouse shipment exchange and the 195-row logits layer), small hidden width and batch
+    "cfg5_many_warehouses_3x64_vanilla": dict(
+        setting="many_warehouses_lost_demand", policy="vanilla_warehouse", n=16, periods=10, ignore=3, torch_seed=24,
+        hidden=[64, 64],
+        problem_overrides={"n_stores": 64, "n_warehouses": 3, "warehouse_store_adjacency": _ADJ64},
+        store_overrides={"lead_time": {"sample_across_stores": False, "vary_across_samples": False, "expand": True,
+                                       "value": _LEAD64}},
         warehouse_overrides={"holding_cost": [0.3, 0.4, 0.2], "lead_time": 3, "edge_cost": [0.5, 1.5, 0.7]}),
     # the reference's transshipment setting (backlogged demand, warehouse that cannot hold stock: the softmax head has no
     # 'keep' column) + its vanilla_transshipment policy file (VanillaWarehouse with transshipment: True)

@@ -308,7 +308,13 @@ def check_serial_head(be, E):
     torch.testing.assert_close(ref_view(gei, B).cpu(), ech.grad, rtol=3e-5, atol=1e-6)
 
 
+def _cfg5_adjacency():
+    from cases import CASES
+    return CASES["cfg5_many_warehouses_3x64_vanilla"]["problem_overrides"]["warehouse_store_adjacency"]
+
+
 WAREHOUSE_HEAD_CASES = [
+    (64, 3, _cfg5_adjacency()),  # BASELINE cfg5's real topology: 16 stores per lane of the quad, 195 logit rows
     (16, 1, None),
     (10, 2, [[0, 0, 1, 1, 1, 0, 1, 1, 1, 0], [1, 1, 1, 1, 1, 1, 0, 1, 1, 1]]),
     (8, 3, [[1, 1, 0, 0, 1, 0, 1, 0], [0, 1, 1, 1, 0, 0, 1, 1], [1, 0, 0, 1, 0, 1, 0, 1]]),

@@ -27,13 +27,25 @@ DEV = "cuda:0"
 # than the CPU reference) is amplified by the recurrence; costs stay within 1e-5, individual pipeline slots within 1e-4
 STATE_TOL = dict(rtol=1e-4, atol=2e-3)
 MLP_CASES = [n for n in case_names() if n.endswith("vanilla")]
-# random-init softmax heads saturate late in the horizon, which puts warehouse on-hand (stock - sum of shares) within
-# float noise of zero: the `>= 0` mask of its holding cost then flips with summation order ("knife
-# edges").  Gradients of those configurations are compared with a looser bound; costs are unaffected.
-GRAD_TOL = {"cfg5_many_warehouses_2x10_vanilla": 5e-3, "cfg5_many_warehouses_3x8_vanilla": 5e-3,
-            "cfg3_one_warehouse_16_vanilla": 2e-4, "cfg3_one_warehouse_5_vanilla": 2e-4,
-            # GNN: batched incidence-matrix aggregation associates sums differently from upstream's edge loops
-            "f1_one_warehouse_gnn": 2e-4, "f1_one_warehouse_16_gnn": 2e-4}
+# Gradient bar: d(mean_loss)/d(theta) per parameter tensor within 2e-5 relative L2 of the reference's golden gradient for EVERY
+# configuration (measured on MI355X: <= 1.3e-6 on all fixtures, the 3-warehouse x 64-store one included).  Nothing is
+# widened per case; where the two sides sum 10^5 fp32 terms per weight in different orders (benchmark width and horizon)
+# the criterion is the fp64 referee below instead of a wider band.
+GRAD_TOL = 2e-5
+
+
+def _fp64_referee_grads(c_nn, params, problem_params, ub, periods, data, obs, ignore=0):
+    """d(mean_loss)/d(theta) of the SAME inputs and weights evaluated by the oracle in float64: the yard-stick both the
+    reference's float32 arithmetic and the HIP engine are measured against."""
+    from oracle import inventory_oracle as orc
+    pol = orc.policy_from_state_dict(c_nn, params, problem_params, ub, dtype=torch.float64)
+    d64 = {k: v.double() for k, v in data.items()}
+    _, _, g64 = orc.train_step_gradients(pol, periods, problem_params, d64, obs, ignore)
+    return g64
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
 def _model(g, c, scenario=None):
@@ -95,10 +107,23 @@ def test_fused_rollout_matches_reference(name):
     final = eng.final_state()
     for k, v in g.states(c["periods"]).items():
         torch.testing.assert_close(final[k].cpu(), v, **STATE_TOL)
-    _check_grads(model, g, GRAD_TOL.get(name, 2e-5))
+    _check_grads(model, g, GRAD_TOL)
     # evaluation mode (no activations kept) gives the same costs
     t2, r2 = eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"])
     assert float(t2) == float(total) and float(r2) == float(reported)
+
+
+@pytest.mark.parametrize("name", MLP_CASES)
+def test_hybrid_host_sweep_on_device(name):
+    """tests/host_rollout.py on the device: the HIP env-step and head kernels (through the C ABI) composed in the engine's
+    sweep order with torch matmuls instead of the MFMA GEMMs — isolates the adjoint of the kernel composition from GEMM
+    summation order.  Same bars as the CPU run of the harness (tests/test_host_rollout.py)."""
+    import kernel_checks as kc
+    from test_host_rollout import run_case
+    g, c, out, worst = run_case(kc.HipBackend(), name)
+    assert abs(float(out["total"]) - float(g.z["total"])) <= 1e-6 * abs(float(g.z["total"]))
+    torch.testing.assert_close(out["rewards"].cpu(), g.tensor("rewards"), rtol=2e-6, atol=1e-5)
+    assert worst <= 5e-6, worst
 
 
 @pytest.mark.parametrize("name", case_names())
@@ -126,7 +151,7 @@ def test_simulator_autograd_route_matches_reference(name):
     for k, v in g.states(c["periods"]).items():
         torch.testing.assert_close(sim.observation[k].cpu(), v, **STATE_TOL)
     assert int(sim.observation["current_period"]) == c["periods"]
-    _check_grads(model, g, GRAD_TOL.get(name, 2e-5))
+    _check_grads(model, g, GRAD_TOL)
 
 
 @pytest.mark.parametrize("name", ["cfg1_one_store_lost_vanilla", "cfg3_one_warehouse_5_vanilla", "cfg4_serial_vanilla"])
@@ -425,9 +450,8 @@ def test_ragged_multi_block_batch_matches_oracle(name, B):
     tot_b = eng.per_period_rewards().sum(dim=0).cpu()
     ref_b = res.per_period.sum(dim=0)
     assert float(((tot_b - ref_b).abs() / ref_b.abs().clamp_min(1e-9)).max()) <= 1e-5
-    tol = max(GRAD_TOL.get(name, 2e-5), 1e-4)  # fresh demands may put a few more scenarios on a clamp knife edge
     for p, ref in zip(model.parameters(), grads):
-        assert float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30)) <= tol
+        assert _rel(p.grad, ref) <= GRAD_TOL
 
 
 # ---- evaluation (Trainer.test): forward only, discrete allocation, long horizons -----------------------
@@ -497,7 +521,9 @@ def test_long_horizon_evaluation_matches_oracle():
     assert abs(float(total) - float(res.total)) <= 1e-5 * abs(float(res.total))
     assert abs(float(reported) - float(res.reported)) <= 1e-5 * abs(float(res.reported))
     per_scn = (eng.per_period_rewards().sum(dim=0).cpu() - res.per_period.sum(dim=0)).abs() / res.per_period.sum(dim=0)
-    assert float((per_scn <= 1e-5).float().mean()) >= 0.99
+    frac = float((per_scn <= 1e-5).float().mean())
+    print(f"T=5000 discrete evaluation: {frac:.4f} of {B} scenarios within 1e-5 of the oracle; worst {float(per_scn.max()):.2e}")
+    assert frac >= 0.99, f"only {frac:.4f} of the scenarios within 1e-5 (worst {float(per_scn.max()):.2e})"
 
 
 def _one_store_yaml_dicts(tmp_path):
@@ -607,8 +633,9 @@ def test_captured_generic_training_step_matches_eager(name):
 def test_gradient_parity_at_benchmark_width_and_horizon():
     """BASELINE cfg3's network (512 x 3) and horizon (T = 100) on 2,048 scenarios: the HIP engine's training step — weight
     gradients contracted over all 100 periods x 2,048 scenarios in one fp32 accumulation — against the CPU oracle's autograd
-    on identical inputs and weights.  Bars: per-scenario total cost 1e-5 relative (north star); gradients 1e-4 relative L2
-    per tensor (the two sides sum ~200k fp32 terms per weight in different orders)."""
+    on identical inputs and weights.  Per-scenario total cost: 1e-5 relative (north star).  Gradients: each side sums ~200k
+    fp32 terms per weight in its own order, so the criterion is an fp64 REFEREE (the oracle evaluated in float64): per
+    parameter tensor the engine must be no further from it than twice the reference's own float32 arithmetic is."""
     from collections import defaultdict
     from neural_inventory_control_amd import workloads
     from neural_inventory_control_amd.neural_networks import NeuralNetworkCreator
@@ -622,6 +649,10 @@ def test_gradient_parity_at_benchmark_width_and_horizon():
     F = 16 * data["initial_inventories"].shape[2] + data["initial_warehouse_inventories"].shape[2]
     pol = orc.init_policy(policy, setting["problem_params"], F, 4321, setting["store_params"])
     res, _, grads = orc.train_step_gradients(pol, T, setting["problem_params"], data, obs)
+    pol64 = orc.OraclePolicy(pol.name, [(w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True))
+                                        for w, b in pol.layers], pol.inner_activation, pol.output_activation,
+                             pol.warehouse_upper_bound.double(), pol.adjacency, pol.transshipment)
+    _, _, g64 = orc.train_step_gradients(pol64, T, setting["problem_params"], {k: v.double() for k, v in data.items()}, obs)
 
     class _Sc:
         problem_params = setting["problem_params"]
@@ -641,11 +672,10 @@ def test_gradient_parity_at_benchmark_width_and_horizon():
     per_scn = eng.per_period_rewards().sum(dim=0).cpu()
     ref_scn = res.per_period.sum(dim=0)
     assert float(((per_scn - ref_scn).abs() / ref_scn.abs().clamp_min(1e-9)).max()) <= 1e-5
-    worst = 0.0
-    for p, ref in zip(model.parameters(), grads):
-        worst = max(worst, float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30)))
-    print(f"worst relative gradient error at 512x3, T=100, B=2048: {worst:.2e}")
-    assert worst <= 1e-4, worst
+    for i, (p, ref32, ref64) in enumerate(zip(model.parameters(), grads, g64)):
+        e_hip, e_ref = _rel(p.grad, ref64), _rel(ref32, ref64)
+        print(f"tensor {i}: |HIP - fp64| = {e_hip:.2e}   |reference fp32 - fp64| = {e_ref:.2e}   |HIP - fp32| = {_rel(p.grad, ref32):.2e}")
+        assert e_hip <= 2.0 * e_ref, (i, e_hip, e_ref)
 
 
 def test_trainer_epochs_with_step_graph_match_eager_training():
