@@ -5,14 +5,23 @@ on synthetic demand, BASELINE.json's metric: scenario-steps/s = scenarios x n_st
 
     python bench.py --gpus N --steps K --warmup W [--workload cfg3]
 
-N = 1: plain process.  N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, one
-rank per GPU; scenarios are sharded (weak scaling: 65,536 scenarios PER GPU for cfg3), one RCCL all-reduce of the flat
-gradient per step.  Rank 0 prints ONE JSON line.  Inputs (demand traces from the HIP Philox sampler, initial state,
-weights) are resident in HBM before the timed region.
+N = 1: this process.  N > 1 with no RANK in the environment: this process starts N fresh ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, one rank per GPU) BEFORE touching the GPU,
+relays rank 0's JSON line and exits with the job's code; it refuses (non-zero exit, no JSON line) when fewer than N GPUs are
+visible.  Under torchrun (RANK set) each rank runs its shard: scenarios are sharded (weak scaling: 65,536 scenarios PER GPU
+for cfg3), one RCCL all-reduce of the flat gradient per step.  Rank 0 prints ONE JSON line.  Inputs (demand traces from the
+HIP Philox sampler, initial state, weights) are resident in HBM before the timed region.
+
+The JSON line carries `roofline` for the kernel class with the largest total time in the step (its name is what the C ABI
+reported launching, `nic_last_kernel()`; `bound` is "mfma" for the 512-wide policy GEMMs and "hbm" for everything else,
+with the algorithmic bytes / flops per launch defined in `algorithmic_work`), `kernels` with the same figures for every
+class, `roofline_env_step` for the env-step kernel, and `cpu_baseline` (the oracle timed on this host's cores).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -22,9 +31,37 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X dense FP32 matrix peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0         # HBM3E (MI355X_MICROARCH.md)
 
 
-def build_case(workload, device, rank, scenarios=None, periods=None):
+# ---- N > 1 without a launcher: start the ranks ourselves ---------------------------------------------------------------
+def spawn_ranks(n_gpus, argv):
+    """Parent of a multi-GPU run.  Decided before any HIP call (device_count() does not initialise the GPU on this image);
+    the parent never touches the GPU, only waits and relays."""
+    visible = torch.cuda.device_count()
+    if visible < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} requested but only {visible} GPU(s) visible; refusing to report a "
+              f"{visible or 1}-rank number as a {n_gpus}-GPU result", file=sys.stderr)
+        return 2
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(proc.stdout[-4000:])
+        print(f"bench.py: the {n_gpus}-rank job failed (rc {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    print(lines[-1])
+    return 0
+
+
+def build_case(workload, device, rank, world, scenarios=None, periods=None):
     from collections import defaultdict
     from neural_inventory_control_amd import workloads
     from neural_inventory_control_amd.data_handling import Scenario
@@ -35,25 +72,30 @@ def build_case(workload, device, rank, scenarios=None, periods=None):
         desc += f" [overridden: {scenarios or n} scenarios/GPU x T={periods or T}]"
     n, T = scenarios or n, periods or T
     obs = defaultdict(lambda: None, setting["observation_params"])
+    # each rank generates rows [rank*n, (rank+1)*n) of the (world*n)-scenario job; initial inventories use the GLOBAL demand mean
     sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"],
                   setting["echelon_params"], n, obs, setting["seeds"], sampler="hip", device=device,
-                  scenario_offset=rank * n)
+                  scenario_offset=rank * n, num_total=world * n)
     data = {k: v.to(device) for k, v in sc.get_data().items()}
-    torch.manual_seed(1234)  # identical initial weights on every rank
+    torch.manual_seed(1234)  # identical initial weights on every rank (and broadcast below when world > 1)
     model = NeuralNetworkCreator().create_neural_network(sc, policy, device=device)
     eng = FusedRollout(model, setting["problem_params"], device) if FusedRollout.supports(model) else None
     return setting, policy, sc, data, model, eng, n, T, desc
 
 
-def _pmc_traffic(kind, N, K, n_scenarios):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_traffic.json):
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH doubled (gfx950 reports half of a wide coalesced
-    read stream), both x1024 (KiB units).  None if no pass matches this kernel / shape."""
+def _pmc_traffic(kernel_name, n_scenarios):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*traffic*.json): FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc passes and corrected as the files' notes say.  None if no pass has this kernel
+    at this scenario count."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+    squash = lambda s: s.replace(" ", "")  # noqa: E731
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
         try:
-            for e in json.load(open(f)):
-                if e["kind"] == kind and e["N"] == N and e["K"] == K and e["n_scenarios"] == n_scenarios:
+            doc = json.load(open(f))
+            if not isinstance(doc, dict) or doc.get("n_scenarios") != n_scenarios:
+                continue
+            for e in doc.get("kernels", []):
+                if squash(e["kernel"]) == squash(kernel_name):
                     return {"bytes_per_launch": e["hbm_bytes_per_launch"], "source": os.path.basename(f)}
         except Exception:
             pass
@@ -77,14 +119,15 @@ def _pick_threads(avail):
     return best
 
 
-def cpu_baseline(workload, sample_scenarios, periods):
-    """The oracle (CPU restatement of the reference path, PyTorch eager) timed on this host's cores: one training step
-    (rollout + backward) of the same workload on a bounded sample of scenarios."""
+def cpu_baseline(workload, sample_scenarios, periods, reps=3):
+    """The oracle (CPU restatement of the reference path, PyTorch eager) timed on this host's cores: training steps
+    (rollout + backward) of the same workload on a bounded sample of scenarios; 1 warm-up + `reps` timed repetitions,
+    median."""
     from collections import defaultdict
     from neural_inventory_control_amd import workloads
     from oracle import inventory_oracle as orc
     # eager PyTorch on small tensors collapses when oversubscribed (256 threads on this path ran 40x slower than 8), so
-    # the thread count is calibrated on a short rollout and the best one is used and reported
+    # the thread count is calibrated on a short probe and the best one is used and reported as `cores`
     avail = os.cpu_count() or 1
     cores = _pick_threads(avail)
     torch.set_num_threads(cores)
@@ -93,20 +136,83 @@ def cpu_baseline(workload, sample_scenarios, periods):
     data = orc.generate_scenario_data(periods, setting["problem_params"], setting["store_params"],
                                       setting["warehouse_params"], setting["echelon_params"], sample_scenarios, obs,
                                       setting["seeds"])
-    S, Wn, E = (setting["problem_params"][k] for k in ("n_stores", "n_warehouses", "n_extra_echelons"))
+    S = setting["problem_params"]["n_stores"]
     F = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
     if policy["name"] != "vanilla_one_store":
         F += sum(data[k].shape[1] * data[k].shape[2] for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
                  if k in data)
+    if policy["name"] in ("base_stock", "capped_base_stock", "echelon_stock"):
+        F = 1  # closed-form policies: one Linear fed the constant 0 (neural_networks.py:228)
     pol = orc.init_policy(policy, setting["problem_params"], F, 1234, setting["store_params"])
     warm = {k: v[:max(8, sample_scenarios // 16)] for k, v in data.items()}
-    orc.train_step_gradients(pol, min(periods, 10), setting["problem_params"], warm, obs)
-    t0 = time.perf_counter()
-    orc.train_step_gradients(pol, periods, setting["problem_params"], data, obs)
-    dt = time.perf_counter() - t0
-    return {"value": sample_scenarios * S * periods / dt, "unit": "scenario-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (PyTorch-CPU eager restatement of the reference path), 1 training step fwd+bwd, "
-                      f"{sample_scenarios} scenarios x {S} stores x T={periods}, {cores} threads, {dt:.2f} s"}
+    orc.train_step_gradients(pol, min(periods, 10), setting["problem_params"], warm, obs)  # warm-up
+    times = []
+    while len(times) < reps or (sum(times) < 10.0 and len(times) < 25):  # >= 3 repetitions and ~10 s of CPU work
+        t0 = time.perf_counter()
+        orc.train_step_gradients(pol, periods, setting["problem_params"], data, obs)
+        times.append(time.perf_counter() - t0)
+        if sum(times) > 45.0:  # keep the default run within minutes on a slow host
+            break
+    dt = statistics.median(times)
+    return {"value": sample_scenarios * S * periods / dt, "unit": "scenario-steps/s", "cores": cores,
+            "host_cores": avail, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU eager restatement of the reference path), training step fwd+bwd on "
+                      f"{sample_scenarios} scenarios x {S} stores x T={periods}: 1 warm-up + {len(times)} timed repetitions, "
+                      f"median {dt:.3f} s (min {min(times):.3f}, max {max(times):.3f}), {cores} of {avail} host threads"}
+
+
+def algorithmic_work(tag, kernel, shape):
+    """(bound, amount per launch, unit) of one launch of a kernel class.  `shape`: n (scenarios), T, S, Wn, E, Ws, Ww, We, F (MLP
+    input rows), nh (hidden layers of the small route), n_out, train.  DESIGN.md §4 states the same formulas."""
+    n, T = shape["n"], shape["T"]
+    kind, _, dims = tag.partition("_")
+    if kind in ("fwd", "dgrad", "wgrad", "wgradT") and "x" in dims:
+        N, K = (int(v) for v in dims.split("x"))
+        cols = n * (T if kind == "wgradT" else 1)
+        if kernel.startswith("wgrad_small_kernel"):   # small route: one launch contracts over all T * ldb columns
+            return "hbm", 4.0 * (N + K) * n * T, "B"  # operands read once (dZ [N] + X [K] rows per column)
+        if max(N, K) <= 64:                           # 32-wide layers on the per-period route: operand streaming
+            return "hbm", 4.0 * (N + K) * cols, "B"
+        return "mfma", 2.0 * N * K * cols, "FLOP"
+    if tag.startswith("bwd_thin_"):
+        N, K = (int(v) for v in tag[len("bwd_thin_"):].split("x"))
+        return "hbm", 4.0 * (2 * K + N) * n, "B"      # layer input read once, input gradient written once, dY read
+    S, Wn, E = shape["S"], shape["Wn"], shape["E"]
+    f_state = S * shape["Ws"] + Wn * shape["Ww"] + E * shape["We"]
+    n_ord = S * max(Wn, 1) + Wn + E
+    if tag == "env_fwd":  # SURVEY §8d: state read + write, demand, orders, reward (static tables amortised over T)
+        return "hbm", 4.0 * (2 * f_state + S + n_ord + 1) * n, "B"
+    if tag == "env_bwd":  # state + orders + demand read, incoming state gradient read, state / order gradients written
+        return "hbm", 4.0 * (3 * f_state + S + 2 * n_ord) * n, "B"
+    hist = shape["F"] + 32 * shape["nh"] + shape["n_out"]
+    if tag == "small_rollout_fwd":  # demand in, reward out (+ the activation history when training)
+        return "hbm", 4.0 * (2 + (hist if shape["train"] else 0)) * n * T, "B"
+    if tag == "small_rollout_bwd":  # history + demand in, pre-activation gradients out
+        return "hbm", 4.0 * (1 + hist + 32 * shape["nh"] + shape["n_out"]) * n * T, "B"
+    if tag in ("closed_form_fwd", "closed_form_bwd"):  # whole-horizon closed-form policy: demand read (+ reward written)
+        return "hbm", 4.0 * (S + (1 if tag.endswith("fwd") else 0)) * n * T, "B"
+    return None
+
+
+def kernel_report(timer, shape, steps):
+    summ = timer.summary()
+    out = {}
+    for tag, (cnt, mean_ms) in summ.items():
+        name = timer.names.get(tag, "")
+        rec = {"kernel": name, "launches_per_step": cnt / steps, "launches_timed": len(timer.events[tag]),
+               "mean_ms": round(mean_ms, 5), "total_ms_per_step": round(cnt * mean_ms / steps, 4)}
+        w = algorithmic_work(tag, name, shape)
+        if w is not None:
+            bound, amount, unit = w
+            if bound == "mfma":
+                ach, peak, u = amount / mean_ms / 1e9, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+                rec["algorithmic_flops_per_launch"] = amount
+            else:
+                ach, peak, u = amount / (mean_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+                rec["algorithmic_bytes_per_launch"] = amount
+            rec.update(bound=bound, achieved=round(ach, 2), peak=peak, unit=u, frac=round(ach / peak, 4))
+        out[tag] = rec
+    return out
 
 
 def main():
@@ -120,23 +226,37 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--timing-stride", type=int, default=10,
-                    help="bracket every n-th launch of each kernel class with HIP events (1 = all; each pair costs ~5 us)")
+    ap.add_argument("--timing-stride", type=int, default=None,
+                    help="bracket every n-th launch of each kernel class with HIP events (default: 10 on the per-period route, "
+                         "1 on the whole-horizon route; each pair costs ~5 us)")
     ap.add_argument("--graph", action="store_true", help="replay the launch sequence from a HIP graph (implies --no-kernel-timing)")
     ap.add_argument("--eval", action="store_true",
                     help="SURVEY 8(f2): time the forward-only evaluation pass (Trainer.test: no gradients, discrete allocation "
                          "for Poisson demand) instead of a training step; use with --periods 5000 for the reference's test horizon")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     from neural_inventory_control_amd import _lib, parallel
     from neural_inventory_control_amd.rollout import KernelTimer
     rank, world, device = parallel.init_from_env()
     _lib.require_device()
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
 
-    setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, device, rank, args.scenarios, args.periods)
-    S = setting["problem_params"]["n_stores"]
+    setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, device, rank, world, args.scenarios,
+                                                                   args.periods)
+    pp = setting["problem_params"]
+    S = pp["n_stores"]
+    if eng is not None:  # materialise the lazy layers now so that replicas can be synchronised before the first step
+        F_in = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
+        if policy["name"] != "vanilla_one_store":
+            F_in += sum(data[k].shape[1] * data[k].shape[2]
+                        for k in ("initial_warehouse_inventories", "initial_echelon_inventories") if k in data)
+        eng.materialize(F_in)
+        parallel.broadcast_model(model, src=0)
     opt = torch.optim.Adam(model.parameters(), lr=3e-4)
     if args.graph and eng is not None:
         eng.use_graph = True
@@ -153,24 +273,22 @@ def main():
                                demand_soa=sc.demands_soa, discrete_allocation=discrete)
         return total
 
-    if eng is None:  # policies outside the fused engine (GNN, closed-form, user plugins): the reference-style loop
+    if eng is None:  # policies outside the fused engine (GNN, user plugins): the reference-style loop
         from neural_inventory_control_amd.environment import Simulator
         from neural_inventory_control_amd.loss_functions import PolicyLoss
         from neural_inventory_control_amd.trainer import Trainer
         sim, tr, loss_fn = Simulator(device=device), Trainer(device=device), PolicyLoss()
         args.no_kernel_timing = True
-
         tr._global_batch = global_b
 
         def generic_step():
             if args.graph:  # whole training step (all periods + autograd sweep) replayed from one HIP graph
                 opt.zero_grad(set_to_none=False)
-                total, _ = tr._graphed_generic_step(loss_fn, sim, model, T, setting["problem_params"], data,
-                                                    setting["observation_params"], 0)
+                total, _ = tr._graphed_generic_step(loss_fn, sim, model, T, pp, data, setting["observation_params"], 0,
+                                                    global_batch=global_b)
             else:
                 opt.zero_grad(set_to_none=True)
-                total, _ = tr.simulate_batch(loss_fn, sim, model, T, setting["problem_params"], data,
-                                             setting["observation_params"], 0, False)
+                total, _ = tr.simulate_batch(loss_fn, sim, model, T, pp, data, setting["observation_params"], 0, False)
                 (total * grad_scale).backward()
             if reducer is not None:
                 total, _ = reducer.all_reduce(total.detach(), total.detach())
@@ -195,9 +313,12 @@ def main():
 
     for _ in range(max(args.warmup, 0) + (2 if args.graph else 0)):  # graph mode: eager run + capture run before timing
         step()
+    if eng is None and args.warmup == 0:
+        step()  # lazy layers materialise on the first forward; keep that out of the timed region
     timer = None
     if not args.no_kernel_timing:
-        timer = eng.timer = KernelTimer(stride=args.timing_stride)
+        stride = args.timing_stride or (1 if (eng is not None and eng.small is not None) else 10)
+        timer = eng.timer = KernelTimer(stride=stride)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -227,69 +348,48 @@ def main():
                                            "; training step = rollout fwd + bwd + Adam" + (" + RCCL grad all-reduce" if world > 1 else "")),
                        "name": args.workload, "scenarios_per_gpu": n, "global_scenarios": global_b, "stores": S,
                        "periods": T, "parallelism": f"scenario-sharded dp{world}",
+                       "route": ("generic (Simulator.step + autograd)" if eng is None else
+                                 "whole-horizon kernels" if eng.small is not None else "per-period kernels"),
                        "mean_cost_per_store_period": loss},
         }
         if timer is not None:
-            summ = timer.summary()
-            dims = eng.dims
-            gemm = {}
-            for tag, (cnt, mean_ms) in summ.items():
-                kind, _, shape = tag.partition("_")
-                if kind in ("fwd", "dgrad", "wgrad", "wgradT") and "x" in shape:
-                    N_, K_ = (int(v) for v in shape.split("x"))
-                    flops = 2.0 * N_ * K_ * n * (T if kind == "wgradT" else 1)  # wgradT: all T periods in one launch
-                    gemm[tag] = {"launches": cnt, "mean_ms": mean_ms, "total_ms_per_step": cnt * mean_ms / args.steps,
-                                 "tflops": flops / mean_ms / 1e9}
-            if gemm:
-                dom = max(gemm, key=lambda k: gemm[k]["total_ms_per_step"])
-                kind, _, shape = dom.partition("_")
-                N_, K_ = (int(v) for v in shape.split("x"))
+            Wn_, E_ = pp["n_warehouses"], pp["n_extra_echelons"]
+            shape = dict(n=n, T=T, S=S, Wn=Wn_, E=E_, Ws=data["initial_inventories"].shape[2],
+                         Ww=data["initial_warehouse_inventories"].shape[2] if Wn_ else 0,
+                         We=data["initial_echelon_inventories"].shape[2] if E_ else 0,
+                         F=eng.dims[0], nh=len(eng.dims) - 2, n_out=eng.dims[-1], train=not args.eval)
+            kernels = kernel_report(timer, shape, args.steps)
+            rated = {k: v for k, v in kernels.items() if "bound" in v}
+            if rated:
+                dom = max(rated, key=lambda k: rated[k]["total_ms_per_step"])
+                d = rated[dom]
                 out["roofline"] = {
-                    "bound": "mfma", "achieved": gemm[dom]["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": gemm[dom]["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                    "kernel": {"fwd": "gemm_wx_dma_kernel<2,4,4,2,EPI_BIAS_ACT>", "dgrad": "gemm_wx_dma_kernel<2,4,4,2,EPI_DGRAD>",
-                               "wgrad": "gemm_wgrad_dma_kernel<2,4,4,2>",
-                               "wgradT": "gemm_wgrad_dma_kernel<2,4,4,2> over all periods"}.get(kind, kind) + f" ({dom})",
-                    "algorithmic_flops_per_launch": 2.0 * N_ * K_ * n * (T if kind == "wgradT" else 1),
-                    "mean_launch_ms": gemm[dom]["mean_ms"],
-                    "launches": gemm[dom]["launches"], "launches_timed": len(timer.events[dom]),
+                    "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"], "frac": d["frac"],
+                    "traffic": None, "kernel": f"{d['kernel']} ({dom})",
+                    ("algorithmic_flops_per_launch" if d["bound"] == "mfma" else "algorithmic_bytes_per_launch"):
+                        d.get("algorithmic_flops_per_launch", d.get("algorithmic_bytes_per_launch")),
+                    "mean_launch_ms": d["mean_ms"], "launches_per_step": d["launches_per_step"],
+                    "launches_timed": d["launches_timed"], "share_of_step": round(d["total_ms_per_step"] / ms, 4),
                 }
-                tr = _pmc_traffic(kind, N_, K_, n)
-                if tr is not None:
-                    out["roofline"]["traffic"] = tr["bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = tr["source"]
-                out["kernels"] = {k: {kk: round(vv, 5) if isinstance(vv, float) else vv for kk, vv in v.items()}
-                                  for k, v in sorted(gemm.items())}
-                pp = setting["problem_params"]
-                Wn_, E_ = pp["n_warehouses"], pp["n_extra_echelons"]
-                Ws_ = data["initial_inventories"].shape[2]
-                Ww_ = data["initial_warehouse_inventories"].shape[2] if Wn_ else 0
-                We_ = data["initial_echelon_inventories"].shape[2] if E_ else 0
-                # state read + write, demand, orders, reward (static tables amortised over T)
-                env_bytes = 4.0 * (2 * (S * Ws_ + Wn_ * Ww_ + E_ * We_) + S + (S * max(Wn_, 1) + Wn_ + E_) + 1) * n
-                for tag in ("env_fwd", "env_bwd", "small_rollout_fwd", "small_rollout_bwd"):
-                    if tag in summ:
-                        out["kernels"][tag] = {"launches": summ[tag][0], "mean_ms": round(summ[tag][1], 5)}
-                for tag, (cnt, mean_ms) in summ.items():  # fused thin-layer backward: HBM-bound, X in + dX out
-                    if tag.startswith("bwd_thin_"):
-                        N_t, K_t = (int(v) for v in tag[len("bwd_thin_"):].split("x"))
-                        out["kernels"][tag] = {"launches": cnt, "mean_ms": round(mean_ms, 5),
-                                               "total_ms_per_step": round(cnt * mean_ms / args.steps, 5),
-                                               "gb_per_s": round(2.0 * K_t * n * 4 / (mean_ms * 1e-3) / 1e9, 1)}
-                if "env_fwd" in summ:
-                    gbs = env_bytes / (summ["env_fwd"][1] * 1e-3) / 1e9
-                    out["roofline_env_step"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
-                                                "frac": gbs / 8000.0, "kernel": "env_step_fwd_kernel",
-                                                "algorithmic_bytes_per_launch": env_bytes,
-                                                "mean_launch_ms": summ["env_fwd"][1]}
+                tr_ = _pmc_traffic(d["kernel"], n)
+                if tr_ is not None:
+                    out["roofline"]["traffic"] = tr_["bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = tr_["source"]
+            out["kernels"] = kernels
+            if "env_fwd" in kernels and "bound" in kernels["env_fwd"]:
+                e = kernels["env_fwd"]
+                out["roofline_env_step"] = {"bound": "hbm", "achieved": e["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": e["frac"], "kernel": e["kernel"],
+                                            "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
+                                            "mean_launch_ms": e["mean_ms"]}
         if world == 1 and not args.no_cpu_baseline and not args.eval:
-            sample = args.cpu_sample or {"cfg3": 4096, "cfg5": 1024, "cfg2": 32768, "cfg4": 16384, "cfg1": 256}.get(args.workload, 1024)
+            sample = args.cpu_sample or {"cfg3": 4096, "cfg5": 1024, "cfg2": 32768, "cfg4": 16384, "cfg1": 256, "base_stock": 32768}.get(args.workload, 1024)
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, min(sample, n), T)
                 out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline must never take the bench line down
-                out["cpu_baseline"] = {"value": None, "unit": "scenario-steps/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": f"failed: {e!r}"}
+                out["cpu_baseline"] = {"value": None, "unit": "scenario-steps/s", "cores": None, "host_cores": os.cpu_count(),
+                                       "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

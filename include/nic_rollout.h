@@ -83,6 +83,9 @@ typedef struct NicEnvStepIO {
 /* ---- library ------------------------------------------------------------------------------------------- */
 int nic_abi_version(void);
 const char* nic_last_error(void);
+/* Name (with template arguments) of the kernel the calling thread's most recent nic_* call launched; "" before the first.
+ * Measurement aid: bench.py labels its roofline object with it instead of keeping a shape -> kernel table by hand. */
+const char* nic_last_kernel(void);
 /* number of visible HIP devices (does not initialise a context beyond hipGetDeviceCount) */
 int nic_device_count(void);
 

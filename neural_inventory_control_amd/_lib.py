@@ -65,6 +65,7 @@ _IOP = C.POINTER(NicEnvStepIO)
 PROTOTYPES = {
     "nic_abi_version": (C.c_int, []),
     "nic_last_error": (C.c_char_p, []),
+    "nic_last_kernel": (C.c_char_p, []),
     "nic_device_count": (C.c_int, []),
     "nic_env_step_fwd": (C.c_int, [_IOP, _vp, _vp, _vp, _vp, _vp]),
     "nic_env_step_bwd": (C.c_int, [_IOP, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

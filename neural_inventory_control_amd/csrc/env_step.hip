@@ -132,6 +132,7 @@ int nic_env_step_fwd(const NicEnvStepIO* io, float* store_inv_out, float* wh_inv
     const dim3 grid(nic::ceil_div(d.n_scenarios, kLanes)), block(kLanes * nic::kQuad);
     hipStream_t s = nic::as_stream(stream);
     const int m = max_slots(d);
+    nic::note_kernelf("env_step_fwd_kernel<%d>", m <= 4 ? 4 : (m <= 8 ? 8 : NIC_MAX_SLOTS));
     if (m <= 4)
         hipLaunchKernelGGL(env_step_fwd_kernel<4>, grid, block, 0, s, *io, store_inv_out, wh_inv_out, ech_inv_out, reward);
     else if (m <= 8)
@@ -154,6 +155,7 @@ int nic_env_step_bwd(const NicEnvStepIO* io, const float* g_store_out, const flo
     const dim3 grid(nic::ceil_div(d.n_scenarios, kLanes)), block(kLanes * nic::kQuad);
     hipStream_t s = nic::as_stream(stream);
     const int m = max_slots(d);
+    nic::note_kernelf("env_step_bwd_kernel<%d>", m <= 4 ? 4 : (m <= 8 ? 8 : NIC_MAX_SLOTS));
 #define NIC_LAUNCH_BWD(MW)                                                                                              \
     hipLaunchKernelGGL(env_step_bwd_kernel<MW>, grid, block, 0, s, *io, g_store_out, g_wh_out, g_ech_out, g_reward,      \
                        g_store_in, g_wh_in, g_ech_in, g_store_orders, g_wh_orders, g_ech_orders)

@@ -39,7 +39,7 @@ constexpr int LDA_S = 36;    // padded LDS row (floats) for k-contiguous tiles
 constexpr int kThreads = 256;
 
 enum { EPI_BIAS_ACT = 0, EPI_DGRAD = 1 };
-int gemm_variant();
+const char* epi_name(int epi) { return epi == EPI_BIAS_ACT ? "EPI_BIAS_ACT" : "EPI_DGRAD"; }
 
 struct WxParams {
     const float* A;      // [M][lda]
@@ -52,7 +52,6 @@ struct WxParams {
     int64_t ldb;
     int act;             // NIC_ACT_*
     int accumulate;      // EPI_DGRAD: C += result
-    int dbg;             // timing experiments only (0 in production)
 };
 
 // ELU.  libm's expm1f is ~40 VALU instructions and the epilogue applies it to every output element (33.5 M per 512-wide
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
 
     auto ktile = [&](int kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk && !(p.dbg & 1)) {  // stage cur^1 was last read in tile kt-1; every wave is past that barrier
+        if (kt + 1 < nk) {  // stage cur^1 was last read in tile kt-1; every wave is past that barrier
             advance();
             issue(cur ^ 1);
         }
@@ -1070,6 +1069,7 @@ template <int WM, int WN, int MT, int NT, int EPI>
 void launch_wx_dma(const WxParams& p, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.ncols + BN - 1) / BN;
+    nic::note_kernelf("gemm_wx_dma_kernel<%d,%d,%d,%d,%s>", WM, WN, MT, NT, epi_name(EPI));
     hipLaunchKernelGGL((gemm_wx_dma_kernel<WM, WN, MT, NT, EPI>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), 0, s, p);
 }
 
@@ -1077,11 +1077,15 @@ template <int WM, int WN, int MT, int NT, int EPI>
 void launch_wx(const WxParams& p, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.ncols + BN - 1) / BN;
+    nic::note_kernelf("gemm_wx_kernel<%d,%d,%d,%d,%s>", WM, WN, MT, NT, epi_name(EPI));
     hipLaunchKernelGGL((gemm_wx_kernel<WM, WN, MT, NT, EPI>), dim3(tiles_m * tiles_n), dim3(kThreads), 0, s, p);
 }
 
-// NIC_GEMM_VARIANT (tuning / A-B only): 1 = 128 x 128 tiles for the big layers, 2 = register-staged wgrad,
-// 3 = wgrad without the XCD tile order, 4 = TIMING ONLY: no DMA inside the k loop (results are wrong)
+// A/B variants of the dispatch (1 = 128 x 128 tiles for the big layers, 2 = register-staged wgrad, 3 = wgrad without the XCD
+// tile order) exist only in the tuning build tools/gemm_probe.py makes for itself (-DNIC_TUNING_BUILD, a separate .so
+// outside the package); the product library has no environment switches: every variant below is a correct kernel, but
+// which one runs must not depend on a stray variable.
+#ifdef NIC_TUNING_BUILD
 int gemm_variant() {
     static int v = -1;
     if (v < 0) {
@@ -1090,6 +1094,9 @@ int gemm_variant() {
     }
     return v;
 }
+#else
+constexpr int gemm_variant() { return 0; }
+#endif
 
 template <int EPI>
 void dispatch_wx(const WxParams& p, hipStream_t s) {
@@ -1115,6 +1122,7 @@ void launch_wg(const WgParams& p, int n_splits, hipStream_t s) {
     const bool fast = p.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(p.dY) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(p.X) & 15) == 0 && (int64_t)p.N * p.ldb < (1ll << 28) &&
                       (int64_t)p.K * p.ldb < (1ll << 28);
+    nic::note_kernelf("gemm_wgrad_kernel<%d,%d,%d,%d,%d>", WM, WN, MT, NT, fast ? 1 : 0);
     if (fast) hipLaunchKernelGGL((gemm_wgrad_kernel<WM, WN, MT, NT, 1>), grid, dim3(kThreads), 0, s, p);
     else hipLaunchKernelGGL((gemm_wgrad_kernel<WM, WN, MT, NT, 0>), grid, dim3(kThreads), 0, s, p);
 }
@@ -1133,6 +1141,7 @@ template <int WM, int WN, int MT, int NT>
 void launch_wg_dma(const WgParams& p, int n_splits, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     dim3 grid(((p.K + BN - 1) / BN) * ((p.N + BM - 1) / BM) * n_splits);
+    nic::note_kernelf("gemm_wgrad_dma_kernel<%d,%d,%d,%d>", WM, WN, MT, NT);
     hipLaunchKernelGGL((gemm_wgrad_dma_kernel<WM, WN, MT, NT>), grid, dim3(64 * WM * WN), 0, s, p);
 }
 
@@ -1154,7 +1163,7 @@ int nic_linear_fwd(const float* W, int64_t ldw, const float* bias, const float* 
     if (int e = require_ld("nic_linear_fwd", n_scenarios, ldb)) return e;
     NIC_REQUIRE((reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
                 "nic_linear_fwd: X/Y must be 16-byte aligned");
-    WxParams p{W, ldw, X, Y, bias, nullptr, N, K, (n_scenarios + 3) / 4 * 4, ldb, act, 0, gemm_variant() == 4 ? 1 : 0};
+    WxParams p{W, ldw, X, Y, bias, nullptr, N, K, (n_scenarios + 3) / 4 * 4, ldb, act, 0};
     dispatch_wx<EPI_BIAS_ACT>(p, nic::as_stream(stream));
     return nic::check_launch("nic_linear_fwd");
 }
@@ -1167,7 +1176,7 @@ int nic_linear_dgrad(const float* Wt, int64_t ldwt, const float* dY, const float
     NIC_REQUIRE((reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(dX) & 15) == 0,
                 "nic_linear_dgrad: dY/dX must be 16-byte aligned");
     // dX[K][b] = Wt[K][N] * dY[N][b]: output rows = K, contraction = N
-    WxParams p{Wt, ldwt, dY, dX, nullptr, Hprev, K, N, (n_scenarios + 3) / 4 * 4, ldb, act_prev, accumulate, gemm_variant() == 4 ? 1 : 0};
+    WxParams p{Wt, ldwt, dY, dX, nullptr, Hprev, K, N, (n_scenarios + 3) / 4 * 4, ldb, act_prev, accumulate};
     dispatch_wx<EPI_DGRAD>(p, nic::as_stream(stream));
     return nic::check_launch("nic_linear_dgrad");
 }
@@ -1222,6 +1231,7 @@ static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t l
                           (int64_t)N * ldb < (1ll << 28) && (int64_t)K * ldb < (1ll << 28);
     if (small_ok) {  // thin output (<= 32 rows), up to 128 input features: one wave per split, 1..4 accumulators
         const dim3 g((n_splits + 3) / 4), b(kThreads);
+        nic::note_kernelf("wgrad_small_kernel<%d>", K <= 32 ? 1 : (K <= 64 ? 2 : (K <= 96 ? 3 : 4)));
         if (K <= 32) hipLaunchKernelGGL(wgrad_small_kernel<1>, g, b, 0, s, p, n_splits);
         else if (K <= 64) hipLaunchKernelGGL(wgrad_small_kernel<2>, g, b, 0, s, p, n_splits);
         else if (K <= 96) hipLaunchKernelGGL(wgrad_small_kernel<3>, g, b, 0, s, p, n_splits);
@@ -1314,6 +1324,7 @@ int nic_wgrad_reduce(const float* slab, int64_t lds_, int32_t n_splits, float* d
     NIC_REQUIRE(slab && dW, "nic_wgrad_reduce: null buffer");
     NIC_REQUIRE(N > 0 && K > 0 && lds_ >= K + 1 && lddw >= K && n_splits >= 1, "nic_wgrad_reduce: bad sizes");
     const int64_t total = (int64_t)N * (K + 1);
+    nic::note_kernel(n_splits >= 128 && total <= 65536 ? "wgrad_reduce_wide_kernel" : "wgrad_reduce_kernel");
     if (n_splits >= 128 && total <= 65536)
         hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(nic::ceil_div(total, 4)), dim3(256), 0, nic::as_stream(stream), slab,
                            lds_, n_splits, dW, lddw, db, N, K, scale);

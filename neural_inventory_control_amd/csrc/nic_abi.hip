@@ -6,9 +6,19 @@ char* last_error_buffer() {
     static thread_local char buf[512] = {0};
     return buf;
 }
+const char** last_kernel_slot() {
+    static thread_local const char* name = "";
+    return &name;
+}
+char* last_kernel_buffer() {
+    static thread_local char buf[160] = {0};
+    return buf;
+}
 }  // namespace nic
 
 extern "C" {
+
+const char* nic_last_kernel(void) { return *nic::last_kernel_slot(); }
 
 int nic_abi_version(void) { return NIC_ABI_VERSION; }
 
@@ -28,6 +38,7 @@ __global__ void axpy_kernel(float* __restrict__ out, const float* __restrict__ i
 int nic_axpy(float* out, const float* in, float alpha, int64_t n, void* stream) {
     NIC_REQUIRE(out && in, "nic_axpy: null buffer");
     if (n <= 0) return 0;
+    nic::note_kernel("axpy_kernel");
     hipLaunchKernelGGL(axpy_kernel, dim3(nic::ceil_div(n, 256)), dim3(256), 0, nic::as_stream(stream), out, in, alpha, n);
     return nic::check_launch("nic_axpy");
 }

@@ -24,6 +24,19 @@ inline int check_launch(const char* what) {
     return 0;
 }
 
+// Name of the kernel the calling thread's most recent nic_* call launched (nic_last_kernel()).  bench.py reads it so that its
+// roofline object names the kernel that RAN for a shape rather than a table it keeps by hand.
+const char** last_kernel_slot();  // thread-local (nic_abi.hip)
+char* last_kernel_buffer();       // thread-local, 160 bytes
+inline void note_kernel(const char* literal) { *last_kernel_slot() = literal; }
+inline void note_kernelf(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_kernel_buffer(), 160, fmt, ap);
+    va_end(ap);
+    *last_kernel_slot() = last_kernel_buffer();
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

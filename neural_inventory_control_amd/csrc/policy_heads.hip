@@ -65,6 +65,7 @@ extern "C" {
 
 int nic_round_orders(float* x, int32_t rows, int32_t n_scenarios, int32_t ldb, void* stream) {
     NIC_REQUIRE(x && rows > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_round_orders: bad arguments");
+    nic::note_kernel("round_orders_kernel");
     hipLaunchKernelGGL(round_orders_kernel, dim3(nic::ceil_div(n_scenarios, 256), rows < 64 ? rows : 64), dim3(256), 0,
                        nic::as_stream(stream), x, rows, n_scenarios, (int64_t)ldb);
     return nic::check_launch("nic_round_orders");
@@ -75,6 +76,7 @@ int nic_head_warehouse_fwd(const float* Z, const float* wh_inv, const int32_t* a
                            int32_t n_scenarios, int32_t ldb, void* stream) {
     NIC_REQUIRE(Z && wh_inv && adjacency && store_orders && wh_orders, "nic_head_warehouse_fwd: null buffer");
     NIC_REQUIRE(S > 0 && Wn > 0 && Ww > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_warehouse_fwd: bad sizes");
+    nic::note_kernel("head_warehouse_fwd_kernel");
     hipLaunchKernelGGL(head_warehouse_fwd_kernel, dim3(nic::ceil_div(n_scenarios, kBlock), Wn < 4 ? Wn : 4), dim3(kBlock), 0,
                        nic::as_stream(stream), Z, wh_inv, adjacency, upper_bound, transshipment, store_orders, wh_orders, S,
                        Wn, Ww, n_scenarios, (int64_t)ldb);
@@ -88,6 +90,7 @@ int nic_head_warehouse_bwd(const float* Z, const float* wh_inv, const int32_t* a
     NIC_REQUIRE(Z && wh_inv && adjacency && g_store_orders && g_wh_orders && dZ && g_wh_inv,
                 "nic_head_warehouse_bwd: null buffer");
     NIC_REQUIRE(S > 0 && Wn > 0 && Ww > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_warehouse_bwd: bad sizes");
+    nic::note_kernel("head_warehouse_bwd_kernel");
     hipLaunchKernelGGL(head_warehouse_bwd_kernel, dim3(nic::ceil_div(n_scenarios, kBlock), Wn < 4 ? Wn : 4), dim3(kBlock), 0,
                        nic::as_stream(stream), Z, wh_inv, adjacency, upper_bound, transshipment, g_store_orders, g_wh_orders,
                        dZ, g_wh_inv, S, Wn, Ww, n_scenarios, (int64_t)ldb);
@@ -96,6 +99,7 @@ int nic_head_warehouse_bwd(const float* Z, const float* wh_inv, const int32_t* a
 
 int nic_head_softplus_fwd(const float* Z, float* orders, int32_t rows, int32_t n_scenarios, int32_t ldb, void* stream) {
     NIC_REQUIRE(Z && orders && rows > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_softplus_fwd: bad arguments");
+    nic::note_kernel("head_softplus_fwd_kernel");
     hipLaunchKernelGGL(head_softplus_fwd_kernel, dim3(nic::ceil_div(n_scenarios, 256)), dim3(256), 0, nic::as_stream(stream),
                        Z, orders, rows, n_scenarios, (int64_t)ldb);
     return nic::check_launch("nic_head_softplus_fwd");
@@ -105,6 +109,7 @@ int nic_head_softplus_bwd(const float* Z, const float* g_orders, float* dZ, int3
                           void* stream) {
     NIC_REQUIRE(Z && g_orders && dZ && rows > 0 && n_scenarios > 0 && ldb >= n_scenarios,
                 "nic_head_softplus_bwd: bad arguments");
+    nic::note_kernel("head_softplus_bwd_kernel");
     hipLaunchKernelGGL(head_softplus_bwd_kernel, dim3(nic::ceil_div(n_scenarios, 256)), dim3(256), 0, nic::as_stream(stream),
                        Z, g_orders, dZ, rows, n_scenarios, (int64_t)ldb);
     return nic::check_launch("nic_head_softplus_bwd");
@@ -116,6 +121,7 @@ int nic_head_serial_fwd(const float* Z, const float* wh_inv, const float* ech_in
     NIC_REQUIRE(Z && wh_inv && store_orders && wh_orders && (E == 0 || (ech_inv && ech_orders)),
                 "nic_head_serial_fwd: null buffer");
     NIC_REQUIRE(E >= 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_serial_fwd: bad sizes");
+    nic::note_kernel("head_serial_fwd_kernel");
     hipLaunchKernelGGL(head_serial_fwd_kernel, dim3(nic::ceil_div(n_scenarios, kBlock)), dim3(kBlock), 0,
                        nic::as_stream(stream), Z, wh_inv, ech_inv, upper_bound, store_orders, wh_orders, ech_orders, E, Ww, We,
                        n_scenarios, (int64_t)ldb);
@@ -129,6 +135,7 @@ int nic_head_serial_bwd(const float* Z, const float* wh_inv, const float* ech_in
     NIC_REQUIRE(Z && wh_inv && g_store_orders && g_wh_orders && dZ && g_wh_inv && (E == 0 || (ech_inv && g_ech_orders && g_ech_inv)),
                 "nic_head_serial_bwd: null buffer");
     NIC_REQUIRE(E >= 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_serial_bwd: bad sizes");
+    nic::note_kernel("head_serial_bwd_kernel");
     hipLaunchKernelGGL(head_serial_bwd_kernel, dim3(nic::ceil_div(n_scenarios, kBlock)), dim3(kBlock), 0,
                        nic::as_stream(stream), Z, wh_inv, ech_inv, upper_bound, g_store_orders, g_wh_orders, g_ech_orders, dZ,
                        g_wh_inv, g_ech_inv, E, Ww, We, n_scenarios, (int64_t)ldb);

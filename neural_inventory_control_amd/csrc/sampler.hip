@@ -85,6 +85,7 @@ extern "C" int nic_sample_demand(float* out, int32_t T, int32_t S, int32_t n_sce
     NIC_REQUIRE(kind == 0 || kind == 1, "nic_sample_demand: unknown distribution %d", kind);
     NIC_REQUIRE(T > 0 && T <= 65535 && S > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_sample_demand: bad sizes");
     dim3 grid(nic::ceil_div(n_scenarios, 256), T);
+    nic::note_kernel("sample_demand_kernel");
     hipLaunchKernelGGL(sample_demand_kernel, grid, dim3(256), 0, nic::as_stream(stream), out, T, S, n_scenarios, (int64_t)ldb,
                        scenario_offset, (uint32_t)seed, (uint32_t)(seed >> 32), kind, mean, chol, clip);
     return nic::check_launch("nic_sample_demand");

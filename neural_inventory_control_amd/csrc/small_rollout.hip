@@ -1,9 +1,9 @@
 // Whole-horizon rollout kernels for the small (one-store chain, 32-wide MLP) policies: ONE launch runs all T periods.
-// One lane = one scenario (64-lane workgroups), state / activations / gradients in registers across the horizon (body:
-// small_rollout_body.h).  The weight pointer is a separate `const __restrict__` kernel argument so that hipcc proves the
-// (wave-uniform) weight reads invariant and issues them on the scalar path (s_load) instead of 64-lane vector loads.
-// VALU-bound: ~2 * params FMAs per scenario-period forward; HBM traffic is 4 B (demand) + 4 B (reward) per scenario-period
-// plus, when training, the stored activations (4 * (F + 32 * n_hidden + n_out) B).
+// One wavefront = 32 scenarios; the 32-wide layers run on the matrix cores with the weights resident in VGPRs, the env
+// step / head are per-lane code shared with the host build (small_rollout_body.h, which also holds the scalar per-scenario
+// restatement of the whole kernel that tests/hostsim checks against the golden vectors).
+// HBM traffic is 4 B (demand) + 4 B (reward) per scenario-period plus, when training, the stored activations
+// (4 * (F + 32 * n_hidden + n_out) B).
 #include <stdlib.h>
 
 #include "nic_common.h"
@@ -11,51 +11,6 @@
 
 namespace {
 constexpr int kBlock = 64;
-// packed weights staged in LDS once per workgroup: every lane reads the same address (LDS broadcast, conflict-free), the
-// reads vectorise to ds_read_b128 and pipeline behind counted lgkmcnt waits.  (Streaming the ~2.3k weights through the
-// scalar cache every period left the single wave per SIMD stalled on s_load latency: 72k cycles per period measured.)
-constexpr int kMaxPacked = (NIC_SR_HIDDEN * NIC_SR_MAX_INPUTS + NIC_SR_HIDDEN) + 2 * (NIC_SR_HIDDEN * NIC_SR_HIDDEN + NIC_SR_HIDDEN) +
-                           (NIC_SR_MAX_OUTPUTS * NIC_SR_HIDDEN + NIC_SR_MAX_OUTPUTS);
-
-__device__ __forceinline__ void stage_weights(float* wlds, const float* __restrict__ weights, const NicSmallRolloutDesc& d) {
-    const int n = (NIC_SR_HIDDEN * d.F + NIC_SR_HIDDEN) + (d.n_hidden - 1) * (NIC_SR_HIDDEN * NIC_SR_HIDDEN + NIC_SR_HIDDEN) +
-                  (d.n_out * NIC_SR_HIDDEN + d.n_out);
-    for (int i = threadIdx.x; i < n; i += kBlock) wlds[i] = weights[i];
-    __syncthreads();
-}
-
-template <int NL>
-__global__ __launch_bounds__(kBlock) void small_rollout_fwd_kernel(NicSmallRolloutDesc d, const float* __restrict__ weights,
-                                                                   const float* __restrict__ demand,
-                                                                   const float* __restrict__ state0, float* __restrict__ rewards,
-                                                                   float* __restrict__ state_final, float* __restrict__ states_hist,
-                                                                   float* __restrict__ hidden_hist, float* __restrict__ logits_hist) {
-    __shared__ __attribute__((aligned(16))) float wlds[kMaxPacked];
-    stage_weights(wlds, weights, d);
-    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (b >= d.n_scenarios) return;
-    d.weights = wlds;
-    d.demand = demand;
-    d.state0 = state0;
-    nic::small_rollout_fwd_scenario<NL>(d, rewards, state_final, states_hist, hidden_hist, logits_hist, b);
-}
-
-template <int NL>
-__global__ __launch_bounds__(kBlock) void small_rollout_bwd_kernel(NicSmallRolloutDesc d, const float* __restrict__ weights,
-                                                                   const float* __restrict__ demand,
-                                                                   const float* __restrict__ states_hist,
-                                                                   const float* __restrict__ hidden_hist,
-                                                                   const float* __restrict__ logits_hist, NicTable2 g_reward,
-                                                                   float* __restrict__ dz_hidden, float* __restrict__ dz_out) {
-    __shared__ __attribute__((aligned(16))) float wlds[kMaxPacked];
-    stage_weights(wlds, weights, d);
-    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (b >= d.n_scenarios) return;
-    d.weights = wlds;
-    d.demand = demand;
-    nic::small_rollout_bwd_scenario<NL>(d, states_hist, hidden_hist, logits_hist, g_reward, dz_hidden, dz_out, b);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // MFMA form of the whole-horizon FORWARD: one wavefront = 32 scenarios; the 32-wide layers run on the matrix cores with
 // the weights RESIDENT IN VGPRs for the whole horizon (no per-period weight traffic at all — the per-lane VALU form above
@@ -343,8 +298,8 @@ int nic_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* s
     NIC_REQUIRE(d->state0 && rewards && state_final, "nic_small_rollout_fwd: null buffer");
     NIC_REQUIRE(!states_hist || (hidden_hist && logits_hist), "nic_small_rollout_fwd: incomplete history buffers");
     hipStream_t s = nic::as_stream(stream);
-    static const int variant = getenv("NIC_SMALL_VARIANT") ? atoi(getenv("NIC_SMALL_VARIANT")) : 0;
-    if (variant != 1) {  // matrix-core form: 32 scenarios per wavefront
+    {  // matrix-core form: 32 scenarios per wavefront
+        nic::note_kernelf("small_rollout_fwd_mfma_kernel<%d>", d->n_hidden);
         const dim3 g32(nic::ceil_div(d->n_scenarios, 32)), b64(64);
 #define NIC_SR_FWD_MFMA(NL)                                                                                                \
     hipLaunchKernelGGL(small_rollout_fwd_mfma_kernel<NL>, g32, b64, 0, s, *d, d->weights, d->demand, d->state0, rewards,  \
@@ -355,15 +310,6 @@ int nic_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* s
 #undef NIC_SR_FWD_MFMA
         return nic::check_launch("nic_small_rollout_fwd");
     }
-    const dim3 grid(nic::ceil_div(d->n_scenarios, kBlock)), block(kBlock);
-#define NIC_SR_FWD(NL)                                                                                                     \
-    hipLaunchKernelGGL(small_rollout_fwd_kernel<NL>, grid, block, 0, s, *d, d->weights, d->demand, d->state0, rewards,    \
-                       state_final, states_hist, hidden_hist, logits_hist)
-    if (d->n_hidden == 1) NIC_SR_FWD(1);
-    else if (d->n_hidden == 2) NIC_SR_FWD(2);
-    else NIC_SR_FWD(3);
-#undef NIC_SR_FWD
-    return nic::check_launch("nic_small_rollout_fwd");
 }
 
 int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
@@ -372,8 +318,8 @@ int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist
     NIC_REQUIRE(states_hist && hidden_hist && logits_hist && g_reward.p && dz_hidden && dz_out,
                 "nic_small_rollout_bwd: null buffer");
     hipStream_t s = nic::as_stream(stream);
-    static const int variant = getenv("NIC_SMALL_VARIANT") ? atoi(getenv("NIC_SMALL_VARIANT")) : 0;
-    if (variant != 1) {
+    {
+        nic::note_kernelf("small_rollout_bwd_mfma_kernel<%d>", d->n_hidden);
         const dim3 g32(nic::ceil_div(d->n_scenarios, 32)), b64(64);
 #define NIC_SR_BWD_MFMA(NL)                                                                                                \
     hipLaunchKernelGGL(small_rollout_bwd_mfma_kernel<NL>, g32, b64, 0, s, *d, d->weights, d->demand, states_hist,         \
@@ -384,14 +330,5 @@ int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist
 #undef NIC_SR_BWD_MFMA
         return nic::check_launch("nic_small_rollout_bwd");
     }
-    const dim3 grid(nic::ceil_div(d->n_scenarios, kBlock)), block(kBlock);
-#define NIC_SR_BWD(NL)                                                                                                     \
-    hipLaunchKernelGGL(small_rollout_bwd_kernel<NL>, grid, block, 0, s, *d, d->weights, d->demand, states_hist,           \
-                       hidden_hist, logits_hist, g_reward, dz_hidden, dz_out)
-    if (d->n_hidden == 1) NIC_SR_BWD(1);
-    else if (d->n_hidden == 2) NIC_SR_BWD(2);
-    else NIC_SR_BWD(3);
-#undef NIC_SR_BWD
-    return nic::check_launch("nic_small_rollout_bwd");
 }
 }

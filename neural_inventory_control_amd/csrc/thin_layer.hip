@@ -249,6 +249,7 @@ int nic_linear_bwd_thin(const float* W, int64_t ldw, const float* dY, const floa
     hipStream_t s = nic::as_stream(stream);
     const int steps = (N + 1) / 2;
     const bool full = ldb % CB == 0 && K % (32 * KG) == 0;
+    nic::note_kernelf("thin_bwd_kernel<%d,%s>", steps <= 4 ? 4 : (steps <= 9 ? 9 : 16), full ? "true" : "false");
 #define NIC_THIN_LAUNCH(NS_)                                                                    \
     do {                                                                                        \
         if (full) hipLaunchKernelGGL((thin_bwd_kernel<NS_, true>), grid, block, 0, s, p);       \

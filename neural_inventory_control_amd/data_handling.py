@@ -7,7 +7,13 @@ Two samplers produce the demand traces:
     fixtures), including its in-place mutations of `store_params['demand']` and `seeds['demand']`.
   * sampler="hip": csrc/sampler.hip — Philox4x32-10 keyed by (seed, GLOBAL scenario index, period), written straight into
     the [T][S][ldb] layout the env-step kernel reads.  Same distribution parameters; statistical (not bitwise) parity
-    with numpy.  `scenario_offset`/`num_total` make shards of a multi-GPU job reproduce the single-GPU traces.
+    with numpy.
+
+Sharded generation (one process per GPU): `Scenario(..., num_samples=n_local, scenario_offset=lo, num_total=N)`
+builds rows [lo, lo + n_local) of the N-scenario job.  Demand traces are keyed by the global scenario index, the initial
+store pipelines use the GLOBAL per-store demand mean (data_handling.py:298 — the one cross-scenario coupling of data
+generation: an S-float SUM all-reduce over the ranks) and rows [lo, lo + n_local) of the global multiplier draw, so the
+concatenated shards equal the single-process dataset.
 
 `Alias`: `Scenarios = Scenario` (BASELINE.json's spelling).
 """
@@ -23,7 +29,7 @@ from .layout import pad_ld
 
 class Scenario:
     def __init__(self, periods, problem_params, store_params, warehouse_params, echelon_params, num_samples,
-                 observation_params, seeds=None, sampler="numpy", device=None, scenario_offset=0):
+                 observation_params, seeds=None, sampler="numpy", device=None, scenario_offset=0, num_total=None):
         self.problem_params = problem_params
         self.store_params = store_params
         self.warehouse_params = warehouse_params
@@ -34,7 +40,8 @@ class Scenario:
         self.seeds = seeds
         self.sampler = sampler
         self.device = device
-        self.scenario_offset = scenario_offset
+        self.scenario_offset = int(scenario_offset)
+        self.num_total = int(num_total) if num_total is not None else self.scenario_offset + num_samples
         self.demands_soa = None  # [T][S][ldb] device tensor when sampler == "hip"
 
         self.demands = self.generate_demand_samples(problem_params, store_params, store_params["demand"], seeds)
@@ -112,10 +119,21 @@ class Scenario:
             return self._generate_on_device(problem_params, demand_params, seeds["demand"])
         gen = {"normal": self.generate_normal_demand, "poisson": self.generate_poisson_demand,
                "real": self.read_real_demand_data}[kind]
-        demand = gen(problem_params, demand_params, seeds["demand"])
+        local, lo = self.num_samples, self.scenario_offset
+        if kind != "real" and self.num_total != local:
+            # a shard on the host path: numpy's stream is sequential, so the GLOBAL trace is drawn and rows [lo, lo + n) kept
+            self.num_samples = self.num_total
+        try:
+            demand = gen(problem_params, demand_params, seeds["demand"])
+        finally:
+            self.num_samples = local
         if demand_params["clip"]:
             demand = np.clip(demand, 0, None)
-        return torch.tensor(demand)
+        demand = torch.tensor(demand)
+        if kind != "real" and self.num_total != local:
+            self._global_store_mean = demand.float().mean(dim=2).mean(dim=0)  # the reference's formula on the global draw
+            demand = demand[lo:lo + local]
+        return demand
 
     def adjust_seeds_for_consistency(self, problem_params, store_params, seeds):
         """One-store synthetic settings shift the demand seed by lead time + 10 * underage cost (data_handling.py:155-158)."""
@@ -214,11 +232,36 @@ class Scenario:
         S = problem_params["n_stores"]
         if not spec["sample"]:
             return torch.zeros(self.num_samples, S, spec["inventory_periods"])
-        # GLOBAL per-store mean over every sample and period (data_handling.py:298)
-        demand_mean = demands.float().mean(dim=2).mean(dim=0).cpu()
+        demand_mean = self.global_store_demand_mean(demands)
         slots = max(spec["inventory_periods"], lead_times.max().item())
-        mults = np.random.uniform(*spec["range_mult"], size=(self.num_samples, S, slots))
+        mults = self._uniform_rows(spec["range_mult"], S * slots).reshape(self.num_samples, S, slots)
         return demand_mean[None, :, None] * torch.from_numpy(mults)  # f32 x f64 -> f64, cast to f32 in get_data
+
+    def global_store_demand_mean(self, demands):
+        """Per-store mean demand over EVERY scenario of the job and every period (data_handling.py:298).
+        Host sampler: the reference's float32 mean-of-means (bit-equal; a shard computed it on the global draw).
+        Device sampler: the traces exist only on their shard, so the per-store float64 sums are added across ranks (one
+        S-element all-reduce) and divided by the global count; a single process uses the same formula, which makes the
+        result independent of the number of shards (up to float64 rounding of the partial sums, far below float32)."""
+        if getattr(self, "_global_store_mean", None) is not None:
+            return self._global_store_mean
+        if self.demands_soa is None:
+            return demands.float().mean(dim=2).mean(dim=0).cpu()
+        from . import parallel
+        part = self.demands_soa[:, :, :self.num_samples].double().sum(dim=(0, 2))
+        if self.num_total != self.num_samples:
+            part = parallel.all_reduce_sum(part)
+        return (part / float(self.num_total * self.periods)).float().cpu()
+
+    def _uniform_rows(self, rng, row_len):
+        """Rows [scenario_offset, scenario_offset + num_samples) of the (num_total, row_len) uniform draw the single-process
+        job makes at this point of numpy's global stream (the preceding rows are drawn in bounded chunks and dropped)."""
+        skip = self.scenario_offset * row_len
+        while skip > 0:
+            k = min(skip, 1 << 22)
+            np.random.uniform(rng[0], rng[1], size=k)
+            skip -= k
+        return np.random.uniform(rng[0], rng[1], size=(self.num_samples, row_len))
 
     def generate_initial_warehouse_inventory(self, warehouse_params):
         if warehouse_params is None:

@@ -37,6 +37,17 @@ def _load_yaml(arg, config_dir, sub):
         return yaml.safe_load(f)
 
 
+def materialize_policy(model, simulator, dataset, problem_params, observation_params, periods, device):
+    """One forward of the policy on the first two samples (no gradients): creates the parameters of LazyLinear layers
+    exactly as the reference's first training forward would (neural_networks.py:88)."""
+    batch = {k: v[:2].to(device) for k, v in dataset.data.items()}
+    with torch.no_grad():
+        obs, _ = simulator.reset(periods, problem_params, batch, observation_params)
+        obs = dict(obs)
+        obs["internal_data"] = simulator._internal_data
+        model(obs)
+
+
 def build(config_setting, config_hyperparams, device, rank=0, world_size=1):
     """Everything main_run.py builds between reading the YAMLs and calling the trainer (main_run.py:33-118)."""
     (seeds, test_seeds, problem_params, params_by_dataset, observation_params, store_params, warehouse_params,
@@ -64,6 +75,15 @@ def build(config_setting, config_hyperparams, device, rank=0, world_size=1):
     data_loaders = {"train": loader(train_set, "train", True), "dev": loader(dev_set, "dev", False),
                     "test": loader(test_set, "test", False)}
     model = NeuralNetworkCreator().create_neural_network(test_scenario, nn_params, device=device)
+    simulator = Simulator(device=device)
+    if world_size > 1:
+        # replicas must start from identical parameters: materialise the lazy layers with one throw-away forward, then
+        # take rank 0's (only gradients are all-reduced afterwards)
+        materialize_policy(model, simulator, train_set, problem_params, observation_params,
+                           params_by_dataset["train"]["periods"], device)
+        parallel.broadcast_model(model, src=0)
+        if not parallel.parameters_in_sync(model):
+            raise RuntimeError("policy parameters differ across ranks after the broadcast")
     optimizer = torch.optim.Adam(model.parameters(), lr=optimizer_params["learning_rate"])
     trainer = Trainer(device=device)
     trainer_params = dict(trainer_params)
@@ -74,7 +94,7 @@ def build(config_setting, config_hyperparams, device, rank=0, world_size=1):
     trainer_params["save_model_filename"] = trainer.get_time_stamp()
     if trainer_params.get("load_previous_model"):
         model, optimizer = trainer.load_model(model, optimizer, trainer_params["load_model_path"])
-    return dict(model=model, optimizer=optimizer, trainer=trainer, simulator=Simulator(device=device),
+    return dict(model=model, optimizer=optimizer, trainer=trainer, simulator=simulator,
                 loss_function=PolicyLoss(), data_loaders=data_loaders, problem_params=problem_params,
                 observation_params=observation_params, params_by_dataset=params_by_dataset, trainer_params=trainer_params,
                 store_params=store_params)

@@ -54,20 +54,77 @@ def shard_range(n_total, rank_, world):
     return lo, min(lo + per, n_total)
 
 
+def _collective(fn, t):
+    """Runs the in-place collective `fn(tensor)` on `t`, staging it where the backend can reach it: RCCL ("nccl") only
+    moves device tensors, gloo only host tensors (the CPU tests; two test ranks sharing one GPU)."""
+    backend = dist.get_backend()
+    if backend == "gloo" and t.is_cuda:
+        h = t.cpu()
+        fn(h)
+        t.copy_(h)
+    elif backend == "nccl" and not t.is_cuda:
+        d = t.cuda()
+        fn(d)
+        t.copy_(d)
+    else:
+        fn(t)
+    return t
+
+
+def all_reduce_sum(t):
+    """SUM all-reduce of a small tensor over the ranks, in place on a contiguous copy (identity in a single process)."""
+    if world_size() == 1:
+        return t
+    t = t.contiguous()
+    return _collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM), t)
+
+
+def broadcast_model(model, src=0):
+    """Every rank starts from rank `src`'s parameters, buffers and order upper bound (lazy layers must be materialised
+    first).  Only gradients are all-reduced afterwards, so replicas that start equal stay equal; without this, equality
+    would rest on every rank having drawn identical initial weights from identical RNG states."""
+    if world_size() == 1:
+        return
+    tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
+    ub = getattr(model, "warehouse_upper_bound", None)
+    if torch.is_tensor(ub):
+        tensors.append(ub.data)
+    for t in tensors:
+        _collective(lambda x: dist.broadcast(x, src=src), t)
+
+
+def parameters_in_sync(model):
+    """True if every rank holds the same parameters: float64 (sum, sum of squares) per rank, MIN and MAX over ranks equal."""
+    if world_size() == 1:
+        return True
+    ps = [p.detach().double() for p in model.parameters()]
+    mine = torch.stack([sum(p.sum() for p in ps), sum((p * p).sum() for p in ps)])
+    lo, hi = mine.clone(), mine.clone()
+    _collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN), lo)
+    _collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX), hi)
+    return bool(torch.equal(lo.cpu(), hi.cpu()))
+
+
 def all_reduce_scalars(*scalars):
     if world_size() == 1:
         return scalars
     buf = torch.stack([s.detach().float().reshape(()) for s in scalars])
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    buf = all_reduce_sum(buf)
     return tuple(buf[i] for i in range(len(scalars)))
 
 
 class GradientAllReducer:
-    """Flat-buffer SUM all-reduce of every parameter gradient plus trailing scalars, once per optimizer step."""
+    """Flat-buffer SUM all-reduce of every parameter gradient plus trailing scalars, once per optimizer step.
+
+    The flat buffer is carved into per-parameter views once; packing and unpacking are ONE multi-tensor copy each
+    (`torch._foreach_copy_`: a fused launch on the device instead of one small copy per parameter on either side of a
+    latency-bound collective).  Gradient tensors keep their identity (a captured training step accumulates into fixed
+    `.grad` tensors; the fused engine hands out its own buffers), only their contents are replaced by the sum."""
+
     @classmethod
     def get(cls, model):
-        """One reducer per model, stored ON the model (a table keyed by id(model) would outlive the model and could hand a
-        new model at the same address another model's parameter list)."""
+        """One reducer per model, stored ON the model (a table keyed by id(model) would outlive the model and could hand
+        a new model at the same address another model's parameter list)."""
         r = model.__dict__.get("_nic_grad_reducer")
         if r is None:
             r = model.__dict__["_nic_grad_reducer"] = cls(model)
@@ -75,34 +132,42 @@ class GradientAllReducer:
 
     def __init__(self, model):
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.flat = None
+        self.flat, self.views, self.n_scalars = None, None, 0
+
+    def _layout(self, n_scalars, device):
+        n = sum(p.numel() for p in self.params)
+        if self.flat is None or self.flat.numel() != n + n_scalars or self.flat.device != device:
+            self.flat = torch.zeros(n + n_scalars, device=device, dtype=torch.float32)
+            self.views, off = [], 0
+            for p in self.params:
+                self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self.tail = self.flat[n:]
 
     def all_reduce(self, *scalars):
         params = self.params
-        n = sum(p.numel() for p in params) + len(scalars)
         dev = params[0].device if params else scalars[0].device
-        if self.flat is None or self.flat.numel() != n or self.flat.device != dev:
-            self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        off = 0
-        for p in params:
-            k = p.numel()
+        self._layout(len(scalars), dev)
+        src, dst = [], []
+        for p, v in zip(params, self.views):
             if p.grad is None:
-                self.flat[off:off + k].zero_()
-            else:
-                self.flat[off:off + k].copy_(p.grad.reshape(-1))
-            off += k
-        for s in scalars:
-            self.flat[off] = s.detach().float().reshape(())
-            off += 1
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad.detach() if p.grad.dtype == torch.float32 else p.grad.detach().float())
+                dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if scalars:
+            self.tail.copy_(torch.stack([s.detach().float().reshape(()) for s in scalars]))
         if world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        off = 0
-        for p in params:
-            k = p.numel()
-            g = self.flat[off:off + k].view_as(p)
+            _collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM), self.flat)
+        back_dst, back_src = [], []
+        for p, v in zip(params, self.views):
             if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += k
-        return tuple(self.flat[off + i].clone() for i in range(len(scalars)))
+                p.grad = v.clone()
+            elif p.grad.data_ptr() != v.data_ptr():
+                back_dst.append(p.grad)
+                back_src.append(v)
+        if back_dst:
+            torch._foreach_copy_(back_dst, back_src)
+        return tuple(self.tail[i].clone() for i in range(len(scalars)))

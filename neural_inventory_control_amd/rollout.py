@@ -39,6 +39,7 @@ class KernelTimer:
         self.tags = set(tags) if tags is not None else None
         self.events = {}
         self.calls = {}
+        self.names = {}  # tag -> name of the kernel the C ABI reported launching for it (nic_last_kernel)
         self.stride = max(1, int(stride))
         self.enabled = True
 
@@ -57,6 +58,8 @@ class KernelTimer:
         out = fn(*args, **kw)
         b.record()
         self.events.setdefault(tag, []).append((a, b))
+        if tag not in self.names:
+            self.names[tag] = (_lib.lib().nic_last_kernel() or b"").decode()
         return out
 
     def summary(self):
@@ -66,6 +69,7 @@ class KernelTimer:
     def reset(self):
         self.events = {}
         self.calls = {}
+        self.names = {}
 
 
 class FusedRollout:

@@ -117,6 +117,22 @@ class Trainer:
                 train_now = bool(train and model.trainable)
                 # every rank normalises by the GLOBAL batch (trainer.py:169 with B summed over ranks)
                 global_batch = getattr(data_loader, "last_global_batch", None) or len(data_batch["demands"]) * world
+                if len(data_batch["demands"]) == 0:
+                    # a sharded job whose last global batch is smaller than the world size leaves this rank without
+                    # scenarios: it contributes zeros but still joins the step's collective and steps the optimizer
+                    # (and adds the step's GLOBAL totals, so that every rank reports - and early-stops on - the same losses)
+                    zero = torch.zeros((), device=self.device)
+                    tot, rep = zero, zero
+                    if train and model.trainable and world > 1:
+                        tot, rep = parallel.GradientAllReducer.get(model).all_reduce(zero, zero)
+                        if getattr(model, "gradient_clipping_norm_value", None) is not None:
+                            torch.nn.utils.clip_grad_norm_(model.parameters(), model.gradient_clipping_norm_value)
+                        optimizer.step()
+                    elif world > 1:
+                        tot, rep = parallel.all_reduce_scalars(zero, zero)
+                    epoch_loss += tot.detach()
+                    epoch_report += rep.detach()
+                    continue
                 graphed = (train and model.trainable and self.use_step_graph and not discrete_allocation
                            and not (self.use_fused_rollout and FusedRollout.supports(model)
                                     and self._plain_observation(observation_params)))

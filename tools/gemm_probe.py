@@ -1,5 +1,7 @@
 """Micro-benchmark of the policy GEMM kernels at BASELINE cfg3 shapes (HIP events on the current stream).
-NIC_GEMM_VARIANT selects a tuning variant of the wx kernel (see dispatch_wx in csrc/linear_mfma.hip)."""
+NIC_GEMM_VARIANT=1|2|3 selects an A/B variant of the dispatch (see dispatch_wx in csrc/linear_mfma.hip).  The product
+library has no such switch: when the variable is set this tool compiles ITS OWN copy of the library with -DNIC_TUNING_BUILD
+into tools/_build/ and binds the ops to that copy for the duration of the probe."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,7 +21,21 @@ def timeit(fn, iters=20, warm=3):
     return s.elapsed_time(e) / iters
 
 
+def _tuning_library():
+    import subprocess
+    from neural_inventory_control_amd import build as nb
+    out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libnic_hip_tuning.so")
+    srcs = [os.path.join(nb.CSRC, s) for s, _ in nb.SOURCES]
+    subprocess.check_call([nb._hipcc(), f"--offload-arch={nb.ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNIC_TUNING_BUILD",
+                           "-ffp-contract=off", "-o", out] + srcs)
+    return out
+
+
 def main():
+    if os.environ.get("NIC_GEMM_VARIANT"):
+        _lib._lib = _lib.load_library(_tuning_library())
     dev = "cuda"
     B = int(os.environ.get("PROBE_B", 65536))
     shapes = [(512, 512)] if os.environ.get("PROBE_MAIN_ONLY") else [(512, 512), (512, 51), (17, 512)]
