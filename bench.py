@@ -66,6 +66,7 @@ def build_case(workload, device, rank, world, scenarios=None, periods=None):
     from neural_inventory_control_amd import workloads
     from neural_inventory_control_amd.data_handling import Scenario
     from neural_inventory_control_amd.neural_networks import NeuralNetworkCreator
+    from neural_inventory_control_amd.closed_form import ClosedFormRollout
     from neural_inventory_control_amd.rollout import FusedRollout
     setting, policy, n, T, desc = workloads.get(workload)
     if scenarios or periods:
@@ -79,7 +80,13 @@ def build_case(workload, device, rank, world, scenarios=None, periods=None):
     data = {k: v.to(device) for k, v in sc.get_data().items()}
     torch.manual_seed(1234)  # identical initial weights on every rank (and broadcast below when world > 1)
     model = NeuralNetworkCreator().create_neural_network(sc, policy, device=device)
-    eng = FusedRollout(model, setting["problem_params"], device) if FusedRollout.supports(model) else None
+    eng = None
+    if FusedRollout.supports(model):
+        eng = FusedRollout(model, setting["problem_params"], device)
+    elif ClosedFormRollout.supports(model):
+        eng = ClosedFormRollout(model, setting["problem_params"], device)
+        if not eng.shapes_ok(data):
+            eng = None
     return setting, policy, sc, data, model, eng, n, T, desc
 
 
@@ -189,8 +196,8 @@ def algorithmic_work(tag, kernel, shape):
         return "hbm", 4.0 * (2 + (hist if shape["train"] else 0)) * n * T, "B"
     if tag == "small_rollout_bwd":  # history + demand in, pre-activation gradients out
         return "hbm", 4.0 * (1 + hist + 32 * shape["nh"] + shape["n_out"]) * n * T, "B"
-    if tag in ("closed_form_fwd", "closed_form_bwd"):  # whole-horizon closed-form policy: demand read (+ reward written)
-        return "hbm", 4.0 * (S + (1 if tag.endswith("fwd") else 0)) * n * T, "B"
+    if tag == "closed_form_fwd":  # whole-horizon closed-form policy: the demand trace + one state load / store + totals
+        return "hbm", 4.0 * (S * T + 2 * f_state + 2 * S) * n, "B"
     return None
 
 
@@ -250,7 +257,12 @@ def main():
                                                                    args.periods)
     pp = setting["problem_params"]
     S = pp["n_stores"]
-    if eng is not None:  # materialise the lazy layers now so that replicas can be synchronised before the first step
+    closed_form = eng is not None and type(eng).__name__ == "ClosedFormRollout"
+    if closed_form:
+        with torch.no_grad():
+            eng.model.closed_form_levels()  # materialises the policy's one lazy layer
+        parallel.broadcast_model(model, src=0)
+    elif eng is not None:  # materialise the lazy layers now so that replicas can be synchronised before the first step
         F_in = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
         if policy["name"] != "vanilla_one_store":
             F_in += sum(data[k].shape[1] * data[k].shape[2]
@@ -258,7 +270,7 @@ def main():
         eng.materialize(F_in)
         parallel.broadcast_model(model, src=0)
     opt = torch.optim.Adam(model.parameters(), lr=3e-4)
-    if args.graph and eng is not None:
+    if args.graph and eng is not None and not closed_form:
         eng.use_graph = True
         args.no_kernel_timing = True
     reducer = parallel.GradientAllReducer.get(model) if world > 1 else None
@@ -304,6 +316,15 @@ def main():
         if args.eval:
             return eval_step()
         opt.zero_grad(set_to_none=True)
+        if closed_form:  # one launch: rollout + forward-mode gradient; autograd only chains through the policy's tiny net
+            total, reported = eng.run(data, T, 0, train=True, observation_params=setting["observation_params"],
+                                      demand_soa=sc.demands_soa)
+            (total * grad_scale).backward()
+            total, reported = total.detach(), reported.detach()
+            if reducer is not None:
+                total, reported = reducer.all_reduce(total, reported)
+            opt.step()
+            return total
         total, reported = eng.run(data, T, 0, train=True, observation_params=setting["observation_params"],
                                   demand_soa=sc.demands_soa, grad_scale=grad_scale)
         if reducer is not None:
@@ -317,7 +338,7 @@ def main():
         step()  # lazy layers materialise on the first forward; keep that out of the timed region
     timer = None
     if not args.no_kernel_timing:
-        stride = args.timing_stride or (1 if (eng is not None and eng.small is not None) else 10)
+        stride = args.timing_stride or (1 if (closed_form or eng.small is not None) else 10)
         timer = eng.timer = KernelTimer(stride=stride)
     if world > 1:
         torch.distributed.barrier()
@@ -349,6 +370,7 @@ def main():
                        "name": args.workload, "scenarios_per_gpu": n, "global_scenarios": global_b, "stores": S,
                        "periods": T, "parallelism": f"scenario-sharded dp{world}",
                        "route": ("generic (Simulator.step + autograd)" if eng is None else
+                                 "whole-horizon closed-form kernel (forward-mode gradient)" if closed_form else
                                  "whole-horizon kernels" if eng.small is not None else "per-period kernels"),
                        "mean_cost_per_store_period": loss},
         }
@@ -357,7 +379,8 @@ def main():
             shape = dict(n=n, T=T, S=S, Wn=Wn_, E=E_, Ws=data["initial_inventories"].shape[2],
                          Ww=data["initial_warehouse_inventories"].shape[2] if Wn_ else 0,
                          We=data["initial_echelon_inventories"].shape[2] if E_ else 0,
-                         F=eng.dims[0], nh=len(eng.dims) - 2, n_out=eng.dims[-1], train=not args.eval)
+                         F=0 if closed_form else eng.dims[0], nh=0 if closed_form else len(eng.dims) - 2,
+                         n_out=0 if closed_form else eng.dims[-1], train=not args.eval)
             kernels = kernel_report(timer, shape, args.steps)
             rated = {k: v for k, v in kernels.items() if "bound" in v}
             if rated:

@@ -229,6 +229,44 @@ int nic_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* s
 int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
                           const float* logits_hist, NicTable2 g_reward, float* dz_hidden, float* dz_out, void* stream);
 
+/* ---- whole-horizon rollout of the closed-form policies ---------------------------------------------------------
+ * base_stock (neural_networks.py:216-229), capped_base_stock (:296-311) and echelon_stock (:231-294) for T periods of
+ * Trainer.simulate_batch (trainer.py:190-213) in ONE launch, forward AND gradient: one lane per store chain, pipelines in
+ * registers, the demand trace is the only HBM stream.  The policies' few scalar parameters enter as `levels` (device
+ * floats, the output of the reference's tiny `net` after its activation: base_stock [level]; capped [level, cap];
+ * echelon_stock [level_0 .. level_{E+1}] = cumsum(softplus(net + 10)).flip(0), upstream first) and the kernel returns
+ * d(total cost)/d(level_j) by forward-mode differentiation with torch's tie rules (csrc/closed_form_body.h); the chain
+ * through `net` stays in torch autograd.
+ * Settings: base / capped: Wn = 0, E = 0, any S (stores are independent chains: grid.y = store);
+ *           echelon_stock: S = 1, Wn = 1, 1 <= E <= 3 (serial_system).  Ws + Wn*Ww + E*We <= NIC_CF_MAX_STATE. */
+#define NIC_CF_MAX_STATE 16
+#define NIC_CF_MAX_LEVELS 5
+#define NIC_CF_BASE_STOCK 0
+#define NIC_CF_CAPPED 1
+#define NIC_CF_ECHELON 2
+typedef struct NicClosedFormDesc {
+    int32_t n_scenarios, ldb, T, t0;       /* t0 = observation_params['demand']['period_shift'] */
+    int32_t ignore_periods;                /* totals row 1 sums periods >= ignore_periods (trainer.py:209-210) */
+    int32_t policy, n_levels;              /* NIC_CF_*; 1, 2 or E + 2 */
+    int32_t S, Ws, Wn, Ww, E, We;
+    int32_t lost_demand, maximize_profit;
+    int32_t round_orders;                  /* discrete allocation (trainer.py:201-202); evaluation only */
+    const float* levels;                   /* device [n_levels] */
+    const float* demand;                   /* [T_total][S][ldb] */
+    const float* state0;                   /* [S][F][ldb], F = Ws + Wn*Ww + E*We, slots in the reference's cat order */
+    NicTable2 underage, holding, lead;     /* (s, b) */
+    NicTable2 wh_holding, wh_lead, wh_edge;
+    NicTable2 ech_holding, ech_lead;       /* (e, b) */
+} NicClosedFormDesc;
+/* Number of rows of the g_levels_partial buffer nic_closed_form_rollout fills (one per workgroup). */
+int nic_closed_form_num_partials(int32_t n_scenarios, int32_t S);
+/* Outputs, each may be NULL: reward_hist [T][S][ldb] (per-period cost per chain), totals [2][S][ldb] (sum over all periods;
+ * over periods >= ignore_periods), state_final [S][F][ldb], g_levels_partial [num_partials][n_levels]: per-workgroup sums
+ * over its chains of d(totals[0])/d(level_j) — the caller adds the rows (deterministic, no atomics).  Padding columns
+ * (b >= n_scenarios) of the outputs are left untouched. */
+int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
+                            float* g_levels_partial, void* stream);
+
 /* ---- batched demand sampler -------------------------------------------------------------------------------
  * Replaces Scenario.generate_normal_demand / generate_poisson_demand (data_handling.py:178-211) for synthetic
  * throughput runs: counter-based Philox4x32-10 keyed by (seed, global scenario index, period), so results do not

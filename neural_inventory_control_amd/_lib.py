@@ -56,6 +56,17 @@ class NicSmallRolloutDesc(C.Structure):
                                             "ech_holding", "ech_lead")])
 
 
+class NicClosedFormDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in (
+        "n_scenarios", "ldb", "T", "t0", "ignore_periods", "policy", "n_levels", "S", "Ws", "Wn", "Ww", "E", "We",
+        "lost_demand", "maximize_profit", "round_orders")]
+                + [("levels", C.c_void_p), ("demand", C.c_void_p), ("state0", C.c_void_p)]
+                + [(n, NicTable2) for n in ("underage", "holding", "lead", "wh_holding", "wh_lead", "wh_edge",
+                                            "ech_holding", "ech_lead")])
+
+
+NIC_CF_MAX_STATE, NIC_CF_MAX_LEVELS = 16, 5
+NIC_CF_BASE_STOCK, NIC_CF_CAPPED, NIC_CF_ECHELON = 0, 1, 2
 NIC_SR_MAX_INPUTS, NIC_SR_HIDDEN, NIC_SR_MAX_OUTPUTS = 16, 32, 8
 NIC_THIN_MAX_ROWS = 32
 _vp, _i32, _i64, _f32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
@@ -87,6 +98,8 @@ PROTOTYPES = {
     "nic_small_rollout_fwd": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_small_rollout_bwd": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, NicTable2, _vp, _vp, _vp]),
     "nic_round_orders": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
+    "nic_closed_form_num_partials": (C.c_int, [_i32, _i32]),
+    "nic_closed_form_rollout": (C.c_int, [C.POINTER(NicClosedFormDesc), _vp, _vp, _vp, _vp, _vp]),
     "nic_sample_demand": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i64, _u64, _i32, _vp, _vp, _i32, _vp]),
     "nic_axpy": (C.c_int, [_vp, _vp, _f32, _i64, _vp]),
 }

@@ -1,0 +1,89 @@
+// Whole-horizon rollout + forward-mode gradient of the closed-form policies (body: closed_form_body.h).  One lane = one
+// store chain for all T periods; 64-lane workgroups (one wavefront) so that 32k scenarios already spread over every CU.
+// HBM traffic: 4 B of demand per chain-period, nothing else in the period loop unless reward_hist is requested.
+// Latency-bound below ~10^6 chains (one dependent ~60-instruction chain per period per lane); the next period's demand is
+// always in flight.
+#include "nic_common.h"
+#include "closed_form_body.h"
+
+namespace {
+constexpr int kBlock = 64;
+
+template <int NP>
+__global__ __launch_bounds__(kBlock) void closed_form_kernel(NicClosedFormDesc d, const float* __restrict__ levels,
+                                                              const float* __restrict__ demand,
+                                                              const float* __restrict__ state0, float* __restrict__ reward_hist,
+                                                              float* __restrict__ totals, float* __restrict__ state_final,
+                                                              float* __restrict__ g_partial) {
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int s = blockIdx.y;
+    d.levels = levels;
+    d.demand = demand;
+    d.state0 = state0;
+    float g[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int j = 0; j < (NP > 0 ? NP : 1); ++j) g[j] = 0.f;
+    if (b < d.n_scenarios) nic::closed_form_chain<NP>(d, reward_hist, totals, state_final, s, b, g);
+    if (NP > 0 && g_partial) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            float v = g[j];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (threadIdx.x == 0) g_partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + j] = v;
+        }
+    }
+}
+
+int validate(const NicClosedFormDesc* d) {
+    NIC_REQUIRE(d, "nic_closed_form_rollout: null descriptor");
+    NIC_REQUIRE(d->levels && d->demand && d->state0, "nic_closed_form_rollout: null levels / demand / state0");
+    NIC_REQUIRE(d->n_scenarios > 0 && d->ldb >= d->n_scenarios && d->T > 0 && d->t0 >= 0 && d->S >= 1,
+                "nic_closed_form_rollout: bad sizes");
+    NIC_REQUIRE(d->policy >= NIC_CF_BASE_STOCK && d->policy <= NIC_CF_ECHELON, "nic_closed_form_rollout: unknown policy %d", d->policy);
+    const int F = d->Ws + d->Wn * d->Ww + d->E * d->We;
+    NIC_REQUIRE(d->Ws >= 2 && F <= NIC_CF_MAX_STATE, "nic_closed_form_rollout: %d state slots per chain (need Ws >= 2, at most %d)", F,
+                NIC_CF_MAX_STATE);
+    if (d->policy == NIC_CF_ECHELON) {
+        NIC_REQUIRE(d->S == 1 && d->Wn == 1 && d->E >= 1 && d->E <= 3 && d->Ww >= 2 && d->We >= 2,
+                    "nic_closed_form_rollout: echelon_stock needs the serial system (S = 1, Wn = 1, 1 <= E <= 3)");
+        NIC_REQUIRE(d->n_levels == d->E + 2, "nic_closed_form_rollout: echelon_stock takes E + 2 levels");
+    } else {
+        NIC_REQUIRE(d->Wn == 0 && d->E == 0, "nic_closed_form_rollout: base-stock policies run on settings without warehouses");
+        NIC_REQUIRE(d->n_levels == (d->policy == NIC_CF_CAPPED ? 2 : 1), "nic_closed_form_rollout: wrong number of levels");
+    }
+    NIC_REQUIRE(d->underage.p && d->holding.p && d->lead.p, "nic_closed_form_rollout: null store table");
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int nic_closed_form_num_partials(int32_t n_scenarios, int32_t S) {
+    if (n_scenarios <= 0 || S <= 0) return 0;
+    return nic::ceil_div(n_scenarios, kBlock) * S;
+}
+
+int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
+                            float* g_levels_partial, void* stream) {
+    if (int e = validate(d)) return e;
+    NIC_REQUIRE(!(d->round_orders && g_levels_partial), "nic_closed_form_rollout: rounded orders have no gradient");
+    const dim3 grid(nic::ceil_div(d->n_scenarios, kBlock), d->S), block(kBlock);
+    hipStream_t s = nic::as_stream(stream);
+    const int np = g_levels_partial ? d->n_levels : 0;
+    nic::note_kernelf("closed_form_kernel<%d>", np);
+#define NIC_CF_LAUNCH(NP)                                                                                                 \
+    hipLaunchKernelGGL(closed_form_kernel<NP>, grid, block, 0, s, *d, d->levels, d->demand, d->state0, reward_hist, totals, \
+                       state_final, g_levels_partial)
+    switch (np) {
+        case 0: NIC_CF_LAUNCH(0); break;
+        case 1: NIC_CF_LAUNCH(1); break;
+        case 2: NIC_CF_LAUNCH(2); break;
+        case 3: NIC_CF_LAUNCH(3); break;
+        case 4: NIC_CF_LAUNCH(4); break;
+        default: NIC_CF_LAUNCH(5); break;
+    }
+#undef NIC_CF_LAUNCH
+    return nic::check_launch("nic_closed_form_rollout");
+}
+}

@@ -9,7 +9,8 @@ heads (softmax share of warehouse stock, sigmoid x upstream on-hand, softplus) a
 csrc/policy_heads.hip.  `trainer.Trainer` additionally recognises these architectures and runs the whole horizon
 through `rollout.FusedRollout` (no autograd graph at all); the modules below are the general path and the plugin base.
 
-Out of scope this round: GNN, data-driven / quantile / just-in-time policies.
+The closed-form policies (base_stock, capped_base_stock, echelon_stock) additionally expose `closed_form_levels()` for the
+whole-horizon kernel of closed_form.py; `GNN` lives here too.
 """
 import copy
 
@@ -279,35 +280,51 @@ class VanillaOneStore(MyNeuralNetwork):
         return {"stores": _SoftplusHead.apply(self.net["master"](x)).unsqueeze(2)}
 
 
-class BaseStock(MyNeuralNetwork):
+class _ClosedFormPolicy(MyNeuralNetwork):
+    """Policies whose `net` maps the constant 0 to a handful of scalar levels (neural_networks.py:228): the trainer runs them
+    through the whole-horizon kernel of closed_form.py, which takes `closed_form_levels()`; `forward` is the per-period form
+    for `Simulator.step` callers."""
+
+    def _net_of_zero(self):
+        dev = next(self.parameters()).device
+        return self.net["master"](torch.zeros(1, device=dev))
+
+    def closed_form_levels(self):
+        return self._net_of_zero()
+
+
+class BaseStock(_ClosedFormPolicy):
     """neural_networks.py:216-229."""
 
     def forward(self, observation):
         x = observation["store_inventories"]
         inv_pos = x.sum(dim=2)
-        level = self.net["master"](torch.zeros(1, device=x.device))
+        level = self.closed_form_levels()
         return {"stores": torch.clip(level - inv_pos, min=0).unsqueeze(2)}
 
 
-class CappedBaseStock(MyNeuralNetwork):
+class CappedBaseStock(_ClosedFormPolicy):
     """neural_networks.py:296-311."""
 
     def forward(self, observation):
         x = observation["store_inventories"]
         inv_pos = x.sum(dim=2)
-        out = self.net["master"](torch.zeros(1, device=x.device))
+        out = self.closed_form_levels()
         return {"stores": torch.clip(out[0] - inv_pos, min=torch.zeros(1, device=x.device), max=out[1]).unsqueeze(2)}
 
 
-class EchelonStock(MyNeuralNetwork):
+class EchelonStock(_ClosedFormPolicy):
     """neural_networks.py:231-294 (locations ordered upstream -> downstream; cumulative softplus base levels)."""
+
+    def closed_form_levels(self):
+        x = self.activation_functions["softplus"](self._net_of_zero() + 10.0)
+        return torch.cumsum(x, dim=0).flip(dims=[0])
 
     def forward(self, observation):
         s_inv, w_inv, e_inv = (observation[k] for k in ("store_inventories", "warehouse_inventories",
                                                         "echelon_inventories"))
         E = e_inv.size(1)
-        x = self.activation_functions["softplus"](self.net["master"](torch.zeros(1, device=s_inv.device)) + 10.0)
-        levels = torch.cumsum(x, dim=0).flip(dims=[0])
+        levels = self.closed_form_levels()
         pos = torch.concat((e_inv.sum(dim=2), w_inv.sum(dim=2), s_inv.sum(dim=2)), dim=1)
         upstream = torch.concat((1000000 * torch.ones_like(w_inv[:, :, 0]), e_inv[:, :, 0], w_inv[:, :, 0]), dim=1)
         want = torch.clip(torch.stack([levels[k] - pos[:, k:].sum(dim=1) for k in range(2 + E)], dim=1), min=0)

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import parallel
+from .closed_form import ClosedFormRollout
 from .loss_functions import PolicyLoss
 from .rollout import FusedRollout
 
@@ -134,8 +135,8 @@ class Trainer:
                     epoch_report += rep.detach()
                     continue
                 graphed = (train and model.trainable and self.use_step_graph and not discrete_allocation
-                           and not (self.use_fused_rollout and FusedRollout.supports(model)
-                                    and self._plain_observation(observation_params)))
+                           and not (self.use_fused_rollout and self._plain_observation(observation_params)
+                                    and (FusedRollout.supports(model) or ClosedFormRollout.supports(model))))
                 if graphed:
                     total_reward, reward_to_report = self._graphed_generic_step(
                         loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
@@ -175,7 +176,18 @@ class Trainer:
             train = torch.is_grad_enabled() and bool(getattr(model, "trainable", True))
         train = bool(train) and torch.is_grad_enabled()
         # (rounded actions have zero gradient: a training step with discrete allocation keeps the reference's generic route;
-        # a custom loss module is honoured by the generic route - the fused engine implements PolicyLoss = reward.sum())
+        # a custom loss module is honoured by the generic route - the fused engines implement PolicyLoss = reward.sum())
+        fusable = (self.use_fused_rollout and not (discrete_allocation and train) and isinstance(loss_function, PolicyLoss)
+                   and self._plain_observation(observation_params))
+        if fusable and ClosedFormRollout.supports(model):
+            # closed-form policies: ONE kernel for the whole horizon, gradient included (forward mode); the returned total
+            # is an ordinary differentiable tensor, so the caller's mean_loss.backward() reaches the policy's parameters
+            eng = self._engines.get((id(model), "closed_form"))
+            if eng is None or eng.model is not model:
+                eng = self._engines[(id(model), "closed_form")] = ClosedFormRollout(model, problem_params, self.device)
+            if eng.shapes_ok(data_batch):
+                return eng.run(data_batch, periods, ignore_periods, train=train, observation_params=observation_params,
+                               discrete_allocation=discrete_allocation)
         if self.use_fused_rollout and not (discrete_allocation and train) and FusedRollout.supports(model) \
                 and isinstance(loss_function, PolicyLoss) and self._plain_observation(observation_params):
             # one engine per (policy, training / evaluation): an epoch alternates a training pass and a dev pass with

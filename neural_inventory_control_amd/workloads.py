@@ -92,6 +92,12 @@ def many_warehouses(n_stores=64, n_warehouses=3, seed=0):
     return s_
 
 
+def _closed_form(name, n_out, out_act="softplus", bias=10.0):
+    """base_stock.yml / capped_base_stock.yml (softplus output, initial bias 10) and echelon_stock.yml (neither)."""
+    return {"name": name, "inner_layer_activations": {"master": None}, "output_layer_activation": {"master": out_act},
+            "neurons_per_hidden_layer": {"master": []}, "output_sizes": {"master": n_out}, "initial_bias": {"master": bias}}
+
+
 def gnn_policy():
     """gnn.yml of the reference: five 32-wide MLPs (elu inside; softplus on the per-edge output, bias 5.0)."""
     mods = ("initial_node", "initial_edge", "node_update", "edge_update", "output")
@@ -115,12 +121,14 @@ WORKLOADS = {
              "serial_system 4 echelons, 16384 scenarios/GPU x T=100, vanilla_serial"),
     "cfg5": (lambda: many_warehouses(64, 3), _mlp("vanilla_warehouse", [512, 512, 512], None, 4), 32768, 70,
              "many_warehouses_lost_demand 3x64 stores, 32768 scenarios/GPU x T=70, vanilla_warehouse 512x3"),
-    # closed-form policy on the generic route (base_stock.yml): one trainable level, everything else arithmetic
-    "base_stock": (lambda: one_store(False, False),
-                   {"name": "base_stock", "inner_layer_activations": {"master": None},
-                    "output_layer_activation": {"master": "softplus"}, "neurons_per_hidden_layer": {"master": []},
-                    "output_sizes": {"master": 1}, "initial_bias": {"master": 10.0}}, 32768, 100,
-                   "one_store_backlogged + base_stock, 32768 scenarios x T=100 (generic route: Simulator.step + autograd)"),
+    # closed-form policies (base_stock.yml, echelon_stock.yml): a few trainable levels, everything else arithmetic - the
+    # "env-only" number of SURVEY 8(d): whole horizon + gradient in one launch, the demand trace is the only HBM stream
+    "base_stock": (lambda: one_store(False, False), _closed_form("base_stock", 1), 32768, 100,
+                   "one_store_backlogged + base_stock, 32768 scenarios x T=100"),
+    "base_stock_1m": (lambda: one_store(False, False), _closed_form("base_stock", 1), 1 << 20, 100,
+                      "one_store_backlogged + base_stock, 1,048,576 scenarios x T=100 (enough chains in flight to be HBM-bound)"),
+    "echelon_stock": (serial_system, _closed_form("echelon_stock", 4, None, None), 131072, 100,
+                      "serial_system 4 echelons + echelon_stock, 131072 scenarios x T=100"),
     # the GNN policy on cfg3's graph (generic route: Simulator.step + autograd, MLPs on the matrix cores)
     "gnn": (lambda: one_warehouse(16), gnn_policy(), 8192, 50,
             "one_warehouse_lost_demand, 16 stores, 8192 scenarios x T=50, gnn (5 x 32-wide MLPs, 1 message-passing step)"),

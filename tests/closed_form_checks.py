@@ -1,0 +1,102 @@
+"""Parity of the whole-horizon closed-form rollout (closed_form_body.h: forward AND forward-mode gradient) against the
+reference's golden vectors: per-period rewards, final state, totals and d(mean_loss)/d(theta).  Backend-agnostic like
+kernel_checks.py: the host build of the body (CPU suite) and the HIP kernel through the C ABI (GPU suite) run this."""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from golden_io import Golden
+from neural_inventory_control_amd import _lib, closed_form as cf
+from neural_inventory_control_amd.layout import EnvProblem
+
+CLOSED_FORM_CASES = ["cfg2_one_store_backlogged_base_stock", "cfg2_one_store_backlogged_capped", "cfg4_serial_echelon_stock"]
+_ACT = {None: lambda x: x, "softplus": F.softplus, "relu": F.relu, "elu": F.elu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+
+
+def levels_from_params(nn_params, params):
+    """The reference's tiny `net` applied to the constant 0, then the policy's own transformation (differentiable, CPU)."""
+    w = params["net.master.0.weight"].clone().requires_grad_(True)
+    b = params["net.master.0.bias"].clone().requires_grad_(True)
+    out = _ACT[nn_params["output_layer_activation"]["master"]](F.linear(torch.zeros(1), w, b))
+    if nn_params["name"] == "echelon_stock":
+        out = torch.cumsum(F.softplus(out + 10.0), dim=0).flip(dims=[0])
+    return out, (w, b)
+
+
+def host_launch(h):
+    def run(desc, rewards, totals, final, n_levels, want_grad):
+        g = (C.c_double * n_levels)() if want_grad else None
+        h.hostsim_closed_form_rollout(desc, rewards.data_ptr(), totals.data_ptr(), final.data_ptr(), g)
+        return torch.tensor(list(g), dtype=torch.float64) if want_grad else None
+    return run
+
+
+def hip_launch():
+    def run(desc, rewards, totals, final, n_levels, want_grad):
+        n_part = _lib.lib().nic_closed_form_num_partials(desc.n_scenarios, desc.S)
+        part = torch.zeros(n_part, n_levels, device=rewards.device) if want_grad else None
+        _lib.check(_lib.lib().nic_closed_form_rollout(desc, rewards.data_ptr(), totals.data_ptr(), final.data_ptr(),
+                                                      _lib.ptr(part), _lib.current_stream()))
+        torch.cuda.synchronize()
+        return part.double().sum(dim=0).cpu() if want_grad else None
+    return run
+
+
+def run_case(name, launch, dev, profit=False):
+    g = Golden(name)
+    c = g.fresh_config()
+    c["problem_params"]["maximize_profit"] = profit
+    data = {k: v.to(dev) for k, v in g.data.items()}
+    prob = EnvProblem(c["problem_params"], data, dev)
+    pol = c["policy"]
+    assert cf.supports_shapes(pol, prob), name
+    T, B, ld, S = c["periods"], c["n"], prob.ldb, prob.S
+    levels, (w, b) = levels_from_params(c["nn_params"], g.params)
+    lv = levels.detach().float().contiguous().to(dev)
+    demand = torch.zeros(data["demands"].shape[2], S, ld, device=dev)
+    demand[:, :, :B] = data["demands"].permute(2, 1, 0)
+    state0 = cf.pack_state0(data, prob)
+    Fs = state0.shape[1]
+    rewards, totals, final = (torch.zeros(T, S, ld, device=dev), torch.zeros(2, S, ld, device=dev),
+                              torch.zeros(S, Fs, ld, device=dev))
+    desc = cf.make_desc(prob, pol, T, 0, c["ignore"], lv, demand, state0)
+    g_levels = launch(desc, rewards, totals, final, lv.numel(), True)
+    out = dict(rewards=rewards[:, :, :B].sum(dim=1).cpu(), total=float(totals[0].double().sum()),
+               reported=float(totals[1].double().sum()), final=final.cpu(), prob=prob, golden=g, config=c)
+    # chain through the tiny net on the CPU: d mean_loss / d theta = (1 / (B T S)) * sum_j g_levels[j] * d level_j / d theta
+    levels.backward((g_levels / (B * T * c["problem_params"]["n_stores"])).float())
+    out["grads"] = {"net.master.0.weight": w.grad, "net.master.0.bias": b.grad}
+    # forward-only launch (no tangents) must reproduce the same costs
+    r2, t2, f2 = torch.zeros_like(rewards), torch.zeros_like(totals), torch.zeros_like(final)
+    launch(desc, r2, t2, f2, lv.numel(), False)
+    assert torch.equal(r2, rewards) and torch.equal(t2, totals) and torch.equal(f2, final)
+    return out
+
+
+def check_against_golden(out):
+    g, c, prob = out["golden"], out["config"], out["prob"]
+    B, T = c["n"], c["periods"]
+    ref_r = g.tensor("rewards")
+    torch.testing.assert_close(out["rewards"], ref_r, rtol=2e-6, atol=1e-5)
+    tot_b, ref_b = out["rewards"].double().sum(dim=0), ref_r.double().sum(dim=0)
+    assert float(((tot_b - ref_b).abs() / ref_b.abs().clamp_min(1e-9)).max()) <= 1e-5
+    assert abs(out["total"] - float(g.z["total"])) <= 1e-6 * abs(float(g.z["total"]))
+    assert abs(out["reported"] - float(g.z["reported"])) <= 1e-6 * abs(float(g.z["reported"]))
+    fin = g.states(T)
+    want = [fin["store_inventories"].reshape(B, -1)]
+    if prob.Wn:
+        want.append(fin["warehouse_inventories"].reshape(B, -1))
+    if prob.E:
+        want.append(fin["echelon_inventories"].reshape(B, -1))
+    torch.testing.assert_close(out["final"][0, :, :B].t(), torch.cat(want, dim=1), rtol=1e-5, atol=1e-4)
+    worst = 0.0
+    for k, ref in g.grads.items():
+        got = out["grads"][k]
+        if float(ref.abs().max()) == 0.0:  # the weight multiplies the constant 0: exactly zero upstream too
+            assert got is None or float(got.abs().max()) == 0.0, k
+            continue
+        rel = float((got - ref).norm() / ref.norm())
+        worst = max(worst, rel)
+        assert rel <= 2e-5, (k, rel)
+    return worst

@@ -4,6 +4,7 @@
 #include "../../neural_inventory_control_amd/csrc/env_step_body.h"
 #include "../../neural_inventory_control_amd/csrc/policy_heads_body.h"
 #include "../../neural_inventory_control_amd/csrc/small_rollout_body.h"
+#include "../../neural_inventory_control_amd/csrc/closed_form_body.h"
 
 template <int MAXW>
 static void fwd_all(const NicEnvStepIO& io, float* so, float* wo, float* eo, float* r) {
@@ -14,6 +15,16 @@ static void bwd_all(const NicEnvStepIO& io, const float* gso, const float* gwo, 
                     float* gsi, float* gwi, float* gei, float* gas, float* gaw, float* gae) {
     for (int64_t b = 0; b < io.dims.n_scenarios; ++b)
         nic::env_step_bwd_scenario<MAXW>(io, gso, gwo, geo, gr, gsi, gwi, gei, gas, gaw, gae, b);
+}
+
+template <int NP>
+static void closed_form_all(const NicClosedFormDesc& d, float* reward_hist, float* totals, float* state_final, double* g_levels) {
+    for (int s = 0; s < d.S; ++s)
+        for (int64_t b = 0; b < d.n_scenarios; ++b) {
+            float g[NP > 0 ? NP : 1] = {0.f};
+            nic::closed_form_chain<NP>(d, reward_hist, totals, state_final, s, b, g);
+            for (int j = 0; j < NP; ++j) g_levels[j] += g[j];
+        }
 }
 
 extern "C" {
@@ -76,6 +87,21 @@ int hostsim_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_
         if (d->n_hidden == 1) nic::small_rollout_bwd_scenario<1>(*d, states_hist, hidden_hist, logits_hist, g_reward, dz_hidden, dz_out, b);
         else if (d->n_hidden == 2) nic::small_rollout_bwd_scenario<2>(*d, states_hist, hidden_hist, logits_hist, g_reward, dz_hidden, dz_out, b);
         else nic::small_rollout_bwd_scenario<3>(*d, states_hist, hidden_hist, logits_hist, g_reward, dz_hidden, dz_out, b);
+    }
+    return 0;
+}
+
+// g_levels: [n_levels] doubles (sum over all chains of d total / d level_j), or NULL for a forward-only run
+int hostsim_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
+                                double* g_levels) {
+    const int np = g_levels ? d->n_levels : 0;
+    switch (np) {
+        case 0: closed_form_all<0>(*d, reward_hist, totals, state_final, g_levels); break;
+        case 1: closed_form_all<1>(*d, reward_hist, totals, state_final, g_levels); break;
+        case 2: closed_form_all<2>(*d, reward_hist, totals, state_final, g_levels); break;
+        case 3: closed_form_all<3>(*d, reward_hist, totals, state_final, g_levels); break;
+        case 4: closed_form_all<4>(*d, reward_hist, totals, state_final, g_levels); break;
+        default: closed_form_all<5>(*d, reward_hist, totals, state_final, g_levels); break;
     }
     return 0;
 }

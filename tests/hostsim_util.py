@@ -32,7 +32,7 @@ def load():
         return _h
     os.makedirs(OUT_DIR, exist_ok=True)
     deps = [SRC] + [os.path.join(HERE, "..", "neural_inventory_control_amd", "csrc", f)
-                    for f in ("env_step_body.h", "policy_heads_body.h", "small_rollout_body.h")] + [os.path.join(HERE, "..", "include", "nic_rollout.h")]
+                    for f in ("env_step_body.h", "policy_heads_body.h", "small_rollout_body.h", "closed_form_body.h")] + [os.path.join(HERE, "..", "include", "nic_rollout.h")]
     if not os.path.isfile(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         subprocess.check_call(["g++"] + FLAGS + ["-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", OUT])
     h = C.CDLL(OUT)
@@ -49,5 +49,6 @@ def load():
     SRP = C.POINTER(_lib.NicSmallRolloutDesc)
     h.hostsim_small_rollout_fwd.argtypes = [SRP, vp, vp, vp, vp, vp]
     h.hostsim_small_rollout_bwd.argtypes = [SRP, vp, vp, vp, _lib.NicTable2, vp, vp]
+    h.hostsim_closed_form_rollout.argtypes = [C.POINTER(_lib.NicClosedFormDesc), vp, vp, vp, vp]
     _h = h
     return h

@@ -29,3 +29,27 @@ def test_two_rank_training_equals_single_process():
                    "127.0.0.1", "--master-port", "29541", helper], {"NIC_DIST_BACKEND": "gloo"})
     assert single["world"] == 1 and double["world"] == 2
     assert abs(single["test_loss"] - double["test_loss"]) <= 1e-6 * abs(single["test_loss"]), (single, double)
+
+
+@pytest.mark.parametrize("name,n_total,T", [("cfg3", 300, 9), ("cfg1", 130, 7)])
+def test_sharded_device_scenarios_equal_single_process(tmp_path, name, n_total, T):
+    """SURVEY §8e 'extra exchange': two ranks generate their rows with the HIP sampler; the initial inventories use the GLOBAL
+    per-store demand mean (one S-float all-reduce) and the global multiplier rows — the concatenation is the 1-process set."""
+    import torch
+    helper = os.path.join(HERE, "shard_helper.py")
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir()
+    two.mkdir()
+    args = [name, str(n_total), str(T)]
+    r = subprocess.run([sys.executable, helper, str(one)] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, NIC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29547", helper, str(two)] + args, capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    whole = torch.load(one / "rank0.pt")
+    parts = [torch.load(two / f"rank{k}.pt") for k in (0, 1)]
+    for k, v in whole.items():
+        cat = torch.cat([p[k] for p in parts], dim=0)
+        assert torch.equal(cat, v), k

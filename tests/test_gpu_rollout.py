@@ -593,6 +593,7 @@ def test_captured_generic_training_step_matches_eager(name):
         _load(model, g)
         tr = Trainer(device=DEV)
         tr.use_step_graph = graph
+        tr.use_fused_rollout = False  # this test is about the GENERIC route (the closed-form cases have a fused kernel too)
         tr._global_batch = c["n"]
         sim, lf = Simulator(device=DEV), PolicyLoss()
         out = []
@@ -691,6 +692,7 @@ def test_trainer_epochs_with_step_graph_match_eager_training():
         _load(model, g)
         opt = torch.optim.Adam(model.parameters(), lr=0.05)
         tr = Trainer(device=DEV)
+        tr.use_fused_rollout = False  # generic route: Simulator.step + autograd (optionally replayed from a HIP graph)
         tr.use_step_graph = graph
         loader = DeviceBatches(ds, 20, shuffle=False, device=DEV)
         losses = [tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, c["periods"], c["problem_params"],
@@ -703,3 +705,89 @@ def test_trainer_epochs_with_step_graph_match_eager_training():
     for a, b in zip(pe, pg):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     assert le[-1] < le[0]  # and it learns
+
+
+# ---- closed-form policies: whole horizon + forward-mode gradient in one kernel (csrc/closed_form.hip) -------------------
+
+CLOSED_FORM_CASES = ["cfg2_one_store_backlogged_base_stock", "cfg2_one_store_backlogged_capped", "cfg4_serial_echelon_stock"]
+
+
+@pytest.mark.parametrize("name", CLOSED_FORM_CASES)
+def test_closed_form_kernel_matches_reference(name):
+    """nic_closed_form_rollout through the C ABI against the reference's golden vectors (rewards, final state, gradient)."""
+    import closed_form_checks as cfc
+    worst = cfc.check_against_golden(cfc.run_case(name, cfc.hip_launch(), DEV))
+    assert worst <= GRAD_TOL
+
+
+@pytest.mark.parametrize("name", CLOSED_FORM_CASES)
+def test_trainer_takes_closed_form_route_and_matches_reference(name):
+    """`Trainer.simulate_batch` + the reference idiom `(total / n).backward()` on a closed-form policy: one kernel for the
+    horizon, gradients reach net.master.0.* through autograd; same numbers as the generic Simulator.step route."""
+    from neural_inventory_control_amd.closed_form import ClosedFormRollout
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    n = c["n"] * c["periods"] * c["problem_params"]["n_stores"]
+    res = {}
+    for fused in (True, False):
+        model = _model(g, c)
+        sim, tr = Simulator(device=DEV), Trainer(device=DEV)
+        tr.use_fused_rollout = fused
+        with torch.no_grad():
+            obs, _ = sim.reset(c["periods"], c["problem_params"], data, c["observation_params"])
+            o = dict(obs)
+            o["internal_data"] = sim._internal_data
+            model(o)  # materialises the lazy layer
+        _load(model, g)
+        model.zero_grad()
+        total, reported = tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data,
+                                            c["observation_params"], c["ignore"], False)
+        (total / n).backward()
+        torch.cuda.synchronize()
+        took = any(isinstance(e, ClosedFormRollout) for e in tr._engines.values())
+        assert took == fused
+        assert abs(float(total) - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
+        assert abs(float(reported) - float(g.z["reported"])) <= 1e-5 * abs(float(g.z["reported"]))
+        _check_grads(model, g, GRAD_TOL)
+        res[fused] = float(total)
+        # evaluation (no_grad) and discrete allocation run the same kernel without tangents
+        with torch.no_grad():
+            t_eval, _ = tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data,
+                                          c["observation_params"], c["ignore"], False)
+            t_disc, _ = tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data,
+                                          c["observation_params"], c["ignore"], True)
+        assert abs(float(t_eval) - float(total)) <= 1e-6 * abs(float(total))
+        res[(fused, "disc")] = float(t_disc)
+    assert abs(res[True] - res[False]) <= 2e-6 * abs(res[False])
+    assert abs(res[(True, "disc")] - res[(False, "disc")]) <= 2e-6 * abs(res[(False, "disc")])
+    assert res[(True, "disc")] != res[True]
+
+
+def test_closed_form_multi_store_and_training():
+    """base_stock on 5 independent stores (Wn = 0): every store is its own chain (grid.y); a few Adam steps through
+    `Trainer.do_one_epoch` lower the cost, and the fused route follows the generic route step for step."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    setting, policy, _, _, _ = workloads.get("base_stock")
+    setting["problem_params"]["n_stores"] = 5
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    T, n = 40, 300
+    finals = {}
+    for fused in (True, False):
+        sc = Scenario(T, setting["problem_params"], setting["store_params"], None, None, n, obs, dict(setting["seeds"]))
+        ds = DatasetCreator().create_datasets(sc, split=False)
+        torch.manual_seed(3)
+        model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+        opt = torch.optim.Adam(model.parameters(), lr=0.3)
+        tr, sim = Trainer(device=DEV), Simulator(device=DEV)
+        tr.use_fused_rollout = fused
+        loader = DeviceBatches(ds, 128, shuffle=False, device=DEV)
+        losses = [tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, T, setting["problem_params"], obs, train=True,
+                                  ignore_periods=10)[1] for _ in range(6)]
+        assert losses[-1] < losses[0]
+        finals[fused] = (losses, [p.detach().clone() for p in model.parameters()])
+    for a, b in zip(finals[True][0], finals[False][0]):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    for a, b in zip(finals[True][1], finals[False][1]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
