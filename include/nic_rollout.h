@@ -238,8 +238,7 @@ int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist
  * d(total cost)/d(level_j) by forward-mode differentiation with torch's tie rules (csrc/closed_form_body.h); the chain
  * through `net` stays in torch autograd.
  * Settings: base / capped: Wn = 0, E = 0, any S (stores are independent chains: grid.y = store);
- *           echelon_stock: S = 1, Wn = 1, 1 <= E <= 3 (serial_system).  Ws + Wn*Ww + E*We <= NIC_CF_MAX_STATE. */
-#define NIC_CF_MAX_STATE 16
+ *           echelon_stock: S = 1, Wn = 1, 1 <= E <= 3 (serial_system).  Every pipeline has 2..NIC_MAX_SLOTS slots. */
 #define NIC_CF_MAX_LEVELS 5
 #define NIC_CF_BASE_STOCK 0
 #define NIC_CF_CAPPED 1

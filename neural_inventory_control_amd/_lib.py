@@ -65,7 +65,7 @@ class NicClosedFormDesc(C.Structure):
                                             "ech_holding", "ech_lead")])
 
 
-NIC_CF_MAX_STATE, NIC_CF_MAX_LEVELS = 16, 5
+NIC_CF_MAX_LEVELS = 5
 NIC_CF_BASE_STOCK, NIC_CF_CAPPED, NIC_CF_ECHELON = 0, 1, 2
 NIC_SR_MAX_INPUTS, NIC_SR_HIDDEN, NIC_SR_MAX_OUTPUTS = 16, 32, 8
 NIC_THIN_MAX_ROWS = 32

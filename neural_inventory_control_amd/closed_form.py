@@ -19,8 +19,7 @@ POLICY_ID = {"base_stock": _lib.NIC_CF_BASE_STOCK, "capped_base_stock": _lib.NIC
 
 
 def supports_shapes(name, prob: EnvProblem):
-    F = prob.Ws + prob.Wn * prob.Ww + prob.E * prob.We
-    if name not in POLICY_ID or F > _lib.NIC_CF_MAX_STATE:
+    if name not in POLICY_ID or max(prob.Ws, prob.Ww, prob.We) > _lib.NIC_MAX_SLOTS:
         return False
     if name == "echelon_stock":
         return prob.S == 1 and prob.Wn == 1 and 1 <= prob.E <= 3

@@ -9,7 +9,7 @@
 namespace {
 constexpr int kBlock = 64;
 
-template <int NP>
+template <int NP, int MF, bool CHAIN>
 __global__ __launch_bounds__(kBlock) void closed_form_kernel(NicClosedFormDesc d, const float* __restrict__ levels,
                                                               const float* __restrict__ demand,
                                                               const float* __restrict__ state0, float* __restrict__ reward_hist,
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kBlock) void closed_form_kernel(NicClosedFormDesc d
     float g[NP > 0 ? NP : 1];
 #pragma unroll
     for (int j = 0; j < (NP > 0 ? NP : 1); ++j) g[j] = 0.f;
-    if (b < d.n_scenarios) nic::closed_form_chain<NP>(d, reward_hist, totals, state_final, s, b, g);
+    if (b < d.n_scenarios) nic::closed_form_chain<NP, MF, CHAIN>(d, reward_hist, totals, state_final, s, b, g);
     if (NP > 0 && g_partial) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -42,8 +42,9 @@ int validate(const NicClosedFormDesc* d) {
                 "nic_closed_form_rollout: bad sizes");
     NIC_REQUIRE(d->policy >= NIC_CF_BASE_STOCK && d->policy <= NIC_CF_ECHELON, "nic_closed_form_rollout: unknown policy %d", d->policy);
     const int F = d->Ws + d->Wn * d->Ww + d->E * d->We;
-    NIC_REQUIRE(d->Ws >= 2 && F <= NIC_CF_MAX_STATE, "nic_closed_form_rollout: %d state slots per chain (need Ws >= 2, at most %d)", F,
-                NIC_CF_MAX_STATE);
+    NIC_REQUIRE(d->Ws >= 2 && d->Ws <= NIC_MAX_SLOTS && d->Ww <= NIC_MAX_SLOTS && d->We <= NIC_MAX_SLOTS,
+                "nic_closed_form_rollout: pipelines need 2..%d slots", NIC_MAX_SLOTS);
+    (void)F;
     if (d->policy == NIC_CF_ECHELON) {
         NIC_REQUIRE(d->S == 1 && d->Wn == 1 && d->E >= 1 && d->E <= 3 && d->Ww >= 2 && d->We >= 2,
                     "nic_closed_form_rollout: echelon_stock needs the serial system (S = 1, Wn = 1, 1 <= E <= 3)");
@@ -71,17 +72,37 @@ int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, floa
     const dim3 grid(nic::ceil_div(d->n_scenarios, kBlock), d->S), block(kBlock);
     hipStream_t s = nic::as_stream(stream);
     const int np = g_levels_partial ? d->n_levels : 0;
-    nic::note_kernelf("closed_form_kernel<%d>", np);
-#define NIC_CF_LAUNCH(NP)                                                                                                 \
-    hipLaunchKernelGGL(closed_form_kernel<NP>, grid, block, 0, s, *d, d->levels, d->demand, d->state0, reward_hist, totals, \
-                       state_final, g_levels_partial)
-    switch (np) {
-        case 0: NIC_CF_LAUNCH(0); break;
-        case 1: NIC_CF_LAUNCH(1); break;
-        case 2: NIC_CF_LAUNCH(2); break;
-        case 3: NIC_CF_LAUNCH(3); break;
-        case 4: NIC_CF_LAUNCH(4); break;
-        default: NIC_CF_LAUNCH(5); break;
+    const bool chain = d->policy == NIC_CF_ECHELON;
+    int w = d->Ws;  // register slots per pipeline: the longest live pipeline, rounded up to 4 / 8 / 16
+    if (chain) w = w > d->Ww ? w : d->Ww, w = w > d->We ? w : d->We;
+    const int mf = w <= 4 ? 4 : (w <= 8 ? 8 : 16);
+    nic::note_kernelf("closed_form_kernel<%d,%d,%s>", np, mf, chain ? "true" : "false");
+#define NIC_CF_LAUNCH(NP, MF, CH)                                                                                          \
+    hipLaunchKernelGGL((closed_form_kernel<NP, MF, CH>), grid, block, 0, s, *d, d->levels, d->demand, d->state0, reward_hist, \
+                       totals, state_final, g_levels_partial)
+    if (chain) {  // echelon_stock on the serial system: E + 2 = 3..5 levels
+#define NIC_CF_CHAIN(MF)                                        \
+    do {                                                        \
+        if (np == 0) NIC_CF_LAUNCH(0, MF, true);                \
+        else if (np == 3) NIC_CF_LAUNCH(3, MF, true);           \
+        else if (np == 4) NIC_CF_LAUNCH(4, MF, true);           \
+        else NIC_CF_LAUNCH(5, MF, true);                        \
+    } while (0)
+        if (mf == 4) NIC_CF_CHAIN(4);
+        else if (mf == 8) NIC_CF_CHAIN(8);
+        else NIC_CF_CHAIN(16);
+#undef NIC_CF_CHAIN
+    } else {      // base_stock (1 level) / capped_base_stock (2 levels) on independent stores
+#define NIC_CF_STORE(MF)                                        \
+    do {                                                        \
+        if (np == 0) NIC_CF_LAUNCH(0, MF, false);               \
+        else if (np == 1) NIC_CF_LAUNCH(1, MF, false);          \
+        else NIC_CF_LAUNCH(2, MF, false);                       \
+    } while (0)
+        if (mf == 4) NIC_CF_STORE(4);
+        else if (mf == 8) NIC_CF_STORE(8);
+        else NIC_CF_STORE(16);
+#undef NIC_CF_STORE
     }
 #undef NIC_CF_LAUNCH
     return nic::check_launch("nic_closed_form_rollout");

@@ -20,7 +20,6 @@
 
 namespace nic {
 
-constexpr int CF_MAXF = NIC_CF_MAX_STATE;  // state slots of one chain: Ws + Wn*Ww + E*We
 constexpr int CF_MAXE = 3;
 
 template <int NP>
@@ -157,101 +156,103 @@ struct CfOrders {
     Dual<NP> store, wh, ech[CF_MAXE];
 };
 
-template <int NP>
-NIC_HD Dual<NP> cf_at(const Dual<NP> (&a)[CF_MAXF], int idx) {
-    Dual<NP> r = dconst<NP>(0.f);
+// One pipeline = MW register slots (slot 0 = on hand); W <= MW of them are live.  All slot indices below are compile-time
+// after unrolling; only the comparison with the (per-scenario) lead time and with W is data.
+template <int NP, int MW>
+struct CfPipe {
+    Dual<NP> s[MW];
+};
+
+// sum of the live slots, left to right (x.sum(dim=2) over one pipeline, neural_networks.py:226)
+template <int NP, int MW>
+NIC_HD Dual<NP> cf_pipe_sum(const CfPipe<NP, MW>& p, int W) {
+    Dual<NP> r = p.s[0];
 #pragma unroll
-    for (int k = 0; k < CF_MAXF; ++k)
-        if (k == idx) r = a[k];
+    for (int k = 1; k < MW; ++k)
+        if (k < W) r = r + p.s[k];
     return r;
 }
 
-// sum of the slots of segment [o, o+W), left to right (x.sum(dim=2) over one pipeline, neural_networks.py:226)
-template <int NP>
-NIC_HD Dual<NP> cf_segment_sum(const Dual<NP> (&st)[CF_MAXF], int o, int W) {
-    Dual<NP> r = dconst<NP>(0.f);
+// new[0] = after + old[1]; new[k] = old[k+1]; new[W-1] = 0; new[L-1] += a if a != 0   (environment.py:405-432)
+template <int NP, int MW>
+NIC_HD CfPipe<NP, MW> cf_pipe_step(const CfPipe<NP, MW>& old, int W, const Dual<NP>& after, const Dual<NP>& a, float lead) {
+    CfPipe<NP, MW> nw;
+    const int slot = (int)lead - 1;
+    const bool place = a.v != 0.f;  // zero orders are filtered out before the put (:426-429)
 #pragma unroll
-    for (int k = 0; k < CF_MAXF; ++k)
-        if (k >= o && k < o + W) r = r + st[k];
-    return r;
-}
-
-// new[o] = after + old[o+1]; new[k] = old[k+1]; new[o+W-1] = 0; new[o+L-1] += a if a != 0   (environment.py:405-432)
-template <int NP>
-NIC_HD void cf_segment_step(const Dual<NP> (&old)[CF_MAXF], Dual<NP> (&nw)[CF_MAXF], int o, int W, const Dual<NP>& after,
-                            const Dual<NP>& a, float lead) {
-    const int slot = o + (int)lead - 1;
-#pragma unroll
-    for (int k = 0; k < CF_MAXF; ++k) {
-        if (k >= o && k < o + W) {
-            Dual<NP> v = dconst<NP>(0.f);
-            const Dual<NP> nxt = (k + 1 < CF_MAXF) ? old[(k + 1 < CF_MAXF) ? k + 1 : k] : dconst<NP>(0.f);
-            if (k == o) v = after + nxt;
-            else if (k < o + W - 1) v = nxt;
-            if (a.v != 0.f && k == slot) v = v + a;  // zero orders are filtered out before the put (:426-429)
-            nw[k] = v;
-        }
+    for (int k = 0; k < MW; ++k) {
+        Dual<NP> v = dconst<NP>(0.f);
+        if (k + 1 < MW && k < W - 1) v = old.s[k + 1 < MW ? k + 1 : k];
+        if (k == 0) v = after + v;
+        if (place && k == slot) v = v + a;
+        nw.s[k] = v;
     }
+    return nw;
 }
 
-// one period of dynamics of the chain (environment.py:179-299 for S = 1, Wn <= 1); returns the period cost
-template <int NP>
-NIC_HD Dual<NP> cf_env_step(const NicClosedFormDesc& d, const CfStatics& c, const Dual<NP> (&st)[CF_MAXF],
-                            Dual<NP> (&nx)[CF_MAXF], float dem, const CfOrders<NP>& o) {
-#pragma unroll
-    for (int k = 0; k < CF_MAXF; ++k) nx[k] = dconst<NP>(0.f);
-    const Dual<NP> on_hand = st[0];
+// state of one chain: the store's pipeline and, for CHAIN, the warehouse's and up to CF_MAXE echelons'
+template <int NP, int MW, bool CHAIN>
+struct CfState {
+    CfPipe<NP, MW> store;
+    CfPipe<NP, MW> wh;
+    CfPipe<NP, MW> ech[CHAIN ? CF_MAXE : 1];
+};
+
+// one period of dynamics of the chain (environment.py:179-299 for S = 1, Wn <= 1); returns the period cost.
+// CHAIN = false compiles the single-store form only (Wn = E = 0 known at compile time: base_stock / capped_base_stock)
+template <int NP, int MW, bool CHAIN>
+NIC_HD Dual<NP> cf_env_step(const NicClosedFormDesc& d, const CfStatics& c, CfState<NP, MW, CHAIN>& st, float dem,
+                            const CfOrders<NP>& o) {
+    const Dual<NP> on_hand = st.store.s[0];
     Dual<NP> after = dsub(on_hand, dem);
     Dual<NP> cost;
     if (d.maximize_profit) cost = dscale(-c.p, dmin_const(on_hand, dem)) + dscale(c.h, drelu(after));  // :191-194
     else cost = dscale(c.p, drelu(dneg(after))) + dscale(c.h, drelu(after));                            // :198-201
     if (d.lost_demand) after = drelu(after);                                                            // :204-205
-    cf_segment_step(st, nx, 0, d.Ws, after, o.store, c.lead);
     Dual<NP> total = cost;
-    if (d.Wn) {
-        const Dual<NP> w_after = cf_at(st, d.Ws) - o.store;  // ships what the store ordered (no clip, :249)
+    if (CHAIN) {
+        // the warehouse ships what the store ordered (no clip, :249); echelon e ships what its downstream neighbour ordered
+        const Dual<NP> w_after = st.wh.s[0] - o.store;
         Dual<NP> cw = dscale(c.wh_h, drelu(w_after));
         if (d.wh_edge.p) cw = cw + dscale(c.wh_edge, o.wh);
-        cf_segment_step(st, nx, d.Ws, d.Ww, w_after, o.wh, c.wh_lead);
         total = total + cw;
-    }
-    if (d.E > 0) {
         Dual<NP> r_e = dconst<NP>(0.f);
 #pragma unroll
         for (int e = 0; e < CF_MAXE; ++e) {
             if (e < d.E) {
                 const Dual<NP> ship = (e < d.E - 1) ? o.ech[(e + 1 < CF_MAXE) ? e + 1 : e] : o.wh;
-                const int off = d.Ws + d.Ww + e * d.We;
-                const Dual<NP> e_after = cf_at(st, off) - ship;
+                const Dual<NP> e_after = st.ech[CHAIN ? e : 0].s[0] - ship;
                 r_e = r_e + dscale(c.e_h[e], drelu(e_after));
-                cf_segment_step(st, nx, off, d.We, e_after, o.ech[e], c.e_lead[e]);
+                st.ech[CHAIN ? e : 0] = cf_pipe_step(st.ech[CHAIN ? e : 0], d.We, e_after, o.ech[e], c.e_lead[e]);
             }
         }
         total = total + r_e;
+        st.wh = cf_pipe_step(st.wh, d.Ww, w_after, o.wh, c.wh_lead);
     }
+    st.store = cf_pipe_step(st.store, d.Ws, after, o.store, c.lead);
     return total;
 }
 
 // orders of the closed-form policies from the current state and the levels
-template <int NP>
-NIC_HD CfOrders<NP> cf_policy(const NicClosedFormDesc& d, const Dual<NP> (&lv)[NIC_CF_MAX_LEVELS], const Dual<NP> (&st)[CF_MAXF]) {
+template <int NP, int MW, bool CHAIN>
+NIC_HD CfOrders<NP> cf_policy(const NicClosedFormDesc& d, const Dual<NP> (&lv)[NIC_CF_MAX_LEVELS],
+                              const CfState<NP, MW, CHAIN>& st) {
     CfOrders<NP> o;
     o.store = o.wh = dconst<NP>(0.f);
 #pragma unroll
     for (int e = 0; e < CF_MAXE; ++e) o.ech[e] = dconst<NP>(0.f);
-    const Dual<NP> store_pos = cf_segment_sum(st, 0, d.Ws);
-    if (d.policy == NIC_CF_BASE_STOCK) {           // clip(level - position, min=0)            neural_networks.py:227-229
+    const Dual<NP> store_pos = cf_pipe_sum(st.store, d.Ws);
+    if (!CHAIN && d.policy == NIC_CF_BASE_STOCK) {  // clip(level - position, min=0)            neural_networks.py:227-229
         o.store = drelu(lv[0] - store_pos);
-    } else if (d.policy == NIC_CF_CAPPED) {        // clip(level - position, min=0, max=cap)   :306-311
+    } else if (!CHAIN) {                           // clip(level - position, min=0, max=cap)   :306-311
         o.store = dclamp0_cap(lv[0] - store_pos, lv[1]);
     } else {                                       // echelon base stock                       :247-288
         // locations ordered upstream -> downstream: k = 0..E-1 echelons, E warehouse, E+1 store; level k covers the
         // positions of locations k..E+1; allocation = min(clip(level_k - sum, 0), on-hand of the location upstream of k)
-        Dual<NP> pos[CF_MAXE + 2];
+        Dual<NP> pos[CF_MAXE];
 #pragma unroll
-        for (int e = 0; e < CF_MAXE; ++e)
-            pos[e] = e < d.E ? cf_segment_sum(st, d.Ws + d.Ww + e * d.We, d.We) : dconst<NP>(0.f);
-        const Dual<NP> wh_pos = cf_segment_sum(st, d.Ws, d.Ww);
+        for (int e = 0; e < CF_MAXE; ++e) pos[e] = e < d.E ? cf_pipe_sum(st.ech[CHAIN ? e : 0], d.We) : dconst<NP>(0.f);
+        const Dual<NP> wh_pos = cf_pipe_sum(st.wh, d.Ww);
 #pragma unroll
         for (int k = 0; k < CF_MAXE + 2; ++k) {
             if (k < d.E + 2) {
@@ -272,8 +273,13 @@ NIC_HD CfOrders<NP> cf_policy(const NicClosedFormDesc& d, const Dual<NP> (&lv)[N
                 const Dual<NP> want = drelu(lv[k < NIC_CF_MAX_LEVELS ? k : 0] - s);
                 Dual<NP> a;
                 if (k == 0) a = dmin_const(want, 1000000.f);  // the outside supplier never binds (:262)
-                else if (k <= d.E) a = dmin(want, cf_at(st, d.Ws + d.Ww + (k - 1) * d.We));  // on hand of echelon k-1
-                else a = dmin(want, cf_at(st, d.Ws));                                         // on hand of the warehouse
+                else if (k <= d.E) {                           // on hand of echelon k-1
+                    Dual<NP> up = dconst<NP>(0.f);
+#pragma unroll
+                    for (int e = 0; e < CF_MAXE; ++e)
+                        if (e == k - 1) up = st.ech[CHAIN ? e : 0].s[0];
+                    a = dmin(want, up);
+                } else a = dmin(want, st.wh.s[0]);             // on hand of the warehouse
                 if (k < d.E) o.ech[k < CF_MAXE ? k : 0] = a;
                 else if (k == d.E) o.wh = a;
                 else o.store = a;
@@ -289,12 +295,25 @@ NIC_HD CfOrders<NP> cf_policy(const NicClosedFormDesc& d, const Dual<NP> (&lv)[N
     return o;
 }
 
-// Whole horizon of chain (store s, scenario b).  Outputs (each may be NULL):
+template <int NP, int MW>
+NIC_HD void cf_pipe_load(CfPipe<NP, MW>& p, const float* src, int W, int64_t ldb) {
+#pragma unroll
+    for (int k = 0; k < MW; ++k) p.s[k] = dconst<NP>(k < W ? src[(int64_t)k * ldb] : 0.f);
+}
+template <int NP, int MW>
+NIC_HD void cf_pipe_store(const CfPipe<NP, MW>& p, float* dst, int W, int64_t ldb) {
+#pragma unroll
+    for (int k = 0; k < MW; ++k)
+        if (k < W) dst[(int64_t)k * ldb] = p.s[k].v;
+}
+
+// Whole horizon of chain (store s, scenario b).  MW = register slots per pipeline (>= every live pipeline length).
+// Outputs (each may be NULL):
 //   reward_hist [T][S][ldb]   per-period cost of this chain
 //   totals      [2][S][ldb]   sum over all periods / over periods >= ignore_periods
 //   state_final [S][F][ldb]
 //   g_levels    [NP] (returned through `g`): d(totals[0]) / d(level_j) of this chain
-template <int NP>
+template <int NP, int MW, bool CHAIN>
 NIC_HD void closed_form_chain(const NicClosedFormDesc& d, float* reward_hist, float* totals, float* state_final, int s,
                               int64_t b, float (&g)[NP > 0 ? NP : 1]) {
     const int64_t ldb = d.ldb;
@@ -303,9 +322,13 @@ NIC_HD void closed_form_chain(const NicClosedFormDesc& d, float* reward_hist, fl
     Dual<NP> lv[NIC_CF_MAX_LEVELS];
 #pragma unroll
     for (int j = 0; j < NIC_CF_MAX_LEVELS; ++j) lv[j] = j < d.n_levels ? dparam<NP>(d.levels[j], j) : dconst<NP>(0.f);
-    Dual<NP> st[CF_MAXF], nx[CF_MAXF];
+    CfState<NP, MW, CHAIN> st;
+    const float* s0 = d.state0 + (int64_t)s * F * ldb + b;
+    cf_pipe_load(st.store, s0, d.Ws, ldb);
+    cf_pipe_load(st.wh, s0 + (int64_t)d.Ws * ldb, CHAIN ? d.Ww : 0, ldb);
 #pragma unroll
-    for (int k = 0; k < CF_MAXF; ++k) st[k] = dconst<NP>(k < F ? d.state0[((int64_t)s * F + k) * ldb + b] : 0.f);
+    for (int e = 0; e < (CHAIN ? CF_MAXE : 1); ++e)
+        cf_pipe_load(st.ech[e], s0 + (int64_t)(d.Ws + d.Ww + e * d.We) * ldb, (CHAIN && e < d.E) ? d.We : 0, ldb);
     Dual<NP> total = dconst<NP>(0.f);
     float reported = 0.f;
     const float* dem_p = d.demand + ((int64_t)d.t0 * d.S + s) * ldb + b;
@@ -313,23 +336,27 @@ NIC_HD void closed_form_chain(const NicClosedFormDesc& d, float* reward_hist, fl
     float dem = dem_p[0];
     for (int t = 0; t < d.T; ++t) {
         const float dem_next = t + 1 < d.T ? dem_p[(int64_t)(t + 1) * dem_stride] : 0.f;  // next period's demand in flight
-        const CfOrders<NP> o = cf_policy(d, lv, st);
-        const Dual<NP> r = cf_env_step(d, c, st, nx, dem, o);
+        const CfOrders<NP> o = cf_policy<NP, MW, CHAIN>(d, lv, st);
+        const Dual<NP> r = cf_env_step<NP, MW, CHAIN>(d, c, st, dem, o);
         total = total + r;
         if (t >= d.ignore_periods) reported += r.v;
         if (reward_hist) reward_hist[((int64_t)t * d.S + s) * ldb + b] = r.v;
-#pragma unroll
-        for (int k = 0; k < CF_MAXF; ++k) st[k] = nx[k];
         dem = dem_next;
     }
     if (totals) {
         totals[(int64_t)s * ldb + b] = total.v;
         totals[((int64_t)d.S + s) * ldb + b] = reported;
     }
-    if (state_final)
+    if (state_final) {
+        float* f0 = state_final + (int64_t)s * F * ldb + b;
+        cf_pipe_store(st.store, f0, d.Ws, ldb);
+        if (CHAIN) {
+            cf_pipe_store(st.wh, f0 + (int64_t)d.Ws * ldb, d.Ww, ldb);
 #pragma unroll
-        for (int k = 0; k < CF_MAXF; ++k)
-            if (k < F) state_final[((int64_t)s * F + k) * ldb + b] = st[k].v;
+            for (int e = 0; e < CF_MAXE; ++e)
+                if (e < d.E) cf_pipe_store(st.ech[CHAIN ? e : 0], f0 + (int64_t)(d.Ws + d.Ww + e * d.We) * ldb, d.We, ldb);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) g[j] = total.d[j];
 }

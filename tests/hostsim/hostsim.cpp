@@ -17,12 +17,12 @@ static void bwd_all(const NicEnvStepIO& io, const float* gso, const float* gwo, 
         nic::env_step_bwd_scenario<MAXW>(io, gso, gwo, geo, gr, gsi, gwi, gei, gas, gaw, gae, b);
 }
 
-template <int NP>
+template <int NP, int MF, bool CHAIN>
 static void closed_form_all(const NicClosedFormDesc& d, float* reward_hist, float* totals, float* state_final, double* g_levels) {
     for (int s = 0; s < d.S; ++s)
         for (int64_t b = 0; b < d.n_scenarios; ++b) {
             float g[NP > 0 ? NP : 1] = {0.f};
-            nic::closed_form_chain<NP>(d, reward_hist, totals, state_final, s, b, g);
+            nic::closed_form_chain<NP, MF, CHAIN>(d, reward_hist, totals, state_final, s, b, g);
             for (int j = 0; j < NP; ++j) g_levels[j] += g[j];
         }
 }
@@ -95,13 +95,21 @@ int hostsim_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_
 int hostsim_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
                                 double* g_levels) {
     const int np = g_levels ? d->n_levels : 0;
-    switch (np) {
-        case 0: closed_form_all<0>(*d, reward_hist, totals, state_final, g_levels); break;
-        case 1: closed_form_all<1>(*d, reward_hist, totals, state_final, g_levels); break;
-        case 2: closed_form_all<2>(*d, reward_hist, totals, state_final, g_levels); break;
-        case 3: closed_form_all<3>(*d, reward_hist, totals, state_final, g_levels); break;
-        case 4: closed_form_all<4>(*d, reward_hist, totals, state_final, g_levels); break;
-        default: closed_form_all<5>(*d, reward_hist, totals, state_final, g_levels); break;
+    if (d->policy == NIC_CF_ECHELON) {  // (a host build only needs one slot count per form; the device picks 4 / 8 / 16)
+        switch (np) {
+            case 0: closed_form_all<0, NIC_MAX_SLOTS, true>(*d, reward_hist, totals, state_final, g_levels); break;
+            case 3: closed_form_all<3, NIC_MAX_SLOTS, true>(*d, reward_hist, totals, state_final, g_levels); break;
+            case 4: closed_form_all<4, NIC_MAX_SLOTS, true>(*d, reward_hist, totals, state_final, g_levels); break;
+            default: closed_form_all<5, NIC_MAX_SLOTS, true>(*d, reward_hist, totals, state_final, g_levels); break;
+        }
+    } else if (d->Ws <= 4) {
+        if (np == 0) closed_form_all<0, 4, false>(*d, reward_hist, totals, state_final, g_levels);
+        else if (np == 1) closed_form_all<1, 4, false>(*d, reward_hist, totals, state_final, g_levels);
+        else closed_form_all<2, 4, false>(*d, reward_hist, totals, state_final, g_levels);
+    } else {
+        if (np == 0) closed_form_all<0, NIC_MAX_SLOTS, false>(*d, reward_hist, totals, state_final, g_levels);
+        else if (np == 1) closed_form_all<1, NIC_MAX_SLOTS, false>(*d, reward_hist, totals, state_final, g_levels);
+        else closed_form_all<2, NIC_MAX_SLOTS, false>(*d, reward_hist, totals, state_final, g_levels);
     }
     return 0;
 }
