@@ -277,6 +277,12 @@ int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, floa
 int nic_sample_demand(float* out, int32_t T, int32_t S, int32_t n_scenarios, int32_t ldb, int64_t scenario_offset,
                       uint64_t seed, int32_t kind, const float* mean /* [S] */, const float* chol /* [S][S] */,
                       int32_t clip, void* stream);
+/* The covariance the reference actually builds (data_handling.py:194-201): cov_ij = rho * std_i * std_j (i != j), std_i^2 on
+ * the diagonal, 0 <= rho <= 1.  d_s = mean_s + std_s * (sqrt(rho) * z_common + sqrt(1 - rho) * z_s) has exactly that
+ * covariance with S + 1 normals per (scenario, period) and no factor matrix (S = 1 or rho = 0: independent stores). */
+int nic_sample_demand_equicorrelated(float* out, int32_t T, int32_t S, int32_t n_scenarios, int32_t ldb,
+                                     int64_t scenario_offset, uint64_t seed, const float* mean /* [S] */,
+                                     const float* std /* [S] */, float rho, int32_t clip, void* stream);
 
 /* ---- small utilities on SoA buffers ---------------------------------------------------------------------- */
 /* out[b] += in[b] for b < n (per-scenario running cost); */

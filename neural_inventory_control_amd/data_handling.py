@@ -176,17 +176,22 @@ class Scenario:
         dev = torch.device(self.device or "cuda")
         S, N, T = problem_params["n_stores"], self.num_samples, self.periods
         mean = torch.as_tensor(np.broadcast_to(np.asarray(demand_params["mean"], dtype=np.float32), (S,)).copy())
-        kind = 1 if demand_params["distribution"] == "poisson" else 0
-        chol = None
-        if kind == 0:
-            if S == 1:
-                cov = np.array([[float(np.asarray(demand_params["std"]).reshape(-1)[0]) ** 2]])
-            else:
-                cov = np.asarray(self._covariance(demand_params), dtype=np.float64)
-            chol = torch.as_tensor(np.linalg.cholesky(cov).astype(np.float32)).contiguous().to(dev)
         out = torch.zeros(T, S, pad_ld(N), device=dev)
-        ops.sample_demand(out, T, S, N, self.scenario_offset, int(seed), kind, mean.to(dev), chol,
-                          bool(demand_params["clip"]))
+        clip = bool(demand_params["clip"])
+        if demand_params["distribution"] == "poisson":
+            ops.sample_demand(out, T, S, N, self.scenario_offset, int(seed), 1, mean.to(dev), None, clip)
+        else:
+            std = torch.as_tensor(np.broadcast_to(np.asarray(demand_params["std"], dtype=np.float32), (S,)).copy())
+            rho = float(demand_params.get("correlation", 0.0) or 0.0) if S > 1 else 0.0
+            if 0.0 <= rho <= 1.0:
+                # the reference's covariance (rho s_i s_j off the diagonal, data_handling.py:194-201) through its
+                # one-factor form: S + 1 normals per (scenario, period), no factor matrix
+                ops.sample_demand_equicorrelated(out, T, S, N, self.scenario_offset, int(seed), mean.to(dev), std.to(dev),
+                                                 rho, clip)
+            else:  # a negative correlation has no one-factor form: general Cholesky path
+                cov = np.asarray(self._covariance(demand_params), dtype=np.float64)
+                chol = torch.as_tensor(np.linalg.cholesky(cov).astype(np.float32)).contiguous().to(dev)
+                ops.sample_demand(out, T, S, N, self.scenario_offset, int(seed), 0, mean.to(dev), chol, clip)
         self.demands_soa = out
         return out[:, :, :N].permute(2, 1, 0)
 

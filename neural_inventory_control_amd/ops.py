@@ -186,6 +186,14 @@ def sample_demand(out, T, S, n_scenarios, scenario_offset, seed, kind, mean, cho
     return out
 
 
+def sample_demand_equicorrelated(out, T, S, n_scenarios, scenario_offset, seed, mean, std, rho, clip):
+    """out: [T][S][ldb]; normal demand with cov_ij = rho std_i std_j off the diagonal (the reference's covariance)."""
+    _dev(out)
+    check(lib().nic_sample_demand_equicorrelated(ptr(out), T, S, n_scenarios, out.stride(1), int(scenario_offset), int(seed),
+                                                 ptr(mean), ptr(std), float(rho), int(clip), current_stream()))
+    return out
+
+
 def axpy(out, x, alpha=1.0):
     _dev(out)
     check(lib().nic_axpy(ptr(out), ptr(x), float(alpha), out.numel(), current_stream()))

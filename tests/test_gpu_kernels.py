@@ -286,6 +286,82 @@ def test_sampler_normal_moments_and_sharding_invariance():
     assert float(oc.min()) == 0.0
 
 
+@pytest.mark.parametrize("S", [1, 5, 16, 64])
+def test_sampler_equicorrelated_moments_covariance_and_sharding(S):
+    """The reference's covariance (rho s_i s_j off the diagonal, data_handling.py:194-201) through the one-factor sampler:
+    per-store mean / variance, every pairwise covariance, independence across periods, bit-exact sharding invariance."""
+    dev = "cuda"
+    T, B = 24, 8192
+    gen = torch.Generator().manual_seed(S)
+    mean = 2.5 + 5.0 * torch.rand(S, generator=gen)
+    std = mean * (0.25 + 0.25 * torch.rand(S, generator=gen))
+    rho = 0.5 if S > 1 else 0.0
+    cov = rho * std[:, None] * std[None, :]
+    cov[range(S), range(S)] = std * std
+    ldb = pad_ld(B)
+    out = torch.zeros(T, S, ldb, device=dev)
+    ops.sample_demand_equicorrelated(out, T, S, B, 0, 4321, mean.to(dev), std.to(dev), rho, False)
+    torch.cuda.synchronize()
+    assert float(out[:, :, B:].abs().sum()) == 0.0
+    x = out[:, :, :B].permute(1, 0, 2).reshape(S, -1).double().cpu()  # S x (T*B) = 196,608 draws per store
+    np.testing.assert_allclose(x.mean(dim=1).numpy(), mean.numpy(), atol=0.03)
+    got = np.atleast_2d(np.cov(x.numpy()))
+    np.testing.assert_allclose(got, cov.numpy(), atol=0.06 * float(cov.max()))
+    # normality of the marginals: skewness ~ 0, kurtosis ~ 3
+    zs = (x - x.mean(dim=1, keepdim=True)) / x.std(dim=1, keepdim=True)
+    assert float((zs ** 3).mean(dim=1).abs().max()) < 0.03 and float(((zs ** 4).mean(dim=1) - 3).abs().max()) < 0.08
+    a, b = out[0, 0, :B].double().cpu(), out[1, 0, :B].double().cpu()
+    assert abs(np.corrcoef(a.numpy(), b.numpy())[0, 1]) < 0.05
+    half = B // 2
+    o1, o2 = torch.zeros(T, S, pad_ld(half), device=dev), torch.zeros(T, S, pad_ld(half), device=dev)
+    ops.sample_demand_equicorrelated(o1, T, S, half, 0, 4321, mean.to(dev), std.to(dev), rho, False)
+    ops.sample_demand_equicorrelated(o2, T, S, half, half, 4321, mean.to(dev), std.to(dev), rho, False)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([o1[:, :, :half], o2[:, :, :half]], dim=2), out[:, :, :B])
+    oc = torch.zeros(T, S, ldb, device=dev)
+    ops.sample_demand_equicorrelated(oc, T, S, B, 0, 4321, (mean * 0).to(dev), std.to(dev), rho, True)
+    torch.cuda.synchronize()
+    assert float(oc.min()) == 0.0
+
+
+def test_sampler_equicorrelated_is_launch_geometry_independent():
+    """Above ~4M (scenario, period) pairs the sampler gives each lane four periods, below it one: a big run and its two
+    half-size shards (which take the other form) must agree bit for bit, ragged horizon included."""
+    dev = "cuda"
+    S, T, B = 16, 18, 262144
+    mean, std = torch.full((S,), 5.0, device=dev), torch.linspace(1.0, 2.0, S).to(dev)
+    full = torch.zeros(T, S, B, device=dev)
+    ops.sample_demand_equicorrelated(full, T, S, B, 0, 9, mean, std, 0.5, True)
+    assert _lib.lib().nic_last_kernel() == b"sample_equicorrelated_kernel<4>"
+    half = B // 2
+    parts = []
+    for off in (0, half):
+        o = torch.zeros(T, S, half, device=dev)
+        ops.sample_demand_equicorrelated(o, T, S, half, off, 9, mean, std, 0.5, True)
+        assert _lib.lib().nic_last_kernel() == b"sample_equicorrelated_kernel<1>"
+        parts.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts, dim=2), full)
+
+
+@pytest.mark.parametrize("S", [3, 16, 40, 64])
+def test_sampler_general_covariance(S):
+    """Arbitrary (here: negatively correlated blocks) covariance through the Cholesky sampler: z kept in registers."""
+    dev = "cuda"
+    T, B = 16, 8192
+    gen = torch.Generator().manual_seed(100 + S)
+    A = torch.randn(S, S, generator=gen, dtype=torch.float64) * 0.4
+    cov = A @ A.t() + torch.eye(S, dtype=torch.float64)
+    chol = torch.linalg.cholesky(cov).float()
+    mean = torch.linspace(3.0, 9.0, S)
+    out = torch.zeros(T, S, pad_ld(B), device=dev)
+    ops.sample_demand(out, T, S, B, 0, 77, 0, mean.to(dev), chol.to(dev).contiguous(), False)
+    torch.cuda.synchronize()
+    x = out[:, :, :B].permute(1, 0, 2).reshape(S, -1).double().cpu()
+    np.testing.assert_allclose(x.mean(dim=1).numpy(), mean.numpy(), atol=0.05)
+    np.testing.assert_allclose(np.cov(x.numpy()), cov.numpy(), atol=0.05 * float(cov.max()))
+
+
 def test_sampler_poisson():
     dev = "cuda"
     S, T, B = 2, 50, 8192
@@ -299,3 +375,10 @@ def test_sampler_poisson():
     np.testing.assert_allclose(x.var(dim=1).numpy(), lam.numpy(), rtol=0.03)
     # P(X = 0) = exp(-lambda)
     np.testing.assert_allclose((x == 0).double().mean(dim=1).numpy(), np.exp(-lam.numpy()), atol=0.003)
+    # a mean whose mass reaches past the 64-entry CDF table: the search continues the recurrence
+    big = torch.tensor([45.0])
+    ob = torch.zeros(8, 1, pad_ld(B), device=dev)
+    ops.sample_demand(ob, 8, 1, B, 0, 5, 1, big.to(dev), None, True)
+    torch.cuda.synchronize()
+    xb = ob[:, :, :B].double().cpu().reshape(-1)
+    assert abs(float(xb.mean()) - 45.0) < 0.15 and abs(float(xb.var()) - 45.0) < 1.5 and float(xb.max()) > 63
