@@ -73,12 +73,14 @@ def _sample_store_demand_moments(n_stores, demand_spec, seeds):
 def _demand_traces(n_samples, n_stores, periods, demand_spec, seed):
     """(N,S,T) demand array.  data_handling.py:178-211."""
     kind = demand_spec["distribution"]
+    if kind == "real":  # :162-168: the first n_samples rows of a (products, stores, weeks) tensor file
+        return torch.load(demand_spec["file_location"], map_location="cpu")[:n_samples]
     if seed is not None:
         np.random.seed(seed)
     if kind == "poisson":  # :205-211
         return np.random.poisson(demand_spec["mean"], size=(n_samples, n_stores, periods))
     if kind != "normal":
-        raise NotImplementedError("oracle: only synthetic normal/poisson demand is on the hot path")
+        raise NotImplementedError(f"oracle: unknown demand distribution {kind}")
     if n_stores == 1:  # :187-191
         return np.random.normal(demand_spec["mean"], demand_spec["std"], size=(n_samples, 1, periods))
     # correlated multivariate normal, cov_ij = rho*s_i*s_j (i != j), s_i^2 on the diagonal (:194-201)
@@ -114,7 +116,7 @@ def generate_scenario_data(periods, problem_params, store_params, warehouse_para
     demand = _demand_traces(num_samples, S, periods, demand_spec, seeds["demand"])
     if demand_spec["clip"]:
         demand = np.clip(demand, 0, None)
-    demands = torch.tensor(demand)
+    demands = torch.as_tensor(demand).clone()
 
     # --- per-store costs and lead times (data_handling.py:20-22, 273-288)
     underage = _per_store_table(num_samples, S, store_params["underage_cost"], seeds["underage_cost"], False)
@@ -171,7 +173,28 @@ def generate_scenario_data(periods, problem_params, store_params, warehouse_para
         out["echelon_holding_costs"] = torch.tensor(echelon_params["holding_cost"]).unsqueeze(0).expand(num_samples, -1)
         out["echelon_lead_times"] = torch.tensor(el).unsqueeze(0).expand(num_samples, -1)
 
+    # --- time / sample features read from a csv (data_handling.py:36-48)
+    for kind_, file_key in (("time_features", "time_features_file"), ("sample_features", "sample_features_file")):
+        if observation_params.get(kind_) and observation_params.get(file_key):
+            import pandas as pd
+            table = pd.read_csv(observation_params[file_key])
+            for k in observation_params[kind_]:
+                col = torch.tensor(table[k].values)
+                out[k] = (col.unsqueeze(0).unsqueeze(0).expand(num_samples, S, -1) if kind_ == "time_features"
+                          else col.unsqueeze(1).expand(-1, S))
+
     return {k: v.float() for k, v in out.items() if v is not None}
+
+
+def split_data_by_period(data, period_ranges, observation_params):
+    """DatasetCreator.split_by_period (data_handling.py:431-448): per-sample tensors are shared, `demands` and the time
+    features are sliced along the period axis.  period_ranges: strings like '(0, 111)' as the YAML holds them."""
+    by_period = ["demands"] + list(observation_params.get("time_features") or [])
+    out = []
+    for rng in period_ranges:
+        sl = slice(*map(int, str(rng).strip("() ").split(",")))
+        out.append({k: (v[:, :, sl] if k in by_period else v.clone()) for k, v in data.items()})
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -213,6 +236,8 @@ class OracleEnv:
     periods: int
     obs: Dict[str, torch.Tensor] = field(default_factory=dict)
     t: int = 0
+    observation_params: Optional[dict] = None
+    data: Optional[dict] = None
 
 
 def env_reset(periods, problem_params, data, observation_params) -> OracleEnv:
@@ -233,17 +258,56 @@ def env_reset(periods, problem_params, data, observation_params) -> OracleEnv:
     for k, on in observation_params["include_static_features"].items():
         if on:
             obs[k] = data[k]
-    if observation_params["demand"]["past_periods"] > 0 or observation_params.get("time_features") \
-            or observation_params.get("sample_features"):
-        raise NotImplementedError("oracle: real-data observation features are outside the hot path (SURVEY §8 f4)")
+    env.observation_params = observation_params
+    env.data = data
+    if observation_params["demand"]["past_periods"] > 0:  # :329-330
+        obs["past_demands"] = _past_demands(env, current_period=0)
+    if observation_params.get("time_features"):            # :333-334
+        _update_time_features(env, obs, current_period=0)
+    if observation_params.get("sample_features") is not None:
+        for k in observation_params["sample_features"]:
+            obs[k] = data[k]
     env.obs = obs
     return env
+
+
+def _past_demands(env, current_period):
+    """environment.py:436-458: the last `past_periods` demands before (current_period + period_shift), zero-filled on the left."""
+    past = env.observation_params["demand"]["past_periods"]
+    cur = current_period + env.period_shift
+    d = env.demands
+    B, S = d.shape[0], d.shape[1]
+    if cur == 0:
+        return torch.zeros(B, S, past, dtype=d.dtype)
+    window = d[:, :, max(0, cur - past):cur]
+    missing = past - (cur - max(0, cur - past))
+    if missing > 0:
+        window = torch.cat([torch.zeros(B, S, missing, dtype=d.dtype), window], dim=2)
+    return window
+
+
+def _update_time_features(env, obs, current_period):
+    """environment.py:460-468."""
+    for k in env.observation_params["time_features"]:
+        feat = env.data[k]
+        if feat.shape[2] + 2 < current_period:
+            raise ValueError("Current period is greater than the number of periods in the data")
+        obs[k] = feat[:, :, min(current_period + env.period_shift, feat.shape[2] - 1)]
 
 
 def env_step(env: OracleEnv, action: Dict[str, torch.Tensor]) -> torch.Tensor:
     """One period; returns the per-scenario cost (B,) and rebinds the state.  environment.py:110-169."""
     obs, prob = env.obs, env.problem
     d = env.demands[:, :, env.t + env.period_shift]  # :171-177
+    op = getattr(env, "observation_params", None)
+    if op is not None:
+        # observation features of the NEXT period are refreshed before the dynamics (:126-136, :486-501)
+        if env.demands.shape[2] + 2 < env.t:
+            raise ValueError("Current period is greater than the number of periods in the data")
+        if op["demand"]["past_periods"] > 0:
+            obs["past_demands"] = _past_demands(env, current_period=min(env.t + 1, env.demands.shape[2]))
+        if op.get("time_features"):
+            _update_time_features(env, obs, current_period=env.t + 1)
 
     # --- stores (:179-234)
     inv = obs["store_inventories"]
@@ -307,12 +371,22 @@ class OraclePolicy:
     warehouse_upper_bound: Optional[torch.Tensor] = None
     adjacency: Optional[Sequence[Sequence[int]]] = None  # problem_params['warehouse_store_adjacency']
     transshipment: bool = False
+    forecaster: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None  # frozen quantile forecaster (quantile policies)
+    forecaster_lead_times: Optional[Sequence[int]] = None
 
     def parameters(self):
         return [t for wb in self.layers for t in wb]
 
 
-def policy_from_state_dict(nn_params, state_dict, problem_params=None, warehouse_upper_bound=None, dtype=torch.float32):
+def forecaster_layers(forecaster_state, dtype=torch.float32):
+    """(weight, bias) pairs of the frozen FullyConnectedForecaster from its state dict (`net.<i>.weight/bias`)."""
+    idx = sorted({int(k.split(".")[1]) for k in forecaster_state})
+    return [(forecaster_state[f"net.{i}.weight"].detach().to(dtype), forecaster_state[f"net.{i}.bias"].detach().to(dtype))
+            for i in idx]
+
+
+def policy_from_state_dict(nn_params, state_dict, problem_params=None, warehouse_upper_bound=None, dtype=torch.float32,
+                           forecaster_state=None):
     """Builds an OraclePolicy from reference-format keys `net.master.<i>.weight/bias`
     (layout produced by neural_networks.py:80-106).  dtype=torch.float64 (with float64 data) gives the fp64 REFEREE the
     gradient-parity tests measure both the reference's float32 arithmetic and the HIP engine against."""
@@ -330,6 +404,8 @@ def policy_from_state_dict(nn_params, state_dict, problem_params=None, warehouse
         warehouse_upper_bound=warehouse_upper_bound,
         adjacency=(problem_params or {}).get("warehouse_store_adjacency"),
         transshipment=nn_params.get("transshipment", False),
+        forecaster=forecaster_layers(forecaster_state, dtype) if forecaster_state is not None else None,
+        forecaster_lead_times=nn_params.get("forecaster_lead_times"),
     )
 
 
@@ -469,7 +545,100 @@ def policy_act(pol: OraclePolicy, obs: Dict[str, torch.Tensor]) -> Dict[str, tor
         wh = torch.sigmoid(wh_logits) * pol.warehouse_upper_bound
         return {"stores": alloc, "warehouses": wh.unsqueeze(2)}
 
+    if name == "data_driven":  # neural_networks.py:438-512
+        s_inv = obs["store_inventories"]
+        Wn = obs["warehouse_inventories"].size(1) if "warehouse_inventories" in obs else 0
+        S = s_inv.size(1)
+        feats = [s_inv] + ([obs["warehouse_inventories"]] if Wn > 0 else [])
+        feats += [obs["past_demands"], obs["underage_costs"], obs["holding_costs"], obs["days_from_christmas"], obs["lead_times"]]
+        out = _mlp(pol, torch.cat([t.flatten(start_dim=1) for t in feats], dim=1))
+        if Wn == 0:
+            return {"stores": out.unsqueeze(2)}
+        edge_mask = torch.tensor(pol.adjacency, dtype=out.dtype).transpose(0, 1)  # [S, Wn]
+        wh_out, store_flat = out[:, :Wn], out[:, Wn:]
+        alloc = store_flat.reshape(out.size(0), S, Wn) * edge_mask.unsqueeze(0)
+        final = torch.zeros_like(alloc)
+        for w in range(Wn):
+            if edge_mask[:, w].sum() > 0:  # proportional allocation against the warehouse's whole pipeline (:111-138, :497-500)
+                desired = alloc[:, :, w]
+                avail = obs["warehouse_inventories"][:, w].sum(dim=1)
+                scaling = torch.clip(avail / (desired.sum(dim=1) + 1e-10), max=1.0)
+                final[:, :, w] = desired * scaling[:, None]
+        return {"stores": final, "warehouses": wh_out.unsqueeze(2)}
+
+    if name in ("transformed_nv", "quantile_nv", "returns_nv", "fixed_quantile"):  # :517-631
+        lead = obs["lead_times"][:, :, 0]
+        p, h = obs["underage_costs"], obs["holding_costs"]
+        if name == "transformed_nv":
+            q = _mlp(pol, p / (p + h))
+        elif name == "fixed_quantile":
+            q = _mlp(pol, _zero_input(pol)).unsqueeze(1).expand(p.shape[0], p.shape[1])
+        else:
+            q = p / (p + h)
+        past, xmas = obs["past_demands"], obs["days_from_christmas"]
+        x = torch.cat([past, xmas.unsqueeze(1).expand(past.shape[0], past.shape[1], 1)], dim=2)
+        levels = forecaster_quantile(pol, x, q, lead)
+        pos = obs["store_inventories"].sum(dim=2)
+        alloc = levels - pos if name == "returns_nv" else torch.clip(levels - pos, min=0)
+        return {"stores": alloc.unsqueeze(2)}
+
+    if name == "just_in_time":  # :634-739 (non-admissible: reads future demand from internal_data)
+        return _just_in_time(pol, obs)
+
     raise KeyError(name)
+
+
+FORECASTER_QS = np.arange(0.05, 1, 0.05)
+
+
+def forecaster_quantile(pol, x, quantile, lead_times):
+    """FullyConnectedForecaster.get_quantile (quantile_forecaster.py:62-123): the frozen net predicts, for each of 19
+    probability points and each lead time, cumulative demand; the requested quantile is a linear interpolation between the two
+    neighbouring points, with points 0 and 1 extrapolated linearly."""
+    # the probability points are a float64 tensor upstream (built from a numpy array, quantile_forecaster.py:33), so the
+    # interpolation below - and with it the orders and, from the first step on, the state - is carried in float64
+    prob_points = torch.tensor([0] + list(FORECASTER_QS.round(2)) + [1])
+    idx = torch.searchsorted(prob_points, quantile.detach())
+    h = x
+    for i, (w, b) in enumerate(pol.forecaster):
+        h = F.linear(h, w, b)
+        if i < len(pol.forecaster) - 1:
+            h = F.elu(h)
+    n_lt = len(pol.forecaster_lead_times)
+    h = torch.clip(h, min=0).reshape(*h.shape[:-1], len(FORECASTER_QS), n_lt)
+    dif = (lead_times - min(pol.forecaster_lead_times)).to(torch.int64)
+    h = torch.gather(h, 3, dif.unsqueeze(2).expand(-1, -1, h.shape[2]).unsqueeze(3)).squeeze(3)
+    h = torch.cat([(2 * h[:, :, 0] - h[:, :, 1]).unsqueeze(2), h, (2 * h[:, :, -1] - h[:, :, -2]).unsqueeze(2)], dim=2)
+    prev_q = torch.gather(h, 2, (idx - 1).unsqueeze(2)).squeeze(2)
+    next_q = torch.gather(h, 2, idx.unsqueeze(2)).squeeze(2)
+    d_prev = quantile - prob_points[idx - 1]
+    d_next = prob_points[idx] - quantile
+    return prev_q + (next_q - prev_q) * d_prev / (d_prev + d_next)
+
+
+def _just_in_time(pol, obs):
+    cur = obs["current_period"]
+    demands, shift = obs["internal_data"]["demands"], obs["internal_data"]["period_shift"]
+    N, S, L = demands.shape
+    Wn = obs["warehouse_inventories"].size(1) if "warehouse_inventories" in obs else 0
+    rows = torch.arange(N)
+    if Wn == 0:
+        lt = obs["lead_times"][:, :, 0]
+        fut = torch.stack([demands[:, j][rows, torch.clip(cur + shift + lt[:, j].long(), max=L - 1)] for j in range(S)], dim=1)
+        return {"stores": torch.clip(fut, min=0).unsqueeze(2)}
+    lt, wlt = obs["lead_times"], obs["warehouse_lead_times"]
+    adj = torch.tensor(pol.adjacency, dtype=torch.float32)
+    alloc = torch.zeros(N, S, Wn, dtype=demands.dtype)
+    wh = torch.zeros(N, Wn, dtype=demands.dtype)
+    for st in range(S):
+        conn = adj[:, st].nonzero(as_tuple=True)[0]
+        if len(conn) > 0:
+            w = conn[torch.argmin(lt[:, st, conn].mean(dim=0))].item()  # the connected warehouse with the shortest lead time
+            t_store = torch.clip(cur + lt[:, st, w].long() + shift, max=L - 1)
+            alloc[:, st, w] = demands[:, st][rows, t_store]
+            t_wh = torch.clip(cur + wlt[:, w].long() + lt[:, st, w].long() + shift, max=L - 1)
+            wh[:, w] += demands[:, st][rows, t_wh]
+    return {"stores": torch.clip(alloc, min=0), "warehouses": torch.clip(wh, min=0).unsqueeze(2)}
 
 
 # --------------------------------------------------------------------------------------
@@ -719,7 +888,11 @@ def rollout(pol: OraclePolicy, periods, problem_params, data, observation_params
     for t in range(periods):
         if keep_states:
             states.append({k: v.detach().clone() for k, v in env.obs.items() if k.endswith("inventories")})
-        action = policy_act(pol, env.obs)
+        obs_in = env.obs
+        if pol.name == "just_in_time":  # trainer.py:195-196: non-admissible policies read the simulator's internal data
+            obs_in = dict(env.obs)
+            obs_in["internal_data"] = {"demands": env.demands, "period_shift": env.period_shift}
+        action = policy_act(pol, obs_in)
         if discrete_allocation:
             action = {k: v.round() for k, v in action.items()}  # trainer.py:201-202 (half-to-even)
         reward = env_step(env, action)

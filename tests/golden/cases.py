@@ -81,6 +81,32 @@ CASES = {
     "f1_one_warehouse_16_gnn": dict(
         setting="one_warehouse_lost_demand", policy="gnn", n=12, periods=6, ignore=2, torch_seed=23,
         problem_overrides={"n_stores": 16}),
+    # the real-data path.  Favorita weekly sales (288 products x 21 stores x 171 weeks, shipped with the reference),
+    # 3 warehouses, profit objective, past-demand window (16) + days-from-christmas in the observation, period_shift 16,
+    # datasets split BY PERIOD; data_driven_net = MLP over all features + proportional allocation of warehouse stock
+    "f4_real_many_warehouses_data_driven": dict(
+        setting="many_warehouses_real_data_lost_demand", policy="data_driven_net", n=12, periods=10, ignore=3, torch_seed=31,
+        hidden=[32, 32], real=True, period_range="(0, 48)"),
+    "f4_real_many_warehouses_just_in_time": dict(
+        setting="many_warehouses_real_data_lost_demand", policy="just_in_time", n=12, periods=10, ignore=3, torch_seed=32,
+        real=True, period_range="(0, 48)"),
+    # the quantile (generalised newsvendor) policies on the one-store real-data setting.  Its data blob is not shipped, so the
+    # generator derives one from the shipped 21-store file: every (product, store) series becomes a one-store sample
+    "f4_real_one_store_transformed_nv": dict(
+        setting="one_store_real_data_lost_demand", policy="transformed_nv", n=40, periods=12, ignore=4, torch_seed=33,
+        real=True, period_range="(0, 48)", one_store_from_21=True),
+    "f4_real_one_store_fixed_quantile": dict(
+        setting="one_store_real_data_lost_demand", policy="fixed_quantile", n=40, periods=12, ignore=4, torch_seed=34,
+        real=True, period_range="(0, 48)", one_store_from_21=True),
+    "f4_real_one_store_quantile_nv": dict(
+        setting="one_store_real_data_lost_demand", policy="quantile_nv", n=40, periods=12, ignore=4, torch_seed=35,
+        real=True, period_range="(0, 48)", one_store_from_21=True),
+    "f4_real_one_store_returns_nv": dict(
+        setting="one_store_real_data_lost_demand", policy="returns_nv", n=40, periods=12, ignore=4, torch_seed=36,
+        real=True, period_range="(0, 48)", one_store_from_21=True),
+    "f4_real_one_store_just_in_time": dict(
+        setting="one_store_real_data_lost_demand", policy="just_in_time", n=40, periods=12, ignore=4, torch_seed=37,
+        real=True, period_range="(0, 48)", one_store_from_21=True),
 }
 
 

@@ -50,10 +50,29 @@ def run_case(name, case, ref):
     }
     obs_params = defaultdict(lambda: None, cs["observation_params"])
     seeds = cs["seeds"]
+    real = bool(case.get("real"))
+    cfg_record["real"] = real
+    if case.get("one_store_from_21"):
+        # the one-store real-data blob is not shipped: derive it from the shipped 21-store file (every (product, store)
+        # weekly-sales series becomes a one-store sample); the derived tensor lives in a temp dir, the fixture keeps `data/*`
+        import tempfile
+        src = torch.load(os.path.join(rh.REFERENCE_ROOT, "data_files/favorita_21_stores/weekly_sales.pt"), map_location="cpu")
+        derived = os.path.join(tempfile.mkdtemp(), "weekly_sales_one_store.pt")
+        torch.save(src.reshape(-1, 1, src.shape[2]).clone(), derived)
+        cs["store_params"]["demand"]["file_location"] = derived
+        cfg_record["store_params"]["demand"]["file_location"] = "<derived: favorita_21_stores/weekly_sales.pt reshaped to (6048, 1, 171)>"
     with rh.in_reference_dir():
-        scenario = ref.Scenario(case["periods"], cs["problem_params"], cs["store_params"], cs["warehouse_params"],
-                                cs["echelon_params"], case["n"], obs_params, seeds)
-        data = scenario.get_data()
+        if real:  # one scenario over all weeks, datasets split by period (main_run.py:50-66); the fixture keeps one short range
+            scenario = ref.Scenario(None, cs["problem_params"], cs["store_params"], cs["warehouse_params"],
+                                    cs["echelon_params"], case["n"], obs_params, seeds)
+            (dataset,) = ref.DatasetCreator().create_datasets(scenario, split=True, by_period=True,
+                                                             periods_for_split=[case["period_range"]])
+            data = dataset.data
+            cfg_record["period_range"] = case["period_range"]
+        else:
+            scenario = ref.Scenario(case["periods"], cs["problem_params"], cs["store_params"], cs["warehouse_params"],
+                                    cs["echelon_params"], case["n"], obs_params, seeds)
+            data = scenario.get_data()
         torch.manual_seed(case["torch_seed"])
         model = ref.NeuralNetworkCreator().create_neural_network(scenario, ch["nn_params"], device="cpu")
         sim = ref.Simulator(device="cpu")
@@ -68,22 +87,26 @@ def run_case(name, case, ref):
             o["internal_data"] = sim._internal_data
             model(o)
         # perturb closed-form parameters a little so gradients are non-degenerate but keep defaults meaningful
-        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        lazy = torch.nn.parameter.UninitializedParameter  # (policies that never call their `net`, e.g. just_in_time)
+        state = {k: v.detach().clone() for k, v in model.state_dict().items() if not isinstance(v, lazy)}
 
         # --- pass 1: the reference's own simulate_batch + backward (the pinned numbers)
         model.zero_grad()
         total, reported = trainer.simulate_batch(loss_fn, sim, model, T, cs["problem_params"], dict(data),
                                                  obs_params, case["ignore"], False)
         mean_loss = total / (B * T * S)
-        mean_loss.backward()
-        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        if model.trainable and total.requires_grad:
+            mean_loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
 
         # --- pass 2: step-by-step trace (same calls as trainer.py:190-213) to record states/actions/rewards
-        rewards, states, actions = [], [], []
+        rewards, states, actions, features = [], [], [], []
+        feat_keys = ["past_demands"] + list(obs_params["time_features"] or [])
         with torch.no_grad():
             obs, _ = sim.reset(T, cs["problem_params"], dict(data), obs_params)
             for t in range(T):
                 states.append({k: v.clone() for k, v in obs.items() if k.endswith("inventories")})
+                features.append({k: obs[k].clone() for k in feat_keys if k in obs})
                 o = {k: v for k, v in obs.items()}
                 o["internal_data"] = sim._internal_data
                 a = model(o)
@@ -104,7 +127,7 @@ def run_case(name, case, ref):
         out["data/" + k] = v.contiguous().numpy()
     out["mutated_demand_seed"] = np.array(seeds["demand"])
     dm = cs["store_params"]["demand"]
-    out["mutated_mean"] = np.asarray(dm["mean"], dtype=np.float64)
+    out["mutated_mean"] = np.asarray(dm.get("mean", []), dtype=np.float64)
     if "std" in dm:
         out["mutated_std"] = np.asarray(dm["std"], dtype=np.float64)
     for k, v in state.items():
@@ -118,6 +141,13 @@ def run_case(name, case, ref):
     for t, ac in enumerate(actions):
         for k, v in ac.items():
             out[f"actions/{t}/{k}"] = v.contiguous().numpy()
+    for t, ft in enumerate(features):  # observation features of period t (real-data settings: past-demand window, time features)
+        for k, v in ft.items():
+            out[f"features/{t}/{k}"] = v.contiguous().numpy()
+    fixed = getattr(model, "fixed_nets", None)
+    if fixed:  # the frozen quantile forecaster the policy loaded from the reference's quantile_forecasters/ (weights = data)
+        for k, v in fixed["quantile_forecaster"].state_dict().items():
+            out["forecaster/" + k] = v.detach().cpu().numpy()
     out["total"] = total.detach().numpy()
     out["reported"] = reported.detach().numpy()
     out["mean_loss"] = mean_loss.detach().numpy()

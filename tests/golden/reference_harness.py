@@ -47,6 +47,21 @@ def _install_gym_stub():
     sys.modules["gymnasium.spaces"] = spaces
 
 
+def _install_cpu_load_shim():
+    """The reference's quantile-forecaster checkpoint was saved from a CUDA tensor and is loaded without a map_location
+    (neural_networks.py:536); on this CPU-only container torch.load needs one.  Harness-level shim like the gymnasium stub."""
+    import torch
+    if getattr(torch.load, "_nic_cpu_shim", False):
+        return
+    orig = torch.load
+
+    def load(f, *a, **k):
+        k.setdefault("map_location", "cpu")
+        return orig(f, *a, **k)
+    load._nic_cpu_shim = True
+    torch.load = load
+
+
 _REF = None
 
 
@@ -58,6 +73,7 @@ def load_reference():
     if not reference_available():
         raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
     _install_gym_stub()
+    _install_cpu_load_shim()
     sys.dont_write_bytecode = True
     import matplotlib
     matplotlib.use("Agg")

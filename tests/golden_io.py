@@ -36,6 +36,15 @@ class Golden:
     def grads(self):
         return self.group("grad")
 
+    @property
+    def forecaster(self):
+        """state dict of the frozen quantile forecaster (quantile policies), or None"""
+        f = self.group("forecaster")
+        return f or None
+
+    def features(self, t):
+        return self.group(f"features/{t}")
+
     def states(self, t):
         return self.group(f"states/{t}")
 

@@ -11,10 +11,38 @@ from golden_io import Golden, case_names
 from oracle import inventory_oracle as orc
 
 
-def _build(g):
+REF_ROOT = "/root/reference"
+
+
+def _build(g, need_data=True):
+    """Config of a fixture and, for synthetic cases, the oracle's own scenario data.  Real-data cases read the
+    Favorita files the reference ships: their data is rebuilt only where /root/reference exists (this container)."""
+    import os
     c = g.fresh_config()
-    data = orc.generate_scenario_data(c["periods"], c["problem_params"], c["store_params"], c["warehouse_params"],
-                                      c["echelon_params"], c["n"], c["observation_params"], c["seeds"])
+    if not c.get("real"):
+        data = orc.generate_scenario_data(c["periods"], c["problem_params"], c["store_params"], c["warehouse_params"],
+                                          c["echelon_params"], c["n"], c["observation_params"], c["seeds"])
+        return c, data
+    if not need_data:
+        return c, None
+    if not os.path.isdir(os.path.join(REF_ROOT, "data_files")):
+        pytest.skip("the reference's data files are not on this machine")
+    sp = c["store_params"]
+    loc = sp["demand"]["file_location"]
+    cwd = os.getcwd()
+    os.chdir(REF_ROOT)  # the YAMLs hold paths relative to the reference root
+    try:
+        if loc.startswith("<derived"):  # one-store blob derived from the shipped 21-store file (tests/golden/make_golden.py)
+            import tempfile
+            src = torch.load("data_files/favorita_21_stores/weekly_sales.pt", map_location="cpu")
+            loc = os.path.join(tempfile.mkdtemp(), "one.pt")
+            torch.save(src.reshape(-1, 1, src.shape[2]).clone(), loc)
+            sp["demand"]["file_location"] = loc
+        full = orc.generate_scenario_data(None, c["problem_params"], sp, c["warehouse_params"], c["echelon_params"], c["n"],
+                                          c["observation_params"], c["seeds"])
+    finally:
+        os.chdir(cwd)
+    (data,) = orc.split_data_by_period(full, [c["period_range"]], c["observation_params"])
     return c, data
 
 
@@ -30,18 +58,25 @@ def test_scenario_data_bit_equal(name):
         assert torch.equal(data[k], ref[k]), k
     # the reference mutates its config in place; downstream code depends on it
     assert c["seeds"]["demand"] == int(g.z["mutated_demand_seed"])
-    np.testing.assert_array_equal(np.asarray(c["store_params"]["demand"]["mean"], dtype=np.float64), g.z["mutated_mean"])
+    if not c.get("real"):
+        np.testing.assert_array_equal(np.asarray(c["store_params"]["demand"]["mean"], dtype=np.float64), g.z["mutated_mean"])
 
 
 @pytest.mark.parametrize("name", case_names())
 def test_rollout_and_gradients_bit_equal(name):
     g = Golden(name)
-    c, _ = _build(g)
+    c, _ = _build(g, need_data=False)
     data = g.data
     pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"],
-                                     warehouse_upper_bound=g.tensor("warehouse_upper_bound"))
-    res, mean_loss, grads = orc.train_step_gradients(pol, c["periods"], c["problem_params"], data,
-                                                     c["observation_params"], c["ignore"])
+                                     warehouse_upper_bound=g.tensor("warehouse_upper_bound"), forecaster_state=g.forecaster)
+    if not g.grads:  # non-trainable policies (quantile_nv, returns_nv, just_in_time): forward only
+        with torch.no_grad():
+            res = orc.rollout(pol, c["periods"], c["problem_params"], data, c["observation_params"], c["ignore"])
+        mean_loss = res.total / (c["n"] * c["periods"] * c["problem_params"]["n_stores"])
+        grads = []
+    else:
+        res, mean_loss, grads = orc.train_step_gradients(pol, c["periods"], c["problem_params"], data,
+                                                         c["observation_params"], c["ignore"])
     assert torch.equal(res.per_period, g.tensor("rewards"))
     assert float(res.total) == float(g.z["total"])
     assert float(res.reported) == float(g.z["reported"])
@@ -55,6 +90,10 @@ def test_rollout_and_gradients_bit_equal(name):
         keys = sorted(ref_grads.keys(), key=lambda s: (int(s.split(".")[2]), s.split(".")[3] != "weight"))
     assert len(keys) == len(grads)
     for k, mine in zip(keys, grads):
+        if c.get("real"):
+            # the quantile policies interpolate between forecaster outputs; gradients agree to the last bits, not bitwise
+            assert float((mine - ref_grads[k]).norm()) <= 1e-6 * float(ref_grads[k].norm()) + 1e-12, k
+            continue
         if hasattr(pol, "param_keys"):
             # GNN: the forward (rewards, states, totals above) is bit-equal; its autograd graph has hundreds of fan-in points
             # whose accumulation order is an implementation detail of how the graph was built — gradients agree to ~1 ulp
@@ -66,15 +105,19 @@ def test_rollout_and_gradients_bit_equal(name):
 @pytest.mark.parametrize("name", case_names())
 def test_states_and_actions_trace(name):
     g = Golden(name)
-    c, _ = _build(g)
+    c, _ = _build(g, need_data=False)
     pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"],
-                                     warehouse_upper_bound=g.tensor("warehouse_upper_bound"))
+                                     warehouse_upper_bound=g.tensor("warehouse_upper_bound"), forecaster_state=g.forecaster)
     env = orc.env_reset(c["periods"], c["problem_params"], g.data, c["observation_params"])
     with torch.no_grad():
         for t in range(c["periods"]):
             for k, v in g.states(t).items():
                 assert torch.equal(env.obs[k], v), (t, k)
-            a = orc.policy_act(pol, env.obs)
+            for k, v in g.features(t).items():  # past-demand window / time features of period t (real-data settings)
+                assert torch.equal(env.obs[k], v), (t, k)
+            obs_in = dict(env.obs)
+            obs_in["internal_data"] = {"demands": env.demands, "period_shift": env.period_shift}
+            a = orc.policy_act(pol, obs_in)
             for k, v in g.actions(t).items():
                 assert torch.equal(a[k], v), (t, k)
             orc.env_step(env, a)

@@ -62,9 +62,63 @@ def _run_both(case, n, periods, ignore, torch_seed, maximize_profit=False, discr
             assert torch.equal(sim.observation[k], res.final_obs[k]), k
 
 
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", [k for k, v in CASES.items() if not v.get("real")])
 def test_fresh_seed_and_size(name):
     _run_both(CASES[name], n=37, periods=9, ignore=2, torch_seed=1234)
+
+
+@pytest.mark.parametrize("name", [k for k, v in CASES.items() if v.get("real")])
+def test_real_data_cases_fresh_products_and_weeks(name):
+    """SURVEY 8 f4 live: the reference and the oracle on the shipped Favorita data, other products / weeks / weights than the
+    committed fixtures: data dict, totals, final state and gradients."""
+    import os
+    import tempfile
+    case = CASES[name]
+    ref = rh.load_reference()
+    cs, ch = rh.load_reference_configs(case["setting"], case["policy"])
+    cs, ch = apply_overrides(case, cs, ch)
+    n, periods, ignore, rng = 23, 11, 2, "(30, 90)"
+    if case.get("one_store_from_21"):
+        src = torch.load(os.path.join(rh.REFERENCE_ROOT, "data_files/favorita_21_stores/weekly_sales.pt"), map_location="cpu")
+        derived = os.path.join(tempfile.mkdtemp(), "one.pt")
+        torch.save(src.reshape(-1, 1, src.shape[2])[100:].clone(), derived)
+        cs["store_params"]["demand"]["file_location"] = derived
+    cs_o = copy.deepcopy(cs)
+    obs_r = defaultdict(lambda: None, cs["observation_params"])
+    obs_o = defaultdict(lambda: None, cs_o["observation_params"])
+    with rh.in_reference_dir():
+        sc = ref.Scenario(None, cs["problem_params"], cs["store_params"], cs["warehouse_params"], cs["echelon_params"], n,
+                          obs_r, cs["seeds"])
+        (ds,) = ref.DatasetCreator().create_datasets(sc, split=True, by_period=True, periods_for_split=[rng])
+        data_r = ds.data
+        torch.manual_seed(77)
+        model = ref.NeuralNetworkCreator().create_neural_network(sc, ch["nn_params"], device="cpu")
+        sim, tr = ref.Simulator(device="cpu"), ref.Trainer(device="cpu")
+        total, rep = tr.simulate_batch(ref.PolicyLoss(), sim, model, periods, cs["problem_params"], dict(data_r), obs_r,
+                                       ignore, False)
+        if total.requires_grad:
+            (total / (n * periods * cs["problem_params"]["n_stores"])).backward()
+        full = orc.generate_scenario_data(None, cs_o["problem_params"], cs_o["store_params"], cs_o["warehouse_params"],
+                                          cs_o["echelon_params"], n, obs_o, cs_o["seeds"])
+    (data_o,) = orc.split_data_by_period(full, [rng], obs_o)
+    assert set(data_r) == set(data_o)
+    for k in data_r:
+        assert torch.equal(data_r[k], data_o[k]), k
+    lazy = torch.nn.parameter.UninitializedParameter
+    state = {k: v for k, v in model.state_dict().items() if not isinstance(v, lazy)}
+    fixed = getattr(model, "fixed_nets", None)
+    pol = orc.policy_from_state_dict(ch["nn_params"], state, cs_o["problem_params"], None,
+                                     forecaster_state=fixed["quantile_forecaster"].state_dict() if fixed else None)
+    res = orc.rollout(pol, periods, cs_o["problem_params"], data_o, obs_o, ignore)
+    assert float(res.total.detach()) == float(total.detach()) and float(res.reported.detach()) == float(rep.detach())
+    if res.total.requires_grad:
+        (res.total / (n * periods * cs_o["problem_params"]["n_stores"])).backward()
+        for (k, p), mine in zip(((k, p) for k, p in model.named_parameters() if not isinstance(p, lazy)), pol.parameters()):
+            if p.grad is not None and float(p.grad.abs().max()) > 0:
+                assert float((p.grad - mine.grad).norm()) <= 1e-6 * float(p.grad.norm()), k
+    for k in ("store_inventories", "warehouse_inventories"):
+        if k in sim.observation:
+            assert torch.equal(sim.observation[k], res.final_obs[k]), k
 
 
 @pytest.mark.parametrize("name", ["cfg1_one_store_lost_vanilla", "cfg3_one_warehouse_5_vanilla"])
