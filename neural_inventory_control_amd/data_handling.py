@@ -146,7 +146,7 @@ class Scenario:
                 print(f"Error: {e}")
 
     def read_real_demand_data(self, problem_params, demand_params, seed):
-        return torch.load(demand_params["file_location"])[: self.num_samples]
+        return torch.load(demand_params["file_location"], map_location="cpu")[: self.num_samples]
 
     def generate_demand_parameters(self, problem_params, demand_params, seeds):
         if demand_params["sample_across_stores"]:
@@ -212,7 +212,7 @@ class Scenario:
         draw = np.random.randint if discrete else np.random.uniform
         S = problem_params["n_stores"]
         if flag("file_location"):
-            p["value"] = torch.load(p["file_location"])[: self.num_samples]
+            p["value"] = torch.load(p["file_location"], map_location="cpu")[: self.num_samples]
         if flag("sample_across_stores"):
             return torch.tensor(draw(*p["range"], S)).expand(self.num_samples, -1)
         if flag("vary_across_samples"):

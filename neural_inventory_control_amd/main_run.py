@@ -9,8 +9,8 @@ datasets -> device-resident batches -> policy -> Adam -> Trainer, on the GPU the
 GPU under `torch.distributed.run`; scenarios are then sharded across ranks).
 
 Differences from the reference script, on purpose: `train` also runs the test pass afterwards (its README says so; its
-`elif` at main_run.py:131 skips it), batches are device-resident (no per-sample collate), and synthetic settings only
-(`split_by_period` needs the real-data blobs the reference does not ship).
+`elif` at main_run.py:131 skips it) and batches are device-resident (no per-sample collate).  Real-data settings
+(`split_by_period`) read the demand / feature files their YAML names, exactly like the reference.
 """
 import argparse
 import os
@@ -54,19 +54,26 @@ def build(config_setting, config_hyperparams, device, rank=0, world_size=1):
      echelon_params, sample_data_params) = [config_setting[k] for k in SETTING_KEYS]
     trainer_params, optimizer_params, nn_params = [config_hyperparams[k] for k in HYPERPARAM_KEYS]
     observation_params = defaultdict(lambda: None, observation_params)
-    if sample_data_params and sample_data_params.get("split_by_period"):
-        raise NotImplementedError("split_by_period settings need the reference's real-data files (out of scope, DESIGN.md §8)")
-
     creator = DatasetCreator()
-    max_periods = max(params_by_dataset["train"]["periods"], params_by_dataset["dev"]["periods"])
-    scenario = Scenario(max_periods, problem_params, store_params, warehouse_params, echelon_params,
-                        params_by_dataset["train"]["n_samples"] + params_by_dataset["dev"]["n_samples"],
-                        observation_params, seeds)
-    train_set, dev_set = creator.create_datasets(scenario, split=True, by_sample_indexes=True,
-                                                 sample_index_for_split=params_by_dataset["dev"]["n_samples"])
-    test_scenario = Scenario(params_by_dataset["test"]["periods"], problem_params, store_params, warehouse_params,
-                             echelon_params, params_by_dataset["test"]["n_samples"], observation_params, test_seeds)
-    test_set = creator.create_datasets(test_scenario, split=False)
+    if sample_data_params and sample_data_params.get("split_by_period"):
+        # real data (main_run.py:50-66): train, dev and test sets are the SAME products over different week ranges - one
+        # scenario, per-sample tensors shared, demands and time features sliced along the period axis
+        scenario = Scenario(None, problem_params, store_params, warehouse_params, echelon_params,
+                            params_by_dataset["train"]["n_samples"], observation_params, seeds)
+        train_set, dev_set, test_set = creator.create_datasets(
+            scenario, split=True, by_period=True,
+            periods_for_split=[sample_data_params[k] for k in ("train_periods", "dev_periods", "test_periods")])
+        test_scenario = scenario
+    else:
+        max_periods = max(params_by_dataset["train"]["periods"], params_by_dataset["dev"]["periods"])
+        scenario = Scenario(max_periods, problem_params, store_params, warehouse_params, echelon_params,
+                            params_by_dataset["train"]["n_samples"] + params_by_dataset["dev"]["n_samples"],
+                            observation_params, seeds)
+        train_set, dev_set = creator.create_datasets(scenario, split=True, by_sample_indexes=True,
+                                                     sample_index_for_split=params_by_dataset["dev"]["n_samples"])
+        test_scenario = Scenario(params_by_dataset["test"]["periods"], problem_params, store_params, warehouse_params,
+                                 echelon_params, params_by_dataset["test"]["n_samples"], observation_params, test_seeds)
+        test_set = creator.create_datasets(test_scenario, split=False)
 
     def loader(ds, key, shuffle):
         return DeviceBatches(ds, params_by_dataset[key]["batch_size"], shuffle=shuffle, device=device, rank=rank,

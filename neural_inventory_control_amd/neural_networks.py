@@ -380,6 +380,153 @@ class VanillaWarehouse(MyNeuralNetwork):
 
 
 
+class DataDrivenNet(MyNeuralNetwork):
+    """neural_networks.py:430-515: one MLP over every observed feature of the real-data settings (pipelines, the past-demand
+    window, costs, days from christmas, lead-time matrix); with warehouses the outputs are [Wn warehouse orders | S x Wn store
+    orders], masked by the adjacency and scaled down proportionally when a warehouse's pipeline total is short."""
+
+    def __init__(self, args, scenario=None, device="cpu"):
+        super().__init__(args, device)
+        self.scenario = scenario
+
+    def forward(self, observation):
+        n_warehouses = observation["warehouse_inventories"].size(1) if "warehouse_inventories" in observation else 0
+        n_stores = observation["store_inventories"].size(1)
+        feats = [observation["store_inventories"]]
+        if n_warehouses > 0:
+            feats.append(observation["warehouse_inventories"])
+        feats += [observation["past_demands"], observation["underage_costs"], observation["holding_costs"],
+                  observation["days_from_christmas"], observation["lead_times"]]
+        outputs = self.net["master"](self.flatten_then_concatenate_tensors(feats))
+        if n_warehouses == 0:
+            return {"stores": outputs.unsqueeze(2)}
+        adjacency = self.scenario.problem_params["warehouse_store_adjacency"]
+        edge_mask = torch.tensor(adjacency, dtype=torch.float32, device=outputs.device).transpose(0, 1)  # [S, Wn]
+        warehouse_outputs, store_flat = outputs[:, :n_warehouses], outputs[:, n_warehouses:]
+        store_allocation = store_flat.reshape(outputs.size(0), n_stores, n_warehouses) * edge_mask.unsqueeze(0)
+        final = torch.zeros_like(store_allocation)
+        for w in range(n_warehouses):
+            if edge_mask[:, w].sum() > 0:
+                final[:, :, w] = self.apply_proportional_allocation(store_allocation[:, :, w],
+                                                                    observation["warehouse_inventories"][:, w])
+        return {"stores": final, "warehouses": warehouse_outputs.unsqueeze(2)}
+
+
+class QuantilePolicy(MyNeuralNetwork):
+    """neural_networks.py:517-588: map features to a desired quantile per store, invert it with the frozen quantile forecaster
+    to a base-stock level, order up to it."""
+
+    def __init__(self, args, device="cpu"):
+        super().__init__(args=args, device=device)
+        self.fixed_nets = {"quantile_forecaster": self.load_forecaster(args, requires_grad=False)}
+        self.allow_back_orders = False
+
+    def load_forecaster(self, nn_params, requires_grad=True):
+        from .quantile_forecaster import FullyConnectedForecaster
+        import numpy as np
+        fc = FullyConnectedForecaster([128, 128], lead_times=nn_params["forecaster_lead_times"], qs=np.arange(0.05, 1, 0.05),
+                                      device=self.device)
+        # (the shipped file was saved from CUDA tensors; map it to wherever this policy lives)
+        fc.load_state_dict(torch.load(f"{nn_params['forecaster_location']}", map_location="cpu"))
+        for p in fc.parameters():
+            p.requires_grad_(requires_grad)
+        return fc.to(self.device)
+
+    def forecast_base_stock_allocation(self, past_demands, days_from_christmas, store_inventories, lead_times, quantiles,
+                                       allow_back_orders=False):
+        x = torch.cat([past_demands, days_from_christmas.unsqueeze(1).expand(past_demands.shape[0], past_demands.shape[1], 1)],
+                      dim=2)
+        levels = self.fixed_nets["quantile_forecaster"].get_quantile(x, quantiles, lead_times)
+        pos = store_inventories.sum(dim=2)
+        alloc = levels - pos if allow_back_orders else torch.clip(levels - pos, min=0)
+        return {"stores": alloc.unsqueeze(2)}
+
+    def compute_desired_quantiles(self, args):
+        raise NotImplementedError
+
+    def forward(self, observation):
+        lead_times = observation["lead_times"][:, :, 0]
+        u, h, past, xmas, inv = [observation[k] for k in ("underage_costs", "holding_costs", "past_demands",
+                                                          "days_from_christmas", "store_inventories")]
+        q = self.compute_desired_quantiles({"underage_costs": u, "holding_costs": h})
+        return self.forecast_base_stock_allocation(past, xmas, inv, lead_times, q, allow_back_orders=self.allow_back_orders)
+
+
+class TransformedNV(QuantilePolicy):
+    """neural_networks.py:590-597: a learned map of the newsvendor quantile u / (u + h)."""
+
+    def compute_desired_quantiles(self, args):
+        return self.net["master"](args["underage_costs"] / (args["underage_costs"] + args["holding_costs"]))
+
+
+class QuantileNV(QuantilePolicy):
+    """neural_networks.py:599-611: the newsvendor quantile itself (nothing to train)."""
+
+    def __init__(self, args, device="cpu"):
+        super().__init__(args=args, device=device)
+        self.trainable = False
+
+    def compute_desired_quantiles(self, args):
+        return args["underage_costs"] / (args["underage_costs"] + args["holding_costs"])
+
+
+class ReturnsNV(QuantileNV):
+    """neural_networks.py:613-622: QuantileNV that may order negative quantities (non-admissible)."""
+
+    def __init__(self, args, device="cpu"):
+        super().__init__(args=args, device=device)
+        self.trainable = False
+        self.allow_back_orders = True
+
+
+class FixedQuantile(QuantilePolicy):
+    """neural_networks.py:624-631: one learned quantile for every store and period."""
+
+    def compute_desired_quantiles(self, args):
+        u = args["underage_costs"]
+        return self.net["master"](torch.zeros(1, device=u.device)).unsqueeze(1).expand(u.shape[0], u.shape[1])
+
+
+class JustInTime(MyNeuralNetwork):
+    """neural_networks.py:634-739: the non-admissible oracle benchmark - reads FUTURE demand from the simulator's internal data
+    and orders so that units arrive exactly when they are demanded (each store served by its fastest connected warehouse)."""
+
+    def __init__(self, args, scenario=None, device="cpu"):
+        super().__init__(args=args, device=device)
+        self.scenario = scenario
+        self.trainable = False
+
+    def forward(self, observation):
+        current_period = observation["current_period"]
+        demands, period_shift = self.unpack_args(observation["internal_data"], ["demands", "period_shift"])
+        dev = demands.device
+        n, n_stores, n_periods = demands.shape
+        cur = int(current_period.reshape(-1)[0]) + period_shift  # (host tensor: no device sync)
+        rows = torch.arange(n, device=dev)
+        n_warehouses = observation["warehouse_inventories"].size(1) if "warehouse_inventories" in observation else 0
+        if n_warehouses == 0:
+            lt = observation["lead_times"][:, :, 0]
+            fut = torch.stack([demands[:, j][rows, torch.clip(cur + lt[:, j].long(), max=n_periods - 1)]
+                               for j in range(n_stores)], dim=1)
+            return {"stores": torch.clip(fut, min=0).unsqueeze(2)}
+        lt, wlt = observation["lead_times"], observation["warehouse_lead_times"]
+        adj = torch.tensor(self.scenario.problem_params["warehouse_store_adjacency"], dtype=torch.float32)
+        fastest = getattr(self, "_fastest", None)
+        if fastest is None:  # static: which connected warehouse has the shortest (batch-mean) lead time for each store
+            mean_lt = lt.mean(dim=0).cpu()
+            fastest = self._fastest = [
+                (int(conn[torch.argmin(mean_lt[st, conn])]) if len(conn) > 0 else None)
+                for st, conn in ((st, adj[:, st].nonzero(as_tuple=True)[0]) for st in range(n_stores))]
+        alloc = torch.zeros(n, n_stores, n_warehouses, device=dev)
+        wh = torch.zeros(n, n_warehouses, device=dev)
+        for st, w in enumerate(fastest):
+            if w is None:
+                continue
+            alloc[:, st, w] = demands[:, st][rows, torch.clip(cur + lt[:, st, w].long(), max=n_periods - 1)]
+            wh[:, w] += demands[:, st][rows, torch.clip(cur + wlt[:, w].long() + lt[:, st, w].long(), max=n_periods - 1)]
+        return {"stores": torch.clip(alloc, min=0), "warehouses": torch.clip(wh, min=0).unsqueeze(2)}
+
+
 class GNN(MyNeuralNetwork):
     """Message-passing policy over the supply graph (neural_networks.py:742-1492 of the reference): nodes =
     [echelons..., warehouses..., stores...], edges = [internal (source-major), supplier, demand, self-loops of supplying
@@ -571,7 +718,8 @@ class NeuralNetworkCreator:
         architectures = {
             "vanilla_one_store": VanillaOneStore, "base_stock": BaseStock, "capped_base_stock": CappedBaseStock,
             "echelon_stock": EchelonStock, "vanilla_serial": VanillaSerial, "vanilla_warehouse": VanillaWarehouse,
-            "gnn": GNN,
+            "data_driven": DataDrivenNet, "transformed_nv": TransformedNV, "fixed_quantile": FixedQuantile,
+            "quantile_nv": QuantileNV, "returns_nv": ReturnsNV, "just_in_time": JustInTime, "gnn": GNN,
         }
         return architectures[name]  # KeyError for unknown names, like the reference (:1536)
 
@@ -587,7 +735,7 @@ class NeuralNetworkCreator:
             if val is None:
                 p["output_sizes"][key] = self.set_default_output_size(key, scenario.problem_params)
         cls = self.get_architecture(p["name"])
-        if p["name"] in ("vanilla_warehouse", "gnn"):
+        if p["name"] in ("vanilla_warehouse", "gnn", "just_in_time", "data_driven"):
             model = cls(p, scenario, device=device)
         else:
             model = cls(p, device=device)

@@ -140,10 +140,14 @@ def check_env_forward(be, name):
     B, T = c["n"], c["periods"]
     rewards = g.tensor("rewards")
     demands = data["demands"].to(dev)
+    shift = c["observation_params"]["demand"]["period_shift"]  # real-data settings start inside the trace (environment.py:177)
+    # the quantile policies' orders are float64 upstream (float64 probability points, quantile_forecaster.py:33), and with them
+    # the reference's state from the first step on: the float32 kernel is then compared to rounding, not bit for bit
+    f64 = g.states(1)["store_inventories"].dtype == torch.float64
     for t in range(T):
-        s, w, e = _state_soa(g.states(t), prob, dev)
-        ts, tw, te, _keep = _orders_tables(g.actions(t), dev)
-        io = prob.make_io(s, w, e, _demand_table(demands, t), ts, tw, te)
+        s, w, e = _state_soa({k: v.float() for k, v in g.states(t).items()}, prob, dev)
+        ts, tw, te, _keep = _orders_tables({k: v.float() for k, v in g.actions(t).items()}, dev)
+        io = prob.make_io(s, w, e, _demand_table(demands, t + shift), ts, tw, te)
         so = torch.zeros_like(s)
         wo = torch.zeros_like(w) if w is not None else None
         eo = torch.zeros_like(e) if e is not None else None
@@ -152,12 +156,15 @@ def check_env_forward(be, name):
         be.sync()
         nxt = g.states(t + 1)
         # integer slot placement and the store pipelines are exact; sums over stores may differ in the last bit
-        assert torch.equal(ref_view(so, B).cpu(), nxt["store_inventories"]), (t, "stores")
+        if f64:
+            torch.testing.assert_close(ref_view(so, B).cpu(), nxt["store_inventories"].float(), rtol=2e-6, atol=1e-4)
+        else:
+            assert torch.equal(ref_view(so, B).cpu(), nxt["store_inventories"]), (t, "stores")
         if prob.Wn:
             torch.testing.assert_close(ref_view(wo, B).cpu(), nxt["warehouse_inventories"], rtol=2e-6, atol=1e-5)
         if prob.E:
             torch.testing.assert_close(ref_view(eo, B).cpu(), nxt["echelon_inventories"], rtol=2e-6, atol=1e-5)
-        torch.testing.assert_close(r[:B].cpu(), rewards[t], rtol=2e-6, atol=1e-5)
+        torch.testing.assert_close(r[:B].cpu(), rewards[t].float(), rtol=2e-6, atol=1e-3 if f64 else 1e-5)
         assert float(r[B:].abs().sum()) == 0.0
 
 
@@ -172,11 +179,12 @@ def check_env_backward(be, name, profit):
     demands = data["demands"].to(dev)
     gen = torch.Generator().manual_seed(7)
     compared = 0
+    shift = c["observation_params"]["demand"]["period_shift"]
     for t in (0, 1, c["periods"] // 2, c["periods"] - 1):
-        st = {k: v.clone().requires_grad_(True) for k, v in g.states(t).items()}
-        act = {k: v.clone().requires_grad_(True) for k, v in g.actions(t).items()}
+        st = {k: v.float().clone().requires_grad_(True) for k, v in g.states(t).items()}
+        act = {k: v.float().clone().requires_grad_(True) for k, v in g.actions(t).items()}
         with torch.no_grad():  # force exact ties / zeros: on-hand == demand, zero orders
-            st["store_inventories"][0, :, 0] = data["demands"][0, :, t]
+            st["store_inventories"][0, :, 0] = data["demands"][0, :, t + shift]
             act["stores"][1 % B] = 0.0
         env = orc.env_reset(c["periods"], c["problem_params"], data, c["observation_params"])
         env.obs.update(st)
@@ -192,7 +200,7 @@ def check_env_backward(be, name, profit):
 
         s, w, e = _state_soa({k: v.detach() for k, v in st.items()}, prob, dev)
         ts, tw, te, _keep = _orders_tables({k: v.detach() for k, v in act.items()}, dev)
-        io = prob.make_io(s, w, e, _demand_table(demands, t), ts, tw, te)
+        io = prob.make_io(s, w, e, _demand_table(demands, t + shift), ts, tw, te)
         gso = to_soa(g_out["store_inventories"].to(dev), prob.ldb)
         gwo = to_soa(g_out["warehouse_inventories"].to(dev), prob.ldb) if prob.Wn else None
         geo = to_soa(g_out["echelon_inventories"].to(dev), prob.ldb) if prob.E else None

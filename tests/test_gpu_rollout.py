@@ -45,13 +45,22 @@ def _model(g, c, scenario=None):
     if scenario is None:
         sc.problem_params = c["problem_params"]
         sc.store_params = {"demand": {"mean": [float(x) for x in np.atleast_1d(g.z["mutated_mean"])]}}
+    if g.forecaster is not None:
+        # quantile policies load their frozen forecaster from nn_params['forecaster_location'] (a file of the reference's
+        # tree); the fixture carries its weights, written to a temporary file in the reference's own format
+        import os
+        import tempfile
+        path = os.path.join(tempfile.mkdtemp(), "forecaster.pt")
+        torch.save(g.forecaster, path)
+        c["nn_params"]["forecaster_location"] = path
     model = NeuralNetworkCreator().create_neural_network(sc, c["nn_params"], device=DEV)
     model.warehouse_upper_bound = g.tensor("warehouse_upper_bound").to(DEV)
     return model
 
 
 def _load(model, g):
-    model.load_state_dict({k: v.to(DEV) for k, v in g.params.items()})
+    if g.params:  # (just_in_time never materialises its unused net: nothing to load)
+        model.load_state_dict({k: v.to(DEV) for k, v in g.params.items()})
 
 
 def _sorted_grad_keys(ref):
@@ -134,14 +143,38 @@ def test_simulator_autograd_route_matches_reference(name):
     model.zero_grad()
     total, reported = tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data,
                                         c["observation_params"], c["ignore"], False)
-    (total / (c["n"] * c["periods"] * c["problem_params"]["n_stores"])).backward()
+    if total.requires_grad:  # (quantile_nv / returns_nv / just_in_time have nothing to train)
+        (total / (c["n"] * c["periods"] * c["problem_params"]["n_stores"])).backward()
     torch.cuda.synchronize()
     assert abs(float(total) - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
     assert abs(float(reported) - float(g.z["reported"])) <= 1e-5 * abs(float(g.z["reported"]))
     for k, v in g.states(c["periods"]).items():
-        torch.testing.assert_close(sim.observation[k].cpu(), v, **STATE_TOL)
+        torch.testing.assert_close(sim.observation[k].cpu(), v.float(), **STATE_TOL)
     assert int(sim.observation["current_period"]) == c["periods"]
     _check_grads(model, g, GRAD_TOL)
+
+
+@pytest.mark.parametrize("name", [n for n in case_names() if n.startswith("f4_real")])
+def test_real_data_observations_and_dynamics_follow_the_reference_tape(name):
+    """`Simulator.reset/step` on a real-data setting (period_shift 16, past-demand window of 16, days from
+    christmas, profit objective) driven by the reference's own action tape: every period's observation features and state are
+    the reference's, per-period rewards within 1e-5."""
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    sim = Simulator(device=DEV)
+    obs, _ = sim.reset(c["periods"], c["problem_params"], data, c["observation_params"])
+    ref_r = g.tensor("rewards").float()
+    assert sim._internal_data["period_shift"] == c["observation_params"]["demand"]["period_shift"] == 16
+    for t in range(c["periods"]):
+        for k, v in g.features(t).items():
+            assert torch.equal(obs[k].cpu(), v), (t, k)
+        for k, v in g.states(t).items():
+            torch.testing.assert_close(obs[k].cpu(), v.float(), rtol=2e-6, atol=2e-3)
+        action = {k: v.float().to(DEV) for k, v in g.actions(t).items()}
+        obs, reward, terminated, _, _ = sim.step(action)
+        torch.testing.assert_close(reward.cpu(), ref_r[t], rtol=1e-5, atol=2e-2)
+        assert bool(terminated) == (t == c["periods"] - 1)
 
 
 @pytest.mark.parametrize("name", ["cfg1_one_store_lost_vanilla", "cfg3_one_warehouse_5_vanilla", "cfg4_serial_vanilla"])
