@@ -579,6 +579,8 @@ def policy_act(pol: OraclePolicy, obs: Dict[str, torch.Tensor]) -> Dict[str, tor
         x = torch.cat([past, xmas.unsqueeze(1).expand(past.shape[0], past.shape[1], 1)], dim=2)
         levels = forecaster_quantile(pol, x, q, lead)
         pos = obs["store_inventories"].sum(dim=2)
+        if isinstance(obs.get("_probe"), list):  # tests: (level, level - position) before the clip, to find knife edges
+            obs["_probe"].append((levels.detach(), (levels - pos).detach()))
         alloc = levels - pos if name == "returns_nv" else torch.clip(levels - pos, min=0)
         return {"stores": alloc.unsqueeze(2)}
 
@@ -879,8 +881,9 @@ def gnn_act(pol: OracleGNNPolicy, obs):
 
 
 def rollout(pol: OraclePolicy, periods, problem_params, data, observation_params,
-            ignore_periods=0, discrete_allocation=False, keep_states=False) -> RolloutResult:
-    """trainer.py:181-216.  PolicyLoss = reward.sum() (loss_functions.py:11-12)."""
+            ignore_periods=0, discrete_allocation=False, keep_states=False, probe=None) -> RolloutResult:
+    """trainer.py:181-216.  PolicyLoss = reward.sum() (loss_functions.py:11-12).  probe: optional list that receives the
+    quantile policies' (level, level - position) per period (see policy_act)."""
     env = env_reset(periods, problem_params, dict(data), observation_params)
     total, reported = 0, 0
     per_period = []
@@ -889,6 +892,9 @@ def rollout(pol: OraclePolicy, periods, problem_params, data, observation_params
         if keep_states:
             states.append({k: v.detach().clone() for k, v in env.obs.items() if k.endswith("inventories")})
         obs_in = env.obs
+        if probe is not None:
+            obs_in = dict(env.obs)
+            obs_in["_probe"] = probe
         if pol.name == "just_in_time":  # trainer.py:195-196: non-admissible policies read the simulator's internal data
             obs_in = dict(env.obs)
             obs_in["internal_data"] = {"demands": env.demands, "period_shift": env.period_shift}
