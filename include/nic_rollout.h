@@ -266,6 +266,52 @@ int nic_closed_form_num_partials(int32_t n_scenarios, int32_t S);
 int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
                             float* g_levels_partial, void* stream);
 
+/* ---- fused three-layer 32-wide MLP over gathered inputs (graph policies) -----------------------------------------
+ * The GNN policy (neural_networks.py:742-1492) applies five small MLPs (`gnn.yml`: K -> 32 -> 32 -> 32 or 1, ELU inside) to
+ * every node / edge of the supply graph of every scenario, on inputs that are concatenations of gathered node / edge
+ * features (:1105-1192, :1229-1269).  One launch evaluates one such MLP for all (entity, scenario) columns: a wavefront owns
+ * 32 scenarios of one entity, GATHERS its K input rows straight from the source buffers through per-segment entity maps
+ * (the static graph: no materialised concatenation), runs the three layers on the matrix cores with the activations chained
+ * in registers (csrc/mlp3.hip), and writes the output plus what the backward needs.
+ *   column (e, b), input row of segment s, row r:  seg[s].base[r*row_stride + ent*ent_stride + b*scn_stride],
+ *   ent = seg[s].map ? seg[s].map[e] : e;  ent < 0 reads 0 (the virtual supplier / customer node).
+ * Buffers are [rows][n_entities][ldb] (scenario-minor); weights packed [W1 32xK][b1 32][W2 32x32][b2 32][W3 n_out x 32][b3]. */
+#define NIC_MLP3_MAX_K 96
+#define NIC_MLP3_MAX_SEGS 4
+#define NIC_MLP3_ACT_NONE 0
+#define NIC_MLP3_ACT_ELU 1
+#define NIC_MLP3_ACT_SOFTPLUS 2
+typedef struct NicMlp3Seg {
+    const float* base;
+    const int32_t* map;      /* [n_entities] or NULL (identity) */
+    int64_t row_stride;      /* elements between consecutive feature rows of the source buffer */
+    int64_t ent_stride;      /* elements between entities (0 broadcasts one entity to all) */
+    int64_t scn_stride;      /* 1, or 0 for a per-entity constant (e.g. an edge's lead time) */
+    int32_t n_rows;
+    int32_t reserved;
+} NicMlp3Seg;
+typedef struct NicMlp3Desc {
+    int32_t n_entities, n_scenarios, ldb;
+    int32_t K, n_out, out_act, n_segs, reserved;   /* K = sum of segment rows <= NIC_MLP3_MAX_K; n_out = 32 or 1..8 */
+    NicMlp3Seg seg[NIC_MLP3_MAX_SEGS];
+    const float* weights;
+} NicMlp3Desc;
+/* Y [n_out][n_entities][ldb] = out_act(MLP(x)).  When X_hist != NULL the gathered inputs and the hidden activations are kept
+ * for the backward / weight gradients: X_hist [K][n_entities][ldb], H1, H2 [32][n_entities][ldb] (post-ELU). */
+int nic_mlp3_fwd(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float* H2, void* stream);
+/* Backward of the same MLP from dY [n_out][n_entities][ldb] and the stored Y / H1 / H2: the pre-activation gradients dZ3
+ * [n_out][..], dZ2, dZ1 [32][..] (the weight gradients are nic_linear_wgrad contractions of these with H2 / H1 / X_hist over
+ * all columns) and dX [K][n_entities][ldb], the gradient with respect to the GATHERED inputs (dense per column; the caller
+ * adds it back to the sources with nic_segment_sum over the transposed maps).  dX may be NULL. */
+int nic_mlp3_bwd(const NicMlp3Desc* d, const float* dY, const float* Y, const float* H1, const float* H2, float* dZ3,
+                 float* dZ2, float* dZ1, float* dX, void* stream);
+/* dst[r][n][b] (+)= dst_scale[n] * sum_{p in [offsets[n], offsets[n+1])} src[r][items[p]][b] for r < R, in item order
+ * (deterministic: no atomics).  Forward: message aggregation over a node's incident edges (:1229-1269, with the
+ * 1/sqrt(degree) normalisation :1275-1296 as dst_scale); backward: the adjoint of every gather above. */
+int nic_segment_sum(float* dst, int64_t dst_row_stride, const float* src, int64_t src_row_stride, const int32_t* offsets,
+                    const int32_t* items, const float* dst_scale /* [n_dst] or NULL */, int32_t R, int32_t n_dst,
+                    int32_t n_scenarios, int32_t ldb, int32_t accumulate, void* stream);
+
 /* ---- batched demand sampler -------------------------------------------------------------------------------
  * Replaces Scenario.generate_normal_demand / generate_poisson_demand (data_handling.py:178-211) for synthetic
  * throughput runs: counter-based Philox4x32-10 keyed by (seed, global scenario index, period), so results do not

@@ -65,6 +65,17 @@ class NicClosedFormDesc(C.Structure):
                                             "ech_holding", "ech_lead")])
 
 
+class NicMlp3Seg(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("map", C.c_void_p), ("row_stride", C.c_int64), ("ent_stride", C.c_int64),
+                ("scn_stride", C.c_int64), ("n_rows", C.c_int32), ("reserved", C.c_int32)]
+
+
+class NicMlp3Desc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("n_entities", "n_scenarios", "ldb", "K", "n_out", "out_act", "n_segs", "reserved")]
+                + [("seg", NicMlp3Seg * 4), ("weights", C.c_void_p)])
+
+
+NIC_MLP3_MAX_K, NIC_MLP3_ACT_NONE, NIC_MLP3_ACT_ELU, NIC_MLP3_ACT_SOFTPLUS = 96, 0, 1, 2
 NIC_CF_MAX_LEVELS = 5
 NIC_CF_BASE_STOCK, NIC_CF_CAPPED, NIC_CF_ECHELON = 0, 1, 2
 NIC_SR_MAX_INPUTS, NIC_SR_HIDDEN, NIC_SR_MAX_OUTPUTS = 16, 32, 8
@@ -98,6 +109,9 @@ PROTOTYPES = {
     "nic_small_rollout_fwd": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_small_rollout_bwd": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, NicTable2, _vp, _vp, _vp]),
     "nic_round_orders": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
+    "nic_mlp3_fwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp]),
+    "nic_mlp3_bwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nic_segment_sum": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_closed_form_num_partials": (C.c_int, [_i32, _i32]),
     "nic_closed_form_rollout": (C.c_int, [C.POINTER(NicClosedFormDesc), _vp, _vp, _vp, _vp, _vp]),
     "nic_sample_demand": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i64, _u64, _i32, _vp, _vp, _i32, _vp]),

@@ -176,6 +176,57 @@ def head_serial_bwd(Z, wh_inv, ech_inv, ub, g_store_orders, g_wh_orders, g_ech_o
                                     current_stream()))
 
 
+# ---- fused 3-layer MLP over gathered inputs + segment sums (graph policies) -----------------------------------------
+
+class Mlp3Segment:
+    """One group of input rows of an MLP3 launch: rows of `tensor` ([rows][n_src_entities][ldb], or [rows][n_src] for a
+    per-entity constant with per_scenario=False) gathered through `index` (int32 device tensor [n_entities], -1 = zeros; None =
+    identity)."""
+
+    def __init__(self, tensor, index=None, per_scenario=True):
+        self.tensor, self.index, self.per_scenario = tensor, index, per_scenario
+
+
+def mlp3_desc(segments, weights, n_entities, n_scenarios, ldb, n_out, out_act):
+    d = _lib.NicMlp3Desc()
+    d.n_entities, d.n_scenarios, d.ldb = n_entities, n_scenarios, ldb
+    d.n_out, d.out_act, d.n_segs = n_out, out_act, len(segments)
+    k = 0
+    for i, sgm in enumerate(segments):
+        t = sgm.tensor
+        s = d.seg[i]
+        s.base, s.map = t.data_ptr(), (sgm.index.data_ptr() if sgm.index is not None else None)
+        s.row_stride = t.stride(0)
+        s.ent_stride = t.stride(1) if t.shape[1] > 1 else 0
+        s.scn_stride = 1 if sgm.per_scenario else 0
+        s.n_rows = t.shape[0]
+        k += t.shape[0]
+    d.K = k
+    d.weights = weights.data_ptr()
+    d._keep = (segments, weights)
+    return d
+
+
+def mlp3_fwd(desc, Y, X_hist=None, H1=None, H2=None):
+    _dev(Y)
+    check(lib().nic_mlp3_fwd(desc, ptr(Y), ptr(X_hist), ptr(H1), ptr(H2), current_stream()))
+    return Y
+
+
+def mlp3_bwd(desc, dY, Y, H1, H2, dZ3, dZ2, dZ1, dX=None):
+    _dev(dY)
+    check(lib().nic_mlp3_bwd(desc, ptr(dY), ptr(Y), ptr(H1), ptr(H2), ptr(dZ3), ptr(dZ2), ptr(dZ1), ptr(dX), current_stream()))
+
+
+def segment_sum(dst, src, offsets, items, dst_scale=None, accumulate=False):
+    """dst [R][n_dst][ldb] (+)= dst_scale[n] * sum over items[offsets[n]:offsets[n+1]] of src[R][.][ldb] rows."""
+    _dev(dst)
+    R, n_dst, ldb = dst.shape
+    check(lib().nic_segment_sum(ptr(dst), dst.stride(0), ptr(src), src.stride(0), ptr(offsets), ptr(items), ptr(dst_scale), R,
+                                n_dst, ldb, ldb, int(accumulate), current_stream()))
+    return dst
+
+
 # ---- sampler / utilities ---------------------------------------------------------------------------------------
 
 def sample_demand(out, T, S, n_scenarios, scenario_offset, seed, kind, mean, chol, clip):

@@ -382,3 +382,98 @@ def test_sampler_poisson():
     torch.cuda.synchronize()
     xb = ob[:, :, :B].double().cpu().reshape(-1)
     assert abs(float(xb.mean()) - 45.0) < 0.15 and abs(float(xb.var()) - 45.0) < 1.5 and float(xb.max()) > 63
+
+
+# ---- fused 3-layer MLP over gathered inputs (csrc/mlp3.hip) ----------------------------------------------------------------
+
+def _mlp3_reference(x, W, act):
+    """x: (cols, K) float64; W: [(w1, b1), (w2, b2), (w3, b3)] float64 with requires_grad."""
+    import torch.nn.functional as F
+    h1 = F.elu(F.linear(x, *W[0]))
+    h2 = F.elu(F.linear(h1, *W[1]))
+    z = F.linear(h2, *W[2])
+    y = F.elu(z) if act == 1 else (F.softplus(z) if act == 2 else z)
+    return y, h1, h2
+
+
+@pytest.mark.parametrize("K_rows,n_out,act,B", [((32, 32, 1), 32, 1, 100), ((32, 32, 32), 32, 1, 64), ((7,), 32, 1, 37),
+                                                 ((32,), 1, 2, 70), ((20, 13), 5, 0, 33)])
+def test_mlp3_fwd_bwd_with_gathered_segments(K_rows, n_out, act, B):
+    """nic_mlp3_fwd / nic_mlp3_bwd against float64 torch autograd: inputs gathered through entity maps (with -1 = zero rows and
+    a per-entity constant segment), every history buffer, dX, and the pre-activation gradients the weight gradients use."""
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(sum(K_rows) + n_out)
+    E, ld = 6, pad_ld(B, 32)
+    n_src = 4
+    K = sum(K_rows)
+    segs, dense_parts = [], []
+    for si, rows in enumerate(K_rows):
+        if rows == 1:  # per-entity constant (an edge's lead time)
+            t = torch.randn(1, E, generator=gen)
+            segs.append(ops.Mlp3Segment(t.to(dev), None, per_scenario=False))
+            dense_parts.append(t[:, :, None].expand(1, E, B))
+        else:
+            t = torch.zeros(rows, n_src, ld)
+            t[:, :, :B] = torch.randn(rows, n_src, B, generator=gen)
+            idx = torch.randint(-1, n_src, (E,), generator=gen, dtype=torch.int32)
+            if si == 0:
+                idx = None if len(K_rows) == 1 and rows != 20 else idx
+            if idx is None:  # identity map needs as many source entities as outputs
+                t = torch.zeros(rows, E, ld)
+                t[:, :, :B] = torch.randn(rows, E, B, generator=gen)
+                dense = t[:, :, :B]
+            else:
+                dense = torch.where((idx >= 0)[None, :, None], t[:, idx.clamp_min(0).long(), :B], torch.zeros(()))
+            segs.append(ops.Mlp3Segment(t.to(dev), idx.to(dev) if idx is not None else None))
+            dense_parts.append(dense)
+    X = torch.cat(dense_parts, dim=0)  # [K][E][B]
+    dims = [(32, K), (32, 32), (n_out, 32)]
+    W = [(torch.randn(n, k, generator=gen) / k ** 0.5, torch.randn(n, generator=gen) * 0.3) for n, k in dims]
+    packed = torch.cat([t.reshape(-1) for wb in W for t in wb]).to(dev)
+    desc = ops.mlp3_desc(segs, packed, E, B, ld, n_out, act)
+    z = lambda r: torch.zeros(r, E, ld, device=dev)  # noqa: E731
+    Y, Xh, H1, H2 = z(n_out), z(K), z(32), z(32)
+    ops.mlp3_fwd(desc, Y, Xh, H1, H2)
+    torch.cuda.synchronize()
+    W64 = [(w.double().requires_grad_(True), b.double().requires_grad_(True)) for w, b in W]
+    x64 = X.permute(1, 2, 0).reshape(E * B, K).double().requires_grad_(True)
+    y, h1, h2 = _mlp3_reference(x64, W64, act)
+    as_rows = lambda t, r: t.reshape(E, B, r).permute(2, 0, 1)  # noqa: E731
+    assert torch.equal(Xh[:, :, :B].cpu(), X)
+    torch.testing.assert_close(H1[:, :, :B].cpu().double(), as_rows(h1.detach(), 32), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(H2[:, :, :B].cpu().double(), as_rows(h2.detach(), 32), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(Y[:, :, :B].cpu().double(), as_rows(y.detach(), n_out), rtol=2e-5, atol=2e-6)
+    assert float(Y[:, :, B:].abs().sum()) == 0.0
+    # backward
+    gY = torch.zeros(n_out, E, ld)
+    gY[:, :, :B] = torch.randn(n_out, E, B, generator=gen)
+    (y * gY[:, :, :B].permute(1, 2, 0).reshape(E * B, n_out).double()).sum().backward()
+    dZ3, dZ2, dZ1, dX = z(n_out), z(32), z(32), z(K)
+    ops.mlp3_bwd(desc, gY.to(dev), Y, H1, H2, dZ3, dZ2, dZ1, dX)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dX[:, :, :B].cpu().double(), as_rows(x64.grad, K), rtol=1e-4, atol=1e-5)
+    # weight gradients = contractions of the stored pre-activation gradients with the stored inputs / activations
+    for (gz, inp), (w, b_) in zip(((dZ1, Xh), (dZ2, H1), (dZ3, H2)), W64):
+        gz2, in2 = gz[:, :, :B].reshape(gz.shape[0], -1).double().cpu(), inp[:, :, :B].reshape(inp.shape[0], -1).double().cpu()
+        torch.testing.assert_close(gz2 @ in2.t(), w.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(gz2.sum(dim=1), b_.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_segment_sum_forward_aggregation_and_gather_adjoint():
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(11)
+    R, n_src, n_dst, B = 32, 9, 4, 130
+    ld = pad_ld(B, 32)
+    src = torch.zeros(R, n_src, ld)
+    src[:, :, :B] = torch.randn(R, n_src, B, generator=gen)
+    lists = [[0, 3, 8], [], [2], [1, 4, 5, 6, 7]]
+    offsets = torch.tensor([0, 3, 3, 4, 9], dtype=torch.int32)
+    items = torch.tensor([i for l in lists for i in l], dtype=torch.int32)
+    scale = torch.tensor([0.5, 1.0, 2.0, 1 / 5 ** 0.5])
+    dst = torch.full((R, n_dst, ld), 7.0, device=dev)
+    ops.segment_sum(dst, src.to(dev), offsets.to(dev), items.to(dev), scale.to(dev), accumulate=False)
+    want = torch.stack([scale[n] * sum((src[:, i] for i in l), torch.zeros(R, ld)) for n, l in enumerate(lists)], dim=1)
+    torch.testing.assert_close(dst.cpu()[:, :, :B], want[:, :, :B], rtol=1e-6, atol=1e-6)
+    ops.segment_sum(dst, src.to(dev), offsets.to(dev), items.to(dev), None, accumulate=True)
+    want2 = want + torch.stack([sum((src[:, i] for i in l), torch.zeros(R, ld)) for l in lists], dim=1)
+    torch.testing.assert_close(dst.cpu()[:, :, :B], want2[:, :, :B], rtol=1e-6, atol=1e-6)
