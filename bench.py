@@ -67,6 +67,7 @@ def build_case(workload, device, rank, world, scenarios=None, periods=None):
     from neural_inventory_control_amd.data_handling import Scenario
     from neural_inventory_control_amd.neural_networks import NeuralNetworkCreator
     from neural_inventory_control_amd.closed_form import ClosedFormRollout
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout
     from neural_inventory_control_amd.rollout import FusedRollout
     setting, policy, n, T, desc = workloads.get(workload)
     if scenarios or periods:
@@ -87,6 +88,8 @@ def build_case(workload, device, rank, world, scenarios=None, periods=None):
         eng = ClosedFormRollout(model, setting["problem_params"], device)
         if not eng.shapes_ok(data):
             eng = None
+    elif GnnRollout.supports(model, setting["problem_params"]) and "mean" in data:
+        eng = GnnRollout(model, setting["problem_params"], device)
     return setting, policy, sc, data, model, eng, n, T, desc
 
 
@@ -173,7 +176,7 @@ def algorithmic_work(tag, kernel, shape):
     input rows), nh (hidden layers of the small route), n_out, train.  DESIGN.md §4 states the same formulas."""
     n, T = shape["n"], shape["T"]
     kind, _, dims = tag.partition("_")
-    if kind in ("fwd", "dgrad", "wgrad", "wgradT") and "x" in dims:
+    if kind in ("fwd", "dgrad", "wgrad", "wgradT") and "x" in dims and dims.replace("x", "").isdigit():
         N, K = (int(v) for v in dims.split("x"))
         cols = n * (T if kind == "wgradT" else 1)
         if kernel.startswith("wgrad_small_kernel"):   # small route: one launch contracts over all T * ldb columns
@@ -181,6 +184,9 @@ def algorithmic_work(tag, kernel, shape):
         if max(N, K) <= 64:                           # 32-wide layers on the per-period route: operand streaming
             return "hbm", 4.0 * (N + K) * cols, "B"
         return "mfma", 2.0 * N * K * cols, "FLOP"
+    if tag.startswith("mlp3_fwd_") or tag.startswith("mlp3_bwd_"):  # fused 3-layer MLP: K -> 32 -> 32 -> n_out per column
+        K, n_out, n_ent = shape["gnn"][tag[len("mlp3_fwd_"):]]
+        return "mfma", 2.0 * (K * 32 + 32 * 32 + 32 * n_out) * n_ent * n, "FLOP"
     if tag.startswith("bwd_thin_"):
         N, K = (int(v) for v in tag[len("bwd_thin_"):].split("x"))
         return "hbm", 4.0 * (2 * K + N) * n, "B"      # layer input read once, input gradient written once, dY read
@@ -258,7 +264,11 @@ def main():
     pp = setting["problem_params"]
     S = pp["n_stores"]
     closed_form = eng is not None and type(eng).__name__ == "ClosedFormRollout"
-    if closed_form:
+    gnn = eng is not None and type(eng).__name__ == "GnnRollout"
+    if gnn:
+        eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+        parallel.broadcast_model(model, src=0)
+    elif closed_form:
         with torch.no_grad():
             eng.model.closed_form_levels()  # materialises the policy's one lazy layer
         parallel.broadcast_model(model, src=0)
@@ -270,7 +280,7 @@ def main():
         eng.materialize(F_in)
         parallel.broadcast_model(model, src=0)
     opt = torch.optim.Adam(model.parameters(), lr=3e-4)
-    if args.graph and eng is not None and not closed_form:
+    if args.graph and eng is not None and not closed_form and not gnn:
         eng.use_graph = True
         args.no_kernel_timing = True
     reducer = parallel.GradientAllReducer.get(model) if world > 1 else None
@@ -329,6 +339,9 @@ def main():
                                   demand_soa=sc.demands_soa, grad_scale=grad_scale)
         if reducer is not None:
             total, reported = reducer.all_reduce(total, reported)
+        clip = getattr(model, "gradient_clipping_norm_value", None)
+        if clip is not None:  # (gnn.yml clips the gradient norm at 1.0, trainer.py:175-176)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
         opt.step()
         return total
 
@@ -338,7 +351,7 @@ def main():
         step()  # lazy layers materialise on the first forward; keep that out of the timed region
     timer = None
     if not args.no_kernel_timing:
-        stride = args.timing_stride or (1 if (closed_form or eng.small is not None) else 10)
+        stride = args.timing_stride or (1 if (closed_form or (not gnn and eng.small is not None)) else 10)
         timer = eng.timer = KernelTimer(stride=stride)
     if world > 1:
         torch.distributed.barrier()
@@ -371,6 +384,7 @@ def main():
                        "periods": T, "parallelism": f"scenario-sharded dp{world}",
                        "route": ("generic (Simulator.step + autograd)" if eng is None else
                                  "whole-horizon closed-form kernel (forward-mode gradient)" if closed_form else
+                                 "per-period fused gather-MLP kernels over the static supply graph" if gnn else
                                  "whole-horizon kernels" if eng.small is not None else "per-period kernels"),
                        "mean_cost_per_store_period": loss},
         }
@@ -379,8 +393,9 @@ def main():
             shape = dict(n=n, T=T, S=S, Wn=Wn_, E=E_, Ws=data["initial_inventories"].shape[2],
                          Ww=data["initial_warehouse_inventories"].shape[2] if Wn_ else 0,
                          We=data["initial_echelon_inventories"].shape[2] if E_ else 0,
-                         F=0 if closed_form else eng.dims[0], nh=0 if closed_form else len(eng.dims) - 2,
-                         n_out=0 if closed_form else eng.dims[-1], train=not args.eval)
+                         F=0 if (closed_form or gnn) else eng.dims[0], nh=0 if (closed_form or gnn) else len(eng.dims) - 2,
+                         n_out=0 if (closed_form or gnn) else eng.dims[-1], train=not args.eval,
+                         gnn={m.name: (m.K, m.n_out, m.n_ent) for m in eng.mlp.values()} if gnn else None)
             kernels = kernel_report(timer, shape, args.steps)
             rated = {k: v for k, v in kernels.items() if "bound" in v}
             if rated:

@@ -1,0 +1,382 @@
+"""`GnnRollout`: the unrolled rollout + backward of `Trainer.simulate_batch` for the GNN policy (`gnn.yml`;
+neural_networks.py:742-1492 of the reference) on the one-warehouse settings, without an autograd graph.
+
+The supply graph is static, so it is compiled once into entity maps and CSR lists (`GraphPlan`).  Per period the engine
+launches five fused gather-MLP kernels (`nic_mlp3_fwd`, csrc/mlp3.hip: each evaluates one of the policy's 32-wide MLPs for every
+(node or edge, scenario) column, gathering its concatenated input rows straight from the node / edge buffers through the maps),
+two segment sums for the message aggregation, a few small tensor ops for the proportional allocation, and the env step.  The
+backward sweep mirrors it: env backward, allocation adjoint, `nic_mlp3_bwd` per MLP, segment sums over the TRANSPOSED maps as
+the adjoint of every gather (deterministic, no atomics); weight gradients are contractions of the stored pre-activation
+gradients with the stored inputs (`nic_linear_wgrad`, slabs accumulated over the periods).  The reference's Python loops over
+edges (:1229-1269) and nodes (:1474-1490) become launches over all scenarios at once; ~60 launches per period instead of ~380.
+
+Everything is feature-major `[rows][entity][ldb]`.  Nodes = [warehouse, stores...]; edges = [internal (warehouse -> store s),
+supplier edge of the warehouse, demand edges of the stores, self loop of the warehouse] — the reference's order, so sums over a
+node's edges associate exactly as upstream.
+"""
+import torch
+
+from . import _lib, ops
+from .layout import ProblemCache, Table
+from .ops import EnvState, Mlp3Segment
+
+MODULES = ("initial_node", "initial_edge", "node_update", "edge_update", "output")
+
+
+def _csr(lists, device):
+    offs, items = [0], []
+    for l in lists:
+        items += l
+        offs.append(len(items))
+    return (torch.tensor(offs, dtype=torch.int32, device=device),
+            torch.tensor(items if items else [0], dtype=torch.int32, device=device))
+
+
+class GraphPlan:
+    """Static structure of the one-warehouse supply graph (neural_networks.py:757-1062) as device index tensors."""
+
+    def __init__(self, S, transshipment, store_lead, wh_lead, device):
+        Wn = 1
+        self.S, self.n_nodes = S, Wn + S
+        internal = [(0, Wn + s) for s in range(S)]
+        n_int, n_sup, n_dem = S, 1, S
+        supplying = [] if transshipment else [0]
+        self.n_self = len(supplying)
+        self.n_edges = n_int + n_sup + n_dem + self.n_self
+        src = [a for a, _ in internal] + [-1] + [Wn + s for s in range(S)] + supplying
+        tgt = [b for _, b in internal] + [0] + [-1] * n_dem + supplying
+        self.e_supplier = n_int
+        self.e_self = n_int + n_sup + n_dem if self.n_self else None
+        in_deg, out_deg = [0] * self.n_nodes, [0] * self.n_nodes
+        for a, b in internal:
+            out_deg[a] += 1
+            in_deg[b] += 1
+        in_deg[0] += 1                      # supplier edge into the warehouse
+        for s in range(S):
+            out_deg[Wn + s] += 1            # demand edge out of every store
+        for n in supplying:
+            in_deg[n] += 1
+            out_deg[n] += 1
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)  # noqa: E731
+        self.src, self.tgt = i32(src), i32(tgt)
+        # message aggregation (:1229-1296): a node sums the edges it is the target of (demand edges have no real target) /
+        # the source of (supplier edges have no real source), in edge order, then divides by sqrt(degree)
+        demand_edges = set(range(n_int + n_sup, n_int + n_sup + n_dem))
+        supplier_edges = set(range(n_int, n_int + n_sup))
+        inc = [[e for e in range(self.n_edges) if tgt[e] == n and e not in demand_edges] for n in range(self.n_nodes)]
+        out = [[e for e in range(self.n_edges) if src[e] == n and e not in supplier_edges] for n in range(self.n_nodes)]
+        self.inc_off, self.inc_items = _csr(inc, device)
+        self.out_off, self.out_items = _csr(out, device)
+        self.in_scale = torch.tensor([1.0 / max(d, 1) ** 0.5 for d in in_deg], device=device)
+        self.out_scale = torch.tensor([1.0 / max(d, 1) ** 0.5 for d in out_deg], device=device)
+        # adjoints of the aggregation: edge e receives from its target's `incoming` / its source's `outgoing` gradient
+        self.e_from_tgt = _csr([[tgt[e]] if (tgt[e] >= 0 and e not in demand_edges) else [] for e in range(self.n_edges)], device)
+        self.e_from_src = _csr([[src[e]] if (src[e] >= 0 and e not in supplier_edges) else [] for e in range(self.n_edges)], device)
+        self.e_in_scale = torch.tensor([self.in_scale[tgt[e]].item() if tgt[e] >= 0 else 0.0 for e in range(self.n_edges)],
+                                       device=device)
+        self.e_out_scale = torch.tensor([self.out_scale[src[e]].item() if src[e] >= 0 else 0.0 for e in range(self.n_edges)],
+                                        device=device)
+        # adjoints of the endpoint gathers: node n receives from the edges it is the source / target of
+        self.n_as_src = _csr([[e for e in range(self.n_edges) if src[e] == n] for n in range(self.n_nodes)], device)
+        self.n_as_tgt = _csr([[e for e in range(self.n_edges) if tgt[e] == n] for n in range(self.n_nodes)], device)
+        lead = list(store_lead) + [wh_lead] + [0.0] * (n_dem + self.n_self)
+        self.lead = torch.tensor(lead, dtype=torch.float32, device=device).view(1, -1)   # per-edge constant input row
+        # proportional allocation group of the warehouse: its internal edges + its self loop (:1435-1492)
+        self.members = list(range(n_int)) + ([self.e_self] if self.n_self else [])
+        self.transshipment = bool(transshipment)
+
+
+class _Mlp:
+    """Packed weights, gradient slabs and per-period history of one of the policy's five MLPs."""
+
+    def __init__(self, name, linears, K, n_out, out_act, n_ent, ld, T, device, train):
+        self.name, self.linears, self.K, self.n_out, self.out_act, self.n_ent = name, linears, K, n_out, out_act, n_ent
+        z = lambda *s: torch.zeros(*s, device=device)  # noqa: E731
+        self.packed = z(32 * K + 32 + 32 * 32 + 32 + n_out * 32 + n_out)
+        self.Y = z(T, n_out, n_ent, ld)
+        if train:
+            self.X, self.H1, self.H2 = z(T, K, n_ent, ld), z(T, 32, n_ent, ld), z(T, 32, n_ent, ld)
+            self.dZ1, self.dZ2, self.dZ3 = z(32, n_ent, ld), z(32, n_ent, ld), z(n_out, n_ent, ld)
+            self.dX = z(K, n_ent, ld)
+            dims = [(32, K), (32, 32), (n_out, 32)]
+            cols = n_ent * ld
+            self.splits = [ops.wgrad_num_splits(n, k, cols) for n, k in dims]
+            self.slabs = [z(sp, n, (k + 1 + 3) // 4 * 4) for sp, (n, k) in zip(self.splits, dims)]
+            self.gw = [torch.zeros_like(m.weight) for m in linears]
+            self.gb = [torch.zeros_like(m.bias) for m in linears]
+
+    def pack(self):
+        self.packed.copy_(torch.cat([t.detach().reshape(-1) for m in self.linears for t in (m.weight, m.bias)]))
+
+
+class GnnRollout:
+    @staticmethod
+    def supports(model, problem_params=None):
+        if type(model).__name__ != "GNN" or not hasattr(model, "nn_args"):
+            return False
+        a = model.nn_args
+        ok = all(a["inner_layer_activations"][m] == "elu" and list(a["neurons_per_hidden_layer"][m]) == [32, 32]
+                 for m in MODULES)
+        ok = ok and all(a["output_layer_activation"][m] == "elu" and a["output_sizes"][m] == 32 for m in MODULES[:-1])
+        ok = ok and a["output_layer_activation"]["output"] == "softplus" and a["output_sizes"]["output"] == 1
+        if problem_params is not None:
+            ok = ok and problem_params["n_warehouses"] == 1 and problem_params["n_extra_echelons"] == 0
+        return bool(ok)
+
+    def __init__(self, model, problem_params, device):
+        _lib.require_device()
+        if not self.supports(model, problem_params):
+            raise ValueError("GnnRollout handles the gnn.yml architecture on one-warehouse settings")
+        self.model, self.problem_params, self.device = model, problem_params, torch.device(device)
+        self.timer = None
+        self._probs = ProblemCache()
+        self._key = None
+
+    def _k(self, tag, fn, *a, **kw):
+        return fn(*a, **kw) if self.timer is None else self.timer.call(tag, fn, *a, **kw)
+
+    # ---- setup --------------------------------------------------------------------------------------------------------------
+    def shapes_ok(self, data):
+        return "mean" in data and "std" in data and data["lead_times"].shape[2] == 1
+
+    def _linears(self, name):
+        return [m for m in self.model.net[name] if isinstance(m, torch.nn.Linear)]
+
+    def materialize(self, Dn):
+        """Creates the lazy first layers without a forward pass (same default init as the reference's first call)."""
+        from .rollout import FusedRollout
+        for name, k in zip(MODULES, (Dn, 65, 96, 96, 32)):
+            shim = type("S", (), {"master_linears": lambda s, n=name: self._linears(n)})()
+            FusedRollout.materialize(type("E", (), {"model": shim})(), k)
+
+    def _setup(self, prob, data, T, train):
+        key = (prob.B, T, bool(train), prob.S, prob.Ws, prob.Ww)
+        if key == self._key:
+            return
+        dev, ld, S = self.device, prob.ldb, prob.S
+        if ld % 32:
+            raise ValueError("ldb must be a multiple of 32")
+        lt0 = data["lead_times"][0, :, 0].tolist()  # sample 0's lead times stand for the batch, as upstream (:984)
+        self.plan = GraphPlan(S, getattr(self.model, "transshipment", False), lt0, float(data["warehouse_lead_times"][0, 0]), dev)
+        P = self.plan
+        self.max_inv = max(prob.Ws, prob.Ww)
+        self.has_edge_cost = data.get("warehouse_edge_costs") is not None
+        self.max_st = max(4, 2 if self.has_edge_cost else 1)
+        self.Dn = self.max_inv + self.max_st
+        self.materialize(self.Dn)
+        z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+        N, E = P.n_nodes, P.n_edges
+        self.F_store, self.F_wh = S * prob.Ws, prob.Ww
+        f_tot = self.F_store + self.F_wh
+        self.states = z(T + 1, f_tot, ld)
+        self.orders = z(T, S + 1, ld)
+        self.rewards = z(T, ld)
+        self.feat = z(T, self.Dn, N, ld)
+        A = _lib
+        ks = (self.Dn, 65, 96, 96, 32)
+        ents = (N, E, N, E, E)
+        self.mlp = {name: _Mlp(name, self._linears(name), k, 1 if name == "output" else 32,
+                               A.NIC_MLP3_ACT_SOFTPLUS if name == "output" else A.NIC_MLP3_ACT_ELU, ne, ld, T, dev, train)
+                    for name, k, ne in zip(MODULES, ks, ents)}
+        self.agg_in, self.agg_out = z(T, 32, N, ld), z(T, 32, N, ld)
+        self.nodes1, self.edges1 = z(T, 32, N, ld), z(T, 32, E, ld)
+        self.sums, self.ratio, self.scale = z(T, ld), z(T, ld), z(T, ld)
+        if train:
+            self.g_state = [z(f_tot, ld), z(f_tot, ld)]
+            self.g_orders = z(S + 1, ld)
+            self.g_reward = z(ld)
+            self.d_nodes0, self.d_nodes1 = z(32, N, ld), z(32, N, ld)
+            self.d_edges0, self.d_edges1 = z(32, E, ld), z(32, E, ld)
+            self.d_out = z(1, E, ld)
+        self._key = key
+
+    def _views(self, block, prob):
+        store = block[:self.F_store].view(prob.S, prob.Ws, -1)
+        wh = block[self.F_store:].view(1, prob.Ww, -1)
+        return EnvState(store, wh, None)
+
+    def _order_tables(self, block, prob):
+        ld = prob.ldb
+        so, wo = block[:prob.S].view(prob.S, 1, -1), block[prob.S:]
+        return Table(so, ld, 1, ld), Table(wo, ld, 1)
+
+    # ---- one batch ------------------------------------------------------------------------------------------------------------
+    def run(self, data, periods, ignore_periods=0, train=True, observation_params=None, demand_soa=None, grad_scale=None,
+            assign_grads=True, discrete_allocation=False):
+        """Same contract as `FusedRollout.run`: returns (total, reported); with `train`, d(mean_loss)/d(theta) in `param.grad`."""
+        if discrete_allocation:
+            raise ValueError("discrete allocation takes the generic route")
+        prob = self._probs.get(self.problem_params, data, self.device)
+        T, B, ld, S = periods, prob.B, prob.ldb, prob.S
+        self._setup(prob, data, T, train)
+        self.prob = prob
+        P = self.plan
+        shift = observation_params["demand"]["period_shift"] if observation_params else 0
+        if demand_soa is None:
+            d = data["demands"]
+            demand_soa = torch.zeros(d.shape[2], d.shape[1], ld, device=self.device)
+            demand_soa[:, :, :B] = d.permute(2, 1, 0)
+        if demand_soa.shape[0] < T + shift:
+            raise ValueError("Current period is greater than the number of periods in the data")
+        self.demand = demand_soa
+        for m in self.mlp.values():
+            m.pack()
+        s0 = self._views(self.states[0], prob)
+        s0.store[:, :, :B].copy_(data["initial_inventories"].permute(1, 2, 0))
+        s0.wh[:, :, :B].copy_(data["initial_warehouse_inventories"].permute(1, 2, 0))
+        # static node features (rows max_inv..): warehouse [holding, (edge cost)], stores [holding, underage, mean, std]
+        f, mi = self.feat, self.max_inv
+        f[:, mi, 0, :B] = data["warehouse_holding_costs"][:, 0]
+        if self.has_edge_cost:
+            f[:, mi + 1, 0, :B] = data["warehouse_edge_costs"][:, 0]
+        for r, k in enumerate(("holding_costs", "underage_costs", "mean", "std")):
+            f[:, mi + r, 1:, :B] = data[k].t()
+        for t in range(T):
+            self._forward_period(t, prob, demand_soa, shift)
+        total = self.rewards.sum()
+        reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
+        if not train:
+            return total, reported
+        if grad_scale is None:
+            grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
+        self.g_reward.zero_()
+        self.g_reward[:B] = grad_scale
+        for m in self.mlp.values():
+            for sl in m.slabs:
+                sl.zero_()
+        self.g_state[0].zero_()
+        g_next, g_cur = self.g_state
+        for t in range(T - 1, -1, -1):
+            self._backward_period(t, prob, demand_soa, shift, g_next, g_cur)
+            g_next, g_cur = g_cur, g_next
+        for m in self.mlp.values():
+            for i, lin in enumerate(m.linears):
+                ops.wgrad_reduce(m.slabs[i], m.gw[i], m.gb[i], lin.weight.shape[1], 1.0)
+        if assign_grads:
+            for p, g in self.param_grads():
+                p.grad = g
+        return total, reported
+
+    def param_grads(self):
+        """[(parameter, gradient buffer of the last training run)] - engine-owned buffers, overwritten by the next run."""
+        return [(t, g) for m in self.mlp.values() for i, lin in enumerate(m.linears)
+                for t, g in ((lin.weight, m.gw[i]), (lin.bias, m.gb[i]))]
+
+    def _desc(self, m, segs, prob):
+        return ops.mlp3_desc(segs, m.packed, m.n_ent, prob.B, prob.ldb, m.n_out, m.out_act)
+
+    def _segments(self, t):
+        """Input segments of the five MLPs at period t (the graph's gathers; no concatenation is materialised)."""
+        P, M = self.plan, self.mlp
+        nodes0, edges0 = M["initial_node"].Y[t], M["initial_edge"].Y[t]
+        return {
+            "initial_node": [Mlp3Segment(self.feat[t])],
+            "initial_edge": [Mlp3Segment(nodes0, P.src), Mlp3Segment(nodes0, P.tgt), Mlp3Segment(P.lead, None, per_scenario=False)],
+            "node_update": [Mlp3Segment(nodes0), Mlp3Segment(self.agg_in[t]), Mlp3Segment(self.agg_out[t])],
+            "edge_update": [Mlp3Segment(edges0), Mlp3Segment(self.nodes1[t], P.src), Mlp3Segment(self.nodes1[t], P.tgt)],
+            "output": [Mlp3Segment(self.edges1[t])],
+        }
+
+    def _run_mlp(self, name, t, segs, prob):
+        m = self.mlp[name]
+        hist = (m.X[t], m.H1[t], m.H2[t]) if hasattr(m, "X") else (None, None, None)
+        self._k("mlp3_fwd_" + name, ops.mlp3_fwd, self._desc(m, segs[name], prob), m.Y[t], *hist)
+
+    def _forward_period(self, t, prob, demand_soa, shift):
+        P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
+        st = self._views(self.states[t], prob)
+        f = self.feat[t]
+        f[:prob.Ww, 0].copy_(st.wh[0])                       # node features: pipelines, padded to the longest one (:846-905)
+        f[:prob.Ws, 1:].copy_(st.store.permute(1, 0, 2))
+        segs = self._segments(t)
+        self._run_mlp("initial_node", t, segs, prob)
+        self._run_mlp("initial_edge", t, segs, prob)
+        edges0 = M["initial_edge"].Y[t]
+        ops.segment_sum(self.agg_in[t], edges0, P.inc_off, P.inc_items, P.in_scale)
+        ops.segment_sum(self.agg_out[t], edges0, P.out_off, P.out_items, P.out_scale)
+        self._run_mlp("node_update", t, segs, prob)
+        torch.add(M["initial_node"].Y[t], M["node_update"].Y[t], out=self.nodes1[t])
+        self._run_mlp("edge_update", t, segs, prob)
+        torch.add(edges0, M["edge_update"].Y[t], out=self.edges1[t])
+        self._run_mlp("output", t, segs, prob)
+        out = M["output"].Y[t][0]                                  # [E][ld] desired quantity per edge
+        # proportional allocation of the warehouse's on-hand stock over its outgoing edges + self loop (:111-138, :1435-1492)
+        mem = out[P.members]
+        on_hand = st.wh[0, 0]
+        torch.sum(mem, dim=0, out=self.sums[t])
+        torch.div(on_hand, self.sums[t] + 1e-10, out=self.ratio[t])
+        if P.transshipment:
+            self.scale[t].copy_(self.ratio[t])
+        else:
+            torch.clamp(self.ratio[t], max=1.0, out=self.scale[t])
+        orders = self.orders[t]
+        torch.mul(out[:S], self.scale[t], out=orders[:S])
+        orders[S].copy_(out[P.e_supplier])
+        ts, tw = self._order_tables(orders, prob)
+        self._k("env_fwd", ops.env_step_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
+                out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
+
+    def _backward_period(self, t, prob, demand_soa, shift, g_next, g_cur):
+        P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
+        st = self._views(self.states[t], prob)
+        ts, tw = self._order_tables(self.orders[t], prob)
+        g_so, g_wo = self.g_orders[:S].view(S, 1, -1), self.g_orders[S:]
+        gc = self._views(g_cur, prob)
+        self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
+                self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=gc, g_orders=(g_so, g_wo, None))
+        # allocation adjoint: alloc_e = out_e * min(1, on_hand / (sum + eps)) for the members, supplier edge passes through
+        out = M["output"].Y[t][0]
+        d_out = self.d_out[0]
+        d_out.zero_()
+        g_alloc = self.g_orders[:S]
+        sums, ratio, scale = self.sums[t], self.ratio[t], self.scale[t]
+        dot = (g_alloc * out[:S]).sum(dim=0)                       # the self loop's allocation feeds nothing: gradient 0
+        passes = torch.ones_like(ratio) if P.transshipment else (ratio <= 1.0).to(ratio.dtype)  # clamp(max): x <= max
+        on_hand = st.wh[0, 0]
+        d_scale = dot * passes
+        d_out[P.members] = -(d_scale * on_hand / (sums + 1e-10) ** 2)
+        d_out[:S] += g_alloc * scale
+        d_out[P.e_supplier] = self.g_orders[S]
+        gc.wh[0, 0] += d_scale / (sums + 1e-10)
+        segs = self._segments(t)
+        # output MLP -> edges1
+        m = M["output"]
+        self._mlp_bwd(m, t, segs, prob, self.d_out, dX=self.d_edges1)
+        # edges1 = edges0 + edge_update(edges0, nodes1[src], nodes1[tgt])
+        m = M["edge_update"]
+        self._mlp_bwd(m, t, segs, prob, self.d_edges1)
+        torch.add(self.d_edges1, m.dX[:32], out=self.d_edges0)
+        ops.segment_sum(self.d_nodes1, m.dX[32:64], *P.n_as_src)
+        ops.segment_sum(self.d_nodes1, m.dX[64:96], *P.n_as_tgt, accumulate=True)
+        # nodes1 = nodes0 + node_update(nodes0, incoming, outgoing)
+        m = M["node_update"]
+        self._mlp_bwd(m, t, segs, prob, self.d_nodes1)
+        torch.add(self.d_nodes1, m.dX[:32], out=self.d_nodes0)
+        ops.segment_sum(self.d_edges0, m.dX[32:64], *P.e_from_tgt, P.e_in_scale, accumulate=True)
+        ops.segment_sum(self.d_edges0, m.dX[64:96], *P.e_from_src, P.e_out_scale, accumulate=True)
+        # edges0 = initial_edge(nodes0[src], nodes0[tgt], lead)
+        m = M["initial_edge"]
+        self._mlp_bwd(m, t, segs, prob, self.d_edges0)
+        ops.segment_sum(self.d_nodes0, m.dX[:32], *P.n_as_src, accumulate=True)
+        ops.segment_sum(self.d_nodes0, m.dX[32:64], *P.n_as_tgt, accumulate=True)
+        # nodes0 = initial_node(features): the pipeline rows of the features are the state
+        m = M["initial_node"]
+        self._mlp_bwd(m, t, segs, prob, self.d_nodes0)
+        gc.wh[0] += m.dX[:prob.Ww, 0]
+        gc.store += m.dX[:prob.Ws, 1:].permute(1, 0, 2)
+
+    def _mlp_bwd(self, m, t, segs, prob, dY, dX=None):
+        self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd, self._desc(m, segs[m.name], prob), dY, m.Y[t], m.H1[t], m.H2[t], m.dZ3,
+                m.dZ2, m.dZ1, dX if dX is not None else m.dX)
+        cols = m.n_ent * prob.ldb
+        for i, (dz, x) in enumerate(((m.dZ1, m.X[t]), (m.dZ2, m.H1[t]), (m.dZ3, m.H2[t]))):
+            self._k("wgrad_" + m.name, ops.linear_wgrad, dz.view(dz.shape[0], cols), x.view(x.shape[0], cols), m.slabs[i], cols)
+
+    # ---- inspection helpers used by the parity tests --------------------------------------------------------------------------
+    def per_period_rewards(self):
+        return self.rewards[:, :self.prob.B]
+
+    def final_state(self):
+        from .layout import ref_view
+        st = self._views(self.states[-1], self.prob)
+        return {"store_inventories": ref_view(st.store, self.prob.B), "warehouse_inventories": ref_view(st.wh, self.prob.B)}

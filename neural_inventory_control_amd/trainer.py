@@ -18,6 +18,7 @@ import torch
 
 from . import parallel
 from .closed_form import ClosedFormRollout
+from .gnn_rollout import GnnRollout
 from .loss_functions import PolicyLoss
 from .rollout import FusedRollout
 
@@ -136,7 +137,8 @@ class Trainer:
                     continue
                 graphed = (train and model.trainable and self.use_step_graph and not discrete_allocation
                            and not (self.use_fused_rollout and self._plain_observation(observation_params)
-                                    and (FusedRollout.supports(model) or ClosedFormRollout.supports(model))))
+                                    and (FusedRollout.supports(model) or ClosedFormRollout.supports(model)
+                                         or GnnRollout.supports(model, problem_params))))
                 if graphed:
                     total_reward, reward_to_report = self._graphed_generic_step(
                         loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
@@ -188,13 +190,20 @@ class Trainer:
             if eng.shapes_ok(data_batch):
                 return eng.run(data_batch, periods, ignore_periods, train=train, observation_params=observation_params,
                                discrete_allocation=discrete_allocation)
-        if self.use_fused_rollout and not (discrete_allocation and train) and FusedRollout.supports(model) \
-                and isinstance(loss_function, PolicyLoss) and self._plain_observation(observation_params):
+        engine_cls = None
+        if fusable and not discrete_allocation:
+            if FusedRollout.supports(model):
+                engine_cls = FusedRollout
+            elif GnnRollout.supports(model, problem_params) and "mean" in data_batch and "std" in data_batch:
+                engine_cls = GnnRollout  # fused gather-MLP kernels over the static supply graph (gnn_rollout.py)
+        elif fusable and FusedRollout.supports(model):
+            engine_cls = FusedRollout    # (evaluation with discrete allocation: the MLP engine rounds in-kernel)
+        if engine_cls is not None:
             # one engine per (policy, training / evaluation): an epoch alternates a training pass and a dev pass with
             # different horizons and buffer needs, and re-sizing one engine back and forth would reallocate tens of GB
             eng = self._engines.get((id(model), train))
             if eng is None or eng.model is not model:  # (the engine holds the model, so its id cannot be recycled)
-                eng = self._engines[(id(model), train)] = FusedRollout(model, problem_params, self.device)
+                eng = self._engines[(id(model), train)] = engine_cls(model, problem_params, self.device)
             if direct and train:
                 total, reported = eng.run(data_batch, periods, ignore_periods, train=True,
                                           observation_params=observation_params, grad_scale=1.0, assign_grads=False)

@@ -129,7 +129,7 @@ WORKLOADS = {
                       "one_store_backlogged + base_stock, 1,048,576 scenarios x T=100 (enough chains in flight to be HBM-bound)"),
     "echelon_stock": (serial_system, _closed_form("echelon_stock", 4, None, None), 131072, 100,
                       "serial_system 4 echelons + echelon_stock, 131072 scenarios x T=100"),
-    # the GNN policy on cfg3's graph (generic route: Simulator.step + autograd, MLPs on the matrix cores)
+    # the GNN policy on cfg3's graph (fused gather-MLP kernels over the static supply graph, gnn_rollout.py)
     "gnn": (lambda: one_warehouse(16), gnn_policy(), 8192, 50,
             "one_warehouse_lost_demand, 16 stores, 8192 scenarios x T=50, gnn (5 x 32-wide MLPs, 1 message-passing step)"),
 }
