@@ -280,7 +280,7 @@ def main():
         eng.materialize(F_in)
         parallel.broadcast_model(model, src=0)
     opt = torch.optim.Adam(model.parameters(), lr=3e-4)
-    if args.graph and eng is not None and not closed_form and not gnn:
+    if args.graph and eng is not None and not closed_form:
         eng.use_graph = True
         args.no_kernel_timing = True
     reducer = parallel.GradientAllReducer.get(model) if world > 1 else None

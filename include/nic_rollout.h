@@ -295,9 +295,15 @@ typedef struct NicMlp3Desc {
     int32_t K, n_out, out_act, n_segs, reserved;   /* K = sum of segment rows <= NIC_MLP3_MAX_K; n_out = 32 or 1..8 */
     NicMlp3Seg seg[NIC_MLP3_MAX_SEGS];
     const float* weights;
+    const float* weights_t;    /* the same weights transposed, read by the FORWARD kernel (lane i of contraction step k reads
+                                  consecutive words): [W1^T K x 32][b1 32][W2^T 32 x 32][b2 32][W3^T 32 x 32, columns >= n_out
+                                  zero][b3 padded to 32].  `weights` (natural layout) is what the backward kernel reads. */
+    int64_t hist_row_stride;   /* elements between feature rows of X_hist / H1 / H2 / dZ*; 0 = n_entities * ldb.  A larger stride
+                                  interleaves several periods in one row so that a weight gradient contracts over all of them */
 } NicMlp3Desc;
 /* Y [n_out][n_entities][ldb] = out_act(MLP(x)).  When X_hist != NULL the gathered inputs and the hidden activations are kept
- * for the backward / weight gradients: X_hist [K][n_entities][ldb], H1, H2 [32][n_entities][ldb] (post-ELU). */
+ * for the backward / weight gradients: X_hist [K][n_entities][ldb], H1, H2 [32][n_entities][ldb] (post-ELU), rows
+ * hist_row_stride apart. */
 int nic_mlp3_fwd(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float* H2, void* stream);
 /* Backward of the same MLP from dY [n_out][n_entities][ldb] and the stored Y / H1 / H2: the pre-activation gradients dZ3
  * [n_out][..], dZ2, dZ1 [32][..] (the weight gradients are nic_linear_wgrad contractions of these with H2 / H1 / X_hist over

@@ -1,7 +1,7 @@
 // Fused three-layer 32-wide MLP over gathered inputs (include/nic_rollout.h: nic_mlp3_fwd / nic_mlp3_bwd) and the segment
 // sum that aggregates messages / scatters gradients over the static supply graph (nic_segment_sum).
 //
-// One wavefront = 32 scenarios of ONE entity (node or edge), so every gather index is wave-uniform: the K input rows of a
+// One wavefront = 32-scenario chunks of ONE entity (node or edge), so every gather index is wave-uniform: the K input rows of a
 // column are K row pointers computed on the scalar unit from the segment table + the entity's map entry; lanes only add their
 // scenario offset.  The layers run on the matrix cores exactly like csrc/small_rollout.hip: A = weights (lane l holds
 // W[i = l & 31][kk = l >> 5]), B = activations (lane = scenario), and MFMA step s of layers 2 / 3 is defined to contract over
@@ -15,26 +15,47 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// uniform: pointer to input row k of entity e (without the scenario offset) and its scenario stride; nullptr = zeros
+// The segment table of one entity, resolved ONCE per wavefront into scalars (base pointer of the entity's rows per segment,
+// first input row of each segment): finding the pointer of input row k afterwards is a few scalar compares and selects, no
+// memory access.  (Resolving the table per row cost three dependent scalar loads per row: the kernel was bound by them.)
+struct SegRegs {
+    const float* base[NIC_MLP3_MAX_SEGS];   // nullptr: the virtual (all-zero) node
+    int64_t row_stride[NIC_MLP3_MAX_SEGS];
+    int scn[NIC_MLP3_MAX_SEGS];
+    int start[NIC_MLP3_MAX_SEGS + 1];
+};
+__device__ __forceinline__ SegRegs resolve_segments(const NicMlp3Desc& d, int e) {
+    SegRegs R;
+    R.start[0] = 0;
+#pragma unroll
+    for (int q = 0; q < NIC_MLP3_MAX_SEGS; ++q) {
+        R.base[q] = nullptr;
+        R.row_stride[q] = 0;
+        R.scn[q] = 0;
+        R.start[q + 1] = R.start[q];
+        if (q < d.n_segs) {
+            const NicMlp3Seg& S = d.seg[q];
+            const int ent = S.map ? S.map[e] : e;
+            R.base[q] = ent >= 0 ? S.base + (int64_t)ent * S.ent_stride : nullptr;
+            R.row_stride[q] = S.row_stride;
+            R.scn[q] = (int)S.scn_stride;
+            R.start[q + 1] = R.start[q] + S.n_rows;
+        }
+    }
+    return R;
+}
 struct RowRef {
     const float* p;
     int64_t scn;
 };
-__device__ __forceinline__ RowRef input_row(const NicMlp3Desc& d, int k, int e) {
+__device__ __forceinline__ RowRef input_row(const SegRegs& R, int k) {
     RowRef out{nullptr, 0};
-    if (k >= d.K) return out;
-    int r = k, sg = 0;
 #pragma unroll
-    for (int q = 0; q < NIC_MLP3_MAX_SEGS - 1; ++q)
-        if (sg == q && q + 1 < d.n_segs && r >= d.seg[q].n_rows) {
-            r -= d.seg[q].n_rows;
-            sg = q + 1;
+    for (int q = 0; q < NIC_MLP3_MAX_SEGS; ++q)
+        if (k >= R.start[q] && k < R.start[q + 1]) {
+            out.p = R.base[q] ? R.base[q] + (int64_t)(k - R.start[q]) * R.row_stride[q] : nullptr;
+            out.scn = R.scn[q];
         }
-    const NicMlp3Seg& S = d.seg[sg];
-    const int ent = S.map ? S.map[e] : e;
-    if (ent < 0) return out;
-    out.p = S.base + (int64_t)r * S.row_stride + (int64_t)ent * S.ent_stride;
-    out.scn = S.scn_stride;
     return out;
 }
 
@@ -50,64 +71,68 @@ __device__ __forceinline__ float out_act_grad(int act, float y) {
     return 1.f;
 }
 
-// KS = MFMA steps of the first layer (input rows 2s + h): K <= 2 * KS
+constexpr int kWaves = 4;   // wavefronts per workgroup (they share one staged copy of the weights)
+constexpr int kChunks = 1;  // 32-scenario chunks each wavefront walks (1: nothing is loop-invariant, so the weight fragments are read from LDS as they are used instead of being hoisted into ~130 VGPRs, which left one wavefront per SIMD)
+
+// KS = MFMA steps of the first layer (input rows 2s + h): K <= 2 * KS.
+// One wavefront per workgroup, no LDS: the weight fragments are read from the PRE-TRANSPOSED copy (`weights_t`: lane i of step
+// k reads consecutive words - one 128-B line per half; the natural layout would touch 32 lines per read) right where they are
+// used, so the kernel stays near 90 VGPRs and five or more wavefronts per SIMD hide the gather latency.  (Variants that staged
+// the weights in LDS for four wavefronts let the compiler hoist every fragment into registers - 300+ VGPRs or scratch - and
+// were 2-4x slower; measured.)
 template <int KS>
-__global__ __launch_bounds__(64) void mlp3_fwd_kernel(NicMlp3Desc d, const float* __restrict__ weights, float* __restrict__ Y,
+__global__ __launch_bounds__(64) void mlp3_fwd_kernel(NicMlp3Desc d, const float* __restrict__ wt, float* __restrict__ Y,
                                                       float* __restrict__ Xh, float* __restrict__ H1, float* __restrict__ H2) {
-    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
-    const int e = blockIdx.y;
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5, i = j;
+    const int e = blockIdx.y, K = d.K;
     const int64_t b_raw = (int64_t)blockIdx.x * 32 + j;
     const bool live = b_raw < d.n_scenarios;
     const int64_t b = live ? b_raw : 0;
     const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;   // elements between feature rows of the [rows][E][ldb] buffers
+    const int64_t hs = d.hist_row_stride ? d.hist_row_stride : ent_ld;  // ... and of the history buffers
     const int64_t col = (int64_t)e * d.ldb + b;
-    const int K = d.K, i = j;
-
-    // layer 1: x rows k = 2s + h gathered straight from the sources; A fragment W1[i][2s + h]
+    const float* w1t = wt;                 // [K][32]
+    const float* b1 = w1t + K * 32;
+    const float* w2t = b1 + 32;            // [32][32]
+    const float* b2 = w2t + 32 * 32;
+    const float* w3t = b2 + 32;            // [32][32], columns >= n_out zero
+    const float* b3 = w3t + 32 * 32;       // padded to 32
+    const SegRegs segs = resolve_segments(d, e);
     f32x16 acc;
-    const float* W1 = weights;
-    const float* b1 = W1 + 32 * K;
-    const float* W2 = b1 + 32;
-    const float* b2 = W2 + 32 * 32;
-    const float* W3 = b2 + 32;
-    const float* b3 = W3 + d.n_out * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = b1[crow(r, h)];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const RowRef r0 = input_row(d, 2 * s, e), r1 = input_row(d, 2 * s + 1, e);
+        const RowRef r0 = input_row(segs, 2 * s), r1 = input_row(segs, 2 * s + 1);
         const float* p = h ? r1.p : r0.p;
         const int64_t scn = h ? r1.scn : r0.scn;
         const int k = 2 * s + h;
         const float x = p ? p[b * scn] : 0.f;
-        const float a = k < K ? W1[i * K + k] : 0.f;
+        const float a = k < K ? w1t[k * 32 + i] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x, acc, 0, 0, 0);
-        if (Xh && live && k < K) Xh[(int64_t)k * ent_ld + col] = x;
+        if (Xh && live && k < K) Xh[(int64_t)k * hs + col] = x;
     }
     float hcur[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) hcur[r] = nic::elu1(acc[r]);
     if (H1 && live) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H1[(int64_t)crow(r, h) * ent_ld + col] = hcur[r];
+        for (int r = 0; r < 16; ++r) H1[(int64_t)crow(r, h) * hs + col] = hcur[r];
     }
-    // layer 2
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = b2[crow(r, h)];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[i * 32 + crow(s, h)], hcur[s], acc, 0, 0, 0);
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2t[crow(s, h) * 32 + i], hcur[s], acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) hcur[r] = nic::elu1(acc[r]);
     if (H2 && live) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H2[(int64_t)crow(r, h) * ent_ld + col] = hcur[r];
+        for (int r = 0; r < 16; ++r) H2[(int64_t)crow(r, h) * hs + col] = hcur[r];
     }
-    // layer 3 (rows >= n_out carry zero weights)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = crow(r, h) < d.n_out ? b3[crow(r, h)] : 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = b3[crow(r, h)];
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(i < d.n_out ? W3[i * 32 + crow(s, h)] : 0.f, hcur[s], acc, 0, 0, 0);
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w3t[crow(s, h) * 32 + i], hcur[s], acc, 0, 0, 0);
     if (live) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -115,71 +140,93 @@ __global__ __launch_bounds__(64) void mlp3_fwd_kernel(NicMlp3Desc d, const float
     }
 }
 
-// KG = 32-row groups of the input gradient (K <= 32 * KG)
+// KG = 32-row groups of the input gradient (K <= 32 * KG).  Weights staged in LDS in their natural row-major layout (the
+// transposed products read W[crow(s, h)][i]: consecutive words per lane); the stored activations of a chunk are fetched
+// before the first MFMA.
 template <int KG>
-__global__ __launch_bounds__(64) void mlp3_bwd_kernel(NicMlp3Desc d, const float* __restrict__ weights,
-                                                      const float* __restrict__ dY, const float* __restrict__ Yo,
-                                                      const float* __restrict__ H1, const float* __restrict__ H2,
-                                                      float* __restrict__ dZ3, float* __restrict__ dZ2, float* __restrict__ dZ1,
-                                                      float* __restrict__ dX) {
-    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(3, 8))) void mlp3_bwd_kernel(NicMlp3Desc d, const float* __restrict__ weights,
+                                                               const float* __restrict__ dY, const float* __restrict__ Yo,
+                                                               const float* __restrict__ H1, const float* __restrict__ H2,
+                                                               float* __restrict__ dZ3, float* __restrict__ dZ2,
+                                                               float* __restrict__ dZ1, float* __restrict__ dX) {
+    __shared__ float w1[32 * 32 * KG], w2[32 * 32], w3[32 * 32];
+    const int K = d.K;
+    {
+        const float* W1 = weights;
+        const float* W2 = W1 + 32 * K + 32;
+        const float* W3 = W2 + 32 * 32 + 32;
+        for (int idx = threadIdx.x; idx < 32 * 32 * KG; idx += 64 * kWaves) {  // [row n][32 * KG input columns], zero padded
+            const int n = idx / (32 * KG), k = idx % (32 * KG);
+            w1[idx] = k < K ? W1[n * K + k] : 0.f;
+        }
+        for (int idx = threadIdx.x; idx < 32 * 32; idx += 64 * kWaves) {
+            w2[idx] = W2[idx];
+            w3[idx] = (idx >> 5) < d.n_out ? W3[idx] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5, i = j;
     const int e = blockIdx.y;
-    const int64_t b_raw = (int64_t)blockIdx.x * 32 + j;
-    const bool live = b_raw < d.n_scenarios;
-    const int64_t b = live ? b_raw : 0;
     const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;
-    const int64_t col = (int64_t)e * d.ldb + b;
-    const int K = d.K, i = j;
-    const float* W1 = weights;
-    const float* W2 = W1 + 32 * K + 32;
-    const float* W3 = W2 + 32 * 32 + 32;
-
-    // dz3 = dY * act'(y) in the C layout (rows crow(r, h)); rows >= n_out are zero
-    float dz[16];
+    const int64_t hs = d.hist_row_stride ? d.hist_row_stride : ent_ld;
+#pragma unroll 1
+    for (int c = 0; c < kChunks; ++c) {
+        if ((int64_t)(blockIdx.x * kWaves + wv) * kChunks * 32 + (int64_t)c * 32 >= d.n_scenarios) break;
+        const int64_t b_raw = ((int64_t)(blockIdx.x * kWaves + wv) * kChunks + c) * 32 + j;
+        const bool live = b_raw < d.n_scenarios;
+        const int64_t b = live ? b_raw : 0;
+        const int64_t col = (int64_t)e * d.ldb + b;
+        // everything this chunk reads, issued up front (rows >= n_out re-read row 0 and are zeroed by a select)
+        float gy[16], yo[16], h2[16], h1[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = crow(r, h);
-        float v = 0.f;
-        if (row < d.n_out) v = dY[(int64_t)row * ent_ld + col] * out_act_grad(d.out_act, Yo[(int64_t)row * ent_ld + col]);
-        dz[r] = live ? v : 0.f;
-        if (live && row < d.n_out) dZ3[(int64_t)row * ent_ld + col] = v;
-    }
-    // dH2 = W3^T dz3: A fragment W3[crow(s, h)][i] (contraction over the output rows)
-    f32x16 acc;
+        for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, h), rr = row < d.n_out ? row : 0;
+            gy[r] = dY[(int64_t)rr * ent_ld + col];
+            yo[r] = Yo[(int64_t)rr * ent_ld + col];
+            h2[r] = H2[(int64_t)row * hs + col];
+            h1[r] = H1[(int64_t)row * hs + col];
+        }
+        float dz[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, h);
+            const float v = (row < d.n_out && live) ? gy[r] * out_act_grad(d.out_act, yo[r]) : 0.f;
+            dz[r] = v;
+            if (live && row < d.n_out) dZ3[(int64_t)row * hs + col] = v;
+        }
+        f32x16 acc;
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(crow(s, h) < d.n_out ? W3[crow(s, h) * 32 + i] : 0.f, dz[s], acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        dz[r] = acc[r] * nic::elu1_grad_from_out(H2[(int64_t)crow(r, h) * ent_ld + col]);
-        if (live) dZ2[(int64_t)crow(r, h) * ent_ld + col] = dz[r];
-    }
-    // dH1 = W2^T dz2
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[crow(s, h) * 32 + i], dz[s], acc, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            dz[r] = acc[r] * nic::elu1_grad_from_out(h2[r]);
+            if (live) dZ2[(int64_t)crow(r, h) * hs + col] = dz[r];
+        }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[crow(s, h) * 32 + i], dz[s], acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        dz[r] = acc[r] * nic::elu1_grad_from_out(H1[(int64_t)crow(r, h) * ent_ld + col]);
-        if (live) dZ1[(int64_t)crow(r, h) * ent_ld + col] = dz[r];
-    }
-    // dX = W1^T dz1, 32 input rows per group
-    if (dX) {
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[crow(s, h) * 32 + i], dz[s], acc, 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < KG; ++g) {
+        for (int r = 0; r < 16; ++r) {
+            dz[r] = acc[r] * nic::elu1_grad_from_out(h1[r]);
+            if (live) dZ1[(int64_t)crow(r, h) * hs + col] = dz[r];
+        }
+        if (dX) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int g = 0; g < KG; ++g) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(32 * g + i < K ? W1[crow(s, h) * K + 32 * g + i] : 0.f, dz[s], acc, 0, 0, 0);
-            if (live) {
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = 32 * g + crow(r, h);
-                    if (k < K) dX[(int64_t)k * ent_ld + col] = acc[r];
+                for (int s = 0; s < 16; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[crow(s, h) * 32 * KG + 32 * g + i], dz[s], acc, 0, 0, 0);
+                if (live) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = 32 * g + crow(r, h);
+                        if (k < K) dX[(int64_t)k * ent_ld + col] = acc[r];
+                    }
                 }
             }
         }
@@ -226,12 +273,13 @@ int nic_mlp3_fwd(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float
     if (int e = validate(d, "nic_mlp3_fwd")) return e;
     NIC_REQUIRE(Y, "nic_mlp3_fwd: null output");
     NIC_REQUIRE(!X_hist || (H1 && H2), "nic_mlp3_fwd: incomplete history buffers");
+    NIC_REQUIRE(d->weights_t, "nic_mlp3_fwd: weights_t (the pre-transposed weight copy) is required");
     const dim3 grid(nic::ceil_div(d->n_scenarios, 32), d->n_entities), block(64);
     hipStream_t s = nic::as_stream(stream);
     const int ks = (d->K + 1) / 2;
     const int t = ks <= 4 ? 4 : (ks <= 16 ? 16 : (ks <= 33 ? 33 : 48));
     nic::note_kernelf("mlp3_fwd_kernel<%d>", t);
-#define NIC_MLP3_FWD(KS) hipLaunchKernelGGL(mlp3_fwd_kernel<KS>, grid, block, 0, s, *d, d->weights, Y, X_hist, H1, H2)
+#define NIC_MLP3_FWD(KS) hipLaunchKernelGGL(mlp3_fwd_kernel<KS>, grid, block, 0, s, *d, d->weights_t, Y, X_hist, H1, H2)
     if (t == 4) NIC_MLP3_FWD(4);
     else if (t == 16) NIC_MLP3_FWD(16);
     else if (t == 33) NIC_MLP3_FWD(33);
@@ -244,7 +292,7 @@ int nic_mlp3_bwd(const NicMlp3Desc* d, const float* dY, const float* Y, const fl
                  float* dZ1, float* dX, void* stream) {
     if (int e = validate(d, "nic_mlp3_bwd")) return e;
     NIC_REQUIRE(dY && Y && H1 && H2 && dZ3 && dZ2 && dZ1, "nic_mlp3_bwd: null buffer");
-    const dim3 grid(nic::ceil_div(d->n_scenarios, 32), d->n_entities), block(64);
+    const dim3 grid(nic::ceil_div(d->n_scenarios, 32 * kWaves * kChunks), d->n_entities), block(64 * kWaves);
     hipStream_t s = nic::as_stream(stream);
     const int kg = (d->K + 31) / 32;
     nic::note_kernelf("mlp3_bwd_kernel<%d>", kg);

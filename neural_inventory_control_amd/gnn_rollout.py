@@ -82,31 +82,47 @@ class GraphPlan:
         lead = list(store_lead) + [wh_lead] + [0.0] * (n_dem + self.n_self)
         self.lead = torch.tensor(lead, dtype=torch.float32, device=device).view(1, -1)   # per-edge constant input row
         # proportional allocation group of the warehouse: its internal edges + its self loop (:1435-1492)
-        self.members = list(range(n_int)) + ([self.e_self] if self.n_self else [])
+        self.members = torch.tensor(list(range(n_int)) + ([self.e_self] if self.n_self else []), dtype=torch.long,
+                                    device=device)  # (a device tensor: indexing with it is capturable into a HIP graph)
         self.transshipment = bool(transshipment)
 
 
 class _Mlp:
     """Packed weights, gradient slabs and per-period history of one of the policy's five MLPs."""
 
-    def __init__(self, name, linears, K, n_out, out_act, n_ent, ld, T, device, train):
+    def __init__(self, name, linears, K, n_out, out_act, n_ent, ld, T, P, device, train):
         self.name, self.linears, self.K, self.n_out, self.out_act, self.n_ent = name, linears, K, n_out, out_act, n_ent
         z = lambda *s: torch.zeros(*s, device=device)  # noqa: E731
         self.packed = z(32 * K + 32 + 32 * 32 + 32 + n_out * 32 + n_out)
         self.Y = z(T, n_out, n_ent, ld)
+        self.P, self.G = P, (T + P - 1) // P
+        self.hist_stride = 0
         if train:
-            self.X, self.H1, self.H2 = z(T, K, n_ent, ld), z(T, 32, n_ent, ld), z(T, 32, n_ent, ld)
-            self.dZ1, self.dZ2, self.dZ3 = z(32, n_ent, ld), z(32, n_ent, ld), z(n_out, n_ent, ld)
+            # histories [group][rows][P periods][entity][ldb]: one row holds P periods, so a weight gradient contracts over
+            # P * n_ent * ldb columns per launch (P is bounded by the GEMM kernels' 2^28-element operand limit)
+            G = self.G
+            self.hist_stride = P * n_ent * ld
+            self.X, self.H1, self.H2 = z(G, K, P, n_ent, ld), z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld)
+            self.dZ1, self.dZ2, self.dZ3 = z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld), z(G, n_out, P, n_ent, ld)
             self.dX = z(K, n_ent, ld)
             dims = [(32, K), (32, 32), (n_out, 32)]
-            cols = n_ent * ld
+            cols = P * n_ent * ld
             self.splits = [ops.wgrad_num_splits(n, k, cols) for n, k in dims]
             self.slabs = [z(sp, n, (k + 1 + 3) // 4 * 4) for sp, (n, k) in zip(self.splits, dims)]
             self.gw = [torch.zeros_like(m.weight) for m in linears]
             self.gb = [torch.zeros_like(m.bias) for m in linears]
 
+    def hist(self, buf, t):
+        """[rows][entity][ldb] view of period t inside a grouped history buffer (row stride = hist_stride)."""
+        return buf[t // self.P, :, t % self.P]
+
     def pack(self):
         self.packed.copy_(torch.cat([t.detach().reshape(-1) for m in self.linears for t in (m.weight, m.bias)]))
+        tr = ops.mlp3_pack_transposed([(m.weight, m.bias) for m in self.linears], self.n_out)
+        if getattr(self, "packed_t", None) is None:
+            self.packed_t = tr.clone()
+        else:
+            self.packed_t.copy_(tr)
 
 
 class GnnRollout:
@@ -129,6 +145,7 @@ class GnnRollout:
             raise ValueError("GnnRollout handles the gnn.yml architecture on one-warehouse settings")
         self.model, self.problem_params, self.device = model, problem_params, torch.device(device)
         self.timer = None
+        self.use_graph = False   # replay the (static) launch sequence of a rollout from a HIP graph after one eager run
         self._probs = ProblemCache()
         self._key = None
 
@@ -175,9 +192,11 @@ class GnnRollout:
         A = _lib
         ks = (self.Dn, 65, 96, 96, 32)
         ents = (N, E, N, E, E)
+        P_ = max(1, min(T, (1 << 28) // (96 * E * ld)))   # periods per history row (see _Mlp)
         self.mlp = {name: _Mlp(name, self._linears(name), k, 1 if name == "output" else 32,
-                               A.NIC_MLP3_ACT_SOFTPLUS if name == "output" else A.NIC_MLP3_ACT_ELU, ne, ld, T, dev, train)
+                               A.NIC_MLP3_ACT_SOFTPLUS if name == "output" else A.NIC_MLP3_ACT_ELU, ne, ld, T, P_, dev, train)
                     for name, k, ne in zip(MODULES, ks, ents)}
+        self._graphs, self._eager_runs = {}, 0
         self.agg_in, self.agg_out = z(T, 32, N, ld), z(T, 32, N, ld)
         self.nodes1, self.edges1 = z(T, 32, N, ld), z(T, 32, E, ld)
         self.sums, self.ratio, self.scale = z(T, ld), z(T, ld), z(T, ld)
@@ -231,11 +250,26 @@ class GnnRollout:
             f[:, mi + 1, 0, :B] = data["warehouse_edge_costs"][:, 0]
         for r, k in enumerate(("holding_costs", "underage_costs", "mean", "std")):
             f[:, mi + r, 1:, :B] = data[k].t()
-        for t in range(T):
-            self._forward_period(t, prob, demand_soa, shift)
+        if self.use_graph:  # captured launches point at engine-owned buffers: keep the demand trace in one of them
+            if getattr(self, "_demand_buf", None) is None or self._demand_buf.shape != demand_soa.shape:
+                self._demand_buf, self._graphs, self._eager_runs = torch.empty_like(demand_soa), {}, 0
+            if self._demand_buf.data_ptr() != demand_soa.data_ptr():
+                self._demand_buf.copy_(demand_soa)
+            demand_soa = self.demand = self._demand_buf
+            if getattr(self, "_graph_prob", None) is not None and self._graph_prob.same_layout(prob):
+                self._graph_prob.copy_tables_from(prob)
+                prob = self.prob = self._graph_prob
+            else:
+                self._graph_prob, self._graphs, self._eager_runs = prob, {}, 0
+
+        def forward():
+            for t in range(T):
+                self._forward_period(t, prob, demand_soa, shift)
+        self._replay_or_capture(("fwd", T, shift, bool(train)), forward)
         total = self.rewards.sum()
         reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
         if not train:
+            self._eager_runs += 1
             return total, reported
         if grad_scale is None:
             grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
@@ -245,13 +279,15 @@ class GnnRollout:
             for sl in m.slabs:
                 sl.zero_()
         self.g_state[0].zero_()
-        g_next, g_cur = self.g_state
-        for t in range(T - 1, -1, -1):
-            self._backward_period(t, prob, demand_soa, shift, g_next, g_cur)
-            g_next, g_cur = g_cur, g_next
-        for m in self.mlp.values():
-            for i, lin in enumerate(m.linears):
-                ops.wgrad_reduce(m.slabs[i], m.gw[i], m.gb[i], lin.weight.shape[1], 1.0)
+
+        def backward():
+            g_next, g_cur = self.g_state
+            for t in range(T - 1, -1, -1):
+                self._backward_period(t, prob, demand_soa, shift, g_next, g_cur)
+                g_next, g_cur = g_cur, g_next
+            self._weight_gradients(T, prob)
+        self._replay_or_capture(("bwd", T, shift), backward)
+        self._eager_runs += 1
         if assign_grads:
             for p, g in self.param_grads():
                 p.grad = g
@@ -262,8 +298,34 @@ class GnnRollout:
         return [(t, g) for m in self.mlp.values() for i, lin in enumerate(m.linears)
                 for t, g in ((lin.weight, m.gw[i]), (lin.bias, m.gb[i]))]
 
+    def _replay_or_capture(self, name, fn):
+        """The launch sequence of a rollout is identical from call to call (same buffers, same shapes): after one eager run
+        it is captured into a HIP graph and replayed, which removes the host cost of ~3,000 launches and descriptor builds."""
+        if not self.use_graph or self.timer is not None or self._eager_runs < 1:
+            return fn()
+        g = self._graphs.get(name)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                fn()
+            self._graphs[name] = g
+        g.replay()
+
+    def _weight_gradients(self, T, prob):
+        """dW = sum over (period, entity, scenario) of dZ X^T per layer: one contraction per history group (P periods each)."""
+        for m in self.mlp.values():
+            for g in range(m.G):
+                n_per = min(m.P, T - g * m.P)
+                cols = n_per * m.n_ent * prob.ldb
+                for i, (dz, x) in enumerate(((m.dZ1, m.X), (m.dZ2, m.H1), (m.dZ3, m.H2))):
+                    self._k("wgrad_" + m.name, ops.linear_wgrad, dz[g].view(dz.shape[1], -1), x[g].view(x.shape[1], -1),
+                            m.slabs[i], cols)
+            for i, lin in enumerate(m.linears):
+                ops.wgrad_reduce(m.slabs[i], m.gw[i], m.gb[i], lin.weight.shape[1], 1.0)
+
     def _desc(self, m, segs, prob):
-        return ops.mlp3_desc(segs, m.packed, m.n_ent, prob.B, prob.ldb, m.n_out, m.out_act)
+        return ops.mlp3_desc(segs, m.packed, m.n_ent, prob.B, prob.ldb, m.n_out, m.out_act, m.hist_stride, m.packed_t)
 
     def _segments(self, t):
         """Input segments of the five MLPs at period t (the graph's gathers; no concatenation is materialised)."""
@@ -279,7 +341,7 @@ class GnnRollout:
 
     def _run_mlp(self, name, t, segs, prob):
         m = self.mlp[name]
-        hist = (m.X[t], m.H1[t], m.H2[t]) if hasattr(m, "X") else (None, None, None)
+        hist = (m.hist(m.X, t), m.hist(m.H1, t), m.hist(m.H2, t)) if hasattr(m, "X") else (None, None, None)
         self._k("mlp3_fwd_" + name, ops.mlp3_fwd, self._desc(m, segs[name], prob), m.Y[t], *hist)
 
     def _forward_period(self, t, prob, demand_soa, shift):
@@ -366,11 +428,8 @@ class GnnRollout:
         gc.store += m.dX[:prob.Ws, 1:].permute(1, 0, 2)
 
     def _mlp_bwd(self, m, t, segs, prob, dY, dX=None):
-        self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd, self._desc(m, segs[m.name], prob), dY, m.Y[t], m.H1[t], m.H2[t], m.dZ3,
-                m.dZ2, m.dZ1, dX if dX is not None else m.dX)
-        cols = m.n_ent * prob.ldb
-        for i, (dz, x) in enumerate(((m.dZ1, m.X[t]), (m.dZ2, m.H1[t]), (m.dZ3, m.H2[t]))):
-            self._k("wgrad_" + m.name, ops.linear_wgrad, dz.view(dz.shape[0], cols), x.view(x.shape[0], cols), m.slabs[i], cols)
+        self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd, self._desc(m, segs[m.name], prob), dY, m.Y[t], m.hist(m.H1, t),
+                m.hist(m.H2, t), m.hist(m.dZ3, t), m.hist(m.dZ2, t), m.hist(m.dZ1, t), dX if dX is not None else m.dX)
 
     # ---- inspection helpers used by the parity tests --------------------------------------------------------------------------
     def per_period_rewards(self):

@@ -187,8 +187,20 @@ class Mlp3Segment:
         self.tensor, self.index, self.per_scenario = tensor, index, per_scenario
 
 
-def mlp3_desc(segments, weights, n_entities, n_scenarios, ldb, n_out, out_act):
+def mlp3_pack_transposed(linears_or_tensors, n_out):
+    """[W1^T][b1][W2^T][b2][W3^T padded to 32 columns][b3 padded to 32] (see NicMlp3Desc.weights_t)."""
+    (w1, b1), (w2, b2), (w3, b3) = linears_or_tensors
+    w3t = torch.zeros(32, 32, device=w3.device)
+    w3t[:, :n_out] = w3.detach().t()
+    b3p = torch.zeros(32, device=w3.device)
+    b3p[:n_out] = b3.detach()
+    return torch.cat([w1.detach().t().reshape(-1), b1.detach(), w2.detach().t().reshape(-1), b2.detach(), w3t.reshape(-1), b3p])
+
+
+def mlp3_desc(segments, weights, n_entities, n_scenarios, ldb, n_out, out_act, hist_row_stride=0, weights_t=None):
     d = _lib.NicMlp3Desc()
+    d.hist_row_stride = int(hist_row_stride)
+    d.weights_t = weights_t.data_ptr() if weights_t is not None else None
     d.n_entities, d.n_scenarios, d.ldb = n_entities, n_scenarios, ldb
     d.n_out, d.out_act, d.n_segs = n_out, out_act, len(segments)
     k = 0
@@ -203,7 +215,7 @@ def mlp3_desc(segments, weights, n_entities, n_scenarios, ldb, n_out, out_act):
         k += t.shape[0]
     d.K = k
     d.weights = weights.data_ptr()
-    d._keep = (segments, weights)
+    d._keep = (segments, weights, weights_t)
     return d
 
 

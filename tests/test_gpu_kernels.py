@@ -430,7 +430,8 @@ def test_mlp3_fwd_bwd_with_gathered_segments(K_rows, n_out, act, B):
     dims = [(32, K), (32, 32), (n_out, 32)]
     W = [(torch.randn(n, k, generator=gen) / k ** 0.5, torch.randn(n, generator=gen) * 0.3) for n, k in dims]
     packed = torch.cat([t.reshape(-1) for wb in W for t in wb]).to(dev)
-    desc = ops.mlp3_desc(segs, packed, E, B, ld, n_out, act)
+    packed_t = ops.mlp3_pack_transposed([(w.to(dev), b_.to(dev)) for w, b_ in W], n_out)
+    desc = ops.mlp3_desc(segs, packed, E, B, ld, n_out, act, 0, packed_t)
     z = lambda r: torch.zeros(r, E, ld, device=dev)  # noqa: E731
     Y, Xh, H1, H2 = z(n_out), z(K), z(32), z(32)
     ops.mlp3_fwd(desc, Y, Xh, H1, H2)

@@ -967,3 +967,35 @@ def test_gnn_fused_rollout_matches_reference(name):
     (tot3 / (c["n"] * c["periods"] * c["problem_params"]["n_stores"])).backward()
     for k, r in ref.items():
         assert float((named[k].grad.cpu() - r).norm() / (r.norm() + 1e-30)) <= GRAD_TOL, k
+
+
+def test_gnn_graph_replay_matches_eager():
+    """The GNN engine's launch sequence (fused MLP launches, segment sums, the small allocation ops, env steps, the batched
+    weight gradients) captured into HIP graphs and replayed: same costs and gradients as eager launches, also after the batch
+    contents change."""
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout
+    g = Golden("f1_one_warehouse_gnn")
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    data2 = dict(data)
+    data2["demands"] = (data["demands"] * 1.3 + 0.25).contiguous()
+    out = {}
+    for mode in ("eager", "graph"):
+        model = _model(g, c)
+        eng = GnnRollout(model, c["problem_params"], DEV)
+        eng.use_graph = mode == "graph"
+        eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+        _load(model, g)
+        res = []
+        for d in (data, data2, data, data2):
+            total, rep = eng.run(d, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+            torch.cuda.synchronize()
+            res.append((float(total), float(rep), [p.grad.clone() for p in model.parameters()]))
+        out[mode] = res
+        if mode == "graph":
+            assert len(eng._graphs) == 2
+    for a, b in zip(out["eager"], out["graph"]):
+        assert a[0] == b[0] and a[1] == b[1]
+        for x, y in zip(a[2], b[2]):
+            assert torch.equal(x, y)
+    assert out["eager"][0][0] != out["eager"][1][0]
