@@ -98,7 +98,8 @@ def _pmc_traffic(kernel_name, n_scenarios):
     WRITE_SIZE collected in separate --pmc passes and corrected as the files' notes say.  None if no pass has this kernel
     at this scenario count."""
     import glob
-    squash = lambda s: s.replace(" ", "")  # noqa: E731
+    # rocprofv3 prints template arguments as numbers, nic_last_kernel() with the enumerator names
+    squash = lambda s: s.replace(" ", "").replace("EPI_BIAS_ACT", "0").replace("EPI_DGRAD", "1")  # noqa: E731
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
         try:
             doc = json.load(open(f))
@@ -129,7 +130,7 @@ def _pick_threads(avail):
     return best
 
 
-def cpu_baseline(workload, sample_scenarios, periods, reps=3):
+def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None):
     """The oracle (CPU restatement of the reference path, PyTorch eager) timed on this host's cores: training steps
     (rollout + backward) of the same workload on a bounded sample of scenarios; 1 warm-up + `reps` timed repetitions,
     median."""
@@ -153,7 +154,11 @@ def cpu_baseline(workload, sample_scenarios, periods, reps=3):
                  if k in data)
     if policy["name"] in ("base_stock", "capped_base_stock", "echelon_stock"):
         F = 1  # closed-form policies: one Linear fed the constant 0 (neural_networks.py:228)
-    pol = orc.init_policy(policy, setting["problem_params"], F, 1234, setting["store_params"])
+    if policy["name"] == "gnn":  # five MLPs: the oracle takes the (already materialised) weights of the device model
+        state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        pol = orc.policy_from_state_dict(policy, state, setting["problem_params"])
+    else:
+        pol = orc.init_policy(policy, setting["problem_params"], F, 1234, setting["store_params"])
     warm = {k: v[:max(8, sample_scenarios // 16)] for k, v in data.items()}
     orc.train_step_gradients(pol, min(periods, 10), setting["problem_params"], warm, obs)  # warm-up
     times = []
@@ -421,9 +426,9 @@ def main():
                                             "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
                                             "mean_launch_ms": e["mean_ms"]}
         if world == 1 and not args.no_cpu_baseline and not args.eval:
-            sample = args.cpu_sample or {"cfg3": 4096, "cfg5": 1024, "cfg2": 32768, "cfg4": 16384, "cfg1": 256, "base_stock": 32768}.get(args.workload, 1024)
+            sample = args.cpu_sample or {"cfg3": 4096, "cfg5": 1024, "cfg2": 32768, "cfg4": 16384, "cfg1": 256, "base_stock": 32768, "gnn": 512}.get(args.workload, 1024)
             try:
-                out["cpu_baseline"] = cpu_baseline(args.workload, min(sample, n), T)
+                out["cpu_baseline"] = cpu_baseline(args.workload, min(sample, n), T, model=model)
                 out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "scenario-steps/s", "cores": None, "host_cores": os.cpu_count(),
