@@ -266,8 +266,23 @@ class _SerialHead(torch.autograd.Function):
         return ref_view(dZ, B), ref_view(g_wh, B), ref_view(g_ech, B), None
 
 
+_SCALAR_CACHE = {}
+
+
 def _scalar(x):
-    return float(x.reshape(-1)[0]) if torch.is_tensor(x) else float(x)
+    """Host value of a (device) scalar such as `warehouse_upper_bound`, read back ONCE per tensor version: the heads take
+    it as a launch argument every period, and a device-to-host copy per period would be a sync (and cannot be captured into a
+    HIP graph)."""
+    if not torch.is_tensor(x):
+        return float(x)
+    key = (x.data_ptr(), x._version, x.device)
+    hit = _SCALAR_CACHE.get(id(x))
+    if hit is None or hit[0] != key or hit[2]() is not x:
+        import weakref
+        if len(_SCALAR_CACHE) > 64:
+            _SCALAR_CACHE.clear()
+        hit = _SCALAR_CACHE[id(x)] = (key, float(x.reshape(-1)[0]), weakref.ref(x))
+    return hit[1]
 
 
 # ---- architectures of the hot path ----------------------------------------------------------------------------------

@@ -360,7 +360,12 @@ class Trainer:
         return {k: v.to(self.device) for k, v in data_batch.items()}
 
     def load_model(self, model, optimizer, model_path):
-        checkpoint = torch.load(model_path, map_location=self.device, weights_only=False)
+        try:  # the reference's checkpoints hold tensors, lists and numbers only: no need to unpickle arbitrary objects
+            checkpoint = torch.load(model_path, map_location=self.device, weights_only=True)
+        except Exception:
+            if not getattr(self, "allow_pickled_checkpoints", True):
+                raise
+            checkpoint = torch.load(model_path, map_location=self.device, weights_only=False)
         model.load_state_dict(checkpoint["model_state_dict"])
         optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
         self.all_train_losses = checkpoint["all_train_losses"]

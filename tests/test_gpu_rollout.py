@@ -999,3 +999,53 @@ def test_gnn_graph_replay_matches_eager():
         for x, y in zip(a[2], b[2]):
             assert torch.equal(x, y)
     assert out["eager"][0][0] != out["eager"][1][0]
+
+
+@pytest.mark.parametrize("setting_name", ["cfg3", "cfg2"])
+def test_per_sample_cost_tables_with_shuffled_batches_follow_the_oracle(setting_name):
+    """`vary_across_samples: True` (data_handling.py:258-259): underage costs differ per SCENARIO, so every shuffled batch has
+    its own cost table.  The engines cache the compacted tables per presented tensors; entries pin those tensors, so a later
+    batch that lands on a recycled address cannot inherit another batch's costs.  Every batch of two shuffled epochs is
+    checked against the oracle on the fused per-period route (cfg3), the whole-horizon route (cfg2) and the Simulator route."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from oracle import inventory_oracle as orc
+    setting, policy, _, _, _ = workloads.get(setting_name)
+    if setting_name == "cfg3":
+        setting["problem_params"]["n_stores"] = 4
+        policy["neurons_per_hidden_layer"]["master"] = [32, 32]
+    setting["store_params"]["underage_cost"] = {"sample_across_stores": False, "vary_across_samples": True, "expand": False,
+                                                "range": [4.0, 14.0]}
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    T, n, bs = 12, 96, 32
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
+                  n, obs, dict(setting["seeds"]))
+    ds = DatasetCreator().create_datasets(sc, split=False)
+    assert float(ds.data["underage_costs"].std(dim=0).max()) > 0.5  # really per-sample
+    torch.manual_seed(5)
+    model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+    S = setting["problem_params"]["n_stores"]
+    F = S * ds.data["initial_inventories"].shape[2] + (ds.data["initial_warehouse_inventories"].shape[2] if "initial_warehouse_inventories" in ds.data and policy["name"] != "vanilla_one_store" else 0)
+    eng = FusedRollout(model, setting["problem_params"], DEV)
+    eng.materialize(F)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    pol = orc.policy_from_state_dict(policy, state, setting["problem_params"],
+                                     model.warehouse_upper_bound.cpu() if torch.is_tensor(model.warehouse_upper_bound) else None)
+    loader = DeviceBatches(ds, bs, shuffle=True, device=DEV, seed=3)
+    sim, tr = Simulator(device=DEV), Trainer(device=DEV)
+    tr.use_fused_rollout = False
+    checked = 0
+    for _epoch in range(2):
+        for batch in loader:
+            cpu = {k: v.cpu() for k, v in batch.items()}
+            with torch.no_grad():
+                ref = orc.rollout(pol, T, setting["problem_params"], cpu, obs, 0)
+                t_fused, _ = eng.run(batch, T, 0, train=False, observation_params=obs)
+                t_sim, _ = tr.simulate_batch(PolicyLoss(), sim, model, T, setting["problem_params"], batch, obs, 0, False)
+            assert abs(float(t_fused) - float(ref.total)) <= 1e-5 * abs(float(ref.total)), (checked, "fused")
+            assert abs(float(t_sim) - float(ref.total)) <= 1e-5 * abs(float(ref.total)), (checked, "simulator")
+            per = eng.per_period_rewards().sum(dim=0).cpu()
+            assert float(((per - ref.per_period.sum(dim=0)).abs() / ref.per_period.sum(dim=0).abs().clamp_min(1e-9)).max()) <= 1e-5
+            checked += 1
+            del batch  # let the allocator recycle the batch's storage for the next one
+    assert checked == 6
