@@ -311,6 +311,15 @@ int nic_mlp3_fwd(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float
  * adds it back to the sources with nic_segment_sum over the transposed maps).  dX may be NULL. */
 int nic_mlp3_bwd(const NicMlp3Desc* d, const float* dY, const float* Y, const float* H1, const float* H2, float* dZ3,
                  float* dZ2, float* dZ1, float* dX, void* stream);
+/* The same backward WITHOUT any stored history: the kernel gathers the inputs again, recomputes the two hidden layers, and
+ * contracts the weight gradients itself — each wavefront keeps dW1 / dW2 / dW3 (+ bias columns) in registers across all the
+ * (entity, 32-scenario) chunks it walks (operands transposed through LDS into the MFMA's row-owner layout) and adds them to
+ * ITS slot of the slabs at the end:  slab_l[slot][n][k] += ..., column K_l = bias gradient, lds_l = slab row length.
+ * nic_mlp3_bwd_fused_slots() slots per launch; slabs persist across the periods of a rollout and are reduced once with
+ * nic_wgrad_reduce.  Needs d->weights AND d->weights_t.  HBM traffic per column: the K gathered input rows, dY / Y, dX. */
+int nic_mlp3_bwd_fused_slots(void);
+int nic_mlp3_bwd_fused(const NicMlp3Desc* d, const float* dY, const float* Y, float* dX, float* slab1, int64_t lds1,
+                       float* slab2, int64_t lds2, float* slab3, int64_t lds3, void* stream);
 /* dst[r][n][b] (+)= dst_scale[n] * sum_{p in [offsets[n], offsets[n+1])} src[r][items[p]][b] for r < R, in item order
  * (deterministic: no atomics).  Forward: message aggregation over a node's incident edges (:1229-1269, with the
  * 1/sqrt(degree) normalisation :1275-1296 as dst_scale); backward: the adjoint of every gather above. */

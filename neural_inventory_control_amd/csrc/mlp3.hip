@@ -233,6 +233,231 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(3, 
     }
 }
 
+// ---- history-free backward: gather again, recompute the hidden layers, contract the weight gradients in the kernel -------------
+// Layouts: the MLP chain runs "column-owner" (lane (h, c) holds rows crow(r, h) of column c: MFMA C layout / B operand); a weight
+// gradient dW[i][k] = sum_c dz[i][c] act[k][c] contracts over the COLUMNS, so both of its operands must be "row-owner" (lane
+// (hh, row) holds columns 2s + hh).  Each 32 x 32 tile changes layout through a wave-private LDS tile with 33-word rows
+// (conflict-free both ways); 5 + KG tiles per chunk.  The dW accumulators (16 registers per 32 x 32 block) stay in registers over
+// all chunks a wavefront walks.
+constexpr int kFusedWaves = 4;     // wavefronts per workgroup
+constexpr int kFusedBlocks = 512;  // persistent workgroups (two per CU): one slab slot per wavefront
+constexpr int kTile = 32 * 33;
+
+__device__ __forceinline__ void to_row_owner(float* tile, const float (&v)[16], float (&out)[16], int h, int j) {
+    // in: lane (h, c = j) holds rows crow(r, h) of column c;  out: lane (hh = h, row = j) holds columns 2s + hh of its row
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[crow(r, h) * 33 + j] = v[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) out[s2] = tile[j * 33 + 2 * s2 + h];
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int KG>
+__global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp3_bwd_fused_kernel(
+    NicMlp3Desc d, const float* __restrict__ wt, const float* __restrict__ w, const float* __restrict__ dY,
+    const float* __restrict__ Yo, float* __restrict__ dX, float* __restrict__ slab1, int64_t lds1, float* __restrict__ slab2,
+    int64_t lds2, float* __restrict__ slab3, int64_t lds3) {
+    __shared__ float tiles[kFusedWaves * kTile];
+    // every weight fragment both directions need, staged once per workgroup (with one wavefront per SIMD reading them from L2
+    // next to each MFMA, every MFMA waited ~0.5 us for its operand: 1 ms per launch)
+    __shared__ float sw1t[32 * KG * 32], sw2t[32 * 32], sW1[32 * 32 * KG], sW2[32 * 32], sW3[32 * 32], sb[64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5, i = j;
+    float* tile = tiles + wv * kTile;
+    const int K = d.K;
+    const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;
+    {
+        const float* T = wt;                     // [W1^T K x 32][b1][W2^T][b2]...
+        const float* T2 = T + K * 32 + 32;
+        const float* N1 = w;                     // natural [W1 32 x K][b1][W2][b2][W3 n_out x 32]
+        const float* N2 = N1 + 32 * K + 32;
+        const float* N3 = N2 + 32 * 32 + 32;
+        for (int idx = threadIdx.x; idx < 32 * KG * 32; idx += 64 * kFusedWaves) {
+            sw1t[idx] = idx < K * 32 ? T[idx] : 0.f;
+            const int n = idx / (32 * KG), k = idx % (32 * KG);
+            sW1[idx] = k < K ? N1[n * K + k] : 0.f;
+        }
+        for (int idx = threadIdx.x; idx < 32 * 32; idx += 64 * kFusedWaves) {
+            sw2t[idx] = T2[idx];
+            sW2[idx] = N2[idx];
+            sW3[idx] = (idx >> 5) < d.n_out ? N3[idx] : 0.f;
+        }
+        if (threadIdx.x < 32) {
+            sb[threadIdx.x] = T[K * 32 + threadIdx.x];
+            sb[32 + threadIdx.x] = T2[32 * 32 + threadIdx.x];
+        }
+    }
+    __syncthreads();
+    const float* w1t_ = sw1t;
+    const float* b1_ = sb;
+    const float* w2t_ = sw2t;
+    const float* b2_ = sb + 32;
+    const float* W1_ = sW1;
+    const float* W2_ = sW2;
+    const float* W3_ = sW3;
+    constexpr int KS = 16 * KG;                  // first-layer MFMA steps (rows 2s + h), K <= 32 * KG
+
+    f32x16 g1[KG], g2, g3;                       // dW1 (KG column blocks), dW2, dW3: rows crow(r, h), column = lane j
+    float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f;       // bias gradients of row i = j (row-owner sums)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        g2[r] = 0.f;
+        g3[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) g1[g][r] = 0.f;
+    }
+    const int chunks = (d.n_scenarios + 31) / 32;
+    const int n_items = d.n_entities * chunks;
+    const int wave_id = blockIdx.x * kFusedWaves + wv, n_waves = gridDim.x * kFusedWaves;
+#pragma unroll 1
+    for (int item = wave_id; item < n_items; item += n_waves) {
+        const int e = item / chunks, ch = item - e * chunks;
+        const int64_t b_raw = (int64_t)ch * 32 + j;
+        const bool live = b_raw < d.n_scenarios;
+        const int64_t b = live ? b_raw : 0;
+        const int64_t col = (int64_t)e * d.ldb + b;
+        const SegRegs segs = resolve_segments(d, e);
+        // The weights are the same for every item, so the compiler would hoist all ~180 fragment loads out of this loop into
+        // registers (512 VGPRs + scratch, one wavefront per SIMD).  An offset it cannot see through keeps each load next to
+        // its MFMA (they hit L1 / L2), and the kernel inside 256 VGPRs.
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const float* w1t = w1t_ + opaque;
+        const float* b1 = b1_ + opaque;
+        const float* w2t = w2t_ + opaque;
+        const float* b2 = b2_ + opaque;
+        const float* W1 = W1_ + opaque;
+        const float* W2 = W2_ + opaque;
+        const float* W3 = W3_ + opaque;
+        // gather the inputs (B-operand layout: lane (h, c) holds row 2s + h) and recompute the hidden layers
+        // (the inputs are NOT kept in registers until the dW1 contraction at the end of the item - 48 VGPRs that pushed the
+        // kernel into scratch; they are gathered a second time there, from L2)
+        auto gather = [&](int s) -> float {
+            const RowRef r0 = input_row(segs, 2 * s), r1 = input_row(segs, 2 * s + 1);
+            const float* p = h ? r1.p : r0.p;
+            const int64_t scn = h ? r1.scn : r0.scn;
+            return p ? p[b * scn] : 0.f;
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b1[crow(r, h)];
+#pragma unroll 2
+        for (int s = 0; s < KS; ++s) {  // (rolled: unrolled, all 48 row pointers and loads are hoisted to the top)
+            const int k = 2 * s + h;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1t[k * 32 + i], gather(s), acc, 0, 0, 0);
+        }
+        float h1[16], h2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1[r] = nic::elu1(acc[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b2[crow(r, h)];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2t[crow(s, h) * 32 + i], h1[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h2[r] = nic::elu1(acc[r]);
+        // output layer: dz3 = dY * act'(y)
+        float dz[16], at[16], bt[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, h), rr = row < d.n_out ? row : 0;
+            const float gy = dY[(int64_t)rr * ent_ld + col], yo = Yo[(int64_t)rr * ent_ld + col];
+            dz[r] = (row < d.n_out && live) ? gy * out_act_grad(d.out_act, yo) : 0.f;
+        }
+        to_row_owner(tile, dz, at, h, j);
+        to_row_owner(tile, h2, bt, h, j);
+        {
+            float sb = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                g3 = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], bt[s], g3, 0, 0, 0);
+                sb += at[s];
+            }
+            gb3 += sb + __shfl_xor(sb, 32);
+        }
+        // dH2 = W3^T dz3 -> dz2
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W3[crow(s, h) * 32 + i], dz[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz[r] = acc[r] * nic::elu1_grad_from_out(h2[r]);
+        to_row_owner(tile, dz, at, h, j);
+        to_row_owner(tile, h1, bt, h, j);
+        {
+            float sb = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                g2 = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], bt[s], g2, 0, 0, 0);
+                sb += at[s];
+            }
+            gb2 += sb + __shfl_xor(sb, 32);
+        }
+        // dH1 = W2^T dz2 -> dz1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[crow(s, h) * 32 + i], dz[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz[r] = acc[r] * nic::elu1_grad_from_out(h1[r]);
+        to_row_owner(tile, dz, at, h, j);
+        {
+            float sb = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) sb += at[s];
+            gb1 += sb + __shfl_xor(sb, 32);
+        }
+        // dW1 block g: the gathered inputs of rows 32g .. 32g+31, from the B-operand layout (row 2s + h) to row-owner
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+#pragma unroll 4
+            for (int u = 0; u < 16; ++u) tile[(2 * u + h) * 33 + j] = gather(16 * g + u);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) bt[s2] = tile[j * 33 + 2 * s2 + h];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) g1[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], bt[s], g1[g], 0, 0, 0);
+        }
+        // dX = W1^T dz1
+        if (dX) {
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[crow(s, h) * 32 * KG + 32 * g + i], dz[s], acc, 0, 0, 0);
+                if (live) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = 32 * g + crow(r, h);
+                        if (k < K) dX[(int64_t)k * ent_ld + col] = acc[r];
+                    }
+                }
+            }
+        }
+    }
+    // this wavefront's slab slot: dW[n = crow(r, h)][k = 32g + j] (+)=, bias column K (row-owner sums: lane (0, i) has row i)
+    float* s1 = slab1 + (int64_t)wave_id * 32 * lds1;
+    float* s2 = slab2 + (int64_t)wave_id * 32 * lds2;
+    float* s3 = slab3 + (int64_t)wave_id * d.n_out * lds3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = crow(r, h);
+#pragma unroll
+        for (int g = 0; g < KG; ++g)
+            if (32 * g + j < K) s1[(int64_t)n * lds1 + 32 * g + j] += g1[g][r];
+        s2[(int64_t)n * lds2 + j] += g2[r];
+        if (n < d.n_out) s3[(int64_t)n * lds3 + j] += g3[r];
+    }
+    if (h == 0) {
+        s1[(int64_t)i * lds1 + K] += gb1;
+        s2[(int64_t)i * lds2 + 32] += gb2;
+        if (i < d.n_out) s3[(int64_t)i * lds3 + 32] += gb3;
+    }
+}
+
 __global__ void segment_sum_kernel(float* __restrict__ dst, int64_t dst_rs, const float* __restrict__ src, int64_t src_rs,
                                    const int32_t* __restrict__ offsets, const int32_t* __restrict__ items,
                                    const float* __restrict__ dst_scale, int R, int B, int64_t ldb, int accumulate) {
@@ -302,6 +527,28 @@ int nic_mlp3_bwd(const NicMlp3Desc* d, const float* dY, const float* Y, const fl
     else NIC_MLP3_BWD(3);
 #undef NIC_MLP3_BWD
     return nic::check_launch("nic_mlp3_bwd");
+}
+
+int nic_mlp3_bwd_fused_slots(void) { return kFusedBlocks * kFusedWaves; }
+
+int nic_mlp3_bwd_fused(const NicMlp3Desc* d, const float* dY, const float* Y, float* dX, float* slab1, int64_t lds1, float* slab2,
+                       int64_t lds2, float* slab3, int64_t lds3, void* stream) {
+    if (int e = validate(d, "nic_mlp3_bwd_fused")) return e;
+    NIC_REQUIRE(dY && Y && slab1 && slab2 && slab3, "nic_mlp3_bwd_fused: null buffer");
+    NIC_REQUIRE(d->weights_t, "nic_mlp3_bwd_fused: weights_t (the pre-transposed weight copy) is required");
+    NIC_REQUIRE(lds1 >= d->K + 1 && lds2 >= 33 && lds3 >= 33, "nic_mlp3_bwd_fused: slab rows too short");
+    const dim3 grid(kFusedBlocks), block(64 * kFusedWaves);
+    hipStream_t s = nic::as_stream(stream);
+    const int kg = (d->K + 31) / 32;
+    nic::note_kernelf("mlp3_bwd_fused_kernel<%d>", kg);
+#define NIC_MLP3_BF(KG)                                                                                                      \
+    hipLaunchKernelGGL(mlp3_bwd_fused_kernel<KG>, grid, block, 0, s, *d, d->weights_t, d->weights, dY, Y, dX, slab1, lds1, slab2, \
+                       lds2, slab3, lds3)
+    if (kg == 1) NIC_MLP3_BF(1);
+    else if (kg == 2) NIC_MLP3_BF(2);
+    else NIC_MLP3_BF(3);
+#undef NIC_MLP3_BF
+    return nic::check_launch("nic_mlp3_bwd_fused");
 }
 
 int nic_segment_sum(float* dst, int64_t dst_row_stride, const float* src, int64_t src_row_stride, const int32_t* offsets,

@@ -458,6 +458,21 @@ def test_mlp3_fwd_bwd_with_gathered_segments(K_rows, n_out, act, B):
         gz2, in2 = gz[:, :, :B].reshape(gz.shape[0], -1).double().cpu(), inp[:, :, :B].reshape(inp.shape[0], -1).double().cpu()
         torch.testing.assert_close(gz2 @ in2.t(), w.grad, rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(gz2.sum(dim=1), b_.grad, rtol=1e-4, atol=1e-5)
+    # the history-free backward (re-gather, recompute, in-kernel weight gradients): same dX, same dW / db after the slab reduce;
+    # slabs accumulate over launches (two launches = twice the gradient)
+    slots = ops.mlp3_bwd_fused_slots()
+    slabs = [torch.zeros(slots, n, (k + 1 + 3) // 4 * 4, device=dev) for n, k in dims]
+    dX2 = z(K)
+    for _ in range(2):
+        ops.mlp3_bwd_fused(desc, gY.to(dev), Y, dX2, slabs)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dX2[:, :, :B].cpu().double(), as_rows(x64.grad, K), rtol=1e-4, atol=1e-5)
+    for sl, (n, k), (w, b_) in zip(slabs, dims, W64):
+        gw, gb = torch.zeros(n, k, device=dev), torch.zeros(n, device=dev)
+        ops.wgrad_reduce(sl, gw, gb, k, 0.5)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(gw.cpu().double(), w.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(gb.cpu().double(), b_.grad, rtol=1e-4, atol=1e-5)
 
 
 def test_segment_sum_forward_aggregation_and_gather_adjoint():

@@ -922,8 +922,9 @@ def test_closed_form_multi_store_and_training():
 GNN_CASES = ["f1_one_warehouse_gnn", "f1_one_warehouse_16_gnn"]
 
 
+@pytest.mark.parametrize("fused_bwd", [True, False])
 @pytest.mark.parametrize("name", GNN_CASES)
-def test_gnn_fused_rollout_matches_reference(name):
+def test_gnn_fused_rollout_matches_reference(name, fused_bwd):
     """`GnnRollout` (five fused gather-MLP launches per period, segment-sum aggregation, manual backward sweep) against the
     reference's golden vectors: per-period rewards, per-scenario cost, final state and d(mean_loss)/d(theta) of all 30 tensors."""
     from neural_inventory_control_amd.gnn_rollout import GnnRollout
@@ -932,6 +933,7 @@ def test_gnn_fused_rollout_matches_reference(name):
     model = _model(g, c)
     assert GnnRollout.supports(model, c["problem_params"])
     eng = GnnRollout(model, c["problem_params"], DEV)
+    eng.fused_bwd = fused_bwd  # history-free backward with in-kernel weight gradients / stored activations + GEMMs
     data = {k: v.to(DEV) for k, v in g.data.items()}
     Dn = max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4
     eng.materialize(Dn)
