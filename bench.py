@@ -288,7 +288,8 @@ def main():
     if args.graph and eng is not None and not closed_form:
         eng.use_graph = True
         args.no_kernel_timing = True
-    reducer = parallel.GradientAllReducer.get(model) if world > 1 else None
+    sharded = parallel.active()  # a process group exists (N ranks, or one rank under NIC_DIST_FORCE_INIT=1)
+    reducer = parallel.GradientAllReducer.get(model) if sharded else None
     global_b = n * world
     grad_scale = 1.0 / (global_b * T * S)
 
@@ -358,7 +359,7 @@ def main():
     if not args.no_kernel_timing:
         stride = args.timing_stride or (1 if (closed_form or (not gnn and eng.small is not None)) else 10)
         timer = eng.timer = KernelTimer(stride=stride)
-    if world > 1:
+    if sharded:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -366,10 +367,10 @@ def main():
     for _ in range(args.steps):
         last = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax)
@@ -384,7 +385,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc + ("; evaluation pass = forward rollout only" + (", discrete allocation" if discrete else "")
                                            if args.eval else
-                                           "; training step = rollout fwd + bwd + Adam" + (" + RCCL grad all-reduce" if world > 1 else "")),
+                                           "; training step = rollout fwd + bwd + Adam" + (" + RCCL grad all-reduce" if sharded else "")),
                        "name": args.workload, "scenarios_per_gpu": n, "global_scenarios": global_b, "stores": S,
                        "periods": T, "parallelism": f"scenario-sharded dp{world}",
                        "route": ("generic (Simulator.step + autograd)" if eng is None else
@@ -434,7 +435,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "scenario-steps/s", "cores": None, "host_cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         torch.distributed.destroy_process_group()
 
 

@@ -254,7 +254,7 @@ class Scenario:
             return demands.float().mean(dim=2).mean(dim=0).cpu()
         from . import parallel
         part = self.demands_soa[:, :, :self.num_samples].double().sum(dim=(0, 2))
-        if self.num_total != self.num_samples:
+        if self.num_total != self.num_samples or parallel.active():
             part = parallel.all_reduce_sum(part)
         return (part / float(self.num_total * self.periods)).float().cpu()
 

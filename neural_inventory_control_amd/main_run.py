@@ -83,7 +83,7 @@ def build(config_setting, config_hyperparams, device, rank=0, world_size=1):
                     "test": loader(test_set, "test", False)}
     model = NeuralNetworkCreator().create_neural_network(test_scenario, nn_params, device=device)
     simulator = Simulator(device=device)
-    if world_size > 1:
+    if world_size > 1 or parallel.active():
         # replicas must start from identical parameters: materialise the lazy layers with one throw-away forward, then
         # take rank 0's (only gradients are all-reduced afterwards)
         materialize_policy(model, simulator, train_set, problem_params, observation_params,

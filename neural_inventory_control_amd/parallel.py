@@ -26,15 +26,25 @@ def rank():
     return dist.get_rank() if initialized() else 0
 
 
+def active():
+    """True when the collectives of a sharded job must run: a process group exists.  (A group of ONE rank counts - that is
+    how the RCCL code path is exercised on a single-GPU box, NIC_DIST_FORCE_INIT=1.)"""
+    return initialized()
+
+
 def init_from_env(backend=None):
-    """torchrun-style init (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Returns (rank, world, device)."""
+    """torchrun-style init (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Returns (rank, world, device).
+    NIC_DIST_FORCE_INIT=1 creates the process group even for WORLD_SIZE = 1, so that every collective of the sharded path
+    (gradient all-reduce, parameter broadcast, global demand mean, barriers) really goes through RCCL with one rank."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-    if world > 1 and not initialized():
+    if (world > 1 or os.environ.get("NIC_DIST_FORCE_INIT") == "1") and not initialized():
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or os.environ.get("NIC_DIST_BACKEND")  # e.g. gloo: two ranks sharing ONE GPU in tests
@@ -72,8 +82,8 @@ def _collective(fn, t):
 
 
 def all_reduce_sum(t):
-    """SUM all-reduce of a small tensor over the ranks, in place on a contiguous copy (identity in a single process)."""
-    if world_size() == 1:
+    """SUM all-reduce of a small tensor over the ranks, in place on a contiguous copy (identity without a process group)."""
+    if not active():
         return t
     t = t.contiguous()
     return _collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM), t)
@@ -83,7 +93,7 @@ def broadcast_model(model, src=0):
     """Every rank starts from rank `src`'s parameters, buffers and order upper bound (lazy layers must be materialised
     first).  Only gradients are all-reduced afterwards, so replicas that start equal stay equal; without this, equality
     would rest on every rank having drawn identical initial weights from identical RNG states."""
-    if world_size() == 1:
+    if not active():
         return
     tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
     ub = getattr(model, "warehouse_upper_bound", None)
@@ -95,7 +105,7 @@ def broadcast_model(model, src=0):
 
 def parameters_in_sync(model):
     """True if every rank holds the same parameters: float64 (sum, sum of squares) per rank, MIN and MAX over ranks equal."""
-    if world_size() == 1:
+    if not active():
         return True
     ps = [p.detach().double() for p in model.parameters()]
     mine = torch.stack([sum(p.sum() for p in ps), sum((p * p).sum() for p in ps)])
@@ -106,7 +116,7 @@ def parameters_in_sync(model):
 
 
 def all_reduce_scalars(*scalars):
-    if world_size() == 1:
+    if not active():
         return scalars
     buf = torch.stack([s.detach().float().reshape(()) for s in scalars])
     buf = all_reduce_sum(buf)
@@ -159,7 +169,7 @@ class GradientAllReducer:
             torch._foreach_copy_(dst, src)
         if scalars:
             self.tail.copy_(torch.stack([s.detach().float().reshape(()) for s in scalars]))
-        if world_size() > 1:
+        if active():
             _collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM), self.flat)
         back_dst, back_src = [], []
         for p, v in zip(params, self.views):

@@ -108,6 +108,7 @@ class Trainer:
         total_samples = len(data_loader.dataset)
         tracked = periods - ignore_periods
         world = parallel.world_size()
+        sharded = parallel.active()  # a process group exists (also with one rank): run the step's collective
         with torch.no_grad() if not train else torch.enable_grad():
             for data_batch in data_loader:
                 data_batch = self.move_batch_to_device(data_batch)
@@ -125,12 +126,12 @@ class Trainer:
                     # (and adds the step's GLOBAL totals, so that every rank reports - and early-stops on - the same losses)
                     zero = torch.zeros((), device=self.device)
                     tot, rep = zero, zero
-                    if train and model.trainable and world > 1:
+                    if train and model.trainable and sharded:
                         tot, rep = parallel.GradientAllReducer.get(model).all_reduce(zero, zero)
                         if getattr(model, "gradient_clipping_norm_value", None) is not None:
                             torch.nn.utils.clip_grad_norm_(model.parameters(), model.gradient_clipping_norm_value)
                         optimizer.step()
-                    elif world > 1:
+                    elif sharded:
                         tot, rep = parallel.all_reduce_scalars(zero, zero)
                     epoch_loss += tot.detach()
                     epoch_report += rep.detach()
@@ -151,13 +152,13 @@ class Trainer:
                     if not self._fused_grads_ready:
                         mean_loss = total_reward / (global_batch * periods * problem_params["n_stores"])
                         mean_loss.backward()
-                    if world > 1:
+                    if sharded:
                         total_reward, reward_to_report = parallel.GradientAllReducer.get(model).all_reduce(
                             total_reward.detach(), reward_to_report.detach())
                     if getattr(model, "gradient_clipping_norm_value", None) is not None:
                         torch.nn.utils.clip_grad_norm_(model.parameters(), model.gradient_clipping_norm_value)
                     optimizer.step()
-                elif world > 1:
+                elif sharded:
                     total_reward, reward_to_report = parallel.all_reduce_scalars(total_reward.detach(),
                                                                                  reward_to_report.detach())
                 epoch_loss += total_reward.detach()

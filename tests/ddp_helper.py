@@ -30,4 +30,5 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     loss = main_run.run("train", setting, hyper)
     if parallel.rank() == 0:
-        print("DDP_RESULT " + json.dumps({"world": parallel.world_size(), "test_loss": loss}))
+        print("DDP_RESULT " + json.dumps({"world": parallel.world_size(), "test_loss": loss,
+                                           "backend": torch.distributed.get_backend() if parallel.initialized() else None}))

@@ -53,3 +53,31 @@ def test_sharded_device_scenarios_equal_single_process(tmp_path, name, n_total, 
     for k, v in whole.items():
         cat = torch.cat([p[k] for p in parts], dim=0)
         assert torch.equal(cat, v), k
+
+
+def test_training_over_a_one_rank_rccl_group_equals_no_group():
+    """RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so the test box cannot run a 2-rank nccl job; what it CAN
+    run is the whole sharded code path - parameter broadcast, global demand mean, the flat gradient all-reduce, barriers -
+    over a ONE-rank RCCL group (NIC_DIST_FORCE_INIT=1).  Same numbers as without a group, and RCCL really was the backend."""
+    helper = os.path.join(HERE, "ddp_helper.py")
+    single = _run([sys.executable, helper])
+    forced = _run([sys.executable, helper], {"NIC_DIST_FORCE_INIT": "1", "MASTER_PORT": "29553"})
+    assert forced["backend"] == "nccl" and single["backend"] is None
+    assert abs(single["test_loss"] - forced["test_loss"]) <= 1e-6 * abs(single["test_loss"]), (single, forced)
+
+
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3", "base_stock", "gnn"])
+def test_bench_over_a_one_rank_rccl_group(workload):
+    """`bench.py`'s multi-GPU leg (broadcast, reducer inside the timed step, barrier + MAX-over-ranks clock) on RCCL."""
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--scenarios", "2048", "--periods", "12"]
+    outs = []
+    for extra in ({}, {"NIC_DIST_FORCE_INIT": "1", "MASTER_PORT": "29557"}):
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **extra), timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    plain, forced = outs
+    assert forced["n_gpus"] == 1 and "RCCL" in json.dumps(forced["config"]) and "RCCL" not in json.dumps(plain["config"])
+    a, b = (o["config"]["mean_cost_per_store_period"] for o in outs)
+    assert abs(a - b) <= 1e-6 * abs(a), (a, b)
