@@ -81,6 +81,9 @@ CASES = {
     "f1_one_warehouse_16_gnn": dict(
         setting="one_warehouse_lost_demand", policy="gnn", n=12, periods=6, ignore=2, torch_seed=23,
         problem_overrides={"n_stores": 16}),
+    # gnn_transshipment.yml (GNN with transshipment: True - no self loop at the warehouse, allocation ratio not capped at 1)
+    "f1_one_warehouse_gnn_transshipment": dict(
+        setting="one_warehouse_lost_demand", policy="gnn_transshipment", n=12, periods=6, ignore=2, torch_seed=42),
     # the real-data path.  Favorita weekly sales (288 products x 21 stores x 171 weeks, shipped with the reference),
     # 3 warehouses, profit objective, past-demand window (16) + days-from-christmas in the observation, period_shift 16,
     # datasets split BY PERIOD; data_driven_net = MLP over all features + proportional allocation of warehouse stock
@@ -104,6 +107,9 @@ CASES = {
     "f4_real_one_store_returns_nv": dict(
         setting="one_store_real_data_lost_demand", policy="returns_nv", n=40, periods=12, ignore=4, torch_seed=36,
         real=True, period_range="(0, 48)", one_store_from_21=True),
+    "f4_real_one_store_data_driven": dict(
+        setting="one_store_real_data_lost_demand", policy="data_driven_net", n=40, periods=12, ignore=4, torch_seed=43,
+        hidden=[32, 32], real=True, period_range="(0, 48)", one_store_from_21=True),
     "f4_real_one_store_just_in_time": dict(
         setting="one_store_real_data_lost_demand", policy="just_in_time", n=40, periods=12, ignore=4, torch_seed=37,
         real=True, period_range="(0, 48)", one_store_from_21=True),

@@ -919,7 +919,7 @@ def test_closed_form_multi_store_and_training():
 
 # ---- GNN policy: fused gather-MLP kernels over the static supply graph (gnn_rollout.py, csrc/mlp3.hip) --------------------
 
-GNN_CASES = ["f1_one_warehouse_gnn", "f1_one_warehouse_16_gnn"]
+GNN_CASES = ["f1_one_warehouse_gnn", "f1_one_warehouse_16_gnn", "f1_one_warehouse_gnn_transshipment"]
 
 
 @pytest.mark.parametrize("fused_bwd", [True, False])
