@@ -320,6 +320,14 @@ int nic_mlp3_bwd(const NicMlp3Desc* d, const float* dY, const float* Y, const fl
 int nic_mlp3_bwd_fused_slots(void);
 int nic_mlp3_bwd_fused(const NicMlp3Desc* d, const float* dY, const float* Y, float* dX, float* slab1, int64_t lds1,
                        float* slab2, int64_t lds2, float* slab3, int64_t lds3, void* stream);
+/* The backward over the STORED activations with the weight gradients contracted in the kernel (no dZ history, no separate
+ * contraction pass): reads dY / Y, X_hist / H1 / H2 (rows hist_row_stride apart, 16-byte aligned, K * hist_row_stride * 4 < 2^31),
+ * writes dX, and adds dW1 / dW2 / dW3 (+ bias columns) to slab slot = workgroup; nic_mlp3_bwd_hist_slots() slots per launch,
+ * reduced once with nic_wgrad_reduce.  HBM traffic per column: K + 64 history rows, dY / Y, dX. */
+int nic_mlp3_bwd_hist_slots(void);
+int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, const float* X_hist, const float* H1,
+                      const float* H2, float* dX, float* slab1, int64_t lds1, float* slab2, int64_t lds2, float* slab3,
+                      int64_t lds3, void* stream);
 /* dst[r][n][b] (+)= dst_scale[n] * sum_{p in [offsets[n], offsets[n+1])} src[r][items[p]][b] for r < R, in item order
  * (deterministic: no atomics).  Forward: message aggregation over a node's incident edges (:1229-1269, with the
  * 1/sqrt(degree) normalisation :1275-1296 as dst_scale); backward: the adjoint of every gather above. */

@@ -458,6 +458,264 @@ __global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_e
     }
 }
 
+// ---- backward with in-kernel weight gradients over the STORED activations ------------------------------------------------------
+// The history path above writes the three pre-activation gradients of every column (64 + n_out rows) for a later contraction
+// kernel that reads them back together with X / H1 / H2.  Here the contraction happens where dz is produced: dz changes to the
+// row-owner layout through a wave-private LDS tile (A operand), the stored activations are read a second time straight from
+// global memory in row-owner form (lane (hh, row) takes the 16 consecutive columns hh*16 .. hh*16+15 of its row: four 16-B
+// loads, the lines were just fetched by the column-owner reads), and the dW accumulators stay in registers over all the
+// (entity, chunk) items a wavefront walks.  No recomputation, no re-gather (what made mlp3_bwd_fused_kernel slow), no dz
+// history.  A workgroup's four wavefronts add their accumulators through LDS in a fixed order into ONE slab slot.
+constexpr int kHistWaves = 4;
+constexpr int kHistBlocks = 512;   // persistent workgroups (two per CU)
+
+template <int KG>
+__global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp3_bwd_hist_kernel(
+    NicMlp3Desc d, const float* __restrict__ weights, const float* __restrict__ dY, const float* __restrict__ Yo,
+    const float* __restrict__ Xh, const float* __restrict__ H1, const float* __restrict__ H2, float* __restrict__ dX,
+    float* __restrict__ slab1, int64_t lds1, float* __restrict__ slab2, int64_t lds2, float* __restrict__ slab3, int64_t lds3) {
+    __shared__ float sW[32 * 32 * (KG + 2)];            // W1 [32][32*KG] | W2 [32][32] | W3 [32][32]; reused for the reduction
+    __shared__ float tiles[kHistWaves * kTile];
+    __shared__ float sbias[3 * 32];
+    float* const sW1 = sW;
+    float* const sW2 = sW + 32 * 32 * KG;
+    float* const sW3 = sW2 + 32 * 32;
+    const int K = d.K;
+    {
+        const float* W1 = weights;
+        const float* W2 = W1 + 32 * K + 32;
+        const float* W3 = W2 + 32 * 32 + 32;
+        for (int idx = threadIdx.x; idx < 32 * 32 * KG; idx += 64 * kHistWaves) {
+            const int n = idx / (32 * KG), k = idx % (32 * KG);
+            sW1[idx] = k < K ? W1[n * K + k] : 0.f;
+        }
+        for (int idx = threadIdx.x; idx < 32 * 32; idx += 64 * kHistWaves) {
+            sW2[idx] = W2[idx];
+            sW3[idx] = (idx >> 5) < d.n_out ? W3[idx] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, h = lane >> 5, i = j;
+    float* tile = tiles + wv * kTile;
+    const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;
+    const int64_t hs = d.hist_row_stride ? d.hist_row_stride : ent_ld;
+
+    f32x16 g1[KG], g2, g3;
+    float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        g2[r] = 0.f;
+        g3[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) g1[g][r] = 0.f;
+    }
+    const int chunks = (d.n_scenarios + 31) / 32;
+    const int n_items = d.n_entities * chunks;
+    const int wave_id = blockIdx.x * kHistWaves + wv, n_waves = gridDim.x * kHistWaves;
+    // Addressing: every buffer is read through a raw buffer descriptor whose base is the item's first column (wave-uniform);
+    // a lane contributes ONE 32-bit byte offset per buffer and the row of each load is a scalar offset - 64-bit per-load
+    // addresses (two VGPRs each, ~100 loads per item) were what pushed the first version into scratch.
+    auto rsrc_of = [](const float* p) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
+    };
+    auto ld1 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    };
+    // row-owner operand of a weight-gradient contraction: the 16 consecutive columns h*16 .. h*16+15 of the lane's row
+    auto row_owner = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff, float (&out)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16 * q, soff, 0));
+            out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+        }
+    };
+    // column-owner registers (rows crow(r, h) of column j) -> row-owner A operand (row j, columns h*16 + s)
+    auto transpose = [&](const float (&v)[16], float (&out)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[crow(r, h) * 33 + j] = v[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) out[s2] = tile[j * 33 + h * 16 + s2];
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int hs4 = (int)hs * 4, el4 = (int)ent_ld * 4;      // row strides in bytes (checked by the launcher to fit)
+    const int out_act = d.out_act, n_out = d.n_out;
+#pragma unroll 1
+    for (int item = wave_id; item < n_items; item += n_waves) {
+        const int e = item / chunks, ch = item - e * chunks;
+        const int64_t colbase = (int64_t)e * d.ldb + (int64_t)ch * 32;
+        const bool live = (int64_t)ch * 32 + j < d.n_scenarios;
+        const int jl = live ? j : 0;
+        const __amdgpu_buffer_rsrc_t rY = rsrc_of(Yo + colbase), rG = rsrc_of(dY + colbase), rH2 = rsrc_of(H2 + colbase),
+                                     rH1 = rsrc_of(H1 + colbase), rX = rsrc_of(Xh + colbase);
+        // column-owner offsets: row crow(r, h) = (r & 3) + 8 (r >> 2) [scalar] + 4 h [lane]
+        const int vo_h = (4 * h) * hs4 + jl * 4, vo_e = (4 * h) * el4 + jl * 4;
+        const int vo_row = j * hs4 + h * 64;                  // row-owner: row j, columns h*16 ..
+        // (see mlp3_bwd_fused_kernel: an offset the compiler cannot see through keeps the weight fragments out of registers)
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const float* W1 = sW1 + opaque;
+        const float* W2 = sW2 + opaque;
+        const float* W3 = sW3 + opaque;
+        // Software-pipelined by hand: each phase issues the loads of the NEXT phase before its own MFMA loop, and scheduling
+        // barriers keep hipcc from hoisting every load of the item to the top.
+        float gy[16], yo[16], h2[16], h1[16], dz[16], at[16], bts[2][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row_s = (r & 3) + 8 * (r >> 2);
+            // dY / Y have n_out rows: lanes whose row does not exist read row 0 of their column and are masked below
+            const int vo_y = (row_s + 4 * h < n_out) ? vo_e + row_s * el4 : jl * 4;
+            gy[r] = ld1(rG, vo_y, 0);
+            yo[r] = ld1(rY, vo_y, 0);
+            h2[r] = ld1(rH2, vo_h, row_s * hs4);
+        }
+        row_owner(rH2, vo_row, 0, bts[0]);
+        if (out_act == NIC_MLP3_ACT_ELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz[r] = (crow(r, h) < n_out && live) ? gy[r] * nic::elu1_grad_from_out(yo[r]) : 0.f;
+        } else if (out_act == NIC_MLP3_ACT_SOFTPLUS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz[r] = (crow(r, h) < n_out && live) ? gy[r] * (1.f - expf(-yo[r])) : 0.f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz[r] = (crow(r, h) < n_out && live) ? gy[r] : 0.f;
+        }
+        transpose(dz, at);
+        __builtin_amdgcn_sched_barrier(0);
+        // layer 3: dW3 += dz3 H2^T, dH2 = W3^T dz3; layer 2's operands on their way
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1[r] = ld1(rH1, vo_h, ((r & 3) + 8 * (r >> 2)) * hs4);
+        row_owner(rH1, vo_row, 0, bts[1]);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            float sb = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                g3 = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], bts[0][s], g3, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W3[crow(s, h) * 32 + i], dz[s], acc, 0, 0, 0);
+                sb += at[s];
+            }
+            gb3 += sb + __shfl_xor(sb, 32);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz[r] = acc[r] * nic::elu1_grad_from_out(h2[r]);
+        transpose(dz, at);
+        __builtin_amdgcn_sched_barrier(0);
+        // layer 2; the first block of X on its way (rows >= K of the last block: past the descriptor's reach -> zeros below)
+        if (j < K) {
+            row_owner(rX, vo_row, 0, bts[0]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bts[0][s] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            float sb = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                g2 = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], bts[1][s], g2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[crow(s, h) * 32 + i], dz[s], acc, 0, 0, 0);
+                sb += at[s];
+            }
+            gb2 += sb + __shfl_xor(sb, 32);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz[r] = acc[r] * nic::elu1_grad_from_out(h1[r]);
+        transpose(dz, at);
+        {
+            float sb = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) sb += at[s];
+            gb1 += sb + __shfl_xor(sb, 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // layer 1: dW1 block g += dz1 X[32g .. 32g+31]^T, dX block g = W1[:, 32g ..]^T dz1; block g + 1 of X on its way
+        const __amdgpu_buffer_rsrc_t rD = rsrc_of(dX ? dX + colbase : Xh);
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            if (g + 1 < KG) {
+                if (32 * (g + 1) + j < K) {
+                    row_owner(rX, vo_row, 32 * (g + 1) * hs4, bts[(g + 1) & 1]);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) bts[(g + 1) & 1][s] = 0.f;
+                }
+            }
+            if (dX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    g1[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], bts[g & 1][s], g1[g], 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[crow(s, h) * 32 * KG + 32 * g + i], dz[s], acc, 0, 0, 0);
+                }
+                if (live) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k_s = 32 * g + (r & 3) + 8 * (r >> 2);
+                        const float v = acc[r];   // (bit_cast straight from the vector element stored element 0 sixteen times)
+                        if (k_s + 4 * h < K) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rD, vo_e, k_s * el4, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) g1[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], bts[g & 1][s], g1[g], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the four wavefronts add their accumulators in wave order through LDS (over the weight staging area), then the workgroup
+    // adds the sum to its slab slot
+    __syncthreads();
+    float* const r1 = sW;
+    float* const r2 = sW + 32 * 32 * KG;
+    float* const r3 = r2 + 32 * 32;
+#pragma unroll 1
+    for (int turn = 0; turn < kHistWaves; ++turn) {
+        if (wv == turn) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = crow(r, h);
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    float* q = r1 + n * 32 * KG + 32 * g + j;
+                    *q = turn ? *q + g1[g][r] : g1[g][r];
+                }
+                float* q2 = r2 + n * 32 + j;
+                *q2 = turn ? *q2 + g2[r] : g2[r];
+                float* q3 = r3 + n * 32 + j;
+                *q3 = turn ? *q3 + g3[r] : g3[r];
+            }
+            if (h == 0) {
+                sbias[i] = turn ? sbias[i] + gb1 : gb1;
+                sbias[32 + i] = turn ? sbias[32 + i] + gb2 : gb2;
+                sbias[64 + i] = turn ? sbias[64 + i] + gb3 : gb3;
+            }
+        }
+        __syncthreads();
+    }
+    float* s1 = slab1 + (int64_t)blockIdx.x * 32 * lds1;
+    float* s2 = slab2 + (int64_t)blockIdx.x * 32 * lds2;
+    float* s3 = slab3 + (int64_t)blockIdx.x * d.n_out * lds3;
+    for (int idx = threadIdx.x; idx < 32 * 32 * KG; idx += 64 * kHistWaves) {
+        const int n = idx / (32 * KG), k = idx % (32 * KG);
+        if (k < K) s1[(int64_t)n * lds1 + k] += r1[idx];
+    }
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 64 * kHistWaves) {
+        const int n = idx >> 5, k = idx & 31;
+        s2[(int64_t)n * lds2 + k] += r2[idx];
+        if (n < d.n_out) s3[(int64_t)n * lds3 + k] += r3[idx];
+    }
+    if (threadIdx.x < 32) {
+        s1[(int64_t)threadIdx.x * lds1 + K] += sbias[threadIdx.x];
+        s2[(int64_t)threadIdx.x * lds2 + 32] += sbias[32 + threadIdx.x];
+        if ((int)threadIdx.x < d.n_out) s3[(int64_t)threadIdx.x * lds3 + 32] += sbias[64 + threadIdx.x];
+    }
+}
+
 __global__ void segment_sum_kernel(float* __restrict__ dst, int64_t dst_rs, const float* __restrict__ src, int64_t src_rs,
                                    const int32_t* __restrict__ offsets, const int32_t* __restrict__ items,
                                    const float* __restrict__ dst_scale, int R, int B, int64_t ldb, int accumulate) {
@@ -549,6 +807,33 @@ int nic_mlp3_bwd_fused(const NicMlp3Desc* d, const float* dY, const float* Y, fl
     else NIC_MLP3_BF(3);
 #undef NIC_MLP3_BF
     return nic::check_launch("nic_mlp3_bwd_fused");
+}
+
+int nic_mlp3_bwd_hist_slots(void) { return kHistBlocks; }
+
+int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, const float* X_hist, const float* H1, const float* H2,
+                      float* dX, float* slab1, int64_t lds1, float* slab2, int64_t lds2, float* slab3, int64_t lds3, void* stream) {
+    if (int e = validate(d, "nic_mlp3_bwd_hist")) return e;
+    NIC_REQUIRE(dY && Y && X_hist && H1 && H2 && slab1 && slab2 && slab3, "nic_mlp3_bwd_hist: null buffer");
+    NIC_REQUIRE(lds1 >= d->K + 1 && lds2 >= 33 && lds3 >= 33, "nic_mlp3_bwd_hist: slab rows too short");
+    const int64_t hs = d->hist_row_stride ? d->hist_row_stride : (int64_t)d->n_entities * d->ldb;
+    NIC_REQUIRE(hs % 4 == 0 && (reinterpret_cast<uintptr_t>(X_hist) & 15) == 0 && (reinterpret_cast<uintptr_t>(H1) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(H2) & 15) == 0,
+                "nic_mlp3_bwd_hist: history rows must be 16-byte aligned");
+    NIC_REQUIRE((int64_t)(d->K + 31) / 32 * 32 * hs * 4 < (1ll << 31) && (int64_t)(d->K + 32) * d->n_entities * d->ldb * 4 < (1ll << 31),
+                "nic_mlp3_bwd_hist: a buffer's rows must span less than 2 GiB (32-bit row offsets)");
+    const dim3 grid(kHistBlocks), block(64 * kHistWaves);
+    hipStream_t s = nic::as_stream(stream);
+    const int kg = (d->K + 31) / 32;
+    nic::note_kernelf("mlp3_bwd_hist_kernel<%d>", kg);
+#define NIC_MLP3_BH(KG)                                                                                                       \
+    hipLaunchKernelGGL(mlp3_bwd_hist_kernel<KG>, grid, block, 0, s, *d, d->weights, dY, Y, X_hist, H1, H2, dX, slab1, lds1, slab2, \
+                       lds2, slab3, lds3)
+    if (kg == 1) NIC_MLP3_BH(1);
+    else if (kg == 2) NIC_MLP3_BH(2);
+    else NIC_MLP3_BH(3);
+#undef NIC_MLP3_BH
+    return nic::check_launch("nic_mlp3_bwd_hist");
 }
 
 int nic_segment_sum(float* dst, int64_t dst_row_stride, const float* src, int64_t src_row_stride, const int32_t* offsets,

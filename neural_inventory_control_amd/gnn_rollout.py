@@ -90,19 +90,30 @@ class GraphPlan:
 class _Mlp:
     """Packed weights, gradient slabs and per-period history of one of the policy's five MLPs."""
 
-    def __init__(self, name, linears, K, n_out, out_act, n_ent, ld, T, P, device, train, fused_bwd=True):
+    def __init__(self, name, linears, K, n_out, out_act, n_ent, ld, T, P, device, train, mode="hist"):
         self.name, self.linears, self.K, self.n_out, self.out_act, self.n_ent = name, linears, K, n_out, out_act, n_ent
         z = lambda *s: torch.zeros(*s, device=device)  # noqa: E731
         self.packed = z(32 * K + 32 + 32 * 32 + 32 + n_out * 32 + n_out)
         self.Y = z(T, n_out, n_ent, ld)
         self.P, self.G = P, (T + P - 1) // P
         self.hist_stride = 0
-        self.fused_bwd = bool(fused_bwd)
-        if train and fused_bwd:
+        self.mode = mode if train else None     # "hist" | "gemm" | "fused" (see GnnRollout.fused_bwd)
+        self.fused_bwd = mode == "fused"
+        dims = [(32, K), (32, 32), (n_out, 32)]
+        if train and mode == "hist":
+            # stored inputs / hidden activations, weight gradients contracted inside the backward kernel (nic_mlp3_bwd_hist):
+            # one slab slot per workgroup, accumulated over the periods
+            self.hist_stride = P * n_ent * ld
+            G = self.G
+            self.X, self.H1, self.H2 = z(G, K, P, n_ent, ld), z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld)
+            self.slabs = [z(ops.mlp3_bwd_hist_slots(), n, (k + 1 + 3) // 4 * 4) for n, k in dims]
+            self.dX = z(K, n_ent, ld)
+            self.gw = [torch.zeros_like(m.weight) for m in linears]
+            self.gb = [torch.zeros_like(m.bias) for m in linears]
+        elif train and mode == "fused":
             # history-free backward (nic_mlp3_bwd_fused): the kernel re-gathers the inputs, recomputes the hidden layers and
             # contracts the weight gradients itself; one slab slot per wavefront, accumulated over the periods
             slots = ops.mlp3_bwd_fused_slots()
-            dims = [(32, K), (32, 32), (n_out, 32)]
             self.slabs = [z(slots, n, (k + 1 + 3) // 4 * 4) for n, k in dims]
             self.dX = z(K, n_ent, ld)
             self.gw = [torch.zeros_like(m.weight) for m in linears]
@@ -115,7 +126,6 @@ class _Mlp:
             self.X, self.H1, self.H2 = z(G, K, P, n_ent, ld), z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld)
             self.dZ1, self.dZ2, self.dZ3 = z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld), z(G, n_out, P, n_ent, ld)
             self.dX = z(K, n_ent, ld)
-            dims = [(32, K), (32, 32), (n_out, 32)]
             cols = P * n_ent * ld
             self.splits = [ops.wgrad_num_splits(n, k, cols) for n, k in dims]
             self.slabs = [z(sp, n, (k + 1 + 3) // 4 * 4) for sp, (n, k) in zip(self.splits, dims)]
@@ -155,10 +165,11 @@ class GnnRollout:
             raise ValueError("GnnRollout handles the gnn.yml architecture on one-warehouse settings")
         self.model, self.problem_params, self.device = model, problem_params, torch.device(device)
         self.timer = None
-        # Backward of the MLPs: None = stored activations + weight-gradient GEMMs while the histories fit in HBM (fastest:
-        # 62 ms per 8,192 x 16 x T=50 step), else the history-free kernel (nic_mlp3_bwd_fused: re-gather, recompute, in-kernel
-        # weight gradients; no per-period buffers at all, 1.8x slower - its gathers are latency-exposed at two wavefronts per
-        # SIMD); True / False force one of them
+        # Backward of the MLPs.  None = "hist" while the stored activations fit in HBM, else the history-free kernel.
+        #   "hist"  stored inputs / hidden activations, weight gradients contracted inside the backward kernel (nic_mlp3_bwd_hist)
+        #   False   ("gemm") stored activations AND pre-activation gradients, weight gradients by nic_linear_wgrad contractions
+        #   True    ("fused") nic_mlp3_bwd_fused: re-gather, recompute, in-kernel weight gradients; no per-period buffers at
+        #           all, but its gathers are latency-exposed at two wavefronts per SIMD
         self.fused_bwd = None
         self.use_graph = False   # replay the (static) launch sequence of a rollout from a HIP graph after one eager run
         self._probs = ProblemCache()
@@ -209,17 +220,18 @@ class GnnRollout:
         ks = (self.Dn, 65, 96, 96, 32)
         ents = (N, E, N, E, E)
         P_ = max(1, min(T, (1 << 28) // (96 * E * ld)))   # periods per history row (see _Mlp)
-        fused_bwd = self.fused_bwd
-        if fused_bwd is None and train:
-            # rows of history per period: X + H1 + H2 + dZ1 + dZ2 + dZ3 of the five MLPs
-            hist_bytes = 4 * T * ld * (N * ((self.Dn + 160) + (96 + 160)) + E * ((65 + 160) + (96 + 160) + (32 + 129)))
+        mode = {None: None, True: "fused", False: "gemm", "hist": "hist", "gemm": "gemm", "fused": "fused"}[self.fused_bwd]
+        if mode is None and train:
+            # rows of history per period: X + H1 + H2 of the five MLPs
+            hist_bytes = 4 * T * ld * (N * ((self.Dn + 64) + (96 + 64)) + E * ((65 + 64) + (96 + 64) + (32 + 64)))
             free = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
                     if dev.type == "cuda" else 0)
-            fused_bwd = hist_bytes > 0.6 * free
-        self._fused_bwd_now = bool(fused_bwd)
+            mode = "fused" if hist_bytes > 0.6 * free else "hist"
+        self._mode_now = mode or "hist"
+        self._fused_bwd_now = self._mode_now == "fused"
         self.mlp = {name: _Mlp(name, self._linears(name), k, 1 if name == "output" else 32,
                                A.NIC_MLP3_ACT_SOFTPLUS if name == "output" else A.NIC_MLP3_ACT_ELU, ne, ld, T, P_, dev, train,
-                               self._fused_bwd_now)
+                               self._mode_now)
                     for name, k, ne in zip(MODULES, ks, ents)}
         self._graphs, self._eager_runs = {}, 0
         self.agg_in, self.agg_out = z(T, 32, N, ld), z(T, 32, N, ld)
@@ -340,7 +352,7 @@ class GnnRollout:
     def _weight_gradients(self, T, prob):
         """dW = sum over (period, entity, scenario) of dZ X^T per layer: one contraction per history group (P periods each)."""
         for m in self.mlp.values():
-            for g in range(0 if m.fused_bwd else m.G):
+            for g in range(m.G if m.mode == "gemm" else 0):
                 n_per = min(m.P, T - g * m.P)
                 cols = n_per * m.n_ent * prob.ldb
                 for i, (dz, x) in enumerate(((m.dZ1, m.X), (m.dZ2, m.H1), (m.dZ3, m.H2))):
@@ -453,7 +465,11 @@ class GnnRollout:
         gc.store += m.dX[:prob.Ws, 1:].permute(1, 0, 2)
 
     def _mlp_bwd(self, m, t, segs, prob, dY, dX=None):
-        if m.fused_bwd:
+        if m.mode == "hist":
+            self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd_hist, self._desc(m, segs[m.name], prob), dY, m.Y[t], m.hist(m.X, t),
+                    m.hist(m.H1, t), m.hist(m.H2, t), dX if dX is not None else m.dX, m.slabs)
+            return
+        if m.mode == "fused":
             self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd_fused, self._desc(m, segs[m.name], prob), dY, m.Y[t],
                     dX if dX is not None else m.dX, m.slabs)
             return

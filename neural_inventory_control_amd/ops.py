@@ -242,6 +242,18 @@ def mlp3_bwd_fused(desc, dY, Y, dX, slabs):
                                    s3.stride(1), current_stream()))
 
 
+def mlp3_bwd_hist_slots():
+    return lib().nic_mlp3_bwd_hist_slots()
+
+
+def mlp3_bwd_hist(desc, dY, Y, X_hist, H1, H2, dX, slabs):
+    """Backward over the stored activations with in-kernel weight gradients into slabs [slots][N][lds] (3 layers)."""
+    _dev(dY)
+    s1, s2, s3 = slabs
+    check(lib().nic_mlp3_bwd_hist(desc, ptr(dY), ptr(Y), ptr(X_hist), ptr(H1), ptr(H2), ptr(dX), ptr(s1), s1.stride(1), ptr(s2),
+                                  s2.stride(1), ptr(s3), s3.stride(1), current_stream()))
+
+
 def segment_sum(dst, src, offsets, items, dst_scale=None, accumulate=False):
     """dst [R][n_dst][ldb] (+)= dst_scale[n] * sum over items[offsets[n]:offsets[n+1]] of src[R][.][ldb] rows."""
     _dev(dst)

@@ -922,7 +922,7 @@ def test_closed_form_multi_store_and_training():
 GNN_CASES = ["f1_one_warehouse_gnn", "f1_one_warehouse_16_gnn", "f1_one_warehouse_gnn_transshipment"]
 
 
-@pytest.mark.parametrize("fused_bwd", [True, False])
+@pytest.mark.parametrize("fused_bwd", [True, False, "hist"])
 @pytest.mark.parametrize("name", GNN_CASES)
 def test_gnn_fused_rollout_matches_reference(name, fused_bwd):
     """`GnnRollout` (five fused gather-MLP launches per period, segment-sum aggregation, manual backward sweep) against the
