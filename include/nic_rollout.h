@@ -323,7 +323,9 @@ int nic_mlp3_bwd_fused(const NicMlp3Desc* d, const float* dY, const float* Y, fl
 /* The backward over the STORED activations with the weight gradients contracted in the kernel (no dZ history, no separate
  * contraction pass): reads dY / Y, X_hist / H1 / H2 (rows hist_row_stride apart, 16-byte aligned, K * hist_row_stride * 4 < 2^31),
  * writes dX, and adds dW1 / dW2 / dW3 (+ bias columns) to slab slot = workgroup; nic_mlp3_bwd_hist_slots() slots per launch,
- * reduced once with nic_wgrad_reduce.  HBM traffic per column: K + 64 history rows, dY / Y, dX. */
+ * reduced once with nic_wgrad_reduce.  X_hist may be NULL: the inputs are then read again from the segments' source buffers
+ * (which must still hold what the forward read, be 16-byte aligned per row and zero in their padding columns), and the forward
+ * need not keep an X history at all.  HBM traffic per column: K input rows + 64 history rows, dY / Y, dX. */
 int nic_mlp3_bwd_hist_slots(void);
 int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, const float* X_hist, const float* H1,
                       const float* H2, float* dX, float* slab1, int64_t lds1, float* slab2, int64_t lds2, float* slab3,

@@ -538,6 +538,43 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
         for (int s2 = 0; s2 < 16; ++s2) out[s2] = tile[j * 33 + h * 16 + s2];
         __builtin_amdgcn_wave_barrier();
     };
+    // Without an X history (X_hist == NULL) the inputs are read again from the SOURCE buffers, directly in row-owner form: lane
+    // (h, j) owns input row k and resolves that row's pointer from the segment table itself (entity index wave-uniform, a few
+    // selects per segment), then takes the same 16 consecutive columns.  The sources are per-period buffers, so they still hold
+    // what the forward read; the K-row copy the forward would write and this kernel would read back is 27 % of the GNN's traffic.
+    auto gather_row_owner = [&](int k, int e, int ch, float (&out)[16]) {
+        const float* rp = nullptr;
+        int scn = 1, start = 0;
+#pragma unroll
+        for (int q = 0; q < NIC_MLP3_MAX_SEGS; ++q) {
+            if (q < d.n_segs) {
+                const NicMlp3Seg& S = d.seg[q];
+                const int ent = S.map ? S.map[e] : e;
+                const bool in = k >= start && k < start + S.n_rows;
+                const float* cand = S.base + (int64_t)ent * S.ent_stride + (int64_t)(k - start) * S.row_stride;
+                if (in) {
+                    rp = ent >= 0 ? cand : nullptr;
+                    scn = (int)S.scn_stride;
+                }
+                start += S.n_rows;
+            }
+        }
+        if (rp == nullptr) {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) out[s2] = 0.f;
+        } else if (scn) {
+            const float4* p4 = reinterpret_cast<const float4*>(rp + (int64_t)ch * 32 + h * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = p4[q];
+                out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+            }
+        } else {  // per-entity constant (an edge's lead time)
+            const float v = *rp;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) out[s2] = v;
+        }
+    };
     const int hs4 = (int)hs * 4, el4 = (int)ent_ld * 4;      // row strides in bytes (checked by the launcher to fit)
     const int out_act = d.out_act, n_out = d.n_out;
 #pragma unroll 1
@@ -547,7 +584,7 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
         const bool live = (int64_t)ch * 32 + j < d.n_scenarios;
         const int jl = live ? j : 0;
         const __amdgpu_buffer_rsrc_t rY = rsrc_of(Yo + colbase), rG = rsrc_of(dY + colbase), rH2 = rsrc_of(H2 + colbase),
-                                     rH1 = rsrc_of(H1 + colbase), rX = rsrc_of(Xh + colbase);
+                                     rH1 = rsrc_of(H1 + colbase), rX = rsrc_of(Xh ? Xh + colbase : H1);
         // column-owner offsets: row crow(r, h) = (r & 3) + 8 (r >> 2) [scalar] + 4 h [lane]
         const int vo_h = (4 * h) * hs4 + jl * 4, vo_e = (4 * h) * el4 + jl * 4;
         const int vo_row = j * hs4 + h * 64;                  // row-owner: row j, columns h*16 ..
@@ -604,11 +641,13 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
         transpose(dz, at);
         __builtin_amdgcn_sched_barrier(0);
         // layer 2; the first block of X on its way (rows >= K of the last block: past the descriptor's reach -> zeros below)
-        if (j < K) {
-            row_owner(rX, vo_row, 0, bts[0]);
-        } else {
+        if (j >= K) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) bts[0][s] = 0.f;
+        } else if (Xh) {
+            row_owner(rX, vo_row, 0, bts[0]);
+        } else {
+            gather_row_owner(j, e, ch, bts[0]);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -633,15 +672,17 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
         }
         __builtin_amdgcn_sched_barrier(0);
         // layer 1: dW1 block g += dz1 X[32g .. 32g+31]^T, dX block g = W1[:, 32g ..]^T dz1; block g + 1 of X on its way
-        const __amdgpu_buffer_rsrc_t rD = rsrc_of(dX ? dX + colbase : Xh);
+        const __amdgpu_buffer_rsrc_t rD = rsrc_of(dX ? dX + colbase : H1);
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             if (g + 1 < KG) {
-                if (32 * (g + 1) + j < K) {
-                    row_owner(rX, vo_row, 32 * (g + 1) * hs4, bts[(g + 1) & 1]);
-                } else {
+                if (32 * (g + 1) + j >= K) {
 #pragma unroll
                     for (int s = 0; s < 16; ++s) bts[(g + 1) & 1][s] = 0.f;
+                } else if (Xh) {
+                    row_owner(rX, vo_row, 32 * (g + 1) * hs4, bts[(g + 1) & 1]);
+                } else {
+                    gather_row_owner(32 * (g + 1) + j, e, ch, bts[(g + 1) & 1]);
                 }
             }
             if (dX) {
@@ -716,19 +757,40 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
     }
 }
 
+// One thread = V consecutive scenarios of one (row, destination) pair; V = 4 (16-byte accesses) when the rows allow it.
+template <int V>
 __global__ void segment_sum_kernel(float* __restrict__ dst, int64_t dst_rs, const float* __restrict__ src, int64_t src_rs,
                                    const int32_t* __restrict__ offsets, const int32_t* __restrict__ items,
                                    const float* __restrict__ dst_scale, int R, int B, int64_t ldb, int accumulate) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     const int n = blockIdx.y;
     if (b >= B) return;
     const int lo = offsets[n], hi = offsets[n + 1];
     const float sc = dst_scale ? dst_scale[n] : 1.f;
     for (int r = blockIdx.z; r < R; r += gridDim.z) {
-        float s = 0.f;
-        for (int p = lo; p < hi; ++p) s += src[(int64_t)r * src_rs + (int64_t)items[p] * ldb + b];
+        float s[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] = 0.f;
+        for (int p = lo; p < hi; ++p) {   // in item order (deterministic; the association upstream's Python loop has)
+            const float* q = src + (int64_t)r * src_rs + (int64_t)items[p] * ldb + b;
+            if (V == 4) {
+                const float4 x = *reinterpret_cast<const float4*>(q);
+                s[0] += x.x; s[1] += x.y; s[2] += x.z; s[3] += x.w;
+            } else {
+                s[0] += q[0];
+            }
+        }
         float* o = dst + (int64_t)r * dst_rs + (int64_t)n * ldb + b;
-        *o = accumulate ? *o + sc * s : sc * s;
+        if (V == 4) {
+            float4 y = accumulate ? *reinterpret_cast<const float4*>(o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            y.x = accumulate ? y.x + sc * s[0] : sc * s[0];
+            y.y = accumulate ? y.y + sc * s[1] : sc * s[1];
+            y.z = accumulate ? y.z + sc * s[2] : sc * s[2];
+            y.w = accumulate ? y.w + sc * s[3] : sc * s[3];
+            *reinterpret_cast<float4*>(o) = y;
+        } else {
+            *o = accumulate ? *o + sc * s[0] : sc * s[0];
+        }
     }
 }
 
@@ -755,7 +817,7 @@ extern "C" {
 int nic_mlp3_fwd(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float* H2, void* stream) {
     if (int e = validate(d, "nic_mlp3_fwd")) return e;
     NIC_REQUIRE(Y, "nic_mlp3_fwd: null output");
-    NIC_REQUIRE(!X_hist || (H1 && H2), "nic_mlp3_fwd: incomplete history buffers");
+    NIC_REQUIRE((!X_hist && !H1 && !H2) || (H1 && H2), "nic_mlp3_fwd: incomplete history buffers (H1 and H2 go together)");
     NIC_REQUIRE(d->weights_t, "nic_mlp3_fwd: weights_t (the pre-transposed weight copy) is required");
     const dim3 grid(nic::ceil_div(d->n_scenarios, 32), d->n_entities), block(64);
     hipStream_t s = nic::as_stream(stream);
@@ -814,7 +876,7 @@ int nic_mlp3_bwd_hist_slots(void) { return kHistBlocks; }
 int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, const float* X_hist, const float* H1, const float* H2,
                       float* dX, float* slab1, int64_t lds1, float* slab2, int64_t lds2, float* slab3, int64_t lds3, void* stream) {
     if (int e = validate(d, "nic_mlp3_bwd_hist")) return e;
-    NIC_REQUIRE(dY && Y && X_hist && H1 && H2 && slab1 && slab2 && slab3, "nic_mlp3_bwd_hist: null buffer");
+    NIC_REQUIRE(dY && Y && H1 && H2 && slab1 && slab2 && slab3, "nic_mlp3_bwd_hist: null buffer");
     NIC_REQUIRE(lds1 >= d->K + 1 && lds2 >= 33 && lds3 >= 33, "nic_mlp3_bwd_hist: slab rows too short");
     const int64_t hs = d->hist_row_stride ? d->hist_row_stride : (int64_t)d->n_entities * d->ldb;
     NIC_REQUIRE(hs % 4 == 0 && (reinterpret_cast<uintptr_t>(X_hist) & 15) == 0 && (reinterpret_cast<uintptr_t>(H1) & 15) == 0 &&
@@ -841,10 +903,22 @@ int nic_segment_sum(float* dst, int64_t dst_row_stride, const float* src, int64_
                     int32_t accumulate, void* stream) {
     NIC_REQUIRE(dst && src && offsets && items, "nic_segment_sum: null buffer");
     NIC_REQUIRE(R > 0 && n_dst > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_segment_sum: bad sizes");
-    const dim3 grid(nic::ceil_div(n_scenarios, 256), n_dst, R < 32 ? R : 32), block(256);
-    nic::note_kernel("segment_sum_kernel");
-    hipLaunchKernelGGL(segment_sum_kernel, grid, block, 0, nic::as_stream(stream), dst, dst_row_stride, src, src_row_stride,
-                       offsets, items, dst_scale, R, n_scenarios, (int64_t)ldb, accumulate);
+    // 16-byte path: rows 16-byte aligned and the scenario count padded to a multiple of 4 inside ldb (padding columns are
+    // summed too: they hold zeros / are never read back)
+    const bool vec = ldb % 4 == 0 && dst_row_stride % 4 == 0 && src_row_stride % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+                     (n_scenarios + 3) / 4 * 4 <= ldb;
+    if (vec) {
+        const dim3 grid(nic::ceil_div(nic::ceil_div(n_scenarios, 4), 256), n_dst, R < 32 ? R : 32), block(256);
+        nic::note_kernel("segment_sum_kernel<4>");
+        hipLaunchKernelGGL(segment_sum_kernel<4>, grid, block, 0, nic::as_stream(stream), dst, dst_row_stride, src, src_row_stride,
+                           offsets, items, dst_scale, R, n_scenarios, (int64_t)ldb, accumulate);
+    } else {
+        const dim3 grid(nic::ceil_div(n_scenarios, 256), n_dst, R < 32 ? R : 32), block(256);
+        nic::note_kernel("segment_sum_kernel<1>");
+        hipLaunchKernelGGL(segment_sum_kernel<1>, grid, block, 0, nic::as_stream(stream), dst, dst_row_stride, src, src_row_stride,
+                           offsets, items, dst_scale, R, n_scenarios, (int64_t)ldb, accumulate);
+    }
     return nic::check_launch("nic_segment_sum");
 }
 }

@@ -90,7 +90,7 @@ class GraphPlan:
 class _Mlp:
     """Packed weights, gradient slabs and per-period history of one of the policy's five MLPs."""
 
-    def __init__(self, name, linears, K, n_out, out_act, n_ent, ld, T, P, device, train, mode="hist"):
+    def __init__(self, name, linears, K, n_out, out_act, n_ent, ld, T, P, device, train, mode="hist", keep_inputs=True):
         self.name, self.linears, self.K, self.n_out, self.out_act, self.n_ent = name, linears, K, n_out, out_act, n_ent
         z = lambda *s: torch.zeros(*s, device=device)  # noqa: E731
         self.packed = z(32 * K + 32 + 32 * 32 + 32 + n_out * 32 + n_out)
@@ -101,11 +101,13 @@ class _Mlp:
         self.fused_bwd = mode == "fused"
         dims = [(32, K), (32, 32), (n_out, 32)]
         if train and mode == "hist":
-            # stored inputs / hidden activations, weight gradients contracted inside the backward kernel (nic_mlp3_bwd_hist):
-            # one slab slot per workgroup, accumulated over the periods
+            # stored hidden activations (and, while they fit, the gathered inputs), weight gradients contracted inside the
+            # backward kernel (nic_mlp3_bwd_hist); without an X history that kernel reads the inputs again from their per-period
+            # source buffers (1.4 % slower per step, 40 % less history).  One slab slot per workgroup, accumulated over the periods
             self.hist_stride = P * n_ent * ld
             G = self.G
-            self.X, self.H1, self.H2 = z(G, K, P, n_ent, ld), z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld)
+            self.X = z(G, K, P, n_ent, ld) if keep_inputs else None
+            self.H1, self.H2 = z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld)
             self.slabs = [z(ops.mlp3_bwd_hist_slots(), n, (k + 1 + 3) // 4 * 4) for n, k in dims]
             self.dX = z(K, n_ent, ld)
             self.gw = [torch.zeros_like(m.weight) for m in linears]
@@ -171,6 +173,7 @@ class GnnRollout:
         #   True    ("fused") nic_mlp3_bwd_fused: re-gather, recompute, in-kernel weight gradients; no per-period buffers at
         #           all, but its gathers are latency-exposed at two wavefronts per SIMD
         self.fused_bwd = None
+        self.keep_inputs = None  # "hist": None = keep the gathered inputs while they fit in HBM; False = always gather again
         self.use_graph = False   # replay the (static) launch sequence of a rollout from a HIP graph after one eager run
         self._probs = ProblemCache()
         self._key = None
@@ -193,7 +196,7 @@ class GnnRollout:
             FusedRollout.materialize(type("E", (), {"model": shim})(), k)
 
     def _setup(self, prob, data, T, train):
-        key = (prob.B, T, bool(train), prob.S, prob.Ws, prob.Ww, self.fused_bwd)
+        key = (prob.B, T, bool(train), prob.S, prob.Ws, prob.Ww, self.fused_bwd, self.keep_inputs)
         if key == self._key:
             return
         dev, ld, S = self.device, prob.ldb, prob.S
@@ -221,17 +224,20 @@ class GnnRollout:
         ents = (N, E, N, E, E)
         P_ = max(1, min(T, (1 << 28) // (96 * E * ld)))   # periods per history row (see _Mlp)
         mode = {None: None, True: "fused", False: "gemm", "hist": "hist", "gemm": "gemm", "fused": "fused"}[self.fused_bwd]
+        self._keep_inputs = True
         if mode is None and train:
-            # rows of history per period: X + H1 + H2 of the five MLPs
-            hist_bytes = 4 * T * ld * (N * ((self.Dn + 64) + (96 + 64)) + E * ((65 + 64) + (96 + 64) + (32 + 64)))
+            # rows of history per period: H1 + H2 of the five MLPs, and their gathered inputs
+            h_bytes = 4 * T * ld * 64 * (2 * N + 3 * E)
+            x_bytes = 4 * T * ld * (N * (self.Dn + 96) + E * (65 + 96 + 32))
             free = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
                     if dev.type == "cuda" else 0)
-            mode = "fused" if hist_bytes > 0.6 * free else "hist"
+            mode = "fused" if h_bytes > 0.6 * free else "hist"
+            self._keep_inputs = h_bytes + x_bytes <= 0.6 * free
         self._mode_now = mode or "hist"
         self._fused_bwd_now = self._mode_now == "fused"
         self.mlp = {name: _Mlp(name, self._linears(name), k, 1 if name == "output" else 32,
                                A.NIC_MLP3_ACT_SOFTPLUS if name == "output" else A.NIC_MLP3_ACT_ELU, ne, ld, T, P_, dev, train,
-                               self._mode_now)
+                               self._mode_now, self._keep_inputs and self.keep_inputs is not False)
                     for name, k, ne in zip(MODULES, ks, ents)}
         self._graphs, self._eager_runs = {}, 0
         self.agg_in, self.agg_out = z(T, 32, N, ld), z(T, 32, N, ld)
@@ -378,7 +384,8 @@ class GnnRollout:
 
     def _run_mlp(self, name, t, segs, prob):
         m = self.mlp[name]
-        hist = (m.hist(m.X, t), m.hist(m.H1, t), m.hist(m.H2, t)) if hasattr(m, "X") else (None, None, None)
+        hist = ((m.hist(m.X, t) if m.X is not None else None, m.hist(m.H1, t), m.hist(m.H2, t)) if hasattr(m, "H1")
+                else (None, None, None))
         self._k("mlp3_fwd_" + name, ops.mlp3_fwd, self._desc(m, segs[name], prob), m.Y[t], *hist)
 
     def _forward_period(self, t, prob, demand_soa, shift):
@@ -466,8 +473,8 @@ class GnnRollout:
 
     def _mlp_bwd(self, m, t, segs, prob, dY, dX=None):
         if m.mode == "hist":
-            self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd_hist, self._desc(m, segs[m.name], prob), dY, m.Y[t], m.hist(m.X, t),
-                    m.hist(m.H1, t), m.hist(m.H2, t), dX if dX is not None else m.dX, m.slabs)
+            self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd_hist, self._desc(m, segs[m.name], prob), dY, m.Y[t],
+                    m.hist(m.X, t) if m.X is not None else None, m.hist(m.H1, t), m.hist(m.H2, t), dX if dX is not None else m.dX, m.slabs)
             return
         if m.mode == "fused":
             self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd_fused, self._desc(m, segs[m.name], prob), dY, m.Y[t],

@@ -476,18 +476,20 @@ def test_mlp3_fwd_bwd_with_gathered_segments(K_rows, n_out, act, B):
 
 
     # the backward over the stored activations with in-kernel weight gradients (nic_mlp3_bwd_hist): same again, one slot per workgroup
-    slabs = [torch.zeros(ops.mlp3_bwd_hist_slots(), n, (k + 1 + 3) // 4 * 4, device=dev) for n, k in dims]
-    dX3 = z(K)
-    for _ in range(2):
-        ops.mlp3_bwd_hist(desc, gY.to(dev), Y, Xh, H1, H2, dX3, slabs)
-    torch.cuda.synchronize()
-    torch.testing.assert_close(dX3[:, :, :B].cpu().double(), as_rows(x64.grad, K), rtol=1e-4, atol=1e-5)
-    for sl, (n, k), (w, b_) in zip(slabs, dims, W64):
-        gw, gb = torch.zeros(n, k, device=dev), torch.zeros(n, device=dev)
-        ops.wgrad_reduce(sl, gw, gb, k, 0.5)
+    # - with the stored inputs (X history) and with the inputs read again from the segments' sources (no X history)
+    for x_hist in (Xh, None):
+        slabs = [torch.zeros(ops.mlp3_bwd_hist_slots(), n, (k + 1 + 3) // 4 * 4, device=dev) for n, k in dims]
+        dX3 = z(K)
+        for _ in range(2):
+            ops.mlp3_bwd_hist(desc, gY.to(dev), Y, x_hist, H1, H2, dX3, slabs)
         torch.cuda.synchronize()
-        torch.testing.assert_close(gw.cpu().double(), w.grad, rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(gb.cpu().double(), b_.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(dX3[:, :, :B].cpu().double(), as_rows(x64.grad, K), rtol=1e-4, atol=1e-5)
+        for sl, (n, k), (w, b_) in zip(slabs, dims, W64):
+            gw, gb = torch.zeros(n, k, device=dev), torch.zeros(n, device=dev)
+            ops.wgrad_reduce(sl, gw, gb, k, 0.5)
+            torch.cuda.synchronize()
+            torch.testing.assert_close(gw.cpu().double(), w.grad, rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(gb.cpu().double(), b_.grad, rtol=1e-4, atol=1e-5)
 
 
 def test_segment_sum_forward_aggregation_and_gather_adjoint():
