@@ -190,8 +190,12 @@ def algorithmic_work(tag, kernel, shape):
             return "hbm", 4.0 * (N + K) * cols, "B"
         return "mfma", 2.0 * N * K * cols, "FLOP"
     if tag.startswith("mlp3_fwd_") or tag.startswith("mlp3_bwd_"):  # fused 3-layer MLP: K -> 32 -> 32 -> n_out per column
+        # HBM-bound: 0.4 flop per byte of activations.  Forward (training): K gathered input rows in, the two hidden
+        # activations the backward needs and the output out.  Backward: dY / Y, the hidden activations and the inputs in,
+        # the input gradient out (weight gradients stay in registers).  The optional X history is a design choice, not counted.
         K, n_out, n_ent = shape["gnn"][tag[len("mlp3_fwd_"):]]
-        return "mfma", 2.0 * (K * 32 + 32 * 32 + 32 * n_out) * n_ent * n, "FLOP"
+        rows = (K + 64 + n_out) if tag.startswith("mlp3_fwd_") else (2 * K + 64 + 2 * n_out)
+        return "hbm", 4.0 * rows * n_ent * n, "B"
     if tag.startswith("bwd_thin_"):
         N, K = (int(v) for v in tag[len("bwd_thin_"):].split("x"))
         return "hbm", 4.0 * (2 * K + N) * n, "B"      # layer input read once, input gradient written once, dY read
