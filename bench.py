@@ -209,8 +209,9 @@ def algorithmic_work(tag, kernel, shape):
     hist = shape["F"] + 32 * shape["nh"] + shape["n_out"]
     if tag == "small_rollout_fwd":  # demand in, reward out (+ the activation history when training)
         return "hbm", 4.0 * (2 + (hist if shape["train"] else 0)) * n * T, "B"
-    if tag == "small_rollout_bwd":  # history + demand in, pre-activation gradients out
-        return "hbm", 4.0 * (1 + hist + 32 * shape["nh"] + shape["n_out"]) * n * T, "B"
+    if tag == "small_rollout_bwd":  # history + demand in (weight gradients stay in registers; the first version also wrote dZ)
+        dz = 0 if "wgrad" in kernel else 32 * shape["nh"] + shape["n_out"]
+        return "hbm", 4.0 * (1 + hist + dz) * n * T, "B"
     if tag == "closed_form_fwd":  # whole-horizon closed-form policy: the demand trace + one state load / store + totals
         return "hbm", 4.0 * (S * T + 2 * f_state + 2 * S) * n, "B"
     return None

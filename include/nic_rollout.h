@@ -228,6 +228,13 @@ int nic_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* s
  * nic_linear_wgrad contractions over n_scenarios = T*ldb with ldb = T*ldb (layer l: dY = its dz rows, X = its input rows). */
 int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
                           const float* logits_hist, NicTable2 g_reward, float* dz_hidden, float* dz_out, void* stream);
+/* The same backward sweep with the weight gradients contracted in the kernel (no dz history, no GEMM launches): every
+ * wavefront (32 scenarios) keeps dW / db of all layers in registers over the whole horizon and stores its partial gradient, in
+ * the layout of the packed weights, to slab[wavefront * slab_stride ...]; the caller sums the
+ * nic_small_rollout_bwd_wgrad_slots(n_scenarios) rows.  Replaces trainer.py:173 (`backward`) for the small policies. */
+int nic_small_rollout_bwd_wgrad_slots(int32_t n_scenarios);
+int nic_small_rollout_bwd_wgrad(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
+                                const float* logits_hist, NicTable2 g_reward, float* slab, int64_t slab_stride, void* stream);
 
 /* ---- whole-horizon rollout of the closed-form policies ---------------------------------------------------------
  * base_stock (neural_networks.py:216-229), capped_base_stock (:296-311) and echelon_stock (:231-294) for T periods of

@@ -108,6 +108,8 @@ PROTOTYPES = {
                                       _i32, _vp]),
     "nic_small_rollout_fwd": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_small_rollout_bwd": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, NicTable2, _vp, _vp, _vp]),
+    "nic_small_rollout_bwd_wgrad_slots": (C.c_int, [C.c_int32]),
+    "nic_small_rollout_bwd_wgrad": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, NicTable2, _vp, _i64, _vp]),
     "nic_round_orders": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "nic_mlp3_fwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp]),
     "nic_mlp3_bwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

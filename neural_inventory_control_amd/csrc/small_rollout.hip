@@ -25,7 +25,31 @@ constexpr int kBlock = 64;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <int NL>
+// Shape specialisation.  The per-lane env step / head bodies (small_rollout_body.h) index the st[16] register array with offsets
+// built from the descriptor's pipeline lengths; with those as run-time values every access is a 16-way select chain whose 64-bit
+// lane masks live in (spilled) SGPRs - 4,100 instructions per period, a quarter of them v_readlane / s_nop spill traffic, on a
+// kernel whose duration IS the instruction count of one wavefront (one wave per SIMD, T sequential periods).  The two chains the
+// reference ships are therefore compiled with their structure as constants: overwriting the structural fields of the kernel's
+// own copy of the descriptor lets constant propagation fold every offset, loop bound and select through the always-inline bodies.
+//   SHAPE 0: any supported chain (run-time structure)
+//   SHAPE 1: one store, Ws = 4, softplus head            (one_store_lost.yml / one_store_backlogged.yml + vanilla_one_store)
+//   SHAPE 2: store + warehouse + 2 echelons, 4 / 3 / 4, serial head   (serial_system.yml + vanilla_serial)
+template <int SHAPE>
+__device__ __forceinline__ void fix_shape(NicSmallRolloutDesc& d, int n_hidden) {
+    d.n_hidden = n_hidden;
+    if (SHAPE == 1) {
+        d.Ws = 4; d.Ww = 0; d.We = 0; d.Wn = 0; d.E = 0; d.head = 0; d.F = 4; d.n_out = 1;
+    } else if (SHAPE == 2) {
+        d.Ws = 4; d.Ww = 3; d.We = 4; d.Wn = 1; d.E = 2; d.head = 1; d.F = 15; d.n_out = 4;
+    }
+}
+int shape_of(const NicSmallRolloutDesc& d) {
+    if (d.Ws == 4 && d.Wn == 0 && d.E == 0 && d.head == 0 && d.F == 4 && d.n_out == 1) return 1;
+    if (d.Ws == 4 && d.Wn == 1 && d.Ww == 3 && d.E == 2 && d.We == 4 && d.head == 1 && d.F == 15 && d.n_out == 4) return 2;
+    return 0;
+}
+
+template <int NL, int SHAPE>
 __global__ __launch_bounds__(64) void small_rollout_fwd_mfma_kernel(NicSmallRolloutDesc d, const float* __restrict__ weights,
                                                                     const float* __restrict__ demand,
                                                                     const float* __restrict__ state0, float* __restrict__ rewards,
@@ -40,6 +64,7 @@ __global__ __launch_bounds__(64) void small_rollout_fwd_mfma_kernel(NicSmallRoll
     d.weights = weights;
     d.demand = demand;
     d.state0 = state0;
+    fix_shape<SHAPE>(d, NL);
 
     // ---- weight fragments, resident for the whole horizon
     const int i = j;  // A-operand row owned by this lane
@@ -142,14 +167,26 @@ __global__ __launch_bounds__(64) void small_rollout_fwd_mfma_kernel(NicSmallRoll
 // A fragments (dH_{l-1} = W_l^T dZ_l), contraction order over neurons n = crow(s, h) so the previous layer's dZ accumulator
 // registers are again the B operands as they stand.  elu'(H) comes from the stored activations, read in the C layout the
 // forward wrote them in.  Emits the same dZ history as the per-lane form for the weight-gradient GEMMs.
-template <int NL>
+//
+// WG = true: the weight gradients are contracted HERE instead of in four GEMM launches over a dZ history.  Per period and layer
+// the pre-activation gradient (column-owner accumulator registers) goes through a wave-private LDS tile into the row-owner A
+// operand, the layer input (the stored activation already in registers for elu') through a second tile into the row-owner B
+// operand, and 16 MFMAs add dZ X^T over the wave's 32 scenarios into an accumulator that lives in registers for the whole
+// horizon (one wavefront per SIMD: the register file is otherwise idle, and these MFMA chains are independent of the
+// latency-bound dH chain, whose bubbles they fill).  No dz history is written (97 rows x T x ldb x 4 B for cfg2) or read back.
+// At the end the wavefront stores its partial gradient, in the layout of the packed weights, to `slab[blockIdx.x]`.
+template <int NL, bool WG, int SHAPE>
 __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRolloutDesc d, const float* __restrict__ weights,
                                                                     const float* __restrict__ demand,
                                                                     const float* __restrict__ states_hist,
                                                                     const float* __restrict__ hidden_hist,
                                                                     const float* __restrict__ logits_hist, NicTable2 g_reward,
-                                                                    float* __restrict__ dz_hidden, float* __restrict__ dz_out) {
+                                                                    float* __restrict__ dz_hidden, float* __restrict__ dz_out,
+                                                                    float* __restrict__ slab, int64_t slab_stride) {
     using namespace nic;
+    __shared__ float tiles[WG ? 2 * 32 * 33 : 1];
+    float* const tA = tiles;
+    float* const tB = tiles + (WG ? 32 * 33 : 0);
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     const int64_t b_raw = (int64_t)blockIdx.x * 32 + j;
     const bool live = b_raw < d.n_scenarios;
@@ -157,6 +194,7 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
     const int64_t ldb = d.ldb, tl = (int64_t)d.T * ldb;
     d.weights = weights;
     d.demand = demand;
+    fix_shape<SHAPE>(d, NL);
 
     const int i = j;  // A-operand row: the INPUT feature of the layer being back-propagated through
     float aWoT[4], aWhT[(NL > 1 ? NL - 1 : 1)][16], aW1T[16];
@@ -184,6 +222,45 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
     // else to switch to), so period t-1's history is fetched into registers while period t is computed.
     float st[SR_MAXF], z[SR_MAXOUT], dem, hh[NL][16];
     float st_n[SR_MAXF], z_n[SR_MAXOUT], dem_n, hh_n[NL][16];
+    // in-kernel weight gradients: dW of the output layer / hidden layers 1.. / first layer, bias sums of row i = j
+    f32x16 gO, gH[(NL > 1 ? NL - 1 : 1)], g1;
+    float sbO = 0.f, sbH[(NL > 1 ? NL - 1 : 1)], sb1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        gO[r] = 0.f;
+        g1[r] = 0.f;
+#pragma unroll
+        for (int l = 0; l < (NL > 1 ? NL - 1 : 1); ++l) gH[l][r] = 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < (NL > 1 ? NL - 1 : 1); ++l) sbH[l] = 0.f;
+    // column-owner registers (rows crow(r, h) of scenario column j) -> row-owner operand (row j, columns h*16 + s); dead lanes
+    // shadow scenario 0 and must not be counted twice: their column of the A operand is zero
+    auto to_A = [&](const float (&v)[16], float (&out)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tA[crow(r, h) * 33 + j] = live ? v[r] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) out[s2] = tA[j * 33 + h * 16 + s2];
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto to_B = [&](const float (&v)[16], float (&out)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tB[crow(r, h) * 33 + j] = v[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) out[s2] = tB[j * 33 + h * 16 + s2];
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto wgrad = [&](f32x16& g, float& sb, const float (&at)[16], const float (&bt)[16]) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            g = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s2], bt[s2], g, 0, 0, 0);
+            s_ += at[s2];
+        }
+        sb += s_ + __shfl_xor(s_, 32);
+    };
     // every load of a fetch is unconditional (rows beyond F / n_out re-read the last valid row and are zeroed by a select) and
     // the fetch sits AFTER the period's only conditional stores (dz_out), followed by unconditional dz_hidden stores: the
     // number of memory operations issued after it is then a compile-time constant and the wait for it at the top of the
@@ -213,12 +290,27 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
         float go[SR_MAXF], dz[SR_MAXOUT];
         const SrOrders g = sr_env_bwd(d, c, st, gn, go, dem, o, gr);
         sr_head_bwd(d, z, st, g, dz, go);
-        if (live && h == 0) {
+        if (!WG) {
+            if (live && h == 0) {
 #pragma unroll
-            for (int n = 0; n < SR_MAXOUT; ++n)
-                if (n < d.n_out) dz_out[n * tl + at] = dz[n];
+                for (int n = 0; n < SR_MAXOUT; ++n)
+                    if (n < d.n_out) dz_out[n * tl + at] = dz[n];
+            }
         }
         fetch(t > 0 ? t - 1 : 0, st_n, z_n, dem_n, hh_n);
+        if (WG) {  // output layer: dWout += dz_out H_last^T (both halves hold the same per-scenario dz: half 0 writes the tile)
+            float a_[16], b_[16];
+            if (h == 0) {
+#pragma unroll
+                for (int n = 0; n < SR_MAXOUT; ++n) tA[n * 33 + j] = (live && n < d.n_out) ? dz[n] : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) a_[s2] = j < SR_MAXOUT ? tA[j * 33 + h * 16 + s2] : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            to_B(hh[NL - 1], b_);
+            wgrad(gO, sbO, a_, b_);
+        }
         // output layer -> last hidden layer: contraction over the n_out logits, n = 2s + h
         f32x16 acc;
         float dh[16];
@@ -231,8 +323,15 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
             dh[r] = acc[r] * elu1_grad_from_out(hh[NL - 1][r]);
 #pragma unroll
         for (int l = NL - 1; l >= 1; --l) {
+            if (WG) {
+                float a_[16], b_[16];
+                to_A(dh, a_);
+                to_B(hh[l - 1], b_);
+                wgrad(gH[l - 1], sbH[l - 1], a_, b_);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dz_hidden[(int64_t)(l * SR_H + crow(r, h)) * tl + at] = dh[r];  // (dead lanes: see b)
+                for (int r = 0; r < 16; ++r) dz_hidden[(int64_t)(l * SR_H + crow(r, h)) * tl + at] = dh[r];  // (dead lanes: see b)
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
@@ -241,8 +340,22 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
             for (int r = 0; r < 16; ++r)
                 dh[r] = acc[r] * elu1_grad_from_out(hh[l - 1][r]);
         }
+        if (WG) {  // first layer: dW1 += dz1 X^T, X = the period's state rows (per-lane scalars, rows >= F are zero)
+            float a_[16], b_[16];
+            to_A(dh, a_);
+            if (h == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dz_hidden[(int64_t)crow(r, h) * tl + at] = dh[r];
+                for (int k = 0; k < SR_MAXF; ++k) tB[k * 33 + j] = st[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) b_[s2] = j < SR_MAXF ? tB[j * 33 + h * 16 + s2] : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            wgrad(g1, sb1, a_, b_);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz_hidden[(int64_t)crow(r, h) * tl + at] = dh[r];
+        }
         // first layer -> state (the reference detaches vanilla_serial's MLP input, neural_networks.py:329)
         if (!d.detach_input) {
 #pragma unroll
@@ -270,6 +383,23 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
         for (int l = 0; l < NL; ++l)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hh[l][r] = hh_n[l][r];
+    }
+    if (WG) {  // this wavefront's partial gradient, in the packed-weight layout
+        float* S = slab + (int64_t)blockIdx.x * slab_stride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = crow(r, h);
+            if (j < d.F) S[n * d.F + j] = g1[r];
+#pragma unroll
+            for (int l = 1; l < NL; ++l) S[sr_hidden_offset(d, l) + n * SR_H + j] = gH[l - 1][r];
+            if (n < d.n_out) S[sr_out_offset(d) + n * SR_H + j] = gO[r];
+        }
+        if (h == 0) {
+            S[SR_H * d.F + i] = sb1;
+#pragma unroll
+            for (int l = 1; l < NL; ++l) S[sr_hidden_offset(d, l) + SR_H * SR_H + i] = sbH[l - 1];
+            if (i < d.n_out) S[sr_out_offset(d) + d.n_out * SR_H + i] = sbO;
+        }
     }
 }
 
@@ -299,14 +429,19 @@ int nic_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* s
     NIC_REQUIRE(!states_hist || (hidden_hist && logits_hist), "nic_small_rollout_fwd: incomplete history buffers");
     hipStream_t s = nic::as_stream(stream);
     {  // matrix-core form: 32 scenarios per wavefront
-        nic::note_kernelf("small_rollout_fwd_mfma_kernel<%d>", d->n_hidden);
+        const int shape = shape_of(*d);
+        nic::note_kernelf("small_rollout_fwd_mfma_kernel<%d,%s>", d->n_hidden, shape == 1 ? "one_store" : (shape == 2 ? "serial" : "any"));
         const dim3 g32(nic::ceil_div(d->n_scenarios, 32)), b64(64);
-#define NIC_SR_FWD_MFMA(NL)                                                                                                \
-    hipLaunchKernelGGL(small_rollout_fwd_mfma_kernel<NL>, g32, b64, 0, s, *d, d->weights, d->demand, d->state0, rewards,  \
+#define NIC_SR_FWD_MFMA(NL, SH)                                                                                             \
+    hipLaunchKernelGGL((small_rollout_fwd_mfma_kernel<NL, SH>), g32, b64, 0, s, *d, d->weights, d->demand, d->state0, rewards, \
                        state_final, states_hist, hidden_hist, logits_hist)
-        if (d->n_hidden == 1) NIC_SR_FWD_MFMA(1);
-        else if (d->n_hidden == 2) NIC_SR_FWD_MFMA(2);
-        else NIC_SR_FWD_MFMA(3);
+        if (shape == 1 && d->n_hidden == 3) NIC_SR_FWD_MFMA(3, 1);
+        else if (shape == 1 && d->n_hidden == 2) NIC_SR_FWD_MFMA(2, 1);
+        else if (shape == 2 && d->n_hidden == 2) NIC_SR_FWD_MFMA(2, 2);
+        else if (shape == 2 && d->n_hidden == 3) NIC_SR_FWD_MFMA(3, 2);
+        else if (d->n_hidden == 1) NIC_SR_FWD_MFMA(1, 0);
+        else if (d->n_hidden == 2) NIC_SR_FWD_MFMA(2, 0);
+        else NIC_SR_FWD_MFMA(3, 0);
 #undef NIC_SR_FWD_MFMA
         return nic::check_launch("nic_small_rollout_fwd");
     }
@@ -319,16 +454,46 @@ int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist
                 "nic_small_rollout_bwd: null buffer");
     hipStream_t s = nic::as_stream(stream);
     {
-        nic::note_kernelf("small_rollout_bwd_mfma_kernel<%d>", d->n_hidden);
+        const int shape = shape_of(*d);
+        nic::note_kernelf("small_rollout_bwd_mfma_kernel<%d,%s>", d->n_hidden, shape == 1 ? "one_store" : (shape == 2 ? "serial" : "any"));
         const dim3 g32(nic::ceil_div(d->n_scenarios, 32)), b64(64);
-#define NIC_SR_BWD_MFMA(NL)                                                                                                \
-    hipLaunchKernelGGL(small_rollout_bwd_mfma_kernel<NL>, g32, b64, 0, s, *d, d->weights, d->demand, states_hist,         \
-                       hidden_hist, logits_hist, g_reward, dz_hidden, dz_out)
-        if (d->n_hidden == 1) NIC_SR_BWD_MFMA(1);
-        else if (d->n_hidden == 2) NIC_SR_BWD_MFMA(2);
-        else NIC_SR_BWD_MFMA(3);
+#define NIC_SR_BWD_MFMA(NL, SH)                                                                                              \
+    hipLaunchKernelGGL((small_rollout_bwd_mfma_kernel<NL, false, SH>), g32, b64, 0, s, *d, d->weights, d->demand, states_hist, \
+                       hidden_hist, logits_hist, g_reward, dz_hidden, dz_out, (float*)nullptr, (int64_t)0)
+        if (shape == 1 && d->n_hidden == 3) NIC_SR_BWD_MFMA(3, 1);
+        else if (shape == 2 && d->n_hidden == 2) NIC_SR_BWD_MFMA(2, 2);
+        else if (d->n_hidden == 1) NIC_SR_BWD_MFMA(1, 0);
+        else if (d->n_hidden == 2) NIC_SR_BWD_MFMA(2, 0);
+        else NIC_SR_BWD_MFMA(3, 0);
 #undef NIC_SR_BWD_MFMA
         return nic::check_launch("nic_small_rollout_bwd");
     }
+}
+
+int nic_small_rollout_bwd_wgrad_slots(int32_t n_scenarios) { return nic::ceil_div(n_scenarios, 32); }
+
+int nic_small_rollout_bwd_wgrad(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
+                                const float* logits_hist, NicTable2 g_reward, float* slab, int64_t slab_stride, void* stream) {
+    if (int e = validate(d, "nic_small_rollout_bwd_wgrad")) return e;
+    NIC_REQUIRE(states_hist && hidden_hist && logits_hist && g_reward.p && slab, "nic_small_rollout_bwd_wgrad: null buffer");
+    const int n_packed = (nic::SR_H * d->F + nic::SR_H) + (d->n_hidden - 1) * (nic::SR_H * nic::SR_H + nic::SR_H) + (d->n_out * nic::SR_H + d->n_out);
+    NIC_REQUIRE(slab_stride >= n_packed, "nic_small_rollout_bwd_wgrad: slab rows (%lld) shorter than the packed weights (%d)",
+                (long long)slab_stride, n_packed);
+    hipStream_t s = nic::as_stream(stream);
+    const int shape = shape_of(*d);
+    nic::note_kernelf("small_rollout_bwd_mfma_kernel<%d,wgrad,%s>", d->n_hidden, shape == 1 ? "one_store" : (shape == 2 ? "serial" : "any"));
+    const dim3 g32(nic::ceil_div(d->n_scenarios, 32)), b64(64);
+#define NIC_SR_BWD_WG(NL, SH)                                                                                                 \
+    hipLaunchKernelGGL((small_rollout_bwd_mfma_kernel<NL, true, SH>), g32, b64, 0, s, *d, d->weights, d->demand, states_hist, \
+                       hidden_hist, logits_hist, g_reward, (float*)nullptr, (float*)nullptr, slab, slab_stride)
+    if (shape == 1 && d->n_hidden == 3) NIC_SR_BWD_WG(3, 1);
+    else if (shape == 1 && d->n_hidden == 2) NIC_SR_BWD_WG(2, 1);
+    else if (shape == 2 && d->n_hidden == 2) NIC_SR_BWD_WG(2, 2);
+    else if (shape == 2 && d->n_hidden == 3) NIC_SR_BWD_WG(3, 2);
+    else if (d->n_hidden == 1) NIC_SR_BWD_WG(1, 0);
+    else if (d->n_hidden == 2) NIC_SR_BWD_WG(2, 0);
+    else NIC_SR_BWD_WG(3, 0);
+#undef NIC_SR_BWD_WG
+    return nic::check_launch("nic_small_rollout_bwd_wgrad");
 }
 }

@@ -94,6 +94,7 @@ class FusedRollout:
         self.timer = None  # KernelTimer or None
         self.use_graph = False  # replay the launch sequence from a HIP graph (see _replay_or_capture)
         self.use_small = True   # whole-horizon kernels for the small one-store-chain policies (small_rollout.py)
+        self.small_wgrad_in_kernel = True  # ... with the weight gradients contracted inside the backward kernel (False: dZ history + one GEMM per layer)
         self.use_thin = True    # fused backward of thin (<= 32 rows) output layers (csrc/thin_layer.hip)
         self.batch_wgrad = True  # hidden-layer weight gradients contracted over all periods in one launch
         self.eval_history = None  # evaluation keeps per-period states/orders/logits: None = while small, True / False = forced
@@ -138,13 +139,13 @@ class FusedRollout:
 
     def _setup(self, prob, T, train):
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin,
-               self.eval_history)
+               self.eval_history, self.small_wgrad_in_kernel)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
         self._prob = None
         for name in ("states", "orders", "logits", "hidden", "dZhist", "dZlast_hist", "dH", "slabs", "sr_states", "sr_hidden",
-                     "sr_logits", "sr_dzh", "sr_dzo"):
+                     "sr_logits", "sr_dzh", "sr_dzo", "sr_slab", "sr_grad"):
             setattr(self, name, None)  # release the previous shapes' buffers before sizing the new ones
         self.F_store, self.F_wh, self.F_ech = prob.S * prob.Ws, prob.Wn * prob.Ww, prob.E * prob.We
         F = self.F_store + self.F_wh + self.F_ech
@@ -169,12 +170,22 @@ class FusedRollout:
             self.sr_weights = z(sr.packed_weight_count(F, nh, no))
             if train:
                 self.sr_states, self.sr_hidden, self.sr_logits = z(F, T, ld), z(nh * sr.H, T, ld), z(no, T, ld)
-                self.sr_dzh, self.sr_dzo = z(nh * sr.H, T, ld), z(no, T, ld)
                 self.g_reward = z(ld)
-                self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], T * ld) for i in range(L)]
-                self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
-                self.gw = [torch.zeros_like(m.weight) for m in lins]
-                self.gb = [torch.zeros_like(m.bias) for m in lins]
+                if self.small_wgrad_in_kernel:
+                    # weight gradients contracted inside the backward kernel: one partial gradient per wavefront in the
+                    # packed-weight layout, summed once; the per-layer gradients are views of that sum
+                    n_packed = sr.packed_weight_count(F, nh, no)
+                    self.sr_slab = z(sr.small_rollout_bwd_wgrad_slots(prob.B), (n_packed + 3) // 4 * 4)
+                    self.sr_grad = z(self.sr_slab.shape[1])
+                    sl = sr.layer_slices(F, nh, no)
+                    self.gw = [self.sr_grad[o:o + n * k].view(n, k) for o, n, k, _ in sl]
+                    self.gb = [self.sr_grad[bo:bo + n] for _, n, _, bo in sl]
+                else:
+                    self.sr_dzh, self.sr_dzo = z(nh * sr.H, T, ld), z(no, T, ld)
+                    self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], T * ld) for i in range(L)]
+                    self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
+                    self.gw = [torch.zeros_like(m.weight) for m in lins]
+                    self.gb = [torch.zeros_like(m.bias) for m in lins]
             self._key = key
             return
         n_ord = prob.S * prob.nsup + prob.Wn + prob.E
@@ -389,6 +400,12 @@ class FusedRollout:
             grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
         self.g_reward.zero_()
         self.g_reward[:B] = grad_scale
+        if self.small_wgrad_in_kernel:
+            self._k("small_rollout_bwd", sr.small_rollout_bwd_wgrad, desc, *hist, Table(self.g_reward, 0, 1), self.sr_slab)
+            torch.sum(self.sr_slab, dim=0, out=self.sr_grad)
+            if assign_grads:
+                self._assign_grads(accumulate_grads)
+            return total, reported
         self._k("small_rollout_bwd", sr.small_rollout_bwd, desc, *hist, Table(self.g_reward, 0, 1), self.sr_dzh, self.sr_dzo)
         # weight gradients: contraction over (period, scenario) = T*ld columns; padding columns of dZ are zero
         n_cols, nh = T * ld, plan.n_hidden

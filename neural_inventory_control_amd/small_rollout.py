@@ -94,3 +94,15 @@ def small_rollout_bwd(desc, states_hist, hidden_hist, logits_hist, g_reward: Tab
     _lib.check(_lib.lib().nic_small_rollout_bwd(desc, _lib.ptr(states_hist), _lib.ptr(hidden_hist), _lib.ptr(logits_hist),
                                                 g_reward.t2(), _lib.ptr(dz_hidden), _lib.ptr(dz_out),
                                                 _lib.current_stream()))
+
+
+def small_rollout_bwd_wgrad_slots(n_scenarios):
+    return _lib.lib().nic_small_rollout_bwd_wgrad_slots(int(n_scenarios))
+
+
+def small_rollout_bwd_wgrad(desc, states_hist, hidden_hist, logits_hist, g_reward: Table, slab):
+    """Backward sweep with in-kernel weight gradients: slab [slots][>= packed_weight_count] receives one partial gradient per
+    wavefront in the packed-weight layout (sum over dim 0 = d total / d packed weights)."""
+    ops._dev(slab)
+    _lib.check(_lib.lib().nic_small_rollout_bwd_wgrad(desc, _lib.ptr(states_hist), _lib.ptr(hidden_hist), _lib.ptr(logits_hist),
+                                                      g_reward.t2(), _lib.ptr(slab), slab.stride(0), _lib.current_stream()))

@@ -447,6 +447,38 @@ def test_small_rollout_kernels_match_reference(name):
     assert out["worst"] <= 2e-5
 
 
+@pytest.mark.parametrize("workload,n,T", [("cfg2", 1000, 23), ("cfg4", 333, 17), ("cfg1", 70, 9)])
+def test_small_route_in_kernel_weight_gradients_match_the_gemm_path(workload, n, T):
+    """The whole-horizon backward contracts the weight gradients itself (one partial gradient per wavefront, summed once); the
+    first version wrote a dZ history and ran one GEMM per layer over it.  Same gradients on ragged batches (scenario counts
+    that leave dead lanes in the last wavefront, which shadow scenario 0 and must not be counted)."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    setting, policy, _, _, _ = workloads.get(workload)
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
+                  n, obs, setting["seeds"])
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    res = {}
+    for in_kernel in (True, False):
+        torch.manual_seed(5)
+        model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+        eng = FusedRollout(model, setting["problem_params"], DEV)
+        eng.small_wgrad_in_kernel = in_kernel
+        F = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
+        if policy["name"] != "vanilla_one_store":
+            F += sum(int(np.prod(data[k].shape[1:])) for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
+                     if k in data)
+        eng.materialize(F)
+        total, _ = eng.run(data, T, 0, train=True, observation_params=obs)
+        torch.cuda.synchronize()
+        assert eng.small is not None
+        res[in_kernel] = (float(total), [p.grad.clone() for p in model.parameters()])
+    assert res[True][0] == res[False][0]
+    for x, y in zip(res[True][1], res[False][1]):
+        assert float((x - y).norm() / (y.norm() + 1e-30)) < 5e-6
+
+
 @pytest.mark.parametrize("name", ["cfg2_one_store_backlogged_vanilla", "cfg4_serial_vanilla"])
 def test_small_route_equals_per_period_route(name):
     """FusedRollout takes the whole-horizon route for these policies; it must agree with its own per-period route."""
