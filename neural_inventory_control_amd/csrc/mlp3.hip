@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_e
 constexpr int kHistWaves = 4;
 constexpr int kHistBlocks = 512;   // persistent workgroups (two per CU)
 
-template <int KG>
+template <int KG, bool GATHER>
 __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp3_bwd_hist_kernel(
     NicMlp3Desc d, const float* __restrict__ weights, const float* __restrict__ dY, const float* __restrict__ Yo,
     const float* __restrict__ Xh, const float* __restrict__ H1, const float* __restrict__ H2, float* __restrict__ dX,
@@ -575,8 +575,8 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
             for (int s2 = 0; s2 < 16; ++s2) out[s2] = v;
         }
     };
-    const int hs4 = (int)hs * 4, el4 = (int)ent_ld * 4;      // row strides in bytes (checked by the launcher to fit)
-    const int out_act = d.out_act, n_out = d.n_out;
+    const int hs4_ = (int)hs * 4, el4_ = (int)ent_ld * 4;    // row strides in bytes (checked by the launcher to fit)
+    const int out_act = d.out_act, n_out_ = d.n_out;
 #pragma unroll 1
     for (int item = wave_id; item < n_items; item += n_waves) {
         const int e = item / chunks, ch = item - e * chunks;
@@ -584,16 +584,20 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
         const bool live = (int64_t)ch * 32 + j < d.n_scenarios;
         const int jl = live ? j : 0;
         const __amdgpu_buffer_rsrc_t rY = rsrc_of(Yo + colbase), rG = rsrc_of(dY + colbase), rH2 = rsrc_of(H2 + colbase),
-                                     rH1 = rsrc_of(H1 + colbase), rX = rsrc_of(Xh ? Xh + colbase : H1);
+                                     rH1 = rsrc_of(H1 + colbase), rX = rsrc_of(GATHER ? H1 : Xh + colbase);
         // column-owner offsets: row crow(r, h) = (r & 3) + 8 (r >> 2) [scalar] + 4 h [lane]
-        const int vo_h = (4 * h) * hs4 + jl * 4, vo_e = (4 * h) * el4 + jl * 4;
-        const int vo_row = j * hs4 + h * 64;                  // row-owner: row j, columns h*16 ..
+        const int vo_h = (4 * h) * hs4_ + jl * 4, vo_e = (4 * h) * el4_ + jl * 4;
+        const int vo_row = j * hs4_ + h * 64;                 // row-owner: row j, columns h*16 ..
         // (see mlp3_bwd_fused_kernel: an offset the compiler cannot see through keeps the weight fragments out of registers)
         int opaque = 0;
         asm volatile("" : "+s"(opaque));
         const float* W1 = sW1 + opaque;
         const float* W2 = sW2 + opaque;
         const float* W3 = sW3 + opaque;
+        // (the scalar row offsets r * stride are loop invariants too: hoisted, there were ~100 of them, spilled to VGPR lanes and
+        // read back with v_readlane + s_nop inside the item loop; recomputed per item they are one s_mul each on the idle SALU)
+        const int hs4 = hs4_ + opaque, el4 = el4_ + opaque;
+        const int n_out = n_out_ + opaque, Kq = K + opaque;   // (and the lane masks built from them: 64 SGPR pairs)
         // Software-pipelined by hand: each phase issues the loads of the NEXT phase before its own MFMA loop, and scheduling
         // barriers keep hipcc from hoisting every load of the item to the top.
         float gy[16], yo[16], h2[16], h1[16], dz[16], at[16], bts[2][16];
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
         if (j >= K) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) bts[0][s] = 0.f;
-        } else if (Xh) {
+        } else if (!GATHER) {
             row_owner(rX, vo_row, 0, bts[0]);
         } else {
             gather_row_owner(j, e, ch, bts[0]);
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
                 if (32 * (g + 1) + j >= K) {
 #pragma unroll
                     for (int s = 0; s < 16; ++s) bts[(g + 1) & 1][s] = 0.f;
-                } else if (Xh) {
+                } else if (!GATHER) {
                     row_owner(rX, vo_row, 32 * (g + 1) * hs4, bts[(g + 1) & 1]);
                 } else {
                     gather_row_owner(32 * (g + 1) + j, e, ch, bts[(g + 1) & 1]);
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
                     for (int r = 0; r < 16; ++r) {
                         const int k_s = 32 * g + (r & 3) + 8 * (r >> 2);
                         const float v = acc[r];   // (bit_cast straight from the vector element stored element 0 sixteen times)
-                        if (k_s + 4 * h < K) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rD, vo_e, k_s * el4, 0);
+                        if (k_s + 4 * h < Kq) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rD, vo_e, k_s * el4, 0);
                     }
                 }
             } else {
@@ -887,13 +891,19 @@ int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, con
     const dim3 grid(kHistBlocks), block(64 * kHistWaves);
     hipStream_t s = nic::as_stream(stream);
     const int kg = (d->K + 31) / 32;
-    nic::note_kernelf("mlp3_bwd_hist_kernel<%d>", kg);
-#define NIC_MLP3_BH(KG)                                                                                                       \
-    hipLaunchKernelGGL(mlp3_bwd_hist_kernel<KG>, grid, block, 0, s, *d, d->weights, dY, Y, X_hist, H1, H2, dX, slab1, lds1, slab2, \
-                       lds2, slab3, lds3)
-    if (kg == 1) NIC_MLP3_BH(1);
-    else if (kg == 2) NIC_MLP3_BH(2);
-    else NIC_MLP3_BH(3);
+    nic::note_kernelf("mlp3_bwd_hist_kernel<%d,%s>", kg, X_hist ? "stored" : "gather");
+#define NIC_MLP3_BH(KG, G)                                                                                                    \
+    hipLaunchKernelGGL((mlp3_bwd_hist_kernel<KG, G>), grid, block, 0, s, *d, d->weights, dY, Y, X_hist, H1, H2, dX, slab1, lds1,  \
+                       slab2, lds2, slab3, lds3)
+    if (X_hist) {
+        if (kg == 1) NIC_MLP3_BH(1, false);
+        else if (kg == 2) NIC_MLP3_BH(2, false);
+        else NIC_MLP3_BH(3, false);
+    } else {
+        if (kg == 1) NIC_MLP3_BH(1, true);
+        else if (kg == 2) NIC_MLP3_BH(2, true);
+        else NIC_MLP3_BH(3, true);
+    }
 #undef NIC_MLP3_BH
     return nic::check_launch("nic_mlp3_bwd_hist");
 }
