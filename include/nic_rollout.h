@@ -337,6 +337,16 @@ int nic_mlp3_bwd_hist_slots(void);
 int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, const float* X_hist, const float* H1,
                       const float* H2, float* dX, float* slab1, int64_t lds1, float* slab2, int64_t lds2, float* slab3,
                       int64_t lds3, void* stream);
+/* The GNN policy's proportional allocation of the warehouse's on-hand stock (neural_networks.py:111-138 via :1435-1492) and
+ * its adjoint, one launch each: out [n_edges][ldb] = desired quantity per edge (internal edges 0..S-1 first), members = the
+ * internal edges + the self loop e_self (-1: none); sum = sum of the members' rows, ratio = on_hand / (sum + 1e-10),
+ * scale = cap_at_one ? min(ratio, 1) : ratio; orders [S+1][ldb]: rows s < S = out[s] * scale, row S = out[e_supplier].
+ * Backward: d_out [n_edges][ldb] is fully written, g_on_hand[b] += d(scale)/... (clamp passes where ratio <= 1). */
+int nic_gnn_alloc_fwd(const float* out, const float* on_hand, float* orders, float* sums, float* ratio, float* scale, int32_t S,
+                      int32_t e_self, int32_t e_supplier, int32_t cap_at_one, int32_t n_scenarios, int32_t ldb, void* stream);
+int nic_gnn_alloc_bwd(const float* out, const float* on_hand, const float* g_orders, const float* sums, const float* ratio,
+                      const float* scale, float* d_out, float* g_on_hand, int32_t S, int32_t n_edges, int32_t e_self,
+                      int32_t e_supplier, int32_t cap_at_one, int32_t n_scenarios, int32_t ldb, void* stream);
 /* dst[r][n][b] (+)= dst_scale[n] * sum_{p in [offsets[n], offsets[n+1])} src[r][items[p]][b] for r < R, in item order
  * (deterministic: no atomics).  Forward: message aggregation over a node's incident edges (:1229-1269, with the
  * 1/sqrt(degree) normalisation :1275-1296 as dst_scale); backward: the adjoint of every gather above. */

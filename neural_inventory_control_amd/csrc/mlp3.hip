@@ -798,6 +798,55 @@ __global__ void segment_sum_kernel(float* __restrict__ dst, int64_t dst_rs, cons
     }
 }
 
+// ---- proportional allocation of the warehouse's on-hand stock over its outgoing edges (+ self loop) ------------------------------
+// (neural_networks.py:111-138 via :1435-1492).  One lane = one scenario; the ~25 small tensor ops per period this replaces were
+// 10 % of the GNN step.  out [E][ldb] = desired quantity per edge; members = internal edges 0..S-1 (+ e_self if >= 0);
+// orders [S+1][ldb] = out[s] * scale for the stores, out[e_supplier] for the warehouse's own order.
+__global__ void gnn_alloc_fwd_kernel(const float* __restrict__ out, const float* __restrict__ on_hand, float* __restrict__ orders,
+                                     float* __restrict__ sums, float* __restrict__ ratio, float* __restrict__ scale, int S,
+                                     int e_self, int e_sup, int cap_at_one, int B, int64_t ldb) {
+#pragma clang fp contract(off)   // separate multiplies and adds, like the aten ops this replaces
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) sum += out[(int64_t)s * ldb + b];
+    if (e_self >= 0) sum += out[(int64_t)e_self * ldb + b];
+    const float r = on_hand[b] / (sum + 1e-10f);
+    const float sc = cap_at_one ? fminf(r, 1.f) : r;   // torch.clamp(max = 1)
+    sums[b] = sum;
+    ratio[b] = r;
+    scale[b] = sc;
+    for (int s = 0; s < S; ++s) orders[(int64_t)s * ldb + b] = out[(int64_t)s * ldb + b] * sc;
+    orders[(int64_t)S * ldb + b] = out[(int64_t)e_sup * ldb + b];
+}
+
+// adjoint: g_orders [S+1][ldb] -> d_out [E][ldb] (every row written) and g_on_hand[b] += d_scale / (sum + eps).
+// clamp(max) passes the gradient where ratio <= 1 (torch's rule); the self loop's allocation feeds nothing.
+__global__ void gnn_alloc_bwd_kernel(const float* __restrict__ out, const float* __restrict__ on_hand,
+                                     const float* __restrict__ g_orders, const float* __restrict__ sums,
+                                     const float* __restrict__ ratio, const float* __restrict__ scale, float* __restrict__ d_out,
+                                     float* __restrict__ g_on_hand, int S, int E, int e_self, int e_sup, int cap_at_one, int B,
+                                     int64_t ldb) {
+#pragma clang fp contract(off)
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float dot = 0.f;
+    for (int s = 0; s < S; ++s) dot += g_orders[(int64_t)s * ldb + b] * out[(int64_t)s * ldb + b];
+    const float passes = cap_at_one ? (ratio[b] <= 1.f ? 1.f : 0.f) : 1.f;
+    const float d_scale = dot * passes;
+    const float den = sums[b] + 1e-10f;
+    const float common = -(d_scale * on_hand[b] / (den * den));
+    const float sc = scale[b];
+    for (int e = 0; e < E; ++e) {
+        float v = 0.f;
+        if (e < S || e == e_self) v = common;
+        if (e < S) v += g_orders[(int64_t)e * ldb + b] * sc;
+        if (e == e_sup) v = g_orders[(int64_t)S * ldb + b];
+        d_out[(int64_t)e * ldb + b] = v;
+    }
+    g_on_hand[b] += d_scale / den;
+}
+
 int validate(const NicMlp3Desc* d, const char* who) {
     NIC_REQUIRE(d && d->weights, "%s: null descriptor / weights", who);
     NIC_REQUIRE(d->n_entities > 0 && d->n_scenarios > 0 && d->ldb >= d->n_scenarios && d->ldb % 32 == 0,
@@ -906,6 +955,28 @@ int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, con
     }
 #undef NIC_MLP3_BH
     return nic::check_launch("nic_mlp3_bwd_hist");
+}
+
+int nic_gnn_alloc_fwd(const float* out, const float* on_hand, float* orders, float* sums, float* ratio, float* scale, int32_t S,
+                      int32_t e_self, int32_t e_supplier, int32_t cap_at_one, int32_t n_scenarios, int32_t ldb, void* stream) {
+    NIC_REQUIRE(out && on_hand && orders && sums && ratio && scale, "nic_gnn_alloc_fwd: null buffer");
+    NIC_REQUIRE(S > 0 && e_supplier >= 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_gnn_alloc_fwd: bad sizes");
+    nic::note_kernel("gnn_alloc_fwd_kernel");
+    hipLaunchKernelGGL(gnn_alloc_fwd_kernel, dim3(nic::ceil_div(n_scenarios, 256)), dim3(256), 0, nic::as_stream(stream), out, on_hand,
+                       orders, sums, ratio, scale, S, e_self, e_supplier, cap_at_one, n_scenarios, (int64_t)ldb);
+    return nic::check_launch("nic_gnn_alloc_fwd");
+}
+
+int nic_gnn_alloc_bwd(const float* out, const float* on_hand, const float* g_orders, const float* sums, const float* ratio,
+                      const float* scale, float* d_out, float* g_on_hand, int32_t S, int32_t n_edges, int32_t e_self,
+                      int32_t e_supplier, int32_t cap_at_one, int32_t n_scenarios, int32_t ldb, void* stream) {
+    NIC_REQUIRE(out && on_hand && g_orders && sums && ratio && scale && d_out && g_on_hand, "nic_gnn_alloc_bwd: null buffer");
+    NIC_REQUIRE(S > 0 && n_edges > S && e_supplier >= 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_gnn_alloc_bwd: bad sizes");
+    nic::note_kernel("gnn_alloc_bwd_kernel");
+    hipLaunchKernelGGL(gnn_alloc_bwd_kernel, dim3(nic::ceil_div(n_scenarios, 256)), dim3(256), 0, nic::as_stream(stream), out, on_hand,
+                       g_orders, sums, ratio, scale, d_out, g_on_hand, S, n_edges, e_self, e_supplier, cap_at_one, n_scenarios,
+                       (int64_t)ldb);
+    return nic::check_launch("nic_gnn_alloc_bwd");
 }
 
 int nic_segment_sum(float* dst, int64_t dst_row_stride, const float* src, int64_t src_row_stride, const int32_t* offsets,

@@ -407,17 +407,9 @@ class GnnRollout:
         self._run_mlp("output", t, segs, prob)
         out = M["output"].Y[t][0]                                  # [E][ld] desired quantity per edge
         # proportional allocation of the warehouse's on-hand stock over its outgoing edges + self loop (:111-138, :1435-1492)
-        mem = out[P.members]
-        on_hand = st.wh[0, 0]
-        torch.sum(mem, dim=0, out=self.sums[t])
-        torch.div(on_hand, self.sums[t] + 1e-10, out=self.ratio[t])
-        if P.transshipment:
-            self.scale[t].copy_(self.ratio[t])
-        else:
-            torch.clamp(self.ratio[t], max=1.0, out=self.scale[t])
         orders = self.orders[t]
-        torch.mul(out[:S], self.scale[t], out=orders[:S])
-        orders[S].copy_(out[P.e_supplier])
+        ops.gnn_alloc_fwd(out, st.wh[0, 0], orders, self.sums[t], self.ratio[t], self.scale[t], S, P.e_self, P.e_supplier,
+                          not P.transshipment, B)
         ts, tw = self._order_tables(orders, prob)
         self._k("env_fwd", ops.env_step_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
                 out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
@@ -431,19 +423,8 @@ class GnnRollout:
         self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
                 self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=gc, g_orders=(g_so, g_wo, None))
         # allocation adjoint: alloc_e = out_e * min(1, on_hand / (sum + eps)) for the members, supplier edge passes through
-        out = M["output"].Y[t][0]
-        d_out = self.d_out[0]
-        d_out.zero_()
-        g_alloc = self.g_orders[:S]
-        sums, ratio, scale = self.sums[t], self.ratio[t], self.scale[t]
-        dot = (g_alloc * out[:S]).sum(dim=0)                       # the self loop's allocation feeds nothing: gradient 0
-        passes = torch.ones_like(ratio) if P.transshipment else (ratio <= 1.0).to(ratio.dtype)  # clamp(max): x <= max
-        on_hand = st.wh[0, 0]
-        d_scale = dot * passes
-        d_out[P.members] = -(d_scale * on_hand / (sums + 1e-10) ** 2)
-        d_out[:S] += g_alloc * scale
-        d_out[P.e_supplier] = self.g_orders[S]
-        gc.wh[0, 0] += d_scale / (sums + 1e-10)
+        ops.gnn_alloc_bwd(M["output"].Y[t][0], st.wh[0, 0], self.g_orders, self.sums[t], self.ratio[t], self.scale[t],
+                          self.d_out[0], gc.wh[0, 0], S, P.e_self, P.e_supplier, not P.transshipment, B)
         segs = self._segments(t)
         # output MLP -> edges1
         m = M["output"]

@@ -254,6 +254,21 @@ def mlp3_bwd_hist(desc, dY, Y, X_hist, H1, H2, dX, slabs):
                                   s2.stride(1), ptr(s3), s3.stride(1), current_stream()))
 
 
+def gnn_alloc_fwd(out, on_hand, orders, sums, ratio, scale, S, e_self, e_supplier, cap_at_one, n_scenarios):
+    """Proportional allocation head of the GNN policy (one launch): see nic_gnn_alloc_fwd."""
+    _dev(out)
+    check(lib().nic_gnn_alloc_fwd(ptr(out), ptr(on_hand), ptr(orders), ptr(sums), ptr(ratio), ptr(scale), S,
+                                  -1 if e_self is None else e_self, e_supplier, int(cap_at_one), n_scenarios, out.stride(0),
+                                  current_stream()))
+
+
+def gnn_alloc_bwd(out, on_hand, g_orders, sums, ratio, scale, d_out, g_on_hand, S, e_self, e_supplier, cap_at_one, n_scenarios):
+    _dev(out)
+    check(lib().nic_gnn_alloc_bwd(ptr(out), ptr(on_hand), ptr(g_orders), ptr(sums), ptr(ratio), ptr(scale), ptr(d_out),
+                                  ptr(g_on_hand), S, d_out.shape[0], -1 if e_self is None else e_self, e_supplier, int(cap_at_one),
+                                  n_scenarios, out.stride(0), current_stream()))
+
+
 def segment_sum(dst, src, offsets, items, dst_scale=None, accumulate=False):
     """dst [R][n_dst][ldb] (+)= dst_scale[n] * sum over items[offsets[n]:offsets[n+1]] of src[R][.][ldb] rows."""
     _dev(dst)
