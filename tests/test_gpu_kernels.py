@@ -510,3 +510,35 @@ def test_segment_sum_forward_aggregation_and_gather_adjoint():
     ops.segment_sum(dst, src.to(dev), offsets.to(dev), items.to(dev), None, accumulate=True)
     want2 = want + torch.stack([sum((src[:, i] for i in l), torch.zeros(R, ld)) for l in lists], dim=1)
     torch.testing.assert_close(dst.cpu()[:, :, :B], want2[:, :, :B], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("S,e_self,cap", [(16, 33, True), (3, None, False), (5, 11, False)])
+def test_gnn_allocation_head_matches_torch_autograd(S, e_self, cap):
+    """nic_gnn_alloc_fwd / bwd against the tensor-op formulation it replaced (neural_networks.py:111-138): orders, and through
+    float64 autograd the gradients w.r.t. the desired quantities and the on-hand stock, on a ragged scenario count."""
+    dev, B = "cuda", 777
+    ld = pad_ld(B, 32)
+    gen = torch.Generator().manual_seed(S)
+    E, e_sup = 2 * S + 2, S
+    out = torch.zeros(E, ld)
+    out[:, :B] = torch.rand(E, B, generator=gen) * 3 + 0.01
+    on_hand = torch.zeros(ld)
+    on_hand[:B] = torch.rand(B, generator=gen) * S * 3
+    g_orders = torch.zeros(S + 1, ld)
+    g_orders[:, :B] = torch.randn(S + 1, B, generator=gen)
+    members = list(range(S)) + ([e_self] if e_self is not None else [])
+    o64, h64 = out[:, :B].double().requires_grad_(True), on_hand[:B].double().requires_grad_(True)
+    ratio = h64 / (o64[members].sum(dim=0) + 1e-10)
+    sc = torch.clamp(ratio, max=1.0) if cap else ratio
+    want = torch.cat([o64[:S] * sc, o64[e_sup:e_sup + 1]], dim=0)
+    (want * g_orders[:, :B].double()).sum().backward()
+    z = lambda *sh: torch.zeros(*sh, device=dev)  # noqa: E731
+    orders, sums, rat, scale = z(S + 1, ld), z(ld), z(ld), z(ld)
+    ops.gnn_alloc_fwd(out.to(dev), on_hand.to(dev), orders, sums, rat, scale, S, e_self, e_sup, cap, B)
+    torch.testing.assert_close(orders[:, :B].cpu().double(), want.detach(), rtol=2e-6, atol=1e-6)
+    d_out, g_on = torch.full((E, ld), 9.0, device=dev), torch.full((ld,), 0.25, device=dev)
+    ops.gnn_alloc_bwd(out.to(dev), on_hand.to(dev), g_orders.to(dev), sums, rat, scale, d_out, g_on, S, e_self, e_sup, cap, B)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(d_out[:, :B].cpu().double(), o64.grad, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(g_on[:B].cpu().double() - 0.25, h64.grad, rtol=2e-5, atol=2e-5)
+    assert float(d_out[:, B:].sub(9.0).abs().max()) == 0.0   # padding columns untouched
