@@ -168,9 +168,23 @@ NIC_HD float env_fwd_stores(const NicEnvStepIO& io, float* store_out, int64_t b,
 }
 
 // this lane's share of what warehouse w ships: sum of the orders of stores s = q, q+4, ...   (:247)
+// The loads of a batch are issued together and then added in the same order as before: written as `a += load` in a loop with a
+// run-time trip count the compiler waits for each load before issuing the next (ISA: load, s_waitcnt vmcnt(0), add, branch) -
+// 16 stores per lane x 3 warehouses = 48 dependent memory round trips per wavefront for BASELINE cfg5, most of that kernel's time.
+constexpr int kShipBatch = 8;
 NIC_HD float env_ship_partial(const NicEnvStepIO& io, int w, int64_t b, int q) {
     float a = 0.f;
-    for (int s = q; s < io.dims.n_stores; s += kQuad) a += t3(io.store_orders, s, w, b);
+    for (int s0 = q; s0 < io.dims.n_stores; s0 += kQuad * kShipBatch) {
+        float v[kShipBatch];
+#pragma unroll
+        for (int u = 0; u < kShipBatch; ++u) {
+            const int s = s0 + u * kQuad;
+            v[u] = t3(io.store_orders, s < io.dims.n_stores ? s : q, w, b);   // (unconditional load of a valid row; masked below)
+        }
+#pragma unroll
+        for (int u = 0; u < kShipBatch; ++u)
+            if (s0 + u * kQuad < io.dims.n_stores) a += v[u];
+    }
     return a;
 }
 
@@ -193,7 +207,14 @@ NIC_HD float env_fwd_warehouse(const NicEnvStepIO& io, float* wh_out, int w, flo
 
 NIC_HD float env_wh_orders_sum(const NicEnvStepIO& io, int64_t b) {
     float s = 0.f;
-    for (int w = 0; w < io.dims.n_warehouses; ++w) s += t2(io.wh_orders, w, b);
+    for (int w0 = 0; w0 < io.dims.n_warehouses; w0 += kShipBatch) {   // loads of a batch first, then the sum in warehouse order
+        float v[kShipBatch];
+#pragma unroll
+        for (int u = 0; u < kShipBatch; ++u) v[u] = t2(io.wh_orders, w0 + u < io.dims.n_warehouses ? w0 + u : 0, b);
+#pragma unroll
+        for (int u = 0; u < kShipBatch; ++u)
+            if (w0 + u < io.dims.n_warehouses) s += v[u];
+    }
     return s;
 }
 
