@@ -101,16 +101,41 @@ __global__ __launch_bounds__(64) void mlp3_fwd_kernel(NicMlp3Desc d, const float
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = b1[crow(r, h)];
+    // First layer in groups of kG contraction steps: the gathers and weight fragments of a group are loaded UNCONDITIONALLY
+    // (a missing row reads a valid dummy address and is zeroed by a select) and all together, the next group's while this
+    // group's MFMAs run.  Written as one step at a time - `x = p ? p[..] : 0; a = k < K ? w[..] : 0; mfma` - every step was
+    // load, s_waitcnt vmcnt(0), MFMA behind two branches: 48 dependent memory round trips per wavefront.
+    constexpr int kG = 16, NG = (KS + kG - 1) / kG;
+    float xg[2][kG], ag[2][kG];
+    auto load_group = [&](int g, float (&x)[kG], float (&a)[kG]) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const RowRef r0 = input_row(segs, 2 * s), r1 = input_row(segs, 2 * s + 1);
-        const float* p = h ? r1.p : r0.p;
-        const int64_t scn = h ? r1.scn : r0.scn;
-        const int k = 2 * s + h;
-        const float x = p ? p[b * scn] : 0.f;
-        const float a = k < K ? w1t[k * 32 + i] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x, acc, 0, 0, 0);
-        if (Xh && live && k < K) Xh[(int64_t)k * hs + col] = x;
+        for (int u = 0; u < kG; ++u) {
+            const int s = g * kG + u;
+            if (s < KS) {
+                const RowRef r0 = input_row(segs, 2 * s), r1 = input_row(segs, 2 * s + 1);
+                const float* p = h ? r1.p : r0.p;
+                const int64_t scn = h ? r1.scn : r0.scn;
+                const int k = 2 * s + h;
+                const float xv = *(p ? p + b * scn : wt);
+                const float av = w1t[(k < K ? k : 0) * 32 + i];
+                x[u] = p ? xv : 0.f;
+                a[u] = k < K ? av : 0.f;
+            }
+        }
+    };
+    load_group(0, xg[0], ag[0]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) load_group(g + 1, xg[(g + 1) & 1], ag[(g + 1) & 1]);
+#pragma unroll
+        for (int u = 0; u < kG; ++u) {
+            const int s = g * kG + u;
+            if (s < KS) {
+                const int k = 2 * s + h;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[g & 1][u], xg[g & 1][u], acc, 0, 0, 0);
+                if (Xh && live && k < K) Xh[(int64_t)k * hs + col] = xg[g & 1][u];
+            }
+        }
     }
     float hcur[16];
 #pragma unroll
@@ -485,13 +510,31 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
         const float* W1 = weights;
         const float* W2 = W1 + 32 * K + 32;
         const float* W3 = W2 + 32 * 32 + 32;
-        for (int idx = threadIdx.x; idx < 32 * 32 * KG; idx += 64 * kHistWaves) {
-            const int n = idx / (32 * KG), k = idx % (32 * KG);
-            sW1[idx] = k < K ? W1[n * K + k] : 0.f;
+        // (all loads of a thread first, then its LDS stores: as `s[idx] = cond ? W[..] : 0` in a loop each load was waited for
+        // before the next was issued - 4 (KG + 2) dependent round trips at the head of every launch)
+        constexpr int NT = 64 * kHistWaves, IT1 = 32 * 32 * KG / NT, IT2 = 32 * 32 / NT;
+        float v1[IT1], v2[IT2], v3[IT2];
+#pragma unroll
+        for (int u = 0; u < IT1; ++u) {
+            const int idx = threadIdx.x + u * NT, n = idx / (32 * KG), k = idx % (32 * KG);
+            v1[u] = W1[k < K ? n * K + k : 0];
         }
-        for (int idx = threadIdx.x; idx < 32 * 32; idx += 64 * kHistWaves) {
-            sW2[idx] = W2[idx];
-            sW3[idx] = (idx >> 5) < d.n_out ? W3[idx] : 0.f;
+#pragma unroll
+        for (int u = 0; u < IT2; ++u) {
+            const int idx = threadIdx.x + u * NT;
+            v2[u] = W2[idx];
+            v3[u] = W3[(idx >> 5) < d.n_out ? idx : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < IT1; ++u) {
+            const int idx = threadIdx.x + u * NT, k = idx % (32 * KG);
+            sW1[idx] = k < K ? v1[u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < IT2; ++u) {
+            const int idx = threadIdx.x + u * NT;
+            sW2[idx] = v2[u];
+            sW3[idx] = (idx >> 5) < d.n_out ? v3[u] : 0.f;
         }
     }
     __syncthreads();
@@ -745,14 +788,31 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
     float* s1 = slab1 + (int64_t)blockIdx.x * 32 * lds1;
     float* s2 = slab2 + (int64_t)blockIdx.x * 32 * lds2;
     float* s3 = slab3 + (int64_t)blockIdx.x * d.n_out * lds3;
-    for (int idx = threadIdx.x; idx < 32 * 32 * KG; idx += 64 * kHistWaves) {
-        const int n = idx / (32 * KG), k = idx % (32 * KG);
-        if (k < K) s1[(int64_t)n * lds1 + k] += r1[idx];
-    }
-    for (int idx = threadIdx.x; idx < 32 * 32; idx += 64 * kHistWaves) {
-        const int n = idx >> 5, k = idx & 31;
-        s2[(int64_t)n * lds2 + k] += r2[idx];
-        if (n < d.n_out) s3[(int64_t)n * lds3 + k] += r3[idx];
+    {   // slab slot += block sum: the slot's old values are all fetched before the first add / store
+        constexpr int NT = 64 * kHistWaves, IT1 = 32 * 32 * KG / NT, IT2 = 32 * 32 / NT;
+        float o1[IT1], o2[IT2], o3[IT2];
+#pragma unroll
+        for (int u = 0; u < IT1; ++u) {
+            const int idx = threadIdx.x + u * NT, n = idx / (32 * KG), k = idx % (32 * KG);
+            o1[u] = s1[(int64_t)n * lds1 + (k < K ? k : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < IT2; ++u) {
+            const int idx = threadIdx.x + u * NT, n = idx >> 5, k = idx & 31;
+            o2[u] = s2[(int64_t)n * lds2 + k];
+            o3[u] = s3[(int64_t)(n < d.n_out ? n : 0) * lds3 + k];
+        }
+#pragma unroll
+        for (int u = 0; u < IT1; ++u) {
+            const int idx = threadIdx.x + u * NT, n = idx / (32 * KG), k = idx % (32 * KG);
+            if (k < K) s1[(int64_t)n * lds1 + k] = o1[u] + r1[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < IT2; ++u) {
+            const int idx = threadIdx.x + u * NT, n = idx >> 5, k = idx & 31;
+            s2[(int64_t)n * lds2 + k] = o2[u] + r2[idx];
+            if (n < d.n_out) s3[(int64_t)n * lds3 + k] = o3[u] + r3[idx];
+        }
     }
     if (threadIdx.x < 32) {
         s1[(int64_t)threadIdx.x * lds1 + K] += sbias[threadIdx.x];
@@ -775,13 +835,27 @@ __global__ void segment_sum_kernel(float* __restrict__ dst, int64_t dst_rs, cons
         float s[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) s[v] = 0.f;
-        for (int p = lo; p < hi; ++p) {   // in item order (deterministic; the association upstream's Python loop has)
-            const float* q = src + (int64_t)r * src_rs + (int64_t)items[p] * ldb + b;
-            if (V == 4) {
-                const float4 x = *reinterpret_cast<const float4*>(q);
-                s[0] += x.x; s[1] += x.y; s[2] += x.z; s[3] += x.w;
-            } else {
-                s[0] += q[0];
+        // in item order (deterministic; the association upstream's Python loop has); the loads of up to four items are issued
+        // together (one dependent round trip per item otherwise: 17 for the warehouse node)
+        for (int p0 = lo; p0 < hi; p0 += 4) {
+            float x[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u < hi ? p0 + u : p0;
+                const float* q = src + (int64_t)r * src_rs + (int64_t)items[p] * ldb + b;
+                if (V == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(q);
+                    x[u][0] = t.x; x[u][1 % V] = t.y; x[u][2 % V] = t.z; x[u][3 % V] = t.w;
+                } else {
+                    x[u][0] = q[0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p0 + u < hi) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) s[v] += x[u][v];
+                }
             }
         }
         float* o = dst + (int64_t)r * dst_rs + (int64_t)n * ldb + b;
