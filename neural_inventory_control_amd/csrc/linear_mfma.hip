@@ -546,6 +546,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
                         cs[(wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + (wn * NT + j) * 32 + li] = acc[i][j][r];
         }
         __syncthreads();
+        float bias_g[ITER];   // (fetched together: one load - wait - store round trip per row otherwise)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int row = m0 + pass * PASS_ROWS + t / TPR + RPI * it;
+            bias_g[it] = (EPI == EPI_BIAS_ACT && p.bias) ? p.bias[row < p.M ? row : 0] : 0.f;
+        }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int row_l = t / TPR + RPI * it;
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
             float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (t % TPR) * 4);
             const int64_t off = (int64_t)row * p.ldb + col;
             if (EPI == EPI_BIAS_ACT) {
-                const float bias = p.bias ? p.bias[row] : 0.f;
+                const float bias = bias_g[it];
                 y.x += bias; y.y += bias; y.z += bias; y.w += bias;
                 if (p.act == NIC_ACT_ELU) { y.x = elu_f(y.x); y.y = elu_f(y.y); y.z = elu_f(y.z); y.w = elu_f(y.w); }
             } else {

@@ -211,10 +211,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void th
 #pragma unroll
     for (int c = 0; c < KG; ++c) {
         if (!FULL && c >= n_chunks) break;
+        // (old values of the 16 rows fetched together, then added and stored: as `slab[..] += acc` per row this was sixteen
+        // dependent load - wait - store round trips at the tail of every wavefront)
+        float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = crow(r, h);
-            if (n < p.N) slab[(int64_t)n * p.lds_ + k_base + c * 32 + li] += wacc[c][r];
+            old[r] = slab[(int64_t)(n < p.N ? n : 0) * p.lds_ + k_base + c * 32 + li];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = crow(r, h);
+            if (n < p.N) slab[(int64_t)n * p.lds_ + k_base + c * 32 + li] = old[r] + wacc[c][r];
         }
     }
     if (kg == 0) {
