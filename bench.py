@@ -253,6 +253,8 @@ def main():
                     help="bracket every n-th launch of each kernel class with HIP events (default: 10 on the per-period route, "
                          "1 on the whole-horizon route; each pair costs ~5 us)")
     ap.add_argument("--graph", action="store_true", help="replay the launch sequence from a HIP graph (implies --no-kernel-timing)")
+    ap.add_argument("--gnn-keep-inputs", action="store_true",
+                    help="gnn: keep a copy of the gathered MLP inputs for the backward instead of reading them again (A/B)")
     ap.add_argument("--eval", action="store_true",
                     help="SURVEY 8(f2): time the forward-only evaluation pass (Trainer.test: no gradients, discrete allocation "
                          "for Poisson demand) instead of a training step; use with --periods 5000 for the reference's test horizon")
@@ -276,6 +278,8 @@ def main():
     closed_form = eng is not None and type(eng).__name__ == "ClosedFormRollout"
     gnn = eng is not None and type(eng).__name__ == "GnnRollout"
     if gnn:
+        if args.gnn_keep_inputs:
+            eng.keep_inputs = True
         eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
         parallel.broadcast_model(model, src=0)
     elif closed_form:

@@ -101,9 +101,9 @@ class _Mlp:
         self.fused_bwd = mode == "fused"
         dims = [(32, K), (32, 32), (n_out, 32)]
         if train and mode == "hist":
-            # stored hidden activations (and, while they fit, the gathered inputs), weight gradients contracted inside the
-            # backward kernel (nic_mlp3_bwd_hist); without an X history that kernel reads the inputs again from their per-period
-            # source buffers (1.4 % slower per step, 40 % less history).  One slab slot per workgroup, accumulated over the periods
+            # stored hidden activations, weight gradients contracted inside the backward kernel (nic_mlp3_bwd_hist), which reads
+            # the MLP inputs again from their per-period source buffers (or, keep_inputs, from a stored copy: same speed, 40 %
+            # more history).  One slab slot per workgroup, accumulated over the periods
             self.hist_stride = P * n_ent * ld
             G = self.G
             self.X = z(G, K, P, n_ent, ld) if keep_inputs else None
@@ -173,7 +173,8 @@ class GnnRollout:
         #   True    ("fused") nic_mlp3_bwd_fused: re-gather, recompute, in-kernel weight gradients; no per-period buffers at
         #           all, but its gathers are latency-exposed at two wavefronts per SIMD
         self.fused_bwd = None
-        self.keep_inputs = None  # "hist": None = keep the gathered inputs while they fit in HBM; False = always gather again
+        self.keep_inputs = False  # "hist": True = also keep a copy of the gathered MLP inputs (while it fits) instead of reading
+        #                         them again from their per-period sources in the backward (same speed, 40 % more history)
         self.use_graph = False   # replay the (static) launch sequence of a rollout from a HIP graph after one eager run
         self._probs = ProblemCache()
         self._key = None
@@ -237,7 +238,7 @@ class GnnRollout:
         self._fused_bwd_now = self._mode_now == "fused"
         self.mlp = {name: _Mlp(name, self._linears(name), k, 1 if name == "output" else 32,
                                A.NIC_MLP3_ACT_SOFTPLUS if name == "output" else A.NIC_MLP3_ACT_ELU, ne, ld, T, P_, dev, train,
-                               self._mode_now, self._keep_inputs and self.keep_inputs is not False)
+                               self._mode_now, self._keep_inputs and bool(self.keep_inputs))
                     for name, k, ne in zip(MODULES, ks, ents)}
         self._graphs, self._eager_runs = {}, 0
         self.agg_in, self.agg_out = z(T, 32, N, ld), z(T, 32, N, ld)

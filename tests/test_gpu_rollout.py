@@ -954,7 +954,7 @@ def test_closed_form_multi_store_and_training():
 GNN_CASES = ["f1_one_warehouse_gnn", "f1_one_warehouse_16_gnn", "f1_one_warehouse_gnn_transshipment"]
 
 
-@pytest.mark.parametrize("fused_bwd", [True, False, "hist", "hist_regather"])
+@pytest.mark.parametrize("fused_bwd", [True, False, "hist", "hist_stored_inputs"])
 @pytest.mark.parametrize("name", GNN_CASES)
 def test_gnn_fused_rollout_matches_reference(name, fused_bwd):
     """`GnnRollout` (five fused gather-MLP launches per period, segment-sum aggregation, manual backward sweep) against the
@@ -967,8 +967,8 @@ def test_gnn_fused_rollout_matches_reference(name, fused_bwd):
     eng = GnnRollout(model, c["problem_params"], DEV)
     # history-free backward with in-kernel weight gradients / stored activations + GEMMs / stored activations with in-kernel
     # weight gradients, with and without the stored copy of the gathered inputs
-    eng.fused_bwd = "hist" if fused_bwd == "hist_regather" else fused_bwd
-    eng.keep_inputs = False if fused_bwd == "hist_regather" else None
+    eng.fused_bwd = "hist" if fused_bwd == "hist_stored_inputs" else fused_bwd
+    eng.keep_inputs = fused_bwd == "hist_stored_inputs"
     data = {k: v.to(DEV) for k, v in g.data.items()}
     Dn = max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4
     eng.materialize(Dn)
