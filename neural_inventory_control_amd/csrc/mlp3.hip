@@ -59,6 +59,35 @@ __device__ __forceinline__ RowRef input_row(const SegRegs& R, int k) {
     return out;
 }
 
+// Row pointers computed ACROSS THE LANES: lane l evaluates the segment table for input row `row0 + l` on the vector unit (a
+// few dozen instructions for 64 rows at once) and every contraction step fetches the pointer it needs from lane 2s + h with one
+// lane permute per 32-bit half.  Resolving each row on the scalar unit (input_row) is ~80 SALU instructions per row; with 96 rows
+// per wavefront the forward kernel was bound by scalar issue (one slot per SIMD every four cycles), not by memory or the matrix
+// pipe.  Encoding: a 4-byte aligned address with bit 0 = the row is indexed by the scenario (scn_stride 1); rows that do not
+// exist (past K, or of the virtual all-zero node) point at a zero constant with bit 0 clear.
+__device__ const float kZeroRow = 0.f;
+__device__ __forceinline__ uint64_t encoded_row_pointer(const NicMlp3Desc& d, int e, int k) {
+    uint64_t enc = reinterpret_cast<uint64_t>(&kZeroRow);
+    int start = 0;
+#pragma unroll
+    for (int q = 0; q < NIC_MLP3_MAX_SEGS; ++q) {
+        if (q < d.n_segs) {
+            const NicMlp3Seg& S = d.seg[q];
+            const int ent = S.map ? S.map[e] : e;
+            const bool in = k >= start && k < start + S.n_rows && ent >= 0;
+            const uint64_t cand = reinterpret_cast<uint64_t>(S.base + (int64_t)ent * S.ent_stride + (int64_t)(k - start) * S.row_stride) |
+                                  (S.scn_stride ? 1ull : 0ull);
+            enc = in ? cand : enc;
+            start += S.n_rows;
+        }
+    }
+    return enc;
+}
+__device__ __forceinline__ uint64_t lane_fetch64(uint64_t v, int src_lane) {
+    const unsigned lo = __shfl((unsigned)v, src_lane), hi = __shfl((unsigned)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ float out_act_fwd(int act, float z) {
     if (act == NIC_MLP3_ACT_ELU) return nic::elu1(z);
     if (act == NIC_MLP3_ACT_SOFTPLUS) return z > 20.f ? z : log1pf(expf(z));  // nn.Softplus(beta=1, threshold=20)
@@ -97,7 +126,7 @@ __global__ __launch_bounds__(64) void mlp3_fwd_kernel(NicMlp3Desc d, const float
     const float* b2 = w2t + 32 * 32;
     const float* w3t = b2 + 32;            // [32][32], columns >= n_out zero
     const float* b3 = w3t + 32 * 32;       // padded to 32
-    const SegRegs segs = resolve_segments(d, e);
+    const uint64_t pv0 = encoded_row_pointer(d, e, lane), pv1 = (2 * KS > 64) ? encoded_row_pointer(d, e, 64 + lane) : 0ull;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = b1[crow(r, h)];
@@ -112,13 +141,11 @@ __global__ __launch_bounds__(64) void mlp3_fwd_kernel(NicMlp3Desc d, const float
         for (int u = 0; u < kG; ++u) {
             const int s = g * kG + u;
             if (s < KS) {
-                const RowRef r0 = input_row(segs, 2 * s), r1 = input_row(segs, 2 * s + 1);
-                const float* p = h ? r1.p : r0.p;
-                const int64_t scn = h ? r1.scn : r0.scn;
                 const int k = 2 * s + h;
-                const float xv = *(p ? p + b * scn : wt);
+                const uint64_t enc = lane_fetch64(2 * s < 64 ? pv0 : pv1, (2 * s + h) & 63);
+                const float* q = reinterpret_cast<const float*>(enc & ~3ull) + ((enc & 1ull) ? b : 0);
                 const float av = w1t[(k < K ? k : 0) * 32 + i];
-                x[u] = p ? xv : 0.f;
+                x[u] = *q;
                 a[u] = k < K ? av : 0.f;
             }
         }
