@@ -337,6 +337,19 @@ int nic_mlp3_bwd_hist_slots(void);
 int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, const float* X_hist, const float* H1,
                       const float* H2, float* dX, float* slab1, int64_t lds1, float* slab2, int64_t lds2, float* slab3,
                       int64_t lds3, void* stream);
+/* Several segment sums / plain addends into one destination in one launch:
+ * dst = (accumulate ? dst : 0) + sum_j scale_j[n] * (offsets_j ? sum over items_j[offsets_j[n] .. offsets_j[n+1]) of src_j rows
+ * : src_j row n), added in term order (the values a chain of nic_segment_sum(accumulate) launches and tensor adds produces). */
+#define NIC_SEG_MAX_TERMS 4
+typedef struct NicSegTerm {
+    const float* src;
+    int64_t src_row_stride;
+    const int32_t* offsets;   /* [n_dst + 1] or NULL: the term is src's own row n */
+    const int32_t* items;
+    const float* scale;       /* [n_dst] or NULL */
+} NicSegTerm;
+int nic_segment_sum_terms(float* dst, int64_t dst_row_stride, const NicSegTerm* terms, int32_t n_terms, int32_t R, int32_t n_dst,
+                          int32_t n_scenarios, int32_t ldb, int32_t accumulate, void* stream);
 /* The GNN policy's proportional allocation of the warehouse's on-hand stock (neural_networks.py:111-138 via :1435-1492) and
  * its adjoint, one launch each: out [n_edges][ldb] = desired quantity per edge (internal edges 0..S-1 first), members = the
  * internal edges + the self loop e_self (-1: none); sum = sum of the members' rows, ratio = on_hand / (sum + 1e-10),

@@ -70,6 +70,11 @@ class NicMlp3Seg(C.Structure):
                 ("scn_stride", C.c_int64), ("n_rows", C.c_int32), ("reserved", C.c_int32)]
 
 
+class NicSegTerm(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_row_stride", C.c_int64), ("offsets", C.c_void_p), ("items", C.c_void_p),
+                ("scale", C.c_void_p)]
+
+
 class NicMlp3Desc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("n_entities", "n_scenarios", "ldb", "K", "n_out", "out_act", "n_segs", "reserved")]
                 + [("seg", NicMlp3Seg * 4), ("weights", C.c_void_p), ("weights_t", C.c_void_p), ("hist_row_stride", C.c_int64)])
@@ -117,6 +122,7 @@ PROTOTYPES = {
     "nic_mlp3_bwd_fused": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "nic_mlp3_bwd_hist_slots": (C.c_int, []),
     "nic_mlp3_bwd_hist": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "nic_segment_sum_terms": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_gnn_alloc_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_gnn_alloc_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_segment_sum": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

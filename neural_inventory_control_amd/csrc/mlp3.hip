@@ -899,6 +899,69 @@ __global__ void segment_sum_kernel(float* __restrict__ dst, int64_t dst_rs, cons
     }
 }
 
+// Several segment sums (and plain addends: offsets == NULL takes row n itself) into ONE destination in one launch:
+// dst = (accumulate ? dst : 0) + scale_0 * S_0 + scale_1 * S_1 + ..., added in term order - exactly the values a chain of
+// nic_segment_sum(..., accumulate) launches and tensor adds produces, without the intermediate round trips through HBM.
+struct SegTerms {
+    NicSegTerm t[NIC_SEG_MAX_TERMS];
+    int n;
+};
+template <int V>
+__global__ void segment_sum_terms_kernel(float* __restrict__ dst, int64_t dst_rs, SegTerms T, int R, int B, int64_t ldb,
+                                         int accumulate) {
+    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const int n = blockIdx.y;
+    if (b >= B) return;
+    for (int r = blockIdx.z; r < R; r += gridDim.z) {
+        float* o = dst + (int64_t)r * dst_rs + (int64_t)n * ldb + b;
+        float y[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) y[v] = 0.f;
+        if (accumulate) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) y[v] = o[v];
+        }
+#pragma unroll
+        for (int j = 0; j < NIC_SEG_MAX_TERMS; ++j) {
+            if (j < T.n) {
+                const NicSegTerm& t = T.t[j];
+                const float* base = t.src + (int64_t)r * t.src_row_stride + b;
+                const float sc = t.scale ? t.scale[n] : 1.f;
+                float s[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) s[v] = 0.f;
+                if (t.offsets == nullptr) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) s[v] = base[(int64_t)n * ldb + v];
+                } else {
+                    const int lo = t.offsets[n], hi = t.offsets[n + 1];
+                    for (int p0 = lo; p0 < hi; p0 += 4) {
+                        float x[4][V];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int p = p0 + u < hi ? p0 + u : p0;
+                            const float* q = base + (int64_t)t.items[p] * ldb;
+#pragma unroll
+                            for (int v = 0; v < V; ++v) x[u][v] = q[v];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (p0 + u < hi) {
+#pragma unroll
+                                for (int v = 0; v < V; ++v) s[v] += x[u][v];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) y[v] = (j == 0 && !accumulate) ? sc * s[v] : y[v] + sc * s[v];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) o[v] = y[v];
+    }
+}
+
 // ---- proportional allocation of the warehouse's on-hand stock over its outgoing edges (+ self loop) ------------------------------
 // (neural_networks.py:111-138 via :1435-1492).  One lane = one scenario; the ~25 small tensor ops per period this replaces were
 // 10 % of the GNN step.  out [E][ldb] = desired quantity per edge; members = internal edges 0..S-1 (+ e_self if >= 0);
@@ -1056,6 +1119,34 @@ int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, con
     }
 #undef NIC_MLP3_BH
     return nic::check_launch("nic_mlp3_bwd_hist");
+}
+
+int nic_segment_sum_terms(float* dst, int64_t dst_row_stride, const NicSegTerm* terms, int32_t n_terms, int32_t R, int32_t n_dst,
+                          int32_t n_scenarios, int32_t ldb, int32_t accumulate, void* stream) {
+    NIC_REQUIRE(dst && terms && n_terms >= 1 && n_terms <= NIC_SEG_MAX_TERMS, "nic_segment_sum_terms: 1..%d terms", NIC_SEG_MAX_TERMS);
+    NIC_REQUIRE(R > 0 && n_dst > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_segment_sum_terms: bad sizes");
+    SegTerms T;
+    T.n = n_terms;
+    bool vec = ldb % 4 == 0 && dst_row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (n_scenarios + 3) / 4 * 4 <= ldb;
+    for (int j = 0; j < NIC_SEG_MAX_TERMS; ++j) {
+        T.t[j] = terms[j < n_terms ? j : 0];
+        if (j < n_terms) {
+            NIC_REQUIRE(terms[j].src && (terms[j].offsets == nullptr || terms[j].items), "nic_segment_sum_terms: null term buffer");
+            vec = vec && terms[j].src_row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(terms[j].src) & 15) == 0;
+        }
+    }
+    if (vec) {
+        const dim3 grid(nic::ceil_div(nic::ceil_div(n_scenarios, 4), 256), n_dst, R < 32 ? R : 32), block(256);
+        nic::note_kernel("segment_sum_terms_kernel<4>");
+        hipLaunchKernelGGL(segment_sum_terms_kernel<4>, grid, block, 0, nic::as_stream(stream), dst, dst_row_stride, T, R, n_scenarios,
+                           (int64_t)ldb, accumulate);
+    } else {
+        const dim3 grid(nic::ceil_div(n_scenarios, 256), n_dst, R < 32 ? R : 32), block(256);
+        nic::note_kernel("segment_sum_terms_kernel<1>");
+        hipLaunchKernelGGL(segment_sum_terms_kernel<1>, grid, block, 0, nic::as_stream(stream), dst, dst_row_stride, T, R, n_scenarios,
+                           (int64_t)ldb, accumulate);
+    }
+    return nic::check_launch("nic_segment_sum_terms");
 }
 
 int nic_gnn_alloc_fwd(const float* out, const float* on_hand, float* orders, float* sums, float* ratio, float* scale, int32_t S,

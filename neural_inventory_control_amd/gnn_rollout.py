@@ -430,23 +430,22 @@ class GnnRollout:
         # output MLP -> edges1
         m = M["output"]
         self._mlp_bwd(m, t, segs, prob, self.d_out, dX=self.d_edges1)
-        # edges1 = edges0 + edge_update(edges0, nodes1[src], nodes1[tgt])
-        m = M["edge_update"]
-        self._mlp_bwd(m, t, segs, prob, self.d_edges1)
-        torch.add(self.d_edges1, m.dX[:32], out=self.d_edges0)
-        ops.segment_sum(self.d_nodes1, m.dX[32:64], *P.n_as_src)
-        ops.segment_sum(self.d_nodes1, m.dX[64:96], *P.n_as_tgt, accumulate=True)
+        # edges1 = edges0 + edge_update(edges0, nodes1[src], nodes1[tgt]).  The adjoints of the residual connections, of the
+        # endpoint gathers and of the message aggregation are sums of segment sums: one multi-term launch per destination.
+        eu = M["edge_update"]
+        self._mlp_bwd(eu, t, segs, prob, self.d_edges1)
+        ops.segment_sum_terms(self.d_nodes1, [(eu.dX[32:64], *P.n_as_src, None), (eu.dX[64:96], *P.n_as_tgt, None)])
         # nodes1 = nodes0 + node_update(nodes0, incoming, outgoing)
-        m = M["node_update"]
-        self._mlp_bwd(m, t, segs, prob, self.d_nodes1)
-        torch.add(self.d_nodes1, m.dX[:32], out=self.d_nodes0)
-        ops.segment_sum(self.d_edges0, m.dX[32:64], *P.e_from_tgt, P.e_in_scale, accumulate=True)
-        ops.segment_sum(self.d_edges0, m.dX[64:96], *P.e_from_src, P.e_out_scale, accumulate=True)
+        nu = M["node_update"]
+        self._mlp_bwd(nu, t, segs, prob, self.d_nodes1)
+        ops.segment_sum_terms(self.d_edges0, [(self.d_edges1, None, None, None), (eu.dX[:32], None, None, None),
+                                              (nu.dX[32:64], *P.e_from_tgt, P.e_in_scale),
+                                              (nu.dX[64:96], *P.e_from_src, P.e_out_scale)])
         # edges0 = initial_edge(nodes0[src], nodes0[tgt], lead)
-        m = M["initial_edge"]
-        self._mlp_bwd(m, t, segs, prob, self.d_edges0)
-        ops.segment_sum(self.d_nodes0, m.dX[:32], *P.n_as_src, accumulate=True)
-        ops.segment_sum(self.d_nodes0, m.dX[32:64], *P.n_as_tgt, accumulate=True)
+        ie = M["initial_edge"]
+        self._mlp_bwd(ie, t, segs, prob, self.d_edges0)
+        ops.segment_sum_terms(self.d_nodes0, [(self.d_nodes1, None, None, None), (nu.dX[:32], None, None, None),
+                                              (ie.dX[:32], *P.n_as_src, None), (ie.dX[32:64], *P.n_as_tgt, None)])
         # nodes0 = initial_node(features): the pipeline rows of the features are the state
         m = M["initial_node"]
         self._mlp_bwd(m, t, segs, prob, self.d_nodes0)

@@ -254,6 +254,19 @@ def mlp3_bwd_hist(desc, dY, Y, X_hist, H1, H2, dX, slabs):
                                   s2.stride(1), ptr(s3), s3.stride(1), current_stream()))
 
 
+def segment_sum_terms(dst, terms, accumulate=False):
+    """dst [R][n_dst][ldb] = (accumulate ? dst : 0) + sum over terms, in order.  A term is (src, offsets, items, scale) - a segment
+    sum of src's [R][.][ldb] rows - or (src, None, None, scale): src's own row n.  One launch (nic_segment_sum_terms)."""
+    _dev(dst)
+    R, n_dst, ldb = dst.shape
+    arr = (_lib.NicSegTerm * len(terms))()
+    for j, (src, offsets, items, scale) in enumerate(terms):
+        arr[j].src, arr[j].src_row_stride = ptr(src), src.stride(0)
+        arr[j].offsets, arr[j].items, arr[j].scale = ptr(offsets), ptr(items), ptr(scale)
+    check(lib().nic_segment_sum_terms(ptr(dst), dst.stride(0), arr, len(terms), R, n_dst, ldb, ldb, int(accumulate), current_stream()))
+    return dst
+
+
 def gnn_alloc_fwd(out, on_hand, orders, sums, ratio, scale, S, e_self, e_supplier, cap_at_one, n_scenarios):
     """Proportional allocation head of the GNN policy (one launch): see nic_gnn_alloc_fwd."""
     _dev(out)

@@ -512,6 +512,37 @@ def test_segment_sum_forward_aggregation_and_gather_adjoint():
     torch.testing.assert_close(dst.cpu()[:, :, :B], want2[:, :, :B], rtol=1e-6, atol=1e-6)
 
 
+def test_segment_sum_terms_equals_the_chain_of_launches():
+    """nic_segment_sum_terms (several segment sums and plain addends into one destination, one launch) is bit-equal to the chain of
+    nic_segment_sum(accumulate) launches and tensor adds it replaces."""
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(5)
+    R, n_src, n_dst, B = 32, 9, 4, 130
+    ld = pad_ld(B, 32)
+    mk = lambda n: torch.nn.functional.pad(torch.randn(R, n, B, generator=gen), (0, ld - B)).to(dev)  # noqa: E731
+    a, b_, c, d_ = mk(n_dst), mk(n_dst), mk(n_src), mk(n_src)
+    off1 = torch.tensor([0, 3, 3, 4, 9], dtype=torch.int32, device=dev)
+    it1 = torch.tensor([0, 3, 8, 2, 1, 4, 5, 6, 7], dtype=torch.int32, device=dev)
+    off2 = torch.tensor([0, 1, 2, 3, 4], dtype=torch.int32, device=dev)
+    it2 = torch.tensor([8, 0, 3, 3], dtype=torch.int32, device=dev)
+    sc = torch.tensor([0.5, 1.0, 2.0, 1 / 5 ** 0.5], device=dev)
+    want = torch.add(a, b_)
+    ops.segment_sum(want, c, off1, it1, sc, accumulate=True)
+    ops.segment_sum(want, d_, off2, it2, None, accumulate=True)
+    got = torch.full_like(want, 3.0)
+    ops.segment_sum_terms(got, [(a, None, None, None), (b_, None, None, None), (c, off1, it1, sc), (d_, off2, it2, None)])
+    assert torch.equal(got, want)
+    want2 = want.clone()
+    ops.segment_sum(want2, c, off1, it1, None, accumulate=True)
+    ops.segment_sum_terms(got, [(c, off1, it1, None)], accumulate=True)
+    assert torch.equal(got, want2)
+    first = torch.zeros_like(want)
+    ops.segment_sum(first, c, off1, it1, sc)
+    ops.segment_sum(first, d_, off2, it2, None, accumulate=True)
+    ops.segment_sum_terms(got, [(c, off1, it1, sc), (d_, off2, it2, None)])
+    assert torch.equal(got, first)
+
+
 @pytest.mark.parametrize("S,e_self,cap", [(16, 33, True), (3, None, False), (5, 11, False)])
 def test_gnn_allocation_head_matches_torch_autograd(S, e_self, cap):
     """nic_gnn_alloc_fwd / bwd against the tensor-op formulation it replaced (neural_networks.py:111-138): orders, and through
