@@ -24,18 +24,23 @@ constexpr int SR_MAXE = 3;
 // ELU negative branch.  libm's expm1f costs several hundred cycles per call on the device and there are 32 * n_hidden of
 // them per scenario-period, more than the FMAs of the layers themselves; this form is a 6-term series near zero (relative
 // error < 2e-7 for x > -0.35) and exp(x) - 1 on the hardware exponential below that (value <= -0.29, absolute error ~1e-7).
+// (both forms are evaluated and one is selected: as an `if` this was a divergent branch per activation - save / restore of the
+// exec mask and a scalar branch around ~8 vector instructions, 48 times per scenario-period in the whole-horizon kernels, with
+// both sides executed anyway whenever the lanes of a wavefront disagree.  Same values as before, bit for bit.)
 NIC_HD float expm1_neg(float x) {
-    if (x > -0.35f) {
-        const float p = fmaf(x, fmaf(x, fmaf(x, fmaf(x, fmaf(x, 1.f / 720.f, 1.f / 120.f), 1.f / 24.f), 1.f / 6.f), 0.5f), 1.f);
-        return x * p;
-    }
+    const float xs = x > -0.35f ? x : 0.f;   // series argument (the other branch's inputs would overflow nothing, but stay tidy)
+    const float p = fmaf(xs, fmaf(xs, fmaf(xs, fmaf(xs, fmaf(xs, 1.f / 720.f, 1.f / 120.f), 1.f / 24.f), 1.f / 6.f), 0.5f), 1.f);
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __expf(x) - 1.f;
+    const float e = __expf(x) - 1.f;
 #else
-    return expf(x) - 1.f;
+    const float e = expf(x) - 1.f;
 #endif
+    return x > -0.35f ? xs * p : e;
 }
-NIC_HD float elu1(float x) { return x > 0.f ? x : expm1_neg(x); }
+NIC_HD float elu1(float x) {
+    const float neg = expm1_neg(x > 0.f ? 0.f : x);   // (NaN stays NaN)
+    return x > 0.f ? x : neg;
+}
 NIC_HD float elu1_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
 
 struct SrStatics {  // per-scenario constants, loaded once
