@@ -312,6 +312,10 @@ typedef struct NicMlp3Desc {
  * for the backward / weight gradients: X_hist [K][n_entities][ldb], H1, H2 [32][n_entities][ldb] (post-ELU), rows
  * hist_row_stride apart. */
 int nic_mlp3_fwd(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float* H2, void* stream);
+/* ... with a residual connection folded in: additionally Ysum [n_out][n_entities][ldb] = residual + Y (the GNN's
+ * nodes1 = nodes0 + node_update(...), edges1 = edges0 + edge_update(...); neural_networks.py:1311-1340). */
+int nic_mlp3_fwd_residual(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float* H2, const float* residual, float* Ysum,
+                          void* stream);
 /* Backward of the same MLP from dY [n_out][n_entities][ldb] and the stored Y / H1 / H2: the pre-activation gradients dZ3
  * [n_out][..], dZ2, dZ1 [32][..] (the weight gradients are nic_linear_wgrad contractions of these with H2 / H1 / X_hist over
  * all columns) and dX [K][n_entities][ldb], the gradient with respect to the GATHERED inputs (dense per column; the caller

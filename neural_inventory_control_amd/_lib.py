@@ -117,6 +117,7 @@ PROTOTYPES = {
     "nic_small_rollout_bwd_wgrad": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, NicTable2, _vp, _i64, _vp]),
     "nic_round_orders": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "nic_mlp3_fwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp]),
+    "nic_mlp3_fwd_residual": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_mlp3_bwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_mlp3_bwd_fused_slots": (C.c_int, []),
     "nic_mlp3_bwd_fused": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),

@@ -111,7 +111,8 @@ constexpr int kChunks = 1;  // 32-scenario chunks each wavefront walks (1: nothi
 // were 2-4x slower; measured.)
 template <int KS>
 __global__ __launch_bounds__(64) void mlp3_fwd_kernel(NicMlp3Desc d, const float* __restrict__ wt, float* __restrict__ Y,
-                                                      float* __restrict__ Xh, float* __restrict__ H1, float* __restrict__ H2) {
+                                                      float* __restrict__ Xh, float* __restrict__ H1, float* __restrict__ H2,
+                                                      const float* __restrict__ Rsd, float* __restrict__ Ysum) {
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5, i = j;
     const int e = blockIdx.y, K = d.K;
     const int64_t b_raw = (int64_t)blockIdx.x * 32 + j;
@@ -186,9 +187,24 @@ __global__ __launch_bounds__(64) void mlp3_fwd_kernel(NicMlp3Desc d, const float
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w3t[crow(s, h) * 32 + i], hcur[s], acc, 0, 0, 0);
     if (live) {
+        if (Ysum) {   // residual connection folded in: Ysum = out + R (the same rounding as the separate tensor add it replaces)
+            float rs[16], y[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (crow(r, h) < d.n_out) Y[(int64_t)crow(r, h) * ent_ld + col] = out_act_fwd(d.out_act, acc[r]);
+            for (int r = 0; r < 16; ++r) rs[r] = Rsd[(int64_t)(crow(r, h) < d.n_out ? crow(r, h) : 0) * ent_ld + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = out_act_fwd(d.out_act, acc[r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (crow(r, h) < d.n_out) {
+                    Y[(int64_t)crow(r, h) * ent_ld + col] = y[r];
+                    Ysum[(int64_t)crow(r, h) * ent_ld + col] = rs[r] + y[r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (crow(r, h) < d.n_out) Y[(int64_t)crow(r, h) * ent_ld + col] = out_act_fwd(d.out_act, acc[r]);
+        }
     }
 }
 
@@ -1031,8 +1047,16 @@ int validate(const NicMlp3Desc* d, const char* who) {
 
 extern "C" {
 
+int nic_mlp3_fwd_residual(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float* H2, const float* residual, float* Ysum,
+                          void* stream);
 int nic_mlp3_fwd(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float* H2, void* stream) {
+    return nic_mlp3_fwd_residual(d, Y, X_hist, H1, H2, nullptr, nullptr, stream);
+}
+
+int nic_mlp3_fwd_residual(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float* H2, const float* residual, float* Ysum,
+                          void* stream) {
     if (int e = validate(d, "nic_mlp3_fwd")) return e;
+    NIC_REQUIRE((residual == nullptr) == (Ysum == nullptr), "nic_mlp3_fwd_residual: residual and Ysum go together");
     NIC_REQUIRE(Y, "nic_mlp3_fwd: null output");
     NIC_REQUIRE((!X_hist && !H1 && !H2) || (H1 && H2), "nic_mlp3_fwd: incomplete history buffers (H1 and H2 go together)");
     NIC_REQUIRE(d->weights_t, "nic_mlp3_fwd: weights_t (the pre-transposed weight copy) is required");
@@ -1041,7 +1065,7 @@ int nic_mlp3_fwd(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float
     const int ks = (d->K + 1) / 2;
     const int t = ks <= 4 ? 4 : (ks <= 16 ? 16 : (ks <= 33 ? 33 : 48));
     nic::note_kernelf("mlp3_fwd_kernel<%d>", t);
-#define NIC_MLP3_FWD(KS) hipLaunchKernelGGL(mlp3_fwd_kernel<KS>, grid, block, 0, s, *d, d->weights_t, Y, X_hist, H1, H2)
+#define NIC_MLP3_FWD(KS) hipLaunchKernelGGL(mlp3_fwd_kernel<KS>, grid, block, 0, s, *d, d->weights_t, Y, X_hist, H1, H2, residual, Ysum)
     if (t == 4) NIC_MLP3_FWD(4);
     else if (t == 16) NIC_MLP3_FWD(16);
     else if (t == 33) NIC_MLP3_FWD(33);

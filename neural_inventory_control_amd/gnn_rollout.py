@@ -383,11 +383,11 @@ class GnnRollout:
             "output": [Mlp3Segment(self.edges1[t])],
         }
 
-    def _run_mlp(self, name, t, segs, prob):
+    def _run_mlp(self, name, t, segs, prob, residual=None, Ysum=None):
         m = self.mlp[name]
         hist = ((m.hist(m.X, t) if m.X is not None else None, m.hist(m.H1, t), m.hist(m.H2, t)) if hasattr(m, "H1")
                 else (None, None, None))
-        self._k("mlp3_fwd_" + name, ops.mlp3_fwd, self._desc(m, segs[name], prob), m.Y[t], *hist)
+        self._k("mlp3_fwd_" + name, ops.mlp3_fwd, self._desc(m, segs[name], prob), m.Y[t], *hist, residual, Ysum)
 
     def _forward_period(self, t, prob, demand_soa, shift):
         P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
@@ -401,10 +401,8 @@ class GnnRollout:
         edges0 = M["initial_edge"].Y[t]
         ops.segment_sum(self.agg_in[t], edges0, P.inc_off, P.inc_items, P.in_scale)
         ops.segment_sum(self.agg_out[t], edges0, P.out_off, P.out_items, P.out_scale)
-        self._run_mlp("node_update", t, segs, prob)
-        torch.add(M["initial_node"].Y[t], M["node_update"].Y[t], out=self.nodes1[t])
-        self._run_mlp("edge_update", t, segs, prob)
-        torch.add(edges0, M["edge_update"].Y[t], out=self.edges1[t])
+        self._run_mlp("node_update", t, segs, prob, M["initial_node"].Y[t], self.nodes1[t])   # nodes1 = nodes0 + update
+        self._run_mlp("edge_update", t, segs, prob, edges0, self.edges1[t])                   # edges1 = edges0 + update
         self._run_mlp("output", t, segs, prob)
         out = M["output"].Y[t][0]                                  # [E][ld] desired quantity per edge
         # proportional allocation of the warehouse's on-hand stock over its outgoing edges + self loop (:111-138, :1435-1492)

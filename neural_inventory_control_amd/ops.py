@@ -219,9 +219,10 @@ def mlp3_desc(segments, weights, n_entities, n_scenarios, ldb, n_out, out_act, h
     return d
 
 
-def mlp3_fwd(desc, Y, X_hist=None, H1=None, H2=None):
+def mlp3_fwd(desc, Y, X_hist=None, H1=None, H2=None, residual=None, Ysum=None):
+    """Y = MLP(gathered inputs); with `residual` / `Ysum` also Ysum = residual + Y in the same launch."""
     _dev(Y)
-    check(lib().nic_mlp3_fwd(desc, ptr(Y), ptr(X_hist), ptr(H1), ptr(H2), current_stream()))
+    check(lib().nic_mlp3_fwd_residual(desc, ptr(Y), ptr(X_hist), ptr(H1), ptr(H2), ptr(residual), ptr(Ysum), current_stream()))
     return Y
 
 
