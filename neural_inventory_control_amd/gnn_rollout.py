@@ -67,8 +67,11 @@ class GraphPlan:
         out = [[e for e in range(self.n_edges) if src[e] == n and e not in supplier_edges] for n in range(self.n_nodes)]
         self.inc_off, self.inc_items = _csr(inc, device)
         self.out_off, self.out_items = _csr(out, device)
+        # both aggregations as ONE segment sum into a [rows][2 * n_nodes][ldb] buffer (incoming sums first, then outgoing)
+        self.agg_off, self.agg_items = _csr(inc + out, device)
         self.in_scale = torch.tensor([1.0 / max(d, 1) ** 0.5 for d in in_deg], device=device)
         self.out_scale = torch.tensor([1.0 / max(d, 1) ** 0.5 for d in out_deg], device=device)
+        self.agg_scale = torch.cat([self.in_scale, self.out_scale])
         # adjoints of the aggregation: edge e receives from its target's `incoming` / its source's `outgoing` gradient
         self.e_from_tgt = _csr([[tgt[e]] if (tgt[e] >= 0 and e not in demand_edges) else [] for e in range(self.n_edges)], device)
         self.e_from_src = _csr([[src[e]] if (src[e] >= 0 and e not in supplier_edges) else [] for e in range(self.n_edges)], device)
@@ -241,7 +244,7 @@ class GnnRollout:
                                self._mode_now, self._keep_inputs and bool(self.keep_inputs))
                     for name, k, ne in zip(MODULES, ks, ents)}
         self._graphs, self._eager_runs = {}, 0
-        self.agg_in, self.agg_out = z(T, 32, N, ld), z(T, 32, N, ld)
+        self.agg = z(T, 32, 2 * N, ld)   # message aggregation: [:, :N] over incoming edges, [:, N:] over outgoing edges
         self.nodes1, self.edges1 = z(T, 32, N, ld), z(T, 32, E, ld)
         self.sums, self.ratio, self.scale = z(T, ld), z(T, ld), z(T, ld)
         if train:
@@ -378,7 +381,7 @@ class GnnRollout:
         return {
             "initial_node": [Mlp3Segment(self.feat[t])],
             "initial_edge": [Mlp3Segment(nodes0, P.src), Mlp3Segment(nodes0, P.tgt), Mlp3Segment(P.lead, None, per_scenario=False)],
-            "node_update": [Mlp3Segment(nodes0), Mlp3Segment(self.agg_in[t]), Mlp3Segment(self.agg_out[t])],
+            "node_update": [Mlp3Segment(nodes0), Mlp3Segment(self.agg[t][:, :P.n_nodes]), Mlp3Segment(self.agg[t][:, P.n_nodes:])],
             "edge_update": [Mlp3Segment(edges0), Mlp3Segment(self.nodes1[t], P.src), Mlp3Segment(self.nodes1[t], P.tgt)],
             "output": [Mlp3Segment(self.edges1[t])],
         }
@@ -399,8 +402,7 @@ class GnnRollout:
         self._run_mlp("initial_node", t, segs, prob)
         self._run_mlp("initial_edge", t, segs, prob)
         edges0 = M["initial_edge"].Y[t]
-        ops.segment_sum(self.agg_in[t], edges0, P.inc_off, P.inc_items, P.in_scale)
-        ops.segment_sum(self.agg_out[t], edges0, P.out_off, P.out_items, P.out_scale)
+        ops.segment_sum(self.agg[t], edges0, P.agg_off, P.agg_items, P.agg_scale)
         self._run_mlp("node_update", t, segs, prob, M["initial_node"].Y[t], self.nodes1[t])   # nodes1 = nodes0 + update
         self._run_mlp("edge_update", t, segs, prob, edges0, self.edges1[t])                   # edges1 = edges0 + update
         self._run_mlp("output", t, segs, prob)
