@@ -479,6 +479,57 @@ def test_small_route_in_kernel_weight_gradients_match_the_gemm_path(workload, n,
         assert float((x - y).norm() / (y.norm() + 1e-30)) < 5e-6
 
 
+@pytest.mark.parametrize("variant", ["one_store_ws3", "serial_one_echelon", "serial_ww4"])
+def test_small_route_run_time_structure_kernels_match_the_per_period_route(variant):
+    """The whole-horizon kernels are compiled with the structure of the two chains the reference ships as constants; every other
+    supported chain takes the run-time-structure instantiation.  Three such chains (store pipeline of 3 slots; store + warehouse +
+    ONE echelon; a 4-slot warehouse pipeline) against the engine's own per-period route: costs, final state, gradients."""
+    from collections import defaultdict
+    import copy
+    from neural_inventory_control_amd import workloads
+    if variant == "one_store_ws3":
+        setting, policy, _, _, _ = workloads.get("cfg2")
+        setting = copy.deepcopy(setting)
+        setting["store_params"]["lead_time"] = {"sample_across_stores": False, "vary_across_samples": False, "expand": True, "value": 3}
+        setting["store_params"]["initial_inventory"]["inventory_periods"] = 3
+    else:
+        setting, policy, _, _, _ = workloads.get("cfg4")
+        setting, policy = copy.deepcopy(setting), copy.deepcopy(policy)
+        if variant == "serial_one_echelon":
+            setting["problem_params"]["n_extra_echelons"] = 1
+            setting["echelon_params"] = {"holding_cost": [0.1], "lead_time": [3]}
+            policy["output_sizes"]["master"] = 3   # one sigmoid head per echelon + warehouse + store
+        else:
+            setting["warehouse_params"] = {"holding_cost": 0.5, "lead_time": 4}
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    n, T = 333, 13
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
+                  n, obs, setting["seeds"])
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    F = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
+    if policy["name"] != "vanilla_one_store":
+        F += sum(int(np.prod(data[k].shape[1:])) for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
+                 if k in data)
+    res = {}
+    for small in (True, False):
+        torch.manual_seed(9)
+        model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+        eng = FusedRollout(model, setting["problem_params"], DEV)
+        eng.use_small = small
+        eng.materialize(F)
+        total, rep = eng.run(data, T, 3, train=True, observation_params=obs)
+        torch.cuda.synchronize()
+        assert (eng.small is not None) == small
+        res[small] = (float(total), float(rep), [p.grad.clone() for p in model.parameters()],
+                      {k: v.clone() for k, v in eng.final_state().items()})
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 2e-6 * abs(b[1])
+    for x, y in zip(a[2], b[2]):
+        assert float((x - y).norm() / (y.norm() + 1e-30)) < 2e-5
+    for k in b[3]:
+        torch.testing.assert_close(a[3][k], b[3][k], **STATE_TOL)
+
+
 @pytest.mark.parametrize("name", ["cfg2_one_store_backlogged_vanilla", "cfg4_serial_vanilla"])
 def test_small_route_equals_per_period_route(name):
     """FusedRollout takes the whole-horizon route for these policies; it must agree with its own per-period route."""
