@@ -81,3 +81,33 @@ def test_bench_over_a_one_rank_rccl_group(workload):
     assert forced["n_gpus"] == 1 and "RCCL" in json.dumps(forced["config"]) and "RCCL" not in json.dumps(plain["config"])
     a, b = (o["config"]["mean_cost_per_store_period"] for o in outs)
     assert abs(a - b) <= 1e-6 * abs(a), (a, b)
+
+
+@pytest.mark.parametrize("workload", ["cfg3", "cfg2", "base_stock"])
+def test_bench_line_contract(workload):
+    """`python bench.py` prints ONE JSON line with the driver's keys; value = units / time, the roofline object is internally
+    consistent (frac = achieved / peak, bound-specific unit), and the CPU baseline leg ran on a bounded sample."""
+    root = os.path.dirname(HERE)
+    small = {"cfg3": ["--scenarios", "4096", "--periods", "10"], "cfg2": ["--scenarios", "8192", "--periods", "20"],
+             "base_stock": ["--scenarios", "8192", "--periods", "20"]}[workload]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "256"] + small, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["scaling"] == "weak" and out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic"
+    cfg = out["config"]
+    assert "workload" in cfg and "model" not in cfg
+    units = cfg["global_scenarios"] * cfg["stores"] * cfg["periods"] * out["steps"]
+    assert abs(out["value"] - units / (out["ms_per_step"] * 1e-3 * out["steps"])) <= 1e-6 * out["value"]
+    rf = out["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == ("GB/s" if rf["bound"] == "hbm" else "TFLOP/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 2e-3 and 0 < rf["frac"] < 1 and "kernel" in rf and "traffic" in rf
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["host_cores"] >= cb["cores"] and "sample" in cb
+    assert cb["unit"] == out["unit"]
