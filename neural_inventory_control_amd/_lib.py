@@ -141,6 +141,19 @@ def library_built():
     return os.path.isfile(LIB_PATH)
 
 
+def _init_torch_device_first():
+    """PyTorch's HIP context must exist BEFORE this library is mapped: loading it registers its code objects with the HIP
+    runtime, and when that happens ahead of torch's own (lazy) device initialisation every later launch from this library fails
+    with "no ROCm-capable device is detected" while torch itself keeps working (measured: build() followed by smoke() in one
+    process).  No-op without a GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def load_library(path=None):
     """dlopen the C-ABI library and attach prototypes.  Works without a GPU (symbols only)."""
     global _lib
@@ -151,6 +164,7 @@ def load_library(path=None):
         raise NicUnavailableError(
             f"{p} not found: build the HIP extension first (python -m neural_inventory_control_amd.build). "
             "This package has no CPU fallback.")
+    _init_torch_device_first()
     lib = C.CDLL(p)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

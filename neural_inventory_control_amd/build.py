@@ -59,6 +59,8 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         import ctypes
+        from ._lib import _init_torch_device_first
+        _init_torch_device_first()   # (on a GPU box: torch's HIP context first, see _lib.load_library)
         ctypes.CDLL(OUT)  # fail the build on unresolved symbols
     return OUT
 

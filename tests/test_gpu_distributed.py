@@ -111,3 +111,20 @@ def test_bench_line_contract(workload):
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["host_cores"] >= cb["cores"] and "sample" in cb
     assert cb["unit"] == out["unit"]
+
+
+def test_library_mapped_before_any_torch_device_use_still_launches():
+    """build() and smoke() in one process: the C-ABI library is mapped (and its code objects registered with the HIP runtime)
+    before PyTorch has touched the device.  `load_library` initialises torch's device first; without that every launch from
+    the library failed with "no ROCm-capable device is detected"."""
+    root = os.path.dirname(HERE)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from neural_inventory_control_amd import _lib\n"
+            "_lib.load_library()\n"
+            "import torch\n"
+            "from neural_inventory_control_amd import ops\n"
+            "x = torch.ones(64, device='cuda'); y = torch.zeros(64, device='cuda')\n"
+            "_lib.check(_lib.lib().nic_axpy(_lib.ptr(y), _lib.ptr(x), 2.0, 64, _lib.current_stream()))\n"
+            "torch.cuda.synchronize(); assert float(y.sum()) == 128.0; print('LAUNCH_OK')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "LAUNCH_OK" in r.stdout, r.stderr[-2000:]
