@@ -45,8 +45,8 @@ def _per_store_table(n_samples, n_stores, spec, seed, integer):
     """
     np.random.seed(seed)
     draw = np.random.randint if integer else np.random.uniform
-    if _flag(spec, "file_location"):
-        raise NotImplementedError("oracle: file-backed parameters are outside the synthetic path")
+    if _flag(spec, "file_location"):  # per-sample values kept on disk (:254-255); later flags still apply to `value`
+        spec = dict(spec, value=torch.load(spec["file_location"], map_location="cpu")[:n_samples])
     if _flag(spec, "sample_across_stores"):
         return torch.tensor(draw(*spec["range"], n_stores)).expand(n_samples, -1)
     if _flag(spec, "vary_across_samples"):
@@ -186,14 +186,28 @@ def generate_scenario_data(periods, problem_params, store_params, warehouse_para
     return {k: v.float() for k, v in out.items() if v is not None}
 
 
-def split_data_by_period(data, period_ranges, observation_params):
-    """DatasetCreator.split_by_period (data_handling.py:431-448): per-sample tensors are shared, `demands` and the time
-    features are sliced along the period axis.  period_ranges: strings like '(0, 111)' as the YAML holds them."""
-    by_period = ["demands"] + list(observation_params.get("time_features") or [])
+def split_data_by_period(data, period_ranges, observation_params, problem_params=None):
+    """DatasetCreator.split_by_period (data_handling.py:431-448) with the key lists of define_how_to_split_data (:84-122): per-sample
+    tensors are shared, `demands` and the time features are sliced along the period axis, and ONLY the listed keys survive -
+    warehouse / echelon entries are listed when the problem has such locations (:94-104), so a setting that configures
+    warehouse_params with n_warehouses = 0 loses its zero-width warehouse tensors here.  period_ranges: strings like '(0, 111)'."""
+    time_feats = list(observation_params.get("time_features") or [])
+    sample_feats = list(observation_params.get("sample_features") or [])
+    by_period = ["demands"] + time_feats
+    by_sample = ["underage_costs", "holding_costs", "lead_times", "initial_inventories"]
+    if problem_params is None or problem_params["n_warehouses"] > 0:
+        by_sample += ["initial_warehouse_inventories", "warehouse_lead_times", "warehouse_holding_costs", "warehouse_edge_costs"]
+    if problem_params is None or problem_params["n_extra_echelons"] > 0:
+        by_sample += ["initial_echelon_inventories", "echelon_holding_costs", "echelon_lead_times"]
+    static = observation_params.get("include_static_features") or {}
+    by_sample += [k for k in ("mean", "std") if static.get(k)]
+    by_sample += sample_feats
     out = []
     for rng in period_ranges:
         sl = slice(*map(int, str(rng).strip("() ").split(",")))
-        out.append({k: (v[:, :, sl] if k in by_period else v.clone()) for k, v in data.items()})
+        this = {k: data[k].clone() for k in by_sample if k in data}
+        this.update({k: data[k][:, :, sl] for k in by_period if k in data})
+        out.append(this)
     return out
 
 

@@ -110,6 +110,11 @@ CASES = {
     "f4_real_one_store_data_driven": dict(
         setting="one_store_real_data_lost_demand", policy="data_driven_net", n=40, periods=12, ignore=4, torch_seed=43,
         hidden=[32, 32], real=True, period_range="(0, 48)", one_store_from_21=True),
+    # the reference's "read file" example: per-sample lead times (4..6), holding and underage costs from tensors on disk, a per-sample
+    # feature column (store number) from a CSV, profit objective, data-driven net
+    "f4_real_one_store_read_files_data_driven": dict(
+        setting="one_store_real_data_read_file_example", policy="data_driven_net", n=40, periods=12, ignore=4, torch_seed=44,
+        hidden=[32, 32], real=True, period_range="(0, 48)", one_store_from_21=True),
     "f4_real_one_store_just_in_time": dict(
         setting="one_store_real_data_lost_demand", policy="just_in_time", n=40, periods=12, ignore=4, torch_seed=37,
         real=True, period_range="(0, 48)", one_store_from_21=True),

@@ -42,7 +42,7 @@ def _build(g, need_data=True):
                                           c["observation_params"], c["seeds"])
     finally:
         os.chdir(cwd)
-    (data,) = orc.split_data_by_period(full, [c["period_range"]], c["observation_params"])
+    (data,) = orc.split_data_by_period(full, [c["period_range"]], c["observation_params"], c["problem_params"])
     return c, data
 
 

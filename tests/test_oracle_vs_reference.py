@@ -100,7 +100,7 @@ def test_real_data_cases_fresh_products_and_weeks(name):
             (total / (n * periods * cs["problem_params"]["n_stores"])).backward()
         full = orc.generate_scenario_data(None, cs_o["problem_params"], cs_o["store_params"], cs_o["warehouse_params"],
                                           cs_o["echelon_params"], n, obs_o, cs_o["seeds"])
-    (data_o,) = orc.split_data_by_period(full, [rng], obs_o)
+    (data_o,) = orc.split_data_by_period(full, [rng], obs_o, cs_o["problem_params"])
     assert set(data_r) == set(data_o)
     for k in data_r:
         assert torch.equal(data_r[k], data_o[k]), k
