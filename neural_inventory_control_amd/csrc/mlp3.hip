@@ -537,7 +537,11 @@ __global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_e
 constexpr int kHistWaves = 4;
 constexpr int kHistBlocks = 512;   // persistent workgroups (two per CU)
 
-template <int KG, bool GATHER>
+// TAIL: input rows beyond the KG full 32-row blocks (K = 32 KG + TAIL, TAIL <= 4; e.g. the edge MLP's [source | target | lead
+// time] = 65 rows).  A 32-row MFMA block for one row costs 32 MFMAs per item (a fifth of the kernel); the tail rows' weight-
+// gradient column and input gradient are ~40 vector instructions each instead.
+constexpr int kMaxTail = 4;
+template <int KG, bool GATHER, int TAIL>
 __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp3_bwd_hist_kernel(
     NicMlp3Desc d, const float* __restrict__ weights, const float* __restrict__ dY, const float* __restrict__ Yo,
     const float* __restrict__ Xh, const float* __restrict__ H1, const float* __restrict__ H2, float* __restrict__ dX,
@@ -545,6 +549,7 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
     __shared__ float sW[32 * 32 * (KG + 2)];            // W1 [32][32*KG] | W2 [32][32] | W3 [32][32]; reused for the reduction
     __shared__ float tiles[kHistWaves * kTile];
     __shared__ float sbias[3 * 32];
+    __shared__ float sWt[32 * kMaxTail], stail[32 * kMaxTail];   // tail columns of W1 [n][tail]; their reduced weight gradients
     float* const sW1 = sW;
     float* const sW2 = sW + 32 * 32 * KG;
     float* const sW3 = sW2 + 32 * 32;
@@ -579,6 +584,7 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
             sW2[idx] = v2[u];
             sW3[idx] = (idx >> 5) < d.n_out ? v3[u] : 0.f;
         }
+        if (TAIL > 0 && threadIdx.x < 32 * TAIL) sWt[threadIdx.x] = W1[(threadIdx.x / TAIL) * K + 32 * KG + threadIdx.x % TAIL];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, h = lane >> 5, i = j;
@@ -588,6 +594,9 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
 
     f32x16 g1[KG], g2, g3;
     float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f;
+    float gtail[TAIL > 0 ? TAIL : 1];   // lane (h, n): sum over its 16 columns of dz1[n][c] x_tail[c]
+#pragma unroll
+    for (int tt = 0; tt < (TAIL > 0 ? TAIL : 1); ++tt) gtail[tt] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         g2[r] = 0.f;
@@ -797,6 +806,23 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (TAIL > 0) {   // rows 32 KG .. 32 KG + TAIL - 1 on the vector unit
+#pragma unroll
+            for (int tt = 0; tt < TAIL; ++tt) {
+                const int k = 32 * KG + tt;
+                float xt[16];   // the row's columns h*16 .. h*16+15 (the same for every lane of a half)
+                if (!GATHER) row_owner(rX, h * 64, k * hs4, xt);
+                else gather_row_owner(k, e, ch, xt);
+                float part = 0.f, gx = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) part = fmaf(at[s2], xt[s2], part);
+                gtail[tt] += part;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gx = fmaf(sWt[crow(r, h) * TAIL + tt], dz[r], gx);
+                gx += __shfl_xor(gx, 32);
+                if (dX && live && h == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gx), rD, jl * 4, k * el4, 0);
+            }
+        }
     }
     // the four wavefronts add their accumulators in wave order through LDS (over the weight staging area), then the workgroup
     // adds the sum to its slab slot
@@ -824,6 +850,13 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
                 sbias[i] = turn ? sbias[i] + gb1 : gb1;
                 sbias[32 + i] = turn ? sbias[32 + i] + gb2 : gb2;
                 sbias[64 + i] = turn ? sbias[64 + i] + gb3 : gb3;
+            }
+            if (TAIL > 0) {
+#pragma unroll
+                for (int tt = 0; tt < TAIL; ++tt) {
+                    const float tot = gtail[tt] + __shfl_xor(gtail[tt], 32);   // both column halves of row i
+                    if (h == 0) stail[tt * 32 + i] = turn ? stail[tt * 32 + i] + tot : tot;
+                }
             }
         }
         __syncthreads();
@@ -859,6 +892,10 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
     }
     if (threadIdx.x < 32) {
         s1[(int64_t)threadIdx.x * lds1 + K] += sbias[threadIdx.x];
+        if (TAIL > 0) {
+#pragma unroll
+            for (int tt = 0; tt < TAIL; ++tt) s1[(int64_t)threadIdx.x * lds1 + 32 * KG + tt] += stail[tt * 32 + threadIdx.x];
+        }
         s2[(int64_t)threadIdx.x * lds2 + 32] += sbias[32 + threadIdx.x];
         if ((int)threadIdx.x < d.n_out) s3[(int64_t)threadIdx.x * lds3 + 32] += sbias[64 + threadIdx.x];
     }
@@ -1127,19 +1164,25 @@ int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, con
                 "nic_mlp3_bwd_hist: a buffer's rows must span less than 2 GiB (32-bit row offsets)");
     const dim3 grid(kHistBlocks), block(64 * kHistWaves);
     hipStream_t s = nic::as_stream(stream);
-    const int kg = (d->K + 31) / 32;
-    nic::note_kernelf("mlp3_bwd_hist_kernel<%d,%s>", kg, X_hist ? "stored" : "gather");
-#define NIC_MLP3_BH(KG, G)                                                                                                    \
-    hipLaunchKernelGGL((mlp3_bwd_hist_kernel<KG, G>), grid, block, 0, s, *d, d->weights, dY, Y, X_hist, H1, H2, dX, slab1, lds1,  \
-                       slab2, lds2, slab3, lds3)
+    // K = 32 kg + tail: up to four rows past the last full block are handled on the vector unit instead of a 32-row MFMA block
+    int kg = (d->K + 31) / 32, tail = 0;
+    if (d->K >= 32 && d->K % 32 >= 1 && d->K % 32 <= 1) kg = d->K / 32, tail = d->K % 32;
+    nic::note_kernelf("mlp3_bwd_hist_kernel<%d,%s%s>", kg, X_hist ? "stored" : "gather", tail ? ",tail" : "");
+#define NIC_MLP3_BH(KG, G, TL)                                                                                                \
+    hipLaunchKernelGGL((mlp3_bwd_hist_kernel<KG, G, TL>), grid, block, 0, s, *d, d->weights, dY, Y, X_hist, H1, H2, dX, slab1,     \
+                       lds1, slab2, lds2, slab3, lds3)
     if (X_hist) {
-        if (kg == 1) NIC_MLP3_BH(1, false);
-        else if (kg == 2) NIC_MLP3_BH(2, false);
-        else NIC_MLP3_BH(3, false);
+        if (tail == 1 && kg == 1) NIC_MLP3_BH(1, false, 1);
+        else if (tail == 1 && kg == 2) NIC_MLP3_BH(2, false, 1);
+        else if (kg == 1) NIC_MLP3_BH(1, false, 0);
+        else if (kg == 2) NIC_MLP3_BH(2, false, 0);
+        else NIC_MLP3_BH(3, false, 0);
     } else {
-        if (kg == 1) NIC_MLP3_BH(1, true);
-        else if (kg == 2) NIC_MLP3_BH(2, true);
-        else NIC_MLP3_BH(3, true);
+        if (tail == 1 && kg == 1) NIC_MLP3_BH(1, true, 1);
+        else if (tail == 1 && kg == 2) NIC_MLP3_BH(2, true, 1);
+        else if (kg == 1) NIC_MLP3_BH(1, true, 0);
+        else if (kg == 2) NIC_MLP3_BH(2, true, 0);
+        else NIC_MLP3_BH(3, true, 0);
     }
 #undef NIC_MLP3_BH
     return nic::check_launch("nic_mlp3_bwd_hist");
