@@ -1,13 +1,20 @@
-// Fused three-layer 32-wide MLP over gathered inputs (include/nic_rollout.h: nic_mlp3_fwd / nic_mlp3_bwd) and the segment
-// sum that aggregates messages / scatters gradients over the static supply graph (nic_segment_sum).
+// Fused three-layer 32-wide MLP over gathered inputs and the graph glue around it (include/nic_rollout.h):
+//   nic_mlp3_fwd / nic_mlp3_fwd_residual   forward (+ optional residual output)           mlp3_fwd_kernel<KS>
+//   nic_mlp3_bwd_hist                      backward, weight gradients contracted in-kernel  mlp3_bwd_hist_kernel<KG, GATHER, TAIL>   (what the GNN engine runs)
+//   nic_mlp3_bwd / nic_mlp3_bwd_fused      backward with a dz history / without any history (kept as references and as the fallback)
+//   nic_segment_sum / nic_segment_sum_terms  message aggregation and the adjoints of every gather / residual connection
+//   nic_gnn_alloc_fwd / nic_gnn_alloc_bwd  proportional allocation head
 //
-// One wavefront = 32-scenario chunks of ONE entity (node or edge), so every gather index is wave-uniform: the K input rows of a
-// column are K row pointers computed on the scalar unit from the segment table + the entity's map entry; lanes only add their
-// scenario offset.  The layers run on the matrix cores exactly like csrc/small_rollout.hip: A = weights (lane l holds
-// W[i = l & 31][kk = l >> 5]), B = activations (lane = scenario), and MFMA step s of layers 2 / 3 is defined to contract over
-// k = crow(s, h) - the row the previous layer's accumulator register s holds - so activations never move between layers.
-// Both halves of the wave carry the same 32 scenarios and own different feature rows; every history row is written once.
-// FP32 (v_mfma_f32_32x32x2_f32: exact products, f32 accumulate); ELU as in the other kernels (small_rollout_body.h).
+// One wavefront = 32-scenario chunks of ONE entity (node or edge), so every gather index is wave-uniform.  The layers run on the
+// matrix cores exactly like csrc/small_rollout.hip: A = weights (lane l holds W[i = l & 31][kk = l >> 5]), B = activations
+// (lane = scenario), and MFMA step s of layers 2 / 3 is defined to contract over k = crow(s, h) - the row the previous layer's
+// accumulator register s holds - so activations never move between layers.  Both halves of the wave carry the same 32 scenarios
+// and own different feature rows; every history row is written once.  FP32 (v_mfma_f32_32x32x2_f32: exact products, f32
+// accumulate); ELU as in the other kernels (small_rollout_body.h).
+// What the compiled code taught (DESIGN.md §4 "reading the ISA"): resolve the K input-row pointers across the LANES (the scalar
+// unit was the bottleneck), load in unconditional batches (a conditional load in a loop is a dependent round trip per iteration),
+// keep loop-invariant scalar offsets / lane masks from being hoisted into spilled SGPRs, address history buffers through buffer
+// descriptors with one 32-bit lane offset each.
 #include "nic_common.h"
 #include "small_rollout_body.h"
 

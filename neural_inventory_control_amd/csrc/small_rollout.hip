@@ -3,7 +3,10 @@
 // step / head are per-lane code shared with the host build (small_rollout_body.h, which also holds the scalar per-scenario
 // restatement of the whole kernel that tests/hostsim checks against the golden vectors).
 // HBM traffic is 4 B (demand) + 4 B (reward) per scenario-period plus, when training, the stored activations
-// (4 * (F + 32 * n_hidden + n_out) B).
+// (4 * (F + 32 * n_hidden + n_out) B).  The backward sweep contracts the weight gradients itself (template WG: accumulators in
+// registers over the whole horizon, one partial gradient per wavefront), and the two chains the reference ships are compiled with
+// their structure as constants (template SHAPE) - a kernel whose duration is the instruction stream of ONE wavefront per SIMD
+// cannot afford the select chains of run-time pipeline offsets.
 #include <stdlib.h>
 
 #include "nic_common.h"
