@@ -310,7 +310,7 @@ def main():
                                demand_soa=sc.demands_soa, discrete_allocation=discrete)
         return total
 
-    if eng is None:  # policies outside the fused engine (GNN, user plugins): the reference-style loop
+    if eng is None or (closed_form and args.graph):  # reference-style loop through the Trainer (with --graph: whole step replayed)
         from neural_inventory_control_amd.environment import Simulator
         from neural_inventory_control_amd.loss_functions import PolicyLoss
         from neural_inventory_control_amd.trainer import Trainer
@@ -336,7 +336,7 @@ def main():
             return total.detach()
 
     def step():
-        if eng is None:
+        if eng is None or (closed_form and args.graph and not args.eval):
             return generic_step()
         if args.eval:
             return eval_step()

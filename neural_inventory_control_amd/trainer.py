@@ -189,6 +189,7 @@ class Trainer:
             if eng is None or eng.model is not model:
                 eng = self._engines[(id(model), "closed_form")] = ClosedFormRollout(model, problem_params, self.device)
             if eng.shapes_ok(data_batch):
+                self._last_engine = eng
                 return eng.run(data_batch, periods, ignore_periods, train=train, observation_params=observation_params,
                                discrete_allocation=discrete_allocation)
         engine_cls = None
@@ -219,6 +220,7 @@ class Trainer:
             self._fused_grads_ready = train
             return total, reported
 
+        self._last_engine = None
         batch_reward, reward_to_report = 0, 0
         observation, _ = simulator.reset(periods, problem_params, data_batch, observation_params)
         for t in range(periods):
@@ -278,7 +280,10 @@ class Trainer:
                 out_total, out_rep = total.detach(), (rep.detach() if torch.is_tensor(rep) else rep)
             # the captured env-step launches read the compact cost / lead-time tables of THIS EnvProblem (built from
             # `static` at capture time), not `static` itself: they are refreshed from every incoming batch below
-            st.update(static=static, graph=graph, total=out_total, rep=out_rep, scale=scale, prob=simulator._prob)
+            # (a closed-form policy's whole-horizon engine owns the EnvProblem its captured launch reads)
+            eng_ = getattr(self, "_last_engine", None)
+            st.update(static=static, graph=graph, total=out_total, rep=out_rep, scale=scale,
+                      prob=simulator._prob if eng_ is None else eng_.prob)
         if st["scale"] != scale:
             raise RuntimeError("captured training step: the global batch size changed; disable use_step_graph")
         incoming = simulator._problem_for(problem_params, {k: v for k, v in data_batch.items() if torch.is_tensor(v)},

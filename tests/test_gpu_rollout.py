@@ -766,8 +766,10 @@ def test_main_run_driver_trains_tests_and_saves(tmp_path, capsys):
         main_run.run("deploy", setting, hyper)
 
 
-@pytest.mark.parametrize("name", ["f1_one_warehouse_gnn", "cfg2_one_store_backlogged_capped", "cfg4_serial_echelon_stock"])
-def test_captured_generic_training_step_matches_eager(name):
+@pytest.mark.parametrize("name,fused", [("f1_one_warehouse_gnn", False), ("cfg2_one_store_backlogged_capped", False),
+                                        ("cfg4_serial_echelon_stock", False), ("cfg2_one_store_backlogged_capped", True),
+                                        ("cfg2_one_store_backlogged_base_stock", True), ("cfg4_serial_echelon_stock", True)])
+def test_captured_generic_training_step_matches_eager(name, fused):
     """Policies on the generic route (GNN, closed-form): the whole training step of a batch - every period's policy and
     env-step launches plus the autograd sweep - captured into one HIP graph (Trainer.use_step_graph) gives the same loss
     and gradients as eager execution, also after the batch contents change."""
@@ -795,7 +797,9 @@ def test_captured_generic_training_step_matches_eager(name):
         _load(model, g)
         tr = Trainer(device=DEV)
         tr.use_step_graph = graph
-        tr.use_fused_rollout = False  # this test is about the GENERIC route (the closed-form cases have a fused kernel too)
+        # fused = False: the GENERIC route (one env-step launch per period + autograd); fused = True: the closed-form policies'
+        # whole-horizon kernel - its launch, the tiny level network's autograd and the totals, all inside the captured step
+        tr.use_fused_rollout = fused
         tr._global_batch = c["n"]
         sim, lf = Simulator(device=DEV), PolicyLoss()
         out = []
