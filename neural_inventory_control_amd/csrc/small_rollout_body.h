@@ -28,17 +28,17 @@ constexpr int SR_MAXE = 3;
 // exec mask and a scalar branch around ~8 vector instructions, 48 times per scenario-period in the whole-horizon kernels, with
 // both sides executed anyway whenever the lanes of a wavefront disagree.  Same values as before, bit for bit.)
 NIC_HD float expm1_neg(float x) {
-    const float xs = x > -0.35f ? x : 0.f;   // series argument (the other branch's inputs would overflow nothing, but stay tidy)
-    const float p = fmaf(xs, fmaf(xs, fmaf(xs, fmaf(xs, fmaf(xs, 1.f / 720.f, 1.f / 120.f), 1.f / 24.f), 1.f / 6.f), 0.5f), 1.f);
+    const float p = fmaf(x, fmaf(x, fmaf(x, fmaf(x, fmaf(x, 1.f / 720.f, 1.f / 120.f), 1.f / 24.f), 1.f / 6.f), 0.5f), 1.f);
 #if defined(__HIP_DEVICE_COMPILE__)
     const float e = __expf(x) - 1.f;
 #else
     const float e = expf(x) - 1.f;
 #endif
-    return x > -0.35f ? xs * p : e;
+    return x > -0.35f ? x * p : e;   // (the unselected form may overflow to inf for a large |x|; it is only ever discarded)
 }
+// elu(x) = x for x > 0, expm1(x) otherwise.  (NaN stays NaN: both comparisons are false, exp(NaN) - 1 is selected.)
 NIC_HD float elu1(float x) {
-    const float neg = expm1_neg(x > 0.f ? 0.f : x);   // (NaN stays NaN)
+    const float neg = expm1_neg(x);
     return x > 0.f ? x : neg;
 }
 NIC_HD float elu1_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
