@@ -28,6 +28,27 @@ constexpr int kBlock = 64;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// ELU of an accumulator: the series of nic::expm1_neg on PAIRS of elements with packed FP32 FMAs (v_pk_fma_f32: two lanes' worth
+// of work per instruction; each component rounds exactly like the scalar fmaf chain, so the values are those of nic::elu1).  The
+// activations are more than half of the forward kernel's instruction stream (48 per scenario-period).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void elu16(const f32x16& z, float (&out)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = {z[r], z[r + 1]};
+        f32x2 p = __builtin_elementwise_fma(x, (f32x2)(1.f / 720.f), (f32x2)(1.f / 120.f));
+        p = __builtin_elementwise_fma(x, p, (f32x2)(1.f / 24.f));
+        p = __builtin_elementwise_fma(x, p, (f32x2)(1.f / 6.f));
+        p = __builtin_elementwise_fma(x, p, (f32x2)(0.5f));
+        p = __builtin_elementwise_fma(x, p, (f32x2)(1.f));
+        const f32x2 sp = x * p;
+        const float e0 = __expf(x.x) - 1.f, e1 = __expf(x.y) - 1.f;
+        const float n0 = x.x > -0.35f ? sp.x : e0, n1 = x.y > -0.35f ? sp.y : e1;
+        out[r] = x.x > 0.f ? x.x : n0;
+        out[r + 1] = x.y > 0.f ? x.y : n1;
+    }
+}
+
 // Shape specialisation.  The per-lane env step / head bodies (small_rollout_body.h) index the st[16] register array with offsets
 // built from the descriptor's pipeline lengths; with those as run-time values every access is a 16-way select chain whose 64-bit
 // lane masks live in (spilled) SGPRs - 4,100 instructions per period, a quarter of them v_readlane / s_nop spill traffic, on a
@@ -110,8 +131,7 @@ __global__ __launch_bounds__(64) void small_rollout_fwd_mfma_kernel(NicSmallRoll
         for (int r = 0; r < 16; ++r) acc[r] = cB[0][r];
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aW1[s], h ? st[2 * s + 1] : st[2 * s], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hcur[r] = elu1(acc[r]);
+        elu16(acc, hcur);
         if (states_hist && live) {
             if (h == 0) {
 #pragma unroll
@@ -127,8 +147,7 @@ __global__ __launch_bounds__(64) void small_rollout_fwd_mfma_kernel(NicSmallRoll
             for (int r = 0; r < 16; ++r) acc[r] = cB[l][r];
 #pragma unroll
             for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aWh[l - 1][s], hcur[s], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hcur[r] = elu1(acc[r]);
+            elu16(acc, hcur);
             if (states_hist && live) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hidden_hist[(int64_t)(l * SR_H + crow(r, h)) * tl + t * ldb + b] = hcur[r];
