@@ -235,7 +235,10 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
     for (int s = 0; s < 16; ++s) aW1T[s] = (i < d.F) ? weights[crow(s, h) * d.F + i] : 0.f;
 
     const SrStatics c = sr_load_statics(d, b);
-    const float gr = g_reward.p[b * g_reward.scn_stride];
+    // WG: a dead lane (shadowing scenario 0) gets a zero cost gradient, so every dz it produces is exactly zero and it adds
+    // nothing to the weight gradients - no per-element masking of the A operands.  (The dz-history form must NOT do this: its
+    // dead lanes store what scenario 0's own lane stores.)
+    const float gr = (WG && !live) ? 0.f : g_reward.p[b * g_reward.scn_stride];
     float gn[SR_MAXF];
 #pragma unroll
     for (int k = 0; k < SR_MAXF; ++k) gn[k] = 0.f;
@@ -257,10 +260,10 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
 #pragma unroll
     for (int l = 0; l < (NL > 1 ? NL - 1 : 1); ++l) sbH[l] = 0.f;
     // column-owner registers (rows crow(r, h) of scenario column j) -> row-owner operand (row j, columns h*16 + s); dead lanes
-    // shadow scenario 0 and must not be counted twice: their column of the A operand is zero
+    // shadow scenario 0 and must not be counted twice: their dz are zero (see gr)
     auto to_A = [&](const float (&v)[16], float (&out)[16]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tA[crow(r, h) * 33 + j] = live ? v[r] : 0.f;
+        for (int r = 0; r < 16; ++r) tA[crow(r, h) * 33 + j] = v[r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) out[s2] = tA[j * 33 + h * 16 + s2];
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
             float a_[16], b_[16];
             if (h == 0) {
 #pragma unroll
-                for (int n = 0; n < SR_MAXOUT; ++n) tA[n * 33 + j] = (live && n < d.n_out) ? dz[n] : 0.f;
+                for (int n = 0; n < SR_MAXOUT; ++n) tA[n * 33 + j] = n < d.n_out ? dz[n] : 0.f;
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
