@@ -799,11 +799,18 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
                     g1[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], bts[g & 1][s], g1[g], 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[crow(s, h) * 32 * KG + 32 * g + i], dz[s], acc, 0, 0, 0);
                 }
-                if (live) {
+                if (live && (K == 32 * KG || g + 1 < KG)) {   // a full block: no per-row guard (an exec-mask branch per store)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int k_s = 32 * g + (r & 3) + 8 * (r >> 2);
                         const float v = acc[r];   // (bit_cast straight from the vector element stored element 0 sixteen times)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rD, vo_e, k_s * el4, 0);
+                    }
+                } else if (live) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k_s = 32 * g + (r & 3) + 8 * (r >> 2);
+                        const float v = acc[r];
                         if (k_s + 4 * h < Kq) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rD, vo_e, k_s * el4, 0);
                     }
                 }
