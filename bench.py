@@ -93,10 +93,10 @@ def build_case(workload, device, rank, world, scenarios=None, periods=None):
     return setting, policy, sc, data, model, eng, n, T, desc
 
 
-def _pmc_traffic(kernel_name, n_scenarios):
+def _pmc_traffic(kernel_name, n_scenarios, label=None):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*traffic*.json): FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc passes and corrected as the files' notes say.  None if no pass has this kernel
-    at this scenario count."""
+    at this scenario count.  Entries that carry a `label` (kernel class: two MLPs may share one template) must match it."""
     import glob
     # rocprofv3 prints template arguments as numbers, nic_last_kernel() with the enumerator names
     squash = lambda s: s.replace(" ", "").replace("EPI_BIAS_ACT", "0").replace("EPI_DGRAD", "1")  # noqa: E731
@@ -106,7 +106,7 @@ def _pmc_traffic(kernel_name, n_scenarios):
             if not isinstance(doc, dict) or doc.get("n_scenarios") != n_scenarios:
                 continue
             for e in doc.get("kernels", []):
-                if squash(e["kernel"]) == squash(kernel_name):
+                if squash(e["kernel"]) == squash(kernel_name) and e.get("label", label) == label:
                     return {"bytes_per_launch": e["hbm_bytes_per_launch"], "source": os.path.basename(f)}
         except Exception:
             pass
@@ -193,8 +193,9 @@ def algorithmic_work(tag, kernel, shape):
         # HBM-bound: 0.4 flop per byte of activations.  Forward (training): K gathered input rows in, the two hidden
         # activations the backward needs and the output out.  Backward: dY / Y, the hidden activations and the inputs in,
         # the input gradient out (weight gradients stay in registers).  The optional X history is a design choice, not counted.
-        K, n_out, n_ent = shape["gnn"][tag[len("mlp3_fwd_"):]]
-        rows = (K + 64 + n_out) if tag.startswith("mlp3_fwd_") else (2 * K + 64 + 2 * n_out)
+        # (a forward launch that folds a residual connection also reads the residual and writes the sum: `fold` rows)
+        K, n_out, n_ent, fold = shape["gnn"][tag[len("mlp3_fwd_"):]]
+        rows = (K + 64 + n_out + fold) if tag.startswith("mlp3_fwd_") else (2 * K + 64 + 2 * n_out)
         return "hbm", 4.0 * rows * n_ent * n, "B"
     if tag.startswith("bwd_thin_"):
         N, K = (int(v) for v in tag[len("bwd_thin_"):].split("x"))
@@ -234,6 +235,9 @@ def kernel_report(timer, shape, steps):
                 ach, peak, u = amount / (mean_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
                 rec["algorithmic_bytes_per_launch"] = amount
             rec.update(bound=bound, achieved=round(ach, 2), peak=peak, unit=u, frac=round(ach / peak, 4))
+            tr_ = _pmc_traffic(name, shape["n"], tag) if bound == "hbm" else None
+            if tr_ is not None:   # counter-measured HBM bytes of this class (committed PMC passes) vs the algorithmic bytes
+                rec.update(traffic=tr_["bytes_per_launch"], traffic_over_algorithmic=round(tr_["bytes_per_launch"] / amount, 3))
         out[tag] = rec
     return out
 
@@ -252,6 +256,9 @@ def main():
     ap.add_argument("--timing-stride", type=int, default=None,
                     help="bracket every n-th launch of each kernel class with HIP events (default: 10 on the per-period route, "
                          "1 on the whole-horizon route; each pair costs ~5 us)")
+    ap.add_argument("--launch-order-out", default=None,
+                    help="write the (kernel class, kernel) sequence of the timed steps as JSON and skip the event timing: what "
+                         "tools/collect_profiles.py joins the profiler's per-dispatch counter rows to")
     ap.add_argument("--graph", action="store_true", help="replay the launch sequence from a HIP graph (implies --no-kernel-timing)")
     ap.add_argument("--gnn-keep-inputs", action="store_true",
                     help="gnn: keep a copy of the gathered MLP inputs for the backward instead of reading them again (A/B)")
@@ -365,7 +372,9 @@ def main():
     if eng is None and args.warmup == 0:
         step()  # lazy layers materialise on the first forward; keep that out of the timed region
     timer = None
-    if not args.no_kernel_timing:
+    if args.launch_order_out and eng is not None:
+        timer = eng.timer = KernelTimer(record_order=True)
+    elif not args.no_kernel_timing:
         stride = args.timing_stride or (1 if (closed_form or (not gnn and eng.small is not None)) else 10)
         timer = eng.timer = KernelTimer(stride=stride)
     if sharded:
@@ -403,14 +412,17 @@ def main():
                                  "whole-horizon kernels" if eng.small is not None else "per-period kernels"),
                        "mean_cost_per_store_period": loss},
         }
-        if timer is not None:
+        if timer is not None and timer.order is not None:
+            json.dump({"workload": args.workload, "n_scenarios": n, "periods": T, "steps": args.steps, "order": timer.order},
+                      open(args.launch_order_out, "w"))
+        elif timer is not None:
             Wn_, E_ = pp["n_warehouses"], pp["n_extra_echelons"]
             shape = dict(n=n, T=T, S=S, Wn=Wn_, E=E_, Ws=data["initial_inventories"].shape[2],
                          Ww=data["initial_warehouse_inventories"].shape[2] if Wn_ else 0,
                          We=data["initial_echelon_inventories"].shape[2] if E_ else 0,
                          F=0 if (closed_form or gnn) else eng.dims[0], nh=0 if (closed_form or gnn) else len(eng.dims) - 2,
                          n_out=0 if (closed_form or gnn) else eng.dims[-1], train=not args.eval,
-                         gnn={m.name: (m.K, m.n_out, m.n_ent) for m in eng.mlp.values()} if gnn else None)
+                         gnn={m.name: (m.K, m.n_out, m.n_ent, getattr(m, "fold_rows", 0)) for m in eng.mlp.values()} if gnn else None)
             kernels = kernel_report(timer, shape, args.steps)
             rated = {k: v for k, v in kernels.items() if "bound" in v}
             if rated:
@@ -424,7 +436,7 @@ def main():
                     "mean_launch_ms": d["mean_ms"], "launches_per_step": d["launches_per_step"],
                     "launches_timed": d["launches_timed"], "share_of_step": round(d["total_ms_per_step"] / ms, 4),
                 }
-                tr_ = _pmc_traffic(d["kernel"], n)
+                tr_ = _pmc_traffic(d["kernel"], n, dom)
                 if tr_ is not None:
                     out["roofline"]["traffic"] = tr_["bytes_per_launch"]
                     out["roofline"]["traffic_source"] = tr_["source"]

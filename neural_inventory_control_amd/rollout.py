@@ -33,10 +33,13 @@ class KernelTimer:
     """Optional per-launch timing with HIP events recorded on the stream the kernels are launched on (torch's current
     stream).  bench.py uses it to report the dominant kernel's average duration over the timed region."""
 
-    def __init__(self, tags=None, stride=1):
+    def __init__(self, tags=None, stride=1, record_order=False):
         """stride: bracket every `stride`-th launch of each kernel class only (a pair of event records costs ~5 us of
-        host + stream time; at ~1,700 launches per cfg3 step timing all of them slows the step by 4 %)."""
+        host + stream time; at ~1,700 launches per cfg3 step timing all of them slows the step by 4 %).
+        record_order: keep the (tag, kernel) sequence of every launch - what joins a profiler's per-dispatch counter rows,
+        which only carry kernel names, to the kernel classes (two MLPs may share one template)."""
         self.tags = set(tags) if tags is not None else None
+        self.order = [] if record_order else None
         self.events = {}
         self.calls = {}
         self.names = {}  # tag -> name of the kernel the C ABI reported launching for it (nic_last_kernel)
@@ -51,6 +54,10 @@ class KernelTimer:
             return fn(*args, **kw)
         n = self.calls.get(tag, 0)
         self.calls[tag] = n + 1
+        if self.order is not None:
+            out = fn(*args, **kw)
+            self.order.append((tag, (_lib.lib().nic_last_kernel() or b"").decode()))
+            return out
         if n % self.stride:
             return fn(*args, **kw)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -3,6 +3,9 @@
 
     python3 tools/collect_profiles.py r02 [workload ...]
 
+`python3 tools/collect_profiles.py r02 traffic:gnn traffic:cfg2 ...` instead collects the HBM counters of every kernel class
+of those workloads (`<round>_traffic_<w>.json`, see traffic_pass).
+
 For each workload: the plain bench line (`<round>_bench_<w>.json`), the `rocprofv3 --kernel-trace --stats` summary of the
 same command (`<round>_bench_<w>_kernel_stats.csv`, per-(kernel, grid) split `..._kernel_by_grid.csv`) and the bench line
 printed under the profiler.  For cfg3 additionally two PMC passes (FETCH_SIZE, WRITE_SIZE - separate runs, kernel trace only,
@@ -68,8 +71,88 @@ def pmc_pass(counter, out_dir, bench_args):
     return {k: (sum(v) / len(v), len(v)) for k, v in res.items()}
 
 
+def note_name(k):
+    """rocprofv3's spelling of a kernel (template arguments as numbers) -> the spelling the C ABI reports (nic_last_kernel),
+    which is what bench.py looks up."""
+    m = re.match(r"mlp3_bwd_hist_kernel<(\d+), (true|false), (\d+)>", k)
+    if m:
+        return "mlp3_bwd_hist_kernel<%s,%s%s>" % (m.group(1), "gather" if m.group(2) == "true" else "stored",
+                                                  ",tail" if m.group(3) != "0" else "")
+    shapes = {"0": "any", "1": "one_store", "2": "serial"}
+    m = re.match(r"small_rollout_fwd_mfma_kernel<(\d+), (\d+)>", k)
+    if m:
+        return "small_rollout_fwd_mfma_kernel<%s,%s>" % (m.group(1), shapes[m.group(2)])
+    m = re.match(r"small_rollout_bwd_mfma_kernel<(\d+), (true|false), (\d+)>", k)
+    if m:
+        return "small_rollout_bwd_mfma_kernel<%s,%s%s>" % (m.group(1), "wgrad," if m.group(2) == "true" else "", shapes[m.group(3)])
+    m = re.match(r"(gemm_wx(?:_dma)?_kernel<\d+, \d+, \d+, \d+), (\d)>", k)
+    if m:
+        return (m.group(1) + "," + {"0": "EPI_BIAS_ACT", "1": "EPI_DGRAD"}.get(m.group(2), m.group(2)) + ">").replace(" ", "")
+    return k.replace(" ", "")
+
+
+def pmc_rows(counter, out_dir, bench_args):
+    """One --pmc pass; [(dispatch id, kernel, value)] in dispatch order (rows of one dispatch averaged)."""
+    run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", "python3", "bench.py"]
+        + bench_args)
+    per = defaultdict(list)
+    names = {}
+    for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                d = int(r["Dispatch_Id"])
+                per[d].append(float(r["Counter_Value"]))
+                names[d] = short(r["Kernel_Name"])
+    return [(d, names[d], sum(v) / len(v)) for d, v in sorted(per.items())]
+
+
+def traffic_pass(rnd, w, out):
+    """HBM bytes per launch of every kernel CLASS of a workload: FETCH_SIZE / WRITE_SIZE passes joined, template by template
+    and in dispatch order, to the launch sequence bench.py recorded in the same process (--launch-order-out)."""
+    few = ["--periods", "8"] if w in ("cfg3", "cfg5", "gnn") else []
+    args = ["--workload", w, "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + few
+    order_f = os.path.join(out, f"order_{w}.json")
+    fetch = pmc_rows("FETCH_SIZE", os.path.join(out, f"pmc_fetch_{w}"), args + ["--launch-order-out", order_f])
+    write = pmc_rows("WRITE_SIZE", os.path.join(out, f"pmc_write_{w}"), args + ["--launch-order-out", order_f])
+    doc = json.load(open(order_f))
+    by_kernel = defaultdict(list)          # kernel (ABI spelling) -> class labels in launch order
+    for tag, kern in doc["order"]:
+        by_kernel[kern.replace(" ", "")].append(tag)
+    kernels = []
+    for kern, tags in sorted(by_kernel.items()):
+        f_rows = [v for _, k, v in fetch if note_name(k) == kern]
+        w_rows = [v for _, k, v in write if note_name(k) == kern]
+        if len(f_rows) < len(tags) or len(w_rows) < len(tags):
+            print("traffic: no counter rows for", kern, len(f_rows), len(w_rows), len(tags), flush=True)
+            continue
+        f_rows, w_rows = f_rows[-len(tags):], w_rows[-len(tags):]   # launches before the timed step (set-up) come first
+        acc = defaultdict(lambda: [0.0, 0.0, 0])
+        for tag, fv, wv in zip(tags, f_rows, w_rows):
+            a = acc[tag]
+            a[0] += fv
+            a[1] += wv
+            a[2] += 1
+        for tag, (fs, ws, cnt) in sorted(acc.items()):
+            # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> doubled; both counters in KiB
+            kernels.append({"kernel": kern, "label": tag, "launches": cnt, "FETCH_SIZE_KiB": round(fs / cnt, 1),
+                            "WRITE_SIZE_KiB": round(ws / cnt, 1), "hbm_bytes_per_launch": (2.0 * fs + ws) / cnt * 1024})
+    json.dump({"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py " + " ".join(args) +
+                       "`; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request).  "
+                       "Counter rows are joined to kernel classes (`label`) through the launch sequence the same process recorded "
+                       "(--launch-order-out): templates shared by several classes are split in dispatch order.",
+               "workload": w, "n_scenarios": doc["n_scenarios"], "periods": doc["periods"], "kernels": kernels},
+              open(os.path.join(out, f"{rnd}_traffic_{w}.json"), "w"), indent=1)
+    print("traffic", w, json.dumps(kernels)[:400], flush=True)
+
+
 def main():
     rnd = sys.argv[1]
+    out = os.path.join(ROOT, "gpurun_out", rnd)
+    os.makedirs(out, exist_ok=True)
+    if any(a.startswith("traffic:") for a in sys.argv[2:]):
+        for a in sys.argv[2:]:
+            traffic_pass(rnd, a.split(":", 1)[1], out)
+        return
     workloads = sys.argv[2:] or ["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "gnn", "base_stock", "base_stock_1m", "echelon_stock"]
     out = os.path.join(ROOT, "gpurun_out", rnd)
     os.makedirs(out, exist_ok=True)
