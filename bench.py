@@ -193,7 +193,7 @@ def algorithmic_work(tag, kernel, shape):
         # HBM-bound: 0.4 flop per byte of activations.  Forward (training): K gathered input rows in, the two hidden
         # activations the backward needs and the output out.  Backward: dY / Y, the hidden activations and the inputs in,
         # the input gradient out (weight gradients stay in registers).  The optional X history is a design choice, not counted.
-        # (a forward launch that folds a residual connection also reads the residual and writes the sum: `fold` rows)
+        # (a forward launch that folds a residual connection also writes the sum: `fold` rows)
         K, n_out, n_ent, fold = shape["gnn"][tag[len("mlp3_fwd_"):]]
         rows = (K + 64 + n_out + fold) if tag.startswith("mlp3_fwd_") else (2 * K + 64 + 2 * n_out)
         return "hbm", 4.0 * rows * n_ent * n, "B"

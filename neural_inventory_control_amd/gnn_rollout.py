@@ -390,8 +390,9 @@ class GnnRollout:
         m = self.mlp[name]
         hist = ((m.hist(m.X, t) if m.X is not None else None, m.hist(m.H1, t), m.hist(m.H2, t)) if hasattr(m, "H1")
                 else (None, None, None))
-        # rows the launch moves beyond [inputs | hidden activations | output]: the residual it adds and the sum it also writes
-        m.fold_rows = (m.n_out if residual is not None else 0) + (m.n_out if Ysum is not None else 0)
+        # rows the launch moves beyond [inputs | hidden activations | output]: the sum it also writes (the residual it adds is one
+        # of its input segments in both uses here, i.e. already counted)
+        m.fold_rows = m.n_out if Ysum is not None else 0
         self._k("mlp3_fwd_" + name, ops.mlp3_fwd, self._desc(m, segs[name], prob), m.Y[t], *hist, residual, Ysum)
 
     def _forward_period(self, t, prob, demand_soa, shift):
