@@ -116,13 +116,19 @@ constexpr int kChunks = 1;  // 32-scenario chunks each wavefront walks (1: nothi
 // used, so the kernel stays near 90 VGPRs and five or more wavefronts per SIMD hide the gather latency.  (Variants that staged
 // the weights in LDS for four wavefronts let the compiler hoist every fragment into registers - 300+ VGPRs or scratch - and
 // were 2-4x slower; measured.)
+#ifndef NIC_FWD_WAVES
+#define NIC_FWD_WAVES 4
+#endif
+constexpr int kFwdWaves = NIC_FWD_WAVES;
 template <int KS>
-__global__ __launch_bounds__(64) void mlp3_fwd_kernel(NicMlp3Desc d, const float* __restrict__ wt, float* __restrict__ Y,
+__global__ __launch_bounds__(64 * kFwdWaves) void mlp3_fwd_kernel(NicMlp3Desc d, const float* __restrict__ wt, float* __restrict__ Y,
                                                       float* __restrict__ Xh, float* __restrict__ H1, float* __restrict__ H2,
                                                       const float* __restrict__ Rsd, float* __restrict__ Ysum) {
-    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5, i = j;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, i = j;
     const int e = blockIdx.y, K = d.K;
-    const int64_t b_raw = (int64_t)blockIdx.x * 32 + j;
+    const int chunk = blockIdx.x * kFwdWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int64_t)chunk * 32 >= d.n_scenarios) return;
+    const int64_t b_raw = (int64_t)chunk * 32 + j;
     const bool live = b_raw < d.n_scenarios;
     const int64_t b = live ? b_raw : 0;
     const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;   // elements between feature rows of the [rows][E][ldb] buffers
@@ -1111,7 +1117,7 @@ int nic_mlp3_fwd_residual(const NicMlp3Desc* d, float* Y, float* X_hist, float* 
     NIC_REQUIRE(Y, "nic_mlp3_fwd: null output");
     NIC_REQUIRE((!X_hist && !H1 && !H2) || (H1 && H2), "nic_mlp3_fwd: incomplete history buffers (H1 and H2 go together)");
     NIC_REQUIRE(d->weights_t, "nic_mlp3_fwd: weights_t (the pre-transposed weight copy) is required");
-    const dim3 grid(nic::ceil_div(d->n_scenarios, 32), d->n_entities), block(64);
+    const dim3 grid(nic::ceil_div(d->n_scenarios, 32 * kFwdWaves), d->n_entities), block(64 * kFwdWaves);
     hipStream_t s = nic::as_stream(stream);
     const int ks = (d->K + 1) / 2;
     const int t = ks <= 4 ? 4 : (ks <= 16 ? 16 : (ks <= 33 ? 33 : 48));

@@ -17,6 +17,48 @@ __global__ __launch_bounds__(64) void probe(const float* __restrict__ in, float*
 #pragma unroll
     for (int r = 0; r < ROUT / 2; ++r) out[addr(2 * r + h, ROUT)] = acc + r;
 }
+// (c) one wavefront = 64 scenarios of one entity, lane = scenario: every load / store instruction covers ONE row x 256 B instead of
+// two rows x 128 B (what a kernel gets that owns two adjacent 32-column MFMA blocks and swaps register halves, v_permlane32_swap)
+template <int RIN, int ROUT>
+__global__ __launch_bounds__(64) void probe_wide(const float* __restrict__ in, float* __restrict__ out, int E, int ld) {
+    const int lane = threadIdx.x, ch = blockIdx.x, e = blockIdx.y;
+    auto addr = [&](int row) -> size_t { return ((size_t)row * E + e) * ld + (size_t)ch * 64 + lane; };
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < RIN; ++s) acc += in[addr(s)];
+#pragma unroll
+    for (int r = 0; r < ROUT; ++r) out[addr(r)] = acc + r;
+}
+// (d) the same two-rows-x-128-B instructions as (a), but one wavefront owns two ADJACENT 32-column chunks and alternates between them
+template <int RIN, int ROUT>
+__global__ __launch_bounds__(64) void probe_pair(const float* __restrict__ in, float* __restrict__ out, int E, int ld) {
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5, ch = blockIdx.x, e = blockIdx.y;
+    auto addr = [&](int row, int c) -> size_t { return ((size_t)row * E + e) * ld + (size_t)ch * 64 + c * 32 + j; };
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < RIN / 2; ++s) acc += in[addr(2 * s + h, 0)] + in[addr(2 * s + h, 1)];
+#pragma unroll
+    for (int r = 0; r < ROUT / 2; ++r) {
+        out[addr(2 * r + h, 0)] = acc + r;
+        out[addr(2 * r + h, 1)] = acc - r;
+    }
+}
+template <int RIN, int ROUT, int KIND>
+float run2(const float* in, float* out, int E, int ld, int iters) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    dim3 grid(ld / 64, E);
+    auto go = [&]() {
+        if (KIND == 0) hipLaunchKernelGGL((probe_wide<RIN, ROUT>), grid, dim3(64), 0, 0, in, out, E, ld);
+        else hipLaunchKernelGGL((probe_pair<RIN, ROUT>), grid, dim3(64), 0, 0, in, out, E, ld);
+    };
+    for (int i = 0; i < 3; ++i) go();
+    hipEventRecord(a);
+    for (int i = 0; i < iters; ++i) go();
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms / iters;
+}
 template <int RIN, int ROUT, bool TILE>
 float run(const float* in, float* out, int E, int ld, int iters) {
     hipEvent_t a, b;
@@ -32,8 +74,8 @@ float run(const float* in, float* out, int E, int ld, int iters) {
 int main() {
     const int E = 34, ld = 8192;
     float *in, *out;
-    hipMalloc(&in, (size_t)96 * E * ld * 4); hipMalloc(&out, (size_t)192 * E * ld * 4);
-    hipMemset(in, 0, (size_t)96 * E * ld * 4);
+    hipMalloc(&in, (size_t)160 * E * ld * 4); hipMalloc(&out, (size_t)192 * E * ld * 4);
+    hipMemset(in, 0, (size_t)160 * E * ld * 4);
     auto report = [&](const char* name, float ms, int rin, int rout) {
         const double bytes = (double)(rin + rout) * E * ld * 4;
         printf("%-34s %8.1f us  %6.2f TB/s\n", name, ms * 1e3, bytes / ms / 1e9);
@@ -44,5 +86,11 @@ int main() {
     report("tile-major    read 96 write 96", run<96, 96, true>(in, out, E, ld, 50), 96, 96);
     report("feature-major read 96 write 32", run<96, 32, false>(in, out, E, ld, 50), 96, 32);
     report("tile-major    read 96 write 32", run<96, 32, true>(in, out, E, ld, 50), 96, 32);
+    report("wide (256 B rows) read 96 write 192", run2<96, 192, 0>(in, out, E, ld, 50), 96, 192);
+    report("pair (2 x 128 B)  read 96 write 192", run2<96, 192, 1>(in, out, E, ld, 50), 96, 192);
+    report("wide (256 B rows) read 96 write 96", run2<96, 96, 0>(in, out, E, ld, 50), 96, 96);
+    report("pair (2 x 128 B)  read 96 write 96", run2<96, 96, 1>(in, out, E, ld, 50), 96, 96);
+    report("wide (256 B rows) read 96 write 32", run2<96, 32, 0>(in, out, E, ld, 50), 96, 32);
+    report("wide (256 B rows) read 160 write 96", run2<160, 96, 0>(in, out, E, ld, 50), 160, 96);
     return 0;
 }
