@@ -1,5 +1,5 @@
 // Fused three-layer 32-wide MLP over gathered inputs and the graph glue around it (include/nic_rollout.h):
-//   nic_mlp3_fwd / nic_mlp3_fwd_residual   forward (+ optional residual output)           mlp3_fwd_kernel<KS>
+//   nic_mlp3_fwd / nic_mlp3_fwd_residual   forward (+ optional residual output)           mlp3_fwd_kernel<KS, CH, ADDR>
 //   nic_mlp3_bwd_hist                      backward, weight gradients contracted in-kernel  mlp3_bwd_hist_kernel<KG, GATHER, TAIL>   (what the GNN engine runs)
 //   nic_mlp3_bwd / nic_mlp3_bwd_fused      backward with a dz history / without any history (kept as references and as the fallback)
 //   nic_segment_sum / nic_segment_sum_terms  message aggregation and the adjoints of every gather / residual connection
@@ -111,7 +111,7 @@ constexpr int kWaves = 4;   // wavefronts per workgroup (they share one staged c
 constexpr int kChunks = 1;  // 32-scenario chunks each wavefront walks (1: nothing is loop-invariant, so the weight fragments are read from LDS as they are used instead of being hoisted into ~130 VGPRs, which left one wavefront per SIMD)
 
 // KS = MFMA steps of the first layer (input rows 2s + h): K <= 2 * KS.
-// One wavefront per workgroup, no LDS: the weight fragments are read from the PRE-TRANSPOSED copy (`weights_t`: lane i of step
+// Independent wavefronts (four per workgroup, adjacent chunks; no LDS, no barriers): the weight fragments are read from the PRE-TRANSPOSED copy (`weights_t`: lane i of step
 // k reads consecutive words - one 128-B line per half; the natural layout would touch 32 lines per read) right where they are
 // used, so the kernel stays near 90 VGPRs and five or more wavefronts per SIMD hide the gather latency.  (Variants that staged
 // the weights in LDS for four wavefronts let the compiler hoist every fragment into registers - 300+ VGPRs or scratch - and
@@ -120,20 +120,57 @@ constexpr int kChunks = 1;  // 32-scenario chunks each wavefront walks (1: nothi
 #define NIC_FWD_WAVES 4
 #endif
 constexpr int kFwdWaves = NIC_FWD_WAVES;
-template <int KS>
+#ifndef NIC_FWD_PAIR_MIN_WAVES
+#define NIC_FWD_PAIR_MIN_WAVES 2048
+#endif
+constexpr int kFwdPairMinWaves = NIC_FWD_PAIR_MIN_WAVES;   // (below: not enough work to care; one chunk keeps more CUs busy)
+constexpr int kFwdSlots = 256 * 4 * 5;
+// CH = adjacent 32-scenario chunks one wavefront owns (1 or 2).  With two, every weight fragment, bias and row pointer is fetched
+// once for both, each row is touched as 2 x 128 B back to back, and a wavefront keeps twice the bytes in flight: the memory
+// pattern alone (tools/layout_probe.hip, "pair") moves the same bytes 20-28 % faster than one chunk per wavefront.
+// ADDR = how the outputs are addressed.  The SQ counters (tools/pmc_gnn_probe.sh) show this kernel bound by vector-ALU issue, not
+// by memory: 2,067 VALU instructions per wavefront for 80 MFMAs, a quarter of them 64-bit address arithmetic of the stores.
+//   kAddrBuf / kAddrBufX: every output buffer is written through a raw buffer descriptor based at the wavefront's first column -
+//     ONE 32-bit lane offset per buffer, the row as a scalar offset (needs rows that span < 2 GiB; the launcher checks) - without
+//     (kAddrBuf: no per-step branch either) or with (kAddrBufX) the stored copy of the inputs;
+//   kAddrFlat: 64-bit addresses and a run-time X history test, for buffers too large for 32-bit offsets.
+constexpr int kAddrFlat = 0, kAddrBuf = 1, kAddrBufX = 2;
+template <int KS, int CH, int ADDR>
 __global__ __launch_bounds__(64 * kFwdWaves) void mlp3_fwd_kernel(NicMlp3Desc d, const float* __restrict__ wt, float* __restrict__ Y,
                                                       float* __restrict__ Xh, float* __restrict__ H1, float* __restrict__ H2,
                                                       const float* __restrict__ Rsd, float* __restrict__ Ysum) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, i = j;
     const int e = blockIdx.y, K = d.K;
-    const int chunk = blockIdx.x * kFwdWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = (blockIdx.x * kFwdWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * CH;
     if ((int64_t)chunk * 32 >= d.n_scenarios) return;
-    const int64_t b_raw = (int64_t)chunk * 32 + j;
-    const bool live = b_raw < d.n_scenarios;
-    const int64_t b = live ? b_raw : 0;
+    bool live[CH];
+    int64_t b[CH], col[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int64_t b_raw = (int64_t)(chunk + c) * 32 + j;
+        live[c] = b_raw < d.n_scenarios;
+        b[c] = live[c] ? b_raw : 0;
+        col[c] = (int64_t)e * d.ldb + b[c];
+    }
+    const bool full = (int64_t)(chunk + CH) * 32 <= d.n_scenarios;   // every lane of every chunk is a scenario
     const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;   // elements between feature rows of the [rows][E][ldb] buffers
     const int64_t hs = d.hist_row_stride ? d.hist_row_stride : ent_ld;  // ... and of the history buffers
-    const int64_t col = (int64_t)e * d.ldb + b;
+    // buffer addressing: descriptor base = column 0 of the wavefront's first chunk in row 0 of the entity; a lane adds
+    // (4 h rows + its column) once, a store adds the row as a scalar
+    constexpr bool BUF = ADDR != kAddrFlat;
+    const int64_t col0 = (int64_t)e * d.ldb + (int64_t)chunk * 32;
+    auto rsrc_of = [](const float* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t rH1 = rsrc_of(BUF && H1 ? H1 + col0 : wt), rH2 = rsrc_of(BUF && H2 ? H2 + col0 : wt),
+                                 rY = rsrc_of(BUF ? Y + col0 : wt), rYs = rsrc_of(BUF && Ysum ? Ysum + col0 : wt),
+                                 rR = rsrc_of(BUF && Rsd ? Rsd + col0 : wt), rXh = rsrc_of(ADDR == kAddrBufX ? Xh + col0 : wt);
+    const int hs4 = (int)hs * 4, el4 = (int)ent_ld * 4;
+    const int vo_h = 4 * h * hs4, vo_e = 4 * h * el4, vo_x = h * hs4;
+    int vc[CH];   // the lane's column inside the wavefront's chunks, in bytes (lanes past the last scenario: column 0, never stored)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) vc[c] = live[c] ? c * 128 + j * 4 : 0;
+    auto put = [](__amdgpu_buffer_rsrc_t r, float v, int voff, int soff) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+    };
     const float* w1t = wt;                 // [K][32]
     const float* b1 = w1t + K * 32;
     const float* w2t = b1 + 32;            // [32][32]
@@ -141,25 +178,30 @@ __global__ __launch_bounds__(64 * kFwdWaves) void mlp3_fwd_kernel(NicMlp3Desc d,
     const float* w3t = b2 + 32;            // [32][32], columns >= n_out zero
     const float* b3 = w3t + 32 * 32;       // padded to 32
     const uint64_t pv0 = encoded_row_pointer(d, e, lane), pv1 = (2 * KS > 64) ? encoded_row_pointer(d, e, 64 + lane) : 0ull;
-    f32x16 acc;
+    f32x16 acc[CH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = b1[crow(r, h)];
+    for (int r = 0; r < 16; ++r) {
+        const float bv = b1[crow(r, h)];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c][r] = bv;
+    }
     // First layer in groups of kG contraction steps: the gathers and weight fragments of a group are loaded UNCONDITIONALLY
     // (a missing row reads a valid dummy address and is zeroed by a select) and all together, the next group's while this
     // group's MFMAs run.  Written as one step at a time - `x = p ? p[..] : 0; a = k < K ? w[..] : 0; mfma` - every step was
     // load, s_waitcnt vmcnt(0), MFMA behind two branches: 48 dependent memory round trips per wavefront.
-    constexpr int kG = 16, NG = (KS + kG - 1) / kG;
-    float xg[2][kG], ag[2][kG];
-    auto load_group = [&](int g, float (&x)[kG], float (&a)[kG]) {
+    constexpr int kG = CH == 1 ? 16 : 8, NG = (KS + kG - 1) / kG;
+    float xg[2][CH][kG], ag[2][kG];
+    auto load_group = [&](int g, float (&x)[CH][kG], float (&a)[kG]) {
 #pragma unroll
         for (int u = 0; u < kG; ++u) {
             const int s = g * kG + u;
             if (s < KS) {
                 const int k = 2 * s + h;
                 const uint64_t enc = lane_fetch64(2 * s < 64 ? pv0 : pv1, (2 * s + h) & 63);
-                const float* q = reinterpret_cast<const float*>(enc & ~3ull) + ((enc & 1ull) ? b : 0);
+                const float* q = reinterpret_cast<const float*>(enc & ~3ull);
                 const float av = w1t[(k < K ? k : 0) * 32 + i];
-                x[u] = *q;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) x[c][u] = q[(enc & 1ull) ? b[c] : 0];
                 a[u] = k < K ? av : 0.f;
             }
         }
@@ -173,50 +215,129 @@ __global__ __launch_bounds__(64 * kFwdWaves) void mlp3_fwd_kernel(NicMlp3Desc d,
             const int s = g * kG + u;
             if (s < KS) {
                 const int k = 2 * s + h;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[g & 1][u], xg[g & 1][u], acc, 0, 0, 0);
-                if (Xh && live && k < K) Xh[(int64_t)k * hs + col] = xg[g & 1][u];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[g & 1][u], xg[g & 1][c][u], acc[c], 0, 0, 0);
+                    if (ADDR == kAddrFlat) {
+                        if (Xh && live[c] && k < K) Xh[(int64_t)k * hs + col[c]] = xg[g & 1][c][u];
+                    } else if (ADDR == kAddrBufX) {
+                        if (live[c] && k < K) put(rXh, xg[g & 1][c][u], vo_x + vc[c], 2 * s * hs4);
+                    }
+                }
             }
         }
     }
-    float hcur[16];
+    float hcur[CH][16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hcur[r] = nic::elu1(acc[r]);
-    if (H1 && live) {
+    for (int c = 0; c < CH; ++c) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H1[(int64_t)crow(r, h) * hs + col] = hcur[r];
+        for (int r = 0; r < 16; ++r) hcur[c][r] = nic::elu1(acc[c][r]);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = b2[crow(r, h)];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2t[crow(s, h) * 32 + i], hcur[s], acc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) hcur[r] = nic::elu1(acc[r]);
-    if (H2 && live) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) H2[(int64_t)crow(r, h) * hs + col] = hcur[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = b3[crow(r, h)];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w3t[crow(s, h) * 32 + i], hcur[s], acc, 0, 0, 0);
-    if (live) {
-        if (Ysum) {   // residual connection folded in: Ysum = out + R (the same rounding as the separate tensor add it replaces)
-            float rs[16], y[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rs[r] = Rsd[(int64_t)(crow(r, h) < d.n_out ? crow(r, h) : 0) * ent_ld + col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = out_act_fwd(d.out_act, acc[r]);
+    // the two hidden activations the backward needs.  (`full` is wave-uniform: the stores of the two chunks alternate, no
+    // per-store lane masks)
+    auto put_hidden = [&](float* H, __amdgpu_buffer_rsrc_t rH) {
+        if (!H) return;
+        if (full) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (crow(r, h) < d.n_out) {
-                    Y[(int64_t)crow(r, h) * ent_ld + col] = y[r];
-                    Ysum[(int64_t)crow(r, h) * ent_ld + col] = rs[r] + y[r];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if (BUF) put(rH, hcur[c][r], vo_h + vc[c], ((r & 3) + 8 * (r >> 2)) * hs4);
+                    else H[(int64_t)crow(r, h) * hs + col[c]] = hcur[c][r];
                 }
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (crow(r, h) < d.n_out) Y[(int64_t)crow(r, h) * ent_ld + col] = out_act_fwd(d.out_act, acc[r]);
+            for (int c = 0; c < CH; ++c) {
+                if (live[c]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (BUF) put(rH, hcur[c][r], vo_h + vc[c], ((r & 3) + 8 * (r >> 2)) * hs4);
+                        else H[(int64_t)crow(r, h) * hs + col[c]] = hcur[c][r];
+                    }
+                }
+            }
+        }
+    };
+    put_hidden(H1, rH1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float bv = b2[crow(r, h)];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c][r] = bv;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float wv = w2t[crow(s, h) * 32 + i];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, hcur[c][s], acc[c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hcur[c][r] = nic::elu1(acc[c][r]);
+    }
+    put_hidden(H2, rH2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float bv = b3[crow(r, h)];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c][r] = bv;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float wv = w3t[crow(s, h) * 32 + i];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, hcur[c][s], acc[c], 0, 0, 0);
+    }
+    const int n_out = d.n_out, out_act = d.out_act;
+    if (Ysum) {   // residual connection folded in: Ysum = out + R (the same rounding as the separate tensor add it replaces)
+        float rs[CH][16];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row_s = (r & 3) + 8 * (r >> 2);
+                if (BUF)   // rows past n_out: the lane's column in row 0 (read, never used)
+                    rs[c][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             rR, (row_s + 4 * h < n_out ? vo_e + row_s * el4 : 0) + vc[c], 0, 0));
+                else
+                    rs[c][r] = Rsd[(int64_t)(crow(r, h) < n_out ? crow(r, h) : 0) * ent_ld + col[c]];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (live[c]) {
+                float y[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[r] = out_act_fwd(out_act, acc[c][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (crow(r, h) < n_out) {
+                        if (BUF) {
+                            put(rY, y[r], vo_e + vc[c], ((r & 3) + 8 * (r >> 2)) * el4);
+                            put(rYs, rs[c][r] + y[r], vo_e + vc[c], ((r & 3) + 8 * (r >> 2)) * el4);
+                        } else {
+                            Y[(int64_t)crow(r, h) * ent_ld + col[c]] = y[r];
+                            Ysum[(int64_t)crow(r, h) * ent_ld + col[c]] = rs[c][r] + y[r];
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (live[c]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (crow(r, h) < n_out) {
+                        const float y = out_act_fwd(out_act, acc[c][r]);
+                        if (BUF) put(rY, y, vo_e + vc[c], ((r & 3) + 8 * (r >> 2)) * el4);
+                        else Y[(int64_t)crow(r, h) * ent_ld + col[c]] = y;
+                    }
+                }
+            }
         }
     }
 }
@@ -1117,16 +1238,38 @@ int nic_mlp3_fwd_residual(const NicMlp3Desc* d, float* Y, float* X_hist, float* 
     NIC_REQUIRE(Y, "nic_mlp3_fwd: null output");
     NIC_REQUIRE((!X_hist && !H1 && !H2) || (H1 && H2), "nic_mlp3_fwd: incomplete history buffers (H1 and H2 go together)");
     NIC_REQUIRE(d->weights_t, "nic_mlp3_fwd: weights_t (the pre-transposed weight copy) is required");
-    const dim3 grid(nic::ceil_div(d->n_scenarios, 32 * kFwdWaves), d->n_entities), block(64 * kFwdWaves);
+    // Two adjacent chunks per wavefront when one chunk per wavefront would not even fill the chip's wavefront slots once (256 CUs x
+    // 4 SIMDs x 5 wavefronts of ~92 VGPRs): then the launch lasts as long as one wavefront's dependency chain, and a wavefront
+    // that keeps twice the bytes in flight shortens it (node update, 17 nodes x 256 chunks: 52.6 -> 46.3 us).  Launches with more
+    // wavefronts than slots lose more from the lower occupancy of the 156-VGPR variant than they gain (edge MLPs: +3 ... +17 %).
+    const int64_t waves1 = (int64_t)nic::ceil_div(d->n_scenarios, 32) * d->n_entities;
+    const int ch = (waves1 <= kFwdSlots && waves1 >= kFwdPairMinWaves) ? 2 : 1;
+    const dim3 grid(nic::ceil_div(d->n_scenarios, 32 * ch * kFwdWaves), d->n_entities), block(64 * kFwdWaves);
     hipStream_t s = nic::as_stream(stream);
     const int ks = (d->K + 1) / 2;
     const int t = ks <= 4 ? 4 : (ks <= 16 ? 16 : (ks <= 33 ? 33 : 48));
-    nic::note_kernelf("mlp3_fwd_kernel<%d>", t);
-#define NIC_MLP3_FWD(KS) hipLaunchKernelGGL(mlp3_fwd_kernel<KS>, grid, block, 0, s, *d, d->weights_t, Y, X_hist, H1, H2, residual, Ysum)
+    // 32-bit row offsets whenever every buffer's rows span < 2 GiB (always at the sizes this engine allocates)
+    const int64_t hs = d->hist_row_stride ? d->hist_row_stride : (int64_t)d->n_entities * d->ldb;
+    const int64_t top = 2 * (int64_t)((d->K + 1) / 2) + 32;
+    const bool fits = top * hs * 4 < (1ll << 31) && top * d->n_entities * d->ldb * 4 < (1ll << 31);
+    const int addr = !fits ? kAddrFlat : (X_hist ? kAddrBufX : kAddrBuf);
+    nic::note_kernelf("mlp3_fwd_kernel<%d,%d,%d>", t, ch, addr);
+#define NIC_MLP3_FWD2(KS, CH_)                                                                                                   \
+    do {                                                                                                                         \
+        if (addr == kAddrBuf) hipLaunchKernelGGL((mlp3_fwd_kernel<KS, CH_, kAddrBuf>), grid, block, 0, s, *d, d->weights_t, Y, X_hist, H1, H2, residual, Ysum); \
+        else if (addr == kAddrBufX) hipLaunchKernelGGL((mlp3_fwd_kernel<KS, CH_, kAddrBufX>), grid, block, 0, s, *d, d->weights_t, Y, X_hist, H1, H2, residual, Ysum); \
+        else hipLaunchKernelGGL((mlp3_fwd_kernel<KS, CH_, kAddrFlat>), grid, block, 0, s, *d, d->weights_t, Y, X_hist, H1, H2, residual, Ysum); \
+    } while (0)
+#define NIC_MLP3_FWD(KS)                                                                                                         \
+    do {                                                                                                                         \
+        if (ch == 2) NIC_MLP3_FWD2(KS, 2);                                                                                       \
+        else NIC_MLP3_FWD2(KS, 1);                                                                                               \
+    } while (0)
     if (t == 4) NIC_MLP3_FWD(4);
     else if (t == 16) NIC_MLP3_FWD(16);
     else if (t == 33) NIC_MLP3_FWD(33);
     else NIC_MLP3_FWD(48);
+#undef NIC_MLP3_FWD2
 #undef NIC_MLP3_FWD
     return nic::check_launch("nic_mlp3_fwd");
 }

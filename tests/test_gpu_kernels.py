@@ -492,6 +492,93 @@ def test_mlp3_fwd_bwd_with_gathered_segments(K_rows, n_out, act, B):
             torch.testing.assert_close(gb.cpu().double(), b_.grad, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("residual", [False, True])
+def test_mlp3_fwd_two_chunks_per_wavefront_equals_one(residual):
+    """Launches that would not fill the chip's wavefront slots once take the variant in which a wavefront owns two adjacent
+    32-scenario chunks (mlp3_fwd_kernel<KS,2>).  Same arithmetic per column: bit-equal to the one-chunk variant (which a launch
+    over the first 64 scenarios takes), float64 reference within the usual band, an odd chunk count (dead second chunk) and a
+    ragged last chunk included."""
+    from neural_inventory_control_amd import _lib
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(77)
+    E, B, n_src, n_out = 17, 4096 + 20, 9, 32
+    ld = pad_ld(B, 32)
+    assert (ld // 32) % 2 == 1
+    rows = (32, 32, 32)
+    K = sum(rows)
+    segs, dense = [], []
+    for si, r in enumerate(rows):
+        t = torch.zeros(r, n_src if si else E, ld)
+        t[:, :, :B] = torch.randn(r, t.shape[1], B, generator=gen)
+        idx = torch.randint(-1, n_src, (E,), generator=gen, dtype=torch.int32) if si else None
+        dense.append(t[:, :, :B] if idx is None else
+                     torch.where((idx >= 0)[None, :, None], t[:, idx.clamp_min(0).long(), :B], torch.zeros(())))
+        segs.append(ops.Mlp3Segment(t.to(dev), idx.to(dev) if idx is not None else None))
+    X = torch.cat(dense, dim=0)
+    dims = [(32, K), (32, 32), (n_out, 32)]
+    W = [(torch.randn(n, k, generator=gen) / k ** 0.5, torch.randn(n, generator=gen) * 0.3) for n, k in dims]
+    packed = torch.cat([t.reshape(-1) for wb in W for t in wb]).to(dev)
+    packed_t = ops.mlp3_pack_transposed([(w.to(dev), b_.to(dev)) for w, b_ in W], n_out)
+    z = lambda r, l=ld: torch.zeros(r, E, l, device=dev)  # noqa: E731
+    R = segs[0].tensor if residual else None
+
+    def run(n_cols):
+        desc = ops.mlp3_desc(segs, packed, E, n_cols, ld, n_out, 1, 0, packed_t)
+        Y, Xh, H1, H2, Ys = z(n_out), z(K), z(32), z(32), (z(n_out) if residual else None)
+        ops.mlp3_fwd(desc, Y, Xh, H1, H2, R, Ys)
+        torch.cuda.synchronize()
+        return Y, Xh, H1, H2, Ys, _lib.lib().nic_last_kernel().decode()
+
+    big, small = run(B), run(64)
+    assert big[5] == "mlp3_fwd_kernel<48,2,2>" and small[5] == "mlp3_fwd_kernel<48,1,2>", (big[5], small[5])
+    for a, b_ in zip(big[:5], small[:5]):
+        if a is not None:
+            assert torch.equal(a[:, :, :64], b_[:, :, :64])
+            assert float(a[:, :, B:].abs().sum()) == 0.0
+    x64 = X.permute(1, 2, 0).reshape(E * B, K).double()
+    y, h1, h2 = _mlp3_reference(x64, [(w.double(), b_.double()) for w, b_ in W], 1)
+    as_rows = lambda t, r: t.reshape(E, B, r).permute(2, 0, 1)  # noqa: E731
+    assert torch.equal(big[1][:, :, :B].cpu(), X)
+    torch.testing.assert_close(big[2][:, :, :B].cpu().double(), as_rows(h1, 32), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(big[3][:, :, :B].cpu().double(), as_rows(h2, 32), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(big[0][:, :, :B].cpu().double(), as_rows(y, n_out), rtol=2e-5, atol=2e-6)
+    if residual:
+        assert torch.equal(big[4], big[0] + R)
+
+
+def test_mlp3_fwd_with_rows_too_far_apart_for_32_bit_offsets():
+    """History rows 64 MiB apart (hist_row_stride = 2^24 floats: 32 rows span 2 GiB) take the forward's 64-bit-address variant
+    (mlp3_fwd_kernel<..,0>); same bits as the buffer-addressed variant on compact buffers."""
+    from neural_inventory_control_amd import _lib
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(3)
+    E, B, K, n_out = 3, 70, 7, 32
+    ld = pad_ld(B, 32)
+    t = torch.zeros(K, E, ld)
+    t[:, :, :B] = torch.randn(K, E, B, generator=gen)
+    segs = [ops.Mlp3Segment(t.to(dev), None)]
+    dims = [(32, K), (32, 32), (n_out, 32)]
+    W = [(torch.randn(n, k, generator=gen) / k ** 0.5, torch.randn(n, generator=gen) * 0.3) for n, k in dims]
+    packed = torch.cat([x.reshape(-1) for wb in W for x in wb]).to(dev)
+    packed_t = ops.mlp3_pack_transposed([(w.to(dev), b_.to(dev)) for w, b_ in W], n_out)
+    stride = 1 << 24
+    out = {}
+    for name, hs in (("compact", 0), ("far", stride)):
+        desc = ops.mlp3_desc(segs, packed, E, B, ld, n_out, 1, hs, packed_t)
+        rows = lambda r: (torch.zeros(r, E, ld, device=dev) if hs == 0 else torch.zeros(r, stride, device=dev))  # noqa: E731
+        Y, Xh, H1, H2 = torch.zeros(n_out, E, ld, device=dev), rows(K), rows(32), rows(32)
+        ops.mlp3_fwd(desc, Y, Xh, H1, H2)
+        torch.cuda.synchronize()
+        kern = _lib.lib().nic_last_kernel().decode()
+        view = lambda x: x.reshape(x.shape[0], -1)[:, :E * ld].reshape(-1, E, ld).clone()  # noqa: E731
+        out[name] = (Y.clone(), view(Xh), view(H1), view(H2), kern)
+        del Xh, H1, H2
+    assert out["compact"][4] == "mlp3_fwd_kernel<4,1,2>" and out["far"][4] == "mlp3_fwd_kernel<4,1,0>", (out["compact"][4], out["far"][4])
+    for a, b_ in zip(out["compact"][:4], out["far"][:4]):
+        assert torch.equal(a, b_)
+    assert float(out["far"][2].abs().sum()) > 0
+
+
 def test_segment_sum_forward_aggregation_and_gather_adjoint():
     dev = "cuda"
     gen = torch.Generator().manual_seed(11)
