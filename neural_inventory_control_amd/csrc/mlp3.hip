@@ -1160,22 +1160,39 @@ __global__ void segment_sum_terms_kernel(float* __restrict__ dst, int64_t dst_rs
 // (neural_networks.py:111-138 via :1435-1492).  One lane = one scenario; the ~25 small tensor ops per period this replaces were
 // 10 % of the GNN step.  out [E][ldb] = desired quantity per edge; members = internal edges 0..S-1 (+ e_self if >= 0);
 // orders [S+1][ldb] = out[s] * scale for the stores, out[e_supplier] for the warehouse's own order.
+constexpr int kAllocBatch = 8, kAllocThreads = 64;   // (64-thread workgroups: 8,192 scenarios spread over 128 CUs instead of 32)
 __global__ void gnn_alloc_fwd_kernel(const float* __restrict__ out, const float* __restrict__ on_hand, float* __restrict__ orders,
                                      float* __restrict__ sums, float* __restrict__ ratio, float* __restrict__ scale, int S,
                                      int e_self, int e_sup, int cap_at_one, int B, int64_t ldb) {
 #pragma clang fp contract(off)   // separate multiplies and adds, like the aten ops this replaces
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    // rows fetched kAllocBatch at a time (unconditionally: a row past S reads row 0 and is dropped by a select), then added in
+    // store order - as `sum += out[s]` in a loop with a run-time trip count every row was one dependent memory round trip
+    const float oh = on_hand[b], self_v = out[(int64_t)(e_self >= 0 ? e_self : 0) * ldb + b], sup_v = out[(int64_t)e_sup * ldb + b];
     float sum = 0.f;
-    for (int s = 0; s < S; ++s) sum += out[(int64_t)s * ldb + b];
-    if (e_self >= 0) sum += out[(int64_t)e_self * ldb + b];
-    const float r = on_hand[b] / (sum + 1e-10f);
+    for (int s0 = 0; s0 < S; s0 += kAllocBatch) {
+        float v[kAllocBatch];
+#pragma unroll
+        for (int u = 0; u < kAllocBatch; ++u) v[u] = out[(int64_t)(s0 + u < S ? s0 + u : 0) * ldb + b];
+#pragma unroll
+        for (int u = 0; u < kAllocBatch; ++u) sum = s0 + u < S ? sum + v[u] : sum;
+    }
+    if (e_self >= 0) sum += self_v;
+    const float r = oh / (sum + 1e-10f);
     const float sc = cap_at_one ? fminf(r, 1.f) : r;   // torch.clamp(max = 1)
     sums[b] = sum;
     ratio[b] = r;
     scale[b] = sc;
-    for (int s = 0; s < S; ++s) orders[(int64_t)s * ldb + b] = out[(int64_t)s * ldb + b] * sc;
-    orders[(int64_t)S * ldb + b] = out[(int64_t)e_sup * ldb + b];
+    for (int s0 = 0; s0 < S; s0 += kAllocBatch) {
+        float v[kAllocBatch];
+#pragma unroll
+        for (int u = 0; u < kAllocBatch; ++u) v[u] = out[(int64_t)(s0 + u < S ? s0 + u : 0) * ldb + b];
+#pragma unroll
+        for (int u = 0; u < kAllocBatch; ++u)
+            if (s0 + u < S) orders[(int64_t)(s0 + u) * ldb + b] = v[u] * sc;
+    }
+    orders[(int64_t)S * ldb + b] = sup_v;
 }
 
 // adjoint: g_orders [S+1][ldb] -> d_out [E][ldb] (every row written) and g_on_hand[b] += d_scale / (sum + eps).
@@ -1188,21 +1205,40 @@ __global__ void gnn_alloc_bwd_kernel(const float* __restrict__ out, const float*
 #pragma clang fp contract(off)
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const float rt = ratio[b], sm = sums[b], oh = on_hand[b], sc = scale[b], g_sup = g_orders[(int64_t)S * ldb + b], goh = g_on_hand[b];
     float dot = 0.f;
-    for (int s = 0; s < S; ++s) dot += g_orders[(int64_t)s * ldb + b] * out[(int64_t)s * ldb + b];
-    const float passes = cap_at_one ? (ratio[b] <= 1.f ? 1.f : 0.f) : 1.f;
-    const float d_scale = dot * passes;
-    const float den = sums[b] + 1e-10f;
-    const float common = -(d_scale * on_hand[b] / (den * den));
-    const float sc = scale[b];
-    for (int e = 0; e < E; ++e) {
-        float v = 0.f;
-        if (e < S || e == e_self) v = common;
-        if (e < S) v += g_orders[(int64_t)e * ldb + b] * sc;
-        if (e == e_sup) v = g_orders[(int64_t)S * ldb + b];
-        d_out[(int64_t)e * ldb + b] = v;
+    for (int s0 = 0; s0 < S; s0 += kAllocBatch) {   // (batched like the forward: same products, same order of additions)
+        float g[kAllocBatch], o[kAllocBatch];
+#pragma unroll
+        for (int u = 0; u < kAllocBatch; ++u) {
+            const int64_t row = (int64_t)(s0 + u < S ? s0 + u : 0) * ldb + b;
+            g[u] = g_orders[row];
+            o[u] = out[row];
+        }
+#pragma unroll
+        for (int u = 0; u < kAllocBatch; ++u) dot = s0 + u < S ? dot + g[u] * o[u] : dot;
     }
-    g_on_hand[b] += d_scale / den;
+    const float passes = cap_at_one ? (rt <= 1.f ? 1.f : 0.f) : 1.f;
+    const float d_scale = dot * passes;
+    const float den = sm + 1e-10f;
+    const float common = -(d_scale * oh / (den * den));
+    for (int e0 = 0; e0 < E; e0 += kAllocBatch) {
+        float g[kAllocBatch];
+#pragma unroll
+        for (int u = 0; u < kAllocBatch; ++u) g[u] = g_orders[(int64_t)(e0 + u < S ? e0 + u : 0) * ldb + b];
+#pragma unroll
+        for (int u = 0; u < kAllocBatch; ++u) {
+            const int e = e0 + u;
+            if (e < E) {
+                float v = 0.f;
+                if (e < S || e == e_self) v = common;
+                if (e < S) v += g[u] * sc;
+                if (e == e_sup) v = g_sup;
+                d_out[(int64_t)e * ldb + b] = v;
+            }
+        }
+    }
+    g_on_hand[b] = goh + d_scale / den;
 }
 
 int validate(const NicMlp3Desc* d, const char* who) {
@@ -1384,7 +1420,7 @@ int nic_gnn_alloc_fwd(const float* out, const float* on_hand, float* orders, flo
     NIC_REQUIRE(out && on_hand && orders && sums && ratio && scale, "nic_gnn_alloc_fwd: null buffer");
     NIC_REQUIRE(S > 0 && e_supplier >= 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_gnn_alloc_fwd: bad sizes");
     nic::note_kernel("gnn_alloc_fwd_kernel");
-    hipLaunchKernelGGL(gnn_alloc_fwd_kernel, dim3(nic::ceil_div(n_scenarios, 256)), dim3(256), 0, nic::as_stream(stream), out, on_hand,
+    hipLaunchKernelGGL(gnn_alloc_fwd_kernel, dim3(nic::ceil_div(n_scenarios, kAllocThreads)), dim3(kAllocThreads), 0, nic::as_stream(stream), out, on_hand,
                        orders, sums, ratio, scale, S, e_self, e_supplier, cap_at_one, n_scenarios, (int64_t)ldb);
     return nic::check_launch("nic_gnn_alloc_fwd");
 }
@@ -1395,7 +1431,7 @@ int nic_gnn_alloc_bwd(const float* out, const float* on_hand, const float* g_ord
     NIC_REQUIRE(out && on_hand && g_orders && sums && ratio && scale && d_out && g_on_hand, "nic_gnn_alloc_bwd: null buffer");
     NIC_REQUIRE(S > 0 && n_edges > S && e_supplier >= 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_gnn_alloc_bwd: bad sizes");
     nic::note_kernel("gnn_alloc_bwd_kernel");
-    hipLaunchKernelGGL(gnn_alloc_bwd_kernel, dim3(nic::ceil_div(n_scenarios, 256)), dim3(256), 0, nic::as_stream(stream), out, on_hand,
+    hipLaunchKernelGGL(gnn_alloc_bwd_kernel, dim3(nic::ceil_div(n_scenarios, kAllocThreads)), dim3(kAllocThreads), 0, nic::as_stream(stream), out, on_hand,
                        g_orders, sums, ratio, scale, d_out, g_on_hand, S, n_edges, e_self, e_supplier, cap_at_one, n_scenarios,
                        (int64_t)ldb);
     return nic::check_launch("nic_gnn_alloc_bwd");

@@ -223,6 +223,10 @@ class GnnRollout:
         self.orders = z(T, S + 1, ld)
         self.rewards = z(T, ld)
         self.feat = z(T, self.Dn, N, ld)
+        # state row -> feature row (slot k of store s -> row k of node 1 + s, slot k of the warehouse -> row k of node 0): the
+        # pipeline part of the node features is ONE index_copy_ per period
+        rows = [k * N + 1 + s_ for s_ in range(S) for k in range(prob.Ws)] + [k * N for k in range(prob.Ww)]
+        self.feat_rows = torch.tensor(rows, dtype=torch.long, device=dev)
         A = _lib
         ks = (self.Dn, 65, 96, 96, 32)
         ents = (N, E, N, E, E)
@@ -398,9 +402,8 @@ class GnnRollout:
     def _forward_period(self, t, prob, demand_soa, shift):
         P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
         st = self._views(self.states[t], prob)
-        f = self.feat[t]
-        f[:prob.Ww, 0].copy_(st.wh[0])                       # node features: pipelines, padded to the longest one (:846-905)
-        f[:prob.Ws, 1:].copy_(st.store.permute(1, 0, 2))
+        # node features: pipelines, padded to the longest one (:846-905)
+        self.feat[t].view(-1, ld).index_copy_(0, self.feat_rows, self.states[t])
         segs = self._segments(t)
         self._run_mlp("initial_node", t, segs, prob)
         self._run_mlp("initial_edge", t, segs, prob)

@@ -92,5 +92,18 @@ int main() {
     report("pair (2 x 128 B)  read 96 write 96", run2<96, 96, 1>(in, out, E, ld, 50), 96, 96);
     report("wide (256 B rows) read 96 write 32", run2<96, 32, 0>(in, out, E, ld, 50), 96, 32);
     report("wide (256 B rows) read 160 write 96", run2<160, 96, 0>(in, out, E, ld, 50), 160, 96);
+    // the 512 x 51 first layer of the cfg3 policy: 52 rows in, 512 rows out, one "entity", 65,536 scenarios
+    {
+        float *in2, *out2;
+        const int E2 = 1, ld2 = 65536;
+        hipMalloc(&in2, (size_t)52 * ld2 * 4); hipMalloc(&out2, (size_t)512 * ld2 * 4);
+        hipMemset(in2, 0, (size_t)52 * ld2 * 4);
+        auto rep2 = [&](const char* name, float ms) {
+            printf("%-40s %8.1f us  %6.2f TB/s\n", name, ms * 1e3, (double)(52 + 512) * ld2 * 4 / ms / 1e9);
+        };
+        rep2("first layer, 128 B rows (2 per instr)", run<52, 512, false>(in2, out2, E2, ld2, 50));
+        rep2("first layer, 256 B rows", run2<52, 512, 0>(in2, out2, E2, ld2, 50));
+        rep2("first layer, pair (2 x 128 B)", run2<52, 512, 1>(in2, out2, E2, ld2, 50));
+    }
     return 0;
 }
