@@ -128,7 +128,7 @@ constexpr int kFwdSlots = 256 * 4 * 5;
 // CH = adjacent 32-scenario chunks one wavefront owns (1 or 2).  With two, every weight fragment, bias and row pointer is fetched
 // once for both, each row is touched as 2 x 128 B back to back, and a wavefront keeps twice the bytes in flight: the memory
 // pattern alone (tools/layout_probe.hip, "pair") moves the same bytes 20-28 % faster than one chunk per wavefront.
-// ADDR = how the outputs are addressed.  The SQ counters (tools/pmc_gnn_probe.sh) show this kernel bound by vector-ALU issue, not
+// ADDR = how the outputs are addressed.  The SQ counters (tools/pmc_sq_probe.sh) show this kernel bound by vector-ALU issue, not
 // by memory: 2,067 VALU instructions per wavefront for 80 MFMAs, a quarter of them 64-bit address arithmetic of the stores.
 //   kAddrBuf / kAddrBufX: every output buffer is written through a raw buffer descriptor based at the wavefront's first column -
 //     ONE 32-bit lane offset per buffer, the row as a scalar offset (needs rows that span < 2 GiB; the launcher checks) - without
