@@ -113,7 +113,7 @@ constexpr int kChunks = 1;  // 32-scenario chunks each wavefront walks (1: nothi
 // KS = MFMA steps of the first layer (input rows 2s + h): K <= 2 * KS.
 // Independent wavefronts (four per workgroup, adjacent chunks; no LDS, no barriers): the weight fragments are read from the PRE-TRANSPOSED copy (`weights_t`: lane i of step
 // k reads consecutive words - one 128-B line per half; the natural layout would touch 32 lines per read) right where they are
-// used, so the kernel stays near 90 VGPRs and five or more wavefronts per SIMD hide the gather latency.  (Variants that staged
+// used, so the kernel stays at 112 VGPRs and four wavefronts per SIMD hide the gather latency.  (Variants that staged
 // the weights in LDS for four wavefronts let the compiler hoist every fragment into registers - 300+ VGPRs or scratch - and
 // were 2-4x slower; measured.)
 #ifndef NIC_FWD_WAVES
@@ -1274,10 +1274,11 @@ int nic_mlp3_fwd_residual(const NicMlp3Desc* d, float* Y, float* X_hist, float* 
     NIC_REQUIRE(Y, "nic_mlp3_fwd: null output");
     NIC_REQUIRE((!X_hist && !H1 && !H2) || (H1 && H2), "nic_mlp3_fwd: incomplete history buffers (H1 and H2 go together)");
     NIC_REQUIRE(d->weights_t, "nic_mlp3_fwd: weights_t (the pre-transposed weight copy) is required");
-    // Two adjacent chunks per wavefront when one chunk per wavefront would not even fill the chip's wavefront slots once (256 CUs x
-    // 4 SIMDs x 5 wavefronts of ~92 VGPRs): then the launch lasts as long as one wavefront's dependency chain, and a wavefront
-    // that keeps twice the bytes in flight shortens it (node update, 17 nodes x 256 chunks: 52.6 -> 46.3 us).  Launches with more
-    // wavefronts than slots lose more from the lower occupancy of the 156-VGPR variant than they gain (edge MLPs: +3 ... +17 %).
+    // Two adjacent chunks per wavefront when one chunk per wavefront is about one round of the chip's wavefront slots or less
+    // (256 CUs x 4 SIMDs x 4-5 wavefronts of ~100 VGPRs): then the launch lasts as long as one wavefront's dependency chain, and
+    // a wavefront that keeps twice the bytes in flight shortens it (node update, 17 nodes x 256 chunks: 52.6 -> 46-50 us).
+    // Launches with clearly more wavefronts than slots lose more from the lower occupancy of the 164-VGPR variant than they gain
+    // (edge MLPs, 34 x 256 chunks: +3 ... +17 %).
     const int64_t waves1 = (int64_t)nic::ceil_div(d->n_scenarios, 32) * d->n_entities;
     const int ch = (waves1 <= kFwdSlots && waves1 >= kFwdPairMinWaves) ? 2 : 1;
     const dim3 grid(nic::ceil_div(d->n_scenarios, 32 * ch * kFwdWaves), d->n_entities), block(64 * kFwdWaves);
