@@ -254,7 +254,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-stride", type=int, default=None,
-                    help="bracket every n-th launch of each kernel class with HIP events (default: 10 on the per-period route, "
+                    help="bracket every n-th launch of each kernel class with HIP events (default: 40 on the per-period route, "
                          "1 on the whole-horizon route; each pair costs ~5 us)")
     ap.add_argument("--launch-order-out", default=None,
                     help="write the (kernel class, kernel) sequence of the timed steps as JSON and skip the event timing: what "
@@ -375,7 +375,7 @@ def main():
     if args.launch_order_out and eng is not None:
         timer = eng.timer = KernelTimer(record_order=True)
     elif not args.no_kernel_timing:
-        stride = args.timing_stride or (1 if (closed_form or (not gnn and eng.small is not None)) else 10)
+        stride = args.timing_stride or (1 if (closed_form or (not gnn and eng.small is not None)) else (10 if gnn else 40))
         timer = eng.timer = KernelTimer(stride=stride)
     if sharded:
         torch.distributed.barrier()
