@@ -186,7 +186,7 @@ def algorithmic_work(tag, kernel, shape):
         cols = n * (T if kind == "wgradT" else 1)
         if kernel.startswith("wgrad_small_kernel"):   # small route: one launch contracts over all T * ldb columns
             return "hbm", 4.0 * (N + K) * n * T, "B"  # operands read once (dZ [N] + X [K] rows per column)
-        if max(N, K) <= 64:                           # 32-wide layers on the per-period route: operand streaming
+        if max(N, K) <= 64 or kernel.startswith("thin_in_fwd"):   # 32-wide layers / the streamed first layer: operand streaming
             return "hbm", 4.0 * (N + K) * cols, "B"
         return "mfma", 2.0 * N * K * cols, "FLOP"
     if tag.startswith("mlp3_fwd_") or tag.startswith("mlp3_bwd_"):  # fused 3-layer MLP: K -> 32 -> 32 -> n_out per column

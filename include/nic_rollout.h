@@ -115,6 +115,14 @@ int nic_env_step_bwd(const NicEnvStepIO* io, const float* g_store_out, const flo
 int nic_linear_fwd(const float* W, int64_t ldw, const float* bias /* may be NULL */, const float* X, float* Y,
                    int32_t N, int32_t K, int32_t n_scenarios, int32_t ldb, int32_t act, void* stream);
 
+/* The same forward for a layer with a SHORT contraction and many output rows (the policy's first layer, create_sequential_net's
+ * LazyLinear at neural_networks.py:88-94: 512 x 51 at BASELINE cfg3), from the TRANSPOSED weights Wt[K][ldwt]: one pass that is
+ * bound by the output write instead of a tiled GEMM's epilogue.  Same contraction order and ELU as nic_linear_fwd (same bits).
+ * N: a multiple of 32, >= 128; K <= 52 (nic_linear_fwd_thin_in_ok); N * ldb * 4 < 2 GiB. */
+int nic_linear_fwd_thin_in_ok(int32_t N, int32_t K);
+int nic_linear_fwd_thin_in(const float* Wt, int64_t ldwt, const float* bias /* may be NULL */, const float* X, float* Y,
+                           int32_t N, int32_t K, int32_t n_scenarios, int32_t ldb, int32_t act, void* stream);
+
 /* Input gradient of the same layer (autograd of F.linear + activation of the PREVIOUS layer):
  *   dX[k][b] = (sum_n Wt[k][n] * dY[n][b]) * act'(Hprev[k][b])  (+ dX[k][b] if accumulate)
  * Wt = W transposed ([K][ldwt], refreshed by the caller once per optimizer step); Hprev = the previous layer's

@@ -97,6 +97,8 @@ PROTOTYPES = {
     "nic_env_step_fwd": (C.c_int, [_IOP, _vp, _vp, _vp, _vp, _vp]),
     "nic_env_step_bwd": (C.c_int, [_IOP, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_linear_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "nic_linear_fwd_thin_in_ok": (C.c_int, [_i32, _i32]),
+    "nic_linear_fwd_thin_in": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_linear_dgrad": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_wgrad_num_splits": (C.c_int, [_i32, _i32, _i32]),
     "nic_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -231,9 +231,122 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void th
     }
 }
 
+
+// ---- forward of a layer with a SHORT contraction and many output rows (the policy's first layer: 512 x 51 at cfg3) -----------
+// Y[N][ldb] = act(W X + b) with K <= 64: the launch is its output write (134 MB at 512 x 65,536 against 13 MB of input), and the
+// tiled GEMM - one 256 x 256 tile per CU at a time, 256 VGPRs - spends it in an epilogue that nothing overlaps (56 us = 2.4 TB/s;
+// the store pattern alone reaches 5.4 TB/s, tools/layout_probe.hip "first layer").  Here a wavefront owns 32 scenarios for ALL
+// output rows: its X tile stays in registers as the B operands (k = 2s + h), the weights stream through as A fragments from
+// the TRANSPOSED copy (lane i reads consecutive words: two 128-B lines per load, L1 / L2 hits shared by the CU's wavefronts),
+// 32 rows at a time, the next block's fragments in flight while this block's MFMAs run; ~130 VGPRs, so several wavefronts per
+// SIMD cover each other's stores and ELUs.  Same contraction order and the same ELU as the GEMM epilogue (elu_f): same bits.
+__device__ __forceinline__ float thin_elu(float x) {
+    const float xn = fminf(x, 0.f);
+    const float series =
+        xn * fmaf(xn, fmaf(xn, fmaf(xn, fmaf(xn, fmaf(xn, 1.f / 720.f, 1.f / 120.f), 1.f / 24.f), 1.f / 6.f), 0.5f), 1.f);
+    const float viaexp = __expf(xn) - 1.f;
+    const float neg = xn > -0.35f ? series : viaexp;
+    return x > 0.f ? x : neg;
+}
+constexpr int kThinInWaves = 4;
+#ifndef NIC_THIN_IN_SPLIT
+#define NIC_THIN_IN_SPLIT 2
+#endif
+constexpr int kThinInSplit = NIC_THIN_IN_SPLIT;   // wavefronts that share a scenario chunk, each taking a slice of the output rows
+template <int KS>
+__global__ __launch_bounds__(64 * kThinInWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void thin_in_fwd_kernel(const float* __restrict__ Wt, int64_t ldwt,
+                                                                        const float* __restrict__ bias, const float* __restrict__ X,
+                                                                        float* __restrict__ Y, int N, int K, int n_cols, int64_t ldb,
+                                                                        int act) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, i = j;
+    const int chunk = blockIdx.x * kThinInWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int64_t)chunk * 32 >= n_cols) return;
+    const int64_t col_raw = (int64_t)chunk * 32 + j;
+    const bool live = col_raw < n_cols;
+    const int64_t col = live ? col_raw : 0;
+    const bool full = (int64_t)(chunk + 1) * 32 <= n_cols;
+    // every operand through raw buffer descriptors: one 32-bit lane offset per buffer, rows as scalar offsets, and the rows past
+    // K (an odd K, or K below the template's step count) simply lie beyond the descriptor's extent and read as zero
+    auto rsrc_n = [](const float* p, int64_t n_floats) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(n_floats * 4), 0x00020000);
+    };
+    auto ldf = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    };
+    const int ld4 = (int)ldb * 4, lw4 = (int)ldwt * 4;
+    const __amdgpu_buffer_rsrc_t rX = rsrc_n(X, (int64_t)K * ldb), rW = rsrc_n(Wt, (int64_t)K * ldwt),
+                                 rB = rsrc_n(bias ? bias : Wt, bias ? N : 0),
+                                 rY = __builtin_amdgcn_make_buffer_rsrc(Y + (int64_t)chunk * 32, 0, 0x7fffffff, 0x00020000);
+    float x[KS];
+    const int vx = h * ld4 + (int)col * 4;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) x[s] = ldf(rX, vx, 2 * s * ld4);
+    const int vo = 4 * h * ld4 + j * 4;
+    // this wavefront's slice of the 32-row blocks (blockIdx.y)
+    const int all_blocks = N / 32, per = (all_blocks + kThinInSplit - 1) / kThinInSplit;
+    const int nb_lo = (int)blockIdx.y * per, n_blocks = (nb_lo + per < all_blocks ? nb_lo + per : all_blocks);
+    if (nb_lo >= n_blocks) return;
+    auto load_block = [&](int nb, float (&a)[KS]) {
+        const int vw = h * lw4 + (nb * 32 + i) * 4;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = ldf(rW, vw, 2 * s * lw4);
+    };
+    auto run_block = [&](int nb, const float (&a)[KS]) {
+        float bv[16];   // fetched here, used after the block's MFMAs
+        const int vb = (nb * 32 + 4 * h) * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = ldf(rB, vb + ((r & 3) + 8 * (r >> 2)) * 4, 0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x[s], acc, 0, 0, 0);
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float z = acc[r] + bv[r];
+            y[r] = act == NIC_ACT_ELU ? thin_elu(z) : z;
+        }
+        if (full || live) {   // (`full` is wave-uniform: no lane masks on the common path)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[r]), rY, vo, (nb * 32 + (r & 3) + 8 * (r >> 2)) * ld4, 0);
+        }
+    };
+    float a0[KS], a1[KS];
+    load_block(nb_lo, a0);
+    for (int nb = nb_lo; nb < n_blocks; nb += 2) {
+        if (nb + 1 < n_blocks) load_block(nb + 1, a1);
+        run_block(nb, a0);
+        if (nb + 1 < n_blocks) {
+            if (nb + 2 < n_blocks) load_block(nb + 2, a0);
+            run_block(nb + 1, a1);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int nic_linear_fwd_thin_in_ok(int32_t N, int32_t K) { return N >= 128 && N % 32 == 0 && K >= 1 && K <= 52; }
+
+int nic_linear_fwd_thin_in(const float* Wt, int64_t ldwt, const float* bias, const float* X, float* Y, int32_t N, int32_t K,
+                           int32_t n_scenarios, int32_t ldb, int32_t act, void* stream) {
+    NIC_REQUIRE(Wt && X && Y, "nic_linear_fwd_thin_in: null buffer");
+    NIC_REQUIRE(nic_linear_fwd_thin_in_ok(N, K), "nic_linear_fwd_thin_in: N (%d) must be a multiple of 32 >= 128 and K (%d) <= 52", N, K);
+    NIC_REQUIRE(ldwt >= N, "nic_linear_fwd_thin_in: ldwt (%lld) < N", (long long)ldwt);
+    NIC_REQUIRE(act == NIC_ACT_NONE || act == NIC_ACT_ELU, "nic_linear_fwd_thin_in: unknown activation %d", act);
+    NIC_REQUIRE(n_scenarios > 0 && ldb >= n_scenarios && ldb % 4 == 0,
+                "nic_linear_fwd_thin_in: ldb (%d) must be a multiple of 4 and >= n_scenarios (%d)", ldb, n_scenarios);
+    NIC_REQUIRE((int64_t)N * ldb * 4 < (1ll << 31), "nic_linear_fwd_thin_in: the output must span less than 2 GiB");
+    const int n_cols = (n_scenarios + 3) / 4 * 4;   // like nic_linear_fwd: the scenario count rounded up to 4 columns is written
+    const dim3 grid(nic::ceil_div(n_cols, 32 * kThinInWaves), kThinInSplit), block(64 * kThinInWaves);
+    hipStream_t s = nic::as_stream(stream);
+    nic::note_kernel("thin_in_fwd_kernel<26>");
+    hipLaunchKernelGGL(thin_in_fwd_kernel<26>, grid, block, 0, s, Wt, ldwt, bias, X, Y, N, K, n_cols, (int64_t)ldb, act);
+    return nic::check_launch("nic_linear_fwd_thin_in");
+}
 
 int nic_linear_bwd_thin(const float* W, int64_t ldw, const float* dY, const float* X, float* dX, float* slab, int64_t lds_,
                         int32_t N, int32_t K, int32_t n_scenarios, int32_t ldb, int32_t act_prev, int32_t n_splits,

@@ -78,6 +78,19 @@ def linear_fwd(W, bias, X, Y, n_scenarios, act):
     return Y
 
 
+def linear_fwd_thin_in_ok(N, K):
+    return bool(lib().nic_linear_fwd_thin_in_ok(int(N), int(K)))
+
+
+def linear_fwd_thin_in(Wt, bias, X, Y, n_scenarios, act):
+    """Y[N][ldb] = act(Wt[K][N(ldwt)]^T @ X[K][ldb] + bias) for a short contraction (K <= 52) and many output rows."""
+    _dev(X)
+    K, N = X.shape[0], Y.shape[0]
+    check(lib().nic_linear_fwd_thin_in(ptr(Wt), _ld(Wt), ptr(bias), ptr(X), ptr(Y), N, K, n_scenarios, X.stride(0), act,
+                                       current_stream()))
+    return Y
+
+
 def linear_dgrad(Wt, dY, Hprev, dX, n_scenarios, act_prev, accumulate):
     """dX[K][ldb] (+)= (Wt[K][N(ldwt)] @ dY[N][ldb]) * act'(Hprev)."""
     _dev(dY)

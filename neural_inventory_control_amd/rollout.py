@@ -452,6 +452,8 @@ class FusedRollout:
         prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
         ub = self._ub_now
         hist = self._hist
+        self._thin_in = (self.use_thin and L > 1 and biases[0] is not None and ops.linear_fwd_thin_in_ok(self.dims[1], self.dims[0])
+                         and 4 * self.dims[1] * ld < 2 ** 31)
         for t in range(T):
             cur, nxt, row = (t, t + 1, t) if hist else (t & 1, (t + 1) & 1, 0)
             st = self._views(self.states[cur], prob)
@@ -459,7 +461,10 @@ class FusedRollout:
             hs = t if train else 0
             for i in range(L - 1):
                 y = self.hidden[i][hs]
-                self._k(f"fwd_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_fwd, Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)
+                if i == 0 and self._thin_in:   # short contraction, many rows: the write-bound streamed forward (thin_layer.hip)
+                    self._k(f"fwd_{self.dims[1]}x{self.dims[0]}", ops.linear_fwd_thin_in, Wtv[0], biases[0], x, y, B, _lib.NIC_ACT_ELU)
+                else:
+                    self._k(f"fwd_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_fwd, Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)
                 x = y
             Z = self.logits[row]
             self._k(f"fwd_{self.dims[L]}x{self.dims[L - 1]}", ops.linear_fwd, Wv[L - 1], biases[L - 1], x, Z, B, _lib.NIC_ACT_NONE)

@@ -80,6 +80,42 @@ def _close(got, want64, scale64, what):
     assert not bool(bad.any()), (what, float(err.max()), float(bound.min()), int(bad.sum()))
 
 
+@pytest.mark.parametrize("N,K,B", [(512, 51, 4096), (512, 51, 1000), (128, 7, 777), (160, 50, 2049), (256, 1, 100), (512, 52, 64),
+                                   (192, 33, 96)])
+def test_linear_fwd_thin_in_equals_the_tiled_forward(N, K, B):
+    """nic_linear_fwd_thin_in (short contraction, many output rows, transposed weights) against nic_linear_fwd: the same
+    contraction order and the same ELU, so the same bits; float64 reference within the GEMM band; padding columns untouched."""
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(N * 100 + K)
+    ldb = pad_ld(B)
+    X = _rand((K, ldb), gen, dev)
+    W = _rand((N, K), gen, dev, 0.3)
+    Wt = torch.zeros(K, (N + 31) // 32 * 32 + 32, device=dev)   # (a row stride larger than N)
+    Wt[:, :N] = W.t()
+    bias = _rand((N,), gen, dev)
+    assert ops.linear_fwd_thin_in_ok(N, K) and not ops.linear_fwd_thin_in_ok(100, K) and not ops.linear_fwd_thin_in_ok(N, 53)
+    for act in (_lib.NIC_ACT_ELU, _lib.NIC_ACT_NONE):
+        for b_ in (bias, None):
+            want = torch.full((N, ldb), float("nan"), device=dev)
+            got = torch.full((N, ldb), float("nan"), device=dev)
+            ops.linear_fwd(W, b_, X, want, B, act)
+            ops.linear_fwd_thin_in(Wt[:, :N], b_, X, got, B, act)
+            torch.cuda.synchronize()
+            n4 = (B + 3) // 4 * 4
+            if K <= 32:   # one k tile in the tiled kernel: the same order of additions
+                assert torch.equal(got[:, :n4], want[:, :n4]), (act, float((got[:, :B] - want[:, :B]).abs().max()))
+            else:
+                torch.testing.assert_close(got[:, :n4], want[:, :n4], rtol=2e-6, atol=2e-6)
+            assert bool(torch.isnan(got[:, n4:]).all())
+    W64, X64 = W.double().cpu(), X.double().cpu()[:, :B]
+    pre = W64 @ X64 + bias.double().cpu()[:, None]
+    Y = torch.zeros(N, ldb, device=dev)
+    ops.linear_fwd_thin_in(Wt[:, :N], bias, X, Y, B, _lib.NIC_ACT_ELU)
+    torch.cuda.synchronize()
+    _close(Y[:, :B], torch.where(pre > 0, pre, torch.expm1(pre)), W64.abs() @ X64.abs() + bias.double().cpu().abs()[:, None], "thin_in")
+    assert _lib.lib().nic_last_kernel().decode() == "thin_in_fwd_kernel<26>"
+
+
 @pytest.mark.parametrize("N,K,B", GEMM_SHAPES)
 @pytest.mark.parametrize("padded_w", [False, True])
 def test_linear_fwd(N, K, B, padded_w):
