@@ -8,8 +8,7 @@ of those workloads (`<round>_traffic_<w>.json`, see traffic_pass).
 
 For each workload: the plain bench line (`<round>_bench_<w>.json`), the `rocprofv3 --kernel-trace --stats` summary of the
 same command (`<round>_bench_<w>_kernel_stats.csv`, per-(kernel, grid) split `..._kernel_by_grid.csv`) and the bench line
-printed under the profiler.  For cfg3 additionally two PMC passes (FETCH_SIZE, WRITE_SIZE - separate runs, kernel trace only,
-as the pool requires) turned into `<round>_traffic_cfg3.json`: HBM bytes per launch of every kernel class.
+printed under the profiler.  For cfg3 additionally the counter traffic (`traffic:cfg3`, see below).
 Everything is written to gpurun_out/<round>/ (merged back by gpurun); the caller copies what it wants judged to profiles/.
 """
 import csv
@@ -58,17 +57,6 @@ def stats_from_trace(trace_csv, stats_out, grid_out):
         w.writerow(["Name", "Workgroups", "WorkgroupSize", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
         for (k, n_wg, wg), v in sorted(by_grid.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([k, n_wg, wg, len(v), sum(v), round(sum(v) / len(v), 1), min(v), max(v)])
-
-
-def pmc_pass(counter, out_dir, bench_args):
-    run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", "python3", "bench.py"]
-        + bench_args)
-    res = defaultdict(list)
-    for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter:
-                res[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in res.items()}
 
 
 def note_name(k):
@@ -168,24 +156,8 @@ def main():
             stats_from_trace(traces[0], os.path.join(out, f"{rnd}_bench_{w}_kernel_stats.csv"),
                              os.path.join(out, f"{rnd}_bench_{w}_kernel_by_grid.csv"))
         print(w, open(os.path.join(out, f"{rnd}_bench_{w}.json")).read()[:300], flush=True)
-    if "cfg3" in workloads:
-        args = ["--steps", "1", "--warmup", "0", "--periods", "8", "--no-cpu-baseline", "--no-kernel-timing"]
-        fetch = pmc_pass("FETCH_SIZE", os.path.join(out, "pmc_fetch"), args)
-        write = pmc_pass("WRITE_SIZE", os.path.join(out, "pmc_write"), args)
-        kernels = []
-        for k in sorted(set(fetch) & set(write)):
-            if any(s in k for s in ("gemm_", "env_step", "thin_bwd", "head_", "wgrad_reduce")):
-                # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> doubled; both counters in KiB
-                kernels.append({"kernel": k, "launches": fetch[k][1], "FETCH_SIZE_KiB": round(fetch[k][0], 1),
-                                "WRITE_SIZE_KiB": round(write[k][0], 1),
-                                "hbm_bytes_per_launch": (2.0 * fetch[k][0] + write[k][0]) * 1024})
-        json.dump({"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --steps 1 --warmup 0 "
-                           "--periods 8 --no-cpu-baseline --no-kernel-timing` (cfg3 shapes); HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) "
-                           "x 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request).  Templates that run several layer shapes "
-                           "(gemm_wx_dma_kernel<2,4,4,2,EPI_BIAS_ACT>: K = 512 twice and K = 51 once per period) are means over them; "
-                           "the all-period weight gradients contract over the 8 periods of this run.",
-                   "n_scenarios": 65536, "kernels": kernels}, open(os.path.join(out, f"{rnd}_traffic_cfg3.json"), "w"), indent=1)
-        print("traffic", json.dumps(kernels)[:600], flush=True)
+    if "cfg3" in workloads:   # counter traffic of the headline workload rides along (bench.py reads it from profiles/ next time)
+        traffic_pass(rnd, "cfg3", out)
 
 
 if __name__ == "__main__":
