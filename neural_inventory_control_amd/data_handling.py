@@ -73,6 +73,8 @@ class Scenario:
                     if kind == "time_features":
                         dest[k] = col.unsqueeze(0).unsqueeze(0).expand(num_samples, problem_params["n_stores"], -1)
                     else:
+                        if self.num_total != num_samples:  # a shard keeps its own rows of a per-sample feature column
+                            col = col[self.scenario_offset: self.scenario_offset + num_samples]
                         dest[k] = col.unsqueeze(1).expand(-1, problem_params["n_stores"])
         self.split_by = self.define_how_to_split_data()
 
@@ -146,7 +148,8 @@ class Scenario:
                 print(f"Error: {e}")
 
     def read_real_demand_data(self, problem_params, demand_params, seed):
-        return torch.load(demand_params["file_location"], map_location="cpu")[: self.num_samples]
+        lo = self.scenario_offset  # (a shard takes ITS rows of the file, not the first ones)
+        return torch.load(demand_params["file_location"], map_location="cpu")[lo: lo + self.num_samples]
 
     def generate_demand_parameters(self, problem_params, demand_params, seeds):
         if demand_params["sample_across_stores"]:
@@ -211,12 +214,21 @@ class Scenario:
         flag = lambda k: p.get(k, False)  # noqa: E731  (missing keys read as False, data_handling.py:248)
         draw = np.random.randint if discrete else np.random.uniform
         S = problem_params["n_stores"]
+        # a shard (scenario_offset / num_total) takes rows [lo, lo + n) of what the single-process job draws or reads; the
+        # GLOBAL maximum of a discrete table is kept for `generate_initial_inventories` (its slot count must not depend on
+        # the shard)
+        lo, n = self.scenario_offset, self.num_samples
+        self._last_table_global_max = None
         if flag("file_location"):
-            p["value"] = torch.load(p["file_location"], map_location="cpu")[: self.num_samples]
+            whole = torch.load(p["file_location"], map_location="cpu")[: self.num_total]
+            self._last_table_global_max = whole.max().item() if whole.numel() else None
+            p["value"] = whole[lo: lo + n]
         if flag("sample_across_stores"):
             return torch.tensor(draw(*p["range"], S)).expand(self.num_samples, -1)
         if flag("vary_across_samples"):
-            return torch.tensor(draw(*p["range"], self.num_samples)).unsqueeze(1).expand(-1, S)
+            whole = torch.tensor(draw(*p["range"], self.num_total))
+            self._last_table_global_max = whole.max().item()
+            return whole[lo: lo + n].unsqueeze(1).expand(-1, S)
         if flag("expand"):
             v = torch.tensor(p["value"])
             if v.dim() == 2:  # [n_stores, n_warehouses] lead-time matrix
@@ -226,6 +238,7 @@ class Scenario:
 
     def generate_lead_times(self, problem_params, lead_time_params, seed):
         raw = self.generate_data_for_samples_and_stores(problem_params, lead_time_params, seed, discrete=True)
+        self._lead_time_global_max = self._last_table_global_max
         if raw.dim() == 2:
             nw = problem_params.get("n_warehouses", 0)
             raw = raw.unsqueeze(2).expand(-1, -1, nw) if nw > 0 else raw.unsqueeze(2)
@@ -238,7 +251,8 @@ class Scenario:
         if not spec["sample"]:
             return torch.zeros(self.num_samples, S, spec["inventory_periods"])
         demand_mean = self.global_store_demand_mean(demands)
-        slots = max(spec["inventory_periods"], lead_times.max().item())
+        lt_max = getattr(self, "_lead_time_global_max", None)   # per-sample lead times: the maximum over the WHOLE job
+        slots = max(spec["inventory_periods"], int(lt_max) if lt_max is not None else lead_times.max().item())
         mults = self._uniform_rows(spec["range_mult"], S * slots).reshape(self.num_samples, S, slots)
         return demand_mean[None, :, None] * torch.from_numpy(mults)  # f32 x f64 -> f64, cast to f32 in get_data
 

@@ -200,7 +200,8 @@ class GnnRollout:
             FusedRollout.materialize(type("E", (), {"model": shim})(), k)
 
     def _setup(self, prob, data, T, train):
-        key = (prob.B, T, bool(train), prob.S, prob.Ws, prob.Ww, self.fused_bwd, self.keep_inputs)
+        key = (prob.B, T, bool(train), prob.S, prob.Ws, prob.Ww, self.fused_bwd, self.keep_inputs,
+               data.get("warehouse_edge_costs") is not None)
         if key == self._key:
             return
         dev, ld, S = self.device, prob.ldb, prob.S
@@ -291,6 +292,10 @@ class GnnRollout:
         self.demand = demand_soa
         for m in self.mlp.values():
             m.pack()
+        # per-edge lead-time input rows: sample 0 of THIS batch stands for the batch, as upstream re-reads it every forward
+        # (:984) - refreshed on the device (no sync, capturable), so a later batch of the same shape never sees stale values
+        P.lead[0, :S].copy_(data["lead_times"][0, :, 0])
+        P.lead[0, S:S + 1].copy_(data["warehouse_lead_times"][0, :1])
         s0 = self._views(self.states[0], prob)
         s0.store[:, :, :B].copy_(data["initial_inventories"].permute(1, 2, 0))
         s0.wh[:, :, :B].copy_(data["initial_warehouse_inventories"].permute(1, 2, 0))

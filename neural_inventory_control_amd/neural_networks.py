@@ -526,12 +526,17 @@ class JustInTime(MyNeuralNetwork):
             return {"stores": torch.clip(fut, min=0).unsqueeze(2)}
         lt, wlt = observation["lead_times"], observation["warehouse_lead_times"]
         adj = torch.tensor(self.scenario.problem_params["warehouse_store_adjacency"], dtype=torch.float32)
-        fastest = getattr(self, "_fastest", None)
-        if fastest is None:  # static: which connected warehouse has the shortest (batch-mean) lead time for each store
+        # which connected warehouse has the shortest batch-mean lead time for each store: recomputed for every BATCH like
+        # upstream (:695-699; per-sample lead times from file can move the argmin from batch to batch), but only once per
+        # batch - the lead-time tensor of an observation is the same object for all periods of a rollout
+        lt_key = (lt.data_ptr(), lt._version, tuple(lt.shape))
+        if getattr(self, "_fastest_key", None) != lt_key:
             mean_lt = lt.mean(dim=0).cpu()
-            fastest = self._fastest = [
+            self._fastest = [
                 (int(conn[torch.argmin(mean_lt[st, conn])]) if len(conn) > 0 else None)
                 for st, conn in ((st, adj[:, st].nonzero(as_tuple=True)[0]) for st in range(n_stores))]
+            self._fastest_key = lt_key
+        fastest = self._fastest
         alloc = torch.zeros(n, n_stores, n_warehouses, device=dev)
         wh = torch.zeros(n, n_warehouses, device=dev)
         for st, w in enumerate(fastest):

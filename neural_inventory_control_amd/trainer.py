@@ -23,6 +23,18 @@ from .loss_functions import PolicyLoss
 from .rollout import FusedRollout
 
 
+def _numpy_scalar_globals():
+    """What a reference-written checkpoint needs beyond tensors: numpy scalars / dtypes (best losses are np.float64)."""
+    out = [np.dtype, np.float64, np.float32, np.int64, type(np.dtype("float64")), type(np.dtype("float32")),
+           type(np.dtype("int64"))]
+    for mod, name in (("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar")):
+        try:
+            out.append(getattr(__import__(mod, fromlist=[name]), name))
+        except Exception:
+            pass
+    return out
+
+
 class _FusedTotal(torch.autograd.Function):
     """Makes the fused rollout's total cost a differentiable function of the policy parameters for callers that use the
     reference idiom `total, _ = trainer.simulate_batch(...); (total / n).backward()` (trainer.py:160-173): the engine has
@@ -136,10 +148,13 @@ class Trainer:
                     epoch_loss += tot.detach()
                     epoch_report += rep.detach()
                     continue
+                # `use_step_graph` captures the whole training step of every policy whose per-period work is launch-bound: the
+                # generic route AND the closed-form policies' whole-horizon kernel (its launch, the level network's autograd
+                # and the totals: 0.55 -> 0.18 ms per step).  The MLP / GNN engines run GPU-bound launch sequences of their own
+                # (`FusedRollout.use_graph` replays those) and keep the eager step.
                 graphed = (train and model.trainable and self.use_step_graph and not discrete_allocation
                            and not (self.use_fused_rollout and self._plain_observation(observation_params)
-                                    and (FusedRollout.supports(model) or ClosedFormRollout.supports(model)
-                                         or GnnRollout.supports(model, problem_params))))
+                                    and (FusedRollout.supports(model) or GnnRollout.supports(model, problem_params))))
                 if graphed:
                     total_reward, reward_to_report = self._graphed_generic_step(
                         loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
@@ -366,11 +381,20 @@ class Trainer:
         return {k: v.to(self.device) for k, v in data_batch.items()}
 
     def load_model(self, model, optimizer, model_path):
-        try:  # the reference's checkpoints hold tensors, lists and numbers only: no need to unpickle arbitrary objects
-            checkpoint = torch.load(model_path, map_location=self.device, weights_only=True)
-        except Exception:
-            if not getattr(self, "allow_pickled_checkpoints", True):
-                raise
+        # The reference's checkpoints hold tensors, lists and numbers (numpy scalars among them: `best_train_loss` is a
+        # np.float64): they are allow-listed for the safe loader instead of unpickling arbitrary objects.  A checkpoint that
+        # still fails the safe load is only unpickled when the caller opted in (`trainer.allow_pickled_checkpoints = True`).
+        import pickle
+        try:
+            with torch.serialization.safe_globals(_numpy_scalar_globals()):
+                checkpoint = torch.load(model_path, map_location=self.device, weights_only=True)
+        except pickle.UnpicklingError as e:
+            if not getattr(self, "allow_pickled_checkpoints", False):
+                raise pickle.UnpicklingError(
+                    f"{model_path}: not loadable with weights_only=True ({e}); set trainer.allow_pickled_checkpoints = True "
+                    "to unpickle it (only for files you trust)") from e
+            import warnings
+            warnings.warn(f"{model_path}: falling back to the unsafe pickle loader (allow_pickled_checkpoints)")
             checkpoint = torch.load(model_path, map_location=self.device, weights_only=False)
         model.load_state_dict(checkpoint["model_state_dict"])
         optimizer.load_state_dict(checkpoint["optimizer_state_dict"])

@@ -875,9 +875,12 @@ def test_gradient_parity_at_benchmark_width_and_horizon():
         assert e_hip <= max(2.0 * e_ref, GRAD_TOL), (i, e_hip, e_ref)  # (tensors already inside the 2e-5 bar need no referee)
 
 
-def test_trainer_epochs_with_step_graph_match_eager_training():
-    """Three epochs of `Trainer.do_one_epoch` on a closed-form policy (generic route), eager vs `use_step_graph`: the same
-    per-epoch losses and the same parameters after Adam."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_trainer_epochs_with_step_graph_match_eager_training(fused):
+    """Three epochs of `Trainer.do_one_epoch` on a closed-form policy, eager vs `use_step_graph`: the same per-epoch losses
+    and the same parameters after Adam.  fused = False: generic route (Simulator.step + autograd).  fused = True (the
+    Trainer's default): the closed-form whole-horizon kernel inside the captured step - what `main_run`'s
+    `use_step_graph: true` reaches through the PUBLIC epoch loop (several batches per epoch, a ragged last batch)."""
     from neural_inventory_control_amd.environment import Simulator
     from neural_inventory_control_amd.loss_functions import PolicyLoss
     from neural_inventory_control_amd.trainer import Trainer
@@ -898,14 +901,16 @@ def test_trainer_epochs_with_step_graph_match_eager_training():
         _load(model, g)
         opt = torch.optim.Adam(model.parameters(), lr=0.05)
         tr = Trainer(device=DEV)
-        tr.use_fused_rollout = False  # generic route: Simulator.step + autograd (optionally replayed from a HIP graph)
+        tr.use_fused_rollout = fused
         tr.use_step_graph = graph
-        loader = DeviceBatches(ds, 20, shuffle=False, device=DEV)
+        loader = DeviceBatches(ds, 20 if not fused else 16, shuffle=False, device=DEV)  # (16: a ragged last batch of 8)
         losses = [tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, c["periods"], c["problem_params"],
                                   c["observation_params"], train=True, ignore_periods=c["ignore"])[1] for _ in range(3)]
         return losses, [p.detach().clone() for p in model.parameters()]
 
     (le, pe), (lg, pg) = train(False), train(True)
+    if fused:
+        assert c["n"] % 16  # the epoch really ends on a smaller batch (its own captured shape)
     for a, b in zip(le, lg):
         assert abs(a - b) <= 1e-6 * abs(a)
     for a, b in zip(pe, pg):

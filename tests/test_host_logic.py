@@ -200,3 +200,35 @@ def test_real_data_scenario_and_period_split_equal_reference(name):
     for k, v in ref.items():
         assert ds.data[k].dtype == torch.float32 and torch.equal(ds.data[k], v), k
     assert sc.split_by["period"] == ["demands"] + list(c["observation_params"]["time_features"])
+
+
+def test_sharded_host_generation_with_per_sample_tables_equals_single_process(tmp_path):
+    """Shards of a job whose tables vary ACROSS SAMPLES (drawn per scenario, or read from a per-sample file): rows
+    [lo, lo + n) of every tensor equal the single-process dataset - per-sample costs, per-sample lead times (whose GLOBAL
+    maximum sets the number of pipeline slots, data_handling.py:302) and file-backed tables."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    n_total, T = 23, 6
+    path = str(tmp_path / "holding.pt")
+    torch.save(torch.rand(40, 1, generator=torch.Generator().manual_seed(5)) + 0.5, path)
+
+    def build(n, lo, total):
+        s, _, _, _, _ = workloads.get("cfg2")
+        s["store_params"]["underage_cost"] = {"sample_across_stores": False, "vary_across_samples": True, "expand": False,
+                                              "range": [5.0, 12.0]}
+        # the largest lead time (8) is not drawn for the first 9 scenarios: a shard that looked at its own rows only would
+        # build fewer pipeline slots (and draw its multipliers from a different place of the stream)
+        s["store_params"]["lead_time"] = {"sample_across_stores": False, "vary_across_samples": True, "expand": False,
+                                          "range": [2, 9]}
+        s["store_params"]["holding_cost"] = {"file_location": path}
+        obs = defaultdict(lambda: None, s["observation_params"])
+        return Scenario(T, s["problem_params"], s["store_params"], None, None, n, obs, s["seeds"], scenario_offset=lo,
+                        num_total=total).get_data()
+
+    whole = build(n_total, 0, n_total)
+    assert whole["initial_inventories"].shape[2] == int(whole["lead_times"].max())
+    cuts = [0, 9, 17, n_total]
+    parts = [build(b - a, a, n_total) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert len({int(p["lead_times"].max()) for p in parts}) > 1   # the shards do see different local maxima
+    for k, v in whole.items():
+        assert torch.equal(torch.cat([p[k] for p in parts], dim=0), v), k
