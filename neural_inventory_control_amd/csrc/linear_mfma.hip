@@ -41,6 +41,24 @@ constexpr int kThreads = 256;
 enum { EPI_BIAS_ACT = 0, EPI_DGRAD = 1 };
 const char* epi_name(int epi) { return epi == EPI_BIAS_ACT ? "EPI_BIAS_ACT" : "EPI_DGRAD"; }
 
+// In-kernel timestamps and timing-only switches (tuning build only: tools/gemm_stamp_probe.py compiles its own copy of the
+// library with -DNIC_TUNING_BUILD; the product library contains none of this).  Slot s of workgroup w: {s_memtime, 100 MHz wall
+// clock} at kernel entry (0), in front of the k loop (1), behind it (2) and at exit (3).
+#ifdef NIC_TUNING_BUILD
+__device__ unsigned long long* g_nic_stamps = nullptr;
+#define NIC_STAMP(slot)                                                                  \
+    do {                                                                                 \
+        if (g_nic_stamps != nullptr && threadIdx.x == 0) {                               \
+            g_nic_stamps[(blockIdx.x * 4 + (slot)) * 2] = __builtin_readcyclecounter();  \
+            g_nic_stamps[(blockIdx.x * 4 + (slot)) * 2 + 1] = wall_clock64();            \
+        }                                                                                \
+    } while (0)
+#define NIC_TUNE(bit) (p.tune & (bit))
+#else
+#define NIC_STAMP(slot) do { } while (0)
+#define NIC_TUNE(bit) false
+#endif
+
 struct WxParams {
     const float* A;      // [M][lda]
     int64_t lda;
@@ -52,6 +70,8 @@ struct WxParams {
     int64_t ldb;
     int act;             // NIC_ACT_*
     int accumulate;      // EPI_DGRAD: C += result
+    int tune;            // tuning build only, timing experiments (results invalid): 1 = no A-tile copies inside the k loop,
+                         // 2 = no B-tile copies, 4 = no barrier per k tile, 32 = s_setprio 1 for waves 4-7 (valid results)
 };
 
 // ELU.  libm's expm1f is ~40 VALU instructions and the epilogue applies it to every output element (33.5 M per 512-wide
@@ -357,6 +377,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+    NIC_STAMP(0);
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     const int m0 = (tile % tiles_m) * BM;
@@ -385,14 +406,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
         offB[q] = (int)(((int64_t)row * p.ldb + c0 + (lane % B_LPR) * 4) * 4);
     }
     const int stepB = (int)(p.ldb * BK * 4);
+    bool in_loop = false;  // (tuning build: the timing-only switches leave the prologue's copy alone)
     auto issue = [&](int stage) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(stage * STAGE) * 4u);
         const unsigned wbase_a = __builtin_amdgcn_readfirstlane(base + (unsigned)(wave * A_INSTR) * 1024u);
         const unsigned wbase_b = __builtin_amdgcn_readfirstlane(base + (unsigned)A_FLOATS * 4u + (unsigned)(wave * B_INSTR) * 1024u);
+        if (!(NIC_TUNE(1) && in_loop)) {
 #pragma unroll
-        for (int q = 0; q < A_INSTR; ++q) dma16(ra, offA[q], wbase_a + q * 1024u);
+            for (int q = 0; q < A_INSTR; ++q) dma16(ra, offA[q], wbase_a + q * 1024u);
+        }
+        if (!(NIC_TUNE(2) && in_loop)) {
 #pragma unroll
-        for (int q = 0; q < B_INSTR; ++q) dma16(rb, offB[q], wbase_b + q * 1024u);
+            for (int q = 0; q < B_INSTR; ++q) dma16(rb, offB[q], wbase_b + q * 1024u);
+        }
     };
     auto advance = [&]() {
 #pragma unroll
@@ -462,11 +488,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
             }
         }
         dma_wait();  // tile kt+1 has landed (this wave's share); the barrier publishes every wave's share
-        __syncthreads();
+        if (!NIC_TUNE(4)) __syncthreads();
     };
     issue(0);
     dma_wait();
     __syncthreads();
+    NIC_STAMP(1);
+    in_loop = true;
+#ifdef NIC_TUNING_BUILD
+    // static priority for the younger half of the workgroup (cdna_hip_programming.md T5, static form)
+    if (NIC_TUNE(32) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= NTHREADS / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     const int nk_plain = pf_on ? nk - PFT : nk;
     for (int kt = 0; kt < nk_plain; ++kt) ktile(kt);
     if constexpr (EPI == EPI_DGRAD) {
@@ -480,6 +512,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
         }
     }
 
+    NIC_STAMP(2);
     // epilogue: stage the block tile through LDS and write whole rows
     float* cs = lds;
     // Production case first (whole tile inside the matrix; forward: bias + ELU, dgrad: prefetched Hprev): straight-line row
@@ -531,6 +564,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
             }
             if (pass + 1 < PASSES) __syncthreads();
         }
+        NIC_STAMP(3);
         return;
     }
 #pragma unroll
@@ -1092,6 +1126,14 @@ void launch_wx(const WxParams& p, hipStream_t s) {
 // outside the package); the product library has no environment switches: every variant below is a correct kernel, but
 // which one runs must not depend on a stray variable.
 #ifdef NIC_TUNING_BUILD
+extern "C" int nic_tuning_set_stamps(void* buf) {  // buf: device memory, 8 x u64 per workgroup of the next launches (or null)
+    unsigned long long* pbuf = static_cast<unsigned long long*>(buf);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nic_stamps), &pbuf, sizeof(pbuf));
+}
+int tune_flags() {  // NIC_GEMM_TUNE: timing experiments inside the wx kernel (see WxParams::tune); read at every launch
+    const char* e = getenv("NIC_GEMM_TUNE");
+    return e ? atoi(e) : 0;
+}
 int gemm_variant() {
     static int v = -1;
     if (v < 0) {
@@ -1102,6 +1144,7 @@ int gemm_variant() {
 }
 #else
 constexpr int gemm_variant() { return 0; }
+constexpr int tune_flags() { return 0; }
 #endif
 
 template <int EPI>
@@ -1169,7 +1212,7 @@ int nic_linear_fwd(const float* W, int64_t ldw, const float* bias, const float* 
     if (int e = require_ld("nic_linear_fwd", n_scenarios, ldb)) return e;
     NIC_REQUIRE((reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
                 "nic_linear_fwd: X/Y must be 16-byte aligned");
-    WxParams p{W, ldw, X, Y, bias, nullptr, N, K, (n_scenarios + 3) / 4 * 4, ldb, act, 0};
+    WxParams p{W, ldw, X, Y, bias, nullptr, N, K, (n_scenarios + 3) / 4 * 4, ldb, act, 0, tune_flags()};
     dispatch_wx<EPI_BIAS_ACT>(p, nic::as_stream(stream));
     return nic::check_launch("nic_linear_fwd");
 }
@@ -1182,7 +1225,7 @@ int nic_linear_dgrad(const float* Wt, int64_t ldwt, const float* dY, const float
     NIC_REQUIRE((reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(dX) & 15) == 0,
                 "nic_linear_dgrad: dY/dX must be 16-byte aligned");
     // dX[K][b] = Wt[K][N] * dY[N][b]: output rows = K, contraction = N
-    WxParams p{Wt, ldwt, dY, dX, nullptr, Hprev, K, N, (n_scenarios + 3) / 4 * 4, ldb, act_prev, accumulate};
+    WxParams p{Wt, ldwt, dY, dX, nullptr, Hprev, K, N, (n_scenarios + 3) / 4 * 4, ldb, act_prev, accumulate, tune_flags()};
     dispatch_wx<EPI_DGRAD>(p, nic::as_stream(stream));
     return nic::check_launch("nic_linear_dgrad");
 }

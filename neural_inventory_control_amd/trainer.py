@@ -276,8 +276,13 @@ class Trainer:
         params = [p for p in model.parameters() if p.requires_grad]
         if st["static"] is None:
             static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_batch.items()}
+            # static gradient tensors: the captured graph writes into THESE.  They are shared by every captured batch shape
+            # of the model (an epoch that ends on a smaller batch captures a second graph: replacing `.grad` here would
+            # leave the first graph accumulating into tensors the optimizer no longer sees)
             for p in params:
-                p.grad = torch.zeros_like(p)
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            st["grads"] = [p.grad for p in params]
             stream = torch.cuda.Stream()
             stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stream):  # one more eager run on the side stream (allocator / autograd warm-up)
@@ -313,6 +318,9 @@ class Trainer:
         for k, v in data_batch.items():
             if torch.is_tensor(v):
                 st["static"][k].copy_(v)
+        for p, g in zip(params, st["grads"]):  # (someone set `.grad` to None / another tensor since the capture)
+            if p.grad is not g:
+                p.grad = g
         st["graph"].replay()
         self._fused_grads_ready = True
         return st["total"], st["rep"]

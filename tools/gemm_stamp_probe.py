@@ -1,0 +1,98 @@
+"""Where does a 512 x 512 policy-GEMM launch spend its time, and at what clock?  Compiles its own copy of the library with
+-DNIC_TUNING_BUILD (in-kernel timestamps: s_memtime + the 100 MHz wall clock at kernel entry, in front of the k loop, behind it
+and at exit, per workgroup), runs the forward / dgrad kernels at BASELINE cfg3's shape and prints per phase the mean duration
+and the s_memtime rate.  PROBE_TUNES=0,1,2,3,4,7 additionally runs timing-only variants of the k loop (results invalid):
+1 = no A-tile copies inside the loop, 2 = no B-tile copies, 4 = no barrier per k tile; 32 = s_setprio 1 for the younger half of
+the workgroup (valid results).  PROBE_PADS=0,64,... adds floats to the scenario stride of every operand.  The product library has no such instrumentation."""
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from neural_inventory_control_amd import _lib, ops
+from neural_inventory_control_amd.layout import pad_ld
+from gemm_probe import _tuning_library
+
+
+def run_case(lib, name, fn, n_wg, K, stamps):
+    for _ in range(30):
+        fn()
+    torch.cuda.synchronize()
+    assert lib.nic_tuning_set_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    fn()
+    e.record()
+    torch.cuda.synchronize()
+    lib.nic_tuning_set_stamps(None)
+    # un-instrumented timing of the same launch (mean of 50)
+    s2, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s2.record()
+    for _ in range(50):
+        fn()
+    e2.record()
+    torch.cuda.synchronize()
+    st = stamps.view(n_wg, 4, 2).double().cpu()
+    t0 = st[:, 0, 1].min()
+    ph = {}
+    for i, nm in enumerate(("prologue", "k_loop", "epilogue")):
+        wall = (st[:, i + 1, 1] - st[:, i, 1]) / 100.0          # us
+        cyc = st[:, i + 1, 0] - st[:, i, 0]
+        ph[nm] = {"us_mean": round(float(wall.mean()), 2), "us_max": round(float(wall.max()), 2),
+                  "memtime_ticks_per_us": round(float((cyc / wall.clamp_min(1e-9)).mean()), 1)}
+    end = (st[:, 3, 1] - t0) / 100.0
+    start = (st[:, 0, 1] - t0) / 100.0
+    first = start < 5.0   # workgroups of the first round (dispatched at launch)
+    kl = (st[:, 2, 1] - st[:, 1, 1]) / 100.0
+    rate = (st[:, 2, 0] - st[:, 1, 0]) / kl.clamp_min(1e-9)
+    rounds = {}
+    for nm, m in (("round1", first), ("later", ~first)):
+        if int(m.sum()):
+            q = torch.quantile(kl[m], torch.tensor([0.0, 0.5, 1.0], dtype=kl.dtype))
+            rounds[nm] = {"n": int(m.sum()), "k_loop_us_min_med_max": [round(float(v), 1) for v in q],
+                          "memtime_ticks_per_us": round(float(rate[m].mean()), 1),
+                          "start_us_min_max": [round(float(start[m].min()), 1), round(float(start[m].max()), 1)]}
+    # MFMA issue cycles of the k loop per SIMD: 2 waves x (K / 2) steps x 8 MFMAs x 64 cycles
+    issue_cycles = 2 * (K // 2) * 8 * 64
+    ph["k_loop"]["mfma_issue_cycles_per_us"] = round(issue_cycles / float(((st[:, 2, 1] - st[:, 1, 1]) / 100.0).mean()), 1)
+    return {"event_us_stamped": round(s.elapsed_time(e) * 1e3, 1), "event_us": round(s2.elapsed_time(e2) * 1e3 / 50, 1),
+            "workgroups": n_wg, "phases": ph, "rounds": rounds, "last_exit_us": round(float(end.max()), 1)}
+
+
+def main():
+    lib = _lib._lib = _lib.load_library(_tuning_library())
+    lib.nic_tuning_set_stamps.argtypes = [ctypes.c_void_p]
+    dev = "cuda"
+    N = K = 512
+    out = {}
+    tunes = [int(v) for v in os.environ.get("PROBE_TUNES", "0").split(",")]
+    for tune in tunes:
+        os.environ["NIC_GEMM_TUNE"] = str(tune)
+        pads = [int(v) for v in os.environ.get("PROBE_PADS", "0").split(",")]
+        for B, pad in [(b_, p_) for b_ in ((65536, 32768, 98304) if tune == 0 and len(pads) == 1 else (65536,)) for p_ in pads]:
+            ldb = pad_ld(B) + pad
+            W = torch.randn(N, K, device=dev) * 0.05
+            Wt = W.t().contiguous()
+            b = torch.randn(N, device=dev)
+            X = torch.nn.functional.elu(torch.randn(K, ldb, device=dev))
+            Y = torch.zeros(N, ldb, device=dev)
+            dX = torch.zeros(K, ldb, device=dev)
+            n_wg = (N // 256) * (B // 256)
+            stamps = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
+            cases = [("fwd", lambda: ops.linear_fwd(W, b, X, Y, B, 1))]
+            if tune == 0:
+                cases.append(("dgrad", lambda: ops.linear_dgrad(Wt, Y, X, dX, B, 1, False)))
+            for name, fn in cases:
+                r = run_case(lib, name, fn, n_wg, K, stamps)
+                r["tflops"] = round(2.0 * N * K * B / (r["event_us"] * 1e-6) / 1e12, 1)
+                out[f"{name}_{B}_pad{pad}_tune{tune}"] = r
+                print(f"{name}_{B}_pad{pad}_tune{tune}", "event", r["event_us"], "tflops", r["tflops"], "| kloop", r["phases"]["k_loop"], "| epi",
+                      r["phases"]["epilogue"]["us_mean"], "|", r["rounds"], flush=True)
+    if os.environ.get("PROBE_JSON"):
+        print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

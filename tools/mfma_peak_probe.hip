@@ -19,7 +19,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int ACC, bool LDS_FED>
+template <int ACC, int LDS_FED>  // LDS_FED: 0 = register-only, 1 = reads waited for right before use, 2 = reads issued one iteration ahead
 __global__ __launch_bounds__(512) void mfma_loop(int iters, float* sink, unsigned long long* stamps, float seed) {
     extern __shared__ float lds[];
     f16v acc[ACC];
@@ -36,18 +36,29 @@ __global__ __launch_bounds__(512) void mfma_loop(int iters, float* sink, unsigne
     float2 fb = make_float2(b, 0.f);
     unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     for (int it = 0; it < iters; it++) {
-        if (LDS_FED) {
-            // per 8 MFMAs the production k loop reads 6 fragments' worth (4 A + 2 B values per lane for 2 k): one b128 + one b64,
-            // fetched one iteration ahead like the production loop's software pipeline
+        if (LDS_FED == 1) {
+            // per 8 MFMAs the production k loop reads 6 fragments' worth (4 A + 2 B values per lane for 2 k): one b128 + one b64.
+            // hipcc puts these reads behind the MFMAs and their s_waitcnt lgkmcnt(0) in front of the next iteration's: the
+            // pattern it also produces for the production loop (read -> wait -> 8 MFMAs)
             a = fa.x + fa.y * 1e-9f + fa.z * 1e-9f + fa.w * 1e-9f;
             b = fb.x + fb.y * 1e-9f;
             fa = *reinterpret_cast<const float4*>(&lds[((threadIdx.x * 4 + it * 256) & 16383) & ~3]);
             fb = *reinterpret_cast<const float2*>(&lds[((threadIdx.x * 2 + it * 128 + 8192) & 16383) & ~1]);
         }
+        if (LDS_FED == 2) {  // software-pipelined: the reads of iteration it + 1 are ISSUED before the MFMAs of iteration it
+            fa = *reinterpret_cast<const float4*>(&lds[((threadIdx.x * 4 + it * 256) & 16383) & ~3]);
+            fb = *reinterpret_cast<const float2*>(&lds[((threadIdx.x * 2 + it * 128 + 8192) & 16383) & ~1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int u = 0; u < 8 / ACC; u++)
 #pragma unroll
             for (int i = 0; i < ACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        if (LDS_FED == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            a = fa.x + fa.y * 1e-9f + fa.z * 1e-9f + fa.w * 1e-9f;
+            b = fb.x + fb.y * 1e-9f;
+        }
     }
     unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     float s = 0.f;
@@ -63,7 +74,7 @@ __global__ __launch_bounds__(512) void mfma_loop(int iters, float* sink, unsigne
     }
 }
 
-template <int ACC, bool LDS_FED>
+template <int ACC, int LDS_FED>
 static void run(const char* name, int waves_per_simd, int iters, int n_cu) {
     const int threads = 256 * waves_per_simd;       // 4 SIMDs x waves_per_simd wavefronts per workgroup, one workgroup per CU
     const size_t lds_bytes = 96 * 1024;             // > half of the 160 KB: at most one workgroup per CU
@@ -104,7 +115,7 @@ static void run(const char* name, int waves_per_simd, int iters, int n_cu) {
     printf("{\"variant\": \"%s\", \"waves_per_simd\": %d, \"acc_sets\": %d, \"lds_fed\": %s, \"mfma_per_wave\": %.0f, "
            "\"ms_best\": %.4f, \"ms_mean\": %.4f, \"tflops_best\": %.1f, \"tflops_mean\": %.1f, "
            "\"in_kernel_loop_us\": %.1f, \"clock_ghz_from_mfma_issue\": %.3f, \"memtime_ticks_per_us\": %.1f}\n",
-           name, waves_per_simd, ACC, LDS_FED ? "true" : "false", mfma_per_wave, best, sum / reps, flop / best / 1e9, flop / (sum / reps) / 1e9,
+           name, waves_per_simd, ACC, LDS_FED == 0 ? "\"no\"" : (LDS_FED == 1 ? "\"read-wait-mfma\"" : "\"prefetched\""), mfma_per_wave, best, sum / reps, flop / best / 1e9, flop / (sum / reps) / 1e9,
            loop_us, issue_cycles / loop_us / 1e3, cyc / loop_us);
     CHECK(hipFree(sink));
     CHECK(hipFree(stamps));
@@ -116,14 +127,17 @@ int main(int argc, char** argv) {
     CHECK(hipGetDeviceProperties(&p, 0));
     const int n_cu = p.multiProcessorCount;
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_rate_khz\": %d}\n", p.gcnArchName, n_cu, p.clockRate);
-    run<4, false>("register-only", 1, iters, n_cu);
-    run<1, false>("register-only, dependent chain", 1, iters, n_cu);
-    run<8, false>("register-only", 1, iters, n_cu);
-    run<4, false>("register-only", 2, iters / 2, n_cu);
-    run<8, false>("register-only (the production wave: 8 tiles)", 2, iters / 2, n_cu);
-    run<8, true>("k-loop-like: + LDS fragment reads", 2, iters / 2, n_cu);
+    run<4, 0>("register-only", 1, iters, n_cu);
+    run<1, 0>("register-only, dependent chain", 1, iters, n_cu);
+    run<8, 0>("register-only", 1, iters, n_cu);
+    run<4, 0>("register-only", 2, iters / 2, n_cu);
+    run<8, 0>("register-only (the production wave: 8 tiles)", 2, iters / 2, n_cu);
+    run<8, 1>("k-loop-like: + LDS fragment reads, read -> wait -> MFMAs (what hipcc emits)", 2, iters / 2, n_cu);
+    run<8, 2>("k-loop-like: + LDS fragment reads issued one iteration ahead", 2, iters / 2, n_cu);
+    run<8, 1>("k-loop-like, one wave per SIMD: read -> wait -> MFMAs", 1, iters, n_cu);
+    run<8, 2>("k-loop-like, one wave per SIMD: reads issued one iteration ahead", 1, iters, n_cu);
     // a short launch of the production kernels' length (2 x 2,048 MFMAs per wave at two waves per SIMD = ~240 us): does the clock
     // the part holds over 0.25 ms differ from the one it holds over 10 ms?
-    run<8, false>("register-only, production launch length", 2, 512, n_cu);
+    run<8, 0>("register-only, production launch length", 2, 512, n_cu);
     return 0;
 }

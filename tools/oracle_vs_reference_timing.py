@@ -68,23 +68,21 @@ def main():
             return float(total.detach())
 
         ref_step(min(T, 5), {k: v[:64] for k, v in data_r.items()})  # warm-up (materialises the lazy layers)
-        t_ref, tot_ref = [], None
+        data_o = orc.generate_scenario_data(T, cs_o["problem_params"], cs_o["store_params"], cs_o["warehouse_params"],
+                                            cs_o["echelon_params"], n, obs_o, cs_o["seeds"])
+        wub = model.warehouse_upper_bound if torch.is_tensor(model.warehouse_upper_bound) else None
+        pol = orc.policy_from_state_dict(ch["nn_params"], model.state_dict(), cs_o["problem_params"], wub)
+        orc.train_step_gradients(pol, min(T, 5), cs_o["problem_params"], {k: v[:64] for k, v in data_o.items()}, obs_o)
+        # the two sides alternate, so that a drift of the host's load hits both alike
+        t_ref, t_orc, tot_ref, tot_orc = [], [], None, None
         for _ in range(args.reps):
             t0 = time.perf_counter()
             tot_ref = ref_step()
             t_ref.append(time.perf_counter() - t0)
-
-    data_o = orc.generate_scenario_data(T, cs_o["problem_params"], cs_o["store_params"], cs_o["warehouse_params"],
-                                        cs_o["echelon_params"], n, obs_o, cs_o["seeds"])
-    wub = model.warehouse_upper_bound if torch.is_tensor(model.warehouse_upper_bound) else None
-    pol = orc.policy_from_state_dict(ch["nn_params"], model.state_dict(), cs_o["problem_params"], wub)
-    orc.train_step_gradients(pol, min(T, 5), cs_o["problem_params"], {k: v[:64] for k, v in data_o.items()}, obs_o)
-    t_orc, tot_orc = [], None
-    for _ in range(args.reps):
-        t0 = time.perf_counter()
-        res, _, _ = orc.train_step_gradients(pol, T, cs_o["problem_params"], data_o, obs_o)
-        t_orc.append(time.perf_counter() - t0)
-        tot_orc = float(res.total.detach())
+            t0 = time.perf_counter()
+            res, _, _ = orc.train_step_gradients(pol, T, cs_o["problem_params"], data_o, obs_o)
+            t_orc.append(time.perf_counter() - t0)
+            tot_orc = float(res.total.detach())
 
     r, o = statistics.median(t_ref), statistics.median(t_orc)
     out = {
