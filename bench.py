@@ -32,6 +32,7 @@ import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X dense FP32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0         # HBM3E (MI355X_MICROARCH.md)
+MACHINE_BALANCE = MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)   # 19.7 flop per byte
 
 
 # ---- N > 1 without a launcher: start the ranks ourselves ---------------------------------------------------------------
@@ -130,6 +131,20 @@ def _pick_threads(avail):
     return best
 
 
+def _certified_ratio():
+    """oracle / reference wall time on identical inputs, timed in the build container (tools/oracle_vs_reference_timing.py;
+    the reference cannot travel to the GPU box): what relates `cpu_baseline` to the reference's own CPU speed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*oracle_vs_reference_timing.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            return {"ratio": round(d["ratio_oracle_over_reference"], 3), "threads": d["threads"], "shape": d["shape"],
+                    "source": os.path.basename(f)}
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None):
     """The oracle (CPU restatement of the reference path, PyTorch eager) timed on this host's cores: training steps
     (rollout + backward) of the same workload on a bounded sample of scenarios; 1 warm-up + `reps` timed repetitions,
@@ -169,7 +184,26 @@ def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None):
         if sum(times) > 45.0:  # keep the default run within minutes on a slow host
             break
     dt = statistics.median(times)
-    return {"value": sample_scenarios * S * periods / dt, "unit": "scenario-steps/s", "cores": cores,
+    # second figure: every host core.  This eager path COLLAPSES when oversubscribed (measured on a 256-thread host:
+    # 2.8e3 scenario-steps/s with 256 threads against 2.2e6 with 32 - 777 x slower, 582 s for 1,024 scenarios), so it is
+    # bounded hard: 16 scenarios x 10 periods, one repetition.
+    all_cores = None
+    if avail != cores:
+        try:
+            torch.set_num_threads(avail)
+            part = {k: v[:16] for k, v in data.items()}
+            nb, pt = len(part["demands"]), min(periods, 10)
+            t0 = time.perf_counter()
+            orc.train_step_gradients(pol, pt, setting["problem_params"], part, obs)
+            dta = time.perf_counter() - t0
+            all_cores = {"value": nb * S * pt / dta, "cores": avail,
+                         "sample": f"{nb} scenarios x T={pt}, one repetition, {dta:.2f} s (oversubscribed eager PyTorch)"}
+        except Exception as e:
+            all_cores = {"value": None, "cores": avail, "sample": f"failed: {e!r}"}
+        finally:
+            torch.set_num_threads(cores)
+    return {"value": sample_scenarios * S * periods / dt, "unit": "scenario-steps/s", "cores": cores, "all_cores": all_cores,
+            "oracle_over_reference_wall_time": _certified_ratio(),
             "host_cores": avail, "kind": "port",
             "sample": f"oracle (PyTorch-CPU eager restatement of the reference path), training step fwd+bwd on "
                       f"{sample_scenarios} scenarios x {S} stores x T={periods}: 1 warm-up + {len(times)} timed repetitions, "
@@ -186,9 +220,15 @@ def algorithmic_work(tag, kernel, shape):
         cols = n * (T if kind == "wgradT" else 1)
         if kernel.startswith("wgrad_small_kernel"):   # small route: one launch contracts over all T * ldb columns
             return "hbm", 4.0 * (N + K) * n * T, "B"  # operands read once (dZ [N] + X [K] rows per column)
-        if max(N, K) <= 64 or kernel.startswith("thin_in_fwd"):   # 32-wide layers / the streamed first layer: operand streaming
-            return "hbm", 4.0 * (N + K) * cols, "B"
-        return "mfma", 2.0 * N * K * cols, "FLOP"
+        # A layer's GEMM streams its two activation operands once (N + K rows per column; the dgrad epilogue also reads the
+        # stored activation: + K rows) and does 2 N K flop per column.  Which roofline binds is decided by the arithmetic
+        # intensity against the machine balance (157.3 TFLOP/s / 8 TB/s = 19.7 flop/B), not by the layer's width: 17 x 512 is
+        # 8 flop/B (HBM), 512 x 51 is 23 (just MFMA), 512 x 512 is 128 (MFMA).  Both figures are reported (`other`).
+        flops = 2.0 * N * K * cols
+        nbytes = 4.0 * (N + K + (K if kind == "dgrad" and min(N, K) > 64 else 0)) * cols
+        if max(N, K) <= 64 or flops / nbytes < MACHINE_BALANCE:
+            return "hbm", nbytes, "B", ("mfma", flops, "FLOP")
+        return "mfma", flops, "FLOP", ("hbm", nbytes, "B")
     if tag.startswith("mlp3_fwd_") or tag.startswith("mlp3_bwd_"):  # fused 3-layer MLP: K -> 32 -> 32 -> n_out per column
         # HBM-bound: 0.4 flop per byte of activations.  Forward (training): K gathered input rows in, the two hidden
         # activations the backward needs and the output out.  Backward: dY / Y, the hidden activations and the inputs in,
@@ -207,6 +247,10 @@ def algorithmic_work(tag, kernel, shape):
         return "hbm", 4.0 * (2 * f_state + S + n_ord + 1) * n, "B"
     if tag == "env_bwd":  # state + orders + demand read, incoming state gradient read, state / order gradients written
         return "hbm", 4.0 * (3 * f_state + S + 2 * n_ord) * n, "B"
+    if tag == "head_fwd":  # logits + the warehouse / echelon on-hand row in, orders out
+        return "hbm", 4.0 * (shape["n_out"] + Wn + E + n_ord) * n, "B"
+    if tag == "head_bwd":  # logits, on-hand rows and order gradients in; logit gradients (+ on-hand gradients) out
+        return "hbm", 4.0 * (2 * shape["n_out"] + 2 * (Wn + E) + n_ord) * n, "B"
     hist = shape["F"] + 32 * shape["nh"] + shape["n_out"]
     if tag == "small_rollout_fwd":  # demand in, reward out (+ the activation history when training)
         return "hbm", 4.0 * (2 + (hist if shape["train"] else 0)) * n * T, "B"
@@ -227,17 +271,26 @@ def kernel_report(timer, shape, steps):
                "mean_ms": round(mean_ms, 5), "total_ms_per_step": round(cnt * mean_ms / steps, 4)}
         w = algorithmic_work(tag, name, shape)
         if w is not None:
-            bound, amount, unit = w
-            if bound == "mfma":
-                ach, peak, u = amount / mean_ms / 1e9, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-                rec["algorithmic_flops_per_launch"] = amount
-            else:
-                ach, peak, u = amount / (mean_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-                rec["algorithmic_bytes_per_launch"] = amount
+            bound, amount, unit = w[:3]
+
+            def rate(b, a):
+                return (a / mean_ms / 1e9, MFMA_F32_PEAK_TFLOPS, "TFLOP/s") if b == "mfma" else \
+                       (a / (mean_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s")
+            ach, peak, u = rate(bound, amount)
+            rec["algorithmic_flops_per_launch" if bound == "mfma" else "algorithmic_bytes_per_launch"] = amount
             rec.update(bound=bound, achieved=round(ach, 2), peak=peak, unit=u, frac=round(ach / peak, 4))
-            tr_ = _pmc_traffic(name, shape["n"], tag) if bound == "hbm" else None
-            if tr_ is not None:   # counter-measured HBM bytes of this class (committed PMC passes) vs the algorithmic bytes
-                rec.update(traffic=tr_["bytes_per_launch"], traffic_over_algorithmic=round(tr_["bytes_per_launch"] / amount, 3))
+            if len(w) > 3:   # the roofline that does NOT bind this shape, for reference
+                ob, oa, _ = w[3]
+                oach, opeak, ou = rate(ob, oa)
+                rec["other"] = {"bound": ob, "achieved": round(oach, 2), "peak": opeak, "unit": ou, "frac": round(oach / opeak, 4)}
+                rec["flop_per_byte"] = round((amount if bound == "mfma" else oa) / (oa if bound == "mfma" else amount), 2)
+            nbytes = amount if bound == "hbm" else (w[3][1] if len(w) > 3 else None)
+            tr_ = _pmc_traffic(name, shape["n"], tag) if nbytes else None
+            if tr_ is not None:
+                # counter-measured HBM bytes of this class vs the algorithmic bytes: from COMMITTED rocprofv3 --pmc passes of the
+                # same workload (profiles/), not collected in this run
+                rec.update(traffic=tr_["bytes_per_launch"], traffic_over_algorithmic=round(tr_["bytes_per_launch"] / nbytes, 3),
+                           traffic_measured="offline", traffic_source=tr_["source"])
         out[tag] = rec
     return out
 
@@ -437,9 +490,12 @@ def main():
                     "launches_timed": d["launches_timed"], "share_of_step": round(d["total_ms_per_step"] / ms, 4),
                 }
                 tr_ = _pmc_traffic(d["kernel"], n, dom)
-                if tr_ is not None:
+                if tr_ is not None:   # (HBM bytes per launch from the committed counter passes, see kernel_report)
                     out["roofline"]["traffic"] = tr_["bytes_per_launch"]
+                    out["roofline"]["traffic_measured"] = "offline"
                     out["roofline"]["traffic_source"] = tr_["source"]
+                if "other" in d:
+                    out["roofline"]["other"] = d["other"]
             out["kernels"] = kernels
             if "env_fwd" in kernels and "bound" in kernels["env_fwd"]:
                 e = kernels["env_fwd"]

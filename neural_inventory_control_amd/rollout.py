@@ -470,12 +470,12 @@ class FusedRollout:
             self._k(f"fwd_{self.dims[L]}x{self.dims[L - 1]}", ops.linear_fwd, Wv[L - 1], biases[L - 1], x, Z, B, _lib.NIC_ACT_NONE)
             so, wo, eo = self._order_views(self.orders[row], prob)
             if self.head == "warehouse":
-                ops.head_warehouse_fwd(Z, st.wh, self.adj, ub, bool(self.model.transshipment), so, wo, prob.S, prob.Wn,
-                                       prob.Ww, B)
+                self._k("head_fwd", ops.head_warehouse_fwd, Z, st.wh, self.adj, ub, bool(self.model.transshipment), so, wo,
+                        prob.S, prob.Wn, prob.Ww, B)
             elif self.head == "serial":
-                ops.head_serial_fwd(Z, st.wh, st.ech, ub, so, wo, eo, prob.E, prob.Ww, prob.We, B)
+                self._k("head_fwd", ops.head_serial_fwd, Z, st.wh, st.ech, ub, so, wo, eo, prob.E, prob.Ww, prob.We, B)
             else:
-                ops.head_softplus_fwd(Z, so.view(-1, ld), prob.S * prob.nsup, B)
+                self._k("head_fwd", ops.head_softplus_fwd, Z, so.view(-1, ld), prob.S * prob.nsup, B)
             if self._round:
                 ops.round_orders(self.orders[row], B)  # discrete allocation (trainer.py:201-202)
             ts, tw, te = self._order_tables(self.orders[row], prob)
@@ -499,12 +499,13 @@ class FusedRollout:
             hist, last_hist = self.dZhist, self.dZlast_hist
             dZ = last_hist[t] if last_hist is not None else self.dZ
             if self.head == "warehouse":
-                ops.head_warehouse_bwd(Z, st.wh, self.adj, ub, bool(self.model.transshipment), gso, gwo, dZ, gc.wh,
-                                       prob.S, prob.Wn, prob.Ww, B)
+                self._k("head_bwd", ops.head_warehouse_bwd, Z, st.wh, self.adj, ub, bool(self.model.transshipment), gso, gwo,
+                        dZ, gc.wh, prob.S, prob.Wn, prob.Ww, B)
             elif self.head == "serial":
-                ops.head_serial_bwd(Z, st.wh, st.ech, ub, gso, gwo, geo, dZ, gc.wh, gc.ech, prob.E, prob.Ww, prob.We, B)
+                self._k("head_bwd", ops.head_serial_bwd, Z, st.wh, st.ech, ub, gso, gwo, geo, dZ, gc.wh, gc.ech, prob.E,
+                        prob.Ww, prob.We, B)
             else:
-                ops.head_softplus_bwd(Z, gso.view(-1, ld), dZ, prob.S * prob.nsup, B)
+                self._k("head_bwd", ops.head_softplus_bwd, Z, gso.view(-1, ld), dZ, prob.S * prob.nsup, B)
             d = dZ
             for i in range(L - 1, -1, -1):
                 x_in = self.hidden[i - 1][t] if i > 0 else self.states[t][:self.F]

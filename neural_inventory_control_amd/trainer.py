@@ -200,9 +200,12 @@ class Trainer:
         if fusable and ClosedFormRollout.supports(model):
             # closed-form policies: ONE kernel for the whole horizon, gradient included (forward mode); the returned total
             # is an ordinary differentiable tensor, so the caller's mean_loss.backward() reaches the policy's parameters
-            eng = self._engines.get((id(model), "closed_form"))
+            # (a captured step holds the engine's buffers by address: with `use_step_graph` every batch shape keeps its own
+            # engine, otherwise an epoch's smaller last batch would re-size - free - what the first graph replays into)
+            ekey = (id(model), "closed_form", len(data_batch["demands"]) if self.use_step_graph else None)
+            eng = self._engines.get(ekey)
             if eng is None or eng.model is not model:
-                eng = self._engines[(id(model), "closed_form")] = ClosedFormRollout(model, problem_params, self.device)
+                eng = self._engines[ekey] = ClosedFormRollout(model, problem_params, self.device)
             if eng.shapes_ok(data_batch):
                 self._last_engine = eng
                 return eng.run(data_batch, periods, ignore_periods, train=train, observation_params=observation_params,

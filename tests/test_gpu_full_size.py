@@ -1,0 +1,123 @@
+"""Size-independent properties at BASELINE's FULL per-GPU sizes (the golden fixtures pin the arithmetic at sizes the CPU oracle
+finishes in seconds; these pin the size-dependent paths: 2^31 offset guards, ragged last wavefronts, every scenario block of the
+grid, the four-periods-per-lane form of the sampler):
+
+  * batch independence - a scenario's trajectory does not depend on the batch it sits in: the first scenarios of the full batch
+    reproduce a small run of the same scenarios BIT FOR BIT (per-period rewards);
+  * additivity of the training step - the parameter gradient of the full batch equals the sum of the gradients of its two halves
+    (same global normalisation), i.e. every scenario block contributes once and only once;
+  * stock conservation over every scenario of the batch (lost demand: pipeline' = pipeline - sales + orders received);
+  * demand comes from `Scenario(sampler="hip")` at full size (131,072 scenarios x T = 100: the four-periods-per-lane form).
+"""
+from collections import defaultdict
+
+import pytest
+import torch
+
+from neural_inventory_control_amd import _lib, workloads
+from neural_inventory_control_amd.data_handling import Scenario
+from neural_inventory_control_amd.neural_networks import NeuralNetworkCreator
+from neural_inventory_control_amd.rollout import FusedRollout
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _case(workload, n, T, T_demand=None):
+    """T_demand: horizon of the sampled demand trace (default T); the rollout then uses its first T periods."""
+    setting, policy, _, _, _ = workloads.get(workload)
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    sc = Scenario(T_demand or T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"], n,
+                  obs, setting["seeds"], sampler="hip", device=DEV)
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    torch.manual_seed(7)
+    model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+    F_in = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
+    if policy["name"] != "vanilla_one_store":
+        F_in += sum(data[k].shape[1] * data[k].shape[2] for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
+                    if k in data)
+    eng = FusedRollout(model, setting["problem_params"], DEV)
+    eng.materialize(F_in)
+    return setting, sc, data, model, eng, obs
+
+
+def _slice(data, lo, hi):
+    return {k: v[lo:hi].contiguous() for k, v in data.items()}
+
+
+def _grads(eng, model, data, T, obs, scale):
+    eng.run(data, T, 0, train=True, observation_params=obs, grad_scale=scale)
+    torch.cuda.synchronize()
+    return [p.grad.detach().clone() for p in model.parameters()]
+
+
+@pytest.mark.parametrize("workload,n,T", [("cfg2", 32768, 12), ("cfg4", 16384, 12), ("cfg4", 131072, 8)])
+def test_whole_horizon_route_at_full_size(workload, n, T):
+    """cfg2 (32,768 one-store scenarios) and cfg4 (16,384 per GPU and the whole 131,072-scenario job on one GPU): the
+    whole-horizon kernels, one wavefront per 32 scenarios."""
+    # the demand trace is drawn at the BENCHMARK horizon (T = 100): at 131,072 scenarios that is the four-periods-per-lane form
+    # of the sampler (>= 4 M (scenario, period) pairs), otherwise the one-period form; the rollout uses the first T periods
+    setting, sc, data, model, eng, obs = _case(workload, n, T, T_demand=100)
+    assert _lib.lib().nic_last_kernel() == (b"sample_equicorrelated_kernel<4>" if n * 100 >= (4 << 20) else
+                                             b"sample_equicorrelated_kernel<1>")
+    S = setting["problem_params"]["n_stores"]
+    scale = 1.0 / (n * T * S)
+    with torch.no_grad():
+        eng.run(data, T, 0, train=False, observation_params=obs, demand_soa=sc.demands_soa)
+    assert eng.small is not None  # the whole-horizon route
+    r_full = eng.per_period_rewards().clone()
+    assert r_full.shape == (T, n) and bool(torch.isfinite(r_full).all())
+    # batch independence, bit for bit: a ragged 45-scenario batch from the middle of the grid and the last 33 scenarios
+    for lo, hi in ((0, 45), (n // 2 - 7, n // 2 + 38), (n - 33, n)):
+        small = FusedRollout(model, setting["problem_params"], DEV)
+        with torch.no_grad():
+            small.run(_slice(data, lo, hi), T, 0, train=False, observation_params=obs)
+        assert torch.equal(small.per_period_rewards(), r_full[:, lo:hi]), (lo, hi)
+    # additivity of the training step over the two halves of the batch
+    g_full = _grads(eng, model, data, T, obs, scale)
+    half = n // 2
+    g_a = _grads(eng, model, _slice(data, 0, half), T, obs, scale)
+    g_b = _grads(eng, model, _slice(data, half, n), T, obs, scale)
+    for gf, ga, gb in zip(g_full, g_a, g_b):
+        assert float((gf - (ga + gb)).norm()) <= 2e-5 * float(gf.norm()) + 1e-12
+
+
+def test_cfg5_per_period_route_at_full_size():
+    """cfg5's per-GPU shape (32,768 scenarios x 64 stores x 3 warehouses, 16 stores per lane of a quad), demand from the HIP
+    sampler: batch independence, stock conservation over all 2.1 M store pipelines,
+    additivity of the training step."""
+    n, T = 32768, 6
+    setting, sc, data, model, eng, obs = _case("cfg5", n, T)
+    pp = setting["problem_params"]
+    S, Wn = pp["n_stores"], pp["n_warehouses"]
+    # counters are keyed by (seed, global scenario, period): the benchmark horizon's trace starts with the short horizon's
+    s70 = workloads.get("cfg5")[0]
+    big = Scenario(70, s70["problem_params"], s70["store_params"], s70["warehouse_params"], s70["echelon_params"], n,
+                   defaultdict(lambda: None, s70["observation_params"]), s70["seeds"], sampler="hip", device=DEV)
+    assert big.demands_soa.shape[0] == 70 and float(big.demands_soa.min()) >= 0.0
+    assert torch.equal(big.demands_soa[:T], sc.demands_soa[:T])
+    with torch.no_grad():
+        eng.run(data, T, 0, train=False, observation_params=obs, demand_soa=sc.demands_soa)
+    assert eng.small is None
+    r_full = eng.per_period_rewards().clone()
+    states, orders, demand = eng.states.clone(), eng.orders.clone(), eng.demand
+    for lo, hi in ((0, 40), (n - 70, n)):
+        small = FusedRollout(model, pp, DEV)
+        with torch.no_grad():
+            small.run(_slice(data, lo, hi), T, 0, train=False, observation_params=obs)
+        assert torch.equal(small.per_period_rewards(), r_full[:, lo:hi]), (lo, hi)
+    Ws = data["initial_inventories"].shape[2]
+    for t in range(T):
+        st = states[t][:S * Ws].view(S, Ws, -1)[:, :, :n].double()
+        nx = states[t + 1][:S * Ws].view(S, Ws, -1)[:, :, :n].double()
+        dem = demand[t][:, :n].double()
+        sales = torch.minimum(st[:, 0], dem)
+        recv = orders[t][:S * Wn].view(S, Wn, -1)[:, :, :n].double().sum(dim=1)   # what every warehouse ships to the store
+        assert float((nx.sum(dim=1) - (st.sum(dim=1) - sales + recv)).abs().max()) < 2e-3
+    scale = 1.0 / (n * T * S)
+    g_full = _grads(eng, model, data, T, obs, scale)
+    half = n // 2
+    g_a = _grads(eng, model, _slice(data, 0, half), T, obs, scale)
+    g_b = _grads(eng, model, _slice(data, half, n), T, obs, scale)
+    for gf, ga, gb in zip(g_full, g_a, g_b):
+        assert float((gf - (ga + gb)).norm()) <= 2e-5 * float(gf.norm()) + 1e-12
