@@ -447,16 +447,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     // every CU at once, on top of the write burst.  The kernel has ~80 free VGPRs, so the rows of the first pass are fetched
     // into registers during the last PFT k tiles (each batch completes under that tile's MFMAs, before its dma_wait), and
     // the rows of the second pass are fetched into the same registers as the first pass consumes them.
-    constexpr int PFT = 4;
+    constexpr int PFT = (ITER % 4 == 0) ? 4 : 2;
     static_assert(ITER % PFT == 0, "prefetch batches must divide the pass");
-    float4 hq[ITER];  // (dead in the forward instantiation)
-    const bool pf_on = EPI == EPI_DGRAD && p.Hprev != nullptr && p.act == NIC_ACT_ELU && nk >= PFT && !p.accumulate;
+    // (the 7-row-tile wave holds 112 accumulators + 56 fragment registers: no room for the prefetch registers as well)
+    constexpr bool PREFETCH_H = EPI == EPI_DGRAD && MT <= 4;
+    float4 hq[PREFETCH_H ? ITER : 1];  // (dead in the forward instantiation)
+    const bool pf_on = PREFETCH_H && p.Hprev != nullptr && p.act == NIC_ACT_ELU && nk >= PFT && !p.accumulate;
     auto load_h = [&](int pass, int it) {
         const int row = m0 + pass * PASS_ROWS + t / TPR + RPI * it;
         return (row < p.M && col < p.ncols) ? *reinterpret_cast<const float4*>(p.Hprev + (int64_t)row * p.ldb + col)
                                             : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
+    const int rows_left = p.M - m0 - wm * MT * 32;     // rows of the matrix at or below this wave's first row
+    const bool full_rows = rows_left > (MT - 1) * 32;  // the wave's last row tile holds at least one row
+    const bool some_rows = rows_left > 0;
     auto ktile = [&](int kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {  // stage cur^1 was last read in tile kt-1; every wave is past that barrier
@@ -465,27 +470,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
         }
         const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * BK;
         const float* b_base = lds + cur * STAGE + A_FLOATS + wn * NT * 32 + li;
+        // row tiles of this wave that lie entirely past the matrix (ragged M: 393 rows in 13 of the 14 tiles of a 448-row block,
+        // 195 in 7 of 8) are skipped; the two wavefronts of a SIMD are (wm = 0, wn) and (wm = 1, wn), so the SIMD's matrix pipe
+        // gets the sum of their counts.  (MTV = MT - 1 also serves waves with fewer valid tiles: surplus tiles compute zeros.)
+        auto body = [&](auto mtv_c) {
+            constexpr int MTV = decltype(mtv_c)::value;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            float a[MT][8];
+            for (int g = 0; g < 2; ++g) {
+                float a[MTV][8];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const float4 lo = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
-                const float4 hi = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
-                a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
-                a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+                for (int i = 0; i < MTV; ++i) {
+                    const float4 lo = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
+                    const float4 hi = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
+                    a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
+                    a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    float b[NT];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) b[j] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
+#pragma unroll
+                    for (int i = 0; i < MTV; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j], acc[i][j], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                float b[NT];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j], acc[i][j], 0, 0, 0);
-            }
+        };
+        if constexpr (MT >= 3 && NT == 1) {  // (the ragged-M tilings; the 256 x 256 kernel of the square layers stays branch-free)
+            if (full_rows) body(std::integral_constant<int, MT>{});
+            else if (some_rows) body(std::integral_constant<int, MT - 1>{});
+        } else {
+            body(std::integral_constant<int, MT>{});
         }
         dma_wait();  // tile kt+1 has landed (this wave's share); the barrier publishes every wave's share
         if (!NIC_TUNE(4)) __syncthreads();
@@ -506,7 +523,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
 #pragma unroll
             for (int b = 0; b < PFT; ++b) {
 #pragma unroll
-                for (int q = 0; q < ITER / PFT; ++q) hq[b * (ITER / PFT) + q] = load_h(0, b * (ITER / PFT) + q);
+                for (int q = 0; q < ITER / PFT; ++q) hq[PREFETCH_H ? b * (ITER / PFT) + q : 0] = load_h(0, b * (ITER / PFT) + q);
                 ktile(nk_plain + b);
             }
         }
@@ -551,11 +568,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
                     y.x = elu_f(y.x + bias_r[it]); y.y = elu_f(y.y + bias_r[it]);
                     y.z = elu_f(y.z + bias_r[it]); y.w = elu_f(y.w + bias_r[it]);
                 } else {
-                    const float4 hv = hq[it];
+                    const float4 hv = hq[PREFETCH_H ? it : 0];
                     y.x *= elu_grad_from_out(hv.x); y.y *= elu_grad_from_out(hv.y);
                     y.z *= elu_grad_from_out(hv.z); y.w *= elu_grad_from_out(hv.w);
                     if (pass + 1 < PASSES)  // next pass's row into the freed register
-                        hq[it] = *reinterpret_cast<const float4*>(p.Hprev + off + off_pass);
+                        hq[PREFETCH_H ? it : 0] = *reinterpret_cast<const float4*>(p.Hprev + off + off_pass);
                 }
                 *reinterpret_cast<float4*>(p.C + off) = y;
                 // keep the scheduler from hoisting all 16 staged rows (64 VGPRs on top of 128 accumulators + 64 Hprev
@@ -599,10 +616,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
                 if (p.act == NIC_ACT_ELU) { y.x = elu_f(y.x); y.y = elu_f(y.y); y.z = elu_f(y.z); y.w = elu_f(y.w); }
             } else {
                 if (p.Hprev && p.act == NIC_ACT_ELU) {
-                    const float4 hv = pf_on ? hq[it] : *reinterpret_cast<const float4*>(p.Hprev + off);
+                    const float4 hv = pf_on ? hq[PREFETCH_H ? it : 0] : *reinterpret_cast<const float4*>(p.Hprev + off);
                     y.x *= elu_grad_from_out(hv.x); y.y *= elu_grad_from_out(hv.y);
                     y.z *= elu_grad_from_out(hv.z); y.w *= elu_grad_from_out(hv.w);
-                    if (pf_on && pass + 1 < PASSES) hq[it] = load_h(pass + 1, it);  // next pass's row into the freed register
+                    if (pf_on && pass + 1 < PASSES) hq[PREFETCH_H ? it : 0] = load_h(pass + 1, it);  // next pass's row into the freed register
                 }
                 if (p.accumulate) {
                     const float4 o = *reinterpret_cast<const float4*>(p.C + off);
@@ -1147,14 +1164,48 @@ constexpr int gemm_variant() { return 0; }
 constexpr int tune_flags() { return 0; }
 #endif
 
+// Tile shape for M > 128 output rows: the estimated time of every candidate - rounds over the 256 CUs x (MFMA tile-columns a
+// SIMD issues per k step, counting only row tiles that hold rows of the matrix, + a fixed per-round share for prologue and
+// epilogue) - and the cheapest wins.  256 x 256 is what the square 512-wide layers get (two full rounds at 65,536 scenarios);
+// 448 x 128 fits M = 393 (13 of its 14 row tiles: 94 % useful, against 77 % of two 256-row blocks) in ONE round at 32,768
+// scenarios; 256 x 128 fits M = 195 (7 of 8 row tiles) in one round; 128 x 128 (two workgroups per CU) fills the chip when
+// there are few scenario columns.
+enum WxTile { WX_256x256, WX_448x128, WX_256x128, WX_128x128 };
+WxTile pick_wx_tile(int M, int ncols) {
+    struct Cand { WxTile id; int bm, bn, mt, nt, wg_per_cu; };
+    const Cand cands[4] = {{WX_256x256, 256, 256, 4, 2, 1}, {WX_256x128, 256, 128, 4, 1, 1}, {WX_448x128, 448, 128, 7, 1, 1},
+                           {WX_128x128, 128, 128, 2, 2, 2}};
+    double best = 0.;
+    WxTile pick = WX_128x128;
+    for (const Cand& c : cands) {
+        const int64_t tiles = (int64_t)((M + c.bm - 1) / c.bm) * ((ncols + c.bn - 1) / c.bn);
+        const int64_t rounds = (tiles + 256 * c.wg_per_cu - 1) / (256 * c.wg_per_cu);
+        // fullest row block = the first one; two wave rows of mt tiles each (one wave row in the 4-wave 128 x 128 kernel, where
+        // the two co-resident workgroups share a SIMD instead)
+        const int rows = M < c.bm ? M : c.bm, row_tiles = (rows + 31) / 32;
+        int per_simd;
+        if (c.wg_per_cu == 2) per_simd = 2 * c.mt * c.nt;
+        else per_simd = ((row_tiles < c.mt ? row_tiles : c.mt) + (row_tiles > c.mt ? (row_tiles - c.mt < c.mt ? row_tiles - c.mt : c.mt) : 0)) * c.nt;
+        // (the 7-tile and the 4-wave kernels: a little more LDS traffic per flop than the 256 x 256 tile)
+        const double cost = (double)rounds * (per_simd * (c.id == WX_256x256 ? 1.0 : 1.03) + 0.6);
+        if (best == 0. || cost < best) { best = cost; pick = c.id; }
+    }
+    return pick;
+}
+
 template <int EPI>
 void dispatch_wx(const WxParams& p, hipStream_t s) {
     if (wx_fast_ok(p)) {
-        // production path: LDS-DMA kernels.  256 x 256 CU-level tiles (8 waves) halve the bytes each CU has to ingest per
-        // flop relative to two co-resident 128 x 128 workgroups; they need >= 256 tiles to fill the chip.
-        const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.ncols + 255) / 256);
-        if (p.M > 128 && tiles256 >= 200 && gemm_variant() != 1) launch_wx_dma<2, 4, 4, 2, EPI>(p, s);   // 256 x 256
-        else if (p.M > 64) launch_wx_dma<2, 2, 2, 2, EPI>(p, s);                                          // 128 x 128
+        // production path: LDS-DMA kernels
+        if (p.M > 128 && gemm_variant() != 1) {
+            switch (pick_wx_tile(p.M, p.ncols)) {
+                case WX_256x256: launch_wx_dma<2, 4, 4, 2, EPI>(p, s); return;
+                case WX_448x128: launch_wx_dma<2, 4, 7, 1, EPI>(p, s); return;
+                case WX_256x128: launch_wx_dma<2, 4, 4, 1, EPI>(p, s); return;
+                default: launch_wx_dma<2, 2, 2, 2, EPI>(p, s); return;
+            }
+        }
+        if (p.M > 64) launch_wx_dma<2, 2, 2, 2, EPI>(p, s);                                               // 128 x 128
         else if (p.M > 32) launch_wx_dma<1, 4, 2, 1, EPI>(p, s);                                          //  64 x 128
         else launch_wx_dma<1, 4, 1, 2, EPI>(p, s);                                                        //  32 x 256
         return;

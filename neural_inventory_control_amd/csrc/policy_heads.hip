@@ -26,6 +26,74 @@ __global__ __launch_bounds__(kBlock) void head_warehouse_bwd_kernel(const float*
     for (int w = blockIdx.y; w < Wn; w += gridDim.y)
         nic::head_warehouse_bwd_one(Z, wh_inv, adj, ub, trans, gso, gwo, dZ, g_wh_inv, S, Wn, Ww, ldb, b, w);
 }
+// Quad form (policy_heads_body.h): 64 scenarios x 4 lanes per workgroup, lane q = wavefront q keeps the logits of stores
+// q, q+4, ... in registers; the three reductions of the softmax cross the quad through LDS.  S <= 4 * MAXSQ.
+constexpr int kLanes = 64;
+template <int MAXSQ>
+__global__ __launch_bounds__(kLanes * nic::kQuad) void head_warehouse_fwd_quad_kernel(
+    const float* __restrict__ Z, const float* __restrict__ wh_inv, const int32_t* __restrict__ adj, float ub, int trans,
+    float* __restrict__ so, float* __restrict__ wo, int S, int Wn, int Ww, int B, int64_t ldb) {
+    __shared__ float xm[nic::kQuad][kLanes], xd[nic::kQuad][kLanes];
+    __shared__ int xn[nic::kQuad][kLanes];
+    const int x = threadIdx.x & (kLanes - 1), q = threadIdx.x / kLanes;
+    const int64_t b = (int64_t)blockIdx.x * kLanes + x;
+    const bool live = b < B;
+    const int64_t bb = live ? b : B - 1;   // dead lanes shadow the last scenario (loads only)
+    for (int w = blockIdx.y; w < Wn; w += gridDim.y) {  // (warehouses are independent: grid.y spreads them over workgroups)
+        if (w != (int)blockIdx.y) __syncthreads();      // the exchange arrays are reused
+        nic::HeadLane<MAXSQ> L;
+        int nc;
+        xm[q][x] = nic::head_quad_load<MAXSQ, false>(L, Z, nullptr, adj, S, Wn, ldb, bb, w, q, nc);
+        xn[q][x] = nc;
+        const float stock = wh_inv[(int64_t)w * Ww * ldb + bb];
+        __syncthreads();
+        const float m = nic::head_quad_max(xm[0][x], xm[1][x], xm[2][x], xm[3][x], trans);
+        const int n_conn = xn[0][x] + xn[1][x] + xn[2][x] + xn[3][x];
+        xd[q][x] = nic::head_quad_exp<MAXSQ>(L, m);
+        __syncthreads();
+        const float denom = nic::head_quad_denom(xd[0][x], xd[1][x], xd[2][x], xd[3][x], m, trans);
+        if (live) {
+            nic::head_quad_fwd_store<MAXSQ>(L, denom, stock, n_conn, so, S, Wn, ldb, b, w, q);
+            if (q == (w & 3)) nic::head_wh_order_fwd(Z, ub, wo, S, Wn, ldb, b, w);
+        }
+    }
+}
+template <int MAXSQ>
+__global__ __launch_bounds__(kLanes * nic::kQuad) void head_warehouse_bwd_quad_kernel(
+    const float* __restrict__ Z, const float* __restrict__ wh_inv, const int32_t* __restrict__ adj, float ub, int trans,
+    const float* __restrict__ gso, const float* __restrict__ gwo, float* __restrict__ dZ, float* g_wh_inv, int S, int Wn, int Ww,
+    int B, int64_t ldb) {
+    __shared__ float xm[nic::kQuad][kLanes], xd[nic::kQuad][kLanes], xt[nic::kQuad][kLanes], xs[nic::kQuad][kLanes];
+    const int x = threadIdx.x & (kLanes - 1), q = threadIdx.x / kLanes;
+    const int64_t b = (int64_t)blockIdx.x * kLanes + x;
+    const bool live = b < B;
+    const int64_t bb = live ? b : B - 1;
+    for (int w = blockIdx.y; w < Wn; w += gridDim.y) {
+        if (w != (int)blockIdx.y) __syncthreads();
+        nic::HeadLane<MAXSQ> L;
+        int nc;
+        xm[q][x] = nic::head_quad_load<MAXSQ, true>(L, Z, gso, adj, S, Wn, ldb, bb, w, q, nc);
+        const float stock = wh_inv[(int64_t)w * Ww * ldb + bb];
+        __syncthreads();
+        const float m = nic::head_quad_max(xm[0][x], xm[1][x], xm[2][x], xm[3][x], trans);
+        xd[q][x] = nic::head_quad_exp<MAXSQ>(L, m);
+        __syncthreads();
+        const float denom = nic::head_quad_denom(xd[0][x], xd[1][x], xd[2][x], xd[3][x], m, trans);
+        float dq, sq;
+        nic::head_quad_bwd_dots<MAXSQ>(L, denom, stock, dq, sq);
+        xt[q][x] = dq;
+        xs[q][x] = sq;
+        __syncthreads();
+        if (live) {
+            const float dot = nic::combine4(xt[0][x], xt[1][x], xt[2][x], xt[3][x]);
+            nic::head_quad_bwd_store<MAXSQ>(L, dot, stock, dZ, S, Wn, ldb, b, w, q);
+            if (q == (w & 3)) {
+                g_wh_inv[(int64_t)w * Ww * ldb + b] += nic::combine4(xs[0][x], xs[1][x], xs[2][x], xs[3][x]);
+                nic::head_wh_order_bwd(Z, ub, gwo, dZ, S, Wn, ldb, b, w);
+            }
+        }
+    }
+}
 __global__ void head_softplus_fwd_kernel(const float* __restrict__ Z, float* __restrict__ o, int rows, int B, int64_t ldb) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B)
@@ -76,6 +144,19 @@ int nic_head_warehouse_fwd(const float* Z, const float* wh_inv, const int32_t* a
                            int32_t n_scenarios, int32_t ldb, void* stream) {
     NIC_REQUIRE(Z && wh_inv && adjacency && store_orders && wh_orders, "nic_head_warehouse_fwd: null buffer");
     NIC_REQUIRE(S > 0 && Wn > 0 && Ww > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_warehouse_fwd: bad sizes");
+    if (S <= 64) {   // stores split over the four lanes of a quad, logits held in registers
+        const dim3 grid(nic::ceil_div(n_scenarios, kLanes), Wn < 8 ? Wn : 8), block(kLanes * nic::kQuad);
+        const int sq = S <= 16 ? 4 : (S <= 32 ? 8 : 16);
+        nic::note_kernelf("head_warehouse_fwd_quad_kernel<%d>", sq);
+#define NIC_LAUNCH_HEAD(SQ)                                                                                              \
+    hipLaunchKernelGGL(head_warehouse_fwd_quad_kernel<SQ>, grid, block, 0, nic::as_stream(stream), Z, wh_inv, adjacency,   \
+                       upper_bound, transshipment, store_orders, wh_orders, S, Wn, Ww, n_scenarios, (int64_t)ldb)
+        if (sq == 4) NIC_LAUNCH_HEAD(4);
+        else if (sq == 8) NIC_LAUNCH_HEAD(8);
+        else NIC_LAUNCH_HEAD(16);
+#undef NIC_LAUNCH_HEAD
+        return nic::check_launch("nic_head_warehouse_fwd");
+    }
     nic::note_kernel("head_warehouse_fwd_kernel");
     hipLaunchKernelGGL(head_warehouse_fwd_kernel, dim3(nic::ceil_div(n_scenarios, kBlock), Wn < 4 ? Wn : 4), dim3(kBlock), 0,
                        nic::as_stream(stream), Z, wh_inv, adjacency, upper_bound, transshipment, store_orders, wh_orders, S,
@@ -90,6 +171,20 @@ int nic_head_warehouse_bwd(const float* Z, const float* wh_inv, const int32_t* a
     NIC_REQUIRE(Z && wh_inv && adjacency && g_store_orders && g_wh_orders && dZ && g_wh_inv,
                 "nic_head_warehouse_bwd: null buffer");
     NIC_REQUIRE(S > 0 && Wn > 0 && Ww > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_warehouse_bwd: bad sizes");
+    if (S <= 64) {
+        const dim3 grid(nic::ceil_div(n_scenarios, kLanes), Wn < 8 ? Wn : 8), block(kLanes * nic::kQuad);
+        const int sq = S <= 16 ? 4 : (S <= 32 ? 8 : 16);
+        nic::note_kernelf("head_warehouse_bwd_quad_kernel<%d>", sq);
+#define NIC_LAUNCH_HEAD(SQ)                                                                                              \
+    hipLaunchKernelGGL(head_warehouse_bwd_quad_kernel<SQ>, grid, block, 0, nic::as_stream(stream), Z, wh_inv, adjacency,   \
+                       upper_bound, transshipment, g_store_orders, g_wh_orders, dZ, g_wh_inv, S, Wn, Ww, n_scenarios,      \
+                       (int64_t)ldb)
+        if (sq == 4) NIC_LAUNCH_HEAD(4);
+        else if (sq == 8) NIC_LAUNCH_HEAD(8);
+        else NIC_LAUNCH_HEAD(16);
+#undef NIC_LAUNCH_HEAD
+        return nic::check_launch("nic_head_warehouse_bwd");
+    }
     nic::note_kernel("head_warehouse_bwd_kernel");
     hipLaunchKernelGGL(head_warehouse_bwd_kernel, dim3(nic::ceil_div(n_scenarios, kBlock), Wn < 4 ? Wn : 4), dim3(kBlock), 0,
                        nic::as_stream(stream), Z, wh_inv, adjacency, upper_bound, transshipment, g_store_orders, g_wh_orders,

@@ -192,6 +192,168 @@ NIC_HD void head_warehouse_bwd_scenario(const float* Z, const float* wh_inv, con
                                b, w);
 }
 
+// ---- the same head with the stores of a scenario split over FOUR lanes (the env step's "quad") -----------------------------
+// One lane per (scenario, warehouse) walks up to S stores three (forward) or four (backward) times, one dependent batch of loads
+// after the other: 9.5 / 13.4 us per period at BASELINE cfg3 and 31 / 43 us at cfg5 for ~10 / ~50 MB, i.e. 0.1 - 0.2 of the HBM
+// roofline.  Here lane q of the quad keeps the logits of stores q, q+4, ... in registers (ONE load per logit, all of a lane's
+// loads in flight together), and the softmax's three reductions - maximum, denominator, and in the backward sum_j y_j g_j -
+// cross the quad through the caller's exchange (LDS on the device, plain arrays in the host build) in the fixed order
+// ((p0 + p1) + p2) + p3.  exp(z - m) is evaluated once per logit.  Pieces are NIC_HD: tests/hostsim runs the four lanes in a
+// loop, so host and device agree bit for bit.
+template <int MAXSQ>
+struct HeadLane {
+    float z[MAXSQ], e[MAXSQ], g[MAXSQ];
+    int a[MAXSQ];
+};
+
+// loads this lane's logits (and, backward, the order gradients); returns the lane's maximum over connected stores and counts them
+template <int MAXSQ, bool BWD>
+NIC_HD float head_quad_load(HeadLane<MAXSQ>& L, const float* Z, const float* g_store_orders, const int32_t* adj, int S, int Wn,
+                            int64_t ldb, int64_t b, int w, int q, int& n_conn) {
+    const float* Zw = Z + (int64_t)w * ldb + b;
+    const float* gw = BWD ? g_store_orders + (int64_t)w * ldb + b : nullptr;
+    const int64_t rs = (int64_t)Wn * ldb;
+    const int32_t* aw = adj + w * S;
+    // every load is unconditional and its value is used unconditionally (a load that only feeds one side of a select gets sunk
+    // into a branch by hipcc and then costs one exposed round trip PER STORE: 16 x vmcnt(0) in the first version of this piece)
+#pragma unroll
+    for (int u = 0; u < MAXSQ; ++u) {
+        const int s = q + kQuad * u;
+        const int sc = s < S ? s : S - 1;
+        L.z[u] = Zw[sc * rs];
+        if (BWD) L.g[u] = gw[sc * rs];
+        L.a[u] = aw[sc];
+    }
+#pragma unroll
+    for (int u = 0; u < MAXSQ; ++u) L.a[u] &= -(int)(q + kQuad * u < S);   // stores past S are not connected
+    float m = -INFINITY;
+    n_conn = 0;
+#pragma unroll
+    for (int u = 0; u < MAXSQ; ++u)
+        if (L.a[u]) {
+            m = L.z[u] > m ? L.z[u] : m;
+            ++n_conn;
+        }
+    return m;
+}
+NIC_HD float head_quad_max(float m0, float m1, float m2, float m3, int transshipment) {
+    float m = transshipment ? -INFINITY : 1.f;   // the constant-1 'keep' logit (:150-153)
+    m = m0 > m ? m0 : m;
+    m = m1 > m ? m1 : m;
+    m = m2 > m ? m2 : m;
+    return m3 > m ? m3 : m;
+}
+// e = exp(z - m) of the connected stores; returns the lane's share of the denominator
+template <int MAXSQ>
+NIC_HD float head_quad_exp(HeadLane<MAXSQ>& L, float m) {
+    float d = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXSQ; ++u) {
+        L.e[u] = L.a[u] ? expf(L.z[u] - m) : 0.f;
+        d += L.e[u];
+    }
+    return d;
+}
+NIC_HD float head_quad_denom(float d0, float d1, float d2, float d3, float m, int transshipment) {
+    return (transshipment ? 0.f : expf(1.f - m)) + combine4(d0, d1, d2, d3);
+}
+template <int MAXSQ>
+NIC_HD void head_quad_fwd_store(const HeadLane<MAXSQ>& L, float denom, float stock, int n_conn, float* store_orders, int S, int Wn,
+                                int64_t ldb, int64_t b, int w, int q) {
+    float* ow = store_orders + (int64_t)w * ldb + b;
+    const int64_t rs = (int64_t)Wn * ldb;
+    float o[MAXSQ];
+#pragma unroll
+    for (int u = 0; u < MAXSQ; ++u) o[u] = (L.a[u] && n_conn > 0) ? (L.e[u] / denom) * stock : 0.f;
+    if (S == kQuad * MAXSQ) {  // every lane owns MAXSQ stores: straight-line stores
+#pragma unroll
+        for (int u = 0; u < MAXSQ; ++u) ow[(q + kQuad * u) * rs] = o[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < MAXSQ; ++u)
+            if (q + kQuad * u < S) ow[(q + kQuad * u) * rs] = o[u];
+    }
+}
+// backward: y = e / denom replaces e; the lane's shares of sum_j y_j (g_j stock) and of d/d(stock)
+template <int MAXSQ>
+NIC_HD void head_quad_bwd_dots(HeadLane<MAXSQ>& L, float denom, float stock, float& dot, float& g_stock) {
+    dot = 0.f;
+    g_stock = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXSQ; ++u) {  // (e is exactly 0 for stores that are not connected: their terms add +0)
+        L.e[u] = L.a[u] ? L.e[u] / denom : 0.f;
+        const float gz = L.a[u] ? L.g[u] : 0.f;
+        dot += L.e[u] * (gz * stock);
+        g_stock += gz * L.e[u];
+    }
+}
+template <int MAXSQ>
+NIC_HD void head_quad_bwd_store(const HeadLane<MAXSQ>& L, float dot, float stock, float* dZ, int S, int Wn, int64_t ldb, int64_t b,
+                                int w, int q) {
+    float* dw = dZ + (int64_t)w * ldb + b;
+    const int64_t rs = (int64_t)Wn * ldb;
+    float d[MAXSQ];
+#pragma unroll
+    for (int u = 0; u < MAXSQ; ++u) d[u] = L.a[u] ? L.e[u] * (L.g[u] * stock - dot) : 0.f;
+    if (S == kQuad * MAXSQ) {
+#pragma unroll
+        for (int u = 0; u < MAXSQ; ++u) dw[(q + kQuad * u) * rs] = d[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < MAXSQ; ++u)
+            if (q + kQuad * u < S) dw[(q + kQuad * u) * rs] = d[u];
+    }
+}
+// the warehouse's own order (:422) and its gradient: one lane per (scenario, warehouse)
+NIC_HD void head_wh_order_fwd(const float* Z, float ub, float* wh_orders, int S, int Wn, int64_t ldb, int64_t b, int w) {
+    wh_orders[(int64_t)w * ldb + b] = sigmoidf_(Z[((int64_t)S * Wn + w) * ldb + b]) * ub;
+}
+NIC_HD void head_wh_order_bwd(const float* Z, float ub, const float* g_wh_orders, float* dZ, int S, int Wn, int64_t ldb,
+                              int64_t b, int w) {
+    const float sg = sigmoidf_(Z[((int64_t)S * Wn + w) * ldb + b]);
+    dZ[((int64_t)S * Wn + w) * ldb + b] = g_wh_orders[(int64_t)w * ldb + b] * ub * sg * (1.f - sg);
+}
+
+// host-side composition of the quad pieces (what the device kernels do with LDS in between): tests/hostsim
+template <int MAXSQ>
+NIC_HD void head_warehouse_fwd_quad_scenario(const float* Z, const float* wh_inv, const int32_t* adj, float ub, int transshipment,
+                                             float* store_orders, float* wh_orders, int S, int Wn, int Ww, int64_t ldb, int64_t b) {
+    for (int w = 0; w < Wn; ++w) {
+        HeadLane<MAXSQ> L[kQuad];
+        float mq[kQuad], dq[kQuad];
+        int nq[kQuad];
+        for (int q = 0; q < kQuad; ++q) mq[q] = head_quad_load<MAXSQ, false>(L[q], Z, nullptr, adj, S, Wn, ldb, b, w, q, nq[q]);
+        const float m = head_quad_max(mq[0], mq[1], mq[2], mq[3], transshipment);
+        const int n_conn = nq[0] + nq[1] + nq[2] + nq[3];
+        for (int q = 0; q < kQuad; ++q) dq[q] = head_quad_exp<MAXSQ>(L[q], m);
+        const float denom = head_quad_denom(dq[0], dq[1], dq[2], dq[3], m, transshipment);
+        const float stock = wh_inv[(int64_t)w * Ww * ldb + b];
+        for (int q = 0; q < kQuad; ++q) head_quad_fwd_store<MAXSQ>(L[q], denom, stock, n_conn, store_orders, S, Wn, ldb, b, w, q);
+        head_wh_order_fwd(Z, ub, wh_orders, S, Wn, ldb, b, w);
+    }
+}
+template <int MAXSQ>
+NIC_HD void head_warehouse_bwd_quad_scenario(const float* Z, const float* wh_inv, const int32_t* adj, float ub, int transshipment,
+                                             const float* g_store_orders, const float* g_wh_orders, float* dZ, float* g_wh_inv,
+                                             int S, int Wn, int Ww, int64_t ldb, int64_t b) {
+    for (int w = 0; w < Wn; ++w) {
+        HeadLane<MAXSQ> L[kQuad];
+        float mq[kQuad], dq[kQuad], tq[kQuad], sq[kQuad];
+        int nq[kQuad];
+        for (int q = 0; q < kQuad; ++q)
+            mq[q] = head_quad_load<MAXSQ, true>(L[q], Z, g_store_orders, adj, S, Wn, ldb, b, w, q, nq[q]);
+        const float m = head_quad_max(mq[0], mq[1], mq[2], mq[3], transshipment);
+        for (int q = 0; q < kQuad; ++q) dq[q] = head_quad_exp<MAXSQ>(L[q], m);
+        const float denom = head_quad_denom(dq[0], dq[1], dq[2], dq[3], m, transshipment);
+        const float stock = wh_inv[(int64_t)w * Ww * ldb + b];
+        for (int q = 0; q < kQuad; ++q) head_quad_bwd_dots<MAXSQ>(L[q], denom, stock, tq[q], sq[q]);
+        const float dot = combine4(tq[0], tq[1], tq[2], tq[3]);
+        for (int q = 0; q < kQuad; ++q) head_quad_bwd_store<MAXSQ>(L[q], dot, stock, dZ, S, Wn, ldb, b, w, q);
+        g_wh_inv[(int64_t)w * Ww * ldb + b] += combine4(sq[0], sq[1], sq[2], sq[3]);
+        head_wh_order_bwd(Z, ub, g_wh_orders, dZ, S, Wn, ldb, b, w);
+    }
+}
+
 // vanilla_serial head.  neural_networks.py:335-349: rows [E echelons..., warehouse, store]; row j is
 // sigmoid(Z[j]) * upstream_j with upstream = [upper bound, echelon on-hands..., warehouse on-hand].
 NIC_HD float serial_upstream(const float* wh_inv, const float* ech_inv, float ub, int j, int E, int We, int64_t ldb,

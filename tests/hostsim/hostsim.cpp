@@ -39,14 +39,20 @@ int hostsim_env_step_bwd(const NicEnvStepIO* io, const float* gso, const float* 
 }
 int hostsim_head_warehouse_fwd(const float* Z, const float* wh_inv, const int32_t* adj, float ub, int32_t trans,
                                float* so, float* wo, int32_t S, int32_t Wn, int32_t Ww, int32_t B, int32_t ldb) {
-    for (int64_t b = 0; b < B; ++b) nic::head_warehouse_fwd_scenario(Z, wh_inv, adj, ub, trans, so, wo, S, Wn, Ww, ldb, b);
+    // up to 64 stores: the quad pieces the device kernel runs (four lanes in a loop, same exchange order); else the one-lane form
+    for (int64_t b = 0; b < B; ++b) {
+        if (S <= 64) nic::head_warehouse_fwd_quad_scenario<16>(Z, wh_inv, adj, ub, trans, so, wo, S, Wn, Ww, ldb, b);
+        else nic::head_warehouse_fwd_scenario(Z, wh_inv, adj, ub, trans, so, wo, S, Wn, Ww, ldb, b);
+    }
     return 0;
 }
 int hostsim_head_warehouse_bwd(const float* Z, const float* wh_inv, const int32_t* adj, float ub, int32_t trans,
                                const float* gso, const float* gwo, float* dZ, float* gwi, int32_t S, int32_t Wn,
                                int32_t Ww, int32_t B, int32_t ldb) {
-    for (int64_t b = 0; b < B; ++b)
-        nic::head_warehouse_bwd_scenario(Z, wh_inv, adj, ub, trans, gso, gwo, dZ, gwi, S, Wn, Ww, ldb, b);
+    for (int64_t b = 0; b < B; ++b) {
+        if (S <= 64) nic::head_warehouse_bwd_quad_scenario<16>(Z, wh_inv, adj, ub, trans, gso, gwo, dZ, gwi, S, Wn, Ww, ldb, b);
+        else nic::head_warehouse_bwd_scenario(Z, wh_inv, adj, ub, trans, gso, gwo, dZ, gwi, S, Wn, Ww, ldb, b);
+    }
     return 0;
 }
 int hostsim_head_softplus_fwd(const float* Z, float* o, int32_t rows, int32_t B, int32_t ldb) {

@@ -65,7 +65,10 @@ GEMM_SHAPES = [(512, 51, 1000), (512, 512, 2048 + 37), (17, 512, 777), (32, 4, 1
                # short contraction, >= 64 output rows: the streamed first-layer forward of thin_layer.hip
                (512, 51, 4096), (128, 7, 777), (96, 64, 2048), (64, 1, 100), (192, 33, 96),
                # thin outputs with up to 128 input features (GNN layers): multi-accumulator wgrad_small_kernel
-               (32, 65, 4096), (17, 96, 1000), (32, 128, 2049), (5, 40, 300)]
+               (32, 65, 4096), (17, 96, 1000), (32, 128, 2049), (5, 40, 300),
+               # BASELINE cfg5's ragged layers at its per-GPU scenario count (+ a ragged tail): 393 rows in ONE 448-row block
+               # (13 of 14 row tiles computed), 195 rows in a 256-row block (7 of 8), and the all-period weight gradients' tilings
+               (512, 393, 32768 + 160), (195, 512, 32768 + 96), (195, 512, 4096), (512, 393, 4096)]
 
 
 def _rand(shape, gen, dev, scale=1.0):
