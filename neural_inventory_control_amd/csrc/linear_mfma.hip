@@ -782,7 +782,9 @@ __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
 // no virtual row of ones here: the waves of the first column tile sum the dY fragments they read anyway.
 // Requires n_scenarios % 32 == 0 (no partial k tiles) — the launcher falls back to gemm_wgrad_kernel otherwise.
 // ---------------------------------------------------------------------------------------------------------------
-template <int WAVES_M, int WAVES_N, int MT, int NT>
+// SKIP_ROWS: row tiles of a wave that lie entirely past N are not computed (N = 195 in a 256-row tile: the wave rows hold 4 and 3
+// of the 7 row tiles with rows, and the two wavefronts of a SIMD are (wm = 0, wn) and (wm = 1, wn)).
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool SKIP_ROWS = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(WgParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WAVES_M * WAVES_N, NTHREADS = 64 * NW;
@@ -856,6 +858,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
 #pragma unroll
     for (int i = 0; i < MT; ++i) rowsum[i] = 0.f;
     const bool bias_owner = (k0 == 0) && (wn == 0);  // these waves also produce the bias-gradient column
+    const int rows_left = p.N - n0 - wm * MT * 32;
+    const bool full_rows = rows_left > (MT - 1) * 32, some_rows = rows_left > 0;
 
     const int sw = (li >> 1) & 7;
     issue(0);
@@ -948,36 +952,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
         }
         const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * BK;
         const float* b_base = lds + cur * STAGE + A_FLOATS + (wn * NT * 32 + li) * BK;
+        auto body = [&](auto mtv_c) {
+            constexpr int MTV = decltype(mtv_c)::value;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            float a[MT][8], b[NT][8];
+            for (int g = 0; g < 2; ++g) {
+                float a[MTV][8], b[NT][8];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const float4 lo = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
-                const float4 hi = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
-                a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
-                a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+                for (int i = 0; i < MTV; ++i) {
+                    const float4 lo = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
+                    const float4 hi = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
+                    a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
+                    a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float4 lo = *reinterpret_cast<const float4*>(b_base + j * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
+                    const float4 hi = *reinterpret_cast<const float4*>(b_base + j * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
+                    b[j][0] = lo.x; b[j][1] = lo.y; b[j][2] = lo.z; b[j][3] = lo.w;
+                    b[j][4] = hi.x; b[j][5] = hi.y; b[j][6] = hi.z; b[j][7] = hi.w;
+                }
+                if (bias_owner) {
+#pragma unroll
+                    for (int i = 0; i < MTV; ++i)
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) rowsum[i] += a[i][kk];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                    for (int i = 0; i < MTV; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float4 lo = *reinterpret_cast<const float4*>(b_base + j * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
-                const float4 hi = *reinterpret_cast<const float4*>(b_base + j * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
-                b[j][0] = lo.x; b[j][1] = lo.y; b[j][2] = lo.z; b[j][3] = lo.w;
-                b[j][4] = hi.x; b[j][5] = hi.y; b[j][6] = hi.z; b[j][7] = hi.w;
-            }
-            if (bias_owner) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) rowsum[i] += a[i][kk];
-            }
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+        };
+        if constexpr (SKIP_ROWS && MT >= 2) {
+            if (full_rows) body(std::integral_constant<int, MT>{});
+            else if (some_rows) body(std::integral_constant<int, MT - 1>{});
+        } else {
+            body(std::integral_constant<int, MT>{});
         }
         dma_wait();
         __syncthreads();
@@ -1236,13 +1249,24 @@ void wgrad_tile(int N, int K, int* bm, int* bn) {
 
 // big layers: 256 x 256 LDS-DMA tiles, one workgroup per CU
 bool wgrad_big(int N, int K) { return N >= 192 && K >= 192; }
+bool wgrad_tall(int N, int K);
 
-template <int WM, int WN, int MT, int NT>
+// tall, narrow layers (the first layer: 512 x 51): ONE 512 x 64 output tile per scenario chunk, so dZ is read exactly once
+// (the 128 x 64 register-staged tiles read it 1.3 x) by the LDS-DMA pipeline; HBM-bound
+bool wgrad_tall(int N, int K) { return N >= 384 && K <= 64; }
+
+template <int WM, int WN, int MT, int NT, bool SKIP = false>
 void launch_wg_dma(const WgParams& p, int n_splits, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     dim3 grid(((p.K + BN - 1) / BN) * ((p.N + BM - 1) / BM) * n_splits);
-    nic::note_kernelf("gemm_wgrad_dma_kernel<%d,%d,%d,%d>", WM, WN, MT, NT);
-    hipLaunchKernelGGL((gemm_wgrad_dma_kernel<WM, WN, MT, NT>), grid, dim3(64 * WM * WN), 0, s, p);
+    nic::note_kernelf(SKIP ? "gemm_wgrad_dma_kernel<%d,%d,%d,%d,skip>" : "gemm_wgrad_dma_kernel<%d,%d,%d,%d>", WM, WN, MT, NT);
+    hipLaunchKernelGGL((gemm_wgrad_dma_kernel<WM, WN, MT, NT, SKIP>), grid, dim3(64 * WM * WN), 0, s, p);
+}
+// the LDS-DMA weight-gradient kernel for a shape (wgrad_big or wgrad_tall)
+void launch_wg_dma_for(const WgParams& p, int n_splits, hipStream_t s) {
+    if (wgrad_tall(p.N, p.K)) launch_wg_dma<8, 1, 2, 2>(p, n_splits, s);
+    else if ((p.N + 255) / 256 * 256 - p.N >= 32) launch_wg_dma<2, 4, 4, 2, true>(p, n_splits, s);  // an empty row tile to skip
+    else launch_wg_dma<2, 4, 4, 2>(p, n_splits, s);
 }
 
 int require_ld(const char* who, int32_t n_scenarios, int32_t ldb) {
@@ -1289,6 +1313,9 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
     int target = 1024;                                 // ~4 workgroups per CU in total
     if (wgrad_big(N, K)) {                             // 256 x 256 tiles, one workgroup per CU, one round
         tiles = ((N + 255) / 256) * ((K + 255) / 256);
+        target = 256;
+    } else if (wgrad_tall(N, K)) {                     // 512 x 64 tiles (LDS-DMA), one workgroup per CU
+        tiles = (N + 511) / 512;
         target = 256;
     }
     if (N <= 32 && (K <= 32 || (K <= 128 && K % 32 != 0))) {  // wgrad_small_kernel: one split per wave, >= 2048 columns each
@@ -1337,7 +1364,7 @@ static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t l
         else if (K <= 96) hipLaunchKernelGGL(wgrad_small_kernel<3>, g, b, 0, s, p, n_splits);
         else hipLaunchKernelGGL(wgrad_small_kernel<4>, g, b, 0, s, p, n_splits);
     }
-    else if (wgrad_big(N, K) && dma_ok && gemm_variant() != 2) launch_wg_dma<2, 4, 4, 2>(p, n_splits, s);
+    else if ((wgrad_big(N, K) || wgrad_tall(N, K)) && dma_ok && gemm_variant() != 2) launch_wg_dma_for(p, n_splits, s);
     else if (bm == 128 && bn == 128) launch_wg<2, 2, 2, 2>(p, n_splits, s);
     else if (bm == 128) launch_wg<2, 2, 2, 1>(p, n_splits, s);
     else if (bm == 64) launch_wg<1, 4, 2, 1>(p, n_splits, s);
@@ -1367,7 +1394,7 @@ int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64
     NIC_REQUIRE(period_stride_dy % 4 == 0 && period_stride_x % 4 == 0,
                 "nic_linear_wgrad_periods: period strides must be multiples of 4 elements (16-byte aligned operands)");
     const bool dma_ok = dY && X && slab && N > 0 && K > 0 && lds_ >= K + 1 && n_splits >= 1 && n_scenarios > 0 && ldb >= n_scenarios &&
-                        wgrad_big(N, K) && gemm_variant() != 2 && ldb % 4 == 0 && n_scenarios % BK == 0 && lds_ % 4 == 0 &&
+                        (wgrad_big(N, K) || wgrad_tall(N, K)) && gemm_variant() != 2 && ldb % 4 == 0 && n_scenarios % BK == 0 && lds_ % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (int64_t)N * ldb < (1ll << 28) &&
                         (int64_t)K * ldb < (1ll << 28);
@@ -1397,7 +1424,7 @@ int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64
     const int flush = 8192 / chunk > 0 ? 8192 / chunk : 1;
     WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, period_stride_dy,
                period_stride_x, flush};
-    launch_wg_dma<2, 4, 4, 2>(p, n_splits, nic::as_stream(stream));
+    launch_wg_dma_for(p, n_splits, nic::as_stream(stream));
     return nic::check_launch("nic_linear_wgrad_periods");
 }
 
