@@ -76,10 +76,21 @@ def build_case(workload, device, rank, world, scenarios=None, periods=None):
     n, T = scenarios or n, periods or T
     obs = defaultdict(lambda: None, setting["observation_params"])
     # each rank generates rows [rank*n, (rank+1)*n) of the (world*n)-scenario job; initial inventories use the GLOBAL demand mean
-    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"],
-                  setting["echelon_params"], n, obs, setting["seeds"], sampler="hip", device=device,
-                  scenario_offset=rank * n, num_total=world * n)
-    data = {k: v.to(device) for k, v in sc.get_data().items()}
+    real = setting["store_params"]["demand"]["distribution"] == "real"
+    if real:   # file-backed demand: the train split of the period axis (past-demand window + T periods), reference-style
+        shift = setting["observation_params"]["demand"]["period_shift"]
+        sc = Scenario(shift + T, setting["problem_params"], setting["store_params"], setting["warehouse_params"],
+                      setting["echelon_params"], n, obs, setting["seeds"], device=device, scenario_offset=rank * n,
+                      num_total=world * n)
+    else:
+        sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"],
+                      setting["echelon_params"], n, obs, setting["seeds"], sampler="hip", device=device,
+                      scenario_offset=rank * n, num_total=world * n)
+    if real:
+        from neural_inventory_control_amd.data_handling import DatasetCreator
+        data = {k: v.to(device) for k, v in DatasetCreator().split_by_period(sc, [f"(0, {shift + T})"])[0].items()}
+    else:
+        data = {k: v.to(device) for k, v in sc.get_data().items()}
     torch.manual_seed(1234)  # identical initial weights on every rank (and broadcast below when world > 1)
     model = NeuralNetworkCreator().create_neural_network(sc, policy, device=device)
     eng = None
@@ -159,9 +170,13 @@ def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None):
     torch.set_num_threads(cores)
     setting, policy, _, _, _ = workloads.get(workload)
     obs = defaultdict(lambda: None, setting["observation_params"])
-    data = orc.generate_scenario_data(periods, setting["problem_params"], setting["store_params"],
+    real = setting["store_params"]["demand"]["distribution"] == "real"
+    shift = setting["observation_params"]["demand"]["period_shift"]
+    data = orc.generate_scenario_data(periods + (shift if real else 0), setting["problem_params"], setting["store_params"],
                                       setting["warehouse_params"], setting["echelon_params"], sample_scenarios, obs,
                                       setting["seeds"])
+    if real:
+        data = orc.split_data_by_period(data, [f"(0, {shift + periods})"], obs, setting["problem_params"])[0]
     S = setting["problem_params"]["n_stores"]
     F = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
     if policy["name"] != "vanilla_one_store":
@@ -169,7 +184,7 @@ def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None):
                  if k in data)
     if policy["name"] in ("base_stock", "capped_base_stock", "echelon_stock"):
         F = 1  # closed-form policies: one Linear fed the constant 0 (neural_networks.py:228)
-    if policy["name"] == "gnn":  # five MLPs: the oracle takes the (already materialised) weights of the device model
+    if policy["name"] in ("gnn", "data_driven"):  # the oracle takes the (already materialised) weights of the device model
         state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         pol = orc.policy_from_state_dict(policy, state, setting["problem_params"])
     else:
@@ -504,7 +519,8 @@ def main():
                                             "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
                                             "mean_launch_ms": e["mean_ms"]}
         if world == 1 and not args.no_cpu_baseline and not args.eval:
-            sample = args.cpu_sample or {"cfg3": 4096, "cfg5": 1024, "cfg2": 32768, "cfg4": 16384, "cfg1": 256, "base_stock": 32768, "gnn": 512}.get(args.workload, 1024)
+            sample = args.cpu_sample or {"cfg3": 4096, "cfg5": 1024, "cfg2": 32768, "cfg4": 16384, "cfg1": 256, "base_stock": 32768, "gnn": 512,
+                                         "real_data_driven": 72}.get(args.workload, 1024)
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, min(sample, n), T, model=model)
                 out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -416,12 +416,21 @@ class DataDrivenNet(MyNeuralNetwork):
         if n_warehouses == 0:
             return {"stores": outputs.unsqueeze(2)}
         adjacency = self.scenario.problem_params["warehouse_store_adjacency"]
-        edge_mask = torch.tensor(adjacency, dtype=torch.float32, device=outputs.device).transpose(0, 1)  # [S, Wn]
+        # The adjacency is a static list of the setting: its device copy is built once per device and the "does warehouse w
+        # serve anyone" test (:499 upstream, a device tensor compared on the host) is answered from the list - the upstream form
+        # costs one host->device copy and Wn device->host syncs per PERIOD (1.3 ms per period on the real-data batch) and cannot
+        # be captured into a HIP graph.
+        mkey = (id(adjacency), str(outputs.device))
+        if getattr(self, "_edge_mask_key", None) != mkey:
+            self._edge_mask = torch.tensor(adjacency, dtype=torch.float32, device=outputs.device).transpose(0, 1)  # [S, Wn]
+            self._serves = [sum(adjacency[w]) > 0 for w in range(len(adjacency))]
+            self._edge_mask_key = mkey
+        edge_mask = self._edge_mask
         warehouse_outputs, store_flat = outputs[:, :n_warehouses], outputs[:, n_warehouses:]
         store_allocation = store_flat.reshape(outputs.size(0), n_stores, n_warehouses) * edge_mask.unsqueeze(0)
         final = torch.zeros_like(store_allocation)
         for w in range(n_warehouses):
-            if edge_mask[:, w].sum() > 0:
+            if self._serves[w]:
                 final[:, :, w] = self.apply_proportional_allocation(store_allocation[:, :, w],
                                                                     observation["warehouse_inventories"][:, w])
         return {"stores": final, "warehouses": warehouse_outputs.unsqueeze(2)}

@@ -109,6 +109,64 @@ def gnn_policy():
             "initial_bias": {"output": 5.0}, "gradient_clipping_norm_value": 1.0}
 
 
+def real_data(n_products=288, n_stores=21, n_warehouses=3, weeks=171, past_periods=16, seed=0):
+    """The shape of the reference's real-data setting (many_warehouses_real_data_lost_demand.yml: 288 Favorita products x 21
+    stores x 171 weeks, 3 warehouses, 16 past demands + days-from-christmas in the observation, profit objective) on SYNTHETIC
+    stand-in files - the Favorita blobs are not redistributable with this repository and cannot travel to the GPU box: a
+    weekly-sales tensor file and a dates csv with the same layout are written to a temporary directory, so the whole real-data
+    pipeline (file-backed demand, period split, past-demand window, time features) runs as it does upstream."""
+    import os
+    import random
+    import tempfile
+    import numpy as np
+    import torch
+    rnd = random.Random(seed)
+    d = tempfile.mkdtemp(prefix="nic_real_data_")
+    gen = torch.Generator().manual_seed(seed)
+    level = torch.rand(n_products, n_stores, 1, generator=gen) * 20.0 + 1.0
+    season = 1.0 + 0.3 * torch.sin(torch.arange(weeks, dtype=torch.float32) * (2 * 3.14159265 / 52.0))
+    sales = torch.clamp(level * season + torch.randn(n_products, n_stores, weeks, generator=gen) * level.sqrt() * 2.0, min=0.0)
+    torch.save(sales.round(decimals=3), os.path.join(d, "weekly_sales.pt"))
+    with open(os.path.join(d, "dates_with_info.csv"), "w") as f:
+        f.write("week,days_from_christmas\n")
+        for w in range(weeks):
+            f.write(f"{w},{(w * 7 + 180) % 365 - 182}\n")
+    adj = [[1] * n_stores for _ in range(n_warehouses)]
+    for w in range(n_warehouses):
+        for s_ in rnd.sample(range(n_stores), 2):
+            adj[w][s_] = 0
+    for s_ in range(n_stores):  # every store keeps at least one supplier
+        if not any(adj[w][s_] for w in range(n_warehouses)):
+            adj[0][s_] = 1
+    lead = [[rnd.randint(4, 6), rnd.randint(1, 2), rnd.randint(4, 6)][:n_warehouses] for _ in range(n_stores)]
+    feats = {"holding_costs": True, "underage_costs": True, "lead_times": True, "mean": False, "std": False}
+    return {
+        "seeds": dict(_SEEDS, warehouse=10),
+        "problem_params": {"n_stores": n_stores, "n_warehouses": n_warehouses, "n_extra_echelons": 0, "lost_demand": True,
+                           "maximize_profit": True, "warehouse_store_adjacency": adj},
+        "observation_params": {"include_warehouse_inventory": True, "include_static_features": feats,
+                               "demand": {"past_periods": past_periods, "period_shift": past_periods},
+                               "time_features_file": os.path.join(d, "dates_with_info.csv"),
+                               "time_features": ["days_from_christmas"], "sample_features": None,
+                               "include_days_to_christmas": True},
+        "store_params": {
+            "demand": {"distribution": "real", "file_location": os.path.join(d, "weekly_sales.pt"), "sample_across_stores": False,
+                       "expand": False, "clip": False, "decimals": 3},
+            "lead_time": _const(lead), "holding_cost": _per_store(0.7, 1.3),
+            "underage_cost": {"sample_across_stores": True, "vary_across_samples": True, "expand": False, "range": [6.3, 11.7]},
+            "initial_inventory": {"sample": False, "inventory_periods": 6}},
+        "warehouse_params": {"holding_cost": [0.3, 0.4, 0.2][:n_warehouses], "lead_time": 3,
+                             "edge_cost": [0.5, 1.5, 0.7][:n_warehouses]},
+        "echelon_params": None,
+    }
+
+
+def data_driven_policy():
+    """data_driven_net.yml: one 64 x 64 MLP over every observed feature, relu outputs."""
+    return {"name": "data_driven", "inner_layer_activations": {"master": "elu"}, "output_layer_activation": {"master": "relu"},
+            "neurons_per_hidden_layer": {"master": [64, 64]}, "initial_bias": {"master": 1.0}, "output_sizes": {"master": None}}
+
+
 WORKLOADS = {
     # name: (setting builder, policy dict, scenarios per GPU, periods, description)
     "cfg1": (lambda: one_store(True, True), _mlp("vanilla_one_store", [32, 32, 32], 1), 256, 50,
@@ -129,6 +187,12 @@ WORKLOADS = {
                       "one_store_backlogged + base_stock, 1,048,576 scenarios x T=100 (enough chains in flight to be HBM-bound)"),
     "echelon_stock": (serial_system, _closed_form("echelon_stock", 4, None, None), 131072, 100,
                       "serial_system 4 echelons + echelon_stock, 131072 scenarios x T=100"),
+    # the reference's real-data training batch (72 of 288 products x 21 stores x 3 warehouses, T = 95 of 111 train
+    # weeks after the 16-week past-demand window) on the GENERIC route: Simulator.step (one HIP kernel per period) + HipLinear
+    # layers + autograd; `--graph` replays the whole training step from one HIP graph
+    "real_data_driven": (real_data, data_driven_policy(), 72, 95,
+                         "many_warehouses_real_data_lost_demand shape (synthetic stand-in files), 72 products x 21 stores x "
+                         "3 warehouses x T=95, data_driven 64x64; generic route"),
     # the GNN policy on cfg3's graph (fused gather-MLP kernels over the static supply graph, gnn_rollout.py)
     "gnn": (lambda: one_warehouse(16), gnn_policy(), 8192, 50,
             "one_warehouse_lost_demand, 16 stores, 8192 scenarios x T=50, gnn (5 x 32-wide MLPs, 1 message-passing step)"),
