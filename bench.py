@@ -328,6 +328,8 @@ def main():
                     help="write the (kernel class, kernel) sequence of the timed steps as JSON and skip the event timing: what "
                          "tools/collect_profiles.py joins the profiler's per-dispatch counter rows to")
     ap.add_argument("--graph", action="store_true", help="replay the launch sequence from a HIP graph (implies --no-kernel-timing)")
+    ap.add_argument("--lane-scenarios", type=int, default=0, choices=(0, 16, 32),
+                    help="whole-horizon route: scenarios per wavefront (0 = chosen by the library from the batch size)")
     ap.add_argument("--gnn-keep-inputs", action="store_true",
                     help="gnn: keep a copy of the gathered MLP inputs for the backward instead of reading them again (A/B)")
     ap.add_argument("--eval", action="store_true",
@@ -367,6 +369,7 @@ def main():
             F_in += sum(data[k].shape[1] * data[k].shape[2]
                         for k in ("initial_warehouse_inventories", "initial_echelon_inventories") if k in data)
         eng.materialize(F_in)
+        eng.small_lane_scenarios = args.lane_scenarios
         parallel.broadcast_model(model, src=0)
     opt = torch.optim.Adam(model.parameters(), lr=3e-4)
     if args.graph and eng is not None and not closed_form:

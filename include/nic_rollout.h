@@ -218,6 +218,11 @@ typedef struct NicSmallRolloutDesc {
     int32_t round_orders;                  /* 1: orders rounded half-to-even before the env step (discrete allocation,
                                               trainer.py:201-202); forward / evaluation only */
     float upper_bound;                     /* model.warehouse_upper_bound (head 1) */
+    int32_t lane_scenarios;                /* scenarios per wavefront of the matrix-core kernels: 0 / 32 (v_mfma_f32_32x32x2_f32)
+                                              or 16 (v_mfma_f32_16x16x4_f32: twice the wavefronts, half the chain per wavefront;
+                                              for batches that leave SIMDs idle at 32).  With 16 the hidden-activation history
+                                              is in a wave-native order private to nic_small_rollout_fwd /
+                                              nic_small_rollout_bwd_wgrad: pass the same value to both */
     const float* weights;                  /* packed: [W1 32xF][b1 32] [W_l 32x32][b_l 32]... [Wout n_out x 32][bout n_out] */
     const float* demand;                   /* [T_total][ldb] */
     const float* state0;                   /* [F][ldb] */
@@ -237,7 +242,7 @@ int nic_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* s
 int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
                           const float* logits_hist, NicTable2 g_reward, float* dz_hidden, float* dz_out, void* stream);
 /* The same backward sweep with the weight gradients contracted in the kernel (no dz history, no GEMM launches): every
- * wavefront (32 scenarios) keeps dW / db of all layers in registers over the whole horizon and stores its partial gradient, in
+ * wavefront (32 or 16 scenarios, see lane_scenarios) keeps dW / db of all layers in registers over the whole horizon and stores its partial gradient, in
  * the layout of the packed weights, to slab[wavefront * slab_stride ...]; the caller sums the
  * nic_small_rollout_bwd_wgrad_slots(n_scenarios) rows.  Replaces trainer.py:173 (`backward`) for the small policies. */
 int nic_small_rollout_bwd_wgrad_slots(int32_t n_scenarios);

@@ -50,7 +50,8 @@ class NicEnvStepIO(C.Structure):
 class NicSmallRolloutDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in (
         "n_scenarios", "ldb", "T", "t0", "F", "n_hidden", "n_out", "head", "Ws", "Wn", "Ww", "E", "We", "lost_demand",
-        "maximize_profit", "detach_input", "round_orders")] + [("upper_bound", C.c_float), ("weights", C.c_void_p), ("demand", C.c_void_p),
+        "maximize_profit", "detach_input", "round_orders")] + [("upper_bound", C.c_float), ("lane_scenarios", C.c_int32),
+                                               ("weights", C.c_void_p), ("demand", C.c_void_p),
                                                ("state0", C.c_void_p)]
                 + [(n, NicTable2) for n in ("underage", "holding", "lead", "wh_holding", "wh_lead", "wh_edge",
                                             "ech_holding", "ech_lead")])

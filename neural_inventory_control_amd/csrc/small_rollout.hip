@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "nic_common.h"
+#include "small_rollout16.h"
 #include "small_rollout_body.h"
 
 namespace {
@@ -428,12 +429,18 @@ __global__ __launch_bounds__(64) void small_rollout_bwd_mfma_kernel(NicSmallRoll
     }
 }
 
+// scenarios per wavefront: 32 unless the descriptor asks for the 16-scenario form (whose hidden-activation history is in a
+// wave-native order private to its forward / backward pair, so the choice is the caller's and the same for both launches)
+int lane_width(const NicSmallRolloutDesc& d, bool) { return d.lane_scenarios == 16 ? 16 : 32; }
+
 int validate(const NicSmallRolloutDesc* d, const char* who) {
     NIC_REQUIRE(d != nullptr, "%s: null descriptor", who);
     NIC_REQUIRE(d->n_scenarios > 0 && d->ldb >= d->n_scenarios && d->T > 0 && d->t0 >= 0, "%s: bad sizes", who);
     NIC_REQUIRE(d->n_hidden >= 1 && d->n_hidden <= 3, "%s: n_hidden must be 1..3", who);
     NIC_REQUIRE(d->n_out >= 1 && d->n_out <= NIC_SR_MAX_OUTPUTS, "%s: n_out out of range", who);
     NIC_REQUIRE(d->head == 0 || d->head == 1, "%s: unknown head", who);
+    NIC_REQUIRE(d->lane_scenarios == 0 || d->lane_scenarios == 16 || d->lane_scenarios == 32, "%s: lane_scenarios must be 0, 16 or 32", who);
+    NIC_REQUIRE(d->lane_scenarios != 16 || d->ldb % 16 == 0, "%s: the 16-scenario form needs ldb to be a multiple of 16", who);
     NIC_REQUIRE(d->Ws >= 2 && d->Wn >= 0 && d->Wn <= 1 && d->E >= 0 && d->E <= 3, "%s: unsupported chain", who);
     NIC_REQUIRE(d->E == 0 || d->Wn == 1, "%s: echelons need the warehouse", who);
     NIC_REQUIRE(d->F == d->Ws + d->Wn * d->Ww + d->E * d->We && d->F <= NIC_SR_MAX_INPUTS, "%s: F mismatch / too large", who);
@@ -453,6 +460,10 @@ int nic_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* s
     NIC_REQUIRE(d->state0 && rewards && state_final, "nic_small_rollout_fwd: null buffer");
     NIC_REQUIRE(!states_hist || (hidden_hist && logits_hist), "nic_small_rollout_fwd: incomplete history buffers");
     hipStream_t s = nic::as_stream(stream);
+    if (lane_width(*d, false) == 16) {
+        nic::small_rollout16_fwd(*d, shape_of(*d), rewards, state_final, states_hist, hidden_hist, logits_hist, s);
+        return nic::check_launch("nic_small_rollout_fwd");
+    }
     {  // matrix-core form: 32 scenarios per wavefront
         const int shape = shape_of(*d);
         nic::note_kernelf("small_rollout_fwd_mfma_kernel<%d,%s>", d->n_hidden, shape == 1 ? "one_store" : (shape == 2 ? "serial" : "any"));
@@ -475,6 +486,7 @@ int nic_small_rollout_fwd(const NicSmallRolloutDesc* d, float* rewards, float* s
 int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
                           const float* logits_hist, NicTable2 g_reward, float* dz_hidden, float* dz_out, void* stream) {
     if (int e = validate(d, "nic_small_rollout_bwd")) return e;
+    NIC_REQUIRE(d->lane_scenarios != 16, "nic_small_rollout_bwd: the dz-history sweep reads the [row][t][ldb] history of the 32-scenario forward");
     NIC_REQUIRE(states_hist && hidden_hist && logits_hist && g_reward.p && dz_hidden && dz_out,
                 "nic_small_rollout_bwd: null buffer");
     hipStream_t s = nic::as_stream(stream);
@@ -495,7 +507,9 @@ int nic_small_rollout_bwd(const NicSmallRolloutDesc* d, const float* states_hist
     }
 }
 
-int nic_small_rollout_bwd_wgrad_slots(int32_t n_scenarios) { return nic::ceil_div(n_scenarios, 32); }
+/* (one partial-gradient row per wavefront; sized for the 16-scenario form - the 32-scenario form fills the first half and the
+ * caller's buffer is zero elsewhere) */
+int nic_small_rollout_bwd_wgrad_slots(int32_t n_scenarios) { return nic::ceil_div(n_scenarios, 16); }
 
 int nic_small_rollout_bwd_wgrad(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
                                 const float* logits_hist, NicTable2 g_reward, float* slab, int64_t slab_stride, void* stream) {
@@ -506,6 +520,10 @@ int nic_small_rollout_bwd_wgrad(const NicSmallRolloutDesc* d, const float* state
                 (long long)slab_stride, n_packed);
     hipStream_t s = nic::as_stream(stream);
     const int shape = shape_of(*d);
+    if (lane_width(*d, true) == 16) {
+        nic::small_rollout16_bwd_wgrad(*d, shape, states_hist, hidden_hist, logits_hist, g_reward, slab, slab_stride, s);
+        return nic::check_launch("nic_small_rollout_bwd_wgrad");
+    }
     nic::note_kernelf("small_rollout_bwd_mfma_kernel<%d,wgrad,%s>", d->n_hidden, shape == 1 ? "one_store" : (shape == 2 ? "serial" : "any"));
     const dim3 g32(nic::ceil_div(d->n_scenarios, 32)), b64(64);
 #define NIC_SR_BWD_WG(NL, SH)                                                                                                 \

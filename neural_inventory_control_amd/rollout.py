@@ -101,6 +101,7 @@ class FusedRollout:
         self.timer = None  # KernelTimer or None
         self.use_graph = False  # replay the launch sequence from a HIP graph (see _replay_or_capture)
         self.use_small = True   # whole-horizon kernels for the small one-store-chain policies (small_rollout.py)
+        self.small_lane_scenarios = 0  # ... 16 or 32 scenarios per wavefront (0: 16 while 32 would leave SIMDs without a wavefront)
         self.small_wgrad_in_kernel = True  # ... with the weight gradients contracted inside the backward kernel (False: dZ history + one GEMM per layer)
         self.use_thin = True    # fused backward of thin (<= 32 rows) output layers (csrc/thin_layer.hip)
         self.batch_wgrad = True  # hidden-layer weight gradients contracted over all periods in one launch
@@ -396,7 +397,16 @@ class FusedRollout:
         if prob.E:
             s0.ech[:, :, :B].copy_(data["initial_echelon_inventories"].permute(1, 2, 0))
         ub = self._ub() if self.head != "softplus" else 0.0
-        desc = plan.desc(T, shift, self.sr_weights, demand_soa, self.sr_state0, ub, round_orders=self._round, prob=prob)
+        # Scenarios per wavefront.  Training: 16 (v_mfma_f32_16x16x4_f32, wave-native activation history) - measured against 32:
+        # cfg1 0.55 -> 0.30 ms, cfg4 (16,384 scenarios: 32 leaves half the SIMDs without a wavefront) 0.83 -> 0.70 ms, cfg2
+        # (32,768) 1.16 -> 1.07 ms, 65,536 scenarios 2.28 -> 1.87 ms.  Evaluation (no history): 16 while 32 would leave SIMDs
+        # idle, else 32 (the per-lane head / env-step code is replicated in four lane groups instead of two).  The dz-history
+        # sweep (small_wgrad_in_kernel = False) only exists in the 32-wide form.
+        width = self.small_lane_scenarios or (16 if (train or B <= 16384) else 32)
+        if train and not self.small_wgrad_in_kernel:
+            width = 32
+        desc = plan.desc(T, shift, self.sr_weights, demand_soa, self.sr_state0, ub, round_orders=self._round, prob=prob,
+                         lane_scenarios=width)
         hist = (self.sr_states, self.sr_hidden, self.sr_logits) if train else (None, None, None)
         self._k("small_rollout_fwd", sr.small_rollout_fwd, desc, self.rewards, self.sr_final, *hist)
         total = self.rewards.sum()

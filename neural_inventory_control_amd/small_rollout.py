@@ -60,7 +60,7 @@ class SmallRolloutPlan:
                 and 1 <= n_hidden <= 3 and all(w == H for w in dims[1:-1]) and dims[-1] <= _lib.NIC_SR_MAX_OUTPUTS
                 and (head != "softplus" or dims[-1] == 1) and (head != "serial" or dims[-1] == prob.E + 2))
 
-    def desc(self, T, t0, weights, demand_soa, state0, upper_bound, round_orders=False, prob=None):
+    def desc(self, T, t0, weights, demand_soa, state0, upper_bound, round_orders=False, prob=None, lane_scenarios=0):
         """demand_soa: [T_total][1][ldb]; state0: [F][ldb]; prob: the CURRENT batch's EnvProblem (same shapes as the
         plan's; its cost / lead-time tables are the ones the kernels read)."""
         p = prob if prob is not None else self.prob
@@ -73,6 +73,7 @@ class SmallRolloutPlan:
         d.detach_input = int(self.head == "serial")
         d.round_orders = int(bool(round_orders))
         d.upper_bound = float(upper_bound)
+        d.lane_scenarios = int(lane_scenarios)   # 0: the library picks 16 or 32 scenarios per wavefront from the batch size
         d.weights, d.demand, d.state0 = weights.data_ptr(), demand_soa.data_ptr(), state0.data_ptr()
         d.underage, d.holding = p.underage.t2(), p.holding.t2()
         lead = p.lead  # (s, w, b) table with one store and one supplier column

@@ -65,11 +65,15 @@ def test_whole_horizon_route_at_full_size(workload, n, T):
     with torch.no_grad():
         eng.run(data, T, 0, train=False, observation_params=obs, demand_soa=sc.demands_soa)
     assert eng.small is not None  # the whole-horizon route
+    # (the library picks 16 or 32 scenarios per wavefront from the batch size; the two forms sum a layer's contraction in
+    # different orders, so the small batches below are run in the form the full batch took)
+    width = 16 if b"small_rollout16" in _lib.lib().nic_last_kernel() else 32
     r_full = eng.per_period_rewards().clone()
     assert r_full.shape == (T, n) and bool(torch.isfinite(r_full).all())
     # batch independence, bit for bit: a ragged 45-scenario batch from the middle of the grid and the last 33 scenarios
     for lo, hi in ((0, 45), (n // 2 - 7, n // 2 + 38), (n - 33, n)):
         small = FusedRollout(model, setting["problem_params"], DEV)
+        small.small_lane_scenarios = width
         with torch.no_grad():
             small.run(_slice(data, lo, hi), T, 0, train=False, observation_params=obs)
         assert torch.equal(small.per_period_rewards(), r_full[:, lo:hi]), (lo, hi)

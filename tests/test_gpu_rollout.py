@@ -460,11 +460,13 @@ def test_small_route_in_kernel_weight_gradients_match_the_gemm_path(workload, n,
                   n, obs, setting["seeds"])
     data = {k: v.to(DEV) for k, v in sc.get_data().items()}
     res = {}
-    for in_kernel in (True, False):
+    # (in-kernel weight gradients with 16 scenarios per wavefront - the engine's default -, with 32, and the dz-history path)
+    for in_kernel, width in ((True, 16), (True, 32), (False, 32)):
         torch.manual_seed(5)
         model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
         eng = FusedRollout(model, setting["problem_params"], DEV)
         eng.small_wgrad_in_kernel = in_kernel
+        eng.small_lane_scenarios = width
         F = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
         if policy["name"] != "vanilla_one_store":
             F += sum(int(np.prod(data[k].shape[1:])) for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
@@ -473,10 +475,14 @@ def test_small_route_in_kernel_weight_gradients_match_the_gemm_path(workload, n,
         total, _ = eng.run(data, T, 0, train=True, observation_params=obs)
         torch.cuda.synchronize()
         assert eng.small is not None
-        res[in_kernel] = (float(total), [p.grad.clone() for p in model.parameters()])
-    assert res[True][0] == res[False][0]
-    for x, y in zip(res[True][1], res[False][1]):
-        assert float((x - y).norm() / (y.norm() + 1e-30)) < 5e-6
+        assert (b"small_rollout16" in _lib.lib().nic_last_kernel()) == (width == 16)
+        res[(in_kernel, width)] = (float(total), [p.grad.clone() for p in model.parameters()])
+    ref = res[(False, 32)]
+    assert res[(True, 32)][0] == ref[0]   # same forward kernel
+    assert abs(res[(True, 16)][0] - ref[0]) <= 2e-6 * abs(ref[0])
+    for key in ((True, 16), (True, 32)):
+        for x, y in zip(res[key][1], ref[1]):
+            assert float((x - y).norm() / (y.norm() + 1e-30)) < 5e-6, key
 
 
 @pytest.mark.parametrize("variant", ["one_store_ws3", "serial_one_echelon", "serial_ww4"])
