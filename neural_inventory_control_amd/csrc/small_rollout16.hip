@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_fwd_kernel(NicSmallRoll
 // scenarios], row stride 17) into row-owner operands, and 16 MFMAs (4 output tiles x 4 steps of 4 scenarios) add dZ X^T into
 // accumulators that stay in registers for the whole horizon.
 template <int NL, int SHAPE>
-__global__ __launch_bounds__(64) void small_rollout16_bwd_kernel(NicSmallRolloutDesc d, const float* __restrict__ weights,
+__global__ __launch_bounds__(64, 2) void small_rollout16_bwd_kernel(NicSmallRolloutDesc d, const float* __restrict__ weights,
                                                                  const float* __restrict__ demand,
                                                                  const float* __restrict__ states_hist,
                                                                  const float* __restrict__ hidden_hist,
