@@ -73,6 +73,15 @@ def note_name(k):
     m = re.match(r"small_rollout_bwd_mfma_kernel<(\d+), (true|false), (\d+)>", k)
     if m:
         return "small_rollout_bwd_mfma_kernel<%s,%s%s>" % (m.group(1), "wgrad," if m.group(2) == "true" else "", shapes[m.group(3)])
+    m = re.match(r"small_rollout16_fwd_kernel<(\d+), (\d+)>", k)
+    if m:
+        return "small_rollout16_fwd_kernel<%s,%s>" % (m.group(1), shapes[m.group(2)])
+    m = re.match(r"small_rollout16_bwd_kernel<(\d+), (\d+)>", k)
+    if m:
+        return "small_rollout16_bwd_kernel<%s,wgrad,%s>" % (m.group(1), shapes[m.group(2)])
+    m = re.match(r"(gemm_wgrad_dma_kernel<\d+, \d+, \d+, \d+), (true|false)>", k)
+    if m:
+        return (m.group(1) + (",skip>" if m.group(2) == "true" else ">")).replace(" ", "")
     m = re.match(r"(gemm_wx(?:_dma)?_kernel<\d+, \d+, \d+, \d+), (\d)>", k)
     if m:
         return (m.group(1) + "," + {"0": "EPI_BIAS_ACT", "1": "EPI_DGRAD"}.get(m.group(2), m.group(2)) + ">").replace(" ", "")
@@ -141,7 +150,8 @@ def main():
         for a in sys.argv[2:]:
             traffic_pass(rnd, a.split(":", 1)[1], out)
         return
-    workloads = sys.argv[2:] or ["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "gnn", "base_stock", "base_stock_1m", "echelon_stock"]
+    workloads = sys.argv[2:] or ["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "gnn", "base_stock", "base_stock_1m", "echelon_stock",
+                                 "real_data_driven"]
     out = os.path.join(ROOT, "gpurun_out", rnd)
     os.makedirs(out, exist_ok=True)
     for w in workloads:
@@ -155,6 +165,9 @@ def main():
         if traces:
             stats_from_trace(traces[0], os.path.join(out, f"{rnd}_bench_{w}_kernel_stats.csv"),
                              os.path.join(out, f"{rnd}_bench_{w}_kernel_by_grid.csv"))
+        if w in ("base_stock", "echelon_stock", "real_data_driven"):   # launch-bound steps: also replayed from one HIP graph
+            run(["python3", "bench.py", "--workload", w, "--graph", "--no-cpu-baseline"] + steps,
+                os.path.join(out, f"{rnd}_bench_{w}_graph.json"))
         print(w, open(os.path.join(out, f"{rnd}_bench_{w}.json")).read()[:300], flush=True)
     if "cfg3" in workloads:   # counter traffic of the headline workload rides along (bench.py reads it from profiles/ next time)
         traffic_pass(rnd, "cfg3", out)
