@@ -395,6 +395,35 @@ class VanillaWarehouse(MyNeuralNetwork):
 
 
 
+class SymmetryAware(MyNeuralNetwork):
+    """The "symmetry-aware policy net" BASELINE.json's cfg3 names.  It is NOT in the reference's current source (no class, no
+    YAML; `get_architecture` registers 13 names without it); SURVEY §2.2 recovered its forward from the stale bytecode, and the
+    pieces it was built from are still upstream: `apply_proportional_allocation` (neural_networks.py:111-138),
+    `concatenate_signal_to_object_state_tensor` (:178-187), the `store` / `warehouse` / `context` defaults of
+    `set_default_output_size` (:1505-1509).  Weight sharing across stores: ONE context net over the whole state, ONE warehouse
+    net applied to (warehouse pipeline | context), ONE store net applied to every (store pipeline | mean, std, underage cost,
+    lead time | context); store orders are scaled down proportionally when they exceed the warehouse's on-hand stock, the
+    warehouse orders its net's output times the upper bound.  Actions are 3-D as today's simulator needs them (the bytecode
+    returned 2-D ones).  One-warehouse settings with the demand moments in the observation.
+    PARITY UNPINNED: there is no reference to compare with; the HIP path is checked against this repository's own
+    CPU restatement (oracle.symmetry_aware_act)."""
+
+    def forward(self, observation):
+        s_inv, w_inv = observation["store_inventories"], observation["warehouse_inventories"]
+        if w_inv.size(1) != 1:
+            raise ValueError("symmetry_aware: one-warehouse settings only")
+        context = self.net["context"](torch.cat((s_inv.flatten(start_dim=1), w_inv.flatten(start_dim=1)), dim=1))
+        warehouse_out = self.net["warehouse"](self.concatenate_signal_to_object_state_tensor(w_inv, context))[:, :, 0]
+        store_params = torch.stack([observation["mean"], observation["std"], observation["underage_costs"],
+                                    observation["lead_times"][:, :, 0]], dim=2)
+        store_in = self.concatenate_signal_to_object_state_tensor(torch.cat((s_inv, store_params), dim=2), context)
+        store_out = self.net["store"](store_in)[:, :, 0]
+        stores = self.apply_proportional_allocation(store_out, w_inv[:, :, 0])
+        ub = self.warehouse_upper_bound
+        ub = ub.to(warehouse_out.device) if torch.is_tensor(ub) else torch.tensor([float(ub)], device=warehouse_out.device)
+        return {"stores": stores.unsqueeze(2), "warehouses": (warehouse_out * ub.reshape(1, -1)).unsqueeze(2)}
+
+
 class DataDrivenNet(MyNeuralNetwork):
     """neural_networks.py:430-515: one MLP over every observed feature of the real-data settings (pipelines, the past-demand
     window, costs, days from christmas, lead-time matrix); with warehouses the outputs are [Wn warehouse orders | S x Wn store
@@ -749,6 +778,8 @@ class NeuralNetworkCreator:
             "echelon_stock": EchelonStock, "vanilla_serial": VanillaSerial, "vanilla_warehouse": VanillaWarehouse,
             "data_driven": DataDrivenNet, "transformed_nv": TransformedNV, "fixed_quantile": FixedQuantile,
             "quantile_nv": QuantileNV, "returns_nv": ReturnsNV, "just_in_time": JustInTime, "gnn": GNN,
+            # not in the reference's current registry (:1521-1535): the policy BASELINE cfg3 names, recovered per SURVEY §2.2
+            "symmetry_aware": SymmetryAware,
         }
         return architectures[name]  # KeyError for unknown names, like the reference (:1536)
 

@@ -167,6 +167,18 @@ def data_driven_policy():
             "neurons_per_hidden_layer": {"master": [64, 64]}, "initial_bias": {"master": 1.0}, "output_sizes": {"master": None}}
 
 
+def symmetry_aware_policy(context=64):
+    """Layer sizes are this repository's choice (no YAML survives upstream): a `context`-wide context vector, 32-wide store and
+    warehouse nets; softplus on the store net's desired order, sigmoid x upper bound on the warehouse's."""
+    mods = ("context", "store", "warehouse")
+    return {"name": "symmetry_aware",
+            "inner_layer_activations": {m: "elu" for m in mods},
+            "output_layer_activation": {"context": "elu", "store": "softplus", "warehouse": "sigmoid"},
+            "neurons_per_hidden_layer": {"context": [256], "store": [32, 32], "warehouse": [32, 32]},
+            "output_sizes": {"context": context, "store": 1, "warehouse": 1},
+            "initial_bias": None, "warehouse_upper_bound_mult": 4}
+
+
 WORKLOADS = {
     # name: (setting builder, policy dict, scenarios per GPU, periods, description)
     "cfg1": (lambda: one_store(True, True), _mlp("vanilla_one_store", [32, 32, 32], 1), 256, 50,
@@ -187,6 +199,10 @@ WORKLOADS = {
                       "one_store_backlogged + base_stock, 1,048,576 scenarios x T=100 (enough chains in flight to be HBM-bound)"),
     "echelon_stock": (serial_system, _closed_form("echelon_stock", 4, None, None), 131072, 100,
                       "serial_system 4 echelons + echelon_stock, 131072 scenarios x T=100"),
+    # BASELINE cfg3 "as worded": the symmetry-aware policy (recovered per SURVEY 2.2; parity unpinned) on the generic route
+    "cfg3_symmetry_aware": (lambda: one_warehouse(16), symmetry_aware_policy(), 8192, 50,
+                            "one_warehouse_lost_demand, 16 stores, 8192 scenarios x T=50, symmetry_aware (context 256->64, store / "
+                            "warehouse nets 32x2); generic route"),
     # the reference's real-data training batch (72 of 288 products x 21 stores x 3 warehouses, T = 95 of 111 train
     # weeks after the 16-week past-demand window) on the GENERIC route: Simulator.step (one HIP kernel per period) + HipLinear
     # layers + autograd; `--graph` replays the whole training step from one HIP graph

@@ -406,6 +406,8 @@ def policy_from_state_dict(nn_params, state_dict, problem_params=None, warehouse
     gradient-parity tests measure both the reference's float32 arithmetic and the HIP engine against."""
     if nn_params["name"] == "gnn":
         return gnn_from_state_dict(nn_params, state_dict, problem_params)
+    if nn_params["name"] == "symmetry_aware":
+        return symmetry_aware_from_state_dict(nn_params, state_dict, warehouse_upper_bound, dtype)
     idx = sorted({int(k.split(".")[2]) for k in state_dict if k.startswith("net.master.")})
     layers = [(state_dict[f"net.master.{i}.weight"].detach().clone().to(dtype).requires_grad_(True),
                state_dict[f"net.master.{i}.bias"].detach().clone().to(dtype).requires_grad_(True)) for i in idx]
@@ -494,11 +496,68 @@ def _softmax_share_of_stock(logits, warehouse_pipeline, transshipment):
     return torch.multiply(sm, stock[:, None])
 
 
+# --------------------------------------------------------------------------------------
+# Symmetry-aware policy (BASELINE cfg3's wording).  NOT in the reference's source: this restates SURVEY §2.2's recovery of the
+# stale bytecode with the helpers that are still upstream (apply_proportional_allocation neural_networks.py:111-138,
+# concatenate_signal_to_object_state_tensor :178-187).  PARITY UNPINNED: it pins the HIP path to this file only.
+# --------------------------------------------------------------------------------------
+SYM_MODULES = ("context", "store", "warehouse")
+
+
+@dataclass
+class OracleSymmetryAwarePolicy:
+    name: str
+    modules: Dict[str, List[Tuple[torch.Tensor, torch.Tensor]]]
+    inner_activation: Dict[str, Optional[str]]
+    output_activation: Dict[str, Optional[str]]
+    warehouse_upper_bound: torch.Tensor
+    keys: Optional[List[str]] = None
+
+    def parameters(self):
+        return [t for m in SYM_MODULES for wb in self.modules[m] for t in wb]
+
+    def param_keys(self):
+        return list(self.keys)
+
+
+def symmetry_aware_from_state_dict(nn_params, state_dict, warehouse_upper_bound, dtype=torch.float32):
+    modules, keys = {}, []
+    for m in SYM_MODULES:
+        idx = sorted({int(k.split(".")[2]) for k in state_dict if k.startswith(f"net.{m}.")})
+        modules[m] = []
+        for i in idx:
+            w = state_dict[f"net.{m}.{i}.weight"].detach().clone().to(dtype).requires_grad_(True)
+            b = state_dict[f"net.{m}.{i}.bias"].detach().clone().to(dtype).requires_grad_(True)
+            modules[m].append((w, b))
+            keys += [f"net.{m}.{i}.weight", f"net.{m}.{i}.bias"]
+    return OracleSymmetryAwarePolicy(name="symmetry_aware", modules=modules,
+                                     inner_activation=dict(nn_params["inner_layer_activations"]),
+                                     output_activation=dict(nn_params["output_layer_activation"]),
+                                     warehouse_upper_bound=warehouse_upper_bound.detach().clone().to(dtype), keys=keys)
+
+
+def symmetry_aware_act(pol, obs):
+    s_inv, w_inv = obs["store_inventories"], obs["warehouse_inventories"]
+    B, S = s_inv.shape[0], s_inv.shape[1]
+    context = _gnn_mlp(pol, "context", torch.cat((s_inv.flatten(start_dim=1), w_inv.flatten(start_dim=1)), dim=1))
+    w_in = torch.cat((w_inv, context.unsqueeze(1).expand(-1, w_inv.size(1), -1)), dim=2)          # :178-187
+    warehouse_out = _gnn_mlp(pol, "warehouse", w_in)[:, :, 0]
+    store_params = torch.stack([obs["mean"], obs["std"], obs["underage_costs"], obs["lead_times"][:, :, 0]], dim=2)
+    s_in = torch.cat((s_inv, store_params, context.unsqueeze(1).expand(-1, S, -1)), dim=2)
+    store_out = _gnn_mlp(pol, "store", s_in)[:, :, 0]
+    available = w_inv[:, :, 0].sum(dim=1)                                                             # :124-126
+    scaling = torch.clip(available / (store_out.sum(dim=1) + 1e-10), max=1.0)                       # :129-135
+    stores = store_out * scaling[:, None]
+    return {"stores": stores.unsqueeze(2), "warehouses": (warehouse_out * pol.warehouse_upper_bound.reshape(1, -1)).unsqueeze(2)}
+
+
 def policy_act(pol: OraclePolicy, obs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Forward of the in-scope architectures; action tensors are always 3-D."""
     name = pol.name
     if name == "gnn":
         return gnn_act(pol, obs)
+    if name == "symmetry_aware":
+        return symmetry_aware_act(pol, obs)
     if name == "vanilla_one_store":  # neural_networks.py:200-214
         x = obs["store_inventories"].flatten(start_dim=1)
         x = F.softplus(_mlp(pol, x) + 1)

@@ -1152,3 +1152,43 @@ def test_per_sample_cost_tables_with_shuffled_batches_follow_the_oracle(setting_
             checked += 1
             del batch  # let the allocator recycle the batch's storage for the next one
     assert checked == 6
+
+
+# ---- the symmetry-aware policy BASELINE cfg3 names (not in the reference's source; parity UNPINNED) -------------------
+
+@pytest.mark.parametrize("n_stores", [5, 16])
+def test_symmetry_aware_policy_matches_its_cpu_restatement(n_stores):
+    """`symmetry_aware` on the generic route (Simulator.step as a HIP kernel per period + HipLinear layers shared over the stores)
+    against this repository's own CPU restatement (oracle.symmetry_aware_act): per-period rewards, total cost at 1e-5, parameter
+    gradients at 2e-5.  There is no upstream implementation to compare with - the oracle follows SURVEY 2.2's recovery."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from oracle import inventory_oracle as orc
+    setting, policy, _, _, _ = workloads.get("cfg3_symmetry_aware")
+    setting["problem_params"]["n_stores"] = n_stores
+    B, T = 37, 9
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    data = orc.generate_scenario_data(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"],
+                                      setting["echelon_params"], B, obs, setting["seeds"])
+
+    class _Sc:
+        problem_params = setting["problem_params"]
+        store_params = setting["store_params"]
+    torch.manual_seed(11)
+    model = NeuralNetworkCreator().create_neural_network(_Sc(), policy, device=DEV)
+    sim, tr = Simulator(device=DEV), Trainer(device=DEV)
+    dev_data = {k: v.to(DEV) for k, v in data.items()}
+    with torch.no_grad():   # materialise the lazy layers
+        o, _ = sim.reset(T, setting["problem_params"], dict(dev_data), obs)
+        model(o)
+    total, rep = tr.simulate_batch(PolicyLoss(), sim, model, T, setting["problem_params"], dict(dev_data), obs, 3, False)
+    (total / (B * T * n_stores)).backward()
+    torch.cuda.synchronize()
+    pol = orc.policy_from_state_dict(policy, {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                                     setting["problem_params"], model.warehouse_upper_bound.cpu())
+    res, _, grads = orc.train_step_gradients(pol, T, setting["problem_params"], data, obs, 3)
+    assert abs(float(total) - float(res.total)) <= 1e-5 * abs(float(res.total))
+    assert abs(float(rep) - float(res.reported)) <= 1e-5 * abs(float(res.reported))
+    named = dict(model.named_parameters())
+    for key, gref in zip(pol.param_keys(), grads):
+        assert _rel(named[key].grad, gref) <= GRAD_TOL, key

@@ -232,3 +232,39 @@ def test_sharded_host_generation_with_per_sample_tables_equals_single_process(tm
     assert len({int(p["lead_times"].max()) for p in parts}) > 1   # the shards do see different local maxima
     for k, v in whole.items():
         assert torch.equal(torch.cat([p[k] for p in parts], dim=0), v), k
+
+
+def test_symmetry_aware_policy_is_registered_and_its_oracle_allocations_are_feasible():
+    """BASELINE cfg3's "symmetry-aware policy net" (not in the reference's source): the factory builds it with the
+    three shared nets, and the CPU restatement allocates no more than the warehouse has on hand."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from oracle import inventory_oracle as orc
+    setting, policy, _, _, _ = workloads.get("cfg3_symmetry_aware")
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    data = orc.generate_scenario_data(6, setting["problem_params"], setting["store_params"], setting["warehouse_params"],
+                                      setting["echelon_params"], 9, obs, setting["seeds"])
+
+    class _Sc:
+        problem_params = setting["problem_params"]
+        store_params = setting["store_params"]
+    model = NeuralNetworkCreator().create_neural_network(_Sc(), policy, device="cpu")
+    assert type(model).__name__ == "SymmetryAware" and set(model.net.keys()) == {"context", "store", "warehouse"}
+    assert float(model.warehouse_upper_bound) == pytest.approx(4 * float(np.sum(setting["store_params"]["demand"]["mean"])), rel=1e-6)
+    # oracle side: random weights of the right shapes (the product module's lazy layers need the device to materialise)
+    gen = torch.Generator().manual_seed(0)
+    F_ctx = 16 * 3 + 3
+    dims = {"context": [F_ctx, 256, 64], "store": [3 + 4 + 64, 32, 32, 1], "warehouse": [3 + 64, 32, 32, 1]}
+    sd = {}
+    for m, ds in dims.items():
+        for li, (k, n) in enumerate(zip(ds[:-1], ds[1:])):
+            sd[f"net.{m}.{2 * li}.weight"] = torch.randn(n, k, generator=gen) * 0.2
+            sd[f"net.{m}.{2 * li}.bias"] = torch.randn(n, generator=gen) * 0.1
+    pol = orc.policy_from_state_dict(policy, sd, setting["problem_params"], model.warehouse_upper_bound)
+    env = orc.env_reset(6, setting["problem_params"], dict(data), obs)
+    act = orc.policy_act(pol, env.obs)
+    assert act["stores"].shape == (9, 16, 1) and act["warehouses"].shape == (9, 1, 1)
+    assert bool((act["stores"] >= 0).all())
+    assert bool((act["stores"].sum(dim=(1, 2)) <= env.obs["warehouse_inventories"][:, 0, 0] + 1e-4).all())
+    res, _, grads = orc.train_step_gradients(pol, 6, setting["problem_params"], data, obs)
+    assert torch.isfinite(res.total) and all(torch.isfinite(g).all() for g in grads)
