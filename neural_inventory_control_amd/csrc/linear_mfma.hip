@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     // (the 7-row-tile wave holds 112 accumulators + 56 fragment registers: no room for the prefetch registers as well)
     constexpr bool PREFETCH_H = EPI == EPI_DGRAD && MT <= 4;
     float4 hq[PREFETCH_H ? ITER : 1];  // (dead in the forward instantiation)
-    const bool pf_on = PREFETCH_H && p.Hprev != nullptr && p.act == NIC_ACT_ELU && nk >= PFT && !p.accumulate;
+    const bool pf_on = PREFETCH_H && p.Hprev != nullptr && p.act == NIC_ACT_ELU && nk >= PFT && !p.accumulate && !NIC_TUNE(8);
     auto load_h = [&](int pass, int it) {
         const int row = m0 + pass * PASS_ROWS + t / TPR + RPI * it;
         return (row < p.M && col < p.ncols) ? *reinterpret_cast<const float4*>(p.Hprev + (int64_t)row * p.ldb + col)
@@ -518,6 +518,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
 #endif
     const int nk_plain = pf_on ? nk - PFT : nk;
     for (int kt = 0; kt < nk_plain; ++kt) ktile(kt);
+    if (NIC_TUNE(16)) NIC_STAMP(1);  // (tuning build: the "k loop" phase then covers the prefetch tiles alone)
     if constexpr (EPI == EPI_DGRAD) {
         if (pf_on) {
 #pragma unroll

@@ -3,7 +3,8 @@
 and at exit, per workgroup), runs the forward / dgrad kernels at BASELINE cfg3's shape and prints per phase the mean duration
 and the s_memtime rate.  PROBE_TUNES=0,1,2,3,4,7 additionally runs timing-only variants of the k loop (results invalid):
 1 = no A-tile copies inside the loop, 2 = no B-tile copies, 4 = no barrier per k tile; 32 = s_setprio 1 for the younger half of
-the workgroup (valid results).  PROBE_PADS=0,64,... adds floats to the scenario stride of every operand.  The product library has no such instrumentation."""
+the workgroup (valid results); 8 = dgrad without the Hprev prefetch (valid), 16 = the k-loop stamp moved behind the plain tiles
+(the phase then covers the four prefetch tiles of dgrad / nothing in the forward kernel).  PROBE_PADS=0,64,... adds floats to the scenario stride of every operand.  The product library has no such instrumentation."""
 import ctypes
 import json
 import os
@@ -82,7 +83,7 @@ def main():
             n_wg = (N // 256) * (B // 256)
             stamps = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
             cases = [("fwd", lambda: ops.linear_fwd(W, b, X, Y, B, 1))]
-            if tune == 0:
+            if tune in (0, 8, 16):
                 cases.append(("dgrad", lambda: ops.linear_dgrad(Wt, Y, X, dX, B, 1, False)))
             for name, fn in cases:
                 r = run_case(lib, name, fn, n_wg, K, stamps)
