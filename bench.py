@@ -62,7 +62,7 @@ def spawn_ranks(n_gpus, argv):
     return 0
 
 
-def build_case(workload, device, rank, world, scenarios=None, periods=None):
+def build_case(workload, device, rank, world, scenarios=None, periods=None, generic_route=False):
     from collections import defaultdict
     from neural_inventory_control_amd import workloads
     from neural_inventory_control_amd.data_handling import Scenario
@@ -94,7 +94,9 @@ def build_case(workload, device, rank, world, scenarios=None, periods=None):
     torch.manual_seed(1234)  # identical initial weights on every rank (and broadcast below when world > 1)
     model = NeuralNetworkCreator().create_neural_network(sc, policy, device=device)
     eng = None
-    if FusedRollout.supports(model):
+    if generic_route:   # A/B: Simulator.step (one HIP kernel per period) + HipLinear layers + autograd, no fused engine
+        pass
+    elif FusedRollout.supports(model):
         eng = FusedRollout(model, setting["problem_params"], device)
     elif ClosedFormRollout.supports(model):
         eng = ClosedFormRollout(model, setting["problem_params"], device)
@@ -328,6 +330,8 @@ def main():
                     help="write the (kernel class, kernel) sequence of the timed steps as JSON and skip the event timing: what "
                          "tools/collect_profiles.py joins the profiler's per-dispatch counter rows to")
     ap.add_argument("--graph", action="store_true", help="replay the launch sequence from a HIP graph (implies --no-kernel-timing)")
+    ap.add_argument("--generic-route", action="store_true",
+                    help="A/B: run the workload on the generic per-period route even where a fused engine exists")
     ap.add_argument("--lane-scenarios", type=int, default=0, choices=(0, 16, 32),
                     help="whole-horizon route: scenarios per wavefront (0 = chosen by the library from the batch size)")
     ap.add_argument("--gnn-keep-inputs", action="store_true",
@@ -349,7 +353,7 @@ def main():
         sys.exit(2)
 
     setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, device, rank, world, args.scenarios,
-                                                                   args.periods)
+                                                                   args.periods, args.generic_route)
     pp = setting["problem_params"]
     S = pp["n_stores"]
     closed_form = eng is not None and type(eng).__name__ == "ClosedFormRollout"
@@ -395,6 +399,8 @@ def main():
         sim, tr, loss_fn = Simulator(device=device), Trainer(device=device), PolicyLoss()
         args.no_kernel_timing = True
         tr._global_batch = global_b
+        if args.generic_route:
+            tr.use_fused_rollout = False
 
         def generic_step():
             if args.graph:  # whole training step (all periods + autograd sweep) replayed from one HIP graph
@@ -522,7 +528,7 @@ def main():
                                             "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
                                             "mean_launch_ms": e["mean_ms"]}
         if world == 1 and not args.no_cpu_baseline and not args.eval:
-            sample = args.cpu_sample or {"cfg3": 4096, "cfg5": 1024, "cfg2": 32768, "cfg4": 16384, "cfg1": 256, "base_stock": 32768, "gnn": 512,
+            sample = args.cpu_sample or {"cfg3": 4096, "cfg5": 1024, "cfg2": 32768, "cfg4": 16384, "cfg1": 256, "base_stock": 32768, "gnn": 512, "gnn_many_warehouses": 256,
                                          "real_data_driven": 72}.get(args.workload, 1024)
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, min(sample, n), T, model=model)

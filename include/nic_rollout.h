@@ -377,6 +377,21 @@ int nic_gnn_alloc_fwd(const float* out, const float* on_hand, float* orders, flo
 int nic_gnn_alloc_bwd(const float* out, const float* on_hand, const float* g_orders, const float* sums, const float* ratio,
                       const float* scale, float* d_out, float* g_on_hand, int32_t S, int32_t n_edges, int32_t e_self,
                       int32_t e_supplier, int32_t cap_at_one, int32_t n_scenarios, int32_t ldb, void* stream);
+/* The same allocation for SEVERAL supplying nodes (many-warehouse graphs: `_apply_proportional_allocation_to_graph`,
+ * neural_networks.py:1435-1492, loops over every node with outgoing edges).  groups [n_groups][4] (device) = {first member edge,
+ * member count, self-loop edge or -1, supplier edge} per warehouse - its internal edges are contiguous rows of `out`;
+ * on_hand + g * on_hand_group_stride = on-hand row of group g; sums / ratio / scale are [n_groups][ldb]; order_row [n_edges]
+ * (device) = row of `orders` (resp. `g_orders`) an edge's quantity is written to (read from), -1 for edges that order nothing.
+ * The column an internal edge lands in is the caller's choice - upstream uses "j-th connected warehouse of the store"
+ * (:1423-1428), not the warehouse's own index; the host side reproduces that and says so.  Backward writes d_out for every
+ * member / self-loop / supplier row and clears rows [zero_first, zero_first + zero_count) (the demand edges). */
+int nic_gnn_alloc_groups_fwd(const float* out, const float* on_hand, int64_t on_hand_group_stride, float* orders, float* sums,
+                             float* ratio, float* scale, const int32_t* groups, const int32_t* order_row, int32_t n_groups,
+                             int32_t cap_at_one, int32_t n_scenarios, int32_t ldb, void* stream);
+int nic_gnn_alloc_groups_bwd(const float* out, const float* on_hand, int64_t on_hand_group_stride, const float* g_orders,
+                             const float* sums, const float* ratio, const float* scale, float* d_out, float* g_on_hand,
+                             const int32_t* groups, const int32_t* order_row, int32_t n_groups, int32_t zero_first,
+                             int32_t zero_count, int32_t cap_at_one, int32_t n_scenarios, int32_t ldb, void* stream);
 /* dst[r][n][b] (+)= dst_scale[n] * sum_{p in [offsets[n], offsets[n+1])} src[r][items[p]][b] for r < R, in item order
  * (deterministic: no atomics).  Forward: message aggregation over a node's incident edges (:1229-1269, with the
  * 1/sqrt(degree) normalisation :1275-1296 as dst_scale); backward: the adjoint of every gather above. */

@@ -129,6 +129,8 @@ PROTOTYPES = {
     "nic_segment_sum_terms": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_gnn_alloc_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_gnn_alloc_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "nic_gnn_alloc_groups_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "nic_gnn_alloc_groups_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_segment_sum": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_closed_form_num_partials": (C.c_int, [_i32, _i32]),
     "nic_closed_form_rollout": (C.c_int, [C.POINTER(NicClosedFormDesc), _vp, _vp, _vp, _vp, _vp]),

@@ -1241,6 +1241,65 @@ __global__ void gnn_alloc_bwd_kernel(const float* __restrict__ out, const float*
     g_on_hand[b] = goh + d_scale / den;
 }
 
+// ---- the same allocation for SEVERAL supplying nodes (many-warehouse graphs) ----------------------------------------------------
+// groups [G][4] = {first member edge, member count, self-loop edge or -1, supplier edge}: the internal edges of one warehouse are
+// contiguous (adjacency.nonzero() is warehouse-major); order_row [n_edges] = row of the orders buffer an edge's quantity goes
+// to (-1: none).  One lane = (scenario, group): blockIdx.y = group.  Sums run in edge order like the one-warehouse kernel.
+__global__ void gnn_alloc_groups_fwd_kernel(const float* __restrict__ out, const float* __restrict__ on_hand, int64_t oh_stride,
+                                            float* __restrict__ orders, float* __restrict__ sums, float* __restrict__ ratio,
+                                            float* __restrict__ scale, const int32_t* __restrict__ groups,
+                                            const int32_t* __restrict__ order_row, int cap_at_one, int B, int64_t ldb) {
+#pragma clang fp contract(off)
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int g = blockIdx.y;
+    const int first = groups[4 * g], count = groups[4 * g + 1], e_self = groups[4 * g + 2], e_sup = groups[4 * g + 3];
+    const float sup_v = out[(int64_t)e_sup * ldb + b];
+    orders[(int64_t)order_row[e_sup] * ldb + b] = sup_v;
+    if (count == 0 && e_self < 0) return;   // a warehouse that supplies nobody: its own order only
+    const float oh = on_hand[(int64_t)g * oh_stride + b];
+    float sum = 0.f;
+    for (int i = 0; i < count; ++i) sum += out[(int64_t)(first + i) * ldb + b];
+    if (e_self >= 0) sum += out[(int64_t)e_self * ldb + b];
+    const float r = oh / (sum + 1e-10f);
+    const float sc = cap_at_one ? fminf(r, 1.f) : r;
+    sums[(int64_t)g * ldb + b] = sum;
+    ratio[(int64_t)g * ldb + b] = r;
+    scale[(int64_t)g * ldb + b] = sc;
+    for (int i = 0; i < count; ++i) orders[(int64_t)order_row[first + i] * ldb + b] = out[(int64_t)(first + i) * ldb + b] * sc;
+}
+
+// adjoint; rows [zero_first, zero_first + zero_count) of d_out (the demand edges: they feed nothing) are cleared by group 0
+__global__ void gnn_alloc_groups_bwd_kernel(const float* __restrict__ out, const float* __restrict__ on_hand, int64_t oh_stride,
+                                            const float* __restrict__ g_orders, const float* __restrict__ sums,
+                                            const float* __restrict__ ratio, const float* __restrict__ scale,
+                                            float* __restrict__ d_out, float* __restrict__ g_on_hand,
+                                            const int32_t* __restrict__ groups, const int32_t* __restrict__ order_row,
+                                            int zero_first, int zero_count, int cap_at_one, int B, int64_t ldb) {
+#pragma clang fp contract(off)
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int g = blockIdx.y;
+    const int first = groups[4 * g], count = groups[4 * g + 1], e_self = groups[4 * g + 2], e_sup = groups[4 * g + 3];
+    if (g == 0)
+        for (int i = 0; i < zero_count; ++i) d_out[(int64_t)(zero_first + i) * ldb + b] = 0.f;
+    d_out[(int64_t)e_sup * ldb + b] = g_orders[(int64_t)order_row[e_sup] * ldb + b];
+    if (count == 0 && e_self < 0) return;
+    const int64_t gb = (int64_t)g * ldb + b;
+    const float rt = ratio[gb], sm = sums[gb], sc = scale[gb], oh = on_hand[(int64_t)g * oh_stride + b];
+    float dot = 0.f;
+    for (int i = 0; i < count; ++i)
+        dot += g_orders[(int64_t)order_row[first + i] * ldb + b] * out[(int64_t)(first + i) * ldb + b];
+    const float passes = cap_at_one ? (rt <= 1.f ? 1.f : 0.f) : 1.f;
+    const float d_scale = dot * passes;
+    const float den = sm + 1e-10f;
+    const float common = -(d_scale * oh / (den * den));
+    for (int i = 0; i < count; ++i)
+        d_out[(int64_t)(first + i) * ldb + b] = common + g_orders[(int64_t)order_row[first + i] * ldb + b] * sc;
+    if (e_self >= 0) d_out[(int64_t)e_self * ldb + b] = common;
+    g_on_hand[(int64_t)g * oh_stride + b] += d_scale / den;
+}
+
 int validate(const NicMlp3Desc* d, const char* who) {
     NIC_REQUIRE(d && d->weights, "%s: null descriptor / weights", who);
     NIC_REQUIRE(d->n_entities > 0 && d->n_scenarios > 0 && d->ldb >= d->n_scenarios && d->ldb % 32 == 0,
@@ -1436,6 +1495,33 @@ int nic_gnn_alloc_bwd(const float* out, const float* on_hand, const float* g_ord
                        g_orders, sums, ratio, scale, d_out, g_on_hand, S, n_edges, e_self, e_supplier, cap_at_one, n_scenarios,
                        (int64_t)ldb);
     return nic::check_launch("nic_gnn_alloc_bwd");
+}
+
+int nic_gnn_alloc_groups_fwd(const float* out, const float* on_hand, int64_t on_hand_group_stride, float* orders, float* sums,
+                             float* ratio, float* scale, const int32_t* groups, const int32_t* order_row, int32_t n_groups,
+                             int32_t cap_at_one, int32_t n_scenarios, int32_t ldb, void* stream) {
+    NIC_REQUIRE(out && on_hand && orders && sums && ratio && scale && groups && order_row, "nic_gnn_alloc_groups_fwd: null buffer");
+    NIC_REQUIRE(n_groups > 0 && n_scenarios > 0 && ldb >= n_scenarios, "nic_gnn_alloc_groups_fwd: bad sizes");
+    nic::note_kernel("gnn_alloc_groups_fwd_kernel");
+    hipLaunchKernelGGL(gnn_alloc_groups_fwd_kernel, dim3(nic::ceil_div(n_scenarios, kAllocThreads), n_groups), dim3(kAllocThreads), 0,
+                       nic::as_stream(stream), out, on_hand, on_hand_group_stride, orders, sums, ratio, scale, groups, order_row,
+                       cap_at_one, n_scenarios, (int64_t)ldb);
+    return nic::check_launch("nic_gnn_alloc_groups_fwd");
+}
+
+int nic_gnn_alloc_groups_bwd(const float* out, const float* on_hand, int64_t on_hand_group_stride, const float* g_orders,
+                             const float* sums, const float* ratio, const float* scale, float* d_out, float* g_on_hand,
+                             const int32_t* groups, const int32_t* order_row, int32_t n_groups, int32_t zero_first,
+                             int32_t zero_count, int32_t cap_at_one, int32_t n_scenarios, int32_t ldb, void* stream) {
+    NIC_REQUIRE(out && on_hand && g_orders && sums && ratio && scale && d_out && g_on_hand && groups && order_row,
+                "nic_gnn_alloc_groups_bwd: null buffer");
+    NIC_REQUIRE(n_groups > 0 && zero_first >= 0 && zero_count >= 0 && n_scenarios > 0 && ldb >= n_scenarios,
+                "nic_gnn_alloc_groups_bwd: bad sizes");
+    nic::note_kernel("gnn_alloc_groups_bwd_kernel");
+    hipLaunchKernelGGL(gnn_alloc_groups_bwd_kernel, dim3(nic::ceil_div(n_scenarios, kAllocThreads), n_groups), dim3(kAllocThreads), 0,
+                       nic::as_stream(stream), out, on_hand, on_hand_group_stride, g_orders, sums, ratio, scale, d_out, g_on_hand,
+                       groups, order_row, zero_first, zero_count, cap_at_one, n_scenarios, (int64_t)ldb);
+    return nic::check_launch("nic_gnn_alloc_groups_bwd");
 }
 
 int nic_segment_sum(float* dst, int64_t dst_row_stride, const float* src, int64_t src_row_stride, const int32_t* offsets,

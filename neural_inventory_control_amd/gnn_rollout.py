@@ -1,5 +1,6 @@
 """`GnnRollout`: the unrolled rollout + backward of `Trainer.simulate_batch` for the GNN policy (`gnn.yml`;
-neural_networks.py:742-1492 of the reference) on the one-warehouse settings, without an autograd graph.
+neural_networks.py:742-1492 of the reference) on the warehouse -> store settings (one or several warehouses),
+without an autograd graph.
 
 The supply graph is static, so it is compiled once into entity maps and CSR lists (`GraphPlan`).  Per period the engine
 launches five fused gather-MLP kernels (`nic_mlp3_fwd`, csrc/mlp3.hip: each evaluates one of the policy's 32-wide MLPs for every
@@ -10,9 +11,9 @@ the adjoint of every gather (deterministic, no atomics); weight gradients are co
 gradients with the stored inputs (`nic_linear_wgrad`, slabs accumulated over the periods).  The reference's Python loops over
 edges (:1229-1269) and nodes (:1474-1490) become launches over all scenarios at once; ~60 launches per period instead of ~380.
 
-Everything is feature-major `[rows][entity][ldb]`.  Nodes = [warehouse, stores...]; edges = [internal (warehouse -> store s),
-supplier edge of the warehouse, demand edges of the stores, self loop of the warehouse] — the reference's order, so sums over a
-node's edges associate exactly as upstream.
+Everything is feature-major `[rows][entity][ldb]`.  Nodes = [warehouses..., stores...]; edges = [internal (warehouse -> store,
+warehouse-major), supplier edges of the warehouses, demand edges of the stores, self loops of the supplying warehouses] — the
+reference's order, so sums over a node's edges associate exactly as upstream.
 """
 import torch
 
@@ -33,25 +34,32 @@ def _csr(lists, device):
 
 
 class GraphPlan:
-    """Static structure of the one-warehouse supply graph (neural_networks.py:757-1062) as device index tensors."""
+    """Static structure of the warehouse -> store supply graph (neural_networks.py:757-1062) as device index tensors.
+    `conn` [W][S] = the setting's `warehouse_store_adjacency` (one warehouse: all ones).  Nodes = [warehouses..., stores...],
+    internal edges warehouse-major (the order of `adjacency.nonzero()`), then one supplier edge per warehouse, one demand edge per
+    store, one self loop per warehouse that supplies somebody (none under transshipment)."""
 
-    def __init__(self, S, transshipment, store_lead, wh_lead, device):
-        Wn = 1
-        self.S, self.n_nodes = S, Wn + S
-        internal = [(0, Wn + s) for s in range(S)]
-        n_int, n_sup, n_dem = S, 1, S
-        supplying = [] if transshipment else [0]
+    def __init__(self, S, conn, transshipment, device):
+        Wn = len(conn)
+        self.S, self.Wn, self.n_nodes = S, Wn, Wn + S
+        internal = [(w, Wn + s) for w in range(Wn) for s in range(S) if conn[w][s]]
+        n_int, n_sup, n_dem = len(internal), Wn, S
+        self.n_int = n_int
+        out_int = [sum(1 for a, _ in internal if a == w) for w in range(Wn)]
+        supplying = [] if transshipment else [w for w in range(Wn) if out_int[w] > 0]
         self.n_self = len(supplying)
         self.n_edges = n_int + n_sup + n_dem + self.n_self
-        src = [a for a, _ in internal] + [-1] + [Wn + s for s in range(S)] + supplying
-        tgt = [b for _, b in internal] + [0] + [-1] * n_dem + supplying
-        self.e_supplier = n_int
-        self.e_self = n_int + n_sup + n_dem if self.n_self else None
+        src = [a for a, _ in internal] + [-1] * n_sup + [Wn + s for s in range(S)] + supplying
+        tgt = [b for _, b in internal] + list(range(Wn)) + [-1] * n_dem + supplying
+        self.e_supplier = n_int                                            # (of warehouse 0; warehouse w: n_int + w)
+        self.e_self = n_int + n_sup + n_dem if self.n_self else None       # (of the first supplying warehouse)
+        self.e_demand = n_int + n_sup
         in_deg, out_deg = [0] * self.n_nodes, [0] * self.n_nodes
         for a, b in internal:
             out_deg[a] += 1
             in_deg[b] += 1
-        in_deg[0] += 1                      # supplier edge into the warehouse
+        for w in range(Wn):
+            in_deg[w] += 1                  # supplier edge into every warehouse
         for s in range(S):
             out_deg[Wn + s] += 1            # demand edge out of every store
         for n in supplying:
@@ -82,11 +90,33 @@ class GraphPlan:
         # adjoints of the endpoint gathers: node n receives from the edges it is the source / target of
         self.n_as_src = _csr([[e for e in range(self.n_edges) if src[e] == n] for n in range(self.n_nodes)], device)
         self.n_as_tgt = _csr([[e for e in range(self.n_edges) if tgt[e] == n] for n in range(self.n_nodes)], device)
-        lead = list(store_lead) + [wh_lead] + [0.0] * (n_dem + self.n_self)
-        self.lead = torch.tensor(lead, dtype=torch.float32, device=device).view(1, -1)   # per-edge constant input row
-        # proportional allocation group of the warehouse: its internal edges + its self loop (:1435-1492)
-        self.members = torch.tensor(list(range(n_int)) + ([self.e_self] if self.n_self else []), dtype=torch.long,
-                                    device=device)  # (a device tensor: indexing with it is capturable into a HIP graph)
+        # per-edge constant input row: lead time of internal / supplier edges, 0 for demand edges and self loops; refreshed on
+        # the device from every batch's lead-time tensors through these two index lists (GnnRollout.run)
+        self.lead = torch.zeros(1, self.n_edges, dtype=torch.float32, device=device)
+        self.lead_store = torch.tensor([b - Wn for _, b in internal], dtype=torch.long, device=device)
+        self.lead_wh = torch.tensor([a for a, _ in internal], dtype=torch.long, device=device)
+        # proportional allocation groups (:1435-1492): a warehouse's internal edges (contiguous) + its self loop
+        first, groups = 0, []
+        for w in range(Wn):
+            e_self = n_int + n_sup + n_dem + supplying.index(w) if w in supplying else -1
+            groups.append([first, out_int[w], e_self, n_int + w])
+            first += out_int[w]
+        self.groups = i32(groups)
+        # where an edge's quantity lands in the orders buffer [S][Wn] + [Wn].  Upstream writes store s's j-th INCOMING edge into
+        # column j (:1423-1428) - for a store that is not connected to every warehouse this is not the column of the warehouse
+        # the edge comes from (the env step reads lead time and shipment source by column).  Reproduced as is: it is what the
+        # reference computes and what the fixtures pin; `misplaced` lists the (store, column, warehouse) triples it affects.
+        order_row, seen, self.misplaced = [-1] * self.n_edges, [0] * S, []
+        for e, (a, b) in enumerate(internal):
+            s_ = b - Wn
+            order_row[e] = s_ * Wn + seen[s_]
+            if seen[s_] != a:
+                self.misplaced.append((s_, seen[s_], a))
+            seen[s_] += 1
+        for w in range(Wn):
+            order_row[n_int + w] = S * Wn + w
+        self.order_row = i32(order_row)
+        self.max_in = max(seen) if seen else 0
         self.transshipment = bool(transshipment)
 
 
@@ -161,13 +191,19 @@ class GnnRollout:
         ok = ok and all(a["output_layer_activation"][m] == "elu" and a["output_sizes"][m] == 32 for m in MODULES[:-1])
         ok = ok and a["output_layer_activation"]["output"] == "softplus" and a["output_sizes"]["output"] == 1
         if problem_params is not None:
-            ok = ok and problem_params["n_warehouses"] == 1 and problem_params["n_extra_echelons"] == 0
+            ok = ok and problem_params["n_warehouses"] >= 1 and problem_params["n_extra_echelons"] == 0
+            if ok and problem_params["n_warehouses"] > 1:
+                # upstream's action tensor has as many columns as the best-connected store has warehouses; the env step needs
+                # one per warehouse (otherwise the reference itself raises): some store must see every warehouse
+                conn = problem_params.get("warehouse_store_adjacency")
+                ok = conn is not None and max(sum(int(bool(conn[w][s_])) for w in range(len(conn)))
+                                              for s_ in range(problem_params["n_stores"])) == problem_params["n_warehouses"]
         return bool(ok)
 
     def __init__(self, model, problem_params, device):
         _lib.require_device()
         if not self.supports(model, problem_params):
-            raise ValueError("GnnRollout handles the gnn.yml architecture on one-warehouse settings")
+            raise ValueError("GnnRollout handles the gnn.yml architecture on warehouse -> store settings (no extra echelons)")
         self.model, self.problem_params, self.device = model, problem_params, torch.device(device)
         self.timer = None
         # Backward of the MLPs.  None = "hist" while the stored activations fit in HBM, else the history-free kernel.
@@ -187,7 +223,7 @@ class GnnRollout:
 
     # ---- setup --------------------------------------------------------------------------------------------------------------
     def shapes_ok(self, data):
-        return "mean" in data and "std" in data and data["lead_times"].shape[2] == 1
+        return "mean" in data and "std" in data and data["lead_times"].shape[2] == self.problem_params["n_warehouses"]
 
     def _linears(self, name):
         return [m for m in self.model.net[name] if isinstance(m, torch.nn.Linear)]
@@ -200,7 +236,7 @@ class GnnRollout:
             FusedRollout.materialize(type("E", (), {"model": shim})(), k)
 
     def _setup(self, prob, data, T, train):
-        key = (prob.B, T, bool(train), prob.S, prob.Ws, prob.Ww, self.fused_bwd, self.keep_inputs,
+        key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.Ws, prob.Ww, self.fused_bwd, self.keep_inputs,
                data.get("warehouse_edge_costs") is not None)
         if key == self._key:
             return
@@ -208,8 +244,9 @@ class GnnRollout:
         self.mlp = None  # release the previous shapes' buffers before sizing the new ones
         if ld % 32:
             raise ValueError("ldb must be a multiple of 32")
-        lt0 = data["lead_times"][0, :, 0].tolist()  # sample 0's lead times stand for the batch, as upstream (:984)
-        self.plan = GraphPlan(S, getattr(self.model, "transshipment", False), lt0, float(data["warehouse_lead_times"][0, 0]), dev)
+        Wn = prob.Wn
+        conn = self.problem_params.get("warehouse_store_adjacency") if Wn > 1 else [[1] * S]
+        self.plan = GraphPlan(S, conn, getattr(self.model, "transshipment", False), dev)
         P = self.plan
         self.max_inv = max(prob.Ws, prob.Ww)
         self.has_edge_cost = data.get("warehouse_edge_costs") is not None
@@ -218,15 +255,15 @@ class GnnRollout:
         self.materialize(self.Dn)
         z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
         N, E = P.n_nodes, P.n_edges
-        self.F_store, self.F_wh = S * prob.Ws, prob.Ww
+        self.F_store, self.F_wh = S * prob.Ws, Wn * prob.Ww
         f_tot = self.F_store + self.F_wh
         self.states = z(T + 1, f_tot, ld)
-        self.orders = z(T, S + 1, ld)
+        self.orders = z(T, S * Wn + Wn, ld)   # store orders [S][Wn] (columns a store has no edge for stay 0), warehouse orders [Wn]
         self.rewards = z(T, ld)
         self.feat = z(T, self.Dn, N, ld)
-        # state row -> feature row (slot k of store s -> row k of node 1 + s, slot k of the warehouse -> row k of node 0): the
+        # state row -> feature row (slot k of store s -> row k of node Wn + s, slot k of warehouse w -> row k of node w): the
         # pipeline part of the node features is ONE index_copy_ per period
-        rows = [k * N + 1 + s_ for s_ in range(S) for k in range(prob.Ws)] + [k * N for k in range(prob.Ww)]
+        rows = [k * N + Wn + s_ for s_ in range(S) for k in range(prob.Ws)] + [k * N + w for w in range(Wn) for k in range(prob.Ww)]
         self.feat_rows = torch.tensor(rows, dtype=torch.long, device=dev)
         A = _lib
         ks = (self.Dn, 65, 96, 96, 32)
@@ -251,10 +288,10 @@ class GnnRollout:
         self._graphs, self._eager_runs = {}, 0
         self.agg = z(T, 32, 2 * N, ld)   # message aggregation: [:, :N] over incoming edges, [:, N:] over outgoing edges
         self.nodes1, self.edges1 = z(T, 32, N, ld), z(T, 32, E, ld)
-        self.sums, self.ratio, self.scale = z(T, ld), z(T, ld), z(T, ld)
+        self.sums, self.ratio, self.scale = z(T, Wn, ld), z(T, Wn, ld), z(T, Wn, ld)
         if train:
             self.g_state = [z(f_tot, ld), z(f_tot, ld)]
-            self.g_orders = z(S + 1, ld)
+            self.g_orders = z(S * Wn + Wn, ld)
             self.g_reward = z(ld)
             self.d_nodes0, self.d_nodes1 = z(32, N, ld), z(32, N, ld)
             self.d_edges0, self.d_edges1 = z(32, E, ld), z(32, E, ld)
@@ -263,13 +300,13 @@ class GnnRollout:
 
     def _views(self, block, prob):
         store = block[:self.F_store].view(prob.S, prob.Ws, -1)
-        wh = block[self.F_store:].view(1, prob.Ww, -1)
+        wh = block[self.F_store:].view(prob.Wn, prob.Ww, -1)
         return EnvState(store, wh, None)
 
     def _order_tables(self, block, prob):
-        ld = prob.ldb
-        so, wo = block[:prob.S].view(prob.S, 1, -1), block[prob.S:]
-        return Table(so, ld, 1, ld), Table(wo, ld, 1)
+        ld, n = prob.ldb, prob.S * prob.Wn
+        so, wo = block[:n].view(prob.S, prob.Wn, -1), block[n:]
+        return Table(so, prob.Wn * ld, 1, ld), Table(wo, ld, 1)
 
     # ---- one batch ------------------------------------------------------------------------------------------------------------
     def run(self, data, periods, ignore_periods=0, train=True, observation_params=None, demand_soa=None, grad_scale=None,
@@ -294,18 +331,18 @@ class GnnRollout:
             m.pack()
         # per-edge lead-time input rows: sample 0 of THIS batch stands for the batch, as upstream re-reads it every forward
         # (:984) - refreshed on the device (no sync, capturable), so a later batch of the same shape never sees stale values
-        P.lead[0, :S].copy_(data["lead_times"][0, :, 0])
-        P.lead[0, S:S + 1].copy_(data["warehouse_lead_times"][0, :1])
+        P.lead[0, :P.n_int].copy_(data["lead_times"][0][P.lead_store, P.lead_wh])
+        P.lead[0, P.n_int:P.n_int + P.Wn].copy_(data["warehouse_lead_times"][0, :P.Wn])
         s0 = self._views(self.states[0], prob)
         s0.store[:, :, :B].copy_(data["initial_inventories"].permute(1, 2, 0))
         s0.wh[:, :, :B].copy_(data["initial_warehouse_inventories"].permute(1, 2, 0))
-        # static node features (rows max_inv..): warehouse [holding, (edge cost)], stores [holding, underage, mean, std]
-        f, mi = self.feat, self.max_inv
-        f[:, mi, 0, :B] = data["warehouse_holding_costs"][:, 0]
+        # static node features (rows max_inv..): warehouses [holding, (edge cost)], stores [holding, underage, mean, std]
+        f, mi, Wn = self.feat, self.max_inv, P.Wn
+        f[:, mi, :Wn, :B] = data["warehouse_holding_costs"].t()
         if self.has_edge_cost:
-            f[:, mi + 1, 0, :B] = data["warehouse_edge_costs"][:, 0]
+            f[:, mi + 1, :Wn, :B] = data["warehouse_edge_costs"].t()
         for r, k in enumerate(("holding_costs", "underage_costs", "mean", "std")):
-            f[:, mi + r, 1:, :B] = data[k].t()
+            f[:, mi + r, Wn:, :B] = data[k].t()
         if self.use_graph:  # captured launches point at engine-owned buffers: keep the demand trace in one of them
             if getattr(self, "_demand_buf", None) is None or self._demand_buf.shape != demand_soa.shape:
                 self._demand_buf, self._graphs, self._eager_runs = torch.empty_like(demand_soa), {}, 0
@@ -420,8 +457,12 @@ class GnnRollout:
         out = M["output"].Y[t][0]                                  # [E][ld] desired quantity per edge
         # proportional allocation of the warehouse's on-hand stock over its outgoing edges + self loop (:111-138, :1435-1492)
         orders = self.orders[t]
-        ops.gnn_alloc_fwd(out, st.wh[0, 0], orders, self.sums[t], self.ratio[t], self.scale[t], S, P.e_self, P.e_supplier,
-                          not P.transshipment, B)
+        if P.Wn == 1:
+            ops.gnn_alloc_fwd(out, st.wh[0, 0], orders, self.sums[t], self.ratio[t], self.scale[t], S, P.e_self, P.e_supplier,
+                              not P.transshipment, B)
+        else:   # one lane per (scenario, warehouse); every warehouse's stock over its own edges + self loop
+            ops.gnn_alloc_groups_fwd(out, st.wh, orders, self.sums[t], self.ratio[t], self.scale[t], P.groups, P.order_row,
+                                     not P.transshipment, B)
         ts, tw = self._order_tables(orders, prob)
         self._k("env_fwd", ops.env_step_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
                 out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
@@ -430,13 +471,17 @@ class GnnRollout:
         P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
         st = self._views(self.states[t], prob)
         ts, tw = self._order_tables(self.orders[t], prob)
-        g_so, g_wo = self.g_orders[:S].view(S, 1, -1), self.g_orders[S:]
+        g_so, g_wo = self.g_orders[:S * P.Wn].view(S, P.Wn, -1), self.g_orders[S * P.Wn:]
         gc = self._views(g_cur, prob)
         self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
                 self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=gc, g_orders=(g_so, g_wo, None))
         # allocation adjoint: alloc_e = out_e * min(1, on_hand / (sum + eps)) for the members, supplier edge passes through
-        ops.gnn_alloc_bwd(M["output"].Y[t][0], st.wh[0, 0], self.g_orders, self.sums[t], self.ratio[t], self.scale[t],
-                          self.d_out[0], gc.wh[0, 0], S, P.e_self, P.e_supplier, not P.transshipment, B)
+        if P.Wn == 1:
+            ops.gnn_alloc_bwd(M["output"].Y[t][0], st.wh[0, 0], self.g_orders, self.sums[t], self.ratio[t], self.scale[t],
+                              self.d_out[0], gc.wh[0, 0], S, P.e_self, P.e_supplier, not P.transshipment, B)
+        else:
+            ops.gnn_alloc_groups_bwd(M["output"].Y[t][0], st.wh, self.g_orders, self.sums[t], self.ratio[t], self.scale[t],
+                                     self.d_out[0], gc.wh, P.groups, P.order_row, P.e_demand, S, not P.transshipment, B)
         segs = self._segments(t)
         # output MLP -> edges1
         m = M["output"]
@@ -460,8 +505,8 @@ class GnnRollout:
         # nodes0 = initial_node(features): the pipeline rows of the features are the state
         m = M["initial_node"]
         self._mlp_bwd(m, t, segs, prob, self.d_nodes0)
-        gc.wh[0] += m.dX[:prob.Ww, 0]
-        gc.store += m.dX[:prob.Ws, 1:].permute(1, 0, 2)
+        gc.wh += m.dX[:prob.Ww, :P.Wn].permute(1, 0, 2)
+        gc.store += m.dX[:prob.Ws, P.Wn:].permute(1, 0, 2)
 
     def _mlp_bwd(self, m, t, segs, prob, dY, dX=None):
         if m.mode == "hist":

@@ -296,6 +296,24 @@ def gnn_alloc_bwd(out, on_hand, g_orders, sums, ratio, scale, d_out, g_on_hand, 
                                   n_scenarios, out.stride(0), current_stream()))
 
 
+def gnn_alloc_groups_fwd(out, on_hand, orders, sums, ratio, scale, groups, order_row, cap_at_one, n_scenarios):
+    """Proportional allocation of several warehouses' stock, one launch (nic_gnn_alloc_groups_fwd).  on_hand [G][Ww][ldb]:
+    slot 0 of every group's pipeline; sums / ratio / scale [G][ldb]."""
+    _dev(out)
+    check(lib().nic_gnn_alloc_groups_fwd(ptr(out), ptr(on_hand), on_hand.stride(0), ptr(orders), ptr(sums), ptr(ratio), ptr(scale),
+                                         ptr(groups), ptr(order_row), groups.shape[0], int(cap_at_one), n_scenarios, out.stride(0),
+                                         current_stream()))
+
+
+def gnn_alloc_groups_bwd(out, on_hand, g_orders, sums, ratio, scale, d_out, g_on_hand, groups, order_row, zero_first, zero_count,
+                         cap_at_one, n_scenarios):
+    _dev(out)
+    assert g_on_hand.stride(0) == on_hand.stride(0)
+    check(lib().nic_gnn_alloc_groups_bwd(ptr(out), ptr(on_hand), on_hand.stride(0), ptr(g_orders), ptr(sums), ptr(ratio), ptr(scale),
+                                         ptr(d_out), ptr(g_on_hand), ptr(groups), ptr(order_row), groups.shape[0], zero_first,
+                                         zero_count, int(cap_at_one), n_scenarios, out.stride(0), current_stream()))
+
+
 def segment_sum(dst, src, offsets, items, dst_scale=None, accumulate=False):
     """dst [R][n_dst][ldb] (+)= dst_scale[n] * sum over items[offsets[n]:offsets[n+1]] of src[R][.][ldb] rows."""
     _dev(dst)

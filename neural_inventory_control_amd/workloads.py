@@ -92,6 +92,17 @@ def many_warehouses(n_stores=64, n_warehouses=3, seed=0):
     return s_
 
 
+def many_warehouses_dense(n_stores=16, n_warehouses=3, seed=0):
+    """A many-warehouse graph the reference's GNN handles consistently (its action columns are "j-th connected warehouse",
+    neural_networks.py:1423-1428: only with every store connected to every warehouse is column j warehouse j)."""
+    import random
+    rnd = random.Random(seed)
+    s_ = many_warehouses(n_stores, n_warehouses, seed)
+    s_["problem_params"]["warehouse_store_adjacency"] = [[1] * n_stores for _ in range(n_warehouses)]
+    s_["store_params"]["lead_time"] = _const([[rnd.randint(1, 6) for _ in range(n_warehouses)] for _ in range(n_stores)])
+    return s_
+
+
 def _closed_form(name, n_out, out_act="softplus", bias=10.0):
     """base_stock.yml / capped_base_stock.yml (softplus output, initial bias 10) and echelon_stock.yml (neither)."""
     return {"name": name, "inner_layer_activations": {"master": None}, "output_layer_activation": {"master": out_act},
@@ -212,6 +223,9 @@ WORKLOADS = {
     # the GNN policy on cfg3's graph (fused gather-MLP kernels over the static supply graph, gnn_rollout.py)
     "gnn": (lambda: one_warehouse(16), gnn_policy(), 8192, 50,
             "one_warehouse_lost_demand, 16 stores, 8192 scenarios x T=50, gnn (5 x 32-wide MLPs, 1 message-passing step)"),
+    # the same engine on a many-warehouse graph (round 3): 3 warehouses x 16 stores, all connected: 19 nodes, 70 edges
+    "gnn_many_warehouses": (lambda: many_warehouses_dense(16, 3), gnn_policy(), 8192, 50,
+                            "many_warehouses_lost_demand shape, 3 warehouses x 16 stores (dense), 8192 scenarios x T=50, gnn"),
 }
 
 

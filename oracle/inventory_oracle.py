@@ -216,7 +216,7 @@ def split_data_by_period(data, period_ranges, observation_params, problem_params
 # --------------------------------------------------------------------------------------
 
 
-def shift_pipeline_and_place(pipeline, on_hand_after, orders, lead_times):
+def shift_pipeline_and_place(pipeline, on_hand_after, orders, lead_times, zero_lead_orders="upstream"):
     """environment.py:391-434.
 
     new[0] = on_hand_after + old[1]; new[k] = old[k+1]; new[W-1] = 0 (:405-412); then every order
@@ -224,7 +224,17 @@ def shift_pipeline_and_place(pipeline, on_hand_after, orders, lead_times):
     flattened (b, location, supplier) order like `Tensor.put(accumulate=True)` on CPU.  Orders
     that are exactly 0 are filtered out BEFORE the put (:426-429) so they carry no gradient on
     this path; if every order is 0 the put is skipped (:427).
+
+    UPSTREAM DEFECT, reproduced on purpose (`zero_lead_orders="upstream"`, what the fixtures pin): a non-zero order whose lead
+    time is 0 gets flat position base - 1, i.e. it is added to the element BEFORE its location's pipeline - the last slot of the
+    previous location, for location 0 the previous SCENARIO's last location, for scenario 0 the last element of the whole
+    batch (`put` takes index -1).  The reference's own policies never order on a (store, warehouse) pair without an edge
+    (lead time 0), except the GNN on a many-warehouse graph, whose action columns are "j-th connected warehouse" rather than
+    warehouse j (neural_networks.py:1423-1428; `gnn_graph`'s `misplaced`).  `zero_lead_orders="drop"` discards such orders
+    instead - what the HIP env step does (an order without a lead time has no slot to arrive in, and scenarios stay
+    independent); tests compare the HIP path with this mode on the one fixture where the two differ.
     """
+    assert zero_lead_orders in ("upstream", "drop")
     B, N, W = pipeline.shape
     cols = [on_hand_after + pipeline[:, :, 1]]
     cols += [pipeline[:, :, k + 1] for k in range(1, W - 1)]
@@ -236,6 +246,8 @@ def shift_pipeline_and_place(pipeline, on_hand_after, orders, lead_times):
     flat_pos = (base.unsqueeze(2).expand(-1, -1, n_sup) + lead_times.long() - 1).flatten()
     vals = orders.flatten()
     keep = vals != 0
+    if zero_lead_orders == "drop":
+        keep = keep & (lead_times.long().expand(B, N, n_sup).flatten() >= 1)
     if keep.any():
         fresh = fresh.put(flat_pos[keep], vals[keep].to(fresh.dtype), accumulate=True)
     return fresh
@@ -252,6 +264,7 @@ class OracleEnv:
     t: int = 0
     observation_params: Optional[dict] = None
     data: Optional[dict] = None
+    zero_lead_orders: str = "upstream"   # see shift_pipeline_and_place
 
 
 def env_reset(periods, problem_params, data, observation_params) -> OracleEnv:
@@ -334,7 +347,7 @@ def env_step(env: OracleEnv, action: Dict[str, torch.Tensor]) -> torch.Tensor:
         cost = p * torch.clip(-after, min=0) + h * torch.clip(after, min=0)  # :198-201
     if prob["lost_demand"]:
         after = torch.clip(after, min=0)  # :204-205
-    obs["store_inventories"] = shift_pipeline_and_place(inv, after, action["stores"], obs["lead_times"])
+    obs["store_inventories"] = shift_pipeline_and_place(inv, after, action["stores"], obs["lead_times"], env.zero_lead_orders)
     total = cost.sum(dim=1)
 
     # --- warehouses (:236-270)
@@ -824,8 +837,15 @@ def gnn_graph(problem_params, obs, transshipment):
                    "echelons": [[n_int]] + [[i - 1] for i in range(1, E)]}
     else:
         stores = [[] for _ in range(S)]
+        misplaced = []  # (store, action column, warehouse the edge comes from) wherever the two differ - see below
         for i, (a, b) in enumerate(internal):
-            stores[b - Wn].append(i)  # the j-th CONNECTED edge of a store becomes its column j (:1423-1428)
+            # UPSTREAM DEFECT, reproduced: the j-th CONNECTED edge of a store becomes its action column j (:1423-1428), but the
+            # env step reads column j as "ordered from warehouse j" (lead time, shipment source).  For a store that is not
+            # connected to every warehouse the order is therefore booked on the wrong warehouse - with lead time 0 when that
+            # pair has no edge, which shift_pipeline_and_place then misplaces as well.
+            if len(stores[b - Wn]) != a:
+                misplaced.append((b - Wn, len(stores[b - Wn]), a))
+            stores[b - Wn].append(i)
         mapping = {"stores": stores, "warehouses": [[n_int + w] for w in range(Wn)]}
     # degrees used for the normalisation (:1275-1296)
     for n in suppliers:
@@ -836,7 +856,7 @@ def gnn_graph(problem_params, obs, transshipment):
         in_deg[n] += 1
         out_deg[n] += 1
     return dict(n_nodes=n_nodes, internal=internal, lead=lead, suppliers=suppliers, supplier_lead=supplier_lead,
-                demand_nodes=demand_nodes, supplying=supplying, mapping=mapping,
+                demand_nodes=demand_nodes, supplying=supplying, mapping=mapping, misplaced=misplaced if E == 0 else [],
                 in_deg=[d if d > 0 else 1 for d in in_deg], out_deg=[d if d > 0 else 1 for d in out_deg],
                 num_message_passing=(E + 1) if E > 0 else 1)
 
@@ -954,10 +974,12 @@ def gnn_act(pol: OracleGNNPolicy, obs):
 
 
 def rollout(pol: OraclePolicy, periods, problem_params, data, observation_params,
-            ignore_periods=0, discrete_allocation=False, keep_states=False, probe=None) -> RolloutResult:
+            ignore_periods=0, discrete_allocation=False, keep_states=False, probe=None, zero_lead_orders="upstream") -> RolloutResult:
     """trainer.py:181-216.  PolicyLoss = reward.sum() (loss_functions.py:11-12).  probe: optional list that receives the
-    quantile policies' (level, level - position) per period (see policy_act)."""
+    quantile policies' (level, level - position) per period (see policy_act).  zero_lead_orders: see
+    shift_pipeline_and_place ("upstream" = the reference bit for bit)."""
     env = env_reset(periods, problem_params, dict(data), observation_params)
+    env.zero_lead_orders = zero_lead_orders
     total, reported = 0, 0
     per_period = []
     states = []
@@ -986,12 +1008,13 @@ def rollout(pol: OraclePolicy, periods, problem_params, data, observation_params
     return res
 
 
-def train_step_gradients(pol: OraclePolicy, periods, problem_params, data, observation_params, ignore_periods=0):
+def train_step_gradients(pol: OraclePolicy, periods, problem_params, data, observation_params, ignore_periods=0,
+                         zero_lead_orders="upstream", keep_states=False):
     """Forward + backward of one batch exactly as trainer.py:160-173 (mean over B*T*S, then backward).
     Returns (rollout result, mean_loss value, list of grads aligned with pol.parameters())."""
     for p in pol.parameters():
         p.grad = None
-    res = rollout(pol, periods, problem_params, data, observation_params, ignore_periods)
+    res = rollout(pol, periods, problem_params, data, observation_params, ignore_periods, zero_lead_orders=zero_lead_orders)
     B = len(data["demands"])
     mean_loss = res.total / (B * periods * problem_params["n_stores"])
     mean_loss.backward()

@@ -84,6 +84,26 @@ CASES = {
     # gnn_transshipment.yml (GNN with transshipment: True - no self loop at the warehouse, allocation ratio not capped at 1)
     "f1_one_warehouse_gnn_transshipment": dict(
         setting="one_warehouse_lost_demand", policy="gnn_transshipment", n=12, periods=6, ignore=2, torch_seed=42),
+    # the GNN on the many-warehouse graph.  Upstream writes store s's j-th incoming edge into action column j (not into the
+    # column of the warehouse the edge comes from, neural_networks.py:1423-1428) and only runs when some store is connected to
+    # every warehouse (otherwise the action tensor is narrower than the lead-time matrix and the env step raises): the shipped
+    # 2 x 10 adjacency has stores with one warehouse (0, 1, 5, 9 -> warehouse 1 only: their order lands in warehouse 0's column,
+    # whose lead time is 0, and the env step's flat-index put (environment.py:422-432) then adds it to the element BEFORE the
+    # store's pipeline - the last slot of the previous store, for store 0 of the previous SCENARIO).  This fixture pins that
+    # upstream behaviour for the oracle; the HIP path drops such orders instead
+    "f1_many_warehouses_2x10_gnn": dict(
+        setting="many_warehouses_lost_demand", policy="gnn", n=10, periods=14, ignore=4, torch_seed=51),
+    # ... and a graph upstream handles consistently: 3 warehouses x 8 stores, every store connected to every warehouse (column j
+    # IS warehouse j, no order ever meets a lead time of 0), heterogeneous lead times, edge costs in the warehouse features
+    "f1_many_warehouses_3x8_dense_gnn": dict(
+        setting="many_warehouses_lost_demand", policy="gnn", n=8, periods=14, ignore=4, torch_seed=52,
+        problem_overrides={
+            "n_stores": 8, "n_warehouses": 3,
+            "warehouse_store_adjacency": [[1] * 8, [1] * 8, [1] * 8]},
+        store_overrides={"lead_time": {"sample_across_stores": False, "vary_across_samples": False, "expand": True,
+                                       "value": [[2, 5, 3], [1, 4, 2], [3, 2, 6], [4, 6, 1],
+                                                 [3, 1, 1], [2, 3, 2], [5, 2, 1], [4, 1, 3]]}},
+        warehouse_overrides={"holding_cost": [0.3, 0.4, 0.2], "lead_time": 3, "edge_cost": [0.5, 1.5, 0.7]}),
     # the real-data path.  Favorita weekly sales (288 products x 21 stores x 171 weeks, shipped with the reference),
     # 3 warehouses, profit objective, past-demand window (16) + days-from-christmas in the observation, period_shift 16,
     # datasets split BY PERIOD; data_driven_net = MLP over all features + proportional allocation of warehouse stock

@@ -58,6 +58,14 @@ class Golden:
         return c
 
 
+# Fixtures on which upstream's env step misplaces orders ACROSS scenarios: a non-zero order on a (store, warehouse) pair whose lead
+# time is 0 is added to the element in front of the store's pipeline (environment.py:422-432).  Only the GNN's "j-th connected
+# warehouse" action columns (neural_networks.py:1423-1428) produce such orders.  The golden file pins that behaviour for the oracle
+# (tests/test_oracle_golden.py); the HIP env step drops such orders, so kernel / engine tests take their expected numbers for
+# these cases from the oracle's `zero_lead_orders="drop"` mode.
+ZERO_LEAD_CASES = {"f1_many_warehouses_2x10_gnn"}
+
+
 def case_names():
     from cases import CASES
     return list(CASES.keys())

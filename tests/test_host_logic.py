@@ -82,7 +82,9 @@ def test_policy_factory_and_state_dict_layout():
     assert float(model.warehouse_upper_bound) == float(g.z["warehouse_upper_bound"][0])
     assert FusedRollout.supports(model)
     with pytest.raises(KeyError):
-        NeuralNetworkCreator().get_architecture("symmetry_aware")  # not registered upstream either
+        NeuralNetworkCreator().get_architecture("no_such_policy")   # unknown names raise KeyError as upstream (:1519-1536)
+    # ("symmetry_aware" is not registered upstream - SURVEY facts; here it names this repository's recovered policy, round 3)
+    assert NeuralNetworkCreator().get_architecture("symmetry_aware").__name__ == "SymmetryAware"
     # materialise like the engine does and load the reference's weights by key
     eng = FusedRollout.__new__(FusedRollout)
     eng.model = model
@@ -146,6 +148,55 @@ def test_main_run_cli_surface():
     with pytest.raises(FileNotFoundError):
         main_run.main(["train", "no_such_setting", "no_such_policy", "--config-dir", "/nonexistent"])
     assert main_run.SETTING_KEYS[0] == "seeds" and "nn_params" in main_run.HYPERPARAM_KEYS
+
+
+@pytest.mark.parametrize("name", ["f1_one_warehouse_gnn", "f1_one_warehouse_gnn_transshipment", "f1_many_warehouses_2x10_gnn",
+                                  "f1_many_warehouses_3x8_dense_gnn"])
+def test_gnn_engine_graph_plan_equals_the_oracles_graph(name):
+    """`GraphPlan` (the GNN engine's compiled supply graph) against the oracle's restatement of neural_networks.py:757-1062 on
+    the fixtures' settings: edge list and order, degrees behind the 1/sqrt normalisation, allocation groups, and the
+    edge -> action-column mapping - including upstream's "j-th connected warehouse" columns (:1423-1428), which the
+    many-warehouse fixtures exercise (stores that see one warehouse of two)."""
+    import oracle.inventory_oracle as orc
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout, GraphPlan
+    g = Golden(name)
+    c = g.fresh_config()
+    prob = c["problem_params"]
+    S, Wn = prob["n_stores"], prob["n_warehouses"]
+    trans = bool(c["nn_params"].get("transshipment", False))
+    obs = {"lead_times": g.data["lead_times"], "warehouse_lead_times": g.data["warehouse_lead_times"]}
+    og = orc.gnn_graph(prob, obs, trans)
+    conn = prob["warehouse_store_adjacency"] if Wn > 1 else [[1] * S]
+    P = GraphPlan(S, conn, trans, "cpu")
+    n_int = len(og["internal"])
+    assert P.n_int == n_int and P.n_nodes == og["n_nodes"]
+    assert P.src[:n_int].tolist() == [a for a, _ in og["internal"]] and P.tgt[:n_int].tolist() == [b for _, b in og["internal"]]
+    assert P.n_self == len(og["supplying"]) and P.n_edges == n_int + Wn + S + len(og["supplying"])
+    torch.testing.assert_close(P.in_scale, torch.tensor([1.0 / d ** 0.5 for d in og["in_deg"]]))
+    torch.testing.assert_close(P.out_scale, torch.tensor([1.0 / d ** 0.5 for d in og["out_deg"]]))
+    # action columns: row s * Wn + j of the orders buffer <-> mapping["stores"][s][j]; warehouse orders <-> supplier edges
+    rows = P.order_row.tolist()
+    for s_, edges in enumerate(og["mapping"]["stores"]):
+        for j, e in enumerate(edges):
+            assert rows[e] == s_ * Wn + j
+    for w, (e,) in enumerate(og["mapping"]["warehouses"]):
+        assert rows[e] == S * Wn + w
+    assert all(r == -1 for r in rows[n_int + Wn:])
+    # allocation groups = every supplying node's outgoing internal edges + its self loop
+    for w, (first, count, e_self, e_sup) in enumerate(P.groups.tolist()):
+        assert list(range(first, first + count)) == [i for i, (a, _) in enumerate(og["internal"]) if a == w]
+        assert e_sup == n_int + w
+        assert e_self == (n_int + Wn + S + og["supplying"].index(w) if w in og["supplying"] else -1)
+    # upstream's column quirk is present exactly where a store's j-th connected warehouse is not warehouse j
+    expect = [(b - Wn, j, a) for s_ in range(S)
+              for j, (a, b) in enumerate([(a, b) for (a, b) in og["internal"] if b - Wn == s_]) if j != a]
+    assert sorted(P.misplaced) == sorted(expect) == sorted(og["misplaced"])
+    if name == "f1_many_warehouses_2x10_gnn":
+        assert [m[0] for m in P.misplaced] == [0, 1, 5, 9]      # the stores served by warehouse 1 only
+    model_ok = type("GNN", (), {"nn_args": c["nn_params"]})()
+    assert GnnRollout.supports(model_ok, prob)
+    narrow = dict(prob, n_warehouses=2, n_stores=2, warehouse_store_adjacency=[[1, 0], [0, 1]])
+    assert not GnnRollout.supports(model_ok, narrow)            # no store sees both warehouses: upstream itself raises there
 
 
 def test_factory_builds_gnn_policy_with_reference_state_dict_keys():

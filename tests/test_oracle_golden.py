@@ -164,3 +164,49 @@ def test_zero_order_has_no_placement_gradient():
     new = orc.shift_pipeline_and_place(pipe, torch.zeros(2, 1), orders, lead)
     new.sum().backward()
     assert orders.grad.flatten().tolist() == [0.0, 1.0]
+
+
+def test_zero_lead_orders_upstream_leak_and_the_drop_mode():
+    """environment.py:422-432 with a lead time of 0: the flat position is base - 1, so upstream adds the order to the last slot of
+    the PREVIOUS location - across scenarios for location 0, wrapping to the end of the batch for scenario 0.  The oracle
+    reproduces that by default and discards such orders in its "drop" mode (what the HIP env step does)."""
+    pipe = torch.zeros(2, 2, 3)
+    orders = torch.tensor([[[5.0], [0.0]], [[7.0], [2.0]]])
+    lead = torch.tensor([[[0.0], [2.0]], [[0.0], [2.0]]])
+    up = orc.shift_pipeline_and_place(pipe, torch.zeros(2, 2), orders, lead)
+    # scenario 0 / store 0's order of 5 wraps to the very last element; scenario 1 / store 0's 7 lands in scenario 0 / store 1
+    assert up.tolist() == [[[0, 0, 0], [0, 0, 7]], [[0, 0, 0], [0, 2, 5]]]
+    drop = orc.shift_pipeline_and_place(pipe, torch.zeros(2, 2), orders, lead, zero_lead_orders="drop")
+    assert drop.tolist() == [[[0, 0, 0], [0, 0, 0]], [[0, 0, 0], [0, 2, 0]]]
+
+
+def test_many_warehouse_gnn_fixture_pins_the_upstream_column_defect():
+    """neural_networks.py:1423-1428 writes store s's j-th CONNECTED edge into action column j; on the shipped 2 x 10 adjacency
+    stores 0, 1, 5, 9 (warehouse 1 only) therefore order in warehouse 0's column, where their lead time is 0, and the env step
+    leaks those orders into the neighbouring store / scenario.  Upstream mode = the fixture bit for bit (test above, all
+    cases): changing scenario 5's initial stock changes scenario 4's cost.  In drop mode the scenarios are independent."""
+    g = Golden("f1_many_warehouses_2x10_gnn")
+    c = g.fresh_config()
+    og = orc.gnn_graph(c["problem_params"], {"lead_times": g.data["lead_times"], "warehouse_lead_times": g.data["warehouse_lead_times"]},
+                       False)
+    assert [m[0] for m in og["misplaced"]] == [0, 1, 5, 9]
+    assert all(float(g.data["lead_times"][0, s_, col]) == 0.0 for s_, col, _ in og["misplaced"])
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"], g.tensor("warehouse_upper_bound"))
+
+    def costs(data, mode):
+        with torch.no_grad():
+            return orc.rollout(pol, c["periods"], c["problem_params"], data, c["observation_params"], c["ignore"],
+                               zero_lead_orders=mode).per_period.sum(dim=0)
+    # starve scenario 5 (its stores order more): upstream books part of that on scenario 4's last store, drop mode does not
+    poked = dict(g.data)
+    poked["initial_inventories"] = g.data["initial_inventories"].clone()
+    poked["initial_inventories"][5] = 0.0
+    others = [b_ for b_ in range(c["n"]) if b_ != 5]
+    assert torch.equal(costs(g.data, "drop")[others], costs(poked, "drop")[others])
+    up, up_poked = costs(g.data, "upstream"), costs(poked, "upstream")
+    assert float(up[4]) != float(up_poked[4]) and torch.equal(up[:4], up_poked[:4]) and torch.equal(up[6:], up_poked[6:])
+    assert abs(float(costs(g.data, "drop").sum()) - float(g.z["total"])) > 1e-2 * float(g.z["total"])
+    dense = Golden("f1_many_warehouses_3x8_dense_gnn")
+    cd = dense.fresh_config()
+    assert orc.gnn_graph(cd["problem_params"], {"lead_times": dense.data["lead_times"],
+                                                "warehouse_lead_times": dense.data["warehouse_lead_times"]}, False)["misplaced"] == []

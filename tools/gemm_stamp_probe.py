@@ -72,7 +72,7 @@ def main():
     for tune in tunes:
         os.environ["NIC_GEMM_TUNE"] = str(tune)
         pads = [int(v) for v in os.environ.get("PROBE_PADS", "0").split(",")]
-        for B, pad in [(b_, p_) for b_ in ((65536, 32768, 98304) if tune == 0 and len(pads) == 1 else (65536,)) for p_ in pads]:
+        for B, pad in [(b_, p_) for b_ in ((65536, 32768, 98304) if tune == 0 and len(pads) == 1 and not os.environ.get('PROBE_ONE_SIZE') else (65536,)) for p_ in pads]:
             ldb = pad_ld(B) + pad
             W = torch.randn(N, K, device=dev) * 0.05
             Wt = W.t().contiguous()
@@ -89,7 +89,7 @@ def main():
                 r = run_case(lib, name, fn, n_wg, K, stamps)
                 r["tflops"] = round(2.0 * N * K * B / (r["event_us"] * 1e-6) / 1e12, 1)
                 out[f"{name}_{B}_pad{pad}_tune{tune}"] = r
-                print(f"{name}_{B}_pad{pad}_tune{tune}", "event", r["event_us"], "tflops", r["tflops"], "| kloop", r["phases"]["k_loop"], "| epi",
+                print(f"{name}_{B}_pad{pad}_tune{tune}", "event", r["event_us"], "tflops", r["tflops"], "| pro", r["phases"]["prologue"]["us_mean"], "| kloop", r["phases"]["k_loop"], "| epi",
                       r["phases"]["epilogue"]["us_mean"], "|", r["rounds"], flush=True)
     if os.environ.get("PROBE_JSON"):
         print(json.dumps(out, indent=1))
