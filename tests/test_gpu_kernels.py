@@ -669,6 +669,69 @@ def test_segment_sum_terms_equals_the_chain_of_launches():
     assert torch.equal(got, first)
 
 
+@pytest.mark.parametrize("cap,self_loops", [(True, True), (False, False)])
+def test_gnn_group_allocation_matches_torch_autograd(cap, self_loops):
+    """nic_gnn_alloc_groups_fwd / bwd (several warehouses, one launch) against the tensor-op formulation
+    (neural_networks.py:111-138 per supplying node, :1435-1492): three warehouses of 4 / 0 / 3 internal edges (the middle one
+    supplies nobody: its own order passes through, nothing else), orders scattered through an edge -> row map, float64 autograd
+    for the gradients w.r.t. the desired quantities and the warehouses' on-hand stock; the demand-edge rows of d_out are cleared."""
+    dev, B, Ww = "cuda", 333, 3
+    ld = pad_ld(B, 32)
+    gen = torch.Generator().manual_seed(5)
+    counts, n_dem = [4, 0, 3], 5
+    n_int, G = sum(counts), len(counts)
+    e_dem = n_int + G
+    selfs = [e_dem + n_dem + i if (self_loops and c_) else -1 for i, c_ in enumerate(counts)]
+    E = e_dem + n_dem + G
+    firsts = [0, 4, 4]
+    groups = torch.tensor([[firsts[g_], counts[g_], selfs[g_], n_int + g_] for g_ in range(G)], dtype=torch.int32, device=dev)
+    perm = torch.randperm(n_int + G, generator=gen).tolist()            # any injective edge -> order-row map
+    order_row = torch.full((E,), -1, dtype=torch.int32)
+    for e in range(n_int + G):
+        order_row[e] = perm[e]
+    n_rows = n_int + G
+    out = torch.zeros(E, ld)
+    out[:, :B] = torch.rand(E, B, generator=gen) * 3 + 0.01
+    on_hand = torch.zeros(G, Ww, ld)
+    on_hand[:, 0, :B] = torch.rand(G, B, generator=gen) * 9
+    g_orders = torch.zeros(n_rows, ld)
+    g_orders[:, :B] = torch.randn(n_rows, B, generator=gen)
+    o64, h64 = out[:, :B].double().requires_grad_(True), on_hand[:, 0, :B].double().requires_grad_(True)
+    want = [None] * n_rows
+    for g_ in range(G):
+        want[perm[n_int + g_]] = o64[n_int + g_]
+        members = list(range(firsts[g_], firsts[g_] + counts[g_]))
+        if not members:
+            continue
+        ratio = h64[g_] / (o64[members + ([selfs[g_]] if selfs[g_] >= 0 else [])].sum(dim=0) + 1e-10)
+        sc = torch.clamp(ratio, max=1.0) if cap else ratio
+        for e in members:
+            want[perm[e]] = o64[e] * sc
+    want = torch.stack(want)
+    (want * g_orders[:, :B].double()).sum().backward()
+    z = lambda *sh: torch.zeros(*sh, device=dev)  # noqa: E731
+    orders, sums, rat, scale = z(n_rows, ld), z(G, ld), z(G, ld), z(G, ld)
+    oh_d = on_hand.to(dev)
+    ops.gnn_alloc_groups_fwd(out.to(dev), oh_d, orders, sums, rat, scale, groups, order_row.to(dev), cap, B)
+    torch.testing.assert_close(orders[:, :B].cpu().double(), want.detach(), rtol=2e-6, atol=1e-6)
+    assert float(orders[:, B:].abs().max()) == 0.0
+    d_out, g_on = torch.full((E, ld), 9.0, device=dev), torch.full((G, Ww, ld), 0.25, device=dev)
+    ops.gnn_alloc_groups_bwd(out.to(dev), oh_d, g_orders.to(dev), sums, rat, scale, d_out, g_on, groups, order_row.to(dev),
+                             e_dem, n_dem, cap, B)
+    torch.cuda.synchronize()
+    ref = o64.grad.clone()
+    got = d_out[:, :B].cpu().double()
+    rows_written = [e for e in range(E) if e < e_dem + n_dem or e in selfs]
+    torch.testing.assert_close(got[rows_written], ref[rows_written], rtol=2e-5, atol=2e-5)
+    untouched = [e for e in range(E) if e not in rows_written]
+    if untouched:   # (self-loop rows that do not exist in this configuration are nobody's to write)
+        assert float(got[untouched].sub(9.0).abs().max()) == 0.0
+    supplying = [g_ for g_ in range(G) if counts[g_]]
+    torch.testing.assert_close(g_on[supplying, 0, :B].cpu().double() - 0.25, h64.grad[supplying], rtol=2e-5, atol=2e-5)
+    assert float(g_on[1, 0, :B].sub(0.25).abs().max()) == 0.0 and float(g_on[:, 1:].sub(0.25).abs().max()) == 0.0
+    assert float(d_out[:, B:].sub(9.0).abs().max()) == 0.0   # padding columns untouched
+
+
 @pytest.mark.parametrize("S,e_self,cap", [(16, 33, True), (3, None, False), (5, 11, False)])
 def test_gnn_allocation_head_matches_torch_autograd(S, e_self, cap):
     """nic_gnn_alloc_fwd / bwd against the tensor-op formulation it replaced (neural_networks.py:111-138): orders, and through

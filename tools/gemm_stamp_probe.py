@@ -4,7 +4,8 @@ and at exit, per workgroup), runs the forward / dgrad kernels at BASELINE cfg3's
 and the s_memtime rate.  PROBE_TUNES=0,1,2,3,4,7 additionally runs timing-only variants of the k loop (results invalid):
 1 = no A-tile copies inside the loop, 2 = no B-tile copies, 4 = no barrier per k tile; 32 = s_setprio 1 for the younger half of
 the workgroup (valid results); 8 = dgrad without the Hprev prefetch (valid), 16 = the k-loop stamp moved behind the plain tiles
-(the phase then covers the four prefetch tiles of dgrad / nothing in the forward kernel).  PROBE_PADS=0,64,... adds floats to the scenario stride of every operand.  The product library has no such instrumentation."""
+(the phase then covers the four prefetch tiles of dgrad / nothing in the forward kernel).  PROBE_PADS=0,64,... adds floats to the scenario stride of every operand; PROBE_SIZES=256,2048,... sets the scenario counts
+(256 = one workgroup column: what prologue / epilogue cost when no other CU is bursting).  The product library has no such instrumentation."""
 import ctypes
 import json
 import os
@@ -72,7 +73,9 @@ def main():
     for tune in tunes:
         os.environ["NIC_GEMM_TUNE"] = str(tune)
         pads = [int(v) for v in os.environ.get("PROBE_PADS", "0").split(",")]
-        for B, pad in [(b_, p_) for b_ in ((65536, 32768, 98304) if tune == 0 and len(pads) == 1 and not os.environ.get('PROBE_ONE_SIZE') else (65536,)) for p_ in pads]:
+        sizes = tuple(int(v) for v in os.environ["PROBE_SIZES"].split(",")) if os.environ.get("PROBE_SIZES") else \
+            ((65536, 32768, 98304) if tune == 0 and len(pads) == 1 and not os.environ.get('PROBE_ONE_SIZE') else (65536,))
+        for B, pad in [(b_, p_) for b_ in sizes for p_ in pads]:
             ldb = pad_ld(B) + pad
             W = torch.randn(N, K, device=dev) * 0.05
             Wt = W.t().contiguous()

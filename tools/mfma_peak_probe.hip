@@ -139,5 +139,16 @@ int main(int argc, char** argv) {
     // a short launch of the production kernels' length (2 x 2,048 MFMAs per wave at two waves per SIMD = ~240 us): does the clock
     // the part holds over 0.25 ms differ from the one it holds over 10 ms?
     run<8, 0>("register-only, production launch length", 2, 512, n_cu);
+    // how the per-CU rate depends on how many CUs are issuing MFMAs (one workgroup per CU; `cus_active` in the variant name):
+    // the production kernels run their k loop 1.8x faster per tile when only a few tiles are in flight (gemm_stamp_probe.py,
+    // PROBE_SIZES=256) - is that the matrix pipe itself, i.e. is the chip-wide peak a power / clock limit rather than the pipe's?
+    for (int cus : {1, 2, 8, 32, 64, 128, 192, 256}) {
+        if (cus > n_cu) break;
+        char name[96];
+        snprintf(name, sizeof name, "register-only, cus_active=%d", cus);
+        run<8, 0>(name, 2, iters / 8, cus);
+        snprintf(name, sizeof name, "register-only, one wave per SIMD, cus_active=%d", cus);
+        run<8, 0>(name, 1, iters / 4, cus);
+    }
     return 0;
 }
