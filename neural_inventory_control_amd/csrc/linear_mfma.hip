@@ -71,7 +71,9 @@ struct WxParams {
     int act;             // NIC_ACT_*
     int accumulate;      // EPI_DGRAD: C += result
     int tune;            // tuning build only, timing experiments (results invalid): 1 = no A-tile copies inside the k loop,
-                         // 2 = no B-tile copies, 4 = no barrier per k tile, 32 = s_setprio 1 for waves 4-7 (valid results)
+                         // 2 = no B-tile copies, 4 = no barrier per k tile, 32 = s_setprio 1 for waves 4-7 (valid results),
+                         // 8 = dgrad without the Hprev prefetch, 16 = stamp 1 behind the plain k tiles, 64 = forward epilogue
+                         // straight from the accumulators, 128 = 256 x 256 tiling whatever the shape (8-128: valid results)
 };
 
 // ELU.  libm's expm1f is ~40 VALU instructions and the epilogue applies it to every output element (33.5 M per 512-wide
@@ -538,6 +540,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
     // refill loads and the stores of one row do not stall the next row.
     const bool full_tile = m0 + BM <= p.M && c0 + BN <= p.ncols;
     const bool fast_epi = full_tile && (EPI == EPI_DGRAD ? pf_on : (p.bias != nullptr && p.act == NIC_ACT_ELU));
+#ifdef NIC_TUNING_BUILD
+    if (EPI == EPI_BIAS_ACT && fast_epi && NIC_TUNE(64)) {
+        // experiment: forward epilogue straight from the accumulators (no LDS staging, no barriers): one dword store per
+        // accumulator register, 32 lanes = 128 contiguous bytes of a row, the wave's two halves four rows apart
+        const int64_t base = (int64_t)(m0 + wm * MT * 32 + 4 * h) * p.ldb + c0 + wn * NT * 32 + li;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = i * 32 + (r & 3) + 8 * (r >> 2);
+                const float bias = p.bias[m0 + wm * MT * 32 + 4 * h + rl];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) p.C[base + (int64_t)rl * p.ldb + j * 32] = elu_f(acc[i][j][r] + bias);
+            }
+        NIC_STAMP(3);
+        return;
+    }
+#endif
     if (fast_epi) {
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
@@ -1212,7 +1232,7 @@ void dispatch_wx(const WxParams& p, hipStream_t s) {
     if (wx_fast_ok(p)) {
         // production path: LDS-DMA kernels
         if (p.M > 128 && gemm_variant() != 1) {
-            switch (pick_wx_tile(p.M, p.ncols)) {
+            switch ((p.tune & 128) ? WX_256x256 : pick_wx_tile(p.M, p.ncols)) {   // (bit 128: tuning builds only, see WxParams::tune)
                 case WX_256x256: launch_wx_dma<2, 4, 4, 2, EPI>(p, s); return;
                 case WX_448x128: launch_wx_dma<2, 4, 7, 1, EPI>(p, s); return;
                 case WX_256x128: launch_wx_dma<2, 4, 4, 1, EPI>(p, s); return;
