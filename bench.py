@@ -368,11 +368,7 @@ def main():
             eng.model.closed_form_levels()  # materialises the policy's one lazy layer
         parallel.broadcast_model(model, src=0)
     elif eng is not None:  # materialise the lazy layers now so that replicas can be synchronised before the first step
-        F_in = data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2]
-        if policy["name"] != "vanilla_one_store":
-            F_in += sum(data[k].shape[1] * data[k].shape[2]
-                        for k in ("initial_warehouse_inventories", "initial_echelon_inventories") if k in data)
-        eng.materialize(F_in)
+        eng.materialize(eng.input_rows(data, setting["observation_params"]))
         eng.small_lane_scenarios = args.lane_scenarios
         parallel.broadcast_model(model, src=0)
     opt = torch.optim.Adam(model.parameters(), lr=3e-4)

@@ -189,6 +189,18 @@ int nic_head_softplus_fwd(const float* Z, float* orders, int32_t rows, int32_t n
 int nic_head_softplus_bwd(const float* Z, const float* g_orders, float* dZ, int32_t rows, int32_t n_scenarios,
                           int32_t ldb, void* stream);
 
+/* data_driven (DataDrivenNet.forward, neural_networks.py:474-515): Z [Wn + S*Wn][ldb] = the last layer's output BEFORE its ReLU,
+ * rows [Wn warehouse orders | S x Wn store orders, store-major]; mask [S][Wn] (device floats, 1 = edge) = the setting's
+ * adjacency transposed.  wh_orders[w] = relu(Z[w]); store_orders[s][w] = relu(Z[Wn + s*Wn + w]) * mask[s][w] *
+ * min(1, sum_k wh_inv[w][k] / (sum_s (...) + 1e-10)) - `apply_proportional_allocation` (:111-138) sums the pipeline it is handed.
+ * Wn == 0 (one-store settings): store_orders[s] = relu(Z[s]); wh_inv / mask / wh_orders may be NULL.
+ * Backward: dZ fully written, g_wh_inv[w][k][b] += d(scale)/... for every slot k (the clip passes where the ratio <= 1). */
+int nic_head_data_driven_fwd(const float* Z, const float* wh_inv, const float* mask, float* store_orders, float* wh_orders,
+                             int32_t S, int32_t Wn, int32_t Ww, int32_t n_scenarios, int32_t ldb, void* stream);
+int nic_head_data_driven_bwd(const float* Z, const float* wh_inv, const float* mask, const float* g_store_orders,
+                             const float* g_wh_orders, float* dZ, float* g_wh_inv, int32_t S, int32_t Wn, int32_t Ww,
+                             int32_t n_scenarios, int32_t ldb, void* stream);
+
 /* vanilla_serial (neural_networks.py:319-355): Z rows = [E echelons..., warehouse, store]; each row is
  * sigmoid(Z) * upstream on-hand, where upstream = [upper_bound, ech_inv[0..E-1][0], wh_inv[0][0]].
  * NOTE: the reference detaches the MLP input (torch.tensor(...) at :329); that is the caller's concern. */

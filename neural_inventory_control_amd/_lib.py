@@ -109,6 +109,8 @@ PROTOTYPES = {
     "nic_head_warehouse_fwd": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_head_warehouse_bwd": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                          _i32, _vp]),
+    "nic_head_data_driven_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "nic_head_data_driven_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_head_softplus_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "nic_head_softplus_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "nic_head_serial_fwd": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

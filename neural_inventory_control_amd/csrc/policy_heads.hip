@@ -94,6 +94,66 @@ __global__ __launch_bounds__(kLanes * nic::kQuad) void head_warehouse_bwd_quad_k
         }
     }
 }
+// ---- data_driven head (neural_networks.py:474-515 + :111-138) -------------------------------------------------------------------
+// Z rows = [Wn warehouse orders | S x Wn store orders (store-major)] BEFORE the output ReLU.  One lane = (scenario, warehouse):
+// out = relu(Z); the warehouse's own order passes through; its store orders are masked by the adjacency, summed in store order
+// and scaled by min(1, pipeline total of the warehouse / (sum + 1e-10)) - upstream passes the whole [Ww] pipeline as "available
+// inventory" and `apply_proportional_allocation` sums it.  Wn == 0 (one-store settings): orders = relu(Z), one lane per scenario.
+__global__ void head_data_driven_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ wh, const float* __restrict__ mask,
+                                            float* __restrict__ so, float* __restrict__ wo, int S, int Wn, int Ww, int B,
+                                            int64_t ldb) {
+#pragma clang fp contract(off)
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (Wn == 0) {
+        for (int s = 0; s < S; ++s) so[(int64_t)s * ldb + b] = fmaxf(Z[(int64_t)s * ldb + b], 0.f);
+        return;
+    }
+    const int w = blockIdx.y;
+    wo[(int64_t)w * ldb + b] = fmaxf(Z[(int64_t)w * ldb + b], 0.f);
+    float avail = 0.f;
+    for (int k = 0; k < Ww; ++k) avail += wh[((int64_t)w * Ww + k) * ldb + b];
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) sum += fmaxf(Z[(int64_t)(Wn + s * Wn + w) * ldb + b], 0.f) * mask[s * Wn + w];
+    const float sc = fminf(avail / (sum + 1e-10f), 1.f);
+    for (int s = 0; s < S; ++s)
+        so[(int64_t)(s * Wn + w) * ldb + b] = fmaxf(Z[(int64_t)(Wn + s * Wn + w) * ldb + b], 0.f) * mask[s * Wn + w] * sc;
+}
+
+// adjoint: dZ (every row written) and g_wh[w][k][b] += d(scale) / (sum + eps) for every slot k of the pipeline
+__global__ void head_data_driven_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ wh, const float* __restrict__ mask,
+                                            const float* __restrict__ g_so, const float* __restrict__ g_wo, float* __restrict__ dZ,
+                                            float* __restrict__ g_wh, int S, int Wn, int Ww, int B, int64_t ldb) {
+#pragma clang fp contract(off)
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (Wn == 0) {
+        for (int s = 0; s < S; ++s) dZ[(int64_t)s * ldb + b] = Z[(int64_t)s * ldb + b] > 0.f ? g_so[(int64_t)s * ldb + b] : 0.f;
+        return;
+    }
+    const int w = blockIdx.y;
+    dZ[(int64_t)w * ldb + b] = Z[(int64_t)w * ldb + b] > 0.f ? g_wo[(int64_t)w * ldb + b] : 0.f;
+    float avail = 0.f;
+    for (int k = 0; k < Ww; ++k) avail += wh[((int64_t)w * Ww + k) * ldb + b];
+    float sum = 0.f, dot = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float a = fmaxf(Z[(int64_t)(Wn + s * Wn + w) * ldb + b], 0.f) * mask[s * Wn + w];
+        sum += a;
+        dot += g_so[(int64_t)(s * Wn + w) * ldb + b] * a;
+    }
+    const float den = sum + 1e-10f, ratio = avail / den;
+    const float sc = fminf(ratio, 1.f);
+    const float d_scale = ratio <= 1.f ? dot : 0.f;          // torch.clip(max = 1) passes the gradient where ratio <= 1
+    const float common = -(d_scale * avail / (den * den));
+    for (int s = 0; s < S; ++s) {
+        const int64_t row = (int64_t)(Wn + s * Wn + w) * ldb + b;
+        const float da = g_so[(int64_t)(s * Wn + w) * ldb + b] * sc + common;
+        dZ[row] = Z[row] > 0.f ? da * mask[s * Wn + w] : 0.f;
+    }
+    const float g_av = d_scale / den;
+    for (int k = 0; k < Ww; ++k) g_wh[((int64_t)w * Ww + k) * ldb + b] += g_av;
+}
+
 __global__ void head_softplus_fwd_kernel(const float* __restrict__ Z, float* __restrict__ o, int rows, int B, int64_t ldb) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B)
@@ -190,6 +250,29 @@ int nic_head_warehouse_bwd(const float* Z, const float* wh_inv, const int32_t* a
                        nic::as_stream(stream), Z, wh_inv, adjacency, upper_bound, transshipment, g_store_orders, g_wh_orders,
                        dZ, g_wh_inv, S, Wn, Ww, n_scenarios, (int64_t)ldb);
     return nic::check_launch("nic_head_warehouse_bwd");
+}
+
+int nic_head_data_driven_fwd(const float* Z, const float* wh_inv, const float* mask, float* store_orders, float* wh_orders,
+                             int32_t S, int32_t Wn, int32_t Ww, int32_t n_scenarios, int32_t ldb, void* stream) {
+    NIC_REQUIRE(Z && store_orders && (Wn == 0 || (wh_inv && mask && wh_orders)), "nic_head_data_driven_fwd: null buffer");
+    NIC_REQUIRE(S > 0 && Wn >= 0 && (Wn == 0 || Ww > 0) && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_data_driven_fwd: bad sizes");
+    nic::note_kernel("head_data_driven_fwd_kernel");
+    hipLaunchKernelGGL(head_data_driven_fwd_kernel, dim3(nic::ceil_div(n_scenarios, 64), Wn > 0 ? Wn : 1), dim3(64), 0,
+                       nic::as_stream(stream), Z, wh_inv, mask, store_orders, wh_orders, S, Wn, Ww, n_scenarios, (int64_t)ldb);
+    return nic::check_launch("nic_head_data_driven_fwd");
+}
+
+int nic_head_data_driven_bwd(const float* Z, const float* wh_inv, const float* mask, const float* g_store_orders,
+                             const float* g_wh_orders, float* dZ, float* g_wh_inv, int32_t S, int32_t Wn, int32_t Ww,
+                             int32_t n_scenarios, int32_t ldb, void* stream) {
+    NIC_REQUIRE(Z && g_store_orders && dZ && (Wn == 0 || (wh_inv && mask && g_wh_orders && g_wh_inv)),
+                "nic_head_data_driven_bwd: null buffer");
+    NIC_REQUIRE(S > 0 && Wn >= 0 && (Wn == 0 || Ww > 0) && n_scenarios > 0 && ldb >= n_scenarios, "nic_head_data_driven_bwd: bad sizes");
+    nic::note_kernel("head_data_driven_bwd_kernel");
+    hipLaunchKernelGGL(head_data_driven_bwd_kernel, dim3(nic::ceil_div(n_scenarios, 64), Wn > 0 ? Wn : 1), dim3(64), 0,
+                       nic::as_stream(stream), Z, wh_inv, mask, g_store_orders, g_wh_orders, dZ, g_wh_inv, S, Wn, Ww, n_scenarios,
+                       (int64_t)ldb);
+    return nic::check_launch("nic_head_data_driven_bwd");
 }
 
 int nic_head_softplus_fwd(const float* Z, float* orders, int32_t rows, int32_t n_scenarios, int32_t ldb, void* stream) {

@@ -165,6 +165,19 @@ def head_warehouse_bwd(Z, wh_inv, adjacency, ub, transshipment, g_store_orders, 
                                        Z.stride(0), current_stream()))
 
 
+def head_data_driven_fwd(Z, wh, mask, store_orders, wh_orders, S, Wn, Ww, B):
+    """nic_head_data_driven_fwd: ReLU, adjacency mask and proportional allocation of the data_driven policy (one launch)."""
+    _dev(Z)
+    check(lib().nic_head_data_driven_fwd(ptr(Z), ptr(wh), ptr(mask), ptr(store_orders), ptr(wh_orders), S, Wn, Ww, B, Z.stride(0),
+                                         current_stream()))
+
+
+def head_data_driven_bwd(Z, wh, mask, g_store_orders, g_wh_orders, dZ, g_wh, S, Wn, Ww, B):
+    _dev(Z)
+    check(lib().nic_head_data_driven_bwd(ptr(Z), ptr(wh), ptr(mask), ptr(g_store_orders), ptr(g_wh_orders), ptr(dZ), ptr(g_wh),
+                                         S, Wn, Ww, B, Z.stride(0), current_stream()))
+
+
 def head_softplus_fwd(Z, orders, rows, B):
     _dev(Z)
     check(lib().nic_head_softplus_fwd(ptr(Z), ptr(orders), rows, B, Z.stride(0), current_stream()))

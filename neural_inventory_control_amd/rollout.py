@@ -22,7 +22,8 @@ from . import small_rollout as sr
 from .layout import EnvProblem, ProblemCache, Table, pad_ld
 from .ops import EnvState
 
-_HEADS = {"vanilla_one_store": "softplus", "vanilla_warehouse": "warehouse", "vanilla_serial": "serial"}
+_HEADS = {"vanilla_one_store": "softplus", "vanilla_warehouse": "warehouse", "vanilla_serial": "serial",
+          "data_driven": "data_driven"}
 
 
 def _pad32(n):
@@ -83,11 +84,30 @@ class FusedRollout:
     @staticmethod
     def supports(model):
         name = getattr(model, "nn_args", {}).get("name") if hasattr(model, "nn_args") else None
-        if name not in _HEADS or type(model).__name__ not in ("VanillaOneStore", "VanillaWarehouse", "VanillaSerial"):
+        if name not in _HEADS or type(model).__name__ not in ("VanillaOneStore", "VanillaWarehouse", "VanillaSerial",
+                                                              "DataDrivenNet"):
             return False
         a = model.nn_args
-        return (a["inner_layer_activations"]["master"] == "elu" and a["output_layer_activation"]["master"] is None
-                and len(a["neurons_per_hidden_layer"]["master"]) >= 1)
+        if name == "data_driven":   # the real-data policy (data_driven_net.yml): ELU inside, ReLU on the output layer
+            return (type(model).__name__ == "DataDrivenNet" and a["inner_layer_activations"]["master"] == "elu"
+                    and a["output_layer_activation"]["master"] == "relu" and len(a["neurons_per_hidden_layer"]["master"]) >= 1)
+        return (type(model).__name__ != "DataDrivenNet" and a["inner_layer_activations"]["master"] == "elu"
+                and a["output_layer_activation"]["master"] is None and len(a["neurons_per_hidden_layer"]["master"]) >= 1)
+
+    @staticmethod
+    def observation_ok(model, observation_params, data=None):
+        """Can this engine build the policy's observation?  The vanilla policies read the inventories only (no past-demand
+        window, no time / sample features: trainer.py's generic loop otherwise); data_driven reads the past-demand window and
+        `days_from_christmas` (neural_networks.py:452-470) and nothing else that moves with the period."""
+        op = observation_params
+        if op is None:
+            return False
+        past, tf, sf = op["demand"]["past_periods"], op["time_features"], op["sample_features"]
+        if getattr(model, "nn_args", {}).get("name") == "data_driven":
+            # (sample features, e.g. `store_nbr`, may be in the observation: DataDrivenNet.forward does not read them)
+            return (list(tf or []) == ["days_from_christmas"] and past >= 1
+                    and (data is None or ("days_from_christmas" in data and "underage_costs" in data)))
+        return past == 0 and not tf and not sf
 
     def __init__(self, model, problem_params, device):
         _lib.require_device()
@@ -145,9 +165,9 @@ class FusedRollout:
                 m.__class__ = m.cls_to_become
             k = m.out_features
 
-    def _setup(self, prob, T, train):
+    def _setup(self, prob, T, train, extra_rows=0):
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin,
-               self.eval_history, self.small_wgrad_in_kernel)
+               self.eval_history, self.small_wgrad_in_kernel, extra_rows)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
@@ -159,6 +179,10 @@ class FusedRollout:
         F = self.F_store + self.F_wh + self.F_ech
         if self.head == "softplus":
             F = self.F_store
+        # rows of the MLP input that are the state (what the first layer's input gradient is needed for); data_driven appends
+        # `extra_rows` observation rows to every period's block: [past-demand window | costs | days from christmas | lead times]
+        self.F_dyn = F
+        F += extra_rows
         self.F = F
         self.materialize(F)
         lins = self._linears()
@@ -197,13 +221,13 @@ class FusedRollout:
             self._key = key
             return
         n_ord = prob.S * prob.nsup + prob.Wn + prob.E
-        f_tot = self.F_store + self.F_wh + self.F_ech
+        f_tot = self.F_store + self.F_wh + self.F_ech + extra_rows
         # evaluation keeps the state / order / logit history only while it is small (tests and short horizons read it);
         # a long-horizon evaluation (test periods: 5000) rolls through two state blocks and one order / logit block
         free_now = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
                     if dev.type == "cuda" else 0)
         auto = 4 * (T + 1) * ld * (f_tot + n_ord + dims[-1]) <= 0.1 * free_now
-        self._hist = bool(train) or (auto if self.eval_history is None else bool(self.eval_history))
+        self._hist = bool(train) or extra_rows > 0 or (auto if self.eval_history is None else bool(self.eval_history))
         self.states = z(T + 1 if self._hist else 2, f_tot, ld)
         self.orders = z(T if self._hist else 1, n_ord, ld)
         self.rewards = z(T, ld)
@@ -242,6 +266,9 @@ class FusedRollout:
         self._eager_runs = 0
         if self.head == "warehouse":
             self.adj = self.model.adjacency(prob.S, prob.Wn, dev)
+        if self.head == "data_driven" and prob.Wn:
+            conn = self.problem_params["warehouse_store_adjacency"]
+            self.edge_mask = torch.tensor(conn, dtype=torch.float32, device=dev).t().contiguous()   # [S][Wn]
         self._key = key
 
     def _views(self, block, prob):
@@ -249,7 +276,7 @@ class FusedRollout:
         a, b = self.F_store, self.F_store + self.F_wh
         store = block[:a].view(prob.S, prob.Ws, -1)
         wh = block[a:b].view(prob.Wn, prob.Ww, -1) if prob.Wn else None
-        ech = block[b:].view(prob.E, prob.We, -1) if prob.E else None
+        ech = block[b:b + self.F_ech].view(prob.E, prob.We, -1) if prob.E else None
         return EnvState(store, wh, ech)
 
     def _order_views(self, block, prob):
@@ -292,7 +319,13 @@ class FusedRollout:
         dev = self.device
         prob = self._problem_for(data)
         T, B, ld = periods, prob.B, prob.ldb
-        self._setup(prob, T, train)
+        extra = 0
+        if self.head == "data_driven":
+            if not self.observation_ok(self.model, observation_params, data):
+                raise ValueError("data_driven needs a past-demand window and the days_from_christmas time feature")
+            P_ = observation_params["demand"]["past_periods"]
+            extra = prob.S * P_ + 2 * prob.S + data["days_from_christmas"].shape[1] + prob.S * data["lead_times"].shape[2]
+        self._setup(prob, T, train, extra)
         if self.use_graph:
             # a captured graph holds raw pointers: keep the first call's table tensors and refresh their CONTENTS
             if self._prob is not None and self._prob.same_layout(prob):
@@ -338,7 +371,9 @@ class FusedRollout:
         if prob.E:
             s0.ech[:, :, :B].copy_(data["initial_echelon_inventories"].permute(1, 2, 0))
 
-        self._ub_now = self._ub() if self.head != "softplus" else 0.0
+        if self.head == "data_driven":
+            self._fill_observation_rows(data, prob, T, B, ld, shift, observation_params, demand_soa)
+        self._ub_now = self._ub() if self.head not in ("softplus", "data_driven") else 0.0
         self._ctx = (prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa)
         self._replay_or_capture("fwd", self._launch_forward)
         total = self.rewards.sum()
@@ -364,6 +399,45 @@ class FusedRollout:
         if assign_grads:
             self._assign_grads(accumulate_grads)
         return total, reported
+
+    def input_rows(self, data, observation_params=None):
+        """Rows of the policy's input for batches shaped like `data` (what `materialize` wants before the first run)."""
+        n = lambda k: (data[k].shape[1] * data[k].shape[2]) if k in data else 0  # noqa: E731
+        rows = n("initial_inventories")
+        if self.head != "softplus":
+            rows += n("initial_warehouse_inventories") + n("initial_echelon_inventories")
+        if self.head == "data_driven":
+            S = data["initial_inventories"].shape[1]
+            rows += (S * observation_params["demand"]["past_periods"] + 2 * S + data["days_from_christmas"].shape[1]
+                     + S * data["lead_times"].shape[2])
+        return rows
+
+    def _fill_observation_rows(self, data, prob, T, B, ld, shift, observation_params, demand_soa):
+        """data_driven: the observation rows behind the state rows of every period's input block, in the reference's
+        concatenation order (neural_networks.py:452-470): past demands [S][P] (the window demands[t+shift-P : t+shift], zeros to
+        the left of period 0: environment.py:436-458), underage [S], holding [S], days_from_christmas [D] (column
+        min(t+shift, last): :460-468), lead times [S][W].  A handful of strided copies for ALL periods, outside the period loop."""
+        S, P_ = prob.S, observation_params["demand"]["past_periods"]
+        X = self.states                       # [T+1][F][ld]
+        o = self.F_dyn
+        n_t = demand_soa.shape[0]
+        if getattr(self, "_dpad", None) is None or self._dpad.shape != (P_ + n_t, S, ld):
+            self._dpad = torch.zeros(P_ + n_t, S, ld, device=self.device)
+        self._dpad[P_:].copy_(demand_soa)      # P zero periods in front: the window of period t is rows [t+shift, t+shift+P)
+        win = self._dpad.as_strided((T, S, P_, ld), (S * ld, ld, S * ld, 1), shift * S * ld)
+        X[:T, o:o + S * P_].view(T, S, P_, ld).copy_(win)
+        o += S * P_
+        for k in ("underage_costs", "holding_costs"):
+            X[:T, o:o + S, :B] = data[k].t()
+            o += S
+        dfc = data["days_from_christmas"]                      # [B][D][periods of the data]
+        D = dfc.shape[1]
+        idx = torch.clamp(torch.arange(T, device=self.device) + shift, max=dfc.shape[2] - 1)
+        X[:T, o:o + D, :B] = dfc[:, :, idx].permute(2, 1, 0)
+        o += D
+        lt = data["lead_times"]                                 # [B][S][W]
+        X[:T, o:o + lt.shape[1] * lt.shape[2], :B] = lt.reshape(B, -1).t()
+        assert o + lt.shape[1] * lt.shape[2] == self.F
 
     def param_grads(self):
         """[(parameter, gradient buffer of the last training run)] - engine-owned buffers, overwritten by the next run."""
@@ -484,6 +558,9 @@ class FusedRollout:
                         prob.S, prob.Wn, prob.Ww, B)
             elif self.head == "serial":
                 self._k("head_fwd", ops.head_serial_fwd, Z, st.wh, st.ech, ub, so, wo, eo, prob.E, prob.Ww, prob.We, B)
+            elif self.head == "data_driven":
+                self._k("head_fwd", ops.head_data_driven_fwd, Z, st.wh, self.edge_mask if prob.Wn else None, so, wo, prob.S,
+                        prob.Wn, prob.Ww, B)
             else:
                 self._k("head_fwd", ops.head_softplus_fwd, Z, so.view(-1, ld), prob.S * prob.nsup, B)
             if self._round:
@@ -514,6 +591,9 @@ class FusedRollout:
             elif self.head == "serial":
                 self._k("head_bwd", ops.head_serial_bwd, Z, st.wh, st.ech, ub, gso, gwo, geo, dZ, gc.wh, gc.ech, prob.E,
                         prob.Ww, prob.We, B)
+            elif self.head == "data_driven":
+                self._k("head_bwd", ops.head_data_driven_bwd, Z, st.wh, self.edge_mask if prob.Wn else None, gso, gwo, dZ,
+                        gc.wh, prob.S, prob.Wn, prob.Ww, B)
             else:
                 self._k("head_bwd", ops.head_softplus_bwd, Z, gso.view(-1, ld), dZ, prob.S * prob.nsup, B)
             d = dZ
@@ -534,9 +614,9 @@ class FusedRollout:
                     self._k(f"dgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_dgrad, Wtv[i], d, x_in, dx, B,
                             _lib.NIC_ACT_ELU, False)
                     d = dx
-                elif not detached_input:
-                    self._k(f"dgrad_{self.dims[1]}x{self.dims[0]}", ops.linear_dgrad, Wtv[0], d, None, g_cur[:self.F], B,
-                            _lib.NIC_ACT_NONE, True)
+                elif not detached_input:   # (only the state rows of the input carry a gradient back in time)
+                    self._k(f"dgrad_{self.dims[1]}x{self.dims[0]}", ops.linear_dgrad, Wtv[0][:self.F_dyn], d, None,
+                            g_cur[:self.F_dyn], B, _lib.NIC_ACT_NONE, True)
             g_next, g_cur = g_cur, g_next
         if self.dZhist is not None:
             # hidden layers: dW_i = sum over (period, scenario) of dZ_i X_i^T in one launch each

@@ -153,8 +153,10 @@ class Trainer:
                 # and the totals: 0.55 -> 0.18 ms per step).  The MLP / GNN engines run GPU-bound launch sequences of their own
                 # (`FusedRollout.use_graph` replays those) and keep the eager step.
                 graphed = (train and model.trainable and self.use_step_graph and not discrete_allocation
-                           and not (self.use_fused_rollout and self._plain_observation(observation_params)
-                                    and (FusedRollout.supports(model) or GnnRollout.supports(model, problem_params))))
+                           and not (self.use_fused_rollout
+                                    and ((FusedRollout.supports(model) and FusedRollout.observation_ok(model, observation_params))
+                                         or (self._plain_observation(observation_params)
+                                             and GnnRollout.supports(model, problem_params)))))
                 if graphed:
                     total_reward, reward_to_report = self._graphed_generic_step(
                         loss_function, simulator, model, periods, problem_params, data_batch, observation_params,
@@ -195,8 +197,8 @@ class Trainer:
         train = bool(train) and torch.is_grad_enabled()
         # (rounded actions have zero gradient: a training step with discrete allocation keeps the reference's generic route;
         # a custom loss module is honoured by the generic route - the fused engines implement PolicyLoss = reward.sum())
-        fusable = (self.use_fused_rollout and not (discrete_allocation and train) and isinstance(loss_function, PolicyLoss)
-                   and self._plain_observation(observation_params))
+        engine_ok = self.use_fused_rollout and not (discrete_allocation and train) and isinstance(loss_function, PolicyLoss)
+        fusable = engine_ok and self._plain_observation(observation_params)
         if fusable and ClosedFormRollout.supports(model):
             # closed-form policies: ONE kernel for the whole horizon, gradient included (forward mode); the returned total
             # is an ordinary differentiable tensor, so the caller's mean_loss.backward() reaches the policy's parameters
@@ -211,13 +213,14 @@ class Trainer:
                 return eng.run(data_batch, periods, ignore_periods, train=train, observation_params=observation_params,
                                discrete_allocation=discrete_allocation)
         engine_cls = None
-        if fusable and not discrete_allocation:
-            if FusedRollout.supports(model):
-                engine_cls = FusedRollout
-            elif GnnRollout.supports(model, problem_params) and "mean" in data_batch and "std" in data_batch:
+        # (the MLP engine builds the observation itself: inventories for the vanilla policies, + the past-demand window and the
+        # days-from-christmas feature for data_driven; everything else with a moving observation keeps the generic loop)
+        mlp_ok = engine_ok and FusedRollout.supports(model) and FusedRollout.observation_ok(model, observation_params, data_batch)
+        if mlp_ok:
+            engine_cls = FusedRollout    # (also evaluation with discrete allocation: the MLP engine rounds in-kernel)
+        elif fusable and not discrete_allocation:
+            if GnnRollout.supports(model, problem_params) and "mean" in data_batch and "std" in data_batch:
                 engine_cls = GnnRollout  # fused gather-MLP kernels over the static supply graph (gnn_rollout.py)
-        elif fusable and FusedRollout.supports(model):
-            engine_cls = FusedRollout    # (evaluation with discrete allocation: the MLP engine rounds in-kernel)
         if engine_cls is not None:
             # one engine per (policy, training / evaluation): an epoch alternates a training pass and a dev pass with
             # different horizons and buffer needs, and re-sizing one engine back and forth would reallocate tens of GB

@@ -215,11 +215,11 @@ WORKLOADS = {
                             "one_warehouse_lost_demand, 16 stores, 8192 scenarios x T=50, symmetry_aware (context 256->64, store / "
                             "warehouse nets 32x2); generic route"),
     # the reference's real-data training batch (72 of 288 products x 21 stores x 3 warehouses, T = 95 of 111 train
-    # weeks after the 16-week past-demand window) on the GENERIC route: Simulator.step (one HIP kernel per period) + HipLinear
-    # layers + autograd; `--graph` replays the whole training step from one HIP graph
+    # weeks after the 16-week past-demand window).  Since round 3 on the MLP engine (per-period kernels, data_driven head);
+    # `bench.py --generic-route` runs it through Simulator.step + HipLinear layers + autograd instead (`--graph`: replayed)
     "real_data_driven": (real_data, data_driven_policy(), 72, 95,
                          "many_warehouses_real_data_lost_demand shape (synthetic stand-in files), 72 products x 21 stores x "
-                         "3 warehouses x T=95, data_driven 64x64; generic route"),
+                         "3 warehouses x T=95, data_driven 64x64"),
     # the GNN policy on cfg3's graph (fused gather-MLP kernels over the static supply graph, gnn_rollout.py)
     "gnn": (lambda: one_warehouse(16), gnn_policy(), 8192, 50,
             "one_warehouse_lost_demand, 16 stores, 8192 scenarios x T=50, gnn (5 x 32-wide MLPs, 1 message-passing step)"),

@@ -669,6 +669,56 @@ def test_segment_sum_terms_equals_the_chain_of_launches():
     assert torch.equal(got, first)
 
 
+@pytest.mark.parametrize("S,Wn", [(21, 3), (5, 2), (1, 0), (4, 0)])
+def test_data_driven_head_matches_torch_autograd(S, Wn):
+    """nic_head_data_driven_fwd / bwd against `DataDrivenNet.forward`'s tail in tensor ops (neural_networks.py:474-515, :111-138):
+    ReLU, adjacency mask, proportional allocation of each warehouse's PIPELINE TOTAL over its stores; float64 autograd for
+    dZ and the gradient of every pipeline slot.  Wn = 0: the one-store settings (orders = relu(Z))."""
+    dev, B, Ww = "cuda", 205, 4
+    ld = pad_ld(B, 32)
+    gen = torch.Generator().manual_seed(S * 7 + Wn)
+    rows = Wn + S * max(Wn, 1) if Wn else S
+    Z = torch.zeros(rows, ld)
+    Z[:, :B] = torch.randn(rows, B, generator=gen) * 2
+    mask = (torch.rand(S, max(Wn, 1), generator=gen) < 0.7).float()
+    if Wn:
+        mask[0] = 1.0
+        mask[:, -1] = 0.0 if S > 6 else mask[:, -1]          # (a warehouse that serves nobody: its column stays 0)
+    wh = torch.zeros(max(Wn, 1), Ww, ld)
+    wh[:, :, :B] = torch.rand(max(Wn, 1), Ww, B, generator=gen) * (S / 3)
+    n_so = S * max(Wn, 1)
+    g_so, g_wo = torch.zeros(n_so, ld), torch.zeros(max(Wn, 1), ld)
+    g_so[:, :B] = torch.randn(n_so, B, generator=gen)
+    g_wo[:, :B] = torch.randn(max(Wn, 1), B, generator=gen)
+    z64 = Z[:, :B].double().requires_grad_(True)
+    w64 = wh[:, :, :B].double().requires_grad_(True)
+    out = torch.relu(z64)
+    if Wn:
+        wo_ref = out[:Wn]
+        alloc = out[Wn:].reshape(S, Wn, B) * mask.double()[:, :, None]
+        scale = torch.clamp(w64.sum(dim=1) / (alloc.sum(dim=0) + 1e-10), max=1.0)      # [Wn][B]
+        so_ref = (alloc * scale[None]).reshape(S * Wn, B)
+        ((so_ref * g_so[:, :B].double()).sum() + (wo_ref * g_wo[:Wn, :B].double()).sum()).backward()
+    else:
+        so_ref = out
+        (so_ref * g_so[:, :B].double()).sum().backward()
+    d = lambda t: t.to(dev)  # noqa: E731
+    so, wo = torch.zeros(n_so, ld, device=dev), torch.zeros(max(Wn, 1), ld, device=dev)
+    Zd, whd, md = d(Z), d(wh) if Wn else None, d(mask) if Wn else None
+    ops.head_data_driven_fwd(Zd, whd, md, so, wo if Wn else None, S, Wn, Ww, B)
+    torch.testing.assert_close(so[:, :B].cpu().double(), so_ref.detach(), rtol=2e-6, atol=1e-6)
+    if Wn:
+        torch.testing.assert_close(wo[:Wn, :B].cpu().double(), wo_ref.detach(), rtol=0, atol=0)
+    dZ = torch.full((rows, ld), 7.0, device=dev)
+    g_wh = torch.full((max(Wn, 1), Ww, ld), 0.5, device=dev)
+    ops.head_data_driven_bwd(Zd, whd, md, d(g_so), d(g_wo) if Wn else None, dZ, g_wh if Wn else None, S, Wn, Ww, B)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dZ[:, :B].cpu().double(), z64.grad, rtol=2e-5, atol=2e-5)
+    if Wn:
+        torch.testing.assert_close(g_wh[:, :, :B].cpu().double() - 0.5, w64.grad, rtol=2e-5, atol=2e-5)
+    assert float(dZ[:, B:].sub(7.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("cap,self_loops", [(True, True), (False, False)])
 def test_gnn_group_allocation_matches_torch_autograd(cap, self_loops):
     """nic_gnn_alloc_groups_fwd / bwd (several warehouses, one launch) against the tensor-op formulation

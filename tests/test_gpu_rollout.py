@@ -133,6 +133,61 @@ def test_fused_rollout_matches_reference(name):
     assert float(t2) == float(total) and float(r2) == float(reported)
 
 
+DATA_DRIVEN_CASES = [n for n in case_names() if n.endswith("data_driven")]
+
+
+@pytest.mark.parametrize("name", DATA_DRIVEN_CASES)
+def test_data_driven_engine_matches_reference(name):
+    """SURVEY 8 f4 on the MLP engine (round 3): `FusedRollout` with the data_driven head - the past-demand window, costs,
+    days-from-christmas and lead-time rows appended to every period's state block, ReLU + adjacency mask + proportional
+    allocation of the warehouses' pipelines in one head kernel (`nic_head_data_driven_fwd/bwd`), profit objective, demand
+    trace entered at period_shift - against the reference-generated real-data fixtures: rewards, totals, final state,
+    gradients at the usual bars; evaluation mode and the Trainer's own routing agree."""
+    assert DATA_DRIVEN_CASES
+    g = Golden(name)
+    c = g.fresh_config()
+    model = _model(g, c)
+    assert FusedRollout.supports(model) and FusedRollout.observation_ok(model, c["observation_params"], g.data)
+    eng = FusedRollout(model, c["problem_params"], DEV)
+    assert eng.head == "data_driven"
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    eng.materialize(g.params["net.master.0.weight"].shape[1])
+    _load(model, g)
+    total, reported = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+    torch.cuda.synchronize()
+    assert eng.small is None and eng.dims[0] == g.params["net.master.0.weight"].shape[1]
+    rewards = eng.per_period_rewards().cpu()
+    ref_r = g.tensor("rewards").float()
+    torch.testing.assert_close(rewards, ref_r, rtol=1e-5, atol=2e-2)
+    assert abs(float(total) - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
+    assert abs(float(reported) - float(g.z["reported"])) <= 1e-5 * abs(float(g.z["reported"]))
+    final = eng.final_state()
+    for k, v in g.states(c["periods"]).items():
+        torch.testing.assert_close(final[k].cpu(), v.float(), rtol=2e-6, atol=2e-3)
+    # every period's observation block is the reference's flattened feature vector (inventories | window | costs | ...)
+    for t in (0, c["periods"] // 2, c["periods"] - 1):
+        feats = g.features(t)
+        o = eng.F_dyn
+        S, P_ = c["problem_params"]["n_stores"], c["observation_params"]["demand"]["past_periods"]
+        got = eng.states[t][o:o + S * P_, :c["n"]].t().reshape(c["n"], S, P_).cpu()
+        assert torch.equal(got, feats["past_demands"]), t
+        o += S * P_ + 2 * S
+        D = feats["days_from_christmas"].shape[1]
+        assert torch.equal(eng.states[t][o:o + D, :c["n"]].t().cpu(), feats["days_from_christmas"]), t
+    worst = _check_grads(model, g, GRAD_TOL)
+    print(f"{name}: worst relative gradient error {worst:.2e}")
+    t2, r2 = eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"])
+    assert float(t2) == float(total) and float(r2) == float(reported)
+    # the Trainer picks this engine by itself for the real-data observation (and keeps the generic loop for other policies)
+    tr = Trainer(device=DEV)
+    model.zero_grad()
+    tot3, _ = tr.simulate_batch(PolicyLoss(), Simulator(device=DEV), model, c["periods"], c["problem_params"], data,
+                                c["observation_params"], c["ignore"], False)
+    assert any(isinstance(e, FusedRollout) for e in tr._engines.values())
+    (tot3 / (c["n"] * c["periods"] * c["problem_params"]["n_stores"])).backward()
+    _check_grads(model, g, GRAD_TOL)
+
+
 @pytest.mark.parametrize("name", MLP_CASES)
 def test_hybrid_host_sweep_on_device(name):
     """tests/host_rollout.py on the device: the HIP env-step and head kernels (through the C ABI) composed in the engine's
