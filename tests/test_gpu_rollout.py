@@ -188,6 +188,46 @@ def test_data_driven_engine_matches_reference(name):
     _check_grads(model, g, GRAD_TOL)
 
 
+def test_data_driven_epochs_engine_follows_generic_route():
+    """Two training epochs + an evaluation pass of the real-data setting's shape (synthetic stand-in files, 21 stores x 3
+    warehouses, past-demand window of 16, datasets split by period) through `Trainer.do_one_epoch` with ragged batches (16, 16, 8
+    products): the MLP engine with the data_driven head against the generic route (Simulator.step + autograd), step for step."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    setting, policy, _, _, _ = workloads.get("real_data_driven")
+    n, T = 40, 12
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    shift = obs["demand"]["period_shift"]
+    sc = Scenario(shift + T, setting["problem_params"], setting["store_params"], setting["warehouse_params"],
+                  setting["echelon_params"], n, obs, setting["seeds"], device=DEV)
+    (ds,) = DatasetCreator().create_datasets(sc, split=True, by_period=True, periods_for_split=[f"(0, {shift + T})"])
+    runs = {}
+    for fused in (True, False):
+        torch.manual_seed(5)
+        model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+        tr, sim = Trainer(device=DEV), Simulator(device=DEV)
+        tr.use_fused_rollout = fused
+        loader = DeviceBatches(ds, 16, shuffle=False, device=DEV)
+        batch = next(iter(loader))
+        o, _ = sim.reset(T, setting["problem_params"], batch, obs)
+        with torch.no_grad():
+            o = dict(o)
+            o["internal_data"] = sim._internal_data
+            model(o)                                    # materialises the lazy first layer identically on both routes
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        losses = [tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, T, setting["problem_params"], obs, train=True,
+                                  ignore_periods=3) for _ in range(2)]
+        ev = tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, T, setting["problem_params"], obs, train=False,
+                             ignore_periods=3)
+        assert any(isinstance(e, FusedRollout) for e in tr._engines.values()) == fused
+        runs[fused] = (losses, ev, [p.detach().clone() for p in model.parameters()])
+    for a, b in zip(runs[True][0] + [runs[True][1]], runs[False][0] + [runs[False][1]]):
+        assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-5 * abs(b[1]), (a, b)
+    for x, y in zip(runs[True][2], runs[False][2]):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-6)
+    assert runs[True][0][0][0] != runs[True][0][1][0]      # the optimizer moved the policy between the epochs
+
+
 @pytest.mark.parametrize("name", MLP_CASES)
 def test_hybrid_host_sweep_on_device(name):
     """tests/host_rollout.py on the device: the HIP env-step and head kernels (through the C ABI) composed in the engine's
