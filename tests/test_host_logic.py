@@ -199,6 +199,36 @@ def test_gnn_engine_graph_plan_equals_the_oracles_graph(name):
     assert not GnnRollout.supports(model_ok, narrow)            # no store sees both warehouses: upstream itself raises there
 
 
+def test_mlp_engine_routing_rules_for_the_data_driven_policy():
+    """Host-side rules only (no device): `FusedRollout.supports` takes `data_driven` with its ELU / ReLU activations,
+    `observation_ok` wants exactly the observation that policy reads (past-demand window + days_from_christmas; sample features
+    may ride along, DataDrivenNet.forward ignores them) and keeps the vanilla policies on plain observations; `input_rows` is
+    the reference's concatenated feature count (neural_networks.py:452-470)."""
+    g = Golden("f4_real_many_warehouses_data_driven")
+    c = g.fresh_config()
+
+    class _Sc:
+        problem_params = c["problem_params"]
+        store_params = {"demand": {}}
+    model = NeuralNetworkCreator().create_neural_network(_Sc(), c["nn_params"], device="cpu")
+    assert FusedRollout.supports(model)
+    obs = c["observation_params"]
+    assert FusedRollout.observation_ok(model, obs, g.data)
+    assert FusedRollout.observation_ok(model, dict(obs, sample_features=["store_nbr"]), g.data)
+    assert not FusedRollout.observation_ok(model, dict(obs, time_features=None), g.data)
+    assert not FusedRollout.observation_ok(model, dict(obs, demand={"past_periods": 0, "period_shift": 0}), g.data)
+    relu_inside = copy.deepcopy(c["nn_params"])
+    relu_inside["inner_layer_activations"]["master"] = "relu"
+    assert not FusedRollout.supports(NeuralNetworkCreator().create_neural_network(_Sc(), relu_inside, device="cpu"))
+    eng = FusedRollout.__new__(FusedRollout)
+    eng.head = "data_driven"
+    assert eng.input_rows(g.data, obs) == g.params["net.master.0.weight"].shape[1]
+    gv = Golden("cfg3_one_warehouse_5_vanilla")
+    cv, scv = _scenario(gv)
+    vanilla = NeuralNetworkCreator().create_neural_network(scv, cv["nn_params"], device="cpu")
+    assert FusedRollout.observation_ok(vanilla, cv["observation_params"]) and not FusedRollout.observation_ok(vanilla, obs)
+
+
 def test_factory_builds_gnn_policy_with_reference_state_dict_keys():
     """`gnn` in the factory registry (neural_networks.py:1519-1536): five named MLPs, bias 5.0 on the output layer, and the
     reference's state-dict key layout (checkpoints interchange)."""
