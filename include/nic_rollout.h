@@ -324,7 +324,10 @@ typedef struct NicMlp3Seg {
 } NicMlp3Seg;
 typedef struct NicMlp3Desc {
     int32_t n_entities, n_scenarios, ldb;
-    int32_t K, n_out, out_act, n_segs, reserved;   /* K = sum of segment rows <= NIC_MLP3_MAX_K; n_out = 32 or 1..8 */
+    int32_t K, n_out, out_act, n_segs;   /* K = sum of segment rows <= NIC_MLP3_MAX_K; n_out = 32 or 1..8 */
+    int32_t hist_native;   /* 1: H1 / H2 are private to nic_mlp3_fwd / nic_mlp3_bwd_hist and kept as one contiguous [32 rows][32
+                              scenarios] block per (entity, 32-scenario chunk): block (e * ldb / 32 + chunk) of the buffer, 4 KB
+                              each - every history access of a wavefront is one DRAM page.  0: rows hist_row_stride apart */
     NicMlp3Seg seg[NIC_MLP3_MAX_SEGS];
     const float* weights;
     const float* weights_t;    /* the same weights transposed, read by the FORWARD kernel (lane i of contraction step k reads

@@ -77,7 +77,7 @@ class NicSegTerm(C.Structure):
 
 
 class NicMlp3Desc(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ("n_entities", "n_scenarios", "ldb", "K", "n_out", "out_act", "n_segs", "reserved")]
+    _fields_ = ([(n, C.c_int32) for n in ("n_entities", "n_scenarios", "ldb", "K", "n_out", "out_act", "n_segs", "hist_native")]
                 + [("seg", NicMlp3Seg * 4), ("weights", C.c_void_p), ("weights_t", C.c_void_p), ("hist_row_stride", C.c_int64)])
 
 

@@ -154,20 +154,29 @@ __global__ __launch_bounds__(64 * kFwdWaves) void mlp3_fwd_kernel(NicMlp3Desc d,
     }
     const bool full = (int64_t)(chunk + CH) * 32 <= d.n_scenarios;   // every lane of every chunk is a scenario
     const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;   // elements between feature rows of the [rows][E][ldb] buffers
-    const int64_t hs = d.hist_row_stride ? d.hist_row_stride : ent_ld;  // ... and of the history buffers
+    // ... and of the history buffers.  hist_native: H1 / H2 are private to the forward / backward pair of kernels and kept per
+    // (entity, 32-scenario chunk) as one contiguous [32 rows][32 scenarios] block (4 KB) instead of 32 pieces of 128 B that lie
+    // n_entities * ldb floats apart - same bytes, one DRAM page per wavefront access instead of 32
+    const bool nat = d.hist_native != 0;
+    const int64_t hs = nat ? 32 : (d.hist_row_stride ? d.hist_row_stride : ent_ld);
     // buffer addressing: descriptor base = column 0 of the wavefront's first chunk in row 0 of the entity; a lane adds
     // (4 h rows + its column) once, a store adds the row as a scalar
     constexpr bool BUF = ADDR != kAddrFlat;
     const int64_t col0 = (int64_t)e * d.ldb + (int64_t)chunk * 32;
+    const int64_t hcol0 = nat ? ((int64_t)e * (d.ldb / 32) + chunk) * 1024 : col0;
     auto rsrc_of = [](const float* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000); };
-    const __amdgpu_buffer_rsrc_t rH1 = rsrc_of(BUF && H1 ? H1 + col0 : wt), rH2 = rsrc_of(BUF && H2 ? H2 + col0 : wt),
+    const __amdgpu_buffer_rsrc_t rH1 = rsrc_of(BUF && H1 ? H1 + hcol0 : wt), rH2 = rsrc_of(BUF && H2 ? H2 + hcol0 : wt),
                                  rY = rsrc_of(BUF ? Y + col0 : wt), rYs = rsrc_of(BUF && Ysum ? Ysum + col0 : wt),
                                  rR = rsrc_of(BUF && Rsd ? Rsd + col0 : wt), rXh = rsrc_of(ADDR == kAddrBufX ? Xh + col0 : wt);
     const int hs4 = (int)hs * 4, el4 = (int)ent_ld * 4;
     const int vo_h = 4 * h * hs4, vo_e = 4 * h * el4, vo_x = h * hs4;
     int vc[CH];   // the lane's column inside the wavefront's chunks, in bytes (lanes past the last scenario: column 0, never stored)
+    int vch[CH];  // ... inside the history buffers (native: the next chunk is the next 4-KB block)
 #pragma unroll
-    for (int c = 0; c < CH; ++c) vc[c] = live[c] ? c * 128 + j * 4 : 0;
+    for (int c = 0; c < CH; ++c) {
+        vc[c] = live[c] ? c * 128 + j * 4 : 0;
+        vch[c] = nat ? (live[c] ? c * 4096 + j * 4 : 0) : vc[c];
+    }
     auto put = [](__amdgpu_buffer_rsrc_t r, float v, int voff, int soff) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
     };
@@ -242,8 +251,8 @@ __global__ __launch_bounds__(64 * kFwdWaves) void mlp3_fwd_kernel(NicMlp3Desc d,
             for (int r = 0; r < 16; ++r) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
-                    if (BUF) put(rH, hcur[c][r], vo_h + vc[c], ((r & 3) + 8 * (r >> 2)) * hs4);
-                    else H[(int64_t)crow(r, h) * hs + col[c]] = hcur[c][r];
+                    if (BUF) put(rH, hcur[c][r], vo_h + vch[c], ((r & 3) + 8 * (r >> 2)) * hs4);
+                    else H[(int64_t)crow(r, h) * hs + (nat ? hcol0 + c * 1024 + j : col[c])] = hcur[c][r];
                 }
             }
         } else {
@@ -252,8 +261,8 @@ __global__ __launch_bounds__(64 * kFwdWaves) void mlp3_fwd_kernel(NicMlp3Desc d,
                 if (live[c]) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if (BUF) put(rH, hcur[c][r], vo_h + vc[c], ((r & 3) + 8 * (r >> 2)) * hs4);
-                        else H[(int64_t)crow(r, h) * hs + col[c]] = hcur[c][r];
+                        if (BUF) put(rH, hcur[c][r], vo_h + vch[c], ((r & 3) + 8 * (r >> 2)) * hs4);
+                        else H[(int64_t)crow(r, h) * hs + (nat ? hcol0 + c * 1024 + j : col[c])] = hcur[c][r];
                     }
                 }
             }
@@ -724,7 +733,8 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, h = lane >> 5, i = j;
     float* tile = tiles + wv * kTile;
     const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;
-    const int64_t hs = d.hist_row_stride ? d.hist_row_stride : ent_ld;
+    const bool nat = d.hist_native != 0;   // H1 / H2 as one [32][32] block per (entity, chunk): see mlp3_fwd_kernel
+    const int64_t hs = nat ? 32 : (d.hist_row_stride ? d.hist_row_stride : ent_ld);
 
     f32x16 g1[KG], g2, g3;
     float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f;
@@ -812,8 +822,9 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
         const int64_t colbase = (int64_t)e * d.ldb + (int64_t)ch * 32;
         const bool live = (int64_t)ch * 32 + j < d.n_scenarios;
         const int jl = live ? j : 0;
-        const __amdgpu_buffer_rsrc_t rY = rsrc_of(Yo + colbase), rG = rsrc_of(dY + colbase), rH2 = rsrc_of(H2 + colbase),
-                                     rH1 = rsrc_of(H1 + colbase), rX = rsrc_of(GATHER ? H1 : Xh + colbase);
+        const int64_t hbase = nat ? ((int64_t)e * (d.ldb / 32) + ch) * 1024 : colbase;
+        const __amdgpu_buffer_rsrc_t rY = rsrc_of(Yo + colbase), rG = rsrc_of(dY + colbase), rH2 = rsrc_of(H2 + hbase),
+                                     rH1 = rsrc_of(H1 + hbase), rX = rsrc_of(GATHER ? H1 : Xh + colbase);
         // column-owner offsets: row crow(r, h) = (r & 3) + 8 (r >> 2) [scalar] + 4 h [lane]
         const int vo_h = (4 * h) * hs4_ + jl * 4, vo_e = (4 * h) * el4_ + jl * 4;
         const int vo_row = j * hs4_ + h * 64;                 // row-owner: row j, columns h*16 ..
@@ -1332,6 +1343,7 @@ int nic_mlp3_fwd_residual(const NicMlp3Desc* d, float* Y, float* X_hist, float* 
     NIC_REQUIRE((residual == nullptr) == (Ysum == nullptr), "nic_mlp3_fwd_residual: residual and Ysum go together");
     NIC_REQUIRE(Y, "nic_mlp3_fwd: null output");
     NIC_REQUIRE((!X_hist && !H1 && !H2) || (H1 && H2), "nic_mlp3_fwd: incomplete history buffers (H1 and H2 go together)");
+    NIC_REQUIRE(!(d->hist_native && X_hist), "nic_mlp3_fwd: the native history layout keeps H1 / H2 only (no X_hist)");
     NIC_REQUIRE(d->weights_t, "nic_mlp3_fwd: weights_t (the pre-transposed weight copy) is required");
     // Two adjacent chunks per wavefront when one chunk per wavefront is about one round of the chip's wavefront slots or less
     // (256 CUs x 4 SIMDs x 4-5 wavefronts of ~100 VGPRs): then the launch lasts as long as one wavefront's dependency chain, and
@@ -1374,6 +1386,7 @@ int nic_mlp3_bwd(const NicMlp3Desc* d, const float* dY, const float* Y, const fl
                  float* dZ1, float* dX, void* stream) {
     if (int e = validate(d, "nic_mlp3_bwd")) return e;
     NIC_REQUIRE(dY && Y && H1 && H2 && dZ3 && dZ2 && dZ1, "nic_mlp3_bwd: null buffer");
+    NIC_REQUIRE(!d->hist_native, "nic_mlp3_bwd: the stored-gradient backward reads H1 / H2 as GEMM operands (row layout only)");
     const dim3 grid(nic::ceil_div(d->n_scenarios, 32 * kWaves * kChunks), d->n_entities), block(64 * kWaves);
     hipStream_t s = nic::as_stream(stream);
     const int kg = (d->K + 31) / 32;
@@ -1414,6 +1427,7 @@ int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, con
                       float* dX, float* slab1, int64_t lds1, float* slab2, int64_t lds2, float* slab3, int64_t lds3, void* stream) {
     if (int e = validate(d, "nic_mlp3_bwd_hist")) return e;
     NIC_REQUIRE(dY && Y && H1 && H2 && slab1 && slab2 && slab3, "nic_mlp3_bwd_hist: null buffer");
+    NIC_REQUIRE(!(d->hist_native && X_hist), "nic_mlp3_bwd_hist: the native history layout re-gathers the inputs (no X_hist)");
     NIC_REQUIRE(lds1 >= d->K + 1 && lds2 >= 33 && lds3 >= 33, "nic_mlp3_bwd_hist: slab rows too short");
     const int64_t hs = d->hist_row_stride ? d->hist_row_stride : (int64_t)d->n_entities * d->ldb;
     NIC_REQUIRE(hs % 4 == 0 && (reinterpret_cast<uintptr_t>(X_hist) & 15) == 0 && (reinterpret_cast<uintptr_t>(H1) & 15) == 0 &&

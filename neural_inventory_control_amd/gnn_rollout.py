@@ -130,6 +130,7 @@ class _Mlp:
         self.Y = z(T, n_out, n_ent, ld)
         self.P, self.G = P, (T + P - 1) // P
         self.hist_stride = 0
+        self.native = False
         self.mode = mode if train else None     # "hist" | "gemm" | "fused" (see GnnRollout.fused_bwd)
         self.fused_bwd = mode == "fused"
         dims = [(32, K), (32, 32), (n_out, 32)]
@@ -140,7 +141,12 @@ class _Mlp:
             self.hist_stride = P * n_ent * ld
             G = self.G
             self.X = z(G, K, P, n_ent, ld) if keep_inputs else None
-            self.H1, self.H2 = z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld)
+            # without the stored inputs the hidden activations are private to the forward / backward kernels of this MLP: kept
+            # in the kernels' native order, [period][entity x chunk][32 rows][32 scenarios] (one 4-KB block per wavefront access
+            # instead of 32 pieces of 128 B spread over the buffer); same size
+            self.native = not keep_inputs
+            self.H1, self.H2 = (z(G, P, 32 * n_ent * ld), z(G, P, 32 * n_ent * ld)) if self.native else \
+                               (z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld))
             self.slabs = [z(ops.mlp3_bwd_hist_slots(), n, (k + 1 + 3) // 4 * 4) for n, k in dims]
             self.dX = z(K, n_ent, ld)
             self.gw = [torch.zeros_like(m.weight) for m in linears]
@@ -168,7 +174,10 @@ class _Mlp:
             self.gb = [torch.zeros_like(m.bias) for m in linears]
 
     def hist(self, buf, t):
-        """[rows][entity][ldb] view of period t inside a grouped history buffer (row stride = hist_stride)."""
+        """[rows][entity][ldb] view of period t inside a grouped history buffer (row stride = hist_stride); the native hidden
+        histories: period t's block."""
+        if self.native and buf is not self.X:
+            return buf[t // self.P, t % self.P]
         return buf[t // self.P, :, t % self.P]
 
     def pack(self):
@@ -418,7 +427,8 @@ class GnnRollout:
                 ops.wgrad_reduce(m.slabs[i], m.gw[i], m.gb[i], lin.weight.shape[1], 1.0)
 
     def _desc(self, m, segs, prob):
-        return ops.mlp3_desc(segs, m.packed, m.n_ent, prob.B, prob.ldb, m.n_out, m.out_act, m.hist_stride, m.packed_t)
+        return ops.mlp3_desc(segs, m.packed, m.n_ent, prob.B, prob.ldb, m.n_out, m.out_act, m.hist_stride, m.packed_t,
+                             hist_native=m.native)
 
     def _segments(self, t):
         """Input segments of the five MLPs at period t (the graph's gathers; no concatenation is materialised)."""
