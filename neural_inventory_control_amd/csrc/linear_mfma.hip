@@ -905,8 +905,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
             advance();
         }
     };
-    constexpr int TPR = BN / 4, RPI = NTHREADS / TPR, ITER = PASS_ROWS / RPI;
+    // threads per output row, rounded up to a power of two (BN = 448: 112 -> 128, the last 16 threads of a row group idle)
+    constexpr int TPR_USED = BN / 4;
+    constexpr int TPR = TPR_USED <= 16 ? 16 : TPR_USED <= 32 ? 32 : TPR_USED <= 64 ? 64 : 128;
+    constexpr int RPI = NTHREADS / TPR, ITER = PASS_ROWS / RPI;
+    static_assert(TPR_USED <= 128 && PASS_ROWS % RPI == 0, "epilogue row groups must tile the pass");
     const int tt = threadIdx.x;
+    const bool col_thread = (tt % TPR) < TPR_USED;
     const int col = k0 + (tt % TPR) * 4;
     float* cs = lds;
     auto flush = [&]() {  // slab += accumulators (all waves; uses the whole staging area, so no copy may be in flight)
@@ -938,7 +943,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
             for (int it = 0; it < ITER; ++it) {
                 const int row_l = tt / TPR + RPI * it;
                 const int row = n0 + pass * PASS_ROWS + row_l;
-                if (row >= p.N || col >= p.K) continue;
+                if (row >= p.N || col >= p.K || !col_thread) continue;
                 const float4 y = *reinterpret_cast<const float4*>(cs + row_l * LDC + (tt % TPR) * 4);
                 float* dst = slab + (int64_t)row * p.lds_ + col;
                 if (col + 3 < p.K && (p.lds_ & 3) == 0) {
@@ -1271,6 +1276,7 @@ void wgrad_tile(int N, int K, int* bm, int* bn) {
 // big layers: 256 x 256 LDS-DMA tiles, one workgroup per CU
 bool wgrad_big(int N, int K) { return N >= 192 && K >= 192; }
 bool wgrad_tall(int N, int K);
+bool wgrad_wide(int N, int K);
 
 // tall, narrow layers (the first layer: 512 x 51): ONE 512 x 64 output tile per scenario chunk, so dZ is read exactly once
 // (the 128 x 64 register-staged tiles read it 1.3 x) by the LDS-DMA pipeline; HBM-bound
@@ -1283,9 +1289,14 @@ void launch_wg_dma(const WgParams& p, int n_splits, hipStream_t s) {
     nic::note_kernelf(SKIP ? "gemm_wgrad_dma_kernel<%d,%d,%d,%d,skip>" : "gemm_wgrad_dma_kernel<%d,%d,%d,%d>", WM, WN, MT, NT);
     hipLaunchKernelGGL((gemm_wgrad_dma_kernel<WM, WN, MT, NT, SKIP>), grid, dim3(64 * WM * WN), 0, s, p);
 }
+// K in (384, 448] (cfg5's 393-wide first hidden layer input): ONE 448-column tile covers it (88 % of the tile's columns used)
+// where two 256-column tiles compute 512 (77 %); 128 x 448 keeps the 112 accumulator registers of the 7-tile wx kernel
+bool wgrad_wide(int N, int K) { return wgrad_big(N, K) && K > 384 && K <= 448 && N % 128 == 0; }
+
 // the LDS-DMA weight-gradient kernel for a shape (wgrad_big or wgrad_tall)
 void launch_wg_dma_for(const WgParams& p, int n_splits, hipStream_t s) {
     if (wgrad_tall(p.N, p.K)) launch_wg_dma<8, 1, 2, 2>(p, n_splits, s);
+    else if (wgrad_wide(p.N, p.K)) launch_wg_dma<4, 2, 1, 7>(p, n_splits, s);
     else if ((p.N + 255) / 256 * 256 - p.N >= 32) launch_wg_dma<2, 4, 4, 2, true>(p, n_splits, s);  // an empty row tile to skip
     else launch_wg_dma<2, 4, 4, 2>(p, n_splits, s);
 }
@@ -1332,7 +1343,10 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
     wgrad_tile(N, K, &bm, &bn);
     int tiles = ((N + bm - 1) / bm) * ((K + 1 + bn - 1) / bn);
     int target = 1024;                                 // ~4 workgroups per CU in total
-    if (wgrad_big(N, K)) {                             // 256 x 256 tiles, one workgroup per CU, one round
+    if (wgrad_wide(N, K)) {                            // 128 x 448 tiles, one workgroup per CU, one round
+        tiles = (N + 127) / 128;
+        target = 256;
+    } else if (wgrad_big(N, K)) {                      // 256 x 256 tiles, one workgroup per CU, one round
         tiles = ((N + 255) / 256) * ((K + 255) / 256);
         target = 256;
     } else if (wgrad_tall(N, K)) {                     // 512 x 64 tiles (LDS-DMA), one workgroup per CU
