@@ -73,8 +73,6 @@ class GraphPlan:
         supplier_edges = set(range(n_int, n_int + n_sup))
         inc = [[e for e in range(self.n_edges) if tgt[e] == n and e not in demand_edges] for n in range(self.n_nodes)]
         out = [[e for e in range(self.n_edges) if src[e] == n and e not in supplier_edges] for n in range(self.n_nodes)]
-        self.inc_off, self.inc_items = _csr(inc, device)
-        self.out_off, self.out_items = _csr(out, device)
         # both aggregations as ONE segment sum into a [rows][2 * n_nodes][ldb] buffer (incoming sums first, then outgoing)
         self.agg_off, self.agg_items = _csr(inc + out, device)
         self.in_scale = torch.tensor([1.0 / max(d, 1) ** 0.5 for d in in_deg], device=device)
@@ -116,7 +114,6 @@ class GraphPlan:
         for w in range(Wn):
             order_row[n_int + w] = S * Wn + w
         self.order_row = i32(order_row)
-        self.max_in = max(seen) if seen else 0
         self.transshipment = bool(transshipment)
 
 
