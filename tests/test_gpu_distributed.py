@@ -66,12 +66,13 @@ def test_training_over_a_one_rank_rccl_group_equals_no_group():
     assert abs(single["test_loss"] - forced["test_loss"]) <= 1e-6 * abs(single["test_loss"]), (single, forced)
 
 
-@pytest.mark.parametrize("workload", ["cfg2", "cfg3", "base_stock", "gnn"])
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3", "base_stock", "gnn", "gnn_many_warehouses", "real_data_driven"])
 def test_bench_over_a_one_rank_rccl_group(workload):
     """`bench.py`'s multi-GPU leg (broadcast, reducer inside the timed step, barrier + MAX-over-ranks clock) on RCCL."""
     root = os.path.dirname(HERE)
+    size = ["--scenarios", "48", "--periods", "12"] if workload == "real_data_driven" else ["--scenarios", "2048", "--periods", "12"]
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--scenarios", "2048", "--periods", "12"]
+           "--no-cpu-baseline"] + size
     outs = []
     for extra in ({}, {"NIC_DIST_FORCE_INIT": "1", "MASTER_PORT": "29557"}):
         r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **extra), timeout=600, cwd=root)
