@@ -188,6 +188,48 @@ def test_data_driven_engine_matches_reference(name):
     _check_grads(model, g, GRAD_TOL)
 
 
+def test_data_driven_engine_graph_replay_and_discrete_evaluation():
+    """The data_driven engine's launch sequence replayed from HIP graphs (the observation rows are written outside the
+    captured region): same totals and gradients as eager launches, also after the batch contents change; and evaluation with
+    discrete allocation (orders rounded half to even between head and env step, trainer.py:201-202) against the oracle."""
+    from oracle import inventory_oracle as orc
+    g = Golden("f4_real_many_warehouses_data_driven")
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    data2 = dict(data)
+    data2["demands"] = (data["demands"] * 1.2 + 0.5).contiguous()
+    out = {}
+    for mode in ("eager", "graph"):
+        model = _model(g, c)
+        eng = FusedRollout(model, c["problem_params"], DEV)
+        eng.use_graph = mode == "graph"
+        eng.materialize(eng.input_rows(data, c["observation_params"]))
+        _load(model, g)
+        res = []
+        for d in (data, data2, data):
+            total, rep = eng.run(d, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+            torch.cuda.synchronize()
+            res.append((float(total), float(rep), [p.grad.clone() for p in model.parameters()]))
+        out[mode] = res
+        if mode == "graph":
+            assert len(eng._graphs) == 2
+    for a, b in zip(out["eager"], out["graph"]):
+        assert a[0] == b[0] and a[1] == b[1]
+        for x, y in zip(a[2], b[2]):
+            assert torch.equal(x, y)
+    assert out["eager"][0][0] != out["eager"][1][0] and out["eager"][0][0] == out["eager"][2][0]
+    with torch.no_grad():
+        total, reported = eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"],
+                                  discrete_allocation=True)
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"], g.tensor("warehouse_upper_bound"))
+    with torch.no_grad():
+        ref = orc.rollout(pol, c["periods"], c["problem_params"], g.data, c["observation_params"], c["ignore"],
+                          discrete_allocation=True)
+    assert abs(float(total) - float(ref.total)) <= 1e-5 * abs(float(ref.total))
+    assert abs(float(reported) - float(ref.reported)) <= 1e-5 * abs(float(ref.reported))
+    assert float(total) != out["eager"][0][0]
+
+
 def test_data_driven_epochs_engine_follows_generic_route():
     """Two training epochs + an evaluation pass of the real-data setting's shape (synthetic stand-in files, 21 stores x 3
     warehouses, past-demand window of 16, datasets split by period) through `Trainer.do_one_epoch` with ragged batches (16, 16, 8
@@ -1191,12 +1233,13 @@ def test_gnn_fused_rollout_matches_reference(name, fused_bwd):
         assert float((named[k].grad.cpu() - r).norm() / (r.norm() + 1e-30)) <= GRAD_TOL, k
 
 
-def test_gnn_graph_replay_matches_eager():
+@pytest.mark.parametrize("name", ["f1_one_warehouse_gnn", "f1_many_warehouses_3x8_dense_gnn"])
+def test_gnn_graph_replay_matches_eager(name):
     """The GNN engine's launch sequence (fused MLP launches, segment sums, the small allocation ops, env steps, the batched
     weight gradients) captured into HIP graphs and replayed: same costs and gradients as eager launches, also after the batch
     contents change."""
     from neural_inventory_control_amd.gnn_rollout import GnnRollout
-    g = Golden("f1_one_warehouse_gnn")
+    g = Golden(name)
     c = g.fresh_config()
     data = {k: v.to(DEV) for k, v in g.data.items()}
     data2 = dict(data)
