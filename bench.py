@@ -495,7 +495,7 @@ def main():
                          We=data["initial_echelon_inventories"].shape[2] if E_ else 0,
                          F=0 if (closed_form or gnn) else eng.dims[0], nh=0 if (closed_form or gnn) else len(eng.dims) - 2,
                          n_out=0 if (closed_form or gnn) else eng.dims[-1], train=not args.eval,
-                         gnn={m.name: (m.K, m.n_out, m.n_ent, getattr(m, "fold_rows", 0)) for m in eng.mlp.values()} if gnn else None)
+                         gnn={m.name: (m.K, m.n_out, m.n_live, getattr(m, "fold_rows", 0)) for m in eng.mlp.values()} if gnn else None)
             kernels = kernel_report(timer, shape, args.steps)
             rated = {k: v for k, v in kernels.items() if "bound" in v}
             if rated:

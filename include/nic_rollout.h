@@ -335,6 +335,9 @@ typedef struct NicMlp3Desc {
                                   zero][b3 padded to 32].  `weights` (natural layout) is what the backward kernel reads. */
     int64_t hist_row_stride;   /* elements between feature rows of X_hist / H1 / H2 / dZ*; 0 = n_entities * ldb.  A larger stride
                                   interleaves several periods in one row so that a weight gradient contracts over all of them */
+    int64_t ent_row_stride;    /* elements between feature rows of Y / Ysum / residual / dY / dX; 0 = n_entities * ldb.  A larger
+                                  stride evaluates the MLP for the FIRST n_entities entities of buffers that hold more (the GNN's
+                                  edge update / output MLPs skip the demand edges, whose results nothing reads) */
 } NicMlp3Desc;
 /* Y [n_out][n_entities][ldb] = out_act(MLP(x)).  When X_hist != NULL the gathered inputs and the hidden activations are kept
  * for the backward / weight gradients: X_hist [K][n_entities][ldb], H1, H2 [32][n_entities][ldb] (post-ELU), rows

@@ -78,7 +78,8 @@ class NicSegTerm(C.Structure):
 
 class NicMlp3Desc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("n_entities", "n_scenarios", "ldb", "K", "n_out", "out_act", "n_segs", "hist_native")]
-                + [("seg", NicMlp3Seg * 4), ("weights", C.c_void_p), ("weights_t", C.c_void_p), ("hist_row_stride", C.c_int64)])
+                + [("seg", NicMlp3Seg * 4), ("weights", C.c_void_p), ("weights_t", C.c_void_p), ("hist_row_stride", C.c_int64),
+                   ("ent_row_stride", C.c_int64)])
 
 
 NIC_MLP3_MAX_K, NIC_MLP3_ACT_NONE, NIC_MLP3_ACT_ELU, NIC_MLP3_ACT_SOFTPLUS = 96, 0, 1, 2

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void mlp3_fwd_kernel(NicMlp3Desc d,
         col[c] = (int64_t)e * d.ldb + b[c];
     }
     const bool full = (int64_t)(chunk + CH) * 32 <= d.n_scenarios;   // every lane of every chunk is a scenario
-    const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;   // elements between feature rows of the [rows][E][ldb] buffers
+    const int64_t ent_ld = d.ent_row_stride ? d.ent_row_stride : (int64_t)d.n_entities * d.ldb;   // elements between feature rows of the [rows][E][ldb] buffers
     // ... and of the history buffers.  hist_native: H1 / H2 are private to the forward / backward pair of kernels and kept per
     // (entity, 32-scenario chunk) as one contiguous [32 rows][32 scenarios] block (4 KB) instead of 32 pieces of 128 B that lie
     // n_entities * ldb floats apart - same bytes, one DRAM page per wavefront access instead of 32
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(3, 
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5, i = j;
     const int e = blockIdx.y;
-    const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;
+    const int64_t ent_ld = d.ent_row_stride ? d.ent_row_stride : (int64_t)d.n_entities * d.ldb;
     const int64_t hs = d.hist_row_stride ? d.hist_row_stride : ent_ld;
 #pragma unroll 1
     for (int c = 0; c < kChunks; ++c) {
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_e
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5, i = j;
     float* tile = tiles + wv * kTile;
     const int K = d.K;
-    const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;
+    const int64_t ent_ld = d.ent_row_stride ? d.ent_row_stride : (int64_t)d.n_entities * d.ldb;
     {
         const float* T = wt;                     // [W1^T K x 32][b1][W2^T][b2]...
         const float* T2 = T + K * 32 + 32;
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64 * kHistWaves) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, h = lane >> 5, i = j;
     float* tile = tiles + wv * kTile;
-    const int64_t ent_ld = (int64_t)d.n_entities * d.ldb;
+    const int64_t ent_ld = d.ent_row_stride ? d.ent_row_stride : (int64_t)d.n_entities * d.ldb;
     const bool nat = d.hist_native != 0;   // H1 / H2 as one [32][32] block per (entity, chunk): see mlp3_fwd_kernel
     const int64_t hs = nat ? 32 : (d.hist_row_stride ? d.hist_row_stride : ent_ld);
 
@@ -1315,6 +1315,8 @@ int validate(const NicMlp3Desc* d, const char* who) {
     NIC_REQUIRE(d && d->weights, "%s: null descriptor / weights", who);
     NIC_REQUIRE(d->n_entities > 0 && d->n_scenarios > 0 && d->ldb >= d->n_scenarios && d->ldb % 32 == 0,
                 "%s: bad sizes (ldb must be a multiple of 32 and >= n_scenarios)", who);
+    NIC_REQUIRE(d->ent_row_stride == 0 || d->ent_row_stride >= (int64_t)d->n_entities * d->ldb,
+                "%s: ent_row_stride shorter than n_entities * ldb", who);
     NIC_REQUIRE(d->K >= 1 && d->K <= NIC_MLP3_MAX_K, "%s: K (%d) must be 1..%d", who, d->K, NIC_MLP3_MAX_K);
     NIC_REQUIRE(d->n_out >= 1 && d->n_out <= 32, "%s: n_out (%d) must be 1..32", who, d->n_out);
     NIC_REQUIRE(d->out_act >= NIC_MLP3_ACT_NONE && d->out_act <= NIC_MLP3_ACT_SOFTPLUS, "%s: unknown output activation", who);
@@ -1357,9 +1359,9 @@ int nic_mlp3_fwd_residual(const NicMlp3Desc* d, float* Y, float* X_hist, float* 
     const int ks = (d->K + 1) / 2;
     const int t = ks <= 4 ? 4 : (ks <= 16 ? 16 : (ks <= 33 ? 33 : 48));
     // 32-bit row offsets whenever every buffer's rows span < 2 GiB (always at the sizes this engine allocates)
-    const int64_t hs = d->hist_row_stride ? d->hist_row_stride : (int64_t)d->n_entities * d->ldb;
+    const int64_t hs = d->hist_row_stride ? d->hist_row_stride : (d->ent_row_stride ? d->ent_row_stride : (int64_t)d->n_entities * d->ldb);
     const int64_t top = 2 * (int64_t)((d->K + 1) / 2) + 32;
-    const bool fits = top * hs * 4 < (1ll << 31) && top * d->n_entities * d->ldb * 4 < (1ll << 31);
+    const bool fits = top * hs * 4 < (1ll << 31) && top * (d->ent_row_stride ? d->ent_row_stride : (int64_t)d->n_entities * d->ldb) * 4 < (1ll << 31);
     const int addr = !fits ? kAddrFlat : (X_hist ? kAddrBufX : kAddrBuf);
     nic::note_kernelf("mlp3_fwd_kernel<%d,%d,%d>", t, ch, addr);
 #define NIC_MLP3_FWD2(KS, CH_)                                                                                                   \
@@ -1429,7 +1431,7 @@ int nic_mlp3_bwd_hist(const NicMlp3Desc* d, const float* dY, const float* Y, con
     NIC_REQUIRE(dY && Y && H1 && H2 && slab1 && slab2 && slab3, "nic_mlp3_bwd_hist: null buffer");
     NIC_REQUIRE(!(d->hist_native && X_hist), "nic_mlp3_bwd_hist: the native history layout re-gathers the inputs (no X_hist)");
     NIC_REQUIRE(lds1 >= d->K + 1 && lds2 >= 33 && lds3 >= 33, "nic_mlp3_bwd_hist: slab rows too short");
-    const int64_t hs = d->hist_row_stride ? d->hist_row_stride : (int64_t)d->n_entities * d->ldb;
+    const int64_t hs = d->hist_row_stride ? d->hist_row_stride : (d->ent_row_stride ? d->ent_row_stride : (int64_t)d->n_entities * d->ldb);
     NIC_REQUIRE(hs % 4 == 0 && (reinterpret_cast<uintptr_t>(X_hist) & 15) == 0 && (reinterpret_cast<uintptr_t>(H1) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(H2) & 15) == 0,
                 "nic_mlp3_bwd_hist: history rows must be 16-byte aligned");

@@ -12,8 +12,9 @@ gradients with the stored inputs (`nic_linear_wgrad`, slabs accumulated over the
 edges (:1229-1269) and nodes (:1474-1490) become launches over all scenarios at once; ~60 launches per period instead of ~380.
 
 Everything is feature-major `[rows][entity][ldb]`.  Nodes = [warehouses..., stores...]; edges = [internal (warehouse -> store,
-warehouse-major), supplier edges of the warehouses, demand edges of the stores, self loops of the supplying warehouses] — the
-reference's order, so sums over a node's edges associate exactly as upstream.
+warehouse-major), supplier edges of the warehouses, self loops of the supplying warehouses, demand edges of the stores].  That is
+the reference's order with the demand edges moved to the end: the edge-update and output MLPs skip them (nothing reads what
+they would compute there), and every sum over a node's edges still adds them in the reference's order (`GraphPlan`).
 """
 import torch
 
@@ -36,8 +37,8 @@ def _csr(lists, device):
 class GraphPlan:
     """Static structure of the warehouse -> store supply graph (neural_networks.py:757-1062) as device index tensors.
     `conn` [W][S] = the setting's `warehouse_store_adjacency` (one warehouse: all ones).  Nodes = [warehouses..., stores...],
-    internal edges warehouse-major (the order of `adjacency.nonzero()`), then one supplier edge per warehouse, one demand edge per
-    store, one self loop per warehouse that supplies somebody (none under transshipment)."""
+    internal edges warehouse-major (the order of `adjacency.nonzero()`), then one supplier edge per warehouse, one self loop per
+    warehouse that supplies somebody (none under transshipment), one demand edge per store (see __init__ on that order)."""
 
     def __init__(self, S, conn, transshipment, device):
         Wn = len(conn)
@@ -47,13 +48,27 @@ class GraphPlan:
         self.n_int = n_int
         out_int = [sum(1 for a, _ in internal if a == w) for w in range(Wn)]
         supplying = [] if transshipment else [w for w in range(Wn) if out_int[w] > 0]
-        self.n_self = len(supplying)
-        self.n_edges = n_int + n_sup + n_dem + self.n_self
-        src = [a for a, _ in internal] + [-1] * n_sup + [Wn + s for s in range(S)] + supplying
-        tgt = [b for _, b in internal] + list(range(Wn)) + [-1] * n_dem + supplying
+        n_self = self.n_self = len(supplying)
+        E = self.n_edges = n_int + n_sup + n_dem + n_self
+        # The reference's edge order is [internal, supplier, demand, self loops].  The engine keeps the demand edges LAST: what
+        # the edge-update and output MLPs compute for them is read by nothing (one message-passing step: their updated embedding
+        # only feeds the output MLP, and a demand edge's output is no action), so those two MLPs - forward and backward - run on
+        # the first `n_live` edges only.  Every sum over a node's edges still adds them in the REFERENCE's order (the lists below
+        # are built in that order and then renamed).
+        r_src = [a for a, _ in internal] + [-1] * n_sup + [Wn + s for s in range(S)] + supplying
+        r_tgt = [b for _, b in internal] + list(range(Wn)) + [-1] * n_dem + supplying
+        r_demand = set(range(n_int + n_sup, n_int + n_sup + n_dem))
+        r_supplier = set(range(n_int, n_int + n_sup))
+        eng = list(range(n_int + n_sup)) + [n_int + n_sup + n_self + s for s in range(n_dem)] + \
+              [n_int + n_sup + k for k in range(n_self)]                   # reference edge id -> engine edge id
+        ref = [0] * E
+        for r_, e_ in enumerate(eng):
+            ref[e_] = r_
+        src, tgt = [r_src[ref[e]] for e in range(E)], [r_tgt[ref[e]] for e in range(E)]
+        self.n_live = n_int + n_sup + n_self
         self.e_supplier = n_int                                            # (of warehouse 0; warehouse w: n_int + w)
-        self.e_self = n_int + n_sup + n_dem if self.n_self else None       # (of the first supplying warehouse)
-        self.e_demand = n_int + n_sup
+        self.e_self = n_int + n_sup if n_self else None                    # (of the first supplying warehouse)
+        self.e_demand = self.n_live
         in_deg, out_deg = [0] * self.n_nodes, [0] * self.n_nodes
         for a, b in internal:
             out_deg[a] += 1
@@ -68,35 +83,38 @@ class GraphPlan:
         i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)  # noqa: E731
         self.src, self.tgt = i32(src), i32(tgt)
         # message aggregation (:1229-1296): a node sums the edges it is the target of (demand edges have no real target) /
-        # the source of (supplier edges have no real source), in edge order, then divides by sqrt(degree)
-        demand_edges = set(range(n_int + n_sup, n_int + n_sup + n_dem))
-        supplier_edges = set(range(n_int, n_int + n_sup))
-        inc = [[e for e in range(self.n_edges) if tgt[e] == n and e not in demand_edges] for n in range(self.n_nodes)]
-        out = [[e for e in range(self.n_edges) if src[e] == n and e not in supplier_edges] for n in range(self.n_nodes)]
+        # the source of (supplier edges have no real source), in (reference) edge order, then divides by sqrt(degree)
+        inc = [[eng[r] for r in range(E) if r_tgt[r] == n and r not in r_demand] for n in range(self.n_nodes)]
+        out = [[eng[r] for r in range(E) if r_src[r] == n and r not in r_supplier] for n in range(self.n_nodes)]
         # both aggregations as ONE segment sum into a [rows][2 * n_nodes][ldb] buffer (incoming sums first, then outgoing)
         self.agg_off, self.agg_items = _csr(inc + out, device)
         self.in_scale = torch.tensor([1.0 / max(d, 1) ** 0.5 for d in in_deg], device=device)
         self.out_scale = torch.tensor([1.0 / max(d, 1) ** 0.5 for d in out_deg], device=device)
         self.agg_scale = torch.cat([self.in_scale, self.out_scale])
         # adjoints of the aggregation: edge e receives from its target's `incoming` / its source's `outgoing` gradient
-        self.e_from_tgt = _csr([[tgt[e]] if (tgt[e] >= 0 and e not in demand_edges) else [] for e in range(self.n_edges)], device)
-        self.e_from_src = _csr([[src[e]] if (src[e] >= 0 and e not in supplier_edges) else [] for e in range(self.n_edges)], device)
-        self.e_in_scale = torch.tensor([self.in_scale[tgt[e]].item() if tgt[e] >= 0 else 0.0 for e in range(self.n_edges)],
-                                       device=device)
-        self.e_out_scale = torch.tensor([self.out_scale[src[e]].item() if src[e] >= 0 else 0.0 for e in range(self.n_edges)],
-                                        device=device)
+        is_demand = [ref[e] in r_demand for e in range(E)]
+        is_supplier = [ref[e] in r_supplier for e in range(E)]
+        self.e_from_tgt = _csr([[tgt[e]] if (tgt[e] >= 0 and not is_demand[e]) else [] for e in range(E)], device)
+        self.e_from_src = _csr([[src[e]] if (src[e] >= 0 and not is_supplier[e]) else [] for e in range(E)], device)
+        self.e_in_scale = torch.tensor([self.in_scale[tgt[e]].item() if tgt[e] >= 0 else 0.0 for e in range(E)], device=device)
+        self.e_out_scale = torch.tensor([self.out_scale[src[e]].item() if src[e] >= 0 else 0.0 for e in range(E)], device=device)
         # adjoints of the endpoint gathers: node n receives from the edges it is the source / target of
-        self.n_as_src = _csr([[e for e in range(self.n_edges) if src[e] == n] for n in range(self.n_nodes)], device)
-        self.n_as_tgt = _csr([[e for e in range(self.n_edges) if tgt[e] == n] for n in range(self.n_nodes)], device)
-        # per-edge constant input row: lead time of internal / supplier edges, 0 for demand edges and self loops; refreshed on
+        self.n_as_src = _csr([[eng[r] for r in range(E) if r_src[r] == n] for n in range(self.n_nodes)], device)
+        self.n_as_tgt = _csr([[eng[r] for r in range(E) if r_tgt[r] == n] for n in range(self.n_nodes)], device)
+        # ... of the edge-update MLP, which leaves the demand edges out: their input-gradient rows are exact zeros upstream
+        self.n_as_src_live = _csr([[eng[r] for r in range(E) if r_src[r] == n and r not in r_demand]
+                                   for n in range(self.n_nodes)], device)
+        self.n_as_tgt_live = _csr([[eng[r] for r in range(E) if r_tgt[r] == n and r not in r_demand]
+                                   for n in range(self.n_nodes)], device)
+        # per-edge constant input row: lead time of internal / supplier edges, 0 for self loops and demand edges; refreshed on
         # the device from every batch's lead-time tensors through these two index lists (GnnRollout.run)
-        self.lead = torch.zeros(1, self.n_edges, dtype=torch.float32, device=device)
+        self.lead = torch.zeros(1, E, dtype=torch.float32, device=device)
         self.lead_store = torch.tensor([b - Wn for _, b in internal], dtype=torch.long, device=device)
         self.lead_wh = torch.tensor([a for a, _ in internal], dtype=torch.long, device=device)
         # proportional allocation groups (:1435-1492): a warehouse's internal edges (contiguous) + its self loop
         first, groups = 0, []
         for w in range(Wn):
-            e_self = n_int + n_sup + n_dem + supplying.index(w) if w in supplying else -1
+            e_self = n_int + n_sup + supplying.index(w) if w in supplying else -1
             groups.append([first, out_int[w], e_self, n_int + w])
             first += out_int[w]
         self.groups = i32(groups)
@@ -104,7 +122,7 @@ class GraphPlan:
         # column j (:1423-1428) - for a store that is not connected to every warehouse this is not the column of the warehouse
         # the edge comes from (the env step reads lead time and shipment source by column).  Reproduced as is: it is what the
         # reference computes and what the fixtures pin; `misplaced` lists the (store, column, warehouse) triples it affects.
-        order_row, seen, self.misplaced = [-1] * self.n_edges, [0] * S, []
+        order_row, seen, self.misplaced = [-1] * E, [0] * S, []
         for e, (a, b) in enumerate(internal):
             s_ = b - Wn
             order_row[e] = s_ * Wn + seen[s_]
@@ -120,8 +138,10 @@ class GraphPlan:
 class _Mlp:
     """Packed weights, gradient slabs and per-period history of one of the policy's five MLPs."""
 
-    def __init__(self, name, linears, K, n_out, out_act, n_ent, ld, T, P, device, train, mode="hist", keep_inputs=True):
+    def __init__(self, name, linears, K, n_out, out_act, n_ent, ld, T, P, device, train, mode="hist", keep_inputs=True,
+                 n_live=None):
         self.name, self.linears, self.K, self.n_out, self.out_act, self.n_ent = name, linears, K, n_out, out_act, n_ent
+        self.n_live = n_ent if n_live is None else n_live   # entities the MLP is evaluated for (the first n_live of its buffers)
         z = lambda *s: torch.zeros(*s, device=device)  # noqa: E731
         self.packed = z(32 * K + 32 + 32 * 32 + 32 + n_out * 32 + n_out)
         self.Y = z(T, n_out, n_ent, ld)
@@ -289,7 +309,8 @@ class GnnRollout:
         self._fused_bwd_now = self._mode_now == "fused"
         self.mlp = {name: _Mlp(name, self._linears(name), k, 1 if name == "output" else 32,
                                A.NIC_MLP3_ACT_SOFTPLUS if name == "output" else A.NIC_MLP3_ACT_ELU, ne, ld, T, P_, dev, train,
-                               self._mode_now, self._keep_inputs and bool(self.keep_inputs))
+                               self._mode_now, self._keep_inputs and bool(self.keep_inputs),
+                               n_live=P.n_live if name in ("edge_update", "output") else None)
                     for name, k, ne in zip(MODULES, ks, ents)}
         self._graphs, self._eager_runs = {}, 0
         self.agg = z(T, 32, 2 * N, ld)   # message aggregation: [:, :N] over incoming edges, [:, N:] over outgoing edges
@@ -424,8 +445,8 @@ class GnnRollout:
                 ops.wgrad_reduce(m.slabs[i], m.gw[i], m.gb[i], lin.weight.shape[1], 1.0)
 
     def _desc(self, m, segs, prob):
-        return ops.mlp3_desc(segs, m.packed, m.n_ent, prob.B, prob.ldb, m.n_out, m.out_act, m.hist_stride, m.packed_t,
-                             hist_native=m.native)
+        return ops.mlp3_desc(segs, m.packed, m.n_live, prob.B, prob.ldb, m.n_out, m.out_act, m.hist_stride, m.packed_t,
+                             hist_native=m.native, ent_row_stride=m.n_ent * prob.ldb if m.n_live != m.n_ent else 0)
 
     def _segments(self, t):
         """Input segments of the five MLPs at period t (the graph's gathers; no concatenation is materialised)."""
@@ -497,7 +518,7 @@ class GnnRollout:
         # endpoint gathers and of the message aggregation are sums of segment sums: one multi-term launch per destination.
         eu = M["edge_update"]
         self._mlp_bwd(eu, t, segs, prob, self.d_edges1)
-        ops.segment_sum_terms(self.d_nodes1, [(eu.dX[32:64], *P.n_as_src, None), (eu.dX[64:96], *P.n_as_tgt, None)])
+        ops.segment_sum_terms(self.d_nodes1, [(eu.dX[32:64], *P.n_as_src_live, None), (eu.dX[64:96], *P.n_as_tgt_live, None)])
         # nodes1 = nodes0 + node_update(nodes0, incoming, outgoing)
         nu = M["node_update"]
         self._mlp_bwd(nu, t, segs, prob, self.d_nodes1)

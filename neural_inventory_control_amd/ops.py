@@ -224,10 +224,11 @@ def mlp3_pack_transposed(linears_or_tensors, n_out):
 
 
 def mlp3_desc(segments, weights, n_entities, n_scenarios, ldb, n_out, out_act, hist_row_stride=0, weights_t=None,
-              hist_native=False):
+              hist_native=False, ent_row_stride=0):
     d = _lib.NicMlp3Desc()
     d.hist_row_stride = int(hist_row_stride)
     d.hist_native = int(bool(hist_native))
+    d.ent_row_stride = int(ent_row_stride)
     d.weights_t = weights_t.data_ptr() if weights_t is not None else None
     d.n_entities, d.n_scenarios, d.ldb = n_entities, n_scenarios, ldb
     d.n_out, d.out_act, d.n_segs = n_out, out_act, len(segments)

@@ -182,11 +182,25 @@ def test_gnn_engine_graph_plan_equals_the_oracles_graph(name):
     for w, (e,) in enumerate(og["mapping"]["warehouses"]):
         assert rows[e] == S * Wn + w
     assert all(r == -1 for r in rows[n_int + Wn:])
-    # allocation groups = every supplying node's outgoing internal edges + its self loop
+    # allocation groups = every supplying node's outgoing internal edges + its self loop.  (The engine numbers the self loops
+    # BEFORE the demand edges - the reference after them - so that the edges whose output matters are the first `n_live`.)
+    n_self = len(og["supplying"])
+    assert P.n_live == n_int + Wn + n_self and P.e_demand == P.n_live
     for w, (first, count, e_self, e_sup) in enumerate(P.groups.tolist()):
         assert list(range(first, first + count)) == [i for i, (a, _) in enumerate(og["internal"]) if a == w]
         assert e_sup == n_int + w
-        assert e_self == (n_int + Wn + S + og["supplying"].index(w) if w in og["supplying"] else -1)
+        assert e_self == (n_int + Wn + og["supplying"].index(w) if w in og["supplying"] else -1)
+    assert P.src[P.e_demand:].tolist() == list(range(Wn, Wn + S)) and P.tgt[P.e_demand:].tolist() == [-1] * S
+    # a node's aggregation lists name its edges in the REFERENCE's order (internal, supplier, demand, self loop)
+    r2e = list(range(n_int + Wn)) + [P.e_demand + s_ for s_ in range(S)] + [n_int + Wn + k for k in range(n_self)]
+    off, items = P.agg_off.tolist(), P.agg_items.tolist()
+    n_e = n_int + Wn + S + n_self
+    r_src = [a for a, _ in og["internal"]] + [-1] * Wn + list(range(Wn, Wn + S)) + og["supplying"]
+    r_tgt = [b for _, b in og["internal"]] + list(range(Wn)) + [-1] * S + og["supplying"]
+    for n in range(P.n_nodes):
+        want_in = [r2e[r] for r in range(n_e) if r_tgt[r] == n and not (n_int + Wn <= r < n_int + Wn + S)]
+        want_out = [r2e[r] for r in range(n_e) if r_src[r] == n and not (n_int <= r < n_int + Wn)]
+        assert items[off[n]:off[n + 1]] == want_in and items[off[P.n_nodes + n]:off[P.n_nodes + n + 1]] == want_out
     # upstream's column quirk is present exactly where a store's j-th connected warehouse is not warehouse j
     expect = [(b - Wn, j, a) for s_ in range(S)
               for j, (a, b) in enumerate([(a, b) for (a, b) in og["internal"] if b - Wn == s_]) if j != a]
