@@ -1277,6 +1277,7 @@ void wgrad_tile(int N, int K, int* bm, int* bn) {
 bool wgrad_big(int N, int K) { return N >= 192 && K >= 192; }
 bool wgrad_tall(int N, int K);
 bool wgrad_wide(int N, int K);
+bool wgrad_mid(int N, int K);
 
 // tall, narrow layers (the first layer: 512 x 51): ONE 512 x 64 output tile per scenario chunk, so dZ is read exactly once
 // (the 128 x 64 register-staged tiles read it 1.3 x) by the LDS-DMA pipeline; HBM-bound
@@ -1293,9 +1294,14 @@ void launch_wg_dma(const WgParams& p, int n_splits, hipStream_t s) {
 // where two 256-column tiles compute 512 (77 %); 128 x 448 keeps the 112 accumulator registers of the 7-tile wx kernel
 bool wgrad_wide(int N, int K) { return wgrad_big(N, K) && K > 384 && K <= 448 && N % 128 == 0; }
 
-// the LDS-DMA weight-gradient kernel for a shape (wgrad_big or wgrad_tall)
+// 96 <= N <= 128 output rows over a wide input (cfg5's compacted logits layer, 98 x 512): 128 x 256 tiles on the LDS-DMA pipeline
+// (the register-staged 128 x 128 kernel reaches 0.37 of peak there)
+bool wgrad_mid(int N, int K) { return N >= 96 && N <= 128 && K >= 192; }
+
+// the LDS-DMA weight-gradient kernel for a shape (wgrad_big, wgrad_mid or wgrad_tall)
 void launch_wg_dma_for(const WgParams& p, int n_splits, hipStream_t s) {
     if (wgrad_tall(p.N, p.K)) launch_wg_dma<8, 1, 2, 2>(p, n_splits, s);
+    else if (wgrad_mid(p.N, p.K)) launch_wg_dma<2, 4, 2, 2>(p, n_splits, s);
     else if (wgrad_wide(p.N, p.K)) launch_wg_dma<4, 2, 1, 7>(p, n_splits, s);
     else if ((p.N + 255) / 256 * 256 - p.N >= 32) launch_wg_dma<2, 4, 4, 2, true>(p, n_splits, s);  // an empty row tile to skip
     else launch_wg_dma<2, 4, 4, 2>(p, n_splits, s);
@@ -1345,6 +1351,9 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
     int target = 1024;                                 // ~4 workgroups per CU in total
     if (wgrad_wide(N, K)) {                            // 128 x 448 tiles, one workgroup per CU, one round
         tiles = (N + 127) / 128;
+        target = 256;
+    } else if (wgrad_mid(N, K)) {                      // 128 x 256 tiles
+        tiles = (K + 255) / 256;
         target = 256;
     } else if (wgrad_big(N, K)) {                      // 256 x 256 tiles, one workgroup per CU, one round
         tiles = ((N + 255) / 256) * ((K + 255) / 256);
@@ -1399,7 +1408,7 @@ static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t l
         else if (K <= 96) hipLaunchKernelGGL(wgrad_small_kernel<3>, g, b, 0, s, p, n_splits);
         else hipLaunchKernelGGL(wgrad_small_kernel<4>, g, b, 0, s, p, n_splits);
     }
-    else if ((wgrad_big(N, K) || wgrad_tall(N, K)) && dma_ok && gemm_variant() != 2) launch_wg_dma_for(p, n_splits, s);
+    else if ((wgrad_big(N, K) || wgrad_tall(N, K) || wgrad_mid(N, K)) && dma_ok && gemm_variant() != 2) launch_wg_dma_for(p, n_splits, s);
     else if (bm == 128 && bn == 128) launch_wg<2, 2, 2, 2>(p, n_splits, s);
     else if (bm == 128) launch_wg<2, 2, 2, 1>(p, n_splits, s);
     else if (bm == 64) launch_wg<1, 4, 2, 1>(p, n_splits, s);
@@ -1429,7 +1438,7 @@ int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64
     NIC_REQUIRE(period_stride_dy % 4 == 0 && period_stride_x % 4 == 0,
                 "nic_linear_wgrad_periods: period strides must be multiples of 4 elements (16-byte aligned operands)");
     const bool dma_ok = dY && X && slab && N > 0 && K > 0 && lds_ >= K + 1 && n_splits >= 1 && n_scenarios > 0 && ldb >= n_scenarios &&
-                        (wgrad_big(N, K) || wgrad_tall(N, K)) && gemm_variant() != 2 && ldb % 4 == 0 && n_scenarios % BK == 0 && lds_ % 4 == 0 &&
+                        (wgrad_big(N, K) || wgrad_tall(N, K) || wgrad_mid(N, K)) && gemm_variant() != 2 && ldb % 4 == 0 && n_scenarios % BK == 0 && lds_ % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (int64_t)N * ldb < (1ll << 28) &&
                         (int64_t)K * ldb < (1ll << 28);

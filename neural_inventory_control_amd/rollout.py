@@ -220,6 +220,19 @@ class FusedRollout:
                     self.gb = [torch.zeros_like(m.bias) for m in lins]
             self._key = key
             return
+        # Many-warehouse vanilla head: the logits of (store, warehouse) pairs without an edge are never read upstream
+        # (`store_intermediate_outputs[:, connected_stores, w_idx]`, neural_networks.py:403-417: zero gradient, no effect), so
+        # the logits layer - forward, input gradient, weight gradient - runs on the LIVE rows only: compact weights, a compact
+        # logits block scattered into the head's [S * Wn + Wn] layout by one row copy per period, and the adjoint gather.
+        self.live_rows, gd = None, list(dims)
+        if self.head == "warehouse" and prob.Wn > 1:
+            conn = self.problem_params["warehouse_store_adjacency"]
+            live = [s_ * prob.Wn + w for s_ in range(prob.S) for w in range(prob.Wn) if conn[w][s_]] + \
+                   [prob.S * prob.Wn + w for w in range(prob.Wn)]
+            if len(live) <= 0.85 * dims[-1]:
+                self.live_rows = torch.tensor(live, dtype=torch.long, device=dev)
+                gd[-1] = len(live)
+        self.gd = gd   # layer widths of the GEMMs (= dims unless the logits layer is compacted)
         n_ord = prob.S * prob.nsup + prob.Wn + prob.E
         f_tot = self.F_store + self.F_wh + self.F_ech + extra_rows
         # evaluation keeps the state / order / logit history only while it is small (tests and short horizons read it);
@@ -235,8 +248,9 @@ class FusedRollout:
         keep = T if train else 1
         self.hidden = [z(keep, dims[i + 1], ld) for i in range(L - 1)]
         # engine copies of the weights: rows padded to a multiple of 32 floats so every A-tile load is a float4
-        self.Wp = [z(dims[i + 1], _pad32(dims[i])) for i in range(L)]
-        self.Wt = [z(dims[i], _pad32(dims[i + 1])) for i in range(L)]
+        self.Wp = [z(gd[i + 1], _pad32(gd[i])) for i in range(L)]
+        self.Wt = [z(gd[i], _pad32(gd[i + 1])) for i in range(L)]
+        self.Zc = z(gd[-1], ld) if self.live_rows is not None else None
         if train:
             self.g_state = [z(self.states.shape[1], ld), z(self.states.shape[1], ld)]
             self.g_orders = z(n_ord, ld)
@@ -246,7 +260,7 @@ class FusedRollout:
             # pre-activation gradients of the hidden layers for EVERY period ([T][N_l][ldb], 13.4 GB per 512-wide layer at
             # BASELINE cfg3 — HBM is sized for it): their weight gradients are contracted once per training step over
             # (period x scenario) instead of once per period (see _launch_backward)
-            hist_bytes = 4 * T * ld * sum(dims[1:])
+            hist_bytes = 4 * T * ld * sum(gd[1:])
             # free HBM = what the driver reports + what torch's caching allocator holds but is not using
             free_bytes = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
                           if dev.type == "cuda" else 0)
@@ -254,13 +268,17 @@ class FusedRollout:
             batch = self.batch_wgrad and hist_bytes <= 0.6 * free_bytes
             self.dZhist = [z(T, dims[i + 1], ld) for i in range(L - 1)] if batch else None
             # ... and the logits gradient too, unless the logits layer takes the fused thin-layer backward (per period)
-            thin_last = L > 1 and self.use_thin and ops.linear_bwd_thin_ok(dims[L], dims[L - 1])
-            self.dZlast_hist = z(T, dims[-1], ld) if batch and not thin_last else None
-            self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], prob.B) for i in range(L)]
-            self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
+            thin_last = L > 1 and self.use_thin and ops.linear_bwd_thin_ok(gd[L], gd[L - 1])
+            self.dZlast_hist = z(T, gd[-1], ld) if batch and not thin_last else None
+            self.dZc = z(gd[-1], ld) if self.live_rows is not None else None
+            self.splits = [ops.wgrad_num_splits(gd[i + 1], gd[i], prob.B) for i in range(L)]
+            self.slabs = [z(self.splits[i], gd[i + 1], (gd[i] + 1 + 3) // 4 * 4) for i in range(L)]
             self.g_reward = z(ld)
             self.gw = [torch.zeros_like(m.weight) for m in lins]
             self.gb = [torch.zeros_like(m.bias) if m.bias is not None else None for m in lins]
+            if self.live_rows is not None:   # the compact logits layer reduces into these; scattered into gw / gb afterwards
+                self.gw_c = z(gd[-1], gd[-2])
+                self.gb_c = z(gd[-1]) if lins[-1].bias is not None else None
         self.demand_buf = None
         self._graphs = {}      # "fwd"/"bwd" -> torch.cuda.CUDAGraph (HIP graph) of the launch sequence
         self._eager_runs = 0
@@ -356,12 +374,16 @@ class FusedRollout:
         # engine copies of the weights (tiny) — refreshed every call because the optimizer moves them
         lins = self._linears()
         L = len(lins)
+        rows = self.live_rows
         for i, m in enumerate(lins):
-            self.Wp[i][:, :self.dims[i]].copy_(m.weight.detach())
-            self.Wt[i][:, :self.dims[i + 1]].copy_(m.weight.detach().t())
+            w = m.weight.detach() if (rows is None or i < L - 1) else m.weight.detach()[rows]
+            self.Wp[i][:, :self.gd[i]].copy_(w)
+            self.Wt[i][:, :self.gd[i + 1]].copy_(w.t())
         biases = [m.bias.detach() if m.bias is not None else None for m in lins]
-        Wv = [self.Wp[i][:, :self.dims[i]] for i in range(L)]
-        Wtv = [self.Wt[i][:, :self.dims[i + 1]] for i in range(L)]
+        if rows is not None and biases[-1] is not None:
+            biases[-1] = biases[-1][rows]
+        Wv = [self.Wp[i][:, :self.gd[i]] for i in range(L)]
+        Wtv = [self.Wt[i][:, :self.gd[i + 1]] for i in range(L)]
 
         # initial state
         s0 = self._views(self.states[0], prob)
@@ -390,7 +412,7 @@ class FusedRollout:
             sl.zero_()
         self.g_state[0].zero_()
         # layers whose backward is ONE fused pass over their input (nic_linear_bwd_thin): thin output, not the first
-        thin = [i > 0 and self.use_thin and ops.linear_bwd_thin_ok(self.dims[i + 1], self.dims[i]) for i in range(len(lins))]
+        thin = [i > 0 and self.use_thin and ops.linear_bwd_thin_ok(self.gd[i + 1], self.gd[i]) for i in range(len(lins))]
         if thin != getattr(self, "_thin", None):
             self._thin = thin
             self._graphs.pop("bwd", None)  # a captured launch sequence no longer applies
@@ -536,8 +558,8 @@ class FusedRollout:
         prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
         ub = self._ub_now
         hist = self._hist
-        self._thin_in = (self.use_thin and L > 1 and biases[0] is not None and ops.linear_fwd_thin_in_ok(self.dims[1], self.dims[0])
-                         and 4 * self.dims[1] * ld < 2 ** 31)
+        self._thin_in = (self.use_thin and L > 1 and biases[0] is not None and ops.linear_fwd_thin_in_ok(self.gd[1], self.gd[0])
+                         and 4 * self.gd[1] * ld < 2 ** 31)
         for t in range(T):
             cur, nxt, row = (t, t + 1, t) if hist else (t & 1, (t + 1) & 1, 0)
             st = self._views(self.states[cur], prob)
@@ -546,12 +568,17 @@ class FusedRollout:
             for i in range(L - 1):
                 y = self.hidden[i][hs]
                 if i == 0 and self._thin_in:   # short contraction, many rows: the write-bound streamed forward (thin_layer.hip)
-                    self._k(f"fwd_{self.dims[1]}x{self.dims[0]}", ops.linear_fwd_thin_in, Wtv[0], biases[0], x, y, B, _lib.NIC_ACT_ELU)
+                    self._k(f"fwd_{self.gd[1]}x{self.gd[0]}", ops.linear_fwd_thin_in, Wtv[0], biases[0], x, y, B, _lib.NIC_ACT_ELU)
                 else:
-                    self._k(f"fwd_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_fwd, Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)
+                    self._k(f"fwd_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_fwd, Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)
                 x = y
             Z = self.logits[row]
-            self._k(f"fwd_{self.dims[L]}x{self.dims[L - 1]}", ops.linear_fwd, Wv[L - 1], biases[L - 1], x, Z, B, _lib.NIC_ACT_NONE)
+            if self.live_rows is None:
+                self._k(f"fwd_{self.gd[L]}x{self.gd[L - 1]}", ops.linear_fwd, Wv[L - 1], biases[L - 1], x, Z, B, _lib.NIC_ACT_NONE)
+            else:   # compact logits, then one row copy into the head's layout (rows of pairs without an edge stay 0: never read)
+                self._k(f"fwd_{self.gd[L]}x{self.gd[L - 1]}", ops.linear_fwd, Wv[L - 1], biases[L - 1], x, self.Zc, B,
+                        _lib.NIC_ACT_NONE)
+                Z.index_copy_(0, self.live_rows, self.Zc)
             so, wo, eo = self._order_views(self.orders[row], prob)
             if self.head == "warehouse":
                 self._k("head_fwd", ops.head_warehouse_fwd, Z, st.wh, self.adj, ub, bool(self.model.transshipment), so, wo,
@@ -584,7 +611,8 @@ class FusedRollout:
             Z = self.logits[t]
             gc = self._views(g_cur, prob)
             hist, last_hist = self.dZhist, self.dZlast_hist
-            dZ = last_hist[t] if last_hist is not None else self.dZ
+            compact = self.live_rows is not None
+            dZ = last_hist[t] if (last_hist is not None and not compact) else self.dZ
             if self.head == "warehouse":
                 self._k("head_bwd", ops.head_warehouse_bwd, Z, st.wh, self.adj, ub, bool(self.model.transshipment), gso, gwo,
                         dZ, gc.wh, prob.S, prob.Wn, prob.Ww, B)
@@ -597,25 +625,28 @@ class FusedRollout:
             else:
                 self._k("head_bwd", ops.head_softplus_bwd, Z, gso.view(-1, ld), dZ, prob.S * prob.nsup, B)
             d = dZ
+            if compact:   # the live rows of the head's logits gradient (the others are exact zeros)
+                d = last_hist[t] if last_hist is not None else self.dZc
+                torch.index_select(dZ, 0, self.live_rows, out=d)
             for i in range(L - 1, -1, -1):
                 x_in = self.hidden[i - 1][t] if i > 0 else self.states[t][:self.F]
                 # gradient wrt the previous layer's pre-activation output: kept for every period when its weight gradient
                 # is contracted at the end of the sweep, else a ping-pong scratch buffer
-                dx = (hist[i - 1][t] if hist is not None else self.dH[i & 1][:self.dims[i]]) if i > 0 else None
+                dx = (hist[i - 1][t] if hist is not None else self.dH[i & 1][:self.gd[i]]) if i > 0 else None
                 if i > 0 and self._thin[i]:
                     # thin (logits) layer: weight gradient and input gradient in ONE pass over the layer's input
-                    self._k(f"bwd_thin_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_bwd_thin, Wv[i], d, x_in, dx,
+                    self._k(f"bwd_thin_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_bwd_thin, Wv[i], d, x_in, dx,
                             self.slabs[i], B, _lib.NIC_ACT_ELU)
                     d = dx
                     continue
                 if hist is None or (i == L - 1 and last_hist is None):  # (else: contracted over all periods after the sweep)
-                    self._k(f"wgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad, d, x_in, self.slabs[i], B)
+                    self._k(f"wgrad_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_wgrad, d, x_in, self.slabs[i], B)
                 if i > 0:
-                    self._k(f"dgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_dgrad, Wtv[i], d, x_in, dx, B,
+                    self._k(f"dgrad_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_dgrad, Wtv[i], d, x_in, dx, B,
                             _lib.NIC_ACT_ELU, False)
                     d = dx
                 elif not detached_input:   # (only the state rows of the input carry a gradient back in time)
-                    self._k(f"dgrad_{self.dims[1]}x{self.dims[0]}", ops.linear_dgrad, Wtv[0][:self.F_dyn], d, None,
+                    self._k(f"dgrad_{self.gd[1]}x{self.gd[0]}", ops.linear_dgrad, Wtv[0][:self.F_dyn], d, None,
                             g_cur[:self.F_dyn], B, _lib.NIC_ACT_NONE, True)
             g_next, g_cur = g_cur, g_next
         if self.dZhist is not None:
@@ -625,10 +656,18 @@ class FusedRollout:
                     continue  # its weight gradient was accumulated period by period (fused thin-layer backward / no history)
                 x_hist = self.hidden[i - 1] if i > 0 else self.states[:T, :self.F]
                 dz_hist = self.dZhist[i] if i < L - 1 else self.dZlast_hist
-                self._k(f"wgradT_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad_periods, dz_hist, x_hist,
+                self._k(f"wgradT_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_wgrad_periods, dz_hist, x_hist,
                         self.slabs[i], B)
         for i in range(L):
-            ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], self.dims[i], 1.0)
+            if i == L - 1 and self.live_rows is not None:   # compact logits layer: reduce, then scatter into the parameter's rows
+                ops.wgrad_reduce(self.slabs[i], self.gw_c, self.gb_c, self.gd[i], 1.0)
+                self.gw[i].zero_()
+                self.gw[i].index_copy_(0, self.live_rows, self.gw_c)
+                if self.gb[i] is not None:
+                    self.gb[i].zero_()
+                    self.gb[i].index_copy_(0, self.live_rows, self.gb_c)
+                continue
+            ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], self.gd[i], 1.0)
 
     # ---- inspection helpers used by the parity tests --------------------------------------------------------------
     def per_period_rewards(self):
