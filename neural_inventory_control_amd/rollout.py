@@ -251,6 +251,7 @@ class FusedRollout:
         self.Wp = [z(gd[i + 1], _pad32(gd[i])) for i in range(L)]
         self.Wt = [z(gd[i], _pad32(gd[i + 1])) for i in range(L)]
         self.Zc = z(gd[-1], ld) if self.live_rows is not None else None
+        self.bias_c = z(gd[-1]) if self.live_rows is not None else None
         if train:
             self.g_state = [z(self.states.shape[1], ld), z(self.states.shape[1], ld)]
             self.g_orders = z(n_ord, ld)
@@ -380,8 +381,9 @@ class FusedRollout:
             self.Wp[i][:, :self.gd[i]].copy_(w)
             self.Wt[i][:, :self.gd[i + 1]].copy_(w.t())
         biases = [m.bias.detach() if m.bias is not None else None for m in lins]
-        if rows is not None and biases[-1] is not None:
-            biases[-1] = biases[-1][rows]
+        if rows is not None and biases[-1] is not None:   # (an engine-owned buffer: a captured graph holds its address)
+            torch.index_select(biases[-1], 0, rows, out=self.bias_c)
+            biases[-1] = self.bias_c
         Wv = [self.Wp[i][:, :self.gd[i]] for i in range(L)]
         Wtv = [self.Wt[i][:, :self.gd[i + 1]] for i in range(L)]
 

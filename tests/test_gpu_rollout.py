@@ -514,7 +514,8 @@ def test_full_size_properties_cfg3():
         assert float((lhs - rhs).abs().max()) < 1e-3
 
 
-@pytest.mark.parametrize("name", ["cfg2_one_store_backlogged_vanilla", "cfg4_serial_vanilla", "cfg3_one_warehouse_5_vanilla"])
+@pytest.mark.parametrize("name", ["cfg2_one_store_backlogged_vanilla", "cfg4_serial_vanilla", "cfg3_one_warehouse_5_vanilla",
+                                  "cfg5_many_warehouses_3x64_vanilla"])   # (the last one: compacted logits layer, row copies)
 def test_graph_replay_matches_eager(name):
     """HIP-graph replay of the launch sequence (use_graph) is bit-identical to eager launches, also after the batch
     contents change between calls (the captured graph points at engine-owned buffers that are refreshed per call)."""
