@@ -1290,9 +1290,11 @@ void launch_wg_dma(const WgParams& p, int n_splits, hipStream_t s) {
     nic::note_kernelf(SKIP ? "gemm_wgrad_dma_kernel<%d,%d,%d,%d,skip>" : "gemm_wgrad_dma_kernel<%d,%d,%d,%d>", WM, WN, MT, NT);
     hipLaunchKernelGGL((gemm_wgrad_dma_kernel<WM, WN, MT, NT, SKIP>), grid, dim3(64 * WM * WN), 0, s, p);
 }
-// K in (384, 448] (cfg5's 393-wide first hidden layer input): ONE 448-column tile covers it (88 % of the tile's columns used)
-// where two 256-column tiles compute 512 (77 %); 128 x 448 keeps the 112 accumulator registers of the 7-tile wx kernel
-bool wgrad_wide(int N, int K) { return wgrad_big(N, K) && K > 384 && K <= 448 && N % 128 == 0; }
+// K in (256, 448] (cfg5's first layer: 393 input rows, 295 of them live): ONE 320 / 384 / 448-column tile covers it (88 % of the
+// tile's columns used at K = 393) where two 256-column tiles compute 512 (77 %); 128 x 448 keeps the 112 accumulator registers
+// of the 7-tile wx kernel
+bool wgrad_wide(int N, int K) { return wgrad_big(N, K) && K > 256 && K <= 448 && N % 128 == 0; }
+int wgrad_wide_nt(int K) { return (K + 63) / 64; }   // 5, 6 or 7 column tiles of 32 per wave column: 320 / 384 / 448 columns
 
 // 96 <= N <= 128 output rows over a wide input (cfg5's compacted logits layer, 98 x 512): 128 x 256 tiles on the LDS-DMA pipeline
 // (the register-staged 128 x 128 kernel reaches 0.37 of peak there)
@@ -1302,7 +1304,12 @@ bool wgrad_mid(int N, int K) { return N >= 96 && N <= 128 && K >= 192; }
 void launch_wg_dma_for(const WgParams& p, int n_splits, hipStream_t s) {
     if (wgrad_tall(p.N, p.K)) launch_wg_dma<8, 1, 2, 2>(p, n_splits, s);
     else if (wgrad_mid(p.N, p.K)) launch_wg_dma<2, 4, 2, 2>(p, n_splits, s);
-    else if (wgrad_wide(p.N, p.K)) launch_wg_dma<4, 2, 1, 7>(p, n_splits, s);
+    else if (wgrad_wide(p.N, p.K)) {
+        const int nt = wgrad_wide_nt(p.K);
+        if (nt == 5) launch_wg_dma<4, 2, 1, 5>(p, n_splits, s);
+        else if (nt == 6) launch_wg_dma<4, 2, 1, 6>(p, n_splits, s);
+        else launch_wg_dma<4, 2, 1, 7>(p, n_splits, s);
+    }
     else if ((p.N + 255) / 256 * 256 - p.N >= 32) launch_wg_dma<2, 4, 4, 2, true>(p, n_splits, s);  // an empty row tile to skip
     else launch_wg_dma<2, 4, 4, 2>(p, n_splits, s);
 }

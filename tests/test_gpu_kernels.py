@@ -70,7 +70,9 @@ GEMM_SHAPES = [(512, 51, 1000), (512, 512, 2048 + 37), (17, 512, 777), (32, 4, 1
                # (13 of 14 row tiles computed), 195 rows in a 256-row block (7 of 8), and the all-period weight gradients' tilings
                (512, 393, 32768 + 160), (195, 512, 32768 + 96), (195, 512, 4096), (512, 393, 4096),
                # the compacted logits layer of cfg5 (98 live rows of 195): 128 x 128 forward, 128 x 256 weight-gradient tiles
-               (98, 512, 32768), (98, 512, 4096 + 64), (128, 512, 8192), (96, 200, 4096)]
+               (98, 512, 32768), (98, 512, 4096 + 64), (128, 512, 8192), (96, 200, 4096),
+               # ... and its first layer on the live input rows (295 of 393): 128 x 320 / 128 x 384 weight-gradient tiles
+               (512, 295, 32768), (512, 295, 4096 + 32), (512, 350, 8192), (256, 320, 4096)]
 
 
 def _rand(shape, gen, dev, scale=1.0):
