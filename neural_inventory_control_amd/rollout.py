@@ -12,6 +12,9 @@ are reduced once at the end.  Everything a period needs later is kept RESIDENT i
     logits   [T][N_out][ldb] ; orders [T][S*nsup+Wn+E][ldb] ; rewards [T][ldb] ; demand [T][S][ldb]
 
 (BASELINE cfg3: 65,536 scenarios x T=100 x 3x512 hidden = 40 GB of activations — sized for 288 GB of HBM3E.)
+Round 3: the real-data `data_driven` policy rides on the same engine (every period's block = [state rows | observation rows:
+past-demand window, costs, days from christmas, lead times], head = ReLU + adjacency mask + proportional allocation), and the
+many-warehouse vanilla head's logits layer runs on its LIVE rows only (pairs without an edge are never read upstream).
 The host loop issues ~6 launches per period forward and ~11 backward and never synchronises; the only device->host
 transfers are the two scalars the trainer reports.
 """
