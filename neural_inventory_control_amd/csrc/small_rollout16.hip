@@ -235,8 +235,11 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_bwd_kernel(NicSmallRoll
 #pragma unroll
     for (int k = 0; k < SR_MAXF; ++k) gn[k] = 0.f;
 
-    float st[SR_MAXF], z[SR_MAXOUT], dem, hh[NL][8];
-    float st_n[SR_MAXF], z_n[SR_MAXOUT], dem_n, hh_n[NL][8];
+    // what a period's backward step reads back: two sets, used alternately (the next period's loads are issued while this period
+    // computes; the loop is unrolled by two so that no set is ever copied into the other - that copy was 71 v_mov per period)
+    struct Per { float st[SR_MAXF], z[SR_MAXOUT], dem, hh[NL][8]; };
+    Per P0, P1;
+    float gn1[SR_MAXF];
     // weight-gradient accumulators: tile (ot, kt) of dW = rows 16 ot + 4 g + i, column 16 kt + j; bias sums of row 16 ot + j
     f32x4 gO[2], gH[NH][2][2], g1[2];
     float sbO = 0.f, sbH[NH][2], sb1[2] = {0.f, 0.f};
@@ -286,13 +289,19 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_bwd_kernel(NicSmallRoll
 #pragma unroll
             for (int e = 0; e < 8; ++e) fh[l][e] = hidden_hist[(((int64_t)t * n_blk + blockIdx.x) * NL + l) * 512 + e * 64 + lane];
     };
-    fetch(d.T - 1, st, z, dem, hh);
-    for (int t = d.T - 1; t >= 0; --t) {
+    fetch(d.T - 1, P0.st, P0.z, P0.dem, P0.hh);
+    // one period: C = this period's set, N = the set the next (earlier) period's loads go to; gin / go = the state gradient
+    // arriving from period t + 1 / leaving for period t - 1
+    auto step = [&](int t, Per& C, Per& N, const float (&gin)[SR_MAXF], float (&go)[SR_MAXF]) {
+        float (&st)[SR_MAXF] = C.st;
+        float (&z)[SR_MAXOUT] = C.z;
+        float (&hh)[NL][8] = C.hh;
+        const float dem = C.dem;
         const SrOrders o = sr_head(d, z, st);
-        float go[SR_MAXF], dz[SR_MAXOUT];
-        const SrOrders gord = sr_env_bwd(d, c, st, gn, go, dem, o, gr);
+        float dz[SR_MAXOUT];
+        const SrOrders gord = sr_env_bwd(d, c, st, gin, go, dem, o, gr);
         sr_head_bwd(d, z, st, gord, dz, go);
-        fetch(t > 0 ? t - 1 : 0, st_n, z_n, dem_n, hh_n);
+        fetch(t > 0 ? t - 1 : 0, N.st, N.z, N.dem, N.hh);
         {   // output layer: dWout (rows n < n_out <= 8 in tile 0) += dz_out H_last^T
             if (g < 2) {   // rows 0..7 hold the logit gradients, rows 8..15 zeros
 #pragma unroll
@@ -385,18 +394,21 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_bwd_kernel(NicSmallRoll
 #pragma unroll
             for (int k = 0; k < SR_MAXF; ++k) go[k] += __shfl(gs[k & 3], j + 16 * (k >> 2));
         }
-#pragma unroll
-        for (int k = 0; k < SR_MAXF; ++k) {
-            gn[k] = go[k];
-            st[k] = st_n[k];
+    };
+    if constexpr (SHAPE != 0 && !(SHAPE == 2 && NL == 3)) {   // shapes compiled in (that fit): two periods per iteration, the sets swap roles
+        int t = d.T - 1;
+        for (; t >= 1; t -= 2) {
+            step(t, P0, P1, gn, gn1);
+            step(t - 1, P1, P0, gn1, gn);
         }
+        if (t == 0) step(0, P0, P1, gn, gn1);
+    } else {   // run-time shapes (and the serial chain with three hidden layers): twice the loop body does not fit the register file
+        for (int t = d.T - 1; t >= 0; --t) {
+            step(t, P0, P1, gn, gn1);
+            P0 = P1;
 #pragma unroll
-        for (int n = 0; n < SR_MAXOUT; ++n) z[n] = z_n[n];
-        dem = dem_n;
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) hh[l][e] = hh_n[l][e];
+            for (int k = 0; k < SR_MAXF; ++k) gn[k] = gn1[k];
+        }
     }
     // this wavefront's partial gradient, in the packed-weight layout: tile (ot, kt) register i = dW[16 ot + 4 g + i][16 kt + j]
     float* S = slab + (int64_t)blockIdx.x * slab_stride;
