@@ -144,7 +144,12 @@ int nic_linear_wgrad(const float* dY, const float* X, float* slab, int64_t lds, 
  * HBM is sized for it) and contracts weight gradients once per training step instead of once per period — one slab
  * read-modify-write instead of T, no per-period pipeline fill/drain.  Periods are accumulated last first (autograd's
  * order; partial sums are added to the slab every ~8k terms).  Shapes the LDS-DMA kernel does not take are
- * served by one nic_linear_wgrad launch per period (same result). */
+ * served by one nic_linear_wgrad launch per period (same result).
+ * The slab's n_splits slots are used as (scenario splits x period groups): scenario chunks go down to 128 scenarios and the
+ * horizon is split into groups of periods for what is still missing to give every CU a workgroup (few scenarios x many
+ * periods: the reference's shipped batch size 1,024, one_warehouse_lost_demand.yml:31-34).  nic_wgrad_periods_num_splits
+ * gives the slot count that fills the chip; any n_splits >= 1 is accepted (unused slots are left untouched). */
+int nic_wgrad_periods_num_splits(int32_t N, int32_t K, int32_t n_scenarios, int32_t n_periods);
 int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64_t lds, int32_t N, int32_t K,
                              int32_t n_scenarios, int32_t ldb, int32_t n_splits, int32_t n_periods,
                              int64_t period_stride_dy, int64_t period_stride_x, void* stream);

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "nic_linear_fwd_thin_in": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_linear_dgrad": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_wgrad_num_splits": (C.c_int, [_i32, _i32, _i32]),
+    "nic_wgrad_periods_num_splits": (C.c_int, [_i32, _i32, _i32, _i32]),
     "nic_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_linear_wgrad_periods": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
     "nic_linear_bwd_thin": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

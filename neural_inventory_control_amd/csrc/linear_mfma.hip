@@ -11,13 +11,15 @@
 // transposition anywhere between the env-step kernels and the GEMMs.
 //
 // Production kernels (16-byte aligned operands — everything the rollout engine allocates):
-//   gemm_wx_dma_kernel     forward + dgrad, 256 x 256 x 32 block tile, 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA tiles
-//   gemm_wgrad_dma_kernel  weight gradient, 256 x 256 output tile per scenario chunk, same wave layout
+//   gemm_wx_dma_kernel     forward + dgrad; 128 x 128 x 32 block tile of 8 waves (2 x 4, wave tile 64 x 32), two workgroups
+//                          co-resident per CU; 64 x 128 (8 waves) and 32 x 128 (4 waves) for small launches / thin or ragged
+//                          outputs (pick_wx_tile; round 4: co-resident workgroups beat one 256 x 256 workgroup per CU)
+//   gemm_wgrad_dma_kernel  weight gradient, 256 x 256 output tile per (scenario chunk, period group), 8 waves (2 x 4)
 //   both: tiles go HBM/L2 -> LDS by `buffer_load_dwordx4 ... lds` (no VGPR round trip), double-buffered, one barrier per
 //   k tile; A-style tiles [rows][32] are unpadded with a 16-byte-chunk XOR swizzle applied on the DMA source address
 //   and on the ds_read_b128 fragment reads; the [32][BN] B tile of the wx kernel is linear (ds_read_b32 rows);
 //   epilogues are staged through the dead LDS tiles and leave as whole-row float4 accesses; logical tile order is
-//   XCD-aware.  Smaller shapes (thin first / last layers) use 128x128 / 64x128 / 32x256 instantiations.
+//   XCD-aware.
 //   k order : within a 16-deep k group, MFMA step kk consumes k = kk (lanes 0-31) and k = 8+kk (lanes 32-63), so a
 //             lane's eight A values of a group are CONTIGUOUS in LDS (two ds_read_b128) — summation order over k is
 //             free because parity is defined to 1e-5, not bitwise, for the policy GEMMs.
@@ -461,9 +463,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
                                             : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
-    const int rows_left = p.M - m0 - wm * MT * 32;     // rows of the matrix at or below this wave's first row
-    const bool full_rows = rows_left > (MT - 1) * 32;  // the wave's last row tile holds at least one row
-    const bool some_rows = rows_left > 0;
     auto ktile = [&](int kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {  // stage cur^1 was last read in tile kt-1; every wave is past that barrier
@@ -472,39 +471,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
         }
         const float* a_base = lds + cur * STAGE + (wm * MT * 32 + li) * BK;
         const float* b_base = lds + cur * STAGE + A_FLOATS + wn * NT * 32 + li;
-        // row tiles of this wave that lie entirely past the matrix (ragged M: 393 rows in 13 of the 14 tiles of a 448-row block,
-        // 195 in 7 of 8) are skipped; the two wavefronts of a SIMD are (wm = 0, wn) and (wm = 1, wn), so the SIMD's matrix pipe
-        // gets the sum of their counts.  (MTV = MT - 1 also serves waves with fewer valid tiles: surplus tiles compute zeros.)
-        auto body = [&](auto mtv_c) {
-            constexpr int MTV = decltype(mtv_c)::value;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                float a[MTV][8];
+        for (int g = 0; g < 2; ++g) {
+            float a[MT][8];
 #pragma unroll
-                for (int i = 0; i < MTV; ++i) {
-                    const float4 lo = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
-                    const float4 hi = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
-                    a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
-                    a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
-                }
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    float b[NT];
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) b[j] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
-#pragma unroll
-                    for (int i = 0; i < MTV; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j], acc[i][j], 0, 0, 0);
-                }
+            for (int i = 0; i < MT; ++i) {
+                const float4 lo = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2) ^ sw) << 2));
+                const float4 hi = *reinterpret_cast<const float4*>(a_base + i * 32 * BK + (((g * 4 + h * 2 + 1) ^ sw) << 2));
+                a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
+                a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
             }
-        };
-        if constexpr (MT >= 3 && NT == 1) {  // (the ragged-M tilings; the 256 x 256 kernel of the square layers stays branch-free)
-            if (full_rows) body(std::integral_constant<int, MT>{});
-            else if (some_rows) body(std::integral_constant<int, MT - 1>{});
-        } else {
-            body(std::integral_constant<int, MT>{});
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                float b[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = b_base[(g * 16 + h * 8 + kk) * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j], acc[i][j], 0, 0, 0);
+            }
         }
         dma_wait();  // tile kt+1 has landed (this wave's share); the barrier publishes every wave's share
         if (!NIC_TUNE(4)) __syncthreads();
@@ -672,6 +659,11 @@ struct WgParams {
     // terms in one register drifts to ~5e-5 relative (measured against the fp32 CPU reference at T = 100 x 1,024 scenarios
     // per split); 8k-term partial sums keep the weight gradients at the per-period accuracy
     int flush_periods;
+    // round 4: the slab slots are (period group, scenario split) pairs - slot = group * scen_splits + scenario split; a group
+    // contracts periods [group * periods_per_group, ...) only.  Few scenarios x many periods (the reference's shipped batch of
+    // 1,024, an 8-GPU shard of 8,192) then still gives every CU a workgroup.  scen_splits = 0: one group (all slots are
+    // scenario splits).
+    int scen_splits, periods_per_group;
 };
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, int FAST>
@@ -825,18 +817,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
     const int k0 = (lid % tiles_k) * BN;              // output cols (features of X)
     const int n0 = ((lid / tiles_k) % tiles_n) * BM;  // output rows (features of dY)
     const int split = lid / (tiles_k * tiles_n);
-    const int b_begin = split * p.chunk;
+    const int ssplit = p.scen_splits > 0 ? split % p.scen_splits : split;   // scenario split / period group of this slab slot
+    const int pgroup = p.scen_splits > 0 ? split / p.scen_splits : 0;
+    const int p_first = pgroup * p.periods_per_group;
+    const int n_per = p.scen_splits > 0 ? min(p.periods_per_group, p.n_periods - p_first) : p.n_periods;
+    const int b_begin = ssplit * p.chunk;
     const int b_end = min(b_begin + p.chunk, p.nB);
     const int nt = (b_end - b_begin) / BK;            // whole tiles only (nB % 32 == 0)
-    if (nt <= 0) return;
+    if (nt <= 0 || n_per <= 0) return;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, h = lane >> 5;
     float* slab = p.slab + (int64_t)split * p.N * p.lds_;
 
-    u32x4 ra = make_desc(p.dY, (int64_t)p.N * p.ldb);
-    u32x4 rb = make_desc(p.X, (int64_t)p.K * p.ldb);
+    u32x4 ra = make_desc(p.dY + p_first * p.pstride_dy, (int64_t)p.N * p.ldb);
+    u32x4 rb = make_desc(p.X + p_first * p.pstride_x, (int64_t)p.K * p.ldb);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
     int offA[A_INSTR], offB[B_INSTR];
@@ -888,9 +884,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wgrad_dma_kernel(
     __syncthreads();
     // flat sequence of (period, k tile): the copy of the next tile crosses period boundaries by moving the two buffer
     // descriptors to the next period's operands and rewinding the offsets, so the pipeline never drains
-    const int total = nt * p.n_periods;
-    const int group = nt * (p.flush_periods > 0 ? p.flush_periods : p.n_periods);  // tiles between two slab updates
-    int t_in = 0, period = 0;
+    const int total = nt * n_per;
+    const int group = nt * (p.flush_periods > 0 ? p.flush_periods : n_per);  // tiles between two slab updates
+    int t_in = 0, period = p_first;
     auto next_tile = [&]() {  // moves descriptors / offsets to tile t+1 (possibly the first tile of the next period)
         if (++t_in == nt) {
             t_in = 0;
@@ -1203,51 +1199,59 @@ constexpr int gemm_variant() { return 0; }
 constexpr int tune_flags() { return 0; }
 #endif
 
-// Tile shape for M > 128 output rows: the estimated time of every candidate - rounds over the 256 CUs x (MFMA tile-columns a
-// SIMD issues per k step, counting only row tiles that hold rows of the matrix, + a fixed per-round share for prologue and
-// epilogue) - and the cheapest wins.  256 x 256 is what the square 512-wide layers get (two full rounds at 65,536 scenarios);
-// 448 x 128 fits M = 393 (13 of its 14 row tiles: 94 % useful, against 77 % of two 256-row blocks) in ONE round at 32,768
-// scenarios; 256 x 128 fits M = 195 (7 of 8 row tiles) in one round; 128 x 128 (two workgroups per CU) fills the chip when
-// there are few scenario columns.
-enum WxTile { WX_256x256, WX_448x128, WX_256x128, WX_128x128 };
-WxTile pick_wx_tile(int M, int ncols) {
-    struct Cand { WxTile id; int bm, bn, mt, nt, wg_per_cu; };
-    const Cand cands[4] = {{WX_256x256, 256, 256, 4, 2, 1}, {WX_256x128, 256, 128, 4, 1, 1}, {WX_448x128, 448, 128, 7, 1, 1},
-                           {WX_128x128, 128, 128, 2, 2, 2}};
-    double best = 0.;
-    WxTile pick = WX_128x128;
-    for (const Cand& c : cands) {
-        const int64_t tiles = (int64_t)((M + c.bm - 1) / c.bm) * ((ncols + c.bn - 1) / c.bn);
-        const int64_t rounds = (tiles + 256 * c.wg_per_cu - 1) / (256 * c.wg_per_cu);
-        // fullest row block = the first one; two wave rows of mt tiles each (one wave row in the 4-wave 128 x 128 kernel, where
-        // the two co-resident workgroups share a SIMD instead)
-        const int rows = M < c.bm ? M : c.bm, row_tiles = (rows + 31) / 32;
-        int per_simd;
-        if (c.wg_per_cu == 2) per_simd = 2 * c.mt * c.nt;
-        else per_simd = ((row_tiles < c.mt ? row_tiles : c.mt) + (row_tiles > c.mt ? (row_tiles - c.mt < c.mt ? row_tiles - c.mt : c.mt) : 0)) * c.nt;
-        // (the 7-tile and the 4-wave kernels: a little more LDS traffic per flop than the 256 x 256 tile)
-        const double cost = (double)rounds * (per_simd * (c.id == WX_256x256 ? 1.0 : 1.03) + 0.6);
-        if (best == 0. || cost < best) { best = cost; pick = c.id; }
+// Tile shape of the LDS-DMA wx kernel.  Round 4 measured seventeen tilings from 1,024 to 65,536 scenarios
+// (tools/gemm_tile_probe.py, profiles/r04_gemm_tile_probe*.json) and what decides is NOT bytes of LDS traffic per flop but how
+// many workgroups a CU holds at once: a lone 256 x 256 workgroup (128 KB of LDS, one per CU) spends ~0.5-1.2 us of every k tile
+// in the copy's round trip + the barrier with nothing else to issue, while two co-resident 128 x 128 workgroups of 8 waves
+// (64 KB each, 65-90 VGPRs) cover each other's stalls: 512 x 512 x 65,536 dgrad 278 -> 262 us (0.786 -> 0.833 of the FP32 MFMA
+// peak), forward 267 = 267; at 8,192 scenarios (cfg3's shard on 8 GPUs) 73 -> 38-40 us, at 1,024 (the reference's shipped
+// batch) 70 -> 14 us.  Round 3's picker counted whole rounds of 256 CUs only, so every launch of fewer than 256 tiles "cost one
+// round" whatever the tile and ran as 16-128 big workgroups.  Three tilings remain:
+//   128 x 128, 8 waves (wave tile 64 x 32), 2 per CU   launches that fill both slots of every CU (>= 512 tiles)
+//    64 x 128, 8 waves (wave tile 32 x 32), 3 per CU   smaller launches with >= 33 output rows
+//    32 x 128, 4 waves (wave tile 32 x 32), 4 per CU   thin outputs (17 logits rows) and ragged heights (393 rows: 13 row
+//                                                      blocks of 32 instead of 4 of 128 - measured 229 us against 252 for
+//                                                      round 3's 448-row tile)
+// chosen by rows computed per row of the matrix (padding to the block height) x the measured relative cost of the tiling.
+// The 256 x 256 tiling only exists in tuning builds (A/B reference of the probes).
+enum WxTile { WX_128x128W8, WX_64x128W8, WX_32x128, WX_256x256, WX_N };
+int pick_wx_tile(int M, int ncols) {
+    auto padded = [&](int bm) { return (double)((M + bm - 1) / bm * bm) / M; };
+    const int64_t tiles128 = (int64_t)((M + 127) / 128) * ((ncols + 127) / 128);
+    double c128 = padded(128), c64 = padded(64) * 1.02, c32 = padded(32) * 1.06;   // (512 x 512 x 65,536: 262 / 265 / 281 us)
+    if (tiles128 < 512) {   // fewer than two workgroups per CU: smaller tiles put more wavefronts on a CU
+        c128 = 1e30;
+        c64 = padded(64);
+        c32 = padded(32) * 1.02;
     }
-    return pick;
+    if (c128 <= c64 && c128 <= c32) return WX_128x128W8;
+    return c64 <= c32 ? WX_64x128W8 : WX_32x128;
 }
+
+#ifdef NIC_TUNING_BUILD
+int forced_wx_tile() {  // NIC_WX_TILE: tiling id for every wx launch (tools/gemm_tile_probe.py); read at every launch
+    const char* e = getenv("NIC_WX_TILE");
+    return e ? atoi(e) : -1;
+}
+#else
+constexpr int forced_wx_tile() { return -1; }
+#endif
 
 template <int EPI>
 void dispatch_wx(const WxParams& p, hipStream_t s) {
     if (wx_fast_ok(p)) {
         // production path: LDS-DMA kernels
-        if (p.M > 128 && gemm_variant() != 1) {
-            switch ((p.tune & 128) ? WX_256x256 : pick_wx_tile(p.M, p.ncols)) {   // (bit 128: tuning builds only, see WxParams::tune)
-                case WX_256x256: launch_wx_dma<2, 4, 4, 2, EPI>(p, s); return;
-                case WX_448x128: launch_wx_dma<2, 4, 7, 1, EPI>(p, s); return;
-                case WX_256x128: launch_wx_dma<2, 4, 4, 1, EPI>(p, s); return;
-                default: launch_wx_dma<2, 2, 2, 2, EPI>(p, s); return;
-            }
+        int tile = pick_wx_tile(p.M, p.ncols);
+#ifdef NIC_TUNING_BUILD
+        if (p.tune & 128) tile = WX_256x256;
+        if (forced_wx_tile() >= 0 && forced_wx_tile() < WX_N) tile = forced_wx_tile();
+        if (tile == WX_256x256) { launch_wx_dma<2, 4, 4, 2, EPI>(p, s); return; }
+#endif
+        switch (tile) {
+            case WX_128x128W8: launch_wx_dma<2, 4, 2, 1, EPI>(p, s); return;
+            case WX_64x128W8: launch_wx_dma<2, 4, 1, 1, EPI>(p, s); return;
+            default: launch_wx_dma<1, 4, 1, 1, EPI>(p, s); return;
         }
-        if (p.M > 64) launch_wx_dma<2, 2, 2, 2, EPI>(p, s);                                               // 128 x 128
-        else if (p.M > 32) launch_wx_dma<1, 4, 2, 1, EPI>(p, s);                                          //  64 x 128
-        else launch_wx_dma<1, 4, 1, 2, EPI>(p, s);                                                        //  32 x 256
-        return;
     }
     if (p.M > 64) launch_wx<2, 2, 2, 2, EPI>(p, s);        // unaligned operands: guarded register-staged kernels
     else if (p.M > 32) launch_wx<1, 4, 2, 1, EPI>(p, s);
@@ -1387,6 +1391,35 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
     return splits;
 }
 
+// Slab slots of the all-period contraction (nic_linear_wgrad_periods) as (scenario splits x period groups): scenario chunks go
+// down to 128 scenarios (4 k tiles per period), what is still missing to fill the chip comes from splitting the horizon.
+static void wgrad_period_factors(int32_t n_slots, int32_t n_scenarios, int32_t n_periods, int* scen_splits, int* groups) {
+    int cap = n_scenarios / 128;
+    if (cap < 1) cap = 1;
+    int ss = n_slots < cap ? n_slots : cap;
+    if (ss < 1) ss = 1;
+    int g = n_slots / ss;
+    if (g > n_periods) g = n_periods;
+    if (g < 1) g = 1;
+    *scen_splits = ss;
+    *groups = g;
+}
+
+int nic_wgrad_periods_num_splits(int32_t N, int32_t K, int32_t n_scenarios, int32_t n_periods) {
+    if (N <= 0 || K <= 0 || n_scenarios <= 0 || n_periods <= 0) return 0;
+    if (!(wgrad_big(N, K) || wgrad_tall(N, K) || wgrad_mid(N, K)) || n_scenarios % BK != 0)
+        return nic_wgrad_num_splits(N, K, n_scenarios);   // shapes served period by period / by the register-staged kernels
+    int tiles;
+    if (wgrad_tall(N, K)) tiles = (N + 511) / 512;
+    else if (wgrad_mid(N, K)) tiles = (K + 255) / 256;
+    else if (wgrad_wide(N, K)) tiles = (N + 127) / 128;
+    else tiles = ((N + 255) / 256) * ((K + 255) / 256);
+    const int slots = (256 + tiles - 1) / tiles;   // one workgroup per CU, one round
+    int ss, g;
+    wgrad_period_factors(slots, n_scenarios, n_periods, &ss, &g);
+    return ss * g;
+}
+
 // argument checks + dispatch shared by nic_linear_wgrad (one period) and nic_linear_wgrad_periods
 static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t lds_, int32_t N, int32_t K, int32_t n_scenarios,
                          int32_t ldb, int32_t n_splits, int32_t n_periods, int64_t pstride_dy, int64_t pstride_x, void* stream,
@@ -1397,7 +1430,7 @@ static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t l
     if (int e = require_ld(who, n_scenarios, ldb)) return e;
     int chunk = (n_scenarios + n_splits - 1) / n_splits;
     chunk = (chunk + BK - 1) / BK * BK;
-    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, pstride_dy, pstride_x, 0};
+    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, pstride_dy, pstride_x, 0, 0, 0};
     hipStream_t s = nic::as_stream(stream);
     int bm, bn;
     wgrad_tile(N, K, &bm, &bn);
@@ -1470,12 +1503,15 @@ int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64
         }
         return 0;
     }
-    int chunk = (n_scenarios + n_splits - 1) / n_splits;
+    int scen_splits, groups;
+    wgrad_period_factors(n_splits, n_scenarios, n_periods, &scen_splits, &groups);
+    int chunk = (n_scenarios + scen_splits - 1) / scen_splits;
     chunk = (chunk + BK - 1) / BK * BK;
     const int flush = 8192 / chunk > 0 ? 8192 / chunk : 1;
+    const int ppg = (n_periods + groups - 1) / groups;
     WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, period_stride_dy,
-               period_stride_x, flush};
-    launch_wg_dma_for(p, n_splits, nic::as_stream(stream));
+               period_stride_x, flush, scen_splits, ppg};
+    launch_wg_dma_for(p, scen_splits * groups, nic::as_stream(stream));
     return nic::check_launch("nic_linear_wgrad_periods");
 }
 

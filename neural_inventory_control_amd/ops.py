@@ -104,6 +104,11 @@ def wgrad_num_splits(N, K, n_scenarios):
     return lib().nic_wgrad_num_splits(N, K, n_scenarios)
 
 
+def wgrad_periods_num_splits(N, K, n_scenarios, n_periods):
+    """Slab slots of `linear_wgrad_periods` (scenario splits x period groups) that give every CU a workgroup."""
+    return lib().nic_wgrad_periods_num_splits(N, K, n_scenarios, n_periods)
+
+
 def linear_wgrad(dY, X, slab, n_scenarios):
     """slab[split][N][lds] += per-split sum_b dY[N][b] X[K][b] (column K = bias gradient)."""
     _dev(dY)

@@ -275,7 +275,12 @@ class FusedRollout:
             thin_last = L > 1 and self.use_thin and ops.linear_bwd_thin_ok(gd[L], gd[L - 1])
             self.dZlast_hist = z(T, gd[-1], ld) if batch and not thin_last else None
             self.dZc = z(gd[-1], ld) if self.live_rows is not None else None
-            self.splits = [ops.wgrad_num_splits(gd[i + 1], gd[i], prob.B) for i in range(L)]
+            # slab slots per layer: layers contracted over ALL periods in one launch split the (period x scenario) range into
+            # (period groups x scenario chunks) so that a batch of 1,024 or 8,192 scenarios still gives every CU a workgroup
+            by_periods = [batch and not (i > 0 and self.use_thin and ops.linear_bwd_thin_ok(gd[i + 1], gd[i]))
+                          and not (i == L - 1 and self.dZlast_hist is None) for i in range(L)]   # (as _launch_backward decides)
+            self.splits = [ops.wgrad_periods_num_splits(gd[i + 1], gd[i], prob.B, T) if by_periods[i]
+                           else ops.wgrad_num_splits(gd[i + 1], gd[i], prob.B) for i in range(L)]
             self.slabs = [z(self.splits[i], gd[i + 1], (gd[i] + 1 + 3) // 4 * 4) for i in range(L)]
             self.g_reward = z(ld)
             self.gw = [torch.zeros_like(m.weight) for m in lins]

@@ -98,5 +98,5 @@ def check_against_golden(out):
             continue
         rel = float((got - ref).norm() / ref.norm())
         worst = max(worst, rel)
-        assert rel <= 2e-5, (k, rel)
+        assert rel <= 1e-5, (k, rel)
     return worst

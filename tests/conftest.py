@@ -26,3 +26,11 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---- gradient-parity record: every golden-gradient comparison of the GPU suite notes its worst relative error per test
+# (tests/grad_parity_log.py); the table is written to gpurun_out/grad_parity.json at the end of a GPU session (the round's copy is
+# committed under profiles/)
+def pytest_sessionfinish(session, exitstatus):
+    import grad_parity_log
+    grad_parity_log.dump(os.path.join(ROOT, "gpurun_out", "grad_parity.json"))

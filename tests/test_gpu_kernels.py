@@ -293,6 +293,87 @@ def test_linear_wgrad_periods_equals_per_period_launches(N, K, B, T):
     _close(db, want_b, torch.full((N,), 2.0 * T * B), "bgrad periods")
 
 
+@pytest.mark.parametrize("N,K,B,T,slots", [(512, 512, 1024, 7, None), (512, 512, 256, 9, 64), (512, 51, 1024, 6, None),
+                                           (512, 51, 512, 5, 7), (98, 512, 512, 5, None), (512, 393, 384, 4, 6),
+                                           (512, 512, 8192, 3, None)])
+def test_linear_wgrad_periods_splits_the_horizon_into_period_groups(N, K, B, T, slots):
+    """Round 4: with few scenarios the slab slots of the all-period contraction are (period group x scenario split) pairs
+    (nic_wgrad_periods_num_splits), so that a batch of 1,024 still gives every CU a workgroup.  Any slot count is accepted:
+    `None` = the count the library asks for, otherwise an arbitrary one (slots that are not used stay untouched)."""
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(N + K + T + B)
+    ldb = pad_ld(B)
+    want_slots = ops.wgrad_periods_num_splits(N, K, B, T)
+    assert want_slots >= ops.wgrad_num_splits(N, K, B) or B >= 8192
+    if B <= 1024 and N * K >= 512 * 51:
+        assert want_slots > max(1, B // 128), "few scenarios: the horizon must be split as well"
+    n_slots = slots or want_slots
+    lds = (K + 1 + 3) // 4 * 4
+    dY = _rand((T, N, ldb), gen, dev)
+    X = _rand((T, K, ldb), gen, dev)
+    want_w = torch.zeros(N, K, dtype=torch.float64)
+    want_b = torch.zeros(N, dtype=torch.float64)
+    scale_w = torch.zeros(N, K, dtype=torch.float64)
+    for t in range(T):
+        dY64, X64 = dY[t].double().cpu()[:, :B], X[t].double().cpu()[:, :B]
+        want_w += dY64 @ X64.t()
+        want_b += dY64.sum(dim=1)
+        scale_w += dY64.abs() @ X64.abs().t()
+    slab = torch.zeros(n_slots, N, lds, device=dev)
+    ops.linear_wgrad_periods(dY, X, slab, B)
+    assert _lib.lib().nic_last_kernel().decode().startswith("gemm_wgrad_dma_kernel")
+    dW = torch.full((N, K), float("nan"), device=dev)
+    db = torch.full((N,), float("nan"), device=dev)
+    ops.wgrad_reduce(slab, dW, db, K, 1.0)
+    torch.cuda.synchronize()
+    _close(dW, want_w, scale_w, "wgrad period groups")
+    _close(db, want_b, torch.full((N,), 1.0 * T * B), "bgrad period groups")
+    used = int((slab.abs().sum(dim=(1, 2)) > 0).sum())
+    assert 1 <= used <= n_slots
+
+
+def test_every_wx_tile_of_the_picker_is_exercised_and_correct():
+    """Round 4: `pick_wx_tile` chooses among three tilings of the LDS-DMA kernel (co-resident workgroups per CU, padding to the
+    block height).  A sweep over output rows x scenario counts - from the reference's shipped batch size to BASELINE cfg3's - checks
+    forward and input gradient against float64 and records which kernel ran: every tiling must come up at least once."""
+    dev = "cuda"
+    seen = set()
+    sweep = [(512, 512, b) for b in (512, 1024, 2048, 4096, 8192, 16384, 32768)] + \
+            [(17, 512, b) for b in (1024, 4096, 16384, 65536)] + [(64, 512, b) for b in (1024, 8192, 65536)] + \
+            [(128, 512, b) for b in (1024, 4096, 32768)] + [(393, 512, b) for b in (2048, 32768)] + \
+            [(256, 256, b) for b in (1024, 4096, 16384, 65536)] + [(195, 512, 32768), (512, 512, 65536)]
+    for N, K, B in sweep:
+        gen = torch.Generator().manual_seed(N * 7 + K + B)
+        ldb = pad_ld(B)
+        W = torch.zeros(N, (K + 31) // 32 * 32, device=dev)
+        W[:, :K] = _rand((N, K), gen, dev, 0.3)
+        Wt = torch.zeros(K, (N + 31) // 32 * 32, device=dev)
+        Wt[:, :N] = W[:, :K].t()
+        bias = _rand((N,), gen, dev)
+        X = _rand((K, ldb), gen, dev)
+        Y = torch.full((N, ldb), float("nan"), device=dev)
+        ops.linear_fwd(W[:, :K], bias, X, Y, B, _lib.NIC_ACT_ELU)
+        seen.add(_lib.lib().nic_last_kernel().decode())
+        # a sample of columns against float64 (the whole product at 65,536 columns would take the CPU a minute)
+        cols = torch.unique(torch.cat([torch.arange(0, min(B, 300)), torch.randint(0, B, (300,), generator=gen),
+                                       torch.arange(max(0, B - 300), B)]))
+        W64, X64 = W[:, :K].double().cpu(), X.double().cpu()[:, cols]
+        pre = W64 @ X64 + bias.double().cpu()[:, None]
+        _close(Y[:, cols.to(dev)], torch.where(pre > 0, pre, torch.expm1(pre)), W64.abs() @ X64.abs() + bias.double().cpu().abs()[:, None],
+               ("fwd", N, K, B))
+        H = torch.where(X > 0, X, torch.expm1(X))
+        dX = torch.full((K, ldb), float("nan"), device=dev)
+        ops.linear_dgrad(Wt[:, :N], Y, H, dX, B, _lib.NIC_ACT_ELU, False)
+        seen.add(_lib.lib().nic_last_kernel().decode())
+        Y64, H64 = Y.double().cpu()[:, cols], H.double().cpu()[:, cols]
+        want = (W64.t() @ Y64) * torch.where(H64 > 0, torch.ones_like(H64), H64 + 1)
+        _close(dX[:, cols.to(dev)], want, W64.t().abs() @ Y64.abs(), ("dgrad", N, K, B))
+        assert bool(torch.isnan(dX[:, (B + 3) // 4 * 4:]).all()) and bool(torch.isnan(Y[:, (B + 3) // 4 * 4:]).all())
+    tiles = {k.split("<")[1].rsplit(",", 1)[0] for k in seen if k.startswith("gemm_wx_dma_kernel<")}
+    every = {"2,4,2,1", "2,4,1,1", "1,4,1,1"}   # 128 x 128 and 64 x 128 (8 waves), 32 x 128 (4 waves)
+    assert tiles == every, (sorted(tiles), sorted(seen))
+
+
 # ---- sampler ------------------------------------------------------------------------------------------------------
 
 def test_sampler_normal_moments_and_sharding_invariance():

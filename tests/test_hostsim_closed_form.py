@@ -16,7 +16,7 @@ def launch():
 @pytest.mark.parametrize("name", cfc.CLOSED_FORM_CASES)
 def test_closed_form_body_matches_golden(launch, name):
     worst = cfc.check_against_golden(cfc.run_case(name, launch, "cpu"))
-    assert worst <= 2e-5
+    assert worst <= 1e-5
 
 
 @pytest.mark.parametrize("name", cfc.CLOSED_FORM_CASES)
@@ -30,4 +30,4 @@ def test_closed_form_profit_objective_matches_oracle(launch, name):
     for (k, got), ref in zip(out["grads"].items(), grads):
         if float(ref.abs().max()) == 0.0:
             continue
-        assert float((got - ref).norm() / ref.norm()) <= 2e-5, k
+        assert float((got - ref).norm() / ref.norm()) <= 1e-5, k
