@@ -313,6 +313,107 @@ def kernel_report(timer, shape, steps):
     return out
 
 
+def bench_epoch(args):
+    """`--workload cfg3_yaml | cfg5_yaml`: the reference's SHIPPED configuration through the public epoch loop
+    (`main_run.build` -> `Trainer.do_one_epoch`, trainer.py:143-179): 8,192 training samples, shuffled batches of 1,024, 50
+    periods, rollout + backward + Adam per batch.  A "step" is one batch; K steps = ceil(K / 8) whole epochs.  The same epoch is
+    also timed with the rollout launch sequence replayed from a HIP graph / launched eagerly (whichever the default is not) and
+    with the reference's torch `DataLoader` (per-sample collate on the host + H2D per batch, main_run.py:101-103) instead of the
+    device-resident batches - reported beside the main figure, not inside it."""
+    from neural_inventory_control_amd import _lib, main_run, parallel, workloads
+    from neural_inventory_control_amd.rollout import KernelTimer
+    rank, world, device = parallel.init_from_env()
+    _lib.require_device()
+    setting, hyper, desc = workloads.get_epoch(args.workload)
+    torch.manual_seed(1234)
+    c = main_run.build(setting, hyper, device, rank, world)
+    tr, model, opt, loaders = c["trainer"], c["model"], c["optimizer"], c["data_loaders"]
+    pp, pbd = c["problem_params"], c["params_by_dataset"]["train"]
+    T, S, n_batches = pbd["periods"], pp["n_stores"], len(loaders["train"])
+    if args.graph:
+        tr.use_rollout_graph = True
+    elif args.no_graph:
+        tr.use_rollout_graph = False
+
+    def epoch(loader=None):
+        return tr.do_one_epoch(opt, loader or loaders["train"], c["loss_function"], c["simulator"], model, T, pp,
+                               c["observation_params"], train=True, ignore_periods=pbd["ignore_periods"])
+
+    def timed(n_epochs, loader=None):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_epochs):
+            last = epoch(loader)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n_epochs, last
+
+    n_epochs = max(1, (args.steps + n_batches - 1) // n_batches)
+    for _ in range(max(1, args.warmup) + 2):   # eager run, auto-graph measurement / capture run, steady state
+        epoch()
+    eng = tr._engines.get((id(model), True))
+    if world > 1:
+        torch.distributed.barrier()
+    dt, last = timed(n_epochs)
+    if world > 1:
+        torch.distributed.barrier()
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax)
+    if rank != 0:
+        return
+    n_samples = len(loaders["train"].dataset)
+    ms_batch = dt / n_batches * 1e3
+    out = {"metric": "scenario-steps/sec (scenarios x stores x T) per training step", "value": n_samples * S * T / dt,
+           "unit": "scenario-steps/s", "n_gpus": world, "steps": n_epochs * n_batches, "warmup": args.warmup, "ms_per_step": ms_batch,
+           "ms_per_epoch": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": desc + "; training step = one shuffled batch: rollout fwd + bwd + Adam", "name": args.workload,
+                      "samples": n_samples, "batch_size": pbd["batch_size"], "batches_per_epoch": n_batches, "stores": S, "periods": T,
+                      "parallelism": f"scenario-sharded dp{world}", "train_loss_per_store_period": last[1],
+                      "route": type(eng).__name__ if eng is not None else "generic",
+                      "rollout_graph": {"setting": tr.use_rollout_graph, "replaying": bool(eng is not None and eng._graph_on()),
+                                        "auto_probe": getattr(eng, "auto_graph_probe", None)}}}
+    if eng is not None and not args.no_kernel_timing:
+        # the other launch mode, and the reference-style host loader, on the same model (after the main figure)
+        alt = {}
+        was = tr.use_rollout_graph
+        for label, mode in (("eager", False), ("graph", True)):
+            tr.use_rollout_graph = mode
+            epoch(); epoch(); epoch()
+            alt[label + "_ms_per_epoch"] = round(timed(n_epochs)[0] * 1e3, 3)
+        tr.use_rollout_graph = was
+        from torch.utils.data import DataLoader
+        host = DataLoader(loaders["train"].dataset, batch_size=pbd["batch_size"], shuffle=True)
+        epoch(host)
+        alt["torch_dataloader_ms_per_epoch"] = round(timed(1, host)[0] * 1e3, 3)
+        out["config"]["epoch_variants"] = alt
+        # per-kernel figures of one eager epoch
+        tr.use_rollout_graph = False
+        epoch()
+        timer = eng.timer = KernelTimer(stride=args.timing_stride or 10)
+        epoch()
+        torch.cuda.synchronize()
+        eng.timer = None
+        tr.use_rollout_graph = was
+        prob = eng.prob
+        shape = dict(n=pbd["batch_size"], T=T, S=S, Wn=prob.Wn, E=prob.E, Ws=prob.Ws, Ww=prob.Ww, We=prob.We, F=eng.dims[0],
+                     nh=len(eng.dims) - 2, n_out=eng.dims[-1], train=True, gnn=None)
+        kernels = kernel_report(timer, shape, n_batches)
+        rated = {k: v for k, v in kernels.items() if "bound" in v}
+        if rated:
+            dom = max(rated, key=lambda k: rated[k]["total_ms_per_step"])
+            d = rated[dom]
+            out["roofline"] = {"bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"], "frac": d["frac"],
+                               "traffic": None, "kernel": f"{d['kernel']} ({dom})", "mean_launch_ms": d["mean_ms"],
+                               "launches_per_step": d["launches_per_step"],
+                               ("algorithmic_flops_per_launch" if d["bound"] == "mfma" else "algorithmic_bytes_per_launch"):
+                                   d.get("algorithmic_flops_per_launch", d.get("algorithmic_bytes_per_launch"))}
+        out["kernels"] = kernels
+    print(json.dumps(out))
+    if parallel.active():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,6 +432,7 @@ def main():
                     help="write the (kernel class, kernel) sequence of the timed steps as JSON and skip the event timing: what "
                          "tools/collect_profiles.py joins the profiler's per-dispatch counter rows to")
     ap.add_argument("--graph", action="store_true", help="replay the launch sequence from a HIP graph (implies --no-kernel-timing)")
+    ap.add_argument("--no-graph", action="store_true", help="epoch workloads: never replay (default: the Trainer's measured choice)")
     ap.add_argument("--generic-route", action="store_true",
                     help="A/B: run the workload on the generic per-period route even where a fused engine exists")
     ap.add_argument("--lane-scenarios", type=int, default=0, choices=(0, 16, 32),
@@ -345,6 +447,9 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
+    from neural_inventory_control_amd import workloads as _w
+    if args.workload in _w.EPOCH_WORKLOADS:
+        return bench_epoch(args)
     from neural_inventory_control_amd import _lib, parallel
     from neural_inventory_control_amd.rollout import KernelTimer
     rank, world, device = parallel.init_from_env()

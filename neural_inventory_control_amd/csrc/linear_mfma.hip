@@ -642,6 +642,124 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_wx_dma_kernel(WxP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// wx kernel, streamed form for SMALL launches (round 4): the reference's shipped batch of 1,024 scenarios, the thin logits /
+// first-layer-gradient GEMMs at every batch size.  A launch with a few hundred 32 x 32 output tiles cannot fill the chip with
+// workgroup tiles, and a lone workgroup's LDS pipeline pays ~0.45 us of copy round trip + barrier per 32-deep k tile that
+// nothing overlaps (16 k tiles: 13-25 us for 0.5 GFLOP).  Here ONE WAVEFRONT owns a 32 x (32 NT) output tile and reads its
+// operands straight from L2 into registers - no LDS tile, no barrier in the k loop: per 16-deep k group a lane fetches its 8
+// A values as two 16-byte loads (row m0 + lane, k contiguous) and its 8 NT B values as dword loads (rows of X: 128 contiguous
+// bytes per half wave), D = 4 groups ahead of the MFMAs that consume them (counted vmcnt, no waits on the critical path).
+// KS wavefronts of a workgroup split the contraction (K / KS each) and add their accumulators through LDS once, so even a
+// 17-row logits layer at 1,024 scenarios is 32 tiles x 4 = 128 wavefronts with 8 k groups each instead of one 16-tile chain.
+// Operand traffic is tiles x K x 32 (1 + NT) x 4 B from L2 (weights and the activations of a small batch are L2-resident):
+// only worth it while that stays below ~100 MB - pick_wx_stream.
+// Same k order as the LDS-DMA kernel within a group (lanes 0-31: k = kk, lanes 32-63: k = 8 + kk).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, int KS, int EPI>
+__global__ __launch_bounds__(64 * KS) void gemm_wx_stream_kernel(WxParams p) {
+    constexpr int D = 4;
+    __shared__ float red[(KS > 1 ? KS - 1 : 1) * NT * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int li = lane & 31, h = lane >> 5;
+    const int tiles_m = (p.M + 31) / 32;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);   // the row tiles of one column panel run on one XCD (shared L2)
+    const int m0 = (tile % tiles_m) * 32, c0 = (tile / tiles_m) * (32 * NT);
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)p.M * p.lda), rB = make_rsrc(p.Bm, (int64_t)p.K * p.ldb);
+    // this wavefront's k groups: [g_lo, g_lo + per), per a multiple of D; groups past K read B rows beyond the descriptor (zeros)
+    const int ng_all = (p.K + 15) / 16;
+    const int per = ((ng_all + KS - 1) / KS + D - 1) / D * D, nblk = per / D;
+    const int g_lo = wave * per;
+    const int ldb4 = (int)p.ldb * 4;
+    int offA = (int)((((int64_t)m0 + li) * p.lda + g_lo * 16 + h * 8) * 4);
+    int offB = (int)((((int64_t)g_lo * 16 + h * 8) * p.ldb + c0 + li) * 4);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float a[D][8], b[D][NT][8];
+    auto load = [&](int d) {
+        const float4 lo = buf_load4(rA, offA), hi = buf_load4(rA, offA + 16);
+        a[d][0] = lo.x; a[d][1] = lo.y; a[d][2] = lo.z; a[d][3] = lo.w;
+        a[d][4] = hi.x; a[d][5] = hi.y; a[d][6] = hi.z; a[d][7] = hi.w;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                b[d][j][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, offB + j * 128, kk * ldb4, 0));
+        offA += 64;
+        offB += 16 * ldb4;
+    };
+    auto compute = [&](int d) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][kk], b[d][j][kk], acc[j], 0, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(d);
+    for (int blk = 0; blk + 1 < nblk; ++blk) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            compute(d);
+            load(d);
+        }
+    }
+    // the epilogue's own operands are fetched under the last block's MFMAs (wave 0 writes the tile)
+    const int row_base = m0 + 4 * h;   // accumulator register r holds row row_base + (r & 3) + 8 (r >> 2), column c0 + 32 j + li
+    float aux[16];   // forward: bias[row]; dgrad: act'(Hprev) of tile column j = 0 (further columns are read in the epilogue)
+    const bool use_h = EPI == EPI_DGRAD && p.Hprev != nullptr && p.act == NIC_ACT_ELU;
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            const bool ok = row < p.M && c0 + li < p.ncols;
+            if (EPI == EPI_BIAS_ACT) aux[r] = (p.bias != nullptr && row < p.M) ? p.bias[row] : 0.f;
+            else aux[r] = (use_h && ok) ? p.Hprev[(int64_t)row * p.ldb + c0 + li] : 1.f;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) compute(d);
+
+    if constexpr (KS > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((wave - 1) * NT + j) * 16 + r) * 64 + lane] = acc[j][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < KS - 1; ++w)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] += red[((w * NT + j) * 16 + r) * 64 + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = c0 + j * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            if (row >= p.M || col >= p.ncols) continue;
+            const int64_t off = (int64_t)row * p.ldb + col;
+            float y = acc[j][r];
+            if (EPI == EPI_BIAS_ACT) {
+                y += aux[r];
+                if (p.act == NIC_ACT_ELU) y = elu_f(y);
+            } else {
+                if (use_h) y *= elu_grad_from_out(j == 0 ? aux[r] : p.Hprev[off]);
+                if (p.accumulate) y += p.C[off];
+            }
+            p.C[off] = y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // wgrad kernel: slab[split][n][k] += sum_{b in split} dY[n][b] * X[k][b]   (k == K: bias column, X row of ones)
 // ---------------------------------------------------------------------------------------------------------------
 struct WgParams {
@@ -1157,12 +1275,21 @@ bool wx_fast_ok(const WxParams& p) {
            (int64_t)p.K * p.ldb < (1ll << 28);
 }
 
+#ifdef NIC_TUNING_BUILD
+int wx_lds_pad() {  // NIC_WX_LDS_PAD: unused dynamic LDS per workgroup = fewer co-resident workgroups per CU (occupancy experiments)
+    const char* e = getenv("NIC_WX_LDS_PAD");
+    return e ? atoi(e) : 0;
+}
+#else
+constexpr int wx_lds_pad() { return 0; }
+#endif
+
 template <int WM, int WN, int MT, int NT, int EPI>
 void launch_wx_dma(const WxParams& p, hipStream_t s) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.ncols + BN - 1) / BN;
     nic::note_kernelf("gemm_wx_dma_kernel<%d,%d,%d,%d,%s>", WM, WN, MT, NT, epi_name(EPI));
-    hipLaunchKernelGGL((gemm_wx_dma_kernel<WM, WN, MT, NT, EPI>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), 0, s, p);
+    hipLaunchKernelGGL((gemm_wx_dma_kernel<WM, WN, MT, NT, EPI>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), wx_lds_pad(), s, p);
 }
 
 template <int WM, int WN, int MT, int NT, int EPI>
@@ -1237,9 +1364,52 @@ int forced_wx_tile() {  // NIC_WX_TILE: tiling id for every wx launch (tools/gem
 constexpr int forced_wx_tile() { return -1; }
 #endif
 
+// Streamed form (gemm_wx_stream_kernel) for launches of at most 1,024 output tiles of 32 x 32: NT = 1 (every tile its own
+// wavefront), KS = wavefronts that split the contraction, so that the launch has ~2,048 wavefronts where K allows.
+// Returns 0 (LDS-DMA kernels) or KS.  Measured (tools/gemm_tile_probe.py --stream, profiles/r04_gemm_stream_probe.json; us per
+// launch, LDS-DMA -> streamed): 512 x 512 x 1,024 scenarios 21.7 -> 10.5, x 2,048 22.8 -> 15.7, x 4,096 25.0 -> 29.4 (not taken);
+// logits 17 x 512 13.2 -> 7.5 up to 8,192 scenarios, 14.5 -> 9.3 at 16,384; first-layer input gradient 51 x 512 20.6 -> 7.6.
+int pick_wx_stream(int M, int K, int ncols) {
+    const int64_t tiles = (int64_t)((M + 31) / 32) * ((ncols + 31) / 32);
+    if (tiles > 1024 || K < 128) return 0;   // (a short contraction is 2-4 k tiles of the LDS pipeline: nothing to gain, measured)
+    int ks = 1;
+    while (ks < 4 && tiles * ks * 2 <= 2048 && K >= 64 * ks * 2) ks *= 2;
+    return ks;
+}
+
+template <int NT, int KS, int EPI>
+void launch_wx_stream(const WxParams& p, hipStream_t s) {
+    const int tiles = ((p.M + 31) / 32) * ((p.ncols + 32 * NT - 1) / (32 * NT));
+    nic::note_kernelf("gemm_wx_stream_kernel<%d,%d,%s>", NT, KS, epi_name(EPI));
+    hipLaunchKernelGGL((gemm_wx_stream_kernel<NT, KS, EPI>), dim3(tiles), dim3(64 * KS), 0, s, p);
+}
+
+#ifdef NIC_TUNING_BUILD
+int forced_wx_stream() {  // NIC_WX_STREAM: 0 = never, 10 * NT + KS = that instantiation for every wx launch; unset = the picker
+    const char* e = getenv("NIC_WX_STREAM");
+    return e ? atoi(e) : -1;
+}
+#else
+constexpr int forced_wx_stream() { return -1; }
+#endif
+
 template <int EPI>
 void dispatch_wx(const WxParams& p, hipStream_t s) {
     if (wx_fast_ok(p)) {
+        int stream = 10 + pick_wx_stream(p.M, p.K, p.ncols);
+        if (stream == 10) stream = 0;
+        if (forced_wx_stream() >= 0) stream = forced_wx_stream();
+        switch (stream) {
+            case 11: launch_wx_stream<1, 1, EPI>(p, s); return;
+            case 12: launch_wx_stream<1, 2, EPI>(p, s); return;
+            case 14: launch_wx_stream<1, 4, EPI>(p, s); return;
+#ifdef NIC_TUNING_BUILD
+            case 21: launch_wx_stream<2, 1, EPI>(p, s); return;
+            case 22: launch_wx_stream<2, 2, EPI>(p, s); return;
+            case 24: launch_wx_stream<2, 4, EPI>(p, s); return;
+#endif
+            default: break;
+        }
         // production path: LDS-DMA kernels
         int tile = pick_wx_tile(p.M, p.ncols);
 #ifdef NIC_TUNING_BUILD
@@ -1278,7 +1448,11 @@ void wgrad_tile(int N, int K, int* bm, int* bn) {
 }
 
 // big layers: 256 x 256 LDS-DMA tiles, one workgroup per CU
-bool wgrad_big(int N, int K) { return N >= 192 && K >= 192; }
+bool wgrad_big(int N, int K) { return N >= 192 && K >= 129; }
+// N >= 192 output rows over 65..128 input rows (the shipped many-warehouse setting's first layer: 512 x 66): 256 x 128 tiles on
+// the LDS-DMA pipeline (round 4; the register-staged 128 x 128 kernel ran that layer's all-period gradient at 0.02 of peak)
+bool wgrad_half(int N, int K) { return N >= 192 && K > 64 && K <= 128; }
+bool wgrad_dma_shape(int N, int K);
 bool wgrad_tall(int N, int K);
 bool wgrad_wide(int N, int K);
 bool wgrad_mid(int N, int K);
@@ -1304,9 +1478,20 @@ int wgrad_wide_nt(int K) { return (K + 63) / 64; }   // 5, 6 or 7 column tiles o
 // (the register-staged 128 x 128 kernel reaches 0.37 of peak there)
 bool wgrad_mid(int N, int K) { return N >= 96 && N <= 128 && K >= 192; }
 
-// the LDS-DMA weight-gradient kernel for a shape (wgrad_big, wgrad_mid or wgrad_tall)
+bool wgrad_dma_shape(int N, int K) { return wgrad_big(N, K) || wgrad_tall(N, K) || wgrad_mid(N, K) || wgrad_half(N, K); }
+// output tiles of one scenario chunk under the LDS-DMA kernel launch_wg_dma_for picks (what the split counts divide 256 by)
+int wgrad_dma_tiles(int N, int K) {
+    if (wgrad_tall(N, K)) return (N + 511) / 512;
+    if (wgrad_half(N, K)) return (N + 255) / 256;
+    if (wgrad_mid(N, K)) return (K + 255) / 256;
+    if (wgrad_wide(N, K)) return (N + 127) / 128;
+    return ((N + 255) / 256) * ((K + 255) / 256);
+}
+
+// the LDS-DMA weight-gradient kernel for a shape (wgrad_dma_shape)
 void launch_wg_dma_for(const WgParams& p, int n_splits, hipStream_t s) {
     if (wgrad_tall(p.N, p.K)) launch_wg_dma<8, 1, 2, 2>(p, n_splits, s);
+    else if (wgrad_half(p.N, p.K)) launch_wg_dma<4, 2, 2, 2>(p, n_splits, s);
     else if (wgrad_mid(p.N, p.K)) launch_wg_dma<2, 4, 2, 2>(p, n_splits, s);
     else if (wgrad_wide(p.N, p.K)) {
         const int nt = wgrad_wide_nt(p.K);
@@ -1360,17 +1545,8 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
     wgrad_tile(N, K, &bm, &bn);
     int tiles = ((N + bm - 1) / bm) * ((K + 1 + bn - 1) / bn);
     int target = 1024;                                 // ~4 workgroups per CU in total
-    if (wgrad_wide(N, K)) {                            // 128 x 448 tiles, one workgroup per CU, one round
-        tiles = (N + 127) / 128;
-        target = 256;
-    } else if (wgrad_mid(N, K)) {                      // 128 x 256 tiles
-        tiles = (K + 255) / 256;
-        target = 256;
-    } else if (wgrad_big(N, K)) {                      // 256 x 256 tiles, one workgroup per CU, one round
-        tiles = ((N + 255) / 256) * ((K + 255) / 256);
-        target = 256;
-    } else if (wgrad_tall(N, K)) {                     // 512 x 64 tiles (LDS-DMA), one workgroup per CU
-        tiles = (N + 511) / 512;
+    if (wgrad_dma_shape(N, K)) {                       // LDS-DMA tiles, one workgroup per CU, one round
+        tiles = wgrad_dma_tiles(N, K);
         target = 256;
     }
     if (N <= 32 && (K <= 32 || (K <= 128 && K % 32 != 0))) {  // wgrad_small_kernel: one split per wave, >= 2048 columns each
@@ -1407,13 +1583,9 @@ static void wgrad_period_factors(int32_t n_slots, int32_t n_scenarios, int32_t n
 
 int nic_wgrad_periods_num_splits(int32_t N, int32_t K, int32_t n_scenarios, int32_t n_periods) {
     if (N <= 0 || K <= 0 || n_scenarios <= 0 || n_periods <= 0) return 0;
-    if (!(wgrad_big(N, K) || wgrad_tall(N, K) || wgrad_mid(N, K)) || n_scenarios % BK != 0)
+    if (!wgrad_dma_shape(N, K) || n_scenarios % BK != 0)
         return nic_wgrad_num_splits(N, K, n_scenarios);   // shapes served period by period / by the register-staged kernels
-    int tiles;
-    if (wgrad_tall(N, K)) tiles = (N + 511) / 512;
-    else if (wgrad_mid(N, K)) tiles = (K + 255) / 256;
-    else if (wgrad_wide(N, K)) tiles = (N + 127) / 128;
-    else tiles = ((N + 255) / 256) * ((K + 255) / 256);
+    const int tiles = wgrad_dma_tiles(N, K);
     const int slots = (256 + tiles - 1) / tiles;   // one workgroup per CU, one round
     int ss, g;
     wgrad_period_factors(slots, n_scenarios, n_periods, &ss, &g);
@@ -1448,7 +1620,7 @@ static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t l
         else if (K <= 96) hipLaunchKernelGGL(wgrad_small_kernel<3>, g, b, 0, s, p, n_splits);
         else hipLaunchKernelGGL(wgrad_small_kernel<4>, g, b, 0, s, p, n_splits);
     }
-    else if ((wgrad_big(N, K) || wgrad_tall(N, K) || wgrad_mid(N, K)) && dma_ok && gemm_variant() != 2) launch_wg_dma_for(p, n_splits, s);
+    else if (wgrad_dma_shape(N, K) && dma_ok && gemm_variant() != 2) launch_wg_dma_for(p, n_splits, s);
     else if (bm == 128 && bn == 128) launch_wg<2, 2, 2, 2>(p, n_splits, s);
     else if (bm == 128) launch_wg<2, 2, 2, 1>(p, n_splits, s);
     else if (bm == 64) launch_wg<1, 4, 2, 1>(p, n_splits, s);
@@ -1478,7 +1650,7 @@ int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64
     NIC_REQUIRE(period_stride_dy % 4 == 0 && period_stride_x % 4 == 0,
                 "nic_linear_wgrad_periods: period strides must be multiples of 4 elements (16-byte aligned operands)");
     const bool dma_ok = dY && X && slab && N > 0 && K > 0 && lds_ >= K + 1 && n_splits >= 1 && n_scenarios > 0 && ldb >= n_scenarios &&
-                        (wgrad_big(N, K) || wgrad_tall(N, K) || wgrad_mid(N, K)) && gemm_variant() != 2 && ldb % 4 == 0 && n_scenarios % BK == 0 && lds_ % 4 == 0 &&
+                        wgrad_dma_shape(N, K) && gemm_variant() != 2 && ldb % 4 == 0 && n_scenarios % BK == 0 && lds_ % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (int64_t)N * ldb < (1ll << 28) &&
                         (int64_t)K * ldb < (1ll << 28);

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * kThinInWaves) __attribute__((amdgpu_waves_per_
     for (int s = 0; s < KS; ++s) x[s] = ldf(rX, vx, 2 * s * ld4);
     const int vo = 4 * h * ld4 + j * 4;
     // this wavefront's slice of the 32-row blocks (blockIdx.y)
-    const int all_blocks = N / 32, per = (all_blocks + kThinInSplit - 1) / kThinInSplit;
+    const int all_blocks = N / 32, n_split = (int)gridDim.y, per = (all_blocks + n_split - 1) / n_split;
     const int nb_lo = (int)blockIdx.y * per, n_blocks = (nb_lo + per < all_blocks ? nb_lo + per : all_blocks);
     if (nb_lo >= n_blocks) return;
     auto load_block = [&](int nb, float (&a)[KS]) {
@@ -341,7 +341,14 @@ int nic_linear_fwd_thin_in(const float* Wt, int64_t ldwt, const float* bias, con
                 "nic_linear_fwd_thin_in: ldb (%d) must be a multiple of 4 and >= n_scenarios (%d)", ldb, n_scenarios);
     NIC_REQUIRE((int64_t)N * ldb * 4 < (1ll << 31), "nic_linear_fwd_thin_in: the output must span less than 2 GiB");
     const int n_cols = (n_scenarios + 3) / 4 * 4;   // like nic_linear_fwd: the scenario count rounded up to 4 columns is written
-    const dim3 grid(nic::ceil_div(n_cols, 32 * kThinInWaves), kThinInSplit), block(64 * kThinInWaves);
+    // wavefronts that share a 32-scenario chunk, each taking a slice of the 32-row output blocks: two at BASELINE's sizes (4,096
+    // wavefronts at 65,536 scenarios); with few scenarios the rows are split further so that the launch still has ~4,096
+    // wavefronts and a wavefront's serial chain of row blocks gets shorter (8,192 scenarios: 19 -> 9 us, round 4)
+    const int chunks = nic::ceil_div(n_cols, 32);
+    int split = (4096 + chunks - 1) / chunks;
+    if (split < kThinInSplit) split = kThinInSplit;
+    if (split > N / 32) split = N / 32;
+    const dim3 grid(nic::ceil_div(n_cols, 32 * kThinInWaves), split), block(64 * kThinInWaves);
     hipStream_t s = nic::as_stream(stream);
     nic::note_kernel("thin_in_fwd_kernel<26>");
     hipLaunchKernelGGL(thin_in_fwd_kernel<26>, grid, block, 0, s, Wt, ldwt, bias, X, Y, N, K, n_cols, (int64_t)ldb, act);

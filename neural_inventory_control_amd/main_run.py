@@ -96,6 +96,8 @@ def build(config_setting, config_hyperparams, device, rank=0, world_size=1):
     trainer_params = dict(trainer_params)
     # optional extension key: replay each generic-route training step from one HIP graph (Trainer.use_step_graph)
     trainer.use_step_graph = bool(trainer_params.get("use_step_graph", False))
+    # ... and for the MLP engine's launch sequence: true / false / "auto" (default: decided by measurement, rollout.py)
+    trainer.use_rollout_graph = trainer_params.get("use_rollout_graph", "auto")
     trainer_params["base_dir"] = trainer_params.get("base_dir", "saved_models")
     trainer_params["save_model_folders"] = [trainer.get_year_month_day(), nn_params["name"]]
     trainer_params["save_model_filename"] = trainer.get_time_stamp()

@@ -449,7 +449,8 @@ class DataDrivenNet(MyNeuralNetwork):
         # serve anyone" test (:499 upstream, a device tensor compared on the host) is answered from the list - the upstream form
         # costs one host->device copy and Wn device->host syncs per PERIOD (1.3 ms per period on the real-data batch) and cannot
         # be captured into a HIP graph.
-        mkey = (id(adjacency), str(outputs.device))
+        # (keyed on the list's CONTENT: `id()` of a list that was replaced can be recycled)
+        mkey = (tuple(tuple(row) for row in adjacency), str(outputs.device))
         if getattr(self, "_edge_mask_key", None) != mkey:
             self._edge_mask = torch.tensor(adjacency, dtype=torch.float32, device=outputs.device).transpose(0, 1)  # [S, Wn]
             self._serves = [sum(adjacency[w]) > 0 for w in range(len(adjacency))]
@@ -567,13 +568,15 @@ class JustInTime(MyNeuralNetwork):
         # which connected warehouse has the shortest batch-mean lead time for each store: recomputed for every BATCH like
         # upstream (:695-699; per-sample lead times from file can move the argmin from batch to batch), but only once per
         # batch - the lead-time tensor of an observation is the same object for all periods of a rollout
-        lt_key = (lt.data_ptr(), lt._version, tuple(lt.shape))
-        if getattr(self, "_fastest_key", None) != lt_key:
+        # (the cache HOLDS the tensor it was computed from and compares identity + version: an address alone can be handed to
+        # the next batch's tensor by the caching allocator; and every rollout starts afresh at its first period)
+        held = getattr(self, "_fastest_for", None)
+        if held is None or held[0] is not lt or held[1] != lt._version or cur == period_shift:
             mean_lt = lt.mean(dim=0).cpu()
             self._fastest = [
                 (int(conn[torch.argmin(mean_lt[st, conn])]) if len(conn) > 0 else None)
                 for st, conn in ((st, adj[:, st].nonzero(as_tuple=True)[0]) for st in range(n_stores))]
-            self._fastest_key = lt_key
+            self._fastest_for = (lt, lt._version)
         fastest = self._fastest
         alloc = torch.zeros(n, n_stores, n_warehouses, device=dev)
         wh = torch.zeros(n, n_warehouses, device=dev)
@@ -795,6 +798,11 @@ class NeuralNetworkCreator:
             if val is None:
                 p["output_sizes"][key] = self.set_default_output_size(key, scenario.problem_params)
         cls = self.get_architecture(p["name"])
+        if p["name"] == "symmetry_aware":
+            import warnings
+            warnings.warn("symmetry_aware is EXPERIMENTAL: the reference ships no source or config for it (its registry raises "
+                          "KeyError for this name); this implementation follows a recovered description and is checked only "
+                          "against this repository's own CPU restatement - results are not reference parity", stacklevel=2)
         if p["name"] in ("vanilla_warehouse", "gnn", "just_in_time", "data_driven"):
             model = cls(p, scenario, device=device)
         else:

@@ -105,10 +105,11 @@ class FusedRollout:
         op = observation_params
         if op is None:
             return False
-        past, tf, sf = op["demand"]["past_periods"], op["time_features"], op["sample_features"]
+        past, tf, sf = (op["demand"] or {}).get("past_periods"), op["time_features"], op["sample_features"]
+        past = past if isinstance(past, int) else 0   # (`past_periods: null` / a missing key: no window -> the generic route)
         if getattr(model, "nn_args", {}).get("name") == "data_driven":
             # (sample features, e.g. `store_nbr`, may be in the observation: DataDrivenNet.forward does not read them)
-            return (list(tf or []) == ["days_from_christmas"] and past >= 1
+            return (isinstance(tf, (list, tuple)) and list(tf) == ["days_from_christmas"] and past >= 1
                     and (data is None or ("days_from_christmas" in data and "underage_costs" in data)))
         return past == 0 and not tf and not sf
 
@@ -122,7 +123,12 @@ class FusedRollout:
         self.head = _HEADS[model.nn_args["name"]]
         self._key = None
         self.timer = None  # KernelTimer or None
-        self.use_graph = False  # replay the launch sequence from a HIP graph (see _replay_or_capture)
+        # replay the launch sequence from a HIP graph (see _replay_or_capture): True / False, or "auto" = decided by MEASUREMENT
+        # on the second training run of a shape: if the host needs longer to enqueue the ~13 launches per period than the GPU
+        # needs to run them (small batches on a slow or busy host), the step is launch-bound and later runs are replayed
+        self.use_graph = False
+        self._auto_graph = None   # "auto": None = not measured yet, else the decision; `auto_graph_probe` = what was measured
+        self.auto_graph_probe = None
         self.use_small = True   # whole-horizon kernels for the small one-store-chain policies (small_rollout.py)
         self.small_lane_scenarios = 0  # ... 16 or 32 scenarios per wavefront (0: 16 while 32 would leave SIMDs without a wavefront)
         self.small_wgrad_in_kernel = True  # ... with the weight gradients contracted inside the backward kernel (False: dZ history + one GEMM per layer)
@@ -137,6 +143,9 @@ class FusedRollout:
         if self.timer is None:
             return fn(*args, **kw)
         return self.timer.call(tag, fn, *args, **kw)
+
+    def _graph_on(self):
+        return self.use_graph is True or (self.use_graph == "auto" and self._auto_graph is True)
 
     # ---- buffers ------------------------------------------------------------------------------------------------
     def _linears(self):
@@ -170,11 +179,12 @@ class FusedRollout:
 
     def _setup(self, prob, T, train, extra_rows=0):
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin,
-               self.eval_history, self.small_wgrad_in_kernel, extra_rows)
+               self.eval_history, self.small_wgrad_in_kernel, extra_rows, self.small_lane_scenarios)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
         self._prob = None
+        self._auto_graph = None   # (a new shape is measured afresh)
         for name in ("states", "orders", "logits", "hidden", "dZhist", "dZlast_hist", "dH", "slabs", "sr_states", "sr_hidden",
                      "sr_logits", "sr_dzh", "sr_dzo", "sr_slab", "sr_grad"):
             setattr(self, name, None)  # release the previous shapes' buffers before sizing the new ones
@@ -353,7 +363,7 @@ class FusedRollout:
             P_ = observation_params["demand"]["past_periods"]
             extra = prob.S * P_ + 2 * prob.S + data["days_from_christmas"].shape[1] + prob.S * data["lead_times"].shape[2]
         self._setup(prob, T, train, extra)
-        if self.use_graph:
+        if self._graph_on():
             # a captured graph holds raw pointers: keep the first call's table tensors and refresh their CONTENTS
             if self._prob is not None and self._prob.same_layout(prob):
                 self._prob.copy_tables_from(prob)
@@ -366,7 +376,7 @@ class FusedRollout:
             d = data["demands"]
             demand_soa = torch.zeros(d.shape[2], d.shape[1], ld, device=dev)
             demand_soa[:, :, :B] = d.permute(2, 1, 0)
-        if self.use_graph:
+        if self._graph_on():
             if self.demand_buf is None or self.demand_buf.shape != demand_soa.shape:
                 self.demand_buf, self._graphs, self._eager_runs = torch.empty_like(demand_soa), {}, 0
             if self.demand_buf.data_ptr() != demand_soa.data_ptr():
@@ -407,6 +417,13 @@ class FusedRollout:
             self._fill_observation_rows(data, prob, T, B, ld, shift, observation_params, demand_soa)
         self._ub_now = self._ub() if self.head not in ("softplus", "data_driven") else 0.0
         self._ctx = (prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa)
+        probe = None
+        if self.use_graph == "auto" and self._auto_graph is None and train and self._eager_runs >= 1 and self.timer is None:
+            import time
+            probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            torch.cuda.synchronize()
+            probe[0].record()
+            probe_t0 = time.perf_counter()
         self._replay_or_capture("fwd", self._launch_forward)
         total = self.rewards.sum()
         reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
@@ -427,6 +444,13 @@ class FusedRollout:
             self._thin = thin
             self._graphs.pop("bwd", None)  # a captured launch sequence no longer applies
         self._replay_or_capture("bwd", self._launch_backward)
+        if probe is not None:   # host time to enqueue the step against GPU time to run it (one synchronisation, once per shape)
+            host_ms = (time.perf_counter() - probe_t0) * 1e3
+            probe[1].record()
+            probe[1].synchronize()
+            gpu_ms = probe[0].elapsed_time(probe[1])
+            self._auto_graph = host_ms > 0.85 * gpu_ms
+            self.auto_graph_probe = {"host_enqueue_ms": host_ms, "gpu_ms": gpu_ms, "replay": self._auto_graph}
         self._eager_runs += 1
         if assign_grads:
             self._assign_grads(accumulate_grads)
@@ -525,7 +549,9 @@ class FusedRollout:
         self.g_reward[:B] = grad_scale
         if self.small_wgrad_in_kernel:
             self._k("small_rollout_bwd", sr.small_rollout_bwd_wgrad, desc, *hist, Table(self.g_reward, 0, 1), self.sr_slab)
-            torch.sum(self.sr_slab, dim=0, out=self.sr_grad)
+            # one partial gradient per wavefront: only the rows THIS width's launch wrote are summed (the slab is sized for the
+            # 16-wide form; a 32-wide launch fills half of it and must not pick up an earlier 16-wide run's rows)
+            torch.sum(self.sr_slab[:(B + width - 1) // width], dim=0, out=self.sr_grad)
             if assign_grads:
                 self._assign_grads(accumulate_grads)
             return total, reported
@@ -549,7 +575,7 @@ class FusedRollout:
         is captured once into a HIP graph and replayed — this removes the per-launch host cost that bounds the small
         (32-wide) policies, whose kernels run for a few microseconds each.  The first call always runs eagerly (module
         loading is not capturable); timers force eager mode."""
-        if not self.use_graph or self.timer is not None or self._eager_runs < 1:
+        if not self._graph_on() or self.timer is not None or self._eager_runs < 1:
             return fn()
         variant = (self._round, self._ctx[4])  # options baked into the captured launch sequence (rounding, demand shift)
         if getattr(self, "_graph_variant", variant) != variant:

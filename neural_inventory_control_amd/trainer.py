@@ -65,6 +65,10 @@ class Trainer:
         # step of a batch shape - every period's policy + env-step launches and the autograd sweep - into ONE HIP graph and
         # replay it; the per-period kernels of these policies run for microseconds, so the step is launch-bound
         self.use_step_graph = False
+        # MLP engine (per-period route): replay each rollout's launch sequence from a HIP graph - True / False / "auto" (the
+        # engine measures host enqueue time against GPU time on a shape's second training step and replays only if the step is
+        # launch-bound; `trainer_params.use_rollout_graph` in main_run)
+        self.use_rollout_graph = "auto"
         self._engines = {}
         self._step_graphs = {}
         self._fused_grads_ready = False
@@ -204,7 +208,10 @@ class Trainer:
             # is an ordinary differentiable tensor, so the caller's mean_loss.backward() reaches the policy's parameters
             # (a captured step holds the engine's buffers by address: with `use_step_graph` every batch shape keeps its own
             # engine, otherwise an epoch's smaller last batch would re-size - free - what the first graph replays into)
-            ekey = (id(model), "closed_form", len(data_batch["demands"]) if self.use_step_graph else None)
+            # ... and every (horizon, training / evaluation) context: a dev pass with the training batch size but another
+            # `periods` would otherwise re-size the buffers the captured training step replays into by raw address
+            ekey = ((id(model), "closed_form", len(data_batch["demands"]), periods, bool(train)) if self.use_step_graph
+                    else (id(model), "closed_form", None))
             eng = self._engines.get(ekey)
             if eng is None or eng.model is not model:
                 eng = self._engines[ekey] = ClosedFormRollout(model, problem_params, self.device)
@@ -227,6 +234,8 @@ class Trainer:
             eng = self._engines.get((id(model), train))
             if eng is None or eng.model is not model:  # (the engine holds the model, so its id cannot be recycled)
                 eng = self._engines[(id(model), train)] = engine_cls(model, problem_params, self.device)
+            if engine_cls is FusedRollout:
+                eng.use_graph = self.use_rollout_graph
             if direct and train:
                 total, reported = eng.run(data_batch, periods, ignore_periods, train=True,
                                           observation_params=observation_params, grad_scale=1.0, assign_grads=False)

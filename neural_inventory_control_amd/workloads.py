@@ -198,6 +198,13 @@ WORKLOADS = {
              "one_store_backlogged + vanilla_one_store, 32768 scenarios x T=100"),
     "cfg3": (lambda: one_warehouse(16), _mlp("vanilla_warehouse", [512, 512, 512], None, 4), 65536, 100,
              "one_warehouse_lost_demand, 16 stores, 65536 scenarios x T=100, vanilla_warehouse 512x3"),
+    # cfg3's shard on ONE of 8 GPUs when the 65,536 scenarios are strong-scaled (round 4: the small-batch regime)
+    "cfg3_shard8": (lambda: one_warehouse(16), _mlp("vanilla_warehouse", [512, 512, 512], None, 4), 8192, 100,
+                    "one_warehouse_lost_demand, 16 stores, 8192 scenarios (= cfg3's 65536 / 8 GPUs) x T=100, vanilla_warehouse 512x3"),
+    # the reference's SHIPPED training batch (one_warehouse_lost_demand.yml:22,31-34 + vanilla_warehouse.yml): 5 stores, batches
+    # of 1,024 scenarios x T=50
+    "cfg3_batch1024": (lambda: one_warehouse(5), _mlp("vanilla_warehouse", [512, 512, 512], None, 4), 1024, 50,
+                       "one_warehouse_lost_demand as shipped (5 stores), one batch of 1024 scenarios x T=50, vanilla_warehouse 512x3"),
     "cfg4": (serial_system, _mlp("vanilla_serial", [32, 32], 4, 4), 16384, 100,
              "serial_system 4 echelons, 16384 scenarios/GPU x T=100, vanilla_serial"),
     "cfg5": (lambda: many_warehouses(64, 3), _mlp("vanilla_warehouse", [512, 512, 512], None, 4), 32768, 70,
@@ -227,6 +234,54 @@ WORKLOADS = {
     "gnn_many_warehouses": (lambda: many_warehouses_dense(16, 3), gnn_policy(), 8192, 50,
                             "many_warehouses_lost_demand shape, 3 warehouses x 16 stores (dense), 8192 scenarios x T=50, gnn"),
 }
+
+
+def many_warehouses_shipped():
+    """many_warehouses_lost_demand.yml exactly as the reference ships it (:22-34, 66-110): 10 stores, 2 warehouses."""
+    s_ = one_warehouse(10)
+    s_["problem_params"].update({"n_warehouses": 2, "warehouse_store_adjacency": [[0, 0, 1, 1, 1, 0, 1, 1, 1, 0],
+                                                                                   [1, 1, 1, 1, 1, 1, 0, 1, 1, 1]]})
+    s_["store_params"]["lead_time"] = _const([[0, 2], [0, 1], [6, 2], [6, 2], [6, 1], [0, 2], [6, 0], [5, 2], [6, 2], [0, 2]])
+    s_["warehouse_params"] = {"holding_cost": [0.3, 0.4], "lead_time": 3, "edge_cost": [0.5, 1.5]}
+    return s_
+
+
+def _as_shipped(setting):
+    """The keys main_run reads besides the setting itself, with the values both warehouse YAMLs ship
+    (one_warehouse_lost_demand.yml:10-45): 8,192 training samples in batches of 1,024 x 50 periods, one dev batch of 8,192 x 100."""
+    s_ = dict(setting)
+    s_["test_seeds"] = dict(_SEEDS, demand=65)
+    s_["sample_data_params"] = {"split_by_period": False}
+    s_["params_by_dataset"] = {"train": {"n_samples": 8192, "batch_size": 1024, "periods": 50, "ignore_periods": 30},
+                               "dev": {"n_samples": 8192, "batch_size": 8192, "periods": 100, "ignore_periods": 60},
+                               "test": {"n_samples": 8192, "batch_size": 8192, "periods": 5000, "ignore_periods": 3000}}
+    return s_
+
+
+def _hyperparams(policy, lr=0.0003):
+    """vanilla_warehouse.yml's trainer / optimizer blocks around a policy dict."""
+    return {"trainer_params": {"epochs": 20000, "do_dev_every_n_epochs": 10, "early_stopping_patience_epochs": 500,
+                               "print_results_every_n_epochs": 1, "save_model": False, "epochs_between_save": 10,
+                               "choose_best_model_on": "dev_loss", "load_previous_model": False, "load_model_path": None},
+            "optimizer_params": {"learning_rate": lr}, "nn_params": policy}
+
+
+# The reference's shipped YAML pairs as they are (main_run.py train <setting> vanilla_warehouse): bench.py times whole TRAINING
+# EPOCHS of these through `Trainer.do_one_epoch` - shuffled device-resident batches, rollout, backward, Adam (trainer.py:143-179).
+EPOCH_WORKLOADS = {
+    "cfg3_yaml": (lambda: _as_shipped(one_warehouse(5)), lambda: _hyperparams(_mlp("vanilla_warehouse", [512, 512, 512], None, 4)),
+                  "one_warehouse_lost_demand.yml + vanilla_warehouse.yml as shipped: 5 stores, 8192 samples in batches of 1024 x "
+                  "T=50 (ignore 30), one training epoch through Trainer.do_one_epoch"),
+    "cfg5_yaml": (lambda: _as_shipped(many_warehouses_shipped()),
+                  lambda: _hyperparams(_mlp("vanilla_warehouse", [512, 512, 512], None, 4)),
+                  "many_warehouses_lost_demand.yml + vanilla_warehouse.yml as shipped: 10 stores x 2 warehouses, 8192 samples in "
+                  "batches of 1024 x T=50 (ignore 30), one training epoch through Trainer.do_one_epoch"),
+}
+
+
+def get_epoch(name):
+    setting, hyper, desc = EPOCH_WORKLOADS[name]
+    return copy.deepcopy(setting()), copy.deepcopy(hyper()), desc
 
 
 def get(name):

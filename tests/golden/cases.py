@@ -152,3 +152,17 @@ def apply_overrides(case, config_setting, config_hyper):
     if case.get("hidden") is not None:
         ch["nn_params"]["neurons_per_hidden_layer"]["master"] = list(case["hidden"])
     return cs, ch
+
+
+# "Slim" fixtures: batch sizes at which storing inputs and per-period traces would take megabytes.  The fixture keeps the config,
+# the weights, rewards (T, B), totals and gradients, plus float64 checksums of every input tensor; the tests regenerate the inputs
+# from the seeds with this repository's `Scenario` host path (seed-for-seed the reference's, pinned by the other fixtures) and
+# check the checksums before comparing anything.
+SLIM_CASES = {
+    # round 4: the reference's SHIPPED training batch (one_warehouse_lost_demand.yml: 5 stores, batch_size 1024, periods 50,
+    # ignore 30) - the small-batch route of the engine (64 x 128 / 32 x 128 GEMM tiles, weight gradients split over period
+    # groups); hidden width 256 keeps weights + gradients at 1 MB while still taking the 256 x 256 weight-gradient tiles
+    "cfg3_shipped_batch1024_vanilla": dict(
+        setting="one_warehouse_lost_demand", policy="vanilla_warehouse", n=1024, periods=50, ignore=30, torch_seed=61,
+        hidden=[256, 256, 256], slim=True),
+}

@@ -69,3 +69,20 @@ ZERO_LEAD_CASES = {"f1_many_warehouses_2x10_gnn"}
 def case_names():
     from cases import CASES
     return list(CASES.keys())
+
+
+def slim_case_names():
+    from cases import SLIM_CASES
+    return list(SLIM_CASES.keys())
+
+
+def check_slim_inputs(g, data):
+    """A slim fixture holds no inputs: `data` (regenerated from the fixture's seeds) must reproduce the float64 checksums and
+    shapes the reference's own tensors had."""
+    keys = [k[len("data_checksum/"):] for k in g.z.files if k.startswith("data_checksum/")]
+    assert set(keys) == set(data.keys()), (sorted(keys), sorted(data.keys()))
+    for k in keys:
+        v = data[k]
+        assert tuple(v.shape) == tuple(int(x) for x in g.z["data_shape/" + k]), k
+        assert float(v.double().sum()) == float(g.z["data_checksum/" + k]), k
+        assert float(v.double().abs().sum()) == float(g.z["data_abs_checksum/" + k]), k

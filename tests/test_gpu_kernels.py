@@ -72,7 +72,10 @@ GEMM_SHAPES = [(512, 51, 1000), (512, 512, 2048 + 37), (17, 512, 777), (32, 4, 1
                # the compacted logits layer of cfg5 (98 live rows of 195): 128 x 128 forward, 128 x 256 weight-gradient tiles
                (98, 512, 32768), (98, 512, 4096 + 64), (128, 512, 8192), (96, 200, 4096),
                # ... and its first layer on the live input rows (295 of 393): 128 x 320 / 128 x 384 weight-gradient tiles
-               (512, 295, 32768), (512, 295, 4096 + 32), (512, 350, 8192), (256, 320, 4096)]
+               (512, 295, 32768), (512, 295, 4096 + 32), (512, 350, 8192), (256, 320, 4096),
+               # round 4: 65..128 input rows under >= 192 output rows (the shipped many-warehouse setting's first layer, 512 x 66):
+               # 256 x 128 weight-gradient tiles; 129..191 input rows: 256 x 256
+               (512, 66, 1024), (512, 100, 2048 + 64), (256, 128, 4096), (300, 150, 1024)]
 
 
 def _rand(shape, gen, dev, scale=1.0):
@@ -295,7 +298,7 @@ def test_linear_wgrad_periods_equals_per_period_launches(N, K, B, T):
 
 @pytest.mark.parametrize("N,K,B,T,slots", [(512, 512, 1024, 7, None), (512, 512, 256, 9, 64), (512, 51, 1024, 6, None),
                                            (512, 51, 512, 5, 7), (98, 512, 512, 5, None), (512, 393, 384, 4, 6),
-                                           (512, 512, 8192, 3, None)])
+                                           (512, 512, 8192, 3, None), (512, 66, 1024, 6, None), (320, 150, 512, 5, None)])
 def test_linear_wgrad_periods_splits_the_horizon_into_period_groups(N, K, B, T, slots):
     """Round 4: with few scenarios the slab slots of the all-period contraction are (period group x scenario split) pairs
     (nic_wgrad_periods_num_splits), so that a batch of 1,024 still gives every CU a workgroup.  Any slot count is accepted:

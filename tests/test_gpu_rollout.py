@@ -14,7 +14,7 @@ import torch
 
 import grad_parity_log
 
-from golden_io import Golden, ZERO_LEAD_CASES, case_names
+from golden_io import Golden, ZERO_LEAD_CASES, case_names, check_slim_inputs, slim_case_names
 from neural_inventory_control_amd import _lib
 from neural_inventory_control_amd.data_handling import DatasetCreator, DeviceBatches, MyDataset, Scenario
 from neural_inventory_control_amd.environment import Simulator
@@ -268,8 +268,13 @@ def test_data_driven_epochs_engine_follows_generic_route():
         runs[fused] = (losses, ev, [p.detach().clone() for p in model.parameters()])
     for a, b in zip(runs[True][0] + [runs[True][1]], runs[False][0] + [runs[False][1]]):
         assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-5 * abs(b[1]), (a, b)
+    # parameters after six Adam steps: Adam divides every gradient element by its own running magnitude, so an element whose
+    # gradient is rounding noise (|g| ~ 1e-9) moves by a full step in a direction the two routes' summation orders decide -
+    # nearly all elements agree to 2e-6, a handful (<= 0.01 %) may differ by a few percent of ONE step (lr = 1e-3)
     for x, y in zip(runs[True][2], runs[False][2]):
-        torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-6)
+        bad = (x - y).abs() > 2e-6 + 1e-4 * y.abs()
+        assert int(bad.sum()) <= max(1, x.numel() // 10000), (int(bad.sum()), x.numel())
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-4)
     assert runs[True][0][0][0] != runs[True][0][1][0]      # the optimizer moved the policy between the epochs
 
 
@@ -1085,6 +1090,101 @@ def test_trainer_epochs_with_step_graph_match_eager_training(fused):
     for a, b in zip(pe, pg):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     assert le[-1] < le[0]  # and it learns
+
+
+@pytest.mark.parametrize("name", slim_case_names())
+@pytest.mark.parametrize("rollout_graph", ["auto", False, True])
+def test_trainer_at_the_shipped_batch_size_matches_reference(name, rollout_graph):
+    """Round 4: the reference's shipped training batch - 1,024 scenarios x 50 periods, ignore 30
+    (one_warehouse_lost_demand.yml:31-34) - through `Trainer.do_one_epoch`, on whatever route and launch mode the Trainer picks:
+    per-scenario cost, totals and reported losses <= 1e-5, d(mean_loss)/d(theta) <= 1e-5 per parameter tensor, against numbers the
+    REFERENCE produced at this batch size.  The inputs are rebuilt from the fixture's seeds by this package's `Scenario`
+    (checksums of the reference's own tensors pinned).  Runs the epoch three times (eager, measured / captured, replayed)."""
+    g = Golden(name)
+    c = g.fresh_config()
+    sc = Scenario(c["periods"], c["problem_params"], c["store_params"], c["warehouse_params"], c["echelon_params"], c["n"],
+                  c["observation_params"], c["seeds"])
+    data = sc.get_data()
+    check_slim_inputs(g, data)
+    model = _model(g, c, scenario=sc)
+    sim, tr = Simulator(device=DEV), Trainer(device=DEV)
+    tr.use_rollout_graph = rollout_graph
+    dev_data = {k: v.to(DEV) for k, v in data.items()}
+    with torch.no_grad():   # materialise the lazy layers, then the fixture's weights
+        obs0, _ = sim.reset(c["periods"], c["problem_params"], dev_data, c["observation_params"])
+        o = dict(obs0)
+        o["internal_data"] = sim._internal_data
+        model(o)
+    _load(model, g)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)   # (the step must not move the weights between the three epochs)
+    loader = DeviceBatches(MyDataset(c["n"], data), c["n"], shuffle=False, device=DEV)
+    S, T, ig = c["problem_params"]["n_stores"], c["periods"], c["ignore"]
+    for rep in range(3):
+        loss, report = tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, T, c["problem_params"], c["observation_params"],
+                                       train=True, ignore_periods=ig)
+        eng = tr._engines[(id(model), True)]
+        assert type(eng).__name__ == "FusedRollout" and eng.small is None
+        assert abs(loss - float(g.z["total"]) / (c["n"] * T * S)) <= 1e-5 * abs(loss)
+        assert abs(report - float(g.z["reported"]) / (c["n"] * (T - ig) * S)) <= 1e-5 * abs(report)
+        rewards, ref_r = eng.per_period_rewards().cpu(), g.tensor("rewards")
+        tot_b, ref_b = rewards.double().sum(dim=0), ref_r.double().sum(dim=0)
+        assert float(((tot_b - ref_b).abs() / ref_b.abs().clamp_min(1e-9)).max()) <= 1e-5
+        _check_grads(model, g, GRAD_TOL)
+    if rollout_graph is True:
+        assert set(eng._graphs) == {"fwd", "bwd"}
+    if rollout_graph == "auto":
+        assert eng.auto_graph_probe is not None and eng.auto_graph_probe["replay"] == eng._graph_on()
+    final = eng.final_state()
+    for k, v in g.states(1).items():
+        torch.testing.assert_close(final[k].cpu(), v, **STATE_TOL)
+    # the small-batch route of round 4: weight gradients of the 256-wide layers contracted over (period group x scenario chunk)
+    assert max(eng.splits) > c["n"] // 128
+
+
+def test_step_graph_survives_dev_passes_of_another_horizon_at_the_same_batch_size():
+    """with `use_step_graph` the captured closed-form training step replays into its engine's buffers by raw
+    address; a dev pass with the SAME batch size but another horizon (the reference's configs: train 50 periods, dev 100) used
+    to share that engine and re-size - free - those buffers.  Train and dev passes are interleaved here; the captured run must
+    reproduce the eager run's losses and parameters (every (batch size, horizon, train / eval) context keeps its own engine)."""
+    from neural_inventory_control_amd.environment import Simulator
+    from neural_inventory_control_amd.loss_functions import PolicyLoss
+    from neural_inventory_control_amd.trainer import Trainer
+    g = Golden("cfg2_one_store_backlogged_base_stock")
+    c = g.fresh_config()
+    ds = MyDataset(c["n"], {k: v.clone() for k, v in g.data.items()})
+    assert c["periods"] > 6
+
+    def run(graph):
+        torch.manual_seed(0)
+        model = _model(g, c)
+        sim = Simulator(device=DEV)
+        with torch.no_grad():
+            obs0, _ = sim.reset(c["periods"], c["problem_params"], {k: v.to(DEV) for k, v in g.data.items()},
+                                c["observation_params"])
+            o = dict(obs0)
+            o["internal_data"] = sim._internal_data
+            model(o)
+        _load(model, g)
+        opt = torch.optim.Adam(model.parameters(), lr=0.05)
+        tr = Trainer(device=DEV)
+        tr.use_step_graph = graph
+        loader = DeviceBatches(ds, c["n"], shuffle=False, device=DEV)   # one batch per pass: train and dev share the batch size
+        out = []
+        for _ in range(4):
+            out.append(tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, c["periods"] - 5, c["problem_params"],
+                                       c["observation_params"], train=True, ignore_periods=0)[0])
+            # garbage the allocator can hand freed engine buffers to (what the saved best-params copy is in a real run)
+            junk = [torch.full((c["n"] * 64,), float("nan"), device=DEV) for _ in range(8)]
+            out.append(tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, c["periods"], c["problem_params"],
+                                       c["observation_params"], train=False, ignore_periods=2)[1])
+            del junk
+        return out, [p.detach().clone() for p in model.parameters()]
+
+    (le, pe), (lg, pg) = run(False), run(True)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 1e-6 * abs(a), (le, lg)
+    for a, b in zip(pe, pg):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
 
 
 # ---- closed-form policies: whole horizon + forward-mode gradient in one kernel (csrc/closed_form.hip) -------------------

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_io import Golden, case_names
+from golden_io import Golden, case_names, check_slim_inputs, slim_case_names
 from oracle import inventory_oracle as orc
 
 
@@ -210,3 +210,25 @@ def test_many_warehouse_gnn_fixture_pins_the_upstream_column_defect():
     cd = dense.fresh_config()
     assert orc.gnn_graph(cd["problem_params"], {"lead_times": dense.data["lead_times"],
                                                 "warehouse_lead_times": dense.data["warehouse_lead_times"]}, False)["misplaced"] == []
+
+
+@pytest.mark.parametrize("name", slim_case_names())
+def test_slim_fixture_at_the_shipped_batch_size(name):
+    """Round 4: the reference's shipped training batch (1,024 scenarios x 50 periods).  The fixture keeps no inputs: the oracle's
+    generator rebuilds them from the seeds (checksums pinned), then rewards, totals, final state and gradients are bit-equal."""
+    g = Golden(name)
+    c, data = _build(g)
+    check_slim_inputs(g, data)
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"],
+                                     warehouse_upper_bound=g.tensor("warehouse_upper_bound"))
+    res, mean_loss, grads = orc.train_step_gradients(pol, c["periods"], c["problem_params"], data, c["observation_params"],
+                                                     c["ignore"])
+    assert torch.equal(res.per_period, g.tensor("rewards"))
+    assert float(res.total) == float(g.z["total"]) and float(res.reported) == float(g.z["reported"])
+    assert float(mean_loss) == float(g.z["mean_loss"])
+    for k, v in g.states(1).items():   # (slim: states/0 = initial, states/1 = final)
+        assert torch.equal(res.final_obs[k], v), k
+    ref_grads = g.grads
+    keys = sorted(ref_grads.keys(), key=lambda s_: (int(s_.split(".")[2]), s_.split(".")[3] != "weight"))
+    for k, mine in zip(keys, grads):
+        assert torch.equal(mine, ref_grads[k]), (k, float((mine - ref_grads[k]).abs().max()))

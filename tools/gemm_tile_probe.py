@@ -57,7 +57,7 @@ def main():
     sizes = (1024, 2048, 4096, 8192, 16384, 32768, 65536)
     if "--main" in sys.argv:   # the square layer at the shard and the headline size only, twice (run-to-run spread)
         shapes, sizes = shapes[:2] * 2, (8192, 65536)
-    for B in sizes:
+    for B in (() if ("--pad" in sys.argv or "--stream" in sys.argv) else sizes):
         ldb = pad_ld(B)
         for kind, N, K in shapes:
             W = (torch.randn(N, (K + 31) // 32 * 32, device=dev) * 0.05)[:, :K]
@@ -86,6 +86,54 @@ def main():
             out["wx"].append(rec)
             print(json.dumps(rec), file=sys.stderr, flush=True)
         del X, Y, dX
+    if "--stream" in sys.argv:   # streamed small-launch kernel (NT, KS) against the LDS-DMA tilings
+        out["stream"] = []
+        shapes_s = [("fwd", 512, 512), ("dgrad", 512, 512), ("fwd", 17, 512), ("dgrad", 512, 51), ("fwd", 98, 512), ("fwd", 512, 66),
+                    ("dgrad", 512, 18), ("fwd", 6, 512)]
+        for B in (1024, 2048, 4096, 8192, 16384, 32768):
+            ldb = pad_ld(B)
+            for kind, N, K in shapes_s:
+                M = N if kind == "fwd" else K
+                if ((M + 31) // 32) * (B // 32) > 4096:
+                    continue
+                W = (torch.randn(N, (K + 31) // 32 * 32, device=dev) * 0.05)[:, :K]
+                Wt = (torch.randn(K, (N + 31) // 32 * 32, device=dev) * 0.05)[:, :N]
+                b = torch.randn(N, device=dev)
+                X, Y = torch.randn(K, ldb, device=dev), torch.zeros(N, ldb, device=dev)
+                dX = torch.zeros(K, ldb, device=dev)
+                fn = (lambda: ops.linear_fwd(W, b, X, Y, B, 1)) if kind == "fwd" else (lambda: ops.linear_dgrad(Wt, Y, X, dX, B, 1, False))
+                rec = {"kind": kind, "N": N, "K": K, "B": B, "us": {}}
+                for mode in (0, 11, 12, 14, 21, 22, 24):
+                    os.environ["NIC_WX_STREAM"] = str(mode)
+                    rec["us"]["dma" if mode == 0 else f"nt{mode // 10}_ks{mode % 10}"] = round(timeit(fn, iters=40), 2)
+                os.environ.pop("NIC_WX_STREAM", None)
+                rec["picked_us"] = round(timeit(fn, iters=40), 2)
+                rec["picked"] = (_lib.lib().nic_last_kernel() or b"").decode()
+                out["stream"].append(rec)
+                print(json.dumps(rec), file=sys.stderr, flush=True)
+        print(json.dumps(out))
+        return
+    if "--pad" in sys.argv:   # occupancy experiment: unused dynamic LDS limits the co-resident workgroups per CU
+        out["pad"] = []
+        for B in (1024, 2048, 4096, 8192, 16384, 65536):
+            ldb = pad_ld(B)
+            W = torch.randn(512, 512, device=dev) * 0.05
+            b = torch.randn(512, device=dev)
+            X, Y = torch.randn(512, ldb, device=dev), torch.zeros(512, ldb, device=dev)
+            for i, name in enumerate(TILES[:3]):
+                for pad in (0, 16384, 32768, 49152, 65536):
+                    os.environ["NIC_WX_TILE"], os.environ["NIC_WX_LDS_PAD"] = str(i), str(pad)
+                    try:
+                        us = round(timeit(lambda: ops.linear_fwd(W, b, X, Y, B, 1), iters=40), 2)
+                    except Exception as e:   # (static + dynamic LDS beyond 160 KB: the launch is refused)
+                        us = None
+                    rec = {"B": B, "tile": name, "lds_pad": pad, "us": us}
+                    out["pad"].append(rec)
+                    print(json.dumps(rec), file=sys.stderr, flush=True)
+        os.environ.pop("NIC_WX_TILE", None)
+        os.environ.pop("NIC_WX_LDS_PAD", None)
+        print(json.dumps(out))
+        return
     # all-period weight gradients: old slot count (scenario splits only) vs the (period group x scenario split) count
     for B, T in (() if "--main" in sys.argv else ((1024, 50), (4096, 100), (8192, 100), (16384, 100))):
         ldb = pad_ld(B)
