@@ -251,6 +251,10 @@ def algorithmic_work(tag, kernel, shape):
         return "hbm", 4.0 * (2 * f_state + S + n_ord + 1) * n, "B"
     if tag == "env_bwd":  # state + orders + demand read, incoming state gradient read, state / order gradients written
         return "hbm", 4.0 * (3 * f_state + S + 2 * n_ord) * n, "B"
+    if tag == "head_env_fwd":  # fused head + env step: state read + write, demand, logits in, orders written (the sweep reads them), reward
+        return "hbm", 4.0 * (2 * f_state + S + shape["n_out"] + n_ord + 1) * n, "B"
+    if tag == "head_env_bwd":  # state, orders, demand, logits, incoming state gradient in; state gradient, order gradients, dZ out
+        return "hbm", 4.0 * (3 * f_state + S + 2 * n_ord + 2 * shape["n_out"]) * n, "B"
     if tag == "head_fwd":  # logits + the warehouse / echelon on-hand row in, orders out
         return "hbm", 4.0 * (shape["n_out"] + Wn + E + n_ord) * n, "B"
     if tag == "head_bwd":  # logits, on-hand rows and order gradients in; logit gradients (+ on-hand gradients) out
@@ -623,8 +627,9 @@ def main():
                 if "other" in d:
                     out["roofline"]["other"] = d["other"]
             out["kernels"] = kernels
-            if "env_fwd" in kernels and "bound" in kernels["env_fwd"]:
-                e = kernels["env_fwd"]
+            env_tag = "env_fwd" if "env_fwd" in kernels else "head_env_fwd"
+            if env_tag in kernels and "bound" in kernels[env_tag]:
+                e = kernels[env_tag]
                 out["roofline_env_step"] = {"bound": "hbm", "achieved": e["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": e["frac"], "kernel": e["kernel"],
                                             "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],

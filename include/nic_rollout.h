@@ -187,6 +187,21 @@ int nic_head_warehouse_bwd(const float* Z, const float* wh_inv, const int32_t* a
                            float* dZ, float* g_wh_inv, int32_t S, int32_t Wn, int32_t Ww, int32_t n_scenarios,
                            int32_t ldb, void* stream);
 
+/* vanilla_warehouse head + one period of dynamics in ONE launch (round 4): what VanillaWarehouse.forward does after its MLP
+ * (neural_networks.py:393-426) followed by Simulator.step (environment.py:110-299) - nic_head_warehouse_fwd then
+ * nic_env_step_fwd, bit for bit, without the second launch and without re-reading the orders from HBM.  `io` as for
+ * nic_env_step_fwd with n_echelons == 0, n_stores <= 64; io->store_orders / io->wh_orders must describe dense
+ * [S][Wn][ldb] / [Wn][ldb] blocks: the kernel WRITES the orders there (the backward sweep reads them) and consumes them.
+ * The warehouse on-hand the head allocates is io->wh_inv[w][0][b] - the state the env step then advances. */
+int nic_head_env_fwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, float upper_bound,
+                     int32_t transshipment, float* store_inv_out, float* wh_inv_out, float* reward, void* stream);
+/* The adjoint pair in one launch: nic_env_step_bwd (no echelons) then nic_head_warehouse_bwd.  g_store_orders /
+ * g_wh_orders ([S][Wn][ldb] / [Wn][ldb]) are scratch outputs of the first half that the second half consumes; dZ receives the
+ * logits' gradient, g_wh_in the warehouse state gradient INCLUDING the head's contribution to the on-hand slot. */
+int nic_head_env_bwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, float upper_bound,
+                     int32_t transshipment, const float* g_store_out, const float* g_wh_out, NicTable2 g_reward,
+                     float* g_store_in, float* g_wh_in, float* g_store_orders, float* g_wh_orders, float* dZ, void* stream);
+
 /* vanilla_one_store (neural_networks.py:200-214): orders[s][b] = softplus(Z[s][b] + 1)  (threshold 20 like
  * nn.Softplus).  rows = number of output rows (1 for the shipped config). */
 int nic_head_softplus_fwd(const float* Z, float* orders, int32_t rows, int32_t n_scenarios, int32_t ldb,

@@ -15,6 +15,7 @@ SOURCES = [
     ("nic_abi.hip", []),
     ("env_step.hip", ["-ffp-contract=off"]),
     ("policy_heads.hip", ["-ffp-contract=off"]),
+    ("head_env.hip", ["-ffp-contract=off"]),
     ("linear_mfma.hip", []),
     ("thin_layer.hip", []),
     ("sampler.hip", []),

@@ -170,6 +170,28 @@ def head_warehouse_bwd(Z, wh_inv, adjacency, ub, transshipment, g_store_orders, 
                                        Z.stride(0), current_stream()))
 
 
+def head_env_fwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders: Table, wh_orders: Table, Z, adjacency, ub,
+                 transshipment, out: EnvState, reward):
+    """nic_head_env_fwd: vanilla_warehouse head + env step in one launch.  `store_orders` / `wh_orders` are the dense
+    [S][Wn][ldb] / [Wn][ldb] blocks the orders are WRITTEN to (and consumed from)."""
+    _dev(Z)
+    io = prob.make_io(state.store, state.wh, None, demand, store_orders, wh_orders, None)
+    check(lib().nic_head_env_fwd(io, ptr(Z), ptr(adjacency), float(ub), int(transshipment), ptr(out.store), ptr(out.wh),
+                                 ptr(reward), current_stream()))
+    return out, reward
+
+
+def head_env_bwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders: Table, wh_orders: Table, Z, adjacency, ub,
+                 transshipment, g_out: EnvState, g_reward: Table, g_in: EnvState, g_orders, dZ):
+    """nic_head_env_bwd: env-step adjoint + head adjoint in one launch (g_orders: scratch (store, warehouse) blocks)."""
+    _dev(Z)
+    io = prob.make_io(state.store, state.wh, None, demand, store_orders, wh_orders, None)
+    check(lib().nic_head_env_bwd(io, ptr(Z), ptr(adjacency), float(ub), int(transshipment), ptr(g_out.store), ptr(g_out.wh),
+                                 g_reward.t2(), ptr(g_in.store), ptr(g_in.wh), ptr(g_orders[0]), ptr(g_orders[1]), ptr(dZ),
+                                 current_stream()))
+    return g_in, dZ
+
+
 def head_data_driven_fwd(Z, wh, mask, store_orders, wh_orders, S, Wn, Ww, B):
     """nic_head_data_driven_fwd: ReLU, adjacency mask and proportional allocation of the data_driven policy (one launch)."""
     _dev(Z)

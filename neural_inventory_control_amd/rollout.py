@@ -134,6 +134,7 @@ class FusedRollout:
         self.small_wgrad_in_kernel = True  # ... with the weight gradients contracted inside the backward kernel (False: dZ history + one GEMM per layer)
         self.use_thin = True    # fused backward of thin (<= 32 rows) output layers (csrc/thin_layer.hip)
         self.batch_wgrad = True  # hidden-layer weight gradients contracted over all periods in one launch
+        self.fuse_head_env = True  # vanilla_warehouse: head + env step (and their adjoints) in one launch each (csrc/head_env.hip)
         self.eval_history = None  # evaluation keeps per-period states/orders/logits: None = while small, True / False = forced
         self.small = None       # SmallRolloutPlan when the current shapes take that route
         self._prob_cache = ProblemCache()
@@ -143,6 +144,12 @@ class FusedRollout:
         if self.timer is None:
             return fn(*args, **kw)
         return self.timer.call(tag, fn, *args, **kw)
+
+    def _fused_head_env(self, prob):
+        """vanilla_warehouse settings the fused head + env-step kernels take (csrc/head_env.hip): up to 64 stores, no extra
+        echelons, no order rounding between head and env step (discrete allocation keeps the three separate launches)."""
+        return (self.fuse_head_env and self.head == "warehouse" and prob.S <= 64 and prob.E == 0 and prob.Wn >= 1
+                and not self._round)
 
     def _graph_on(self):
         return self.use_graph is True or (self.use_graph == "auto" and self._auto_graph is True)
@@ -577,7 +584,7 @@ class FusedRollout:
         loading is not capturable); timers force eager mode."""
         if not self._graph_on() or self.timer is not None or self._eager_runs < 1:
             return fn()
-        variant = (self._round, self._ctx[4])  # options baked into the captured launch sequence (rounding, demand shift)
+        variant = (self._round, self._ctx[4], self.fuse_head_env)  # options baked into the captured launch sequence
         if getattr(self, "_graph_variant", variant) != variant:
             self._graphs = {}
         self._graph_variant = variant
@@ -616,6 +623,11 @@ class FusedRollout:
                         _lib.NIC_ACT_NONE)
                 Z.index_copy_(0, self.live_rows, self.Zc)
             so, wo, eo = self._order_views(self.orders[row], prob)
+            if self._fused_head_env(prob):   # head + env step in one launch (the orders still land in self.orders[row])
+                ts, tw, _ = self._order_tables(self.orders[row], prob)
+                self._k("head_env_fwd", ops.head_env_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, Z, self.adj, ub,
+                        bool(self.model.transshipment), self._views(self.states[nxt], prob), self.rewards[t])
+                continue
             if self.head == "warehouse":
                 self._k("head_fwd", ops.head_warehouse_fwd, Z, st.wh, self.adj, ub, bool(self.model.transshipment), so, wo,
                         prob.S, prob.Wn, prob.Ww, B)
@@ -641,15 +653,20 @@ class FusedRollout:
             st = self._views(self.states[t], prob)
             ts, tw, te = self._order_tables(self.orders[t], prob)
             gso, gwo, geo = self._order_views(self.g_orders, prob)
-            self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te,
-                    self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=self._views(g_cur, prob),
-                    g_orders=(gso, gwo, geo))
+            fused = self._fused_head_env(prob)
+            if not fused:
+                self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te,
+                        self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=self._views(g_cur, prob),
+                        g_orders=(gso, gwo, geo))
             Z = self.logits[t]
             gc = self._views(g_cur, prob)
             hist, last_hist = self.dZhist, self.dZlast_hist
             compact = self.live_rows is not None
             dZ = last_hist[t] if (last_hist is not None and not compact) else self.dZ
-            if self.head == "warehouse":
+            if fused:   # env-step adjoint + head adjoint in one launch
+                self._k("head_env_bwd", ops.head_env_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, Z, self.adj, ub,
+                        bool(self.model.transshipment), self._views(g_next, prob), Table(self.g_reward, 0, 1), gc, (gso, gwo), dZ)
+            elif self.head == "warehouse":
                 self._k("head_bwd", ops.head_warehouse_bwd, Z, st.wh, self.adj, ub, bool(self.model.transshipment), gso, gwo,
                         dZ, gc.wh, prob.S, prob.Wn, prob.Ww, B)
             elif self.head == "serial":

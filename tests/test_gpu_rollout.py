@@ -1092,6 +1092,41 @@ def test_trainer_epochs_with_step_graph_match_eager_training(fused):
     assert le[-1] < le[0]  # and it learns
 
 
+WAREHOUSE_CASES = [n for n in MLP_CASES if n.startswith(("cfg3", "cfg5", "x_transshipment"))]
+
+
+@pytest.mark.parametrize("name", WAREHOUSE_CASES)
+def test_fused_head_env_launches_equal_the_separate_ones(name):
+    """Round 4 (csrc/head_env.hip): vanilla_warehouse head + env step in one launch, and env adjoint + head adjoint in one launch,
+    are the same NIC_HD bodies run back to back - rewards, orders, states, logit gradients and parameter gradients are
+    BIT-IDENTICAL to the three / four separate launches (one and several warehouses, 64 stores, transshipment)."""
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    out = {}
+    for fuse in (True, False):
+        model = _model(g, c)
+        eng = FusedRollout(model, c["problem_params"], DEV)
+        eng.fuse_head_env = fuse
+        eng.materialize(eng.input_rows(data, c["observation_params"]))
+        _load(model, g)
+        from neural_inventory_control_amd.rollout import KernelTimer
+        eng.timer = KernelTimer(record_order=True)
+        total, rep = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+        torch.cuda.synchronize()
+        tags = {t for t, _ in eng.timer.order}
+        assert ("head_env_fwd" in tags and "head_env_bwd" in tags and "env_fwd" not in tags and "head_bwd" not in tags) == fuse, tags
+        out[fuse] = (float(total), float(rep), eng.per_period_rewards().clone(), eng.states.clone(), eng.orders.clone(),
+                     [p.grad.clone() for p in model.parameters()])
+    a, b = out[True], out[False]
+    assert a[0] == b[0] and a[1] == b[1]
+    for x, y in zip(a[2:5], b[2:5]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[5], b[5]):
+        assert torch.equal(x, y)
+    _check_grads(model, g, GRAD_TOL)
+
+
 @pytest.mark.parametrize("name", slim_case_names())
 @pytest.mark.parametrize("rollout_graph", ["auto", False, True])
 def test_trainer_at_the_shipped_batch_size_matches_reference(name, rollout_graph):
