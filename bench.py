@@ -426,6 +426,9 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--scenarios", type=int, default=None, help="scenarios per GPU (default: the workload's)")
     ap.add_argument("--periods", type=int, default=None)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = the workload's scenario count PER GPU (65,536 per GPU for cfg3; the default), strong = "
+                         "the workload's scenario count in TOTAL, sharded over the N ranks (cfg3: 8,192 per GPU at N = 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -462,7 +465,14 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
         sys.exit(2)
 
-    setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, device, rank, world, args.scenarios,
+    per_gpu = args.scenarios
+    if args.scaling == "strong" and world > 1:
+        total = args.scenarios or _w.get(args.workload)[2]   # --scenarios then names the GLOBAL count
+        if total % world:
+            print(f"bench.py: --scaling strong needs a scenario count ({total}) divisible by --gpus ({world})", file=sys.stderr)
+            sys.exit(2)
+        per_gpu = total // world
+    setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, device, rank, world, per_gpu,
                                                                    args.periods, args.generic_route)
     pp = setting["problem_params"]
     S = pp["n_stores"]
@@ -583,7 +593,8 @@ def main():
             "metric": "scenario-steps/sec (scenarios x stores x T) per " + ("evaluation pass" if args.eval else "training step"),
             "value": global_b * S * T * args.steps / dt, "unit": "scenario-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
             "config": {"workload": desc + ("; evaluation pass = forward rollout only" + (", discrete allocation" if discrete else "")
                                            if args.eval else
                                            "; training step = rollout fwd + bwd + Adam" + (" + RCCL grad all-reduce" if sharded else "")),

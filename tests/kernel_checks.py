@@ -175,6 +175,72 @@ def check_env_forward(be, name):
         assert float(r[B:].abs().sum()) == 0.0
 
 
+# ---- zero-lead orders: a hand-computed period (pins the "drop" semantics ZERO_LEAD_CASES are compared against) ----------------
+def zero_lead_micro_case():
+    """One period, one scenario, 2 stores x 2 warehouses, pipelines of 3 slots, lost demand; store 0 is connected to warehouse 1
+    only (lead time 0 on warehouse 0) and still carries an order of 4 in warehouse 0's column - the situation upstream's GNN
+    creates on the shipped many-warehouse adjacency (neural_networks.py:1423-1428).  Expected values are worked out BY HAND below
+    for the semantics the HIP env step implements ("drop": the order reaches no pipeline slot, but it still leaves warehouse 0 -
+    the outflow sum has no filter, environment.py:247):
+
+      store 0: on hand 5, demand 3 -> after 2: cost 1 * 2 = 2;   shift [2 + 1, 0, 0]; order 4 @ lead 0: dropped; 1.5 @ lead 2 -> slot 1
+               -> [3, 1.5, 0]
+      store 1: on hand 2, demand 4 -> after -2: cost 8 * 2 = 16, lost demand -> 0; shift [0 + 0, 3, 0]; 2 @ lead 3 -> slot 2,
+               0.5 @ lead 1 -> slot 0                      -> [0.5, 3, 2]
+      wh 0: on hand 10, ships 4 + 2 = 6 -> after 4: holding 0.25 * 4 = 1, edge 0.5 * 7 = 3.5; shift [4 + 0, 1, 0]; 7 @ lead 3 -> [4, 1, 7]
+      wh 1: on hand 1, ships 1.5 + 0.5 = 2 -> after -1: holding 0, edge 1.5 * 3 = 4.5;      shift [-1 + 2, 0, 0]; 3 @ lead 3 -> [1, 0, 3]
+      cost of the period = 2 + 16 + (1 + 3.5) + (0 + 4.5) = 27
+    """
+    t = torch.tensor
+    problem = {"n_stores": 2, "n_warehouses": 2, "n_extra_echelons": 0, "lost_demand": True, "maximize_profit": False,
+               "warehouse_store_adjacency": [[0, 1], [1, 1]]}
+    data = {"demands": t([[[3.0], [4.0]]]), "initial_inventories": t([[[5.0, 1.0, 0.0], [2.0, 0.0, 3.0]]]),
+            "underage_costs": t([[10.0, 8.0]]), "holding_costs": t([[1.0, 2.0]]),
+            "lead_times": t([[[0.0, 2.0], [3.0, 1.0]]]),
+            "initial_warehouse_inventories": t([[[10.0, 0.0, 1.0], [1.0, 2.0, 0.0]]]),
+            "warehouse_holding_costs": t([[0.25, 0.5]]), "warehouse_lead_times": t([[3.0, 3.0]]),
+            "warehouse_edge_costs": t([[0.5, 1.5]])}
+    action = {"stores": t([[[4.0, 1.5], [2.0, 0.5]]]), "warehouses": t([[[7.0], [3.0]]])}
+    want = {"store_inventories": t([[[3.0, 1.5, 0.0], [0.5, 3.0, 2.0]]]),
+            "warehouse_inventories": t([[[4.0, 1.0, 7.0], [1.0, 0.0, 3.0]]]), "reward": t([27.0])}
+    obs_params = {"include_warehouse_inventory": True, "include_static_features": {"holding_costs": True, "underage_costs": True,
+                                                                                  "lead_times": True},
+                  "demand": {"past_periods": 0, "period_shift": 0}, "include_days_to_christmas": False,
+                  "time_features": None, "sample_features": None}
+    return problem, data, action, want, obs_params
+
+
+def check_zero_lead_micro(be):
+    """The kernel (host build or HIP) and the oracle's drop mode against the hand-computed numbers; the oracle's default mode
+    (upstream's flat-index `put`) differs: it books the dropped 4 on the element in front of store 0's pipeline."""
+    problem, data, action, want, obs_params = zero_lead_micro_case()
+    for mode in ("drop", "upstream"):
+        env = orc.env_reset(1, problem, data, obs_params)
+        env.zero_lead_orders = mode
+        r = orc.env_step(env, action)
+        if mode == "drop":
+            assert torch.equal(env.obs["store_inventories"], want["store_inventories"])
+            assert torch.equal(env.obs["warehouse_inventories"], want["warehouse_inventories"])
+            assert torch.equal(r, want["reward"])
+        else:   # one scenario: the misplaced order wraps to the LAST element of the batch (store 1's last slot)
+            leak = want["store_inventories"].clone()
+            leak[0, 1, 2] += 4.0
+            assert torch.equal(env.obs["store_inventories"], leak)
+    dev = be.device
+    prob = EnvProblem(problem, data, dev)
+    s, w, _ = _state_soa({"store_inventories": data["initial_inventories"], "warehouse_inventories": data["initial_warehouse_inventories"]},
+                         prob, dev)
+    ts, tw, te, _keep = _orders_tables(action, dev)
+    dem = data["demands"].to(dev)   # (kept alive: the table below only holds its address)
+    io = prob.make_io(s, w, None, _demand_table(dem, 0), ts, tw, te)
+    so, wo, r = torch.zeros_like(s), torch.zeros_like(w), torch.zeros(prob.ldb, device=dev)
+    be.env_fwd(io, so, wo, None, r)
+    be.sync()
+    assert torch.equal(ref_view(so, 1).cpu(), want["store_inventories"])
+    assert torch.equal(ref_view(wo, 1).cpu(), want["warehouse_inventories"])
+    assert torch.equal(r[:1].cpu(), want["reward"])
+
+
 def check_env_backward(be, name, profit):
     g = Golden(name)
     c = g.fresh_config()

@@ -139,6 +139,92 @@ def test_sharded_scenarios_equal_single_process_dataset():
         assert ret[r]["reducer_ok"]
 
 
+# ---- four ranks, an epoch whose batches do not divide evenly (round 4) -----------------------------------------------------
+
+def _epoch_worker(rank, world, port, ret):
+    """One epoch of a 22-scenario dataset in global batches of 9 (9, 9, 4) on four ranks: per-rank slices of a batch are
+    ceil(batch / world) long - (3, 3, 3, 0) for a batch of 9 and (1, 1, 1, 1) for the last one - i.e. one rank holds NO scenario of
+    the first two batches and still has to join their collectives.  Per-batch gradients come from the oracle; each rank divides by
+    the GLOBAL batch like Trainer.do_one_epoch; the all-reduced gradient of every batch must be the single-process gradient."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from golden_io import Golden
+    from neural_inventory_control_amd import parallel
+    from neural_inventory_control_amd.data_handling import DeviceBatches, MyDataset
+    from oracle import inventory_oracle as orc
+    parallel.init_from_env(backend="gloo")
+    g = Golden("cfg3_one_warehouse_16_vanilla")
+    c = g.fresh_config()
+    n = 22
+    data = {k: v[:n] for k, v in g.data.items()}
+    T, S = c["periods"], c["problem_params"]["n_stores"]
+    loader = DeviceBatches(MyDataset(n, data), 9, shuffle=True, device="cpu", seed=3, rank=rank, world_size=world)
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"], g.tensor("warehouse_upper_bound"))
+
+    class M(torch.nn.Module):
+        def __init__(self, ps):
+            super().__init__()
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(p.detach().clone()) for p in ps])
+    m = M(pol.parameters())
+    out = []
+    for batch in loader:
+        gb = loader.last_global_batch
+        nb = len(batch["demands"])
+        for p in pol.parameters():
+            p.grad = None
+        if nb:
+            res = orc.rollout(pol, T, c["problem_params"], batch, c["observation_params"], c["ignore"])
+            (res.total / (gb * T * S)).backward()
+            tot, rep = res.total.detach(), res.reported.detach()
+        else:
+            tot = rep = torch.zeros(())
+        for p, src in zip(m.ps, pol.parameters()):
+            p.grad = src.grad.clone() if src.grad is not None else torch.zeros_like(p)
+        tot, rep = parallel.GradientAllReducer.get(m).all_reduce(tot, rep)
+        out.append({"local": nb, "global": gb, "total": float(tot), "reported": float(rep),
+                    "grads": [p.grad.clone() for p in m.ps],
+                    "rows": batch["initial_inventories"][:, 0, 0].clone()})
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_epoch_with_uneven_batches_matches_single_process():
+    sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+    from golden_io import Golden
+    from neural_inventory_control_amd.data_handling import DeviceBatches, MyDataset
+    from oracle import inventory_oracle as orc
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_epoch_worker, args=(4, 29500 + (os.getpid() + 13) % 2000, ret), nprocs=4, join=True)
+    g = Golden("cfg3_one_warehouse_16_vanilla")
+    c = g.fresh_config()
+    n = 22
+    data = {k: v[:n] for k, v in g.data.items()}
+    T, S = c["periods"], c["problem_params"]["n_stores"]
+    single = DeviceBatches(MyDataset(n, data), 9, shuffle=True, device="cpu", seed=3)   # the same permutation, one process
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"], g.tensor("warehouse_upper_bound"))
+    locals_seen = []
+    for i, batch in enumerate(single):
+        gb = len(batch["demands"])
+        for p in pol.parameters():
+            p.grad = None
+        res = orc.rollout(pol, T, c["problem_params"], batch, c["observation_params"], c["ignore"])
+        (res.total / (gb * T * S)).backward()
+        per_rank = [ret[r][i] for r in range(4)]
+        locals_seen.append([x["local"] for x in per_rank])
+        assert all(x["global"] == gb for x in per_rank) and sum(x["local"] for x in per_rank) == gb
+        # the ranks' slices, in rank order, ARE the global batch (every scenario exactly once, same order)
+        assert torch.equal(torch.cat([x["rows"] for x in per_rank]), batch["initial_inventories"][:, 0, 0])
+        for r in range(4):
+            assert abs(per_rank[r]["total"] - float(res.total)) <= 2e-6 * abs(float(res.total))
+            assert abs(per_rank[r]["reported"] - float(res.reported)) <= 2e-6 * abs(float(res.reported))
+            for got, p in zip(per_rank[r]["grads"], pol.parameters()):
+                assert float((got - p.grad).norm() / (p.grad.norm() + 1e-30)) < 5e-6
+    assert locals_seen == [[3, 3, 3, 0], [3, 3, 3, 0], [1, 1, 1, 1]]   # an empty slice on rank 3, a short last batch
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """`python bench.py --gpus N` must start N ranks itself or fail loudly - never report a 1-rank number as N GPUs."""
     import subprocess

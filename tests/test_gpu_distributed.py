@@ -114,6 +114,32 @@ def test_bench_line_contract(workload):
     assert cb["unit"] == out["unit"]
 
 
+def test_bench_epoch_workload_line():
+    """`bench.py --workload cfg3_yaml`: the reference's shipped YAML pair through Trainer.do_one_epoch (8,192 samples, batches of
+    1,024 x 50 periods).  One JSON line with the driver's keys; a step is one batch; the epoch is also reported eager / replayed
+    and with the reference-style host DataLoader."""
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "cfg3_yaml", "--steps", "8", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_epoch", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "kernels"):
+        assert k in out, k
+    cfg = out["config"]
+    assert cfg["samples"] == 8192 and cfg["batch_size"] == 1024 and cfg["batches_per_epoch"] == 8 and cfg["periods"] == 50
+    assert cfg["stores"] == 5 and cfg["route"] == "FusedRollout" and out["steps"] == 8
+    assert abs(out["value"] - 8192 * 5 * 50 / (out["ms_per_epoch"] * 1e-3)) <= 1e-6 * out["value"]
+    assert abs(out["ms_per_step"] * 8 - out["ms_per_epoch"]) <= 1e-6 * out["ms_per_epoch"]
+    ev = cfg["epoch_variants"]
+    assert ev["eager_ms_per_epoch"] > 0 and ev["graph_ms_per_epoch"] > 0 and ev["torch_dataloader_ms_per_epoch"] > ev["graph_ms_per_epoch"]
+    assert cfg["rollout_graph"]["setting"] == "auto" and cfg["rollout_graph"]["auto_probe"] is not None
+    rf = out["roofline"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 2e-3 and 0 < rf["frac"] < 1
+
+
 def test_library_mapped_before_any_torch_device_use_still_launches():
     """build() and smoke() in one process: the C-ABI library is mapped (and its code objects registered with the HIP runtime)
     before PyTorch has touched the device.  `load_library` initialises torch's device first; without that every launch from

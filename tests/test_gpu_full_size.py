@@ -137,3 +137,45 @@ def test_cfg5_per_period_route_at_full_size():
     g_b = _grads(eng, model, _slice(data, half, n), T, obs, scale)
     for gf, ga, gb in zip(g_full, g_a, g_b):
         assert float((gf - (ga + gb)).norm()) <= 2e-5 * float(gf.norm()) + 1e-12
+
+
+# ---- BASELINE's full sizes at the FULL horizon (round 4: the tests above run 6-12 periods) -----------------------------------------
+@pytest.mark.parametrize("workload,n,T", [("cfg2", 32768, 100), ("cfg3", 65536, 100), ("cfg4", 16384, 100), ("cfg5", 32768, 70)])
+def test_full_size_full_horizon_training_step_properties(workload, n, T):
+    """One training step at BASELINE's scenario count AND horizon (cfg3: 65,536 x 16 x T = 100 - the bench's headline step; cfg5:
+    32,768 x 64 x T = 70; cfg2 / cfg4: T = 100 on the whole-horizon kernels), with assertions the bench itself does not make:
+      * additivity: total cost and parameter gradient of the full batch = sum over its two halves (same global normalisation) -
+        every scenario block and every period contributes exactly once, through T periods of recurrence;
+      * stock conservation over every scenario and period of the lost-demand settings (per-period route keeps the history);
+      * per-period costs are finite and non-negative, padding columns of the reward buffer stay zero."""
+    setting, sc, data, model, eng, obs = _case(workload, n, T)
+    pp = setting["problem_params"]
+    S, Wn = pp["n_stores"], pp["n_warehouses"]
+    scale = 1.0 / (n * T * S)
+    tot_full, _ = eng.run(data, T, 0, train=True, observation_params=obs, grad_scale=scale, demand_soa=sc.demands_soa)
+    torch.cuda.synchronize()
+    g_full = [p.grad.detach().clone() for p in model.parameters()]
+    tot_full = float(tot_full)
+    r = eng.rewards
+    assert r.shape[0] == T and bool(torch.isfinite(r).all()) and float(r.min()) >= 0.0 and float(r[:, n:].abs().sum()) == 0.0
+    if eng.small is None and pp["lost_demand"] and pp["n_extra_echelons"] == 0:
+        Ws = data["initial_inventories"].shape[2]
+        worst = 0.0
+        for t in range(0, T, 7):   # (every 7th period: the check reads 3 state-sized blocks per period)
+            st = eng.states[t][:S * Ws].view(S, Ws, -1)[:, :, :n].double()
+            nx = eng.states[t + 1][:S * Ws].view(S, Ws, -1)[:, :, :n].double()
+            dem = eng.demand[t][:, :n].double()
+            sales = torch.minimum(st[:, 0], dem)
+            recv = eng.orders[t][:S * max(Wn, 1)].view(S, max(Wn, 1), -1)[:, :, :n].double().sum(dim=1)
+            worst = max(worst, float((nx.sum(dim=1) - (st.sum(dim=1) - sales + recv)).abs().max()))
+        assert worst < 5e-3, worst
+    half = n // 2
+    ta, _ = eng.run(_slice(data, 0, half), T, 0, train=True, observation_params=obs, grad_scale=scale)
+    torch.cuda.synchronize()
+    g_a, ta = [p.grad.detach().clone() for p in model.parameters()], float(ta)
+    tb, _ = eng.run(_slice(data, half, n), T, 0, train=True, observation_params=obs, grad_scale=scale)
+    torch.cuda.synchronize()
+    g_b, tb = [p.grad.detach().clone() for p in model.parameters()], float(tb)
+    assert abs(tot_full - (ta + tb)) <= 2e-6 * abs(tot_full), (tot_full, ta, tb)
+    for gf, ga, gb in zip(g_full, g_a, g_b):
+        assert float((gf - (ga + gb)).norm()) <= 3e-5 * float(gf.norm()) + 1e-12, float((gf - (ga + gb)).norm() / gf.norm())

@@ -51,6 +51,11 @@ def test_serial_head(be, E):
     kc.check_serial_head(be, E)
 
 
+def test_zero_lead_orders_hand_computed_period(be):
+    """Pins the "drop" semantics of the HIP env step (what ZERO_LEAD_CASES are compared against) with hand-computed numbers."""
+    kc.check_zero_lead_micro(be)
+
+
 def test_env_rejects_bad_arguments(be):
     io = _lib.NicEnvStepIO()
     assert be.l.nic_env_step_fwd(io, None, None, None, None, None) != 0

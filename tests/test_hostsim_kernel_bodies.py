@@ -36,3 +36,8 @@ def test_softplus_head(be):
 @pytest.mark.parametrize("E", [2, 1, 3])
 def test_serial_head(be, E):
     kc.check_serial_head(be, E)
+
+
+def test_zero_lead_orders_hand_computed_period(be):
+    """Pins the "drop" semantics (what ZERO_LEAD_CASES are compared against) with numbers worked out by hand."""
+    kc.check_zero_lead_micro(be)
