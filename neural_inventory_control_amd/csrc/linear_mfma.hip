@@ -797,7 +797,11 @@ __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
     const int k0 = (lid % tiles_k) * BN;                  // output cols  (features of X, plus the bias column K)
     const int n0 = ((lid / tiles_k) % tiles_n) * BM;      // output rows  (features of dY)
     const int split = lid / (tiles_k * tiles_n);
-    const int b_begin = split * p.chunk;
+    // slab slot = (period group, scenario split) when scen_splits > 0 (see WgParams): this workgroup's periods
+    const int ssplit = p.scen_splits > 0 ? split % p.scen_splits : split;
+    const int p_first = p.scen_splits > 0 ? (split / p.scen_splits) * p.periods_per_group : 0;
+    const int p_end = p.scen_splits > 0 ? min(p_first + p.periods_per_group, p.n_periods) : p.n_periods;
+    const int b_begin = ssplit * p.chunk;
     const int b_end = min(b_begin + p.chunk, p.nB);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -819,10 +823,10 @@ __global__ __launch_bounds__(kThreads) void gemm_wgrad_kernel(WgParams p) {
             }
 
     // periods: the accumulators persist over n_periods operand pairs (one slab read-modify-write per launch)
-    for (int period = 0; period < p.n_periods && b_begin < b_end; ++period) {
+    for (int period = p_first; period < p_end && b_begin < b_end; ++period) {
         const float* dYp = p.dY + period * p.pstride_dy;
         const float* Xp = p.X + period * p.pstride_x;
-        if (period > 0) __syncthreads();  // the previous period's last tile has been read by every wave
+        if (period > p_first) __syncthreads();  // the previous period's last tile has been read by every wave
         const bool vec = (p.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(dYp) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(Xp) & 15) == 0);
         KTile<BM> ta;
@@ -1583,8 +1587,18 @@ static void wgrad_period_factors(int32_t n_slots, int32_t n_scenarios, int32_t n
 
 int nic_wgrad_periods_num_splits(int32_t N, int32_t K, int32_t n_scenarios, int32_t n_periods) {
     if (N <= 0 || K <= 0 || n_scenarios <= 0 || n_periods <= 0) return 0;
-    if (!wgrad_dma_shape(N, K) || n_scenarios % BK != 0)
-        return nic_wgrad_num_splits(N, K, n_scenarios);   // shapes served period by period / by the register-staged kernels
+    if (N <= 32 && K <= 32) return nic_wgrad_num_splits(N, K, n_scenarios);   // wgrad_small_kernel: one launch per period
+    if (!wgrad_dma_shape(N, K) || n_scenarios % BK != 0) {
+        // register-staged kernels (ragged scenario counts, narrow layers: the real-data batches of 72-288 products x 95 weeks):
+        // the same (period group x scenario split) slots - ONE launch instead of a serial walk over the horizon by 1-4 workgroups
+        int bm, bn;
+        wgrad_tile(N, K, &bm, &bn);
+        const int tiles = ((N + bm - 1) / bm) * ((K + 1 + bn - 1) / bn);
+        int ss, g;
+        wgrad_period_factors((1024 + tiles - 1) / tiles, n_scenarios, n_periods, &ss, &g);
+        const int base = nic_wgrad_num_splits(N, K, n_scenarios);
+        return ss * g > base ? ss * g : base;
+    }
     const int tiles = wgrad_dma_tiles(N, K);
     const int slots = (256 + tiles - 1) / tiles;   // one workgroup per CU, one round
     int ss, g;
@@ -1595,14 +1609,16 @@ int nic_wgrad_periods_num_splits(int32_t N, int32_t K, int32_t n_scenarios, int3
 // argument checks + dispatch shared by nic_linear_wgrad (one period) and nic_linear_wgrad_periods
 static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t lds_, int32_t N, int32_t K, int32_t n_scenarios,
                          int32_t ldb, int32_t n_splits, int32_t n_periods, int64_t pstride_dy, int64_t pstride_x, void* stream,
-                         const char* who) {
+                         const char* who, int32_t scen_splits = 0, int32_t periods_per_group = 0) {
     NIC_REQUIRE(dY && X && slab, "%s: null buffer", who);
     NIC_REQUIRE(N > 0 && K > 0 && lds_ >= K + 1, "%s: bad N/K/lds (%d/%d/%lld)", who, N, K, (long long)lds_);
     NIC_REQUIRE(n_splits >= 1, "%s: n_splits must be >= 1", who);
     if (int e = require_ld(who, n_scenarios, ldb)) return e;
-    int chunk = (n_scenarios + n_splits - 1) / n_splits;
+    // (scen_splits > 0: the n_splits slab slots are period groups x scen_splits scenario splits, register-staged kernels only)
+    int chunk = (n_scenarios + (scen_splits > 0 ? scen_splits : n_splits) - 1) / (scen_splits > 0 ? scen_splits : n_splits);
     chunk = (chunk + BK - 1) / BK * BK;
-    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, pstride_dy, pstride_x, 0, 0, 0};
+    WgParams p{dY, X, slab, lds_, ldb, N, K, n_scenarios, chunk, gemm_variant() == 3 ? 0 : 1, n_periods, pstride_dy, pstride_x, 0,
+               scen_splits, periods_per_group};
     hipStream_t s = nic::as_stream(stream);
     int bm, bn;
     wgrad_tile(N, K, &bm, &bn);
@@ -1620,7 +1636,7 @@ static int wgrad_generic(const float* dY, const float* X, float* slab, int64_t l
         else if (K <= 96) hipLaunchKernelGGL(wgrad_small_kernel<3>, g, b, 0, s, p, n_splits);
         else hipLaunchKernelGGL(wgrad_small_kernel<4>, g, b, 0, s, p, n_splits);
     }
-    else if (wgrad_dma_shape(N, K) && dma_ok && gemm_variant() != 2) launch_wg_dma_for(p, n_splits, s);
+    else if (wgrad_dma_shape(N, K) && dma_ok && gemm_variant() != 2 && scen_splits == 0) launch_wg_dma_for(p, n_splits, s);
     else if (bm == 128 && bn == 128) launch_wg<2, 2, 2, 2>(p, n_splits, s);
     else if (bm == 128) launch_wg<2, 2, 2, 1>(p, n_splits, s);
     else if (bm == 64) launch_wg<1, 4, 2, 1>(p, n_splits, s);
@@ -1663,7 +1679,19 @@ int nic_linear_wgrad_periods(const float* dY, const float* X, float* slab, int64
                     return e;
             return 0;
         }
-        // register-staged kernels: a launch per group of periods, so that no accumulator sums more than ~8k terms
+        // register-staged kernels.  With enough slab slots: ONE launch, slot = (period group, scenario split), as long as no
+        // accumulator sums more than ~8k terms (chunk x periods per group)
+        {
+            int ss, g;
+            wgrad_period_factors(n_splits, n_scenarios, n_periods, &ss, &g);
+            int chunk_s = (n_scenarios + ss - 1) / ss;
+            chunk_s = (chunk_s + BK - 1) / BK * BK;
+            const int ppg = (n_periods + g - 1) / g;
+            if (g > 1 && (int64_t)chunk_s * ppg <= 8192)
+                return wgrad_generic(dY, X, slab, lds_, N, K, n_scenarios, ldb, ss * g, n_periods, period_stride_dy, period_stride_x,
+                                     stream, "nic_linear_wgrad_periods", ss, ppg);
+        }
+        // otherwise: a launch per group of periods, so that no accumulator sums more than ~8k terms
         // before it is added to the slab (see WgParams::flush_periods)
         int chunk_g = (n_scenarios + n_splits - 1) / n_splits;
         const int group = 8192 / (chunk_g > 0 ? chunk_g : 1) > 0 ? 8192 / (chunk_g > 0 ? chunk_g : 1) : 1;

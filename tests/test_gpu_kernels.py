@@ -303,7 +303,10 @@ def test_linear_wgrad_periods_equals_per_period_launches(N, K, B, T):
 
 @pytest.mark.parametrize("N,K,B,T,slots", [(512, 512, 1024, 7, None), (512, 512, 256, 9, 64), (512, 51, 1024, 6, None),
                                            (512, 51, 512, 5, 7), (98, 512, 512, 5, None), (512, 393, 384, 4, 6),
-                                           (512, 512, 8192, 3, None), (512, 66, 1024, 6, None), (320, 150, 512, 5, None)])
+                                           (512, 512, 8192, 3, None), (512, 66, 1024, 6, None), (320, 150, 512, 5, None),
+                                           # register-staged kernels (ragged scenario counts / narrow layers: the real-data
+                                           # batches of 72 products x 95 weeks with the 64-wide data_driven net)
+                                           (64, 597, 72, 19, None), (66, 64, 72, 10, None), (64, 64, 100, 7, 5), (200, 100, 300, 6, None)])
 def test_linear_wgrad_periods_splits_the_horizon_into_period_groups(N, K, B, T, slots):
     """Round 4: with few scenarios the slab slots of the all-period contraction are (period group x scenario split) pairs
     (nic_wgrad_periods_num_splits), so that a batch of 1,024 still gives every CU a workgroup.  Any slot count is accepted:
@@ -313,7 +316,7 @@ def test_linear_wgrad_periods_splits_the_horizon_into_period_groups(N, K, B, T, 
     ldb = pad_ld(B)
     want_slots = ops.wgrad_periods_num_splits(N, K, B, T)
     assert want_slots >= ops.wgrad_num_splits(N, K, B) or B >= 8192
-    if B <= 1024 and N * K >= 512 * 51:
+    if B <= 1024:
         assert want_slots > max(1, B // 128), "few scenarios: the horizon must be split as well"
     n_slots = slots or want_slots
     lds = (K + 1 + 3) // 4 * 4
@@ -329,7 +332,8 @@ def test_linear_wgrad_periods_splits_the_horizon_into_period_groups(N, K, B, T, 
         scale_w += dY64.abs() @ X64.abs().t()
     slab = torch.zeros(n_slots, N, lds, device=dev)
     ops.linear_wgrad_periods(dY, X, slab, B)
-    assert _lib.lib().nic_last_kernel().decode().startswith("gemm_wgrad_dma_kernel")
+    dma = B % 32 == 0 and ((N >= 192 and K >= 65) or (N >= 384 and K <= 64) or (96 <= N <= 128 and K >= 192))   # wgrad_dma_shape
+    assert _lib.lib().nic_last_kernel().decode().startswith("gemm_wgrad_dma_kernel" if dma else "gemm_wgrad_kernel")
     dW = torch.full((N, K), float("nan"), device=dev)
     db = torch.full((N,), float("nan"), device=dev)
     ops.wgrad_reduce(slab, dW, db, K, 1.0)

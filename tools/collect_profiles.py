@@ -82,6 +82,9 @@ def note_name(k):
     m = re.match(r"(gemm_wgrad_dma_kernel<\d+, \d+, \d+, \d+), (true|false)>", k)
     if m:
         return (m.group(1) + (",skip>" if m.group(2) == "true" else ">")).replace(" ", "")
+    m = re.match(r"(gemm_wx_stream_kernel<\d+, \d+), (\d)>", k)
+    if m:
+        return (m.group(1) + "," + {"0": "EPI_BIAS_ACT", "1": "EPI_DGRAD"}.get(m.group(2), m.group(2)) + ">").replace(" ", "")
     m = re.match(r"(gemm_wx(?:_dma)?_kernel<\d+, \d+, \d+, \d+), (\d)>", k)
     if m:
         return (m.group(1) + "," + {"0": "EPI_BIAS_ACT", "1": "EPI_DGRAD"}.get(m.group(2), m.group(2)) + ">").replace(" ", "")
@@ -106,7 +109,7 @@ def pmc_rows(counter, out_dir, bench_args):
 def traffic_pass(rnd, w, out):
     """HBM bytes per launch of every kernel CLASS of a workload: FETCH_SIZE / WRITE_SIZE passes joined, template by template
     and in dispatch order, to the launch sequence bench.py recorded in the same process (--launch-order-out)."""
-    few = ["--periods", "8"] if w in ("cfg3", "cfg5", "gnn") else []
+    few = ["--periods", "8"] if w in ("cfg3", "cfg5", "gnn", "cfg3_shard8") else []
     args = ["--workload", w, "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + few
     order_f = os.path.join(out, f"order_{w}.json")
     fetch = pmc_rows("FETCH_SIZE", os.path.join(out, f"pmc_fetch_{w}"), args + ["--launch-order-out", order_f])
@@ -150,21 +153,27 @@ def main():
         for a in sys.argv[2:]:
             traffic_pass(rnd, a.split(":", 1)[1], out)
         return
-    workloads = sys.argv[2:] or ["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "gnn", "base_stock", "base_stock_1m", "echelon_stock",
-                                 "real_data_driven"]
+    workloads = sys.argv[2:] or ["cfg3", "cfg3_shard8", "cfg3_batch1024", "cfg3_yaml", "cfg5_yaml", "cfg2", "cfg4", "cfg5", "cfg1",
+                                 "gnn", "gnn_many_warehouses", "base_stock", "base_stock_1m", "echelon_stock", "real_data_driven"]
+    epoch = ("cfg3_yaml", "cfg5_yaml")   # a step = one batch of an epoch of 8: whole epochs
     out = os.path.join(ROOT, "gpurun_out", rnd)
     os.makedirs(out, exist_ok=True)
     for w in workloads:
-        steps = ["--steps", "3", "--warmup", "1"] if w in ("cfg3", "cfg5", "gnn") else ["--steps", "20", "--warmup", "3"]
+        big = ("cfg3", "cfg5", "gnn", "gnn_many_warehouses", "cfg3_shard8")
+        steps = (["--steps", "16", "--warmup", "1"] if w in epoch else
+                 ["--steps", "3", "--warmup", "1"] if w in big else ["--steps", "20", "--warmup", "3"])
         run(["python3", "bench.py", "--workload", w] + steps, os.path.join(out, f"{rnd}_bench_{w}.json"))
         prof = os.path.join(out, "prof_" + w)
-        psteps = ["--steps", "2", "--warmup", "1"] if w in ("cfg3", "cfg5", "gnn") else ["--steps", "5", "--warmup", "2"]
+        psteps = (["--steps", "8", "--warmup", "1", "--no-kernel-timing"] if w in epoch else
+                  ["--steps", "2", "--warmup", "1"] if w in big else ["--steps", "5", "--warmup", "2"])
         run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", prof, "--", "python3", "bench.py",
              "--workload", w, "--no-cpu-baseline"] + psteps, os.path.join(out, f"{rnd}_bench_{w}_under_rocprof.json"))
         traces = glob.glob(os.path.join(prof, "**", "*kernel_trace.csv"), recursive=True)
         if traces:
             stats_from_trace(traces[0], os.path.join(out, f"{rnd}_bench_{w}_kernel_stats.csv"),
                              os.path.join(out, f"{rnd}_bench_{w}_kernel_by_grid.csv"))
+        import shutil
+        shutil.rmtree(prof, ignore_errors=True)   # (the raw traces are tens of MB; the summaries above are what is kept)
         if w in ("base_stock", "echelon_stock", "real_data_driven"):   # launch-bound steps: also replayed from one HIP graph
             run(["python3", "bench.py", "--workload", w, "--graph", "--no-cpu-baseline"] + steps,
                 os.path.join(out, f"{rnd}_bench_{w}_graph.json"))
