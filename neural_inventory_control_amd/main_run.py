@@ -95,7 +95,7 @@ def build(config_setting, config_hyperparams, device, rank=0, world_size=1):
     trainer = Trainer(device=device)
     trainer_params = dict(trainer_params)
     # optional extension key: replay each generic-route training step from one HIP graph (Trainer.use_step_graph)
-    trainer.use_step_graph = bool(trainer_params.get("use_step_graph", False))
+    trainer.use_step_graph = trainer_params.get("use_step_graph", "auto")   # true / false / "auto" (closed-form policies only)
     # ... and for the MLP engine's launch sequence: true / false / "auto" (default: decided by measurement, rollout.py)
     trainer.use_rollout_graph = trainer_params.get("use_rollout_graph", "auto")
     trainer_params["base_dir"] = trainer_params.get("base_dir", "saved_models")

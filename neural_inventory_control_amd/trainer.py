@@ -64,7 +64,10 @@ class Trainer:
         # generic route (policies the fused engine does not take: GNN, closed-form, user plugins): capture the whole training
         # step of a batch shape - every period's policy + env-step launches and the autograd sweep - into ONE HIP graph and
         # replay it; the per-period kernels of these policies run for microseconds, so the step is launch-bound
-        self.use_step_graph = False
+        # True / False / "auto" (default, round 4): the closed-form policies only - their whole-horizon kernel runs for 0.04 ms
+        # inside ~0.5 ms of host work per step (level network, autograd, Adam bookkeeping), so their steps are always launch-bound
+        # (base_stock 32,768 x T=100: 0.54 -> 0.17 ms); other generic-route policies keep eager steps unless asked
+        self.use_step_graph = "auto"
         # MLP engine (per-period route): replay each rollout's launch sequence from a HIP graph - True / False / "auto" (the
         # engine measures host enqueue time against GPU time on a shape's second training step and replays only if the step is
         # launch-bound; `trainer_params.use_rollout_graph` in main_run)
@@ -75,6 +78,12 @@ class Trainer:
 
     def reset(self):
         self.all_train_losses, self.all_dev_losses, self.all_test_losses = [], [], []
+
+    def _step_graph_on(self, model, observation_params):
+        """`use_step_graph` resolved for a policy: "auto" = the closed-form policies (whole-horizon kernel inside the captured step)."""
+        if self.use_step_graph == "auto":
+            return bool(self.use_fused_rollout and ClosedFormRollout.supports(model) and self._plain_observation(observation_params))
+        return bool(self.use_step_graph)
 
     # ---- training / evaluation loops (trainer.py:29-141) ---------------------------------------------------------
     def train(self, epochs, loss_function, simulator, model, data_loaders, optimizer, problem_params, observation_params,
@@ -128,7 +137,8 @@ class Trainer:
         with torch.no_grad() if not train else torch.enable_grad():
             for data_batch in data_loader:
                 data_batch = self.move_batch_to_device(data_batch)
-                if train and not self.use_step_graph:
+                step_graph = self._step_graph_on(model, observation_params)
+                if train and not step_graph:
                     optimizer.zero_grad()
                 elif train:
                     optimizer.zero_grad(set_to_none=False)  # captured steps accumulate into fixed .grad tensors
@@ -156,7 +166,7 @@ class Trainer:
                 # generic route AND the closed-form policies' whole-horizon kernel (its launch, the level network's autograd
                 # and the totals: 0.55 -> 0.18 ms per step).  The MLP / GNN engines run GPU-bound launch sequences of their own
                 # (`FusedRollout.use_graph` replays those) and keep the eager step.
-                graphed = (train and model.trainable and self.use_step_graph and not discrete_allocation
+                graphed = (train and model.trainable and step_graph and not discrete_allocation
                            and not (self.use_fused_rollout
                                     and ((FusedRollout.supports(model) and FusedRollout.observation_ok(model, observation_params))
                                          or (self._plain_observation(observation_params)
@@ -210,8 +220,8 @@ class Trainer:
             # engine, otherwise an epoch's smaller last batch would re-size - free - what the first graph replays into)
             # ... and every (horizon, training / evaluation) context: a dev pass with the training batch size but another
             # `periods` would otherwise re-size the buffers the captured training step replays into by raw address
-            ekey = ((id(model), "closed_form", len(data_batch["demands"]), periods, bool(train)) if self.use_step_graph
-                    else (id(model), "closed_form", None))
+            ekey = ((id(model), "closed_form", len(data_batch["demands"]), periods, bool(train))
+                    if self._step_graph_on(model, observation_params) else (id(model), "closed_form", None))
             eng = self._engines.get(ekey)
             if eng is None or eng.model is not model:
                 eng = self._engines[ekey] = ClosedFormRollout(model, problem_params, self.device)
