@@ -160,7 +160,7 @@ def _certified_ratio():
     return None
 
 
-def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None):
+def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None, setting_policy=None):
     """The oracle (CPU restatement of the reference path, PyTorch eager) timed on this host's cores: training steps
     (rollout + backward) of the same workload on a bounded sample of scenarios; 1 warm-up + `reps` timed repetitions,
     median."""
@@ -168,7 +168,7 @@ def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None):
     from neural_inventory_control_amd import workloads
     from oracle import inventory_oracle as orc
     avail = os.cpu_count() or 1
-    setting, policy, _, _, _ = workloads.get(workload)
+    setting, policy = setting_policy if setting_policy is not None else workloads.get(workload)[:2]
     obs = defaultdict(lambda: None, setting["observation_params"])
     real = setting["store_params"]["demand"]["distribution"] == "real"
     shift = setting["observation_params"]["demand"]["period_shift"]
@@ -413,6 +413,16 @@ def bench_epoch(args):
                                ("algorithmic_flops_per_launch" if d["bound"] == "mfma" else "algorithmic_bytes_per_launch"):
                                    d.get("algorithmic_flops_per_launch", d.get("algorithmic_bytes_per_launch"))}
         out["kernels"] = kernels
+    if world == 1 and not args.no_cpu_baseline:
+        # the oracle on ONE batch of the epoch (same setting, batch size and horizon; gradient step without the optimizer)
+        try:
+            import copy
+            st2, hy2, _ = workloads.get_epoch(args.workload)
+            out["cpu_baseline"] = cpu_baseline(args.workload, pbd["batch_size"], T, setting_policy=(st2, hy2["nn_params"]))
+            out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:  # the baseline must never take the bench line down
+            out["cpu_baseline"] = {"value": None, "unit": "scenario-steps/s", "cores": None, "host_cores": os.cpu_count(),
+                                   "kind": "port", "sample": f"failed: {e!r}"}
     print(json.dumps(out))
     if parallel.active():
         torch.distributed.destroy_process_group()

@@ -14,7 +14,7 @@
 //   gemm_wx_dma_kernel     forward + dgrad; 128 x 128 x 32 block tile of 8 waves (2 x 4, wave tile 64 x 32), two workgroups
 //                          co-resident per CU; 64 x 128 (8 waves) and 32 x 128 (4 waves) for small launches / thin or ragged
 //                          outputs (pick_wx_tile; round 4: co-resident workgroups beat one 256 x 256 workgroup per CU)
-//   gemm_wgrad_dma_kernel  weight gradient, 256 x 256 output tile per (scenario chunk, period group), 8 waves (2 x 4)
+//   gemm_wgrad_dma_kernel  weight gradient, 128 x 256 output tile per (scenario chunk, period group), 8 waves (2 x 4)
 //   both: tiles go HBM/L2 -> LDS by `buffer_load_dwordx4 ... lds` (no VGPR round trip), double-buffered, one barrier per
 //   k tile; A-style tiles [rows][32] are unpadded with a 16-byte-chunk XOR swizzle applied on the DMA source address
 //   and on the ds_read_b128 fragment reads; the [32][BN] B tile of the wx kernel is linear (ds_read_b32 rows);
@@ -1350,7 +1350,7 @@ int pick_wx_tile(int M, int ncols) {
     auto padded = [&](int bm) { return (double)((M + bm - 1) / bm * bm) / M; };
     const int64_t tiles128 = (int64_t)((M + 127) / 128) * ((ncols + 127) / 128);
     double c128 = padded(128), c64 = padded(64) * 1.02, c32 = padded(32) * 1.06;   // (512 x 512 x 65,536: 262 / 265 / 281 us)
-    if (tiles128 < 512) {   // fewer than two workgroups per CU: smaller tiles put more wavefronts on a CU
+    if (tiles128 < 2 * nic::cu_count()) {   // fewer than two workgroups per CU: smaller tiles put more wavefronts on a CU
         c128 = 1e30;
         c64 = padded(64);
         c32 = padded(32) * 1.02;
@@ -1375,9 +1375,10 @@ constexpr int forced_wx_tile() { return -1; }
 // logits 17 x 512 13.2 -> 7.5 up to 8,192 scenarios, 14.5 -> 9.3 at 16,384; first-layer input gradient 51 x 512 20.6 -> 7.6.
 int pick_wx_stream(int M, int K, int ncols) {
     const int64_t tiles = (int64_t)((M + 31) / 32) * ((ncols + 31) / 32);
-    if (tiles > 1024 || K < 128) return 0;   // (a short contraction is 2-4 k tiles of the LDS pipeline: nothing to gain, measured)
+    const int cus = nic::cu_count();
+    if (tiles > 4 * cus || K < 128) return 0;   // (a short contraction is 2-4 k tiles of the LDS pipeline: nothing to gain, measured)
     int ks = 1;
-    while (ks < 4 && tiles * ks * 2 <= 2048 && K >= 64 * ks * 2) ks *= 2;
+    while (ks < 4 && tiles * ks * 2 <= 8 * cus && K >= 64 * ks * 2) ks *= 2;
     return ks;
 }
 
@@ -1489,7 +1490,7 @@ int wgrad_dma_tiles(int N, int K) {
     if (wgrad_half(N, K)) return (N + 255) / 256;
     if (wgrad_mid(N, K)) return (K + 255) / 256;
     if (wgrad_wide(N, K)) return (N + 127) / 128;
-    return ((N + 255) / 256) * ((K + 255) / 256);
+    return ((N + 127) / 128) * ((K + 255) / 256);
 }
 
 // the LDS-DMA weight-gradient kernel for a shape (wgrad_dma_shape)
@@ -1503,8 +1504,10 @@ void launch_wg_dma_for(const WgParams& p, int n_splits, hipStream_t s) {
         else if (nt == 6) launch_wg_dma<4, 2, 1, 6>(p, n_splits, s);
         else launch_wg_dma<4, 2, 1, 7>(p, n_splits, s);
     }
-    else if ((p.N + 255) / 256 * 256 - p.N >= 32) launch_wg_dma<2, 4, 4, 2, true>(p, n_splits, s);  // an empty row tile to skip
-    else launch_wg_dma<2, 4, 4, 2>(p, n_splits, s);
+    // big layers: 128 x 256 tiles (round 4; wave tile 64 x 64 = 64 accumulator registers, no scratch).  Measured against round 3's
+    // 256 x 256 tile (128 accumulators, 516 B of scratch) on 512 x 512 x 16,384 x T=50: 133.3-133.9 against 131.8 TFLOP/s
+    // (profiles/r04_gemm_stagger_and_wgrad_tile_probe.json)
+    else launch_wg_dma<2, 4, 2, 2>(p, n_splits, s);
 }
 
 int require_ld(const char* who, int32_t n_scenarios, int32_t ldb) {
@@ -1548,10 +1551,10 @@ int nic_wgrad_num_splits(int32_t N, int32_t K, int32_t n_scenarios) {
     int bm, bn;
     wgrad_tile(N, K, &bm, &bn);
     int tiles = ((N + bm - 1) / bm) * ((K + 1 + bn - 1) / bn);
-    int target = 1024;                                 // ~4 workgroups per CU in total
+    int target = 4 * nic::cu_count();                  // ~4 workgroups per CU in total
     if (wgrad_dma_shape(N, K)) {                       // LDS-DMA tiles, one workgroup per CU, one round
         tiles = wgrad_dma_tiles(N, K);
-        target = 256;
+        target = nic::cu_count();
     }
     if (N <= 32 && (K <= 32 || (K <= 128 && K % 32 != 0))) {  // wgrad_small_kernel: one split per wave, >= 2048 columns each
         int sp = (int)(((int64_t)n_scenarios + 2047) / 2048);
@@ -1595,12 +1598,12 @@ int nic_wgrad_periods_num_splits(int32_t N, int32_t K, int32_t n_scenarios, int3
         wgrad_tile(N, K, &bm, &bn);
         const int tiles = ((N + bm - 1) / bm) * ((K + 1 + bn - 1) / bn);
         int ss, g;
-        wgrad_period_factors((1024 + tiles - 1) / tiles, n_scenarios, n_periods, &ss, &g);
+        wgrad_period_factors((4 * nic::cu_count() + tiles - 1) / tiles, n_scenarios, n_periods, &ss, &g);
         const int base = nic_wgrad_num_splits(N, K, n_scenarios);
         return ss * g > base ? ss * g : base;
     }
     const int tiles = wgrad_dma_tiles(N, K);
-    const int slots = (256 + tiles - 1) / tiles;   // one workgroup per CU, one round
+    const int slots = (nic::cu_count() + tiles - 1) / tiles;   // one workgroup per CU, one round
     int ss, g;
     wgrad_period_factors(slots, n_scenarios, n_periods, &ss, &g);
     return ss * g;

@@ -39,6 +39,22 @@ inline void note_kernelf(const char* fmt, ...) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Compute units of the current device (256 on MI355X), asked once: the launch heuristics (tile choice, split counts) are written
+// in multiples of it instead of a literal 256.
+inline int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+        (void)hipGetLastError();   // (a CPU-only process asking for split counts: keep the default, clear the error)
+    }
+    return n;
+}
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace nic

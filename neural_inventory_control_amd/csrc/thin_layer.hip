@@ -345,7 +345,7 @@ int nic_linear_fwd_thin_in(const float* Wt, int64_t ldwt, const float* bias, con
     // wavefronts at 65,536 scenarios); with few scenarios the rows are split further so that the launch still has ~4,096
     // wavefronts and a wavefront's serial chain of row blocks gets shorter (8,192 scenarios: 19 -> 9 us, round 4)
     const int chunks = nic::ceil_div(n_cols, 32);
-    int split = (4096 + chunks - 1) / chunks;
+    int split = (16 * nic::cu_count() + chunks - 1) / chunks;
     if (split < kThinInSplit) split = kThinInSplit;
     if (split > N / 32) split = N / 32;
     const dim3 grid(nic::ceil_div(n_cols, 32 * kThinInWaves), split), block(64 * kThinInWaves);
