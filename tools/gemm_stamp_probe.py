@@ -56,8 +56,9 @@ def run_case(lib, name, fn, n_wg, K, stamps):
             rounds[nm] = {"n": int(m.sum()), "k_loop_us_min_med_max": [round(float(v), 1) for v in q],
                           "memtime_ticks_per_us": round(float(rate[m].mean()), 1),
                           "start_us_min_max": [round(float(start[m].min()), 1), round(float(start[m].max()), 1)]}
-    # MFMA issue cycles of the k loop per SIMD: 2 waves x (K / 2) steps x 8 MFMAs x 64 cycles
-    issue_cycles = 2 * (K // 2) * 8 * 64
+    # MFMA issue cycles of ONE workgroup's k loop per SIMD: waves per SIMD x (K / 2) steps x MFMA tiles per wave x 64 cycles
+    # (256 x 256 tile: 2 waves x 8 tiles; 128 x 128, 8 waves: 2 waves x 2 tiles - and a co-resident workgroup issues as much again)
+    issue_cycles = 2 * (K // 2) * int(os.environ.get("PROBE_TILES_PER_WAVE", "2")) * 64
     ph["k_loop"]["mfma_issue_cycles_per_us"] = round(issue_cycles / float(((st[:, 2, 1] - st[:, 1, 1]) / 100.0).mean()), 1)
     return {"event_us_stamped": round(s.elapsed_time(e) * 1e3, 1), "event_us": round(s2.elapsed_time(e2) * 1e3 / 50, 1),
             "workgroups": n_wg, "phases": ph, "rounds": rounds, "last_exit_us": round(float(end.max()), 1)}
@@ -83,7 +84,9 @@ def main():
             X = torch.nn.functional.elu(torch.randn(K, ldb, device=dev))
             Y = torch.zeros(N, ldb, device=dev)
             dX = torch.zeros(K, ldb, device=dev)
-            n_wg = (N // 256) * (B // 256)
+            # workgroup tile of the launch (round 4: 128 x 128 with two workgroups co-resident per CU; 256 x 256 with NIC_GEMM_TUNE & 128)
+            tr_, tc_ = (256, 256) if (tune & 128) else tuple(int(v) for v in os.environ.get("PROBE_TILE", "128,128").split(","))
+            n_wg = (N // tr_) * (B // tc_)
             stamps = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
             cases = [("fwd", lambda: ops.linear_fwd(W, b, X, Y, B, 1))]
             if tune in (0, 8, 16):
