@@ -17,7 +17,10 @@ for f, name in ((fetch, "FETCH_SIZE"), (write, "WRITE_SIZE")):
     for k, v in df.dropna(subset=["k"]).groupby("k")["Counter_Value"].mean().items():
         res.setdefault(k, {})[name] = float(v)
 entries = []
-kinds = {"gemm_wx_dma_kernel<2, 4, 4, 2, 0>": "fwd", "gemm_wx_dma_kernel<2, 4, 4, 2, 1>": "dgrad", "gemm_wgrad_dma_kernel<2, 4, 4, 2>": "wgrad"}
+# (round 4's kernels for the 512 x 512 layer at >= 16,384 scenarios; rounds 1-3: <2, 4, 4, 2, *>)
+kinds = {"gemm_wx_dma_kernel<2, 4, 2, 1, 0>": "fwd", "gemm_wx_dma_kernel<2, 4, 2, 1, 1>": "dgrad",
+         "gemm_wgrad_dma_kernel<2, 4, 2, 2, false>": "wgrad",
+         "gemm_wx_dma_kernel<2, 4, 4, 2, 0>": "fwd", "gemm_wx_dma_kernel<2, 4, 4, 2, 1>": "dgrad", "gemm_wgrad_dma_kernel<2, 4, 4, 2>": "wgrad"}
 for k, c in res.items():
     if k in kinds and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
