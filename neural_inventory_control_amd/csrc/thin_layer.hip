@@ -253,7 +253,7 @@ constexpr int kThinInWaves = 4;
 #define NIC_THIN_IN_SPLIT 2
 #endif
 constexpr int kThinInSplit = NIC_THIN_IN_SPLIT;   // wavefronts that share a scenario chunk, each taking a slice of the output rows
-template <int KS>
+template <int KS, bool BIAS>
 __global__ __launch_bounds__(64 * kThinInWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void thin_in_fwd_kernel(const float* __restrict__ Wt, int64_t ldwt,
                                                                         const float* __restrict__ bias, const float* __restrict__ X,
                                                                         float* __restrict__ Y, int N, int K, int n_cols, int64_t ldb,
@@ -291,37 +291,58 @@ __global__ __launch_bounds__(64 * kThinInWaves) __attribute__((amdgpu_waves_per_
 #pragma unroll
         for (int s = 0; s < KS; ++s) a[s] = ldf(rW, vw, 2 * s * lw4);
     };
-    auto run_block = [&](int nb, const float (&a)[KS]) {
-        float bv[16];   // fetched here, used after the block's MFMAs
-        const int vb = (nb * 32 + 4 * h) * 4;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = ldf(rB, vb + ((r & 3) + 8 * (r >> 2)) * 4, 0);
-        f32x16 acc;
+    // a block's 26 MFMAs; the register each step has just consumed is refilled with the NEXT block's fragment (one resident
+    // fragment set instead of two: 26 registers less, and every load is issued in front of this block's stores)
+    auto mfma_block = [&](float (&a)[KS], int nb_next, f32x16& acc) {
+        const int vw = h * lw4 + (nb_next * 32 + i) * 4;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x[s], acc, 0, 0, 0);
-        float y[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float z = acc[r] + bv[r];
-            y[r] = act == NIC_ACT_ELU ? thin_elu(z) : z;
+        for (int s = 0; s < KS; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x[s], acc, 0, 0, 0);
+            a[s] = ldf(rW, vw, 2 * s * lw4);
         }
+    };
+    // bias + activation.  (The rollout engine passes NO bias: its first layer's bias rides in the contraction - the layer input
+    // carries a row of ones behind its K rows and the transposed weights the bias as row K, rollout.py - so that a block issues no
+    // load that is younger than the previous block's stores.)
+    auto finish_block = [&](int nb, f32x16& y) {
+        if constexpr (BIAS) {
+            const int vb = (nb * 32 + 4 * h) * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] += ldf(rB, vb + ((r & 3) + 8 * (r >> 2)) * 4, 0);
+        }
+        if (act == NIC_ACT_ELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y[r] = thin_elu(y[r]);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four at a time: sixteen ELUs in flight spill registers)
+            }
+        }
+    };
+    auto store_block = [&](int nb, const f32x16& y) {
         if (full || live) {   // (`full` is wave-uniform: no lane masks on the common path)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[r]), rY, vo, (nb * 32 + (r & 3) + 8 * (r >> 2)) * ld4, 0);
         }
     };
-    float a0[KS], a1[KS];
-    load_block(nb_lo, a0);
-    for (int nb = nb_lo; nb < n_blocks; nb += 2) {
-        if (nb + 1 < n_blocks) load_block(nb + 1, a1);
-        run_block(nb, a0);
-        if (nb + 1 < n_blocks) {
-            if (nb + 2 < n_blocks) load_block(nb + 2, a0);
-            run_block(nb + 1, a1);
-        }
+    // Order of a block's work (round 4).  vmcnt counts loads AND stores on this part and retires them in order, so waiting for a
+    // load also waits for every store issued before it: with the next block's fragment loads issued behind this block's stores
+    // (round 2's loop, two fragment sets) each block's first MFMA waited for the PREVIOUS block's 16 stores to be acknowledged -
+    // a wavefront's MFMA phase and store phase never overlapped (52 us = 22 us of MFMA + 27 us of HBM, added).  Now:
+    //     MFMAs(b), each followed by the load of block b+1's fragment into the register it consumed -> activation
+    //     -> s_waitcnt vmcnt(0) [stores(b-1): a block old; fragments(b+1): requested during the MFMA chain] -> stores(b)
+    // so the stores of a block retire under the next block's MFMAs and nothing waits for a store that was just issued.
+    float a[KS];
+    f32x16 y;
+    load_block(nb_lo, a);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // (nothing pending at the loop head: the compiler then adds no waits of its own inside)
+    for (int nb = nb_lo; nb < n_blocks; ++nb) {
+        mfma_block(a, nb + 1 < n_blocks ? nb + 1 : nb, y);   // (the last block re-reads its own fragments: no branch in the chain)
+        finish_block(nb, y);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the previous block's stores and the fragments just requested
+        store_block(nb, y);
     }
 }
 
@@ -351,7 +372,8 @@ int nic_linear_fwd_thin_in(const float* Wt, int64_t ldwt, const float* bias, con
     const dim3 grid(nic::ceil_div(n_cols, 32 * kThinInWaves), split), block(64 * kThinInWaves);
     hipStream_t s = nic::as_stream(stream);
     nic::note_kernel("thin_in_fwd_kernel<26>");
-    hipLaunchKernelGGL(thin_in_fwd_kernel<26>, grid, block, 0, s, Wt, ldwt, bias, X, Y, N, K, n_cols, (int64_t)ldb, act);
+    if (bias != nullptr) hipLaunchKernelGGL((thin_in_fwd_kernel<26, true>), grid, block, 0, s, Wt, ldwt, bias, X, Y, N, K, n_cols, (int64_t)ldb, act);
+    else hipLaunchKernelGGL((thin_in_fwd_kernel<26, false>), grid, block, 0, s, Wt, ldwt, bias, X, Y, N, K, n_cols, (int64_t)ldb, act);
     return nic::check_launch("nic_linear_fwd_thin_in");
 }
 

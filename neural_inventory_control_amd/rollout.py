@@ -261,7 +261,10 @@ class FusedRollout:
                     if dev.type == "cuda" else 0)
         auto = 4 * (T + 1) * ld * (f_tot + n_ord + dims[-1]) <= 0.1 * free_now
         self._hist = bool(train) or extra_rows > 0 or (auto if self.eval_history is None else bool(self.eval_history))
-        self.states = z(T + 1 if self._hist else 2, f_tot, ld)
+        # (+ one row of ONES behind every period's block: with the bias as row K of the transposed first-layer weights the bias is one
+        # more term of the first layer's contraction - the streamed first-layer forward then issues no bias loads, see _launch_forward)
+        self.states = z(T + 1 if self._hist else 2, f_tot + 1, ld)
+        self.states[:, f_tot] = 1.0
         self.orders = z(T if self._hist else 1, n_ord, ld)
         self.rewards = z(T, ld)
         self.logits = z(T if self._hist else 1, dims[-1], ld)
@@ -269,7 +272,7 @@ class FusedRollout:
         self.hidden = [z(keep, dims[i + 1], ld) for i in range(L - 1)]
         # engine copies of the weights: rows padded to a multiple of 32 floats so every A-tile load is a float4
         self.Wp = [z(gd[i + 1], _pad32(gd[i])) for i in range(L)]
-        self.Wt = [z(gd[i], _pad32(gd[i + 1])) for i in range(L)]
+        self.Wt = [z(gd[i] + (1 if i == 0 else 0), _pad32(gd[i + 1])) for i in range(L)]   # (layer 0: + the bias row, see above)
         self.Zc = z(gd[-1], ld) if self.live_rows is not None else None
         self.bias_c = z(gd[-1]) if self.live_rows is not None else None
         if train:
@@ -404,13 +407,15 @@ class FusedRollout:
         for i, m in enumerate(lins):
             w = m.weight.detach() if (rows is None or i < L - 1) else m.weight.detach()[rows]
             self.Wp[i][:, :self.gd[i]].copy_(w)
-            self.Wt[i][:, :self.gd[i + 1]].copy_(w.t())
+            self.Wt[i][:self.gd[i], :self.gd[i + 1]].copy_(w.t())
         biases = [m.bias.detach() if m.bias is not None else None for m in lins]
+        if biases[0] is not None:
+            self.Wt[0][self.gd[0], :self.gd[1]].copy_(biases[0])
         if rows is not None and biases[-1] is not None:   # (an engine-owned buffer: a captured graph holds its address)
             torch.index_select(biases[-1], 0, rows, out=self.bias_c)
             biases[-1] = self.bias_c
         Wv = [self.Wp[i][:, :self.gd[i]] for i in range(L)]
-        Wtv = [self.Wt[i][:, :self.gd[i + 1]] for i in range(L)]
+        Wtv = [self.Wt[i][:self.gd[i], :self.gd[i + 1]] for i in range(L)]
 
         # initial state
         s0 = self._views(self.states[0], prob)
@@ -603,6 +608,9 @@ class FusedRollout:
         hist = self._hist
         self._thin_in = (self.use_thin and L > 1 and biases[0] is not None and ops.linear_fwd_thin_in_ok(self.gd[1], self.gd[0])
                          and 4 * self.gd[1] * ld < 2 ** 31)
+        # the ones row sits right behind the MLP's input rows when the input IS the whole state block (every head of this engine)
+        self._thin_in_aug = (self._thin_in and self.F + 1 == self.states.shape[1]
+                             and ops.linear_fwd_thin_in_ok(self.gd[1], self.gd[0] + 1))
         for t in range(T):
             cur, nxt, row = (t, t + 1, t) if hist else (t & 1, (t + 1) & 1, 0)
             st = self._views(self.states[cur], prob)
@@ -610,7 +618,10 @@ class FusedRollout:
             hs = t if train else 0
             for i in range(L - 1):
                 y = self.hidden[i][hs]
-                if i == 0 and self._thin_in:   # short contraction, many rows: the write-bound streamed forward (thin_layer.hip)
+                if i == 0 and self._thin_in and self._thin_in_aug:   # ... with the bias inside the contraction: K + 1 rows, no bias
+                    self._k(f"fwd_{self.gd[1]}x{self.gd[0]}", ops.linear_fwd_thin_in, self.Wt[0][:self.F + 1, :self.gd[1]], None,
+                            self.states[cur][:self.F + 1], y, B, _lib.NIC_ACT_ELU)
+                elif i == 0 and self._thin_in:   # short contraction, many rows: the write-bound streamed forward (thin_layer.hip)
                     self._k(f"fwd_{self.gd[1]}x{self.gd[0]}", ops.linear_fwd_thin_in, Wtv[0], biases[0], x, y, B, _lib.NIC_ACT_ELU)
                 else:
                     self._k(f"fwd_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_fwd, Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)

@@ -122,6 +122,21 @@ def test_linear_fwd_thin_in_equals_the_tiled_forward(N, K, B):
             else:
                 torch.testing.assert_close(got[:, :n4], want[:, :n4], rtol=2e-6, atol=2e-6)
             assert bool(torch.isnan(got[:, n4:]).all())
+    if K + 1 <= 52:
+        # round 4, what the rollout engine does: the bias as row K of the transposed weights against a row of ONES behind the
+        # input's K rows, no bias argument (no bias loads in the kernel: nothing younger than the previous block's stores)
+        Xa = torch.cat([X, torch.ones(1, ldb, device=dev)], dim=0)
+        Wta = torch.zeros(K + 1, Wt.shape[1], device=dev)
+        Wta[:K] = Wt
+        Wta[K, :N] = bias
+        want = torch.full((N, ldb), float("nan"), device=dev)
+        got = torch.full((N, ldb), float("nan"), device=dev)
+        ops.linear_fwd_thin_in(Wt[:, :N], bias, X, want, B, _lib.NIC_ACT_ELU)
+        ops.linear_fwd_thin_in(Wta[:, :N], None, Xa, got, B, _lib.NIC_ACT_ELU)
+        torch.cuda.synchronize()
+        n4 = (B + 3) // 4 * 4
+        torch.testing.assert_close(got[:, :n4], want[:, :n4], rtol=2e-6, atol=2e-6)
+        assert bool(torch.isnan(got[:, n4:]).all())
     W64, X64 = W.double().cpu(), X.double().cpu()[:, :B]
     pre = W64 @ X64 + bias.double().cpu()[:, None]
     Y = torch.zeros(N, ldb, device=dev)
