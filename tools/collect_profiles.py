@@ -82,6 +82,9 @@ def note_name(k):
     m = re.match(r"(gemm_wgrad_dma_kernel<\d+, \d+, \d+, \d+), (true|false)>", k)
     if m:
         return (m.group(1) + (",skip>" if m.group(2) == "true" else ">")).replace(" ", "")
+    m = re.match(r"thin_in_fwd_kernel<(\d+), (?:true|false)>", k)
+    if m:
+        return "thin_in_fwd_kernel<%s>" % m.group(1)
     m = re.match(r"(gemm_wx_stream_kernel<\d+, \d+), (\d)>", k)
     if m:
         return (m.group(1) + "," + {"0": "EPI_BIAS_ACT", "1": "EPI_DGRAD"}.get(m.group(2), m.group(2)) + ">").replace(" ", "")
