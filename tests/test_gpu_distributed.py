@@ -114,6 +114,37 @@ def test_bench_line_contract(workload):
     assert cb["unit"] == out["unit"]
 
 
+def test_bench_strong_and_weak_scaling_over_ranks_sharing_the_gpu():
+    """`bench.py --gpus N --scaling strong|weak` under a launcher (round 4; ranks share the test box's one GPU, collectives over
+    gloo - timings are meaningless, the SHARDING is what is checked): strong = the scenario count in total, split over the ranks;
+    weak = per rank.  The first step's mean cost depends only on the global scenario set (sharded generation is keyed by the
+    global scenario index), so 4 x 4,096 strong == 2 x 8,192 strong == 1 x 16,384, and weak 4 x 4,096 == the same 16,384."""
+    root = os.path.dirname(HERE)
+
+    def run(n, extra):
+        cmd = [sys.executable]
+        if n > 1:
+            cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                    "--master-port", str(29560 + n)]
+        cmd += [os.path.join(root, "bench.py"), "--gpus", str(n), "--workload", "cfg3", "--periods", "12", "--steps", "1", "--warmup", "0",
+                "--no-cpu-baseline", "--no-kernel-timing"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, NIC_DIST_BACKEND="gloo"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    one = run(1, ["--scenarios", "16384"])
+    outs = {"strong2": run(2, ["--scenarios", "16384", "--scaling", "strong"]),
+            "strong4": run(4, ["--scenarios", "16384", "--scaling", "strong"]),
+            "weak4": run(4, ["--scenarios", "4096"])}
+    for k, o in outs.items():
+        n = int(k[-1])
+        assert o["n_gpus"] == n and o["scaling"] == k[:-1] and o["config"]["global_scenarios"] == 16384
+        assert o["config"]["scenarios_per_gpu"] == 16384 // n
+        a, b = o["config"]["mean_cost_per_store_period"], one["config"]["mean_cost_per_store_period"]
+        assert abs(a - b) <= 1e-6 * abs(b), (k, a, b)
+        assert abs(o["value"] - 16384 * 16 * 12 / (o["ms_per_step"] * 1e-3)) <= 1e-6 * o["value"]
+
+
 def test_bench_epoch_workload_line():
     """`bench.py --workload cfg3_yaml`: the reference's shipped YAML pair through Trainer.do_one_epoch (8,192 samples, batches of
     1,024 x 50 periods).  One JSON line with the driver's keys; a step is one batch; the epoch is also reported eager / replayed
