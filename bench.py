@@ -219,9 +219,9 @@ def algorithmic_work(tag, kernel, shape):
     input rows), nh (hidden layers of the small route), n_out, train.  DESIGN.md §4 states the same formulas."""
     n, T = shape["n"], shape["T"]
     kind, _, dims = tag.partition("_")
-    if kind in ("fwd", "dgrad", "wgrad", "wgradT") and "x" in dims and dims.replace("x", "").isdigit():
+    if kind in ("fwd", "fwdT", "dgrad", "wgrad", "wgradT") and "x" in dims and dims.replace("x", "").isdigit():
         N, K = (int(v) for v in dims.split("x"))
-        cols = n * (T if kind == "wgradT" else 1)
+        cols = n * (T if kind in ("wgradT", "fwdT") else 1)   # (..T: one launch over all (period x scenario) columns)
         if kernel.startswith("wgrad_small_kernel"):   # small route: one launch contracts over all T * ldb columns
             return "hbm", 4.0 * (N + K) * n * T, "B"  # operands read once (dZ [N] + X [K] rows per column)
         # A layer's GEMM streams its two activation operands once (N + K rows per column; the dgrad epilogue also reads the
@@ -265,6 +265,16 @@ def algorithmic_work(tag, kernel, shape):
     if tag == "small_rollout_bwd":  # history + demand in (weight gradients stay in registers; the first version also wrote dZ)
         dz = 0 if "wgrad" in kernel else 32 * shape["nh"] + shape["n_out"]
         return "hbm", 4.0 * (1 + hist + dz) * n * T, "B"
+    if tag in ("horizon_fwd", "horizon_bwd"):
+        # whole-horizon data_driven kernels (csrc/horizon_rollout.hip).  Forward: the observation rows' share of the first layer
+        # and the demand in; reward and the histories out (state rows, two hidden activations, logits, orders).  Backward: the
+        # histories and the demand in, the three pre-activation gradients out.  (A latency-bound chain on n / 16 CUs: the
+        # fraction of the HBM roofline is reported for completeness, microseconds per period is the figure of merit.)
+        h1, h2, no = shape["hidden"][0], shape["hidden"][1], shape["n_out"]
+        hist_rows = f_state + h1 + h2 + no + n_ord
+        if tag == "horizon_fwd":
+            return "hbm", 4.0 * (h1 + S + 1 + (hist_rows if shape["train"] else 0)) * n * T, "B"
+        return "hbm", 4.0 * (hist_rows + S + h1 + h2 + no) * n * T, "B"
     if tag == "closed_form_fwd":  # whole-horizon closed-form policy: the demand trace + one state load / store + totals
         return "hbm", 4.0 * (S * T + 2 * f_state + 2 * S) * n, "B"
     return None
@@ -578,7 +588,8 @@ def main():
     if args.launch_order_out and eng is not None:
         timer = eng.timer = KernelTimer(record_order=True)
     elif not args.no_kernel_timing:
-        stride = args.timing_stride or (1 if (closed_form or (not gnn and eng.small is not None)) else (10 if gnn else 40))
+        whole = closed_form or (not gnn and (eng.small is not None or getattr(eng, "horizon", None) is not None))
+        stride = args.timing_stride or (1 if whole else (10 if gnn else 40))
         timer = eng.timer = KernelTimer(stride=stride)
     if sharded:
         torch.distributed.barrier()
@@ -613,7 +624,9 @@ def main():
                        "route": ("generic (Simulator.step + autograd)" if eng is None else
                                  "whole-horizon closed-form kernel (forward-mode gradient)" if closed_form else
                                  "per-period fused gather-MLP kernels over the static supply graph" if gnn else
-                                 "whole-horizon kernels" if eng.small is not None else "per-period kernels"),
+                                 "whole-horizon kernels" if eng.small is not None else
+                                 "whole-horizon kernels (16 scenarios per workgroup) + (period x scenario) GEMMs"
+                                 if getattr(eng, "horizon", None) is not None else "per-period kernels"),
                        "mean_cost_per_store_period": loss},
         }
         if timer is not None and timer.order is not None:
@@ -626,6 +639,7 @@ def main():
                          We=data["initial_echelon_inventories"].shape[2] if E_ else 0,
                          F=0 if (closed_form or gnn) else eng.dims[0], nh=0 if (closed_form or gnn) else len(eng.dims) - 2,
                          n_out=0 if (closed_form or gnn) else eng.dims[-1], train=not args.eval,
+                         hidden=[] if (closed_form or gnn) else list(eng.dims[1:-1]),
                          gnn={m.name: (m.K, m.n_out, m.n_live, getattr(m, "fold_rows", 0)) for m in eng.mlp.values()} if gnn else None)
             kernels = kernel_report(timer, shape, args.steps)
             rated = {k: v for k, v in kernels.items() if "bound" in v}

@@ -318,6 +318,52 @@ int nic_closed_form_num_partials(int32_t n_scenarios, int32_t S);
 int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
                             float* g_levels_partial, void* stream);
 
+/* ---- whole-horizon rollout of the data_driven policy for small batches (csrc/horizon_rollout.hip) --------------------
+ * The reference trains DataDrivenNet (neural_networks.py:430-515, data_driven_net.yml: two 64-wide hidden layers) on batches of
+ * 72 products x 21 stores x 3 warehouses x 95 weeks (many_warehouses_real_data_lost_demand.yml:44-47): per period that is a
+ * handful of workgroups, and Trainer.simulate_batch's loop (trainer.py:190-213) becomes ~1,050 dependent launches per training
+ * step.  These two entry points run ALL periods in one launch each: a workgroup owns 16 scenarios for the whole horizon, weights
+ * stay in registers as MFMA fragments, state / logits / orders / static tables in LDS, head and env step are the per-period
+ * kernels' own bodies.  The first layer is split: its contraction with the OBSERVATION rows of the input (past demands, costs,
+ * days from christmas, lead times - independent of the rollout) is done by the caller for all periods with one nic_linear_fwd
+ * over T * ldb columns (z1_obs, bias included); the kernel contracts the state rows per period.
+ * Every history buffer holds element (row, t, b) at row * hist_stride + t * ldb + b, so that the weight gradients are plain
+ * nic_linear_wgrad contractions over n_scenarios = T * ldb columns (padding columns of the dz histories are never written:
+ * zero them once).  Supported: no extra echelons, <= 64 stores, pipelines of 2..8 slots, <= 256 state rows, hidden widths <= 64,
+ * n_out = Wn + S*Wn (S when Wn == 0) <= 128 (nic_horizon_rollout_ok). */
+typedef struct NicHorizonDesc {
+    NicEnvStepIO io;            /* dims + static tables; store_inv / wh_inv / ech_inv / demand / *_orders members are ignored */
+    int32_t T, t0;              /* periods; observation_params['demand']['period_shift'] */
+    int32_t H1, H2, n_out;      /* hidden widths; logits rows [Wn warehouse orders | S x Wn store orders] */
+    int32_t round_orders;       /* discrete allocation (trainer.py:201-202); forward / evaluation only */
+    const float* W1;            /* [H1][ldw1]: first-layer weights; columns 0 .. S*Ws + Wn*Ww - 1 multiply the state rows */
+    int64_t ldw1;
+    const float* W2;            /* [H2][ldw2] */
+    int64_t ldw2;
+    const float* W3;            /* [n_out][ldw3] */
+    int64_t ldw3;
+    const float* b2;
+    const float* b3;
+    const float* mask;          /* [S][Wn] adjacency (1 = edge) as nic_head_data_driven_fwd takes it; NULL when Wn == 0 */
+    const float* demand;        /* [>= t0 + T][S][ldb] */
+    int64_t hist_stride;        /* elements between consecutive rows of z1_obs and of every history (>= T * ldb) */
+} NicHorizonDesc;
+/* 1 if the two kernels take this shape (sizes above, LDS budget), else 0 (nic_last_error says why). */
+int nic_horizon_rollout_ok(const NicHorizonDesc* d);
+/* Forward: z1_obs [H1][T][ldb] = first-layer pre-activations from the observation rows + bias; state0 [F_dyn][ldb] (store
+ * pipelines, then warehouse pipelines: the reference's cat order).  rewards [T][ldb], state_final [F_dyn][ldb] (may be NULL).
+ * With state_hist != NULL the histories the backward needs are written: state_hist [F_dyn][T][ldb] (state BEFORE period t),
+ * h1_hist / h2_hist (post-ELU), logits_hist [n_out][T][ldb], orders_hist [S*max(Wn,1) + Wn + Wn][T][ldb] (the orders, then
+ * what every warehouse shipped: the backward does not re-sum the orders). */
+int nic_horizon_rollout_fwd(const NicHorizonDesc* d, const float* z1_obs, const float* state0, float* rewards, float* state_final,
+                            float* state_hist, float* h1_hist, float* h2_hist, float* logits_hist, float* orders_hist,
+                            void* stream);
+/* Backward over the stored histories; g_reward (b) = d loss / d reward[b, t] (the same for every t).  Writes the pre-activation
+ * gradients dz1_hist [H1][T][ldb], dz2_hist [H2][T][ldb], dz3_hist [n_out][T][ldb] (live columns only). */
+int nic_horizon_rollout_bwd(const NicHorizonDesc* d, const float* state_hist, const float* h1_hist, const float* h2_hist,
+                            const float* logits_hist, const float* orders_hist, NicTable2 g_reward, float* dz1_hist,
+                            float* dz2_hist, float* dz3_hist, void* stream);
+
 /* ---- fused three-layer 32-wide MLP over gathered inputs (graph policies) -----------------------------------------
  * The GNN policy (neural_networks.py:742-1492) applies five small MLPs (`gnn.yml`: K -> 32 -> 32 -> 32 or 1, ELU inside) to
  * every node / edge of the supply graph of every scenario, on inputs that are concatenations of gathered node / edge

@@ -57,6 +57,13 @@ class NicSmallRolloutDesc(C.Structure):
                                             "ech_holding", "ech_lead")])
 
 
+class NicHorizonDesc(C.Structure):
+    _fields_ = ([("io", NicEnvStepIO)] + [(n, C.c_int32) for n in ("T", "t0", "H1", "H2", "n_out", "round_orders")]
+                + [("W1", C.c_void_p), ("ldw1", C.c_int64), ("W2", C.c_void_p), ("ldw2", C.c_int64), ("W3", C.c_void_p),
+                   ("ldw3", C.c_int64), ("b2", C.c_void_p), ("b3", C.c_void_p), ("mask", C.c_void_p), ("demand", C.c_void_p),
+                   ("hist_stride", C.c_int64)])
+
+
 class NicClosedFormDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in (
         "n_scenarios", "ldb", "T", "t0", "ignore_periods", "policy", "n_levels", "S", "Ws", "Wn", "Ww", "E", "We",
@@ -124,6 +131,9 @@ PROTOTYPES = {
     "nic_small_rollout_bwd": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, NicTable2, _vp, _vp, _vp]),
     "nic_small_rollout_bwd_wgrad_slots": (C.c_int, [C.c_int32]),
     "nic_small_rollout_bwd_wgrad": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, NicTable2, _vp, _i64, _vp]),
+    "nic_horizon_rollout_ok": (C.c_int, [C.POINTER(NicHorizonDesc)]),
+    "nic_horizon_rollout_fwd": (C.c_int, [C.POINTER(NicHorizonDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nic_horizon_rollout_bwd": (C.c_int, [C.POINTER(NicHorizonDesc), _vp, _vp, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp]),
     "nic_round_orders": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "nic_mlp3_fwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp]),
     "nic_mlp3_fwd_residual": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -22,6 +22,7 @@ SOURCES = [
     ("small_rollout.hip", ["-ffp-contract=off"]),
     ("small_rollout16.hip", ["-ffp-contract=off"]),
     ("closed_form.hip", ["-ffp-contract=off"]),
+    ("horizon_rollout.hip", ["-ffp-contract=off"]),
     ("mlp3.hip", []),
 ]
 HEADERS = ["nic_common.h", "env_step_body.h", "policy_heads_body.h", "small_rollout_body.h", "small_rollout16.h", "closed_form_body.h", os.path.join("..", "..", "include", "nic_rollout.h")]

@@ -167,6 +167,43 @@ NIC_HD float env_fwd_stores(const NicEnvStepIO& io, float* store_out, int64_t b,
     return r;
 }
 
+// ONE store: the same arithmetic as a store of env_fwd_stores' batches (cost, lost-demand clip, pipeline shift, order placement).
+// For kernels that give every (scenario, store) pair its own lane (csrc/horizon_rollout.hip: the state sits in LDS, the chain of a
+// lane is what matters, not the number of loads in flight).  Returns the store's cost.
+template <int MAXW>
+NIC_HD float env_fwd_one_store(const NicEnvStepIO& io, float* store_out, int64_t b, int s) {
+    const NicEnvDims& d = io.dims;
+    const int64_t ldb = d.ldb;
+    const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
+    float old[MAXW], nv[MAXW], ord[kSupBatch], lead[kSupBatch];
+    load_pipeline<MAXW>(io.store_inv + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, old);
+    const float dem = t2(io.demand, s, b), p = t2(io.underage, s, b), h = t2(io.holding, s, b);
+#pragma unroll
+    for (int w = 0; w < kSupBatch; ++w) {
+        if (w < nsup) {
+            ord[w] = t3(io.store_orders, s, w, b);
+            lead[w] = t3(io.lead_times, s, w, b);
+        }
+    }
+    const float on_hand = old[0];
+    float after = on_hand - dem;
+    float c;
+    if (d.maximize_profit) {
+        c = (-p) * (on_hand < dem ? on_hand : dem) + h * relu(after);  // :191-194
+    } else {
+        c = p * relu(-after) + h * relu(after);  // :198-201
+    }
+    if (d.lost_demand) after = relu(after);  // :204-205
+    shift_loaded<MAXW>(old, d.store_slots, after, nv);
+#pragma unroll
+    for (int w = 0; w < kSupBatch; ++w)
+        if (w < nsup) place_order<MAXW>(nv, d.store_slots, ord[w], lead[w]);
+    for (int w = kSupBatch; w < nsup; ++w)
+        place_order<MAXW>(nv, d.store_slots, t3(io.store_orders, s, w, b), t3(io.lead_times, s, w, b));
+    store_pipeline<MAXW>(store_out + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, nv);
+    return c;
+}
+
 // this lane's share of what warehouse w ships: sum of the orders of stores s = q, q+4, ...   (:247)
 // The loads of a batch are issued together and then added in the same order as before: written as `a += load` in a loop with a
 // run-time trip count the compiler waits for each load before issuing the next (ISA: load, s_waitcnt vmcnt(0), add, branch) -
@@ -398,6 +435,66 @@ NIC_HD void env_bwd_stores(const NicEnvStepIO& io, const float* g_store_out, flo
             }
         }
     }
+}
+
+// ONE store of env_bwd_stores (same arithmetic; see env_fwd_one_store)
+template <int MAXW, typename GWAfter>
+NIC_HD void env_bwd_one_store(const NicEnvStepIO& io, const float* g_store_out, float gr, GWAfter g_wafter, float* g_store_in,
+                              float* g_store_orders, int64_t b, int s) {
+    const NicEnvDims& d = io.dims;
+    const int64_t ldb = d.ldb;
+    const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
+    float gn[MAXW], ord[kSupBatch], lead[kSupBatch];
+    const float on_hand = io.store_inv[(int64_t)s * d.store_slots * ldb + b];
+    const float dem = t2(io.demand, s, b), p = t2(io.underage, s, b), h = t2(io.holding, s, b);
+#pragma unroll
+    for (int w = 0; w < kSupBatch; ++w) {
+        if (w < nsup) {
+            ord[w] = t3(io.store_orders, s, w, b);
+            lead[w] = t3(io.lead_times, s, w, b);
+        }
+    }
+    load_grad<MAXW>(g_store_out ? g_store_out + (int64_t)s * d.store_slots * ldb + b : nullptr, ldb, d.store_slots, gn);
+    const float after = on_hand - dem;
+    float g_after = gn[0];
+    if (d.lost_demand && !(after >= 0.f)) g_after = 0.f;
+    float g_on_hand;
+    if (d.maximize_profit) {
+        if (after >= 0.f) g_after += gr * h;
+        const float share = on_hand < dem ? 1.f : (on_hand == dem ? 0.5f : 0.f);  // minimum() tie rule
+        g_on_hand = g_after + gr * (-p) * share;
+    } else {
+        float gc = 0.f;
+        if (-after >= 0.f) gc += -p;
+        if (after >= 0.f) gc += h;
+        g_on_hand = g_after + gr * gc;
+    }
+    store_pipeline_grad<MAXW>(g_store_in + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, gn, g_on_hand);
+#pragma unroll
+    for (int w = 0; w < kSupBatch; ++w) {
+        if (w < nsup) {
+            float ga = (ord[w] != 0.f) ? pick<MAXW>(gn, d.store_slots, (int)lead[w] - 1) : 0.f;
+            if (d.n_warehouses > 0) ga += -g_wafter(w);
+            g_store_orders[((int64_t)s * nsup + w) * ldb + b] = ga;
+        }
+    }
+    for (int w = kSupBatch; w < nsup; ++w) {
+        const float a = t3(io.store_orders, s, w, b);
+        float ga = (a != 0.f) ? pick<MAXW>(gn, d.store_slots, (int)t3(io.lead_times, s, w, b) - 1) : 0.f;
+        if (d.n_warehouses > 0) ga += -g_wafter(w);
+        g_store_orders[((int64_t)s * nsup + w) * ldb + b] = ga;
+    }
+}
+
+// gradient of warehouse w's post-shipping on-hand (what env_bwd_warehouse returns), without its side effects: lets every store
+// lane of a fused kernel compute it for itself instead of waiting for the warehouse lanes
+NIC_HD float env_bwd_wh_g_after(const NicEnvStepIO& io, const float* g_wh_out, float gr, int w, float shipped, int64_t b) {
+    const NicEnvDims& d = io.dims;
+    const int64_t ldb = d.ldb;
+    const float after = io.wh_inv[(int64_t)w * d.warehouse_slots * ldb + b] - shipped;
+    float g_after = g_wh_out ? g_wh_out[(int64_t)w * d.warehouse_slots * ldb + b] : 0.f;
+    if (after >= 0.f) g_after += gr * t2(io.wh_holding, w, b);
+    return g_after;
 }
 
 // reference composition for one scenario (host-side test build)

@@ -109,15 +109,7 @@ __global__ void head_data_driven_fwd_kernel(const float* __restrict__ Z, const f
         for (int s = 0; s < S; ++s) so[(int64_t)s * ldb + b] = fmaxf(Z[(int64_t)s * ldb + b], 0.f);
         return;
     }
-    const int w = blockIdx.y;
-    wo[(int64_t)w * ldb + b] = fmaxf(Z[(int64_t)w * ldb + b], 0.f);
-    float avail = 0.f;
-    for (int k = 0; k < Ww; ++k) avail += wh[((int64_t)w * Ww + k) * ldb + b];
-    float sum = 0.f;
-    for (int s = 0; s < S; ++s) sum += fmaxf(Z[(int64_t)(Wn + s * Wn + w) * ldb + b], 0.f) * mask[s * Wn + w];
-    const float sc = fminf(avail / (sum + 1e-10f), 1.f);
-    for (int s = 0; s < S; ++s)
-        so[(int64_t)(s * Wn + w) * ldb + b] = fmaxf(Z[(int64_t)(Wn + s * Wn + w) * ldb + b], 0.f) * mask[s * Wn + w] * sc;
+    nic::head_data_driven_fwd_one(Z, wh, mask, so, wo, S, Wn, Ww, ldb, b, blockIdx.y);
 }
 
 // adjoint: dZ (every row written) and g_wh[w][k][b] += d(scale) / (sum + eps) for every slot k of the pipeline
@@ -131,27 +123,7 @@ __global__ void head_data_driven_bwd_kernel(const float* __restrict__ Z, const f
         for (int s = 0; s < S; ++s) dZ[(int64_t)s * ldb + b] = Z[(int64_t)s * ldb + b] > 0.f ? g_so[(int64_t)s * ldb + b] : 0.f;
         return;
     }
-    const int w = blockIdx.y;
-    dZ[(int64_t)w * ldb + b] = Z[(int64_t)w * ldb + b] > 0.f ? g_wo[(int64_t)w * ldb + b] : 0.f;
-    float avail = 0.f;
-    for (int k = 0; k < Ww; ++k) avail += wh[((int64_t)w * Ww + k) * ldb + b];
-    float sum = 0.f, dot = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float a = fmaxf(Z[(int64_t)(Wn + s * Wn + w) * ldb + b], 0.f) * mask[s * Wn + w];
-        sum += a;
-        dot += g_so[(int64_t)(s * Wn + w) * ldb + b] * a;
-    }
-    const float den = sum + 1e-10f, ratio = avail / den;
-    const float sc = fminf(ratio, 1.f);
-    const float d_scale = ratio <= 1.f ? dot : 0.f;          // torch.clip(max = 1) passes the gradient where ratio <= 1
-    const float common = -(d_scale * avail / (den * den));
-    for (int s = 0; s < S; ++s) {
-        const int64_t row = (int64_t)(Wn + s * Wn + w) * ldb + b;
-        const float da = g_so[(int64_t)(s * Wn + w) * ldb + b] * sc + common;
-        dZ[row] = Z[row] > 0.f ? da * mask[s * Wn + w] : 0.f;
-    }
-    const float g_av = d_scale / den;
-    for (int k = 0; k < Ww; ++k) g_wh[((int64_t)w * Ww + k) * ldb + b] += g_av;
+    nic::head_data_driven_bwd_one(Z, wh, mask, g_so, g_wo, dZ, g_wh, S, Wn, Ww, ldb, b, blockIdx.y);
 }
 
 __global__ void head_softplus_fwd_kernel(const float* __restrict__ Z, float* __restrict__ o, int rows, int B, int64_t ldb) {

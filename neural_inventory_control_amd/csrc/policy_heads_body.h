@@ -391,4 +391,97 @@ NIC_HD void head_serial_bwd_scenario(const float* Z, const float* wh_inv, const 
     }
 }
 
+// data_driven head (DataDrivenNet.forward, neural_networks.py:474-515 + apply_proportional_allocation :111-138), one (scenario,
+// warehouse): Z rows = [Wn warehouse orders | S x Wn store orders (store-major)] BEFORE the output ReLU; mask [S][Wn] = adjacency.
+// out = relu(Z); the warehouse's own order passes through; its store orders are masked, summed in store order and scaled by
+// min(1, pipeline total of the warehouse / (sum + 1e-10)).  Loads in batches of kHeadBatch ahead of the (serial, store-ordered)
+// arithmetic, as in the vanilla head above.
+NIC_HD void head_data_driven_fwd_one(const float* Z, const float* wh, const float* mask, float* so, float* wo, int S, int Wn,
+                                     int Ww, int64_t ldb, int64_t b, int w) {
+    wo[(int64_t)w * ldb + b] = fmaxf(Z[(int64_t)w * ldb + b], 0.f);
+    float avail = 0.f;
+    for (int k = 0; k < Ww; ++k) avail += wh[((int64_t)w * Ww + k) * ldb + b];
+    const float* Zw = Z + (int64_t)(Wn + w) * ldb + b;   // row Wn + s*Wn + w -> Zw[s * rs]
+    const int64_t rs = (int64_t)Wn * ldb;
+    float sum = 0.f;
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch], mk[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            mk[u] = mask[s * Wn + w];
+        }
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (s0 + u < S) sum += fmaxf(z[u], 0.f) * mk[u];
+    }
+    const float sc = fminf(avail / (sum + 1e-10f), 1.f);
+    float* ow = so + (int64_t)w * ldb + b;
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch], mk[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            mk[u] = mask[s * Wn + w];
+        }
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (s0 + u < S) ow[(s0 + u) * rs] = fmaxf(z[u], 0.f) * mk[u] * sc;
+    }
+}
+
+// adjoint: dZ (every row of this warehouse written) and g_wh[w][k][b] += d(scale) / (sum + eps) for every slot k of the pipeline
+NIC_HD void head_data_driven_bwd_one(const float* Z, const float* wh, const float* mask, const float* g_so, const float* g_wo,
+                                     float* dZ, float* g_wh, int S, int Wn, int Ww, int64_t ldb, int64_t b, int w) {
+    dZ[(int64_t)w * ldb + b] = Z[(int64_t)w * ldb + b] > 0.f ? g_wo[(int64_t)w * ldb + b] : 0.f;
+    float avail = 0.f;
+    for (int k = 0; k < Ww; ++k) avail += wh[((int64_t)w * Ww + k) * ldb + b];
+    const float* Zw = Z + (int64_t)(Wn + w) * ldb + b;
+    const float* gw = g_so + (int64_t)w * ldb + b;
+    float* dZw = dZ + (int64_t)(Wn + w) * ldb + b;
+    const int64_t rs = (int64_t)Wn * ldb;
+    float sum = 0.f, dot = 0.f;
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch], mk[kHeadBatch], gs[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            mk[u] = mask[s * Wn + w];
+            gs[u] = gw[s * rs];
+        }
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (s0 + u < S) {
+                const float a = fmaxf(z[u], 0.f) * mk[u];
+                sum += a;
+                dot += gs[u] * a;
+            }
+    }
+    const float den = sum + 1e-10f, ratio = avail / den;
+    const float sc = fminf(ratio, 1.f);
+    const float d_scale = ratio <= 1.f ? dot : 0.f;          // torch.clip(max = 1) passes the gradient where ratio <= 1
+    const float common = -(d_scale * avail / (den * den));
+    for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
+        float z[kHeadBatch], mk[kHeadBatch], gs[kHeadBatch];
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const int s = s0 + u < S ? s0 + u : S - 1;
+            z[u] = Zw[s * rs];
+            mk[u] = mask[s * Wn + w];
+            gs[u] = gw[s * rs];
+        }
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u)
+            if (s0 + u < S) {
+                const float da = gs[u] * sc + common;
+                dZw[(s0 + u) * rs] = z[u] > 0.f ? da * mk[u] : 0.f;
+            }
+    }
+    const float g_av = d_scale / den;
+    for (int k = 0; k < Ww; ++k) g_wh[((int64_t)w * Ww + k) * ldb + b] += g_av;
+}
+
 }  // namespace nic

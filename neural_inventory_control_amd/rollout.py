@@ -21,6 +21,7 @@ transfers are the two scalars the trainer reports.
 import torch
 
 from . import _lib, ops
+from . import horizon_rollout as hz
 from . import small_rollout as sr
 from .layout import EnvProblem, ProblemCache, Table, pad_ld
 from .ops import EnvState
@@ -135,6 +136,11 @@ class FusedRollout:
         self.use_thin = True    # fused backward of thin (<= 32 rows) output layers (csrc/thin_layer.hip)
         self.batch_wgrad = True  # hidden-layer weight gradients contracted over all periods in one launch
         self.fuse_head_env = True  # vanilla_warehouse: head + env step (and their adjoints) in one launch each (csrc/head_env.hip)
+        # data_driven on small batches (what the reference trains it on: 72 products): all periods in ONE forward and ONE backward
+        # launch (csrc/horizon_rollout.hip) while the batch gives every workgroup of 16 scenarios its own CU a few times over
+        self.use_horizon = True
+        self.horizon_max_scenarios = 8192
+        self.horizon = None     # HorizonPlan when the current shapes take that route
         self.eval_history = None  # evaluation keeps per-period states/orders/logits: None = while small, True / False = forced
         self.small = None       # SmallRolloutPlan when the current shapes take that route
         self._prob_cache = ProblemCache()
@@ -186,14 +192,15 @@ class FusedRollout:
 
     def _setup(self, prob, T, train, extra_rows=0):
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin,
-               self.eval_history, self.small_wgrad_in_kernel, extra_rows, self.small_lane_scenarios)
+               self.eval_history, self.small_wgrad_in_kernel, extra_rows, self.small_lane_scenarios, self.use_horizon,
+               self.horizon_max_scenarios)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
         self._prob = None
         self._auto_graph = None   # (a new shape is measured afresh)
         for name in ("states", "orders", "logits", "hidden", "dZhist", "dZlast_hist", "dH", "slabs", "sr_states", "sr_hidden",
-                     "sr_logits", "sr_dzh", "sr_dzo", "sr_slab", "sr_grad"):
+                     "sr_logits", "sr_dzh", "sr_dzo", "sr_slab", "sr_grad", "hz_X", "hz_z1", "hz_hist", "hz_dz"):
             setattr(self, name, None)  # release the previous shapes' buffers before sizing the new ones
         self.F_store, self.F_wh, self.F_ech = prob.S * prob.Ws, prob.Wn * prob.Ww, prob.E * prob.We
         F = self.F_store + self.F_wh + self.F_ech
@@ -238,6 +245,34 @@ class FusedRollout:
                     self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
                     self.gw = [torch.zeros_like(m.weight) for m in lins]
                     self.gb = [torch.zeros_like(m.bias) for m in lins]
+            self._key = key
+            return
+        self.horizon = None
+        if (self.use_horizon and extra_rows > 0 and prob.B <= self.horizon_max_scenarios and all(m.bias is not None for m in lins)
+                and hz.HorizonPlan.supports(prob, self.head, dims)):
+            # ---- whole-horizon route for data_driven: one forward kernel, one backward kernel, four GEMMs over (period x scenario)
+            # columns (the observation rows' share of the first layer; one weight gradient per layer).  Histories [row][T][ld].
+            plan = self.horizon = hz.HorizonPlan(prob, dims)
+            FD, Fo, n_cols = self.F_dyn, F - self.F_dyn, T * ld
+            self.rewards = z(T, ld)
+            self.hz_state0, self.hz_final = z(FD, ld), z(FD, ld)
+            self.hz_X = z(F, T, ld)               # rows [0, FD): state before period t (written by the kernel); then the observation rows
+            self.hz_z1 = z(dims[1], T, ld)
+            self.hz_W1obs = z(dims[1], _pad32(Fo))   # (rows padded to 32 floats: the GEMM's A-tile loads are float4)
+            if prob.Wn:
+                conn = self.problem_params["warehouse_store_adjacency"]
+                self.edge_mask = torch.tensor(conn, dtype=torch.float32, device=dev).t().contiguous()   # [S][Wn]
+            else:
+                self.edge_mask = None
+            if train:
+                self.hz_hist = [z(dims[1], T, ld), z(dims[2], T, ld), z(dims[3], T, ld), z(plan.n_ord + prob.Wn, T, ld)]  # h1, h2, logits, orders (+ shipped)
+                self.hz_dz = [z(dims[i + 1], T, ld) for i in range(L)]   # (padding columns stay zero: the kernel writes live ones only)
+                self.g_reward = z(ld)
+                self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], n_cols) for i in range(L)]
+                self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
+                self.gw = [torch.zeros_like(m.weight) for m in lins]
+                self.gb = [torch.zeros_like(m.bias) for m in lins]
+            self.demand_buf, self._graphs, self._eager_runs = None, {}, 0
             self._key = key
             return
         # Many-warehouse vanilla head: the logits of (store, warehouse) pairs without an edge are never read upstream
@@ -399,6 +434,9 @@ class FusedRollout:
         if self.small is not None:
             return self._run_small(data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale,
                                    accumulate_grads, assign_grads)
+        if self.horizon is not None:
+            return self._run_horizon(data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale,
+                                     accumulate_grads, assign_grads, observation_params)
 
         # engine copies of the weights (tiny) — refreshed every call because the optimizer moves them
         lins = self._linears()
@@ -479,6 +517,30 @@ class FusedRollout:
             rows += (S * observation_params["demand"]["past_periods"] + 2 * S + data["days_from_christmas"].shape[1]
                      + S * data["lead_times"].shape[2])
         return rows
+
+    def _fill_observation_rows_by_row(self, X, data, prob, T, B, ld, shift, observation_params, demand_soa):
+        """The same rows as `_fill_observation_rows` in the whole-horizon route's [row][T][ld] order (X: [F][T][ld])."""
+        S, P_ = prob.S, observation_params["demand"]["past_periods"]
+        o = self.F_dyn
+        n_t = demand_soa.shape[0]
+        if getattr(self, "_dpad", None) is None or self._dpad.shape != (P_ + n_t, S, ld):
+            self._dpad = torch.zeros(P_ + n_t, S, ld, device=self.device)
+        self._dpad[P_:].copy_(demand_soa)
+        # row (s, p) of period t = demand of period t + shift - P + p = padded row t + shift + p
+        win = self._dpad.as_strided((S, P_, T, ld), (ld, S * ld, S * ld, 1), shift * S * ld)
+        X[o:o + S * P_].view(S, P_, T, ld).copy_(win)
+        o += S * P_
+        for k in ("underage_costs", "holding_costs"):
+            X[o:o + S, :, :B] = data[k].t().unsqueeze(1)
+            o += S
+        dfc = data["days_from_christmas"]                      # [B][D][periods of the data]
+        D = dfc.shape[1]
+        idx = torch.clamp(torch.arange(T, device=self.device) + shift, max=dfc.shape[2] - 1)
+        X[o:o + D, :, :B] = dfc[:, :, idx].permute(1, 2, 0)
+        o += D
+        lt = data["lead_times"]                                 # [B][S][W]
+        X[o:o + lt.shape[1] * lt.shape[2], :, :B] = lt.reshape(B, -1).t().unsqueeze(1)
+        assert o + lt.shape[1] * lt.shape[2] == self.F
 
     def _fill_observation_rows(self, data, prob, T, B, ld, shift, observation_params, demand_soa):
         """data_driven: the observation rows behind the state rows of every period's input block, in the reference's
@@ -577,6 +639,45 @@ class FusedRollout:
             dy, x = dzs[i].reshape(dzs[i].shape[0], n_cols), inputs[i].reshape(inputs[i].shape[0], n_cols)
             self._k(f"wgrad_{self.dims[i + 1]}x{self.dims[i]}", ops.linear_wgrad, dy, x, self.slabs[i], n_cols)
             ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], self.dims[i], 1.0)
+        if assign_grads:
+            self._assign_grads(accumulate_grads)
+        return total, reported
+
+    # ---- whole-horizon route for data_driven on small batches ------------------------------------------------------------
+    def _run_horizon(self, data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale, accumulate_grads,
+                     assign_grads, observation_params):
+        plan, lins = self.horizon, self._linears()
+        F, FD, dims = self.F, self.F_dyn, self.dims
+        Fo, n_cols = F - FD, T * ld
+        a = self.F_store
+        self.hz_state0[:a].view(prob.S, prob.Ws, ld)[:, :, :B].copy_(data["initial_inventories"].permute(1, 2, 0))
+        if prob.Wn:
+            self.hz_state0[a:].view(prob.Wn, prob.Ww, ld)[:, :, :B].copy_(data["initial_warehouse_inventories"].permute(1, 2, 0))
+        X = self.hz_X
+        self._fill_observation_rows_by_row(X, data, prob, T, B, ld, shift, observation_params, demand_soa)
+        # the observation rows' share of the first layer for every period at once (+ bias): independent of the rollout
+        self.hz_W1obs[:, :Fo].copy_(lins[0].weight.detach()[:, FD:])
+        self._k(f"fwdT_{dims[1]}x{Fo}", ops.linear_fwd, self.hz_W1obs[:, :Fo], lins[0].bias.detach(), X[FD:].view(Fo, n_cols),
+                self.hz_z1.view(dims[1], n_cols), n_cols, _lib.NIC_ACT_NONE)
+        desc = plan.desc(prob, T, shift, lins, self.edge_mask, demand_soa, n_cols, round_orders=self._round)
+        hist = ([X] + self.hz_hist) if train else [None] * 5
+        self._k("horizon_fwd", hz.horizon_fwd, desc, self.hz_z1, self.hz_state0, self.rewards, self.hz_final, *hist)
+        total = self.rewards.sum()
+        reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
+        if not train:
+            return total, reported
+        if grad_scale is None:
+            grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
+        self.g_reward.zero_()
+        self.g_reward[:B] = grad_scale
+        self._k("horizon_bwd", hz.horizon_bwd, desc, *hist, Table(self.g_reward, 0, 1), *self.hz_dz)
+        # weight gradients: contractions over (period, scenario) = T * ld columns; padding columns of the dz histories are zero
+        inputs = [X, self.hz_hist[0], self.hz_hist[1]]
+        for i in range(len(lins)):
+            self.slabs[i].zero_()
+            dy, x = self.hz_dz[i].view(dims[i + 1], n_cols), inputs[i].view(dims[i], n_cols)
+            self._k(f"wgradT_{dims[i + 1]}x{dims[i]}", ops.linear_wgrad, dy, x, self.slabs[i], n_cols)
+            ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], dims[i], 1.0)
         if assign_grads:
             self._assign_grads(accumulate_grads)
         return total, reported
@@ -741,6 +842,8 @@ class FusedRollout:
         from .layout import ref_view
         if self.small is not None:
             last = self.sr_final
+        elif self.horizon is not None:
+            last = self.hz_final
         else:  # history: block T; rolling evaluation: block T & 1
             last = self.states[-1] if self._hist else self.states[self._T_last & 1]
         st = self._views(last, self.prob)

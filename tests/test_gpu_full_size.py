@@ -179,3 +179,71 @@ def test_full_size_full_horizon_training_step_properties(workload, n, T):
     assert abs(tot_full - (ta + tb)) <= 2e-6 * abs(tot_full), (tot_full, ta, tb)
     for gf, ga, gb in zip(g_full, g_a, g_b):
         assert float((gf - (ga + gb)).norm()) <= 3e-5 * float(gf.norm()) + 1e-12, float((gf - (ga + gb)).norm() / gf.norm())
+
+
+@pytest.mark.parametrize("n", [72, 288, 40])
+def test_data_driven_whole_horizon_route_at_the_reference_batch(n):
+    """The reference's real-data training batch (many_warehouses_real_data_lost_demand.yml: 72 products per training batch, 288 per
+    dev / test batch; 21 stores x 3 warehouses, T = 95, data_driven 64 x 64) and a ragged one (40: the last workgroup has 8 live
+    scenarios) on the whole-horizon kernels (csrc/horizon_rollout.hip) against the per-period route of the same engine:
+      * per-period rewards and final state agree to rounding (the routes differ in the layers' summation order only), gradients to
+        1e-4 of each tensor's norm after 95 periods of recurrence;
+      * stock conservation over every scenario and period from the state / order histories the forward kernel leaves;
+      * batch independence: a scenario's trajectory does not depend on the block of 16 it sits in or on its column (to 2e-6: the
+        GEMM over (period x scenario) columns that contracts the observation rows splits its contraction by the column count);
+      * additivity of the training step over two ragged parts; padding columns of every history stay zero."""
+    import bench
+    T = 95
+    setting, policy, sc, data, model, eng, n, T, _ = bench.build_case("real_data_driven", torch.device(DEV), 0, 1, n, T, False)
+    obs, pp = setting["observation_params"], setting["problem_params"]
+    S, Wn = pp["n_stores"], pp["n_warehouses"]
+    eng.materialize(eng.input_rows(data, obs))
+    scale = 1.0 / (n * T * S)
+    out = {}
+    for route in ("horizon", "periods"):
+        eng.use_horizon = route == "horizon"
+        tot, _ = eng.run(data, T, 0, train=True, observation_params=obs, demand_soa=sc.demands_soa, grad_scale=scale)
+        torch.cuda.synchronize()
+        assert (eng.horizon is not None) == (route == "horizon")
+        out[route] = (float(tot), eng.per_period_rewards().clone(), {k: v.clone() for k, v in eng.final_state().items()},
+                      [p.grad.detach().clone() for p in model.parameters()])
+    a, b = out["horizon"], out["periods"]
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0])
+    torch.testing.assert_close(a[1], b[1], rtol=2e-5, atol=2e-3)
+    for k in b[2]:
+        torch.testing.assert_close(a[2][k], b[2][k], rtol=2e-5, atol=2e-3)
+    for ga, gb in zip(a[3], b[3]):
+        assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-12, float((ga - gb).norm() / gb.norm())
+    # ---- the histories of the whole-horizon forward: conservation (lost demand), zero padding
+    eng.use_horizon = True
+    eng.run(data, T, 0, train=True, observation_params=obs, demand_soa=sc.demands_soa, grad_scale=scale)
+    torch.cuda.synchronize()
+    Ws = data["initial_inventories"].shape[2]
+    X, orders = eng.hz_X, eng.hz_hist[3]
+    shift = obs["demand"]["period_shift"]
+    worst = 0.0
+    for t in range(T - 1):
+        st = X[:S * Ws, t].view(S, Ws, -1)[:, :, :n].double()
+        nx = X[:S * Ws, t + 1].view(S, Ws, -1)[:, :, :n].double()
+        dem = eng.demand[t + shift][:, :n].double()
+        recv = orders[:S * Wn, t].view(S, Wn, -1)[:, :, :n].double().sum(dim=1)
+        worst = max(worst, float((nx.sum(dim=1) - (st.sum(dim=1) - torch.minimum(st[:, 0], dem) + recv)).abs().max()))
+        shipped = orders[S * Wn + Wn:, t, :n].double()      # what the kernel recorded as shipped = the sum of a warehouse's orders
+        assert float((shipped - orders[:S * Wn, t].view(S, Wn, -1)[:, :, :n].double().sum(dim=0)).abs().max()) < 1e-3
+    assert worst < 5e-3, worst
+    for h in [eng.rewards, X[:eng.F_dyn]] + eng.hz_hist + eng.hz_dz:
+        assert float(h[..., n:].abs().sum()) == 0.0
+    # ---- batch independence (bit for bit) and additivity over ragged parts
+    r_full = eng.per_period_rewards().clone()
+    g_full = [p.grad.detach().clone() for p in model.parameters()]
+    cut = 23 if n > 23 else n // 2
+    parts = []
+    for lo, hi in ((0, cut), (cut, n)):
+        part = _slice(data, lo, hi)
+        eng.run(part, T, 0, train=True, observation_params=obs, grad_scale=scale)
+        torch.cuda.synchronize()
+        assert eng.horizon is not None
+        torch.testing.assert_close(eng.per_period_rewards(), r_full[:, lo:hi], rtol=2e-6, atol=1e-4)
+        parts.append([p.grad.detach().clone() for p in model.parameters()])
+    for gf, ga, gb in zip(g_full, *parts):
+        assert float((gf - (ga + gb)).norm()) <= 3e-5 * float(gf.norm()) + 1e-12, float((gf - (ga + gb)).norm() / gf.norm())

@@ -139,19 +139,23 @@ def test_fused_rollout_matches_reference(name):
 DATA_DRIVEN_CASES = [n for n in case_names() if n.endswith("data_driven")]
 
 
+@pytest.mark.parametrize("route", ["horizon", "periods"])
 @pytest.mark.parametrize("name", DATA_DRIVEN_CASES)
-def test_data_driven_engine_matches_reference(name):
+def test_data_driven_engine_matches_reference(name, route):
     """SURVEY 8 f4 on the MLP engine (round 3): `FusedRollout` with the data_driven head - the past-demand window, costs,
     days-from-christmas and lead-time rows appended to every period's state block, ReLU + adjacency mask + proportional
     allocation of the warehouses' pipelines in one head kernel (`nic_head_data_driven_fwd/bwd`), profit objective, demand
     trace entered at period_shift - against the reference-generated real-data fixtures: rewards, totals, final state,
-    gradients at the usual bars; evaluation mode and the Trainer's own routing agree."""
+    gradients at the usual bars; evaluation mode and the Trainer's own routing agree.  Both routes: `horizon` = all periods in
+    one launch per direction (round 4, csrc/horizon_rollout.hip: what small batches take by default), `periods` = the
+    per-period kernels."""
     assert DATA_DRIVEN_CASES
     g = Golden(name)
     c = g.fresh_config()
     model = _model(g, c)
     assert FusedRollout.supports(model) and FusedRollout.observation_ok(model, c["observation_params"], g.data)
     eng = FusedRollout(model, c["problem_params"], DEV)
+    eng.use_horizon = route == "horizon"
     assert eng.head == "data_driven"
     data = {k: v.to(DEV) for k, v in g.data.items()}
     eng.materialize(g.params["net.master.0.weight"].shape[1])
@@ -159,6 +163,8 @@ def test_data_driven_engine_matches_reference(name):
     total, reported = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
     torch.cuda.synchronize()
     assert eng.small is None and eng.dims[0] == g.params["net.master.0.weight"].shape[1]
+    assert (eng.horizon is not None) == (route == "horizon")
+    block = (lambda t: eng.hz_X[:, t]) if route == "horizon" else (lambda t: eng.states[t])   # one period's input rows
     rewards = eng.per_period_rewards().cpu()
     ref_r = g.tensor("rewards").float()
     torch.testing.assert_close(rewards, ref_r, rtol=1e-5, atol=2e-2)
@@ -172,11 +178,15 @@ def test_data_driven_engine_matches_reference(name):
         feats = g.features(t)
         o = eng.F_dyn
         S, P_ = c["problem_params"]["n_stores"], c["observation_params"]["demand"]["past_periods"]
-        got = eng.states[t][o:o + S * P_, :c["n"]].t().reshape(c["n"], S, P_).cpu()
+        got = block(t)[o:o + S * P_, :c["n"]].t().reshape(c["n"], S, P_).cpu()
         assert torch.equal(got, feats["past_demands"]), t
         o += S * P_ + 2 * S
         D = feats["days_from_christmas"].shape[1]
-        assert torch.equal(eng.states[t][o:o + D, :c["n"]].t().cpu(), feats["days_from_christmas"]), t
+        assert torch.equal(block(t)[o:o + D, :c["n"]].t().cpu(), feats["days_from_christmas"]), t
+        if route == "horizon":   # the state rows the kernel left for the backward are the reference's inventories before period t
+            for k, v in g.states(t).items():
+                rows = block(t)[:eng.F_store] if k == "store_inventories" else block(t)[eng.F_store:eng.F_dyn]
+                torch.testing.assert_close(rows[:, :c["n"]].t().reshape(v.shape).cpu(), v.float(), rtol=2e-6, atol=2e-3)
     worst = _check_grads(model, g, GRAD_TOL)
     print(f"{name}: worst relative gradient error {worst:.2e}")
     t2, r2 = eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"])
@@ -205,6 +215,7 @@ def test_data_driven_engine_graph_replay_and_discrete_evaluation():
     for mode in ("eager", "graph"):
         model = _model(g, c)
         eng = FusedRollout(model, c["problem_params"], DEV)
+        eng.use_horizon = False   # (the per-period launch sequence is what gets captured; the whole-horizon route is two launches)
         eng.use_graph = mode == "graph"
         eng.materialize(eng.input_rows(data, c["observation_params"]))
         _load(model, g)
@@ -231,6 +242,23 @@ def test_data_driven_engine_graph_replay_and_discrete_evaluation():
     assert abs(float(total) - float(ref.total)) <= 1e-5 * abs(float(ref.total))
     assert abs(float(reported) - float(ref.reported)) <= 1e-5 * abs(float(ref.reported))
     assert float(total) != out["eager"][0][0]
+    # the whole-horizon route: same training results as the per-period launches up to the layers' summation order, also when the
+    # batch contents change between runs of one engine; and its own discrete-allocation evaluation
+    model = _model(g, c)
+    hz_eng = FusedRollout(model, c["problem_params"], DEV)
+    hz_eng.materialize(hz_eng.input_rows(data, c["observation_params"]))
+    _load(model, g)
+    for d, want in zip((data, data2, data), out["eager"]):
+        tot, rep = hz_eng.run(d, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+        assert hz_eng.horizon is not None
+        assert abs(float(tot) - want[0]) <= 2e-6 * abs(want[0]) and abs(float(rep) - want[1]) <= 2e-6 * abs(want[1])
+        for p_, y in zip(model.parameters(), want[2]):
+            assert float((p_.grad - y).abs().max()) <= 1e-5 * float(y.abs().max()) + 1e-9
+    with torch.no_grad():
+        tot, rep = hz_eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"],
+                              discrete_allocation=True)
+    assert abs(float(tot) - float(ref.total)) <= 1e-5 * abs(float(ref.total))
+    assert abs(float(rep) - float(ref.reported)) <= 1e-5 * abs(float(ref.reported))
 
 
 def test_data_driven_epochs_engine_follows_generic_route():
