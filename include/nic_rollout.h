@@ -346,7 +346,19 @@ typedef struct NicHorizonDesc {
     const float* b3;
     const float* mask;          /* [S][Wn] adjacency (1 = edge) as nic_head_data_driven_fwd takes it; NULL when Wn == 0 */
     const float* demand;        /* [>= t0 + T][S][ldb] */
-    int64_t hist_stride;        /* elements between consecutive rows of z1_obs and of every history (>= T * ldb) */
+    int64_t hist_stride;        /* elements between consecutive rows of z1_obs, the tape and every history (>= T * ldb) */
+    /* Policies whose decisions do not need the MLP inside the loop ride on the same kernels (same env step, same histories):
+     *   head_mode 1: `tape` [S*max(Wn,1) + Wn][T][ldb] holds every period's ORDERS (store orders, then warehouse orders) - policies
+     *     that do not read the state, e.g. JustInTime (neural_networks.py:634-739); forward / evaluation only.
+     *   head_mode 2: `tape` [S][T][ldb] holds order-up-to LEVELS: order = clip(level - sum of the store's pipeline, min = 0)
+     *     (no clip with allow_negative) - QuantilePolicy.forecast_base_stock_allocation (neural_networks.py:560-575), whose levels
+     *     depend on the demand trace and the policy's parameters but not on the state; one-supplier settings (Wn == 0).  The
+     *     backward then writes d loss / d level into dz3_hist [S][T][ldb] (dz1_hist / dz2_hist and the h / logits histories
+     *     are not touched and may be NULL).
+     * W1..b3, H1, H2 are ignored in both; n_out stays the setting's order count. */
+    int32_t head_mode;          /* 0: the MLP + data_driven head */
+    int32_t allow_negative;     /* head_mode 2: no clip (ReturnsNV, neural_networks.py:613-622) */
+    const float* tape;
 } NicHorizonDesc;
 /* 1 if the two kernels take this shape (sizes above, LDS budget), else 0 (nic_last_error says why). */
 int nic_horizon_rollout_ok(const NicHorizonDesc* d);

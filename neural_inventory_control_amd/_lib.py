@@ -61,7 +61,7 @@ class NicHorizonDesc(C.Structure):
     _fields_ = ([("io", NicEnvStepIO)] + [(n, C.c_int32) for n in ("T", "t0", "H1", "H2", "n_out", "round_orders")]
                 + [("W1", C.c_void_p), ("ldw1", C.c_int64), ("W2", C.c_void_p), ("ldw2", C.c_int64), ("W3", C.c_void_p),
                    ("ldw3", C.c_int64), ("b2", C.c_void_p), ("b3", C.c_void_p), ("mask", C.c_void_p), ("demand", C.c_void_p),
-                   ("hist_stride", C.c_int64)])
+                   ("hist_stride", C.c_int64), ("head_mode", C.c_int32), ("allow_negative", C.c_int32), ("tape", C.c_void_p)])
 
 
 class NicClosedFormDesc(C.Structure):

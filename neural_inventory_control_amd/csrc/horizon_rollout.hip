@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
     const bool live = b < D.n_scenarios;
     const int S = D.n_stores, Wn = D.n_warehouses, nsup = Wn > 0 ? Wn : 1, Ww = D.warehouse_slots;
     const int FD = S * D.store_slots + Wn * Ww, n_ord = S * nsup + Wn, NOp = up(d.n_out, 16);
-    const int H1 = d.H1, H2 = d.H2;
+    const int H1 = d.head_mode == 0 ? d.H1 : 0, H2 = d.head_mode == 0 ? d.H2 : 0;   // (tape modes: no layers, every weight guard false)
     const HzLayout L = hz_layout(D, d.n_out, false);
     NicEnvStepIO io = hz_stage_tables(d, L, lds, I, b);
     const int rows_st = (L.st1 - L.st0) / NB;
@@ -248,11 +248,11 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 16 * I.wave + 4 * I.g + i;
-        bias2[i] = r < H2 ? d.b2[r] : 0.f;
+        bias2[i] = (r < H2 && d.head_mode == 0) ? d.b2[r] : 0.f;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int ro = 16 * out_tile(I.wave, u) + 4 * I.g + i;
-            bias3[u][i] = ro < d.n_out ? d.b3[ro] : 0.f;
+            bias3[u][i] = (ro < d.n_out && d.head_mode == 0) ? d.b3[ro] : 0.f;
         }
     }
 
@@ -262,12 +262,23 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
         lds[L.st1 + r * NB + I.j] = 0.f;
     }
     for (int r = I.r0; r < NOp; r += 16) lds[L.z + r * NB + I.j] = 0.f;
-    float z1[4], dem_pf[kMaxStores / 16];
+    // head_mode 0: the policy MLP + data_driven head.  1: the orders of every period come from a tape (policies that do not read the
+    // state: just-in-time).  2: order-up-to levels from a tape (the quantile policies: order = clip(level - pipeline total, 0))
+    const int mode = d.head_mode, n_tape = mode == 1 ? n_ord : (mode == 2 ? S : 0);
+    float z1[4], dem_pf[kMaxStores / 16], tape_pf[kMaxOut / 16];
     auto prefetch = [&](int t) {
+        if (mode == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * I.wave + 4 * I.g + i;
-            z1[i] = (r < H1 && live) ? z1_obs[(int64_t)r * hs + (int64_t)t * ld + b] : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * I.wave + 4 * I.g + i;
+                z1[i] = (r < H1 && live) ? z1_obs[(int64_t)r * hs + (int64_t)t * ld + b] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kMaxOut / 16; ++u) {
+                const int r = I.r0 + 16 * u;
+                tape_pf[u] = (r < n_tape && live) ? d.tape[(int64_t)r * hs + (int64_t)t * ld + b] : 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < kMaxStores / 16; ++u) {
@@ -286,6 +297,7 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
         if (!state_hist) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (mode != 0) break;
             const int r = 16 * I.wave + 4 * I.g + i;
             if (r < H1) h1_hist[(int64_t)r * hs + at] = h1_p[i];
             if (r < H2) h2_hist[(int64_t)r * hs + at] = h2_p[i];
@@ -310,11 +322,27 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
             const int r = I.r0 + 16 * u;
             if (r < S) lds[L.dem + r * NB + I.j] = dem_pf[u];   // (read next in the env phase, four barriers down)
         }
+        float tape_now[kMaxOut / 16];
+#pragma unroll
+        for (int u = 0; u < kMaxOut / 16; ++u) tape_now[u] = tape_pf[u];
         prefetch(t + 1 < d.T ? t + 1 : t);
         if (t > 0) flush(t - 1);
         if (state_hist && live)
             for (int r = I.r0; r < FD; r += 16) state_hist[(int64_t)r * hs + (int64_t)t * ld + b] = cur[r * NB + I.j];
         HZ_STAMP(t, 1);
+        io.store_inv = cur;
+        io.wh_inv = cur + S * D.store_slots * NB;
+        float* so = lds + L.ord;
+        float* wo = lds + L.ord + S * nsup * NB;
+        const float* Z = lds + L.z;
+        if (mode != 0) {   // the period's tape rows: orders as they are (mode 1), or levels parked in the logits block (mode 2)
+#pragma unroll
+            for (int u = 0; u < kMaxOut / 16; ++u) {
+                const int r = I.r0 + 16 * u;
+                if (r < n_tape) lds[(mode == 1 ? L.ord : L.z) + r * NB + I.j] = (mode == 1 && d.round_orders) ? rintf(tape_now[u]) : tape_now[u];
+            }
+            lds_barrier();
+        } else {
         // ---- layer 1: z1_obs (observation rows + bias, contracted outside) + W1[state rows] x state ----
         {
             float x[MAXS1];
@@ -355,11 +383,6 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
         lds_barrier();
         HZ_STAMP(t, 4);
         // ---- head (DataDrivenNet.forward :474-515): thread (store s = r0 + 16 u, scenario j) ----
-        io.store_inv = cur;
-        io.wh_inv = cur + S * D.store_slots * NB;
-        float* so = lds + L.ord;
-        float* wo = lds + L.ord + S * nsup * NB;
-        const float* Z = lds + L.z;
         if (Wn > 0) {
             // masked ReLU outputs of this thread's stores; then per warehouse the allocation scale (serial sum in store order)
             for (int s = I.r0; s < S; s += 16)
@@ -384,10 +407,18 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
             }
             lds_barrier();
         }
+        }   // (head_mode 0)
         HZ_STAMP(t, 5);
         // ---- this thread's stores: final orders, then cost + pipeline update (env_fwd_one_store = a store of env_fwd_stores) ----
         for (int s = I.r0; s < S; s += 16) {
-            if (Wn > 0) {
+            if (mode == 2) {   // order up to the level (QuantilePolicy.forecast_base_stock_allocation, neural_networks.py:560-575)
+                float pos = 0.f;
+                for (int k = 0; k < D.store_slots; ++k) pos += cur[(s * D.store_slots + k) * NB + I.j];
+                float a = Z[s * NB + I.j] - pos;
+                if (!d.allow_negative) a = fmaxf(a, 0.f);
+                so[s * NB + I.j] = d.round_orders ? rintf(a) : a;
+            } else if (mode == 1) {
+            } else if (Wn > 0) {
                 for (int w = 0; w < Wn; ++w) {
                     const float a = so[(s * Wn + w) * NB + I.j] * lds[L.scl + w * NB + I.j];
                     so[(s * Wn + w) * NB + I.j] = d.round_orders ? rintf(a) : a;   // (discrete allocation, trainer.py:201-202)
@@ -453,7 +484,8 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
     const bool live = b < D.n_scenarios;
     const int S = D.n_stores, Wn = D.n_warehouses, nsup = Wn > 0 ? Wn : 1, Ww = D.warehouse_slots;
     const int FD = S * D.store_slots + Wn * Ww, FDp = up(FD, 16), n_ord = S * nsup + Wn;
-    const int H1 = d.H1, H2 = d.H2, n_t1 = FDp / 16;
+    const int mode = d.head_mode;   // 0: policy MLP + data_driven head; 2: order-up-to levels from a tape (1 has no gradient)
+    const int H1 = mode == 0 ? d.H1 : 0, H2 = mode == 0 ? d.H2 : 0, n_t1 = FDp / 16;
     const HzLayout L = hz_layout(D, d.n_out, true);
     NicEnvStepIO io = hz_stage_tables(d, L, lds, I, b);
     io.store_inv = lds + L.st0;
@@ -493,7 +525,7 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
 #pragma unroll
         for (int u = 0; u < kMaxOut / 16; ++u) {
             const int r = I.r0 + 16 * u;
-            p_z[u] = r < d.n_out ? logits_hist[(int64_t)r * hs + at] : 0.f;
+            p_z[u] = r < d.n_out ? (mode == 0 ? logits_hist : d.tape)[(int64_t)r * hs + at] : 0.f;   // (mode 2: the levels)
         }
 #pragma unroll
         for (int u = 0; u < kMaxOut / 16 + 2; ++u) {   // orders (n_ord == n_out rows) + what the warehouses shipped (Wn <= 32 rows)
@@ -520,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 16 * I.wave + 4 * I.g + i;
-            if (r < H2) dz2_hist[(int64_t)r * hs + at] = dz2_p[i];
+            if (r < H2) dz2_hist[(int64_t)r * hs + at] = dz2_p[i];   // (tape modes: H1 = H2 = 0)
             if (r < H1) dz1_hist[(int64_t)r * hs + at] = dz1_p[i];
         }
         for (int r = I.r0; r < d.n_out; r += 16) dz3_hist[(int64_t)r * hs + at] = lds[L.dz3 + r * NB + I.j];
@@ -577,7 +609,14 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
             nic::env_bwd_one_store<MAXW>(io, g_next, gr,
                                          [&](int w) { return nic::env_bwd_wh_g_after(io, g_next_wh, gr, w, shipped[w * NB + I.j], I.j); },
                                          g_cur, gso, I.j, s);
-            if (Wn > 0) {
+            if (mode == 2) {   // order = clip(level - pipeline total, 0): clamp(min = 0) passes the gradient where its input is >= 0
+                float pos = 0.f;
+                for (int k = 0; k < D.store_slots; ++k) pos += lds[L.st0 + (s * D.store_slots + k) * NB + I.j];
+                const float a = Z[s * NB + I.j] - pos;
+                const float gl = (d.allow_negative || a >= 0.f) ? gso[s * NB + I.j] : 0.f;
+                lds[L.dz3 + s * NB + I.j] = gl;                                   // d loss / d level
+                for (int k = 0; k < D.store_slots; ++k) g_cur[(s * D.store_slots + k) * NB + I.j] -= gl;
+            } else if (Wn > 0) {
                 for (int w = 0; w < Wn; ++w) {
                     const int r = s * Wn + w;
                     const float a = fmaxf(Z[(Wn + r) * NB + I.j], 0.f) * lds[L.mask + r];
@@ -590,6 +629,7 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
         }
         lds_barrier();
         HZ_STAMP(t, 2);
+        if (mode != 0) continue;   // (no layers: the state gradient is complete, the level gradient waits in the dz3 block)
         if (Wn > 0) {
             // per warehouse: sums in store order (head_data_driven_bwd_one's), scale / common term for its stores' logits
             for (int w = I.r0; w < Wn; w += 16) {
@@ -690,6 +730,16 @@ int validate(const NicHorizonDesc* d, const char* who) {
     const int n_out = D.n_warehouses ? D.n_warehouses + D.n_stores * D.n_warehouses : D.n_stores;
     NIC_REQUIRE(d->n_out == n_out && n_out <= kMaxOut, "%s: %d logits rows (the setting has %d; at most %d)", who, d->n_out, n_out,
                 kMaxOut);
+    NIC_REQUIRE(d->head_mode >= 0 && d->head_mode <= 2, "%s: head_mode 0 (MLP), 1 (order tape) or 2 (level tape)", who);
+    if (d->head_mode != 0) {
+        NIC_REQUIRE(d->tape != nullptr && d->demand != nullptr, "%s: null tape / demand", who);
+        NIC_REQUIRE(d->head_mode == 1 || D.n_warehouses == 0, "%s: order-up-to levels are a one-supplier policy (no warehouses)", who);
+        NIC_REQUIRE(d->T > 0 && d->t0 >= 0 && d->hist_stride >= (int64_t)d->T * D.ldb, "%s: bad T / t0 / hist_stride", who);
+        NIC_REQUIRE(D.n_warehouses == 0 || d->mask, "%s: null adjacency mask", who);
+        NIC_REQUIRE(d->io.underage.p && d->io.holding.p && d->io.lead_times.p, "%s: null store table", who);
+        NIC_REQUIRE(D.n_warehouses == 0 || (d->io.wh_holding.p && d->io.wh_lead_times.p), "%s: null warehouse table", who);
+        return 0;
+    }
     NIC_REQUIRE(d->H1 > 0 && d->H1 <= kMaxH && d->H2 > 0 && d->H2 <= kMaxH, "%s: hidden widths 1..%d", who, kMaxH);
     NIC_REQUIRE(d->T > 0 && d->t0 >= 0 && d->hist_stride >= (int64_t)d->T * D.ldb, "%s: bad T / t0 / hist_stride", who);
     NIC_REQUIRE(d->W1 && d->W2 && d->W3 && d->b2 && d->b3 && d->demand, "%s: null weight / demand pointer", who);
@@ -731,8 +781,9 @@ int nic_horizon_rollout_fwd(const NicHorizonDesc* d, const float* z1_obs, const 
                             float* state_hist, float* h1_hist, float* h2_hist, float* logits_hist, float* orders_hist,
                             void* stream) {
     if (int e = validate(d, "nic_horizon_rollout_fwd")) return e;
-    NIC_REQUIRE(z1_obs && state0 && rewards, "nic_horizon_rollout_fwd: null z1_obs / state0 / rewards");
-    NIC_REQUIRE(!state_hist || (h1_hist && h2_hist && logits_hist && orders_hist), "nic_horizon_rollout_fwd: histories come together");
+    NIC_REQUIRE((z1_obs || d->head_mode != 0) && state0 && rewards, "nic_horizon_rollout_fwd: null z1_obs / state0 / rewards");
+    NIC_REQUIRE(!state_hist || (orders_hist && (d->head_mode != 0 || (h1_hist && h2_hist && logits_hist))),
+                "nic_horizon_rollout_fwd: histories come together");
     const NicEnvDims& D = d->io.dims;
     const int FD = D.n_stores * D.store_slots + D.n_warehouses * D.warehouse_slots;
     const int bytes = lds_bytes(d, false);
@@ -758,8 +809,9 @@ int nic_horizon_rollout_bwd(const NicHorizonDesc* d, const float* state_hist, co
                             const float* logits_hist, const float* orders_hist, NicTable2 g_reward, float* dz1_hist,
                             float* dz2_hist, float* dz3_hist, void* stream) {
     if (int e = validate(d, "nic_horizon_rollout_bwd")) return e;
-    NIC_REQUIRE(state_hist && h1_hist && h2_hist && logits_hist && orders_hist && g_reward.p && dz1_hist && dz2_hist && dz3_hist,
-                "nic_horizon_rollout_bwd: null buffer");
+    NIC_REQUIRE(d->head_mode != 1, "nic_horizon_rollout_bwd: an order tape has no gradient");
+    NIC_REQUIRE(state_hist && orders_hist && g_reward.p && dz3_hist, "nic_horizon_rollout_bwd: null buffer");
+    NIC_REQUIRE(d->head_mode != 0 || (h1_hist && h2_hist && logits_hist && dz1_hist && dz2_hist), "nic_horizon_rollout_bwd: null buffer");
     NIC_REQUIRE(!d->round_orders, "nic_horizon_rollout_bwd: rounded orders have no gradient (evaluation only)");
     const NicEnvDims& D = d->io.dims;
     const int FD = D.n_stores * D.store_slots + D.n_warehouses * D.warehouse_slots;

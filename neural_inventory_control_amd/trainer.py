@@ -21,6 +21,7 @@ from .closed_form import ClosedFormRollout
 from .gnn_rollout import GnnRollout
 from .loss_functions import PolicyLoss
 from .rollout import FusedRollout
+from .tape_rollout import TapeRollout
 
 
 def _numpy_scalar_globals():
@@ -61,6 +62,7 @@ class Trainer:
                                       "model_params_to_save": None}
         self.best_epoch = 0
         self.use_fused_rollout = True
+        self.use_tape_rollout = True   # quantile policies / just-in-time: batched decisions + one whole-horizon launch (tape_rollout.py)
         # generic route (policies the fused engine does not take: GNN, closed-form, user plugins): capture the whole training
         # step of a batch shape - every period's policy + env-step launches and the autograd sweep - into ONE HIP graph and
         # replay it; the per-period kernels of these policies run for microseconds, so the step is launch-bound
@@ -225,6 +227,18 @@ class Trainer:
             eng = self._engines.get(ekey)
             if eng is None or eng.model is not model:
                 eng = self._engines[ekey] = ClosedFormRollout(model, problem_params, self.device)
+            if eng.shapes_ok(data_batch):
+                self._last_engine = eng
+                return eng.run(data_batch, periods, ignore_periods, train=train, observation_params=observation_params,
+                               discrete_allocation=discrete_allocation)
+        if engine_ok and self.use_tape_rollout and TapeRollout.supports(model) \
+                and TapeRollout.observation_ok(model, observation_params, data_batch):
+            # quantile policies / just-in-time: the decisions of all periods do not depend on the state - one batched pass computes
+            # them (the forecaster runs once), one whole-horizon launch per direction does the rest (tape_rollout.py); the
+            # returned total is differentiable with respect to the policy's parameters like the closed-form engine's
+            eng = self._engines.get((id(model), "tape", bool(train)))
+            if eng is None or eng.model is not model:
+                eng = self._engines[(id(model), "tape", bool(train))] = TapeRollout(model, problem_params, self.device)
             if eng.shapes_ok(data_batch):
                 self._last_engine = eng
                 return eng.run(data_batch, periods, ignore_periods, train=train, observation_params=observation_params,

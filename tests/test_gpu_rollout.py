@@ -341,9 +341,12 @@ def _order_up_to_knife_edges(g, c):
     return bad
 
 
+@pytest.mark.parametrize("route", ["tape", "generic"])
 @pytest.mark.parametrize("name", QUANTILE_TRAINABLE)
-def test_quantile_policy_gradients_with_knife_edge_exclusion_and_fp64_referee(name):
-    """Gradient parity of the trainable quantile policies through the HIP simulator.  Two effects make a plain band
+def test_quantile_policy_gradients_with_knife_edge_exclusion_and_fp64_referee(name, route):
+    """Gradient parity of the trainable quantile policies through the HIP simulator - on the generic route (Simulator.step +
+    autograd, period by period) and on the tape route the Trainer picks by itself (round 4: all levels in one batched pass, one
+    whole-horizon launch per direction, tape_rollout.py).  Two effects make a plain band
     meaningless here and each gets its own mechanism: (1) knife-edge scenarios (see _order_up_to_knife_edges) are excluded,
     counted and bounded; (2) the base-stock level is an interpolation between ADJACENT outputs of the frozen float32
     forecaster, so d level / d quantile carries the forecaster's rounding amplified by cancellation.  The criterion is an fp64
@@ -379,7 +382,7 @@ def test_quantile_policy_gradients_with_knife_edge_exclusion_and_fp64_referee(na
     model = _model(g, c)
     data = {k: v.to(DEV) for k, v in sub.items()}
     sim, tr = Simulator(device=DEV), Trainer(device=DEV)
-    tr.use_fused_rollout = False
+    tr.use_fused_rollout = route == "tape"
     obs, _ = sim.reset(c["periods"], c["problem_params"], data, c["observation_params"])
     with torch.no_grad():
         o = dict(obs)
@@ -389,6 +392,7 @@ def test_quantile_policy_gradients_with_knife_edge_exclusion_and_fp64_referee(na
     model.zero_grad()
     total, _ = tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data, c["observation_params"],
                                  c["ignore"], False)
+    assert (type(getattr(tr, "_last_engine", None)).__name__ == "TapeRollout") == (route == "tape")
     (total / norm).backward()
     torch.cuda.synchronize()
     assert abs(float(total) - float(res32.total)) <= 1e-5 * abs(float(res32.total))
@@ -433,6 +437,63 @@ def test_simulator_autograd_route_matches_reference(name):
     assert int(sim.observation["current_period"]) == c["periods"]
     if name not in QUANTILE_TRAINABLE:  # (those: test_quantile_policy_gradients_with_knife_edge_exclusion_and_fp64_referee)
         _check_grads(model, g, GRAD_TOL, want.grads)
+
+
+TAPE_CASES = [n for n in case_names() if n.startswith("f4_real") and not n.endswith("data_driven")]
+
+
+@pytest.mark.parametrize("name", TAPE_CASES)
+def test_tape_engine_matches_reference(name):
+    """SURVEY 8 f4, the policies that need no network inside the period loop (round 4, tape_rollout.py): the four quantile policies
+    (all levels from ONE batched pass of the frozen forecaster, order-up-to + env step in one launch of the whole-horizon kernel)
+    and just-in-time on one store and on 21 stores x 3 warehouses (all orders from one batched gather of future demand, one launch)
+    - through `Trainer.simulate_batch`, which picks the engine by itself - against the reference-generated fixtures: per-period
+    rewards, totals, final state; gradients of the trainable ones have their own test (knife edges, fp64 referee); evaluation
+    with discrete allocation against the oracle."""
+    from oracle import inventory_oracle as orc
+    assert len(TAPE_CASES) == 6
+    g = Golden(name)
+    c = g.fresh_config()
+    model = _model(g, c)
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    sim, tr = Simulator(device=DEV), Trainer(device=DEV)
+    if g.params:
+        obs, _ = sim.reset(c["periods"], c["problem_params"], data, c["observation_params"])
+        with torch.no_grad():
+            o = dict(obs)
+            o["internal_data"] = sim._internal_data
+            model(o)   # materialises the lazy layers
+        _load(model, g)
+    model.zero_grad()
+    total, reported = tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data,
+                                        c["observation_params"], c["ignore"], False)
+    eng = tr._last_engine
+    assert type(eng).__name__ == "TapeRollout"
+    assert total.requires_grad == (name in QUANTILE_TRAINABLE)
+    torch.cuda.synchronize()
+    assert abs(float(total) - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
+    assert abs(float(reported) - float(g.z["reported"])) <= 1e-5 * abs(float(g.z["reported"]))
+    torch.testing.assert_close(eng.per_period_rewards().cpu(), g.tensor("rewards").float(), rtol=1e-5, atol=2e-2)
+    final = eng.final_state()
+    for k, v in g.states(c["periods"]).items():
+        torch.testing.assert_close(final[k].cpu(), v.float(), rtol=2e-6, atol=2e-3)
+    if name in QUANTILE_TRAINABLE:   # the backward launch runs and reaches every parameter
+        (total / (c["n"] * c["periods"])).backward()
+        assert all(p_.grad is not None and bool(torch.isfinite(p_.grad).all()) for p_ in model.parameters())
+    # evaluation: same numbers without the histories; discrete allocation (orders rounded half to even) against the oracle
+    with torch.no_grad():
+        t2, r2 = tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data, c["observation_params"],
+                                   c["ignore"], False)
+        t3, r3 = tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data, c["observation_params"],
+                                   c["ignore"], True)
+    assert float(t2) == float(total) and float(r2) == float(reported)
+    pol = orc.policy_from_state_dict(c["nn_params"], g.params, c["problem_params"], g.tensor("warehouse_upper_bound"),
+                                     forecaster_state=g.forecaster)
+    with torch.no_grad():
+        ref = orc.rollout(pol, c["periods"], c["problem_params"], g.data, c["observation_params"], c["ignore"],
+                          discrete_allocation=True)
+    assert abs(float(t3) - float(ref.total)) <= 1e-5 * abs(float(ref.total))
+    assert abs(float(r3) - float(ref.reported)) <= 1e-5 * abs(float(ref.reported))
 
 
 @pytest.mark.parametrize("name", [n for n in case_names() if n.startswith("f4_real")])
