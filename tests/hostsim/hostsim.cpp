@@ -27,7 +27,69 @@ static void closed_form_all(const NicClosedFormDesc& d, float* reward_hist, floa
         }
 }
 
+// One period composed from the ONE-STORE bodies the way csrc/horizon_rollout.hip composes it (a lane per (scenario, store), the
+// warehouse lanes summing their shipments themselves, every store lane recomputing its suppliers' on-hand gradient): must equal
+// the quad composition above bit for bit.  Settings without extra echelons.
+template <int MAXW>
+static void fwd_per_store(const NicEnvStepIO& io, float* so, float* wo, float* r) {
+    const NicEnvDims& d = io.dims;
+    for (int64_t b = 0; b < d.n_scenarios; ++b) {
+        float cst[256], rq[nic::kQuad] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < d.n_stores; ++s) cst[s] = nic::env_fwd_one_store<MAXW>(io, so, b, s);
+        for (int q = 0; q < nic::kQuad; ++q)
+            for (int s = q; s < d.n_stores; s += nic::kQuad) rq[q] += cst[s];
+        float total = nic::combine4(rq[0], rq[1], rq[2], rq[3]);
+        if (d.n_warehouses > 0) {
+            float r_wh = 0.f;
+            for (int w = 0; w < d.n_warehouses; ++w) {
+                const float shipped = nic::combine4(nic::env_ship_partial(io, w, b, 0), nic::env_ship_partial(io, w, b, 1),
+                                                    nic::env_ship_partial(io, w, b, 2), nic::env_ship_partial(io, w, b, 3));
+                r_wh += nic::env_fwd_warehouse<MAXW>(io, wo, w, shipped, b);
+            }
+            total += r_wh;
+        }
+        r[b] = total;
+    }
+}
+template <int MAXW>
+static void bwd_per_store(const NicEnvStepIO& io, const float* gso, const float* gwo, NicTable2 gr_t, float* gsi, float* gwi,
+                          float* gas, float* gaw) {
+    const NicEnvDims& d = io.dims;
+    for (int64_t b = 0; b < d.n_scenarios; ++b) {
+        const float gr = gr_t.p[b * gr_t.scn_stride];
+        float shipped[NIC_MAX_WAREHOUSES];
+        for (int w = 0; w < d.n_warehouses; ++w) {
+            shipped[w] = nic::combine4(nic::env_ship_partial(io, w, b, 0), nic::env_ship_partial(io, w, b, 1),
+                                       nic::env_ship_partial(io, w, b, 2), nic::env_ship_partial(io, w, b, 3));
+            (void)nic::env_bwd_warehouse<MAXW>(io, gwo, gr, 0.f, w, shipped[w], gwi, gaw, b);
+        }
+        for (int s = 0; s < d.n_stores; ++s)
+            nic::env_bwd_one_store<MAXW>(io, gso, gr, [&](int w) { return nic::env_bwd_wh_g_after(io, gwo, gr, w, shipped[w], b); },
+                                         gsi, gas, b, s);
+    }
+}
+
 extern "C" {
+int hostsim_env_step_fwd_per_store(const NicEnvStepIO* io, float* so, float* wo, float* r) {
+    if (io->dims.n_echelons != 0 || io->dims.n_stores > 256) return 1;
+    fwd_per_store<NIC_MAX_SLOTS>(*io, so, wo, r);
+    return 0;
+}
+int hostsim_env_step_bwd_per_store(const NicEnvStepIO* io, const float* gso, const float* gwo, NicTable2 gr, float* gsi, float* gwi,
+                                   float* gas, float* gaw) {
+    if (io->dims.n_echelons != 0) return 1;
+    bwd_per_store<NIC_MAX_SLOTS>(*io, gso, gwo, gr, gsi, gwi, gas, gaw);
+    return 0;
+}
+int hostsim_head_data_driven(const float* Z, const float* wh, const float* mask, const float* g_so, const float* g_wo, float* so,
+                             float* wo, float* dZ, float* g_wh, int32_t S, int32_t Wn, int32_t Ww, int32_t B, int32_t ldb) {
+    for (int64_t b = 0; b < B; ++b)
+        for (int w = 0; w < Wn; ++w) {
+            nic::head_data_driven_fwd_one(Z, wh, mask, so, wo, S, Wn, Ww, ldb, b, w);
+            nic::head_data_driven_bwd_one(Z, wh, mask, g_so, g_wo, dZ, g_wh, S, Wn, Ww, ldb, b, w);
+        }
+    return 0;
+}
 int hostsim_env_step_fwd(const NicEnvStepIO* io, float* so, float* wo, float* eo, float* r) {
     fwd_all<NIC_MAX_SLOTS>(*io, so, wo, eo, r);
     return 0;

@@ -40,6 +40,9 @@ def load():
     IOP = C.POINTER(_lib.NicEnvStepIO)
     h.hostsim_env_step_fwd.argtypes = [IOP, vp, vp, vp, vp]
     h.hostsim_env_step_bwd.argtypes = [IOP, vp, vp, vp, _lib.NicTable2, vp, vp, vp, vp, vp, vp]
+    h.hostsim_env_step_fwd_per_store.argtypes = [IOP, vp, vp, vp]
+    h.hostsim_env_step_bwd_per_store.argtypes = [IOP, vp, vp, _lib.NicTable2, vp, vp, vp, vp]
+    h.hostsim_head_data_driven.argtypes = [vp] * 9 + [i32] * 5
     h.hostsim_head_warehouse_fwd.argtypes = [vp, vp, vp, f32, i32, vp, vp, i32, i32, i32, i32, i32]
     h.hostsim_head_warehouse_bwd.argtypes = [vp, vp, vp, f32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32]
     h.hostsim_head_softplus_fwd.argtypes = [vp, vp, i32, i32, i32]

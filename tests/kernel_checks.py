@@ -147,7 +147,8 @@ def check_env_forward(be, name):
     for t in range(T):
         s, w, e = _state_soa({k: v.float() for k, v in g.states(t).items()}, prob, dev)
         ts, tw, te, _keep = _orders_tables({k: v.float() for k, v in g.actions(t).items()}, dev)
-        io = prob.make_io(s, w, e, _demand_table(demands, t + shift), ts, tw, te)
+        dem_t = _demand_table(demands, t + shift)   # (kept alive: the io holds raw addresses)
+        io = prob.make_io(s, w, e, dem_t, ts, tw, te)
         so = torch.zeros_like(s)
         wo = torch.zeros_like(w) if w is not None else None
         eo = torch.zeros_like(e) if e is not None else None
@@ -274,7 +275,8 @@ def check_env_backward(be, name, profit):
 
         s, w, e = _state_soa({k: v.detach() for k, v in st.items()}, prob, dev)
         ts, tw, te, _keep = _orders_tables({k: v.detach() for k, v in act.items()}, dev)
-        io = prob.make_io(s, w, e, _demand_table(demands, t + shift), ts, tw, te)
+        dem_t = _demand_table(demands, t + shift)   # (kept alive: the io holds raw addresses)
+        io = prob.make_io(s, w, e, dem_t, ts, tw, te)
         gso = to_soa(g_out["store_inventories"].to(dev), prob.ldb)
         gwo = to_soa(g_out["warehouse_inventories"].to(dev), prob.ldb) if prob.Wn else None
         geo = to_soa(g_out["echelon_inventories"].to(dev), prob.ldb) if prob.E else None
