@@ -384,7 +384,8 @@ def bench_epoch(args):
            "config": {"workload": desc + "; training step = one shuffled batch: rollout fwd + bwd + Adam", "name": args.workload,
                       "samples": n_samples, "batch_size": pbd["batch_size"], "batches_per_epoch": n_batches, "stores": S, "periods": T,
                       "parallelism": f"scenario-sharded dp{world}", "train_loss_per_store_period": last[1],
-                      "route": type(eng).__name__ if eng is not None else "generic",
+                      "route": (type(eng).__name__ + (" (whole-horizon kernels)" if getattr(eng, "horizon", None) is not None else ""))
+                      if eng is not None else "generic",
                       "rollout_graph": {"setting": tr.use_rollout_graph, "replaying": bool(eng is not None and eng._graph_on()),
                                         "auto_probe": getattr(eng, "auto_graph_probe", None)}}}
     if eng is not None and not args.no_kernel_timing:
@@ -396,6 +397,14 @@ def bench_epoch(args):
             epoch(); epoch(); epoch()
             alt[label + "_ms_per_epoch"] = round(timed(n_epochs)[0] * 1e3, 3)
         tr.use_rollout_graph = was
+        if getattr(eng, "horizon", None) is not None:   # the same epoch on the per-period kernels (eager, then replayed)
+            eng.use_horizon = False
+            for label, mode in (("per_period_route_eager", False), ("per_period_route_graph", True)):
+                tr.use_rollout_graph = mode
+                epoch(); epoch(); epoch()
+                alt[label + "_ms_per_epoch"] = round(timed(n_epochs)[0] * 1e3, 3)
+            eng.use_horizon, tr.use_rollout_graph = True, was
+            epoch()
         from torch.utils.data import DataLoader
         host = DataLoader(loaders["train"].dataset, batch_size=pbd["batch_size"], shuffle=True)
         epoch(host)
@@ -411,7 +420,7 @@ def bench_epoch(args):
         tr.use_rollout_graph = was
         prob = eng.prob
         shape = dict(n=pbd["batch_size"], T=T, S=S, Wn=prob.Wn, E=prob.E, Ws=prob.Ws, Ww=prob.Ww, We=prob.We, F=eng.dims[0],
-                     nh=len(eng.dims) - 2, n_out=eng.dims[-1], train=True, gnn=None)
+                     nh=len(eng.dims) - 2, n_out=eng.dims[-1], train=True, gnn=None, hidden=list(eng.dims[1:-1]))
         kernels = kernel_report(timer, shape, n_batches)
         rated = {k: v for k, v in kernels.items() if "bound" in v}
         if rated:
@@ -428,7 +437,7 @@ def bench_epoch(args):
         try:
             import copy
             st2, hy2, _ = workloads.get_epoch(args.workload)
-            out["cpu_baseline"] = cpu_baseline(args.workload, pbd["batch_size"], T, setting_policy=(st2, hy2["nn_params"]))
+            out["cpu_baseline"] = cpu_baseline(args.workload, pbd["batch_size"], T, model=model, setting_policy=(st2, hy2["nn_params"]))
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         except Exception as e:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"value": None, "unit": "scenario-steps/s", "cores": None, "host_cores": os.cpu_count(),

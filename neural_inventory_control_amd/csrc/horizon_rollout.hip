@@ -172,6 +172,19 @@ __device__ __forceinline__ NicEnvStepIO hz_stage_tables(const NicHorizonDesc& d,
     return io;
 }
 
+// rows r = r0, r0 + 16, ... < n of a [row][16] LDS array or of a global history.  The trip count is UNIFORM (scalar branch) and the
+// ragged last group gets a clamped row index plus a `valid` flag: loads stay unconditional (no exec-mask branch per access).
+template <int MAXU, class F>
+__device__ __forceinline__ void for_rows(int n, int r0, F&& f) {
+    const int n_u = (n + 15) >> 4;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u)
+        if (u < n_u) {
+            const int r = r0 + 16 * u;
+            f(u, r < n ? r : n - 1, r < n);
+        }
+}
+
 // second output tile of wave w (logits rows beyond 64)
 __device__ __forceinline__ int out_tile(int wave, int u) { return u == 0 ? wave : 4 + (3 - wave); }
 
@@ -218,7 +231,8 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const NicEnvDims& D = d.io.dims;
     const HzIds I = hz_ids();
-    const int64_t b = (int64_t)blockIdx.x * NB + I.j, ld = D.ldb, hs = d.hist_stride;
+    // (32-bit element offsets into every global buffer: the launcher checks that none reaches 2^31)
+    const uint32_t b = blockIdx.x * NB + I.j, ld = D.ldb, hs = (uint32_t)d.hist_stride;
     const bool live = b < D.n_scenarios;
     const int S = D.n_stores, Wn = D.n_warehouses, nsup = Wn > 0 ? Wn : 1, Ww = D.warehouse_slots;
     const int FD = S * D.store_slots + Wn * Ww, n_ord = S * nsup + Wn, NOp = up(d.n_out, 16);
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
 
     // ---- period 0: state; the first z1_obs rows and demand into the prefetch registers ----
     for (int r = I.r0; r < rows_st; r += 16) {
-        lds[L.st0 + r * NB + I.j] = (r < FD && live) ? state0[(int64_t)r * ld + b] : 0.f;
+        lds[L.st0 + r * NB + I.j] = (r < FD && live) ? state0[(uint32_t)r * ld + b] : 0.f;
         lds[L.st1 + r * NB + I.j] = 0.f;
     }
     for (int r = I.r0; r < NOp; r += 16) lds[L.z + r * NB + I.j] = 0.f;
@@ -271,27 +285,19 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * I.wave + 4 * I.g + i;
-                z1[i] = (r < H1 && live) ? z1_obs[(int64_t)r * hs + (int64_t)t * ld + b] : 0.f;
+                z1[i] = (r < H1 && live) ? z1_obs[(uint32_t)r * hs + (uint32_t)t * ld + b] : 0.f;
             }
         } else {
-#pragma unroll
-            for (int u = 0; u < kMaxOut / 16; ++u) {
-                const int r = I.r0 + 16 * u;
-                tape_pf[u] = (r < n_tape && live) ? d.tape[(int64_t)r * hs + (int64_t)t * ld + b] : 0.f;
-            }
+            for_rows<kMaxOut / 16>(n_tape, I.r0, [&](int u, int r, bool) { tape_pf[u] = d.tape[(uint32_t)r * hs + (uint32_t)t * ld + b]; });
         }
-#pragma unroll
-        for (int u = 0; u < kMaxStores / 16; ++u) {
-            const int r = I.r0 + 16 * u;
-            dem_pf[u] = r < S ? d.demand[((int64_t)(d.t0 + t) * S + r) * ld + b] : 0.f;
-        }
+        for_rows<kMaxStores / 16>(S, I.r0, [&](int u, int r, bool) { dem_pf[u] = d.demand[((uint32_t)(d.t0 + t) * S + r) * ld + b]; });
     };
     prefetch(0);
     // results of the previous period, stored at the top of the next one
     f32x4 h1_p = {0.f, 0.f, 0.f, 0.f}, h2_p = h1_p, z_p[2] = {h1_p, h1_p};
     float reward_p = 0.f, ship_p[2] = {0.f, 0.f};
     auto flush = [&](int t) {   // histories of period t (the order block in LDS still holds period t's orders)
-        const int64_t at = (int64_t)t * ld + b;
+        const uint32_t at = (uint32_t)t * ld + b;
         if (!live) return;
         if (I.r0 == 0) rewards[at] = reward_p;
         if (!state_hist) return;
@@ -299,15 +305,17 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
         for (int i = 0; i < 4; ++i) {
             if (mode != 0) break;
             const int r = 16 * I.wave + 4 * I.g + i;
-            if (r < H1) h1_hist[(int64_t)r * hs + at] = h1_p[i];
-            if (r < H2) h2_hist[(int64_t)r * hs + at] = h2_p[i];
+            if (r < H1) h1_hist[(uint32_t)r * hs + at] = h1_p[i];
+            if (r < H2) h2_hist[(uint32_t)r * hs + at] = h2_p[i];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int ro = 16 * out_tile(I.wave, u) + 4 * I.g + i;
-                if (ro < d.n_out) logits_hist[(int64_t)ro * hs + at] = z_p[u][i];
+                if (ro < d.n_out) logits_hist[(uint32_t)ro * hs + at] = z_p[u][i];
             }
         }
-        for (int r = I.r0; r < n_ord + Wn; r += 16) orders_hist[(int64_t)r * hs + at] = lds[L.ord + r * NB + I.j];
+        for_rows<kMaxOut / 16 + 2>(n_ord + Wn, I.r0, [&](int, int r, bool ok) {
+            if (ok) orders_hist[(uint32_t)r * hs + at] = lds[L.ord + r * NB + I.j];
+        });
     };
     lds_barrier();
 
@@ -317,18 +325,18 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
         HZ_STAMP(t, 0);
         // ---- top of the period: consume the prefetch, then ONE burst of global traffic ----
         f32x4 acc0 = {z1[0], z1[1], z1[2], z1[3]}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < kMaxStores / 16; ++u) {
-            const int r = I.r0 + 16 * u;
-            if (r < S) lds[L.dem + r * NB + I.j] = dem_pf[u];   // (read next in the env phase, four barriers down)
-        }
+        for_rows<kMaxStores / 16>(S, I.r0, [&](int u, int r, bool ok) {
+            if (ok) lds[L.dem + r * NB + I.j] = dem_pf[u];   // (read next in the env phase, four barriers down)
+        });
         float tape_now[kMaxOut / 16];
 #pragma unroll
         for (int u = 0; u < kMaxOut / 16; ++u) tape_now[u] = tape_pf[u];
         prefetch(t + 1 < d.T ? t + 1 : t);
         if (t > 0) flush(t - 1);
         if (state_hist && live)
-            for (int r = I.r0; r < FD; r += 16) state_hist[(int64_t)r * hs + (int64_t)t * ld + b] = cur[r * NB + I.j];
+            for_rows<kMaxFD / 16>(FD, I.r0, [&](int, int r, bool ok) {
+                if (ok) state_hist[(uint32_t)r * hs + (uint32_t)t * ld + b] = cur[r * NB + I.j];
+            });
         HZ_STAMP(t, 1);
         io.store_inv = cur;
         io.wh_inv = cur + S * D.store_slots * NB;
@@ -336,11 +344,9 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
         float* wo = lds + L.ord + S * nsup * NB;
         const float* Z = lds + L.z;
         if (mode != 0) {   // the period's tape rows: orders as they are (mode 1), or levels parked in the logits block (mode 2)
-#pragma unroll
-            for (int u = 0; u < kMaxOut / 16; ++u) {
-                const int r = I.r0 + 16 * u;
-                if (r < n_tape) lds[(mode == 1 ? L.ord : L.z) + r * NB + I.j] = (mode == 1 && d.round_orders) ? rintf(tape_now[u]) : tape_now[u];
-            }
+            for_rows<kMaxOut / 16>(n_tape, I.r0, [&](int u, int r, bool ok) {
+                if (ok) lds[(mode == 1 ? L.ord : L.z) + r * NB + I.j] = (mode == 1 && d.round_orders) ? rintf(tape_now[u]) : tape_now[u];
+            });
             lds_barrier();
         } else {
         // ---- layer 1: z1_obs (observation rows + bias, contracted outside) + W1[state rows] x state ----
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
     flush(d.T - 1);
     if (state_final && live) {
         const float* fin = lds + ((d.T & 1) ? L.st1 : L.st0);
-        for (int r = I.r0; r < FD; r += 16) state_final[(int64_t)r * ld + b] = fin[r * NB + I.j];
+        for (int r = I.r0; r < FD; r += 16) state_final[(uint32_t)r * ld + b] = fin[r * NB + I.j];
     }
 }
 
@@ -480,7 +486,8 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const NicEnvDims& D = d.io.dims;
     const HzIds I = hz_ids();
-    const int64_t b = (int64_t)blockIdx.x * NB + I.j, ld = D.ldb, hs = d.hist_stride;
+    // (32-bit element offsets into every global buffer: the launcher checks that none reaches 2^31)
+    const uint32_t b = blockIdx.x * NB + I.j, ld = D.ldb, hs = (uint32_t)d.hist_stride;
     const bool live = b < D.n_scenarios;
     const int S = D.n_stores, Wn = D.n_warehouses, nsup = Wn > 0 ? Wn : 1, Ww = D.warehouse_slots;
     const int FD = S * D.store_slots + Wn * Ww, FDp = up(FD, 16), n_ord = S * nsup + Wn;
@@ -516,46 +523,34 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
     // what a period needs from the histories, fetched one period ahead into registers
     float p_st[kMaxFD / 16], p_z[kMaxOut / 16], p_ord[kMaxOut / 16 + 2], p_dem[kMaxStores / 16], p_h1[4], p_h2[4];
     auto fetch = [&](int t) {
-        const int64_t at = (int64_t)t * ld + b;
-#pragma unroll
-        for (int u = 0; u < kMaxFD / 16; ++u) {
-            const int r = I.r0 + 16 * u;
-            p_st[u] = r < FD ? state_hist[(int64_t)r * hs + at] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < kMaxOut / 16; ++u) {
-            const int r = I.r0 + 16 * u;
-            p_z[u] = r < d.n_out ? (mode == 0 ? logits_hist : d.tape)[(int64_t)r * hs + at] : 0.f;   // (mode 2: the levels)
-        }
-#pragma unroll
-        for (int u = 0; u < kMaxOut / 16 + 2; ++u) {   // orders (n_ord == n_out rows) + what the warehouses shipped (Wn <= 32 rows)
-            const int r = I.r0 + 16 * u;
-            p_ord[u] = r < n_ord + Wn ? orders_hist[(int64_t)r * hs + at] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < kMaxStores / 16; ++u) {
-            const int r = I.r0 + 16 * u;
-            p_dem[u] = r < S ? d.demand[((int64_t)(d.t0 + t) * S + r) * ld + b] : 0.f;
-        }
+        const uint32_t at = (uint32_t)t * ld + b;
+        const float* zsrc = mode == 0 ? logits_hist : d.tape;   // (mode 2: the levels)
+        for_rows<kMaxFD / 16>(FD, I.r0, [&](int u, int r, bool) { p_st[u] = state_hist[(uint32_t)r * hs + at]; });
+        for_rows<kMaxOut / 16>(d.n_out, I.r0, [&](int u, int r, bool) { p_z[u] = zsrc[(uint32_t)r * hs + at]; });
+        // orders (n_ord == n_out rows) + what the warehouses shipped (Wn <= 32 rows)
+        for_rows<kMaxOut / 16 + 2>(n_ord + Wn, I.r0, [&](int u, int r, bool) { p_ord[u] = orders_hist[(uint32_t)r * hs + at]; });
+        for_rows<kMaxStores / 16>(S, I.r0, [&](int u, int r, bool) { p_dem[u] = d.demand[((uint32_t)(d.t0 + t) * S + r) * ld + b]; });
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 16 * I.wave + 4 * I.g + i;
-            p_h1[i] = r < H1 ? h1_hist[(int64_t)r * hs + at] : 0.f;
-            p_h2[i] = r < H2 ? h2_hist[(int64_t)r * hs + at] : 0.f;
+            p_h1[i] = r < H1 ? h1_hist[(uint32_t)r * hs + at] : 0.f;
+            p_h2[i] = r < H2 ? h2_hist[(uint32_t)r * hs + at] : 0.f;
         }
     };
     fetch(d.T - 1);
     f32x4 dz2_p = {0.f, 0.f, 0.f, 0.f}, dz1_p = dz2_p;
     auto flush = [&](int t) {   // pre-activation gradients of period t (the dz3 block in LDS still holds period t's)
         if (!live) return;
-        const int64_t at = (int64_t)t * ld + b;
+        const uint32_t at = (uint32_t)t * ld + b;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 16 * I.wave + 4 * I.g + i;
-            if (r < H2) dz2_hist[(int64_t)r * hs + at] = dz2_p[i];   // (tape modes: H1 = H2 = 0)
-            if (r < H1) dz1_hist[(int64_t)r * hs + at] = dz1_p[i];
+            if (r < H2) dz2_hist[(uint32_t)r * hs + at] = dz2_p[i];   // (tape modes: H1 = H2 = 0)
+            if (r < H1) dz1_hist[(uint32_t)r * hs + at] = dz1_p[i];
         }
-        for (int r = I.r0; r < d.n_out; r += 16) dz3_hist[(int64_t)r * hs + at] = lds[L.dz3 + r * NB + I.j];
+        for_rows<kMaxOut / 16>(d.n_out, I.r0, [&](int, int r, bool ok) {
+            if (ok) dz3_hist[(uint32_t)r * hs + at] = lds[L.dz3 + r * NB + I.j];
+        });
     };
     lds_barrier();
 
@@ -565,26 +560,10 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
         HZ_STAMP(t, 0);
         // ---- top of the period: this period's history out of the prefetch registers, then ONE burst of global traffic ----
         float h1v[4], h2v[4];
-#pragma unroll
-        for (int u = 0; u < kMaxFD / 16; ++u) {
-            const int r = I.r0 + 16 * u;
-            if (r < FD) lds[L.st0 + r * NB + I.j] = p_st[u];
-        }
-#pragma unroll
-        for (int u = 0; u < kMaxOut / 16; ++u) {
-            const int r = I.r0 + 16 * u;
-            if (r < d.n_out) lds[L.z + r * NB + I.j] = p_z[u];
-        }
-#pragma unroll
-        for (int u = 0; u < kMaxOut / 16 + 2; ++u) {
-            const int r = I.r0 + 16 * u;
-            if (r < n_ord + Wn) lds[L.ord + r * NB + I.j] = p_ord[u];
-        }
-#pragma unroll
-        for (int u = 0; u < kMaxStores / 16; ++u) {
-            const int r = I.r0 + 16 * u;
-            if (r < S) lds[L.dem + r * NB + I.j] = p_dem[u];
-        }
+        for_rows<kMaxFD / 16>(FD, I.r0, [&](int u, int r, bool ok) { if (ok) lds[L.st0 + r * NB + I.j] = p_st[u]; });
+        for_rows<kMaxOut / 16>(d.n_out, I.r0, [&](int u, int r, bool ok) { if (ok) lds[L.z + r * NB + I.j] = p_z[u]; });
+        for_rows<kMaxOut / 16 + 2>(n_ord + Wn, I.r0, [&](int u, int r, bool ok) { if (ok) lds[L.ord + r * NB + I.j] = p_ord[u]; });
+        for_rows<kMaxStores / 16>(S, I.r0, [&](int u, int r, bool ok) { if (ok) lds[L.dem + r * NB + I.j] = p_dem[u]; });
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             h1v[i] = p_h1[i];
@@ -750,6 +729,18 @@ int validate(const NicHorizonDesc* d, const char* who) {
     return 0;
 }
 
+// the kernels index every global buffer with 32-bit element offsets
+int check_offsets(const NicHorizonDesc* d, const char* who) {
+    const NicEnvDims& D = d->io.dims;
+    const int64_t FD = D.n_stores * D.store_slots + D.n_warehouses * D.warehouse_slots;
+    int64_t rows = FD > d->n_out + D.n_warehouses ? FD : d->n_out + D.n_warehouses;
+    if (d->head_mode == 0 && rows < kMaxH) rows = kMaxH;
+    NIC_REQUIRE(rows * d->hist_stride + (int64_t)d->T * D.ldb < (1ll << 31), "%s: histories of %lld rows x stride %lld exceed 32-bit offsets",
+                who, (long long)rows, (long long)d->hist_stride);
+    NIC_REQUIRE((int64_t)(d->t0 + d->T + 1) * D.n_stores * D.ldb < (1ll << 31), "%s: demand trace exceeds 32-bit offsets", who);
+    return 0;
+}
+
 int lds_bytes(const NicHorizonDesc* d, bool bwd) { return hz_layout(d->io.dims, d->n_out, bwd).total * (int)sizeof(float); }
 
 template <typename K>
@@ -773,7 +764,7 @@ extern "C" int nic_tuning_set_horizon_stamps(void* buf) {   // buf: device memor
 extern "C" {
 
 int nic_horizon_rollout_ok(const NicHorizonDesc* d) {
-    if (validate(d, "nic_horizon_rollout_ok")) return 0;
+    if (validate(d, "nic_horizon_rollout_ok") || check_offsets(d, "nic_horizon_rollout_ok")) return 0;
     return lds_bytes(d, true) <= 160 * 1024 ? 1 : 0;
 }
 
@@ -781,6 +772,7 @@ int nic_horizon_rollout_fwd(const NicHorizonDesc* d, const float* z1_obs, const 
                             float* state_hist, float* h1_hist, float* h2_hist, float* logits_hist, float* orders_hist,
                             void* stream) {
     if (int e = validate(d, "nic_horizon_rollout_fwd")) return e;
+    if (int e = check_offsets(d, "nic_horizon_rollout_fwd")) return e;
     NIC_REQUIRE((z1_obs || d->head_mode != 0) && state0 && rewards, "nic_horizon_rollout_fwd: null z1_obs / state0 / rewards");
     NIC_REQUIRE(!state_hist || (orders_hist && (d->head_mode != 0 || (h1_hist && h2_hist && logits_hist))),
                 "nic_horizon_rollout_fwd: histories come together");
@@ -809,6 +801,7 @@ int nic_horizon_rollout_bwd(const NicHorizonDesc* d, const float* state_hist, co
                             const float* logits_hist, const float* orders_hist, NicTable2 g_reward, float* dz1_hist,
                             float* dz2_hist, float* dz3_hist, void* stream) {
     if (int e = validate(d, "nic_horizon_rollout_bwd")) return e;
+    if (int e = check_offsets(d, "nic_horizon_rollout_bwd")) return e;
     NIC_REQUIRE(d->head_mode != 1, "nic_horizon_rollout_bwd: an order tape has no gradient");
     NIC_REQUIRE(state_hist && orders_hist && g_reward.p && dz3_hist, "nic_horizon_rollout_bwd: null buffer");
     NIC_REQUIRE(d->head_mode != 0 || (h1_hist && h2_hist && logits_hist && dz1_hist && dz2_hist), "nic_horizon_rollout_bwd: null buffer");

@@ -279,6 +279,25 @@ EPOCH_WORKLOADS = {
 }
 
 
+def _real_data_as_shipped():
+    """many_warehouses_real_data_lost_demand.yml:14-57 around the stand-in files of `real_data()`: 288 products, datasets split BY
+    PERIOD (train weeks 0-111, dev 88-141, test 118-171), training batches of 72 products x 95 weeks (the first 16 ignored)."""
+    s_ = real_data()
+    s_["test_seeds"] = dict(_SEEDS, demand=65)
+    s_["sample_data_params"] = {"split_by_period": True, "train_periods": "(0, 111)", "dev_periods": "(88, 141)",
+                                "test_periods": "(118, 171)"}
+    s_["params_by_dataset"] = {"train": {"n_samples": 288, "batch_size": 72, "periods": 95, "ignore_periods": 16},
+                               "dev": {"n_samples": 288, "batch_size": 288, "periods": 37, "ignore_periods": 16},
+                               "test": {"n_samples": 288, "batch_size": 288, "periods": 37, "ignore_periods": 16}}
+    return s_
+
+
+EPOCH_WORKLOADS["real_data_yaml"] = (
+    _real_data_as_shipped, lambda: _hyperparams(data_driven_policy(), lr=0.003),
+    "many_warehouses_real_data_lost_demand.yml + data_driven_net.yml as shipped (synthetic stand-in files): 288 products x 21 stores "
+    "x 3 warehouses, 4 batches of 72 x T=95 (ignore 16), one training epoch through Trainer.do_one_epoch")
+
+
 def get_epoch(name):
     setting, hyper, desc = EPOCH_WORKLOADS[name]
     return copy.deepcopy(setting()), copy.deepcopy(hyper()), desc

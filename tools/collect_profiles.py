@@ -157,8 +157,9 @@ def main():
             traffic_pass(rnd, a.split(":", 1)[1], out)
         return
     workloads = sys.argv[2:] or ["cfg3", "cfg3_shard8", "cfg3_batch1024", "cfg3_yaml", "cfg5_yaml", "cfg2", "cfg4", "cfg5", "cfg1",
-                                 "gnn", "gnn_many_warehouses", "base_stock", "base_stock_1m", "echelon_stock", "real_data_driven"]
-    epoch = ("cfg3_yaml", "cfg5_yaml")   # a step = one batch of an epoch of 8: whole epochs
+                                 "gnn", "gnn_many_warehouses", "base_stock", "base_stock_1m", "echelon_stock", "real_data_driven",
+                                 "real_data_yaml"]
+    epoch = ("cfg3_yaml", "cfg5_yaml", "real_data_yaml")   # a step = one batch of an epoch (8 or 4 batches): whole epochs
     out = os.path.join(ROOT, "gpurun_out", rnd)
     os.makedirs(out, exist_ok=True)
     for w in workloads:
@@ -177,7 +178,7 @@ def main():
                              os.path.join(out, f"{rnd}_bench_{w}_kernel_by_grid.csv"))
         import shutil
         shutil.rmtree(prof, ignore_errors=True)   # (the raw traces are tens of MB; the summaries above are what is kept)
-        if w in ("base_stock", "echelon_stock", "real_data_driven"):   # launch-bound steps: also replayed from one HIP graph
+        if w in ("base_stock", "echelon_stock"):   # launch-bound steps: also replayed from one HIP graph
             run(["python3", "bench.py", "--workload", w, "--graph", "--no-cpu-baseline"] + steps,
                 os.path.join(out, f"{rnd}_bench_{w}_graph.json"))
         print(w, open(os.path.join(out, f"{rnd}_bench_{w}.json")).read()[:300], flush=True)
