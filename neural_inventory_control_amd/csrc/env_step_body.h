@@ -167,43 +167,6 @@ NIC_HD float env_fwd_stores(const NicEnvStepIO& io, float* store_out, int64_t b,
     return r;
 }
 
-// ONE store: the same arithmetic as a store of env_fwd_stores' batches (cost, lost-demand clip, pipeline shift, order placement).
-// For kernels that give every (scenario, store) pair its own lane (csrc/horizon_rollout.hip: the state sits in LDS, the chain of a
-// lane is what matters, not the number of loads in flight).  Returns the store's cost.
-template <int MAXW>
-NIC_HD float env_fwd_one_store(const NicEnvStepIO& io, float* store_out, int64_t b, int s) {
-    const NicEnvDims& d = io.dims;
-    const int64_t ldb = d.ldb;
-    const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
-    float old[MAXW], nv[MAXW], ord[kSupBatch], lead[kSupBatch];
-    load_pipeline<MAXW>(io.store_inv + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, old);
-    const float dem = t2(io.demand, s, b), p = t2(io.underage, s, b), h = t2(io.holding, s, b);
-#pragma unroll
-    for (int w = 0; w < kSupBatch; ++w) {
-        if (w < nsup) {
-            ord[w] = t3(io.store_orders, s, w, b);
-            lead[w] = t3(io.lead_times, s, w, b);
-        }
-    }
-    const float on_hand = old[0];
-    float after = on_hand - dem;
-    float c;
-    if (d.maximize_profit) {
-        c = (-p) * (on_hand < dem ? on_hand : dem) + h * relu(after);  // :191-194
-    } else {
-        c = p * relu(-after) + h * relu(after);  // :198-201
-    }
-    if (d.lost_demand) after = relu(after);  // :204-205
-    shift_loaded<MAXW>(old, d.store_slots, after, nv);
-#pragma unroll
-    for (int w = 0; w < kSupBatch; ++w)
-        if (w < nsup) place_order<MAXW>(nv, d.store_slots, ord[w], lead[w]);
-    for (int w = kSupBatch; w < nsup; ++w)
-        place_order<MAXW>(nv, d.store_slots, t3(io.store_orders, s, w, b), t3(io.lead_times, s, w, b));
-    store_pipeline<MAXW>(store_out + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, nv);
-    return c;
-}
-
 // this lane's share of what warehouse w ships: sum of the orders of stores s = q, q+4, ...   (:247)
 // The loads of a batch are issued together and then added in the same order as before: written as `a += load` in a loop with a
 // run-time trip count the compiler waits for each load before issuing the next (ISA: load, s_waitcnt vmcnt(0), add, branch) -
@@ -437,66 +400,6 @@ NIC_HD void env_bwd_stores(const NicEnvStepIO& io, const float* g_store_out, flo
     }
 }
 
-// ONE store of env_bwd_stores (same arithmetic; see env_fwd_one_store)
-template <int MAXW, typename GWAfter>
-NIC_HD void env_bwd_one_store(const NicEnvStepIO& io, const float* g_store_out, float gr, GWAfter g_wafter, float* g_store_in,
-                              float* g_store_orders, int64_t b, int s) {
-    const NicEnvDims& d = io.dims;
-    const int64_t ldb = d.ldb;
-    const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
-    float gn[MAXW], ord[kSupBatch], lead[kSupBatch];
-    const float on_hand = io.store_inv[(int64_t)s * d.store_slots * ldb + b];
-    const float dem = t2(io.demand, s, b), p = t2(io.underage, s, b), h = t2(io.holding, s, b);
-#pragma unroll
-    for (int w = 0; w < kSupBatch; ++w) {
-        if (w < nsup) {
-            ord[w] = t3(io.store_orders, s, w, b);
-            lead[w] = t3(io.lead_times, s, w, b);
-        }
-    }
-    load_grad<MAXW>(g_store_out ? g_store_out + (int64_t)s * d.store_slots * ldb + b : nullptr, ldb, d.store_slots, gn);
-    const float after = on_hand - dem;
-    float g_after = gn[0];
-    if (d.lost_demand && !(after >= 0.f)) g_after = 0.f;
-    float g_on_hand;
-    if (d.maximize_profit) {
-        if (after >= 0.f) g_after += gr * h;
-        const float share = on_hand < dem ? 1.f : (on_hand == dem ? 0.5f : 0.f);  // minimum() tie rule
-        g_on_hand = g_after + gr * (-p) * share;
-    } else {
-        float gc = 0.f;
-        if (-after >= 0.f) gc += -p;
-        if (after >= 0.f) gc += h;
-        g_on_hand = g_after + gr * gc;
-    }
-    store_pipeline_grad<MAXW>(g_store_in + (int64_t)s * d.store_slots * ldb + b, ldb, d.store_slots, gn, g_on_hand);
-#pragma unroll
-    for (int w = 0; w < kSupBatch; ++w) {
-        if (w < nsup) {
-            float ga = (ord[w] != 0.f) ? pick<MAXW>(gn, d.store_slots, (int)lead[w] - 1) : 0.f;
-            if (d.n_warehouses > 0) ga += -g_wafter(w);
-            g_store_orders[((int64_t)s * nsup + w) * ldb + b] = ga;
-        }
-    }
-    for (int w = kSupBatch; w < nsup; ++w) {
-        const float a = t3(io.store_orders, s, w, b);
-        float ga = (a != 0.f) ? pick<MAXW>(gn, d.store_slots, (int)t3(io.lead_times, s, w, b) - 1) : 0.f;
-        if (d.n_warehouses > 0) ga += -g_wafter(w);
-        g_store_orders[((int64_t)s * nsup + w) * ldb + b] = ga;
-    }
-}
-
-// gradient of warehouse w's post-shipping on-hand (what env_bwd_warehouse returns), without its side effects: lets every store
-// lane of a fused kernel compute it for itself instead of waiting for the warehouse lanes
-NIC_HD float env_bwd_wh_g_after(const NicEnvStepIO& io, const float* g_wh_out, float gr, int w, float shipped, int64_t b) {
-    const NicEnvDims& d = io.dims;
-    const int64_t ldb = d.ldb;
-    const float after = io.wh_inv[(int64_t)w * d.warehouse_slots * ldb + b] - shipped;
-    float g_after = g_wh_out ? g_wh_out[(int64_t)w * d.warehouse_slots * ldb + b] : 0.f;
-    if (after >= 0.f) g_after += gr * t2(io.wh_holding, w, b);
-    return g_after;
-}
-
 // reference composition for one scenario (host-side test build)
 template <int MAXW>
 NIC_HD void env_step_bwd_scenario(const NicEnvStepIO& io, const float* g_store_out, const float* g_wh_out,
@@ -516,5 +419,208 @@ NIC_HD void env_step_bwd_scenario(const NicEnvStepIO& io, const float* g_store_o
     for (int q = 0; q < kQuad; ++q)
         env_bwd_stores<MAXW>(io, g_store_out, gr, [&](int w) { return gwa[w]; }, g_store_in, g_store_orders, b, q);
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// ACCESSOR-GENERIC one-location bodies (round 4).  The whole-horizon kernels (csrc/horizon_rollout.hip) keep the state of 16
+// scenarios in LDS and give every (scenario, store) pair its own lane; their blocks are addressed by 32-bit LDS offsets with a
+// compile-time row stride, not by NicEnvStepIO's (pointer, stride, stride) tables.  (Measured: handing the io-based bodies LDS
+// pointers runs at the same speed - the compiler folds the constant strides - so this is about saying what the kernel does, not
+// about time.)  These templates are the SAME arithmetic as one store of env_fwd_stores / env_bwd_stores and as
+// env_fwd_warehouse / env_bwd_warehouse, written against an accessor `A` of one scenario:
+//   sizes / flags: S() Wn() nsup() Ws() Ww() lost() profit() has_edge()
+//   reads:  inv(s,k) dem(s) under(s) hold(s) ord(s,w) lead(s,w) | wh_inv(w,k) wh_hold(w) wh_lead(w) wh_edge(w) wh_ord(w)
+//   writes: put_inv(s,k,v) put_wh(w,k,v)                                                 (the state after the period)
+//   adjoint: g_out(s,k) gwh_out(w,k) reads; put_g_in(s,k,v) put_g_ord(s,w,v) put_gwh_in(w,k,v) put_gwh_ord(w,v) writes
+// IoAccess adapts a NicEnvStepIO (tests/hostsim composes a period from them and compares it with the quad composition bit for bit).
+// ------------------------------------------------------------------------------------------------------------
+template <int MAXW, class A>
+NIC_HD float env_fwd_store_t(const A& a, int s) {
+    const int W = a.Ws(), nsup = a.nsup();
+    float old[MAXW], nv[MAXW], ord[kSupBatch], lead[kSupBatch];
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) old[k] = k < W ? a.inv(s, k) : 0.f;
+    const float dem = a.dem(s), p = a.under(s), h = a.hold(s);
+#pragma unroll
+    for (int w = 0; w < kSupBatch; ++w) {
+        if (w < nsup) {
+            ord[w] = a.ord(s, w);
+            lead[w] = a.lead(s, w);
+        }
+    }
+    const float on_hand = old[0];
+    float after = on_hand - dem;
+    float c;
+    if (a.profit()) {
+        c = (-p) * (on_hand < dem ? on_hand : dem) + h * relu(after);  // :191-194
+    } else {
+        c = p * relu(-after) + h * relu(after);  // :198-201
+    }
+    if (a.lost()) after = relu(after);  // :204-205
+    shift_loaded<MAXW>(old, W, after, nv);
+#pragma unroll
+    for (int w = 0; w < kSupBatch; ++w)
+        if (w < nsup) place_order<MAXW>(nv, W, ord[w], lead[w]);
+    for (int w = kSupBatch; w < nsup; ++w) place_order<MAXW>(nv, W, a.ord(s, w), a.lead(s, w));
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k)
+        if (k < W) a.put_inv(s, k, nv[k]);
+    return c;
+}
+
+// what warehouse w ships = sum of its stores' orders in the Sum4 order (env_ship_partial x 4 + combine4) by ONE lane: sixteen
+// orders per batch into the four interleaved accumulators (adding +0 for a store past S changes nothing)
+template <class A>
+NIC_HD float env_shipped_t(const A& a, int w) {
+    const int S = a.S();
+    float acc[kQuad] = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < S; s0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = a.ord(s0 + u < S ? s0 + u : S - 1, w);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (s0 + u < S) acc[u & 3] += v[u];
+    }
+    return combine4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+template <int MAXW, class A>
+NIC_HD float env_fwd_warehouse_t(const A& a, int w, float shipped) {
+    const int W = a.Ww();
+    float old[MAXW], nv[MAXW];
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) old[k] = k < W ? a.wh_inv(w, k) : 0.f;
+    const float after = old[0] - shipped;
+    float c = a.wh_hold(w) * relu(after);  // :251
+    const float o = a.wh_ord(w);
+    if (a.has_edge()) c = c + a.wh_edge(w) * o;  // :254-259
+    shift_loaded<MAXW>(old, W, after, nv);
+    place_order<MAXW>(nv, W, o, a.wh_lead(w));
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k)
+        if (k < W) a.put_wh(w, k, nv[k]);
+    return c;
+}
+
+// gradient of warehouse w's post-shipping on-hand (what env_bwd_warehouse returns), without side effects
+template <class A>
+NIC_HD float env_bwd_wh_g_after_t(const A& a, float gr, int w, float shipped) {
+    const float after = a.wh_inv(w, 0) - shipped;
+    float g_after = a.gwh_out(w, 0);
+    if (after >= 0.f) g_after += gr * a.wh_hold(w);
+    return g_after;
+}
+
+// (no extra echelons: the gradient from an echelon chain into the warehouse orders, g_to_wh_orders of env_bwd_warehouse, is zero)
+template <int MAXW, class A>
+NIC_HD float env_bwd_warehouse_t(const A& a, float gr, int w, float shipped) {
+    const int W = a.Ww();
+    float gn[MAXW];
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) gn[k] = k < W ? a.gwh_out(w, k) : 0.f;
+    const float after = a.wh_inv(w, 0) - shipped;
+    const float o = a.wh_ord(w);
+    float ga = (o != 0.f) ? pick<MAXW>(gn, W, (int)a.wh_lead(w) - 1) : 0.f;
+    if (a.has_edge()) ga += gr * a.wh_edge(w);
+    ga += 0.f;
+    a.put_gwh_ord(w, ga);
+    float g_after = gn[0];
+    if (after >= 0.f) g_after += gr * a.wh_hold(w);
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k)
+        if (k < W) a.put_gwh_in(w, k, k == 0 ? g_after : (k == 1 ? gn[0] : gn[k - 1]));
+    return g_after;
+}
+
+template <int MAXW, class A, class GWAfter>
+NIC_HD void env_bwd_store_t(const A& a, float gr, GWAfter g_wafter, int s) {
+    const int W = a.Ws(), nsup = a.nsup();
+    float gn[MAXW], ord[kSupBatch], lead[kSupBatch];
+    const float on_hand = a.inv(s, 0);
+    const float dem = a.dem(s), p = a.under(s), h = a.hold(s);
+#pragma unroll
+    for (int w = 0; w < kSupBatch; ++w) {
+        if (w < nsup) {
+            ord[w] = a.ord(s, w);
+            lead[w] = a.lead(s, w);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) gn[k] = k < W ? a.g_out(s, k) : 0.f;
+    const float after = on_hand - dem;
+    float g_after = gn[0];
+    if (a.lost() && !(after >= 0.f)) g_after = 0.f;
+    float g_on_hand;
+    if (a.profit()) {
+        if (after >= 0.f) g_after += gr * h;
+        const float share = on_hand < dem ? 1.f : (on_hand == dem ? 0.5f : 0.f);  // minimum() tie rule
+        g_on_hand = g_after + gr * (-p) * share;
+    } else {
+        float gc = 0.f;
+        if (-after >= 0.f) gc += -p;
+        if (after >= 0.f) gc += h;
+        g_on_hand = g_after + gr * gc;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k)
+        if (k < W) a.put_g_in(s, k, k == 0 ? g_on_hand : (k == 1 ? gn[0] : gn[k - 1]));
+#pragma unroll
+    for (int w = 0; w < kSupBatch; ++w) {
+        if (w < nsup) {
+            float ga = (ord[w] != 0.f) ? pick<MAXW>(gn, W, (int)lead[w] - 1) : 0.f;
+            if (a.Wn() > 0) ga += -g_wafter(w);  // the outflow sum has no zero filter (:247)
+            a.put_g_ord(s, w, ga);
+        }
+    }
+    for (int w = kSupBatch; w < nsup; ++w) {
+        const float o = a.ord(s, w);
+        float ga = (o != 0.f) ? pick<MAXW>(gn, W, (int)a.lead(s, w) - 1) : 0.f;
+        if (a.Wn() > 0) ga += -g_wafter(w);
+        a.put_g_ord(s, w, ga);
+    }
+}
+
+// NicEnvStepIO of one scenario as such an accessor (host-side test build)
+struct IoAccess {
+    const NicEnvStepIO& io;
+    int64_t b;
+    float* store_out;
+    float* wh_out;
+    const float* g_store_out;
+    const float* g_wh_out;
+    float* g_store_in;
+    float* g_wh_in;
+    float* g_store_orders;
+    float* g_wh_orders;
+    NIC_HD int S() const { return io.dims.n_stores; }
+    NIC_HD int Wn() const { return io.dims.n_warehouses; }
+    NIC_HD int nsup() const { return io.dims.n_warehouses > 0 ? io.dims.n_warehouses : 1; }
+    NIC_HD int Ws() const { return io.dims.store_slots; }
+    NIC_HD int Ww() const { return io.dims.warehouse_slots; }
+    NIC_HD bool lost() const { return io.dims.lost_demand != 0; }
+    NIC_HD bool profit() const { return io.dims.maximize_profit != 0; }
+    NIC_HD bool has_edge() const { return io.wh_edge_costs.p != nullptr; }
+    NIC_HD int64_t si(int s, int k) const { return ((int64_t)s * io.dims.store_slots + k) * io.dims.ldb + b; }
+    NIC_HD int64_t wi(int w, int k) const { return ((int64_t)w * io.dims.warehouse_slots + k) * io.dims.ldb + b; }
+    NIC_HD float inv(int s, int k) const { return io.store_inv[si(s, k)]; }
+    NIC_HD float dem(int s) const { return t2(io.demand, s, b); }
+    NIC_HD float under(int s) const { return t2(io.underage, s, b); }
+    NIC_HD float hold(int s) const { return t2(io.holding, s, b); }
+    NIC_HD float ord(int s, int w) const { return t3(io.store_orders, s, w, b); }
+    NIC_HD float lead(int s, int w) const { return t3(io.lead_times, s, w, b); }
+    NIC_HD void put_inv(int s, int k, float v) const { store_out[si(s, k)] = v; }
+    NIC_HD float wh_inv(int w, int k) const { return io.wh_inv[wi(w, k)]; }
+    NIC_HD float wh_hold(int w) const { return t2(io.wh_holding, w, b); }
+    NIC_HD float wh_lead(int w) const { return t2(io.wh_lead_times, w, b); }
+    NIC_HD float wh_edge(int w) const { return t2(io.wh_edge_costs, w, b); }
+    NIC_HD float wh_ord(int w) const { return t2(io.wh_orders, w, b); }
+    NIC_HD void put_wh(int w, int k, float v) const { wh_out[wi(w, k)] = v; }
+    NIC_HD float g_out(int s, int k) const { return g_store_out ? g_store_out[si(s, k)] : 0.f; }
+    NIC_HD float gwh_out(int w, int k) const { return g_wh_out ? g_wh_out[wi(w, k)] : 0.f; }
+    NIC_HD void put_g_in(int s, int k, float v) const { g_store_in[si(s, k)] = v; }
+    NIC_HD void put_gwh_in(int w, int k, float v) const { g_wh_in[wi(w, k)] = v; }
+    NIC_HD void put_g_ord(int s, int w, float v) const { g_store_orders[((int64_t)s * nsup() + w) * io.dims.ldb + b] = v; }
+    NIC_HD void put_gwh_ord(int w, float v) const { g_wh_orders[(int64_t)w * io.dims.ldb + b] = v; }
+};
 
 }  // namespace nic

@@ -137,9 +137,44 @@ __device__ __forceinline__ HzIds hz_ids() {
     return I;
 }
 
-// the static tables of the block's 16 scenarios -> LDS, and the io the bodies see (every table [row][16], scenario stride 1)
-__device__ __forceinline__ NicEnvStepIO hz_stage_tables(const NicHorizonDesc& d, const HzLayout& L, float* lds, const HzIds& I,
-                                                          int64_t b) {
+// One scenario's view of the workgroup's LDS blocks for the accessor-generic env bodies (env_step_body.h): 32-bit float offsets with
+// the scenario column folded in, row stride NB known at compile time.
+struct LdsEnv {
+    float* l;                                                        // the workgroup's LDS
+    int o_st, o_nx, o_ord, o_dem, o_tu, o_th, o_tl, o_twh, o_twl, o_twe;   // state before / after the period, orders, demand, static tables (+ column)
+    int o_gout, o_gin, o_gord;                                        // backward: incoming / outgoing state gradients, order gradients
+    int S_, Wn_, nsup_, Ws_, Ww_, whs, flags;                         // whs = first warehouse row of a state block; flags: 1 lost, 2 profit, 4 edge
+    __device__ __forceinline__ int S() const { return S_; }
+    __device__ __forceinline__ int Wn() const { return Wn_; }
+    __device__ __forceinline__ int nsup() const { return nsup_; }
+    __device__ __forceinline__ int Ws() const { return Ws_; }
+    __device__ __forceinline__ int Ww() const { return Ww_; }
+    __device__ __forceinline__ bool lost() const { return flags & 1; }
+    __device__ __forceinline__ bool profit() const { return flags & 2; }
+    __device__ __forceinline__ bool has_edge() const { return flags & 4; }
+    __device__ __forceinline__ float inv(int s, int k) const { return l[o_st + (s * Ws_ + k) * NB]; }
+    __device__ __forceinline__ float dem(int s) const { return l[o_dem + s * NB]; }
+    __device__ __forceinline__ float under(int s) const { return l[o_tu + s * NB]; }
+    __device__ __forceinline__ float hold(int s) const { return l[o_th + s * NB]; }
+    __device__ __forceinline__ float ord(int s, int w) const { return l[o_ord + (s * nsup_ + w) * NB]; }
+    __device__ __forceinline__ float lead(int s, int w) const { return l[o_tl + (s * nsup_ + w) * NB]; }
+    __device__ __forceinline__ void put_inv(int s, int k, float v) const { l[o_nx + (s * Ws_ + k) * NB] = v; }
+    __device__ __forceinline__ float wh_inv(int w, int k) const { return l[o_st + (whs + w * Ww_ + k) * NB]; }
+    __device__ __forceinline__ float wh_hold(int w) const { return l[o_twh + w * NB]; }
+    __device__ __forceinline__ float wh_lead(int w) const { return l[o_twl + w * NB]; }
+    __device__ __forceinline__ float wh_edge(int w) const { return l[o_twe + w * NB]; }
+    __device__ __forceinline__ float wh_ord(int w) const { return l[o_ord + (S_ * nsup_ + w) * NB]; }
+    __device__ __forceinline__ void put_wh(int w, int k, float v) const { l[o_nx + (whs + w * Ww_ + k) * NB] = v; }
+    __device__ __forceinline__ float g_out(int s, int k) const { return l[o_gout + (s * Ws_ + k) * NB]; }
+    __device__ __forceinline__ float gwh_out(int w, int k) const { return l[o_gout + (whs + w * Ww_ + k) * NB]; }
+    __device__ __forceinline__ void put_g_in(int s, int k, float v) const { l[o_gin + (s * Ws_ + k) * NB] = v; }
+    __device__ __forceinline__ void put_gwh_in(int w, int k, float v) const { l[o_gin + (whs + w * Ww_ + k) * NB] = v; }
+    __device__ __forceinline__ void put_g_ord(int s, int w, float v) const { l[o_gord + (s * nsup_ + w) * NB] = v; }
+    __device__ __forceinline__ void put_gwh_ord(int w, float v) const { l[o_gord + (S_ * nsup_ + w) * NB] = v; }
+};
+
+// the static tables of the block's 16 scenarios -> LDS ([row][16], scenario stride 1), and the accessor over them
+__device__ __forceinline__ LdsEnv hz_stage_tables(const NicHorizonDesc& d, const HzLayout& L, float* lds, const HzIds& I, int64_t b) {
     const NicEnvDims& D = d.io.dims;
     const int S = D.n_stores, Wn = D.n_warehouses, nsup = Wn > 0 ? Wn : 1;
     auto fill2 = [&](int at, const NicTable2& tb, int n) {
@@ -155,21 +190,27 @@ __device__ __forceinline__ NicEnvStepIO hz_stage_tables(const NicHorizonDesc& d,
     for (int r = I.r0; r < S * nsup; r += 16)
         lds[L.tab_l + r * NB + I.j] = lt.p[(r / nsup) * lt.loc_stride + (r % nsup) * lt.sup_stride + b * lt.scn_stride];
     for (int r = I.tid; r < S * Wn; r += kThreads) lds[L.mask + r] = d.mask[r];
-    NicEnvStepIO io = d.io;
-    io.dims.ldb = NB;
-    io.dims.n_scenarios = NB;
-    io.ech_inv = nullptr;
-    io.underage = NicTable2{lds + L.tab_u, NB, 1};
-    io.holding = NicTable2{lds + L.tab_h, NB, 1};
-    io.lead_times = NicTable3{lds + L.tab_l, (int64_t)nsup * NB, NB, 1};
-    io.wh_holding = NicTable2{Wn ? lds + L.tab_wh : nullptr, NB, 1};
-    io.wh_lead_times = NicTable2{Wn ? lds + L.tab_wl : nullptr, NB, 1};
-    io.wh_edge_costs = NicTable2{(Wn && d.io.wh_edge_costs.p) ? lds + L.tab_we : nullptr, NB, 1};
-    io.demand = NicTable2{lds + L.dem, NB, 1};
-    io.store_orders = NicTable3{lds + L.ord, (int64_t)nsup * NB, NB, 1};
-    io.wh_orders = NicTable2{Wn ? lds + L.ord + S * nsup * NB : nullptr, NB, 1};
-    io.ech_orders = NicTable2{nullptr, 0, 0};
-    return io;
+    LdsEnv a;
+    a.l = lds;
+    a.o_st = a.o_nx = L.st0 + I.j;
+    a.o_ord = L.ord + I.j;
+    a.o_dem = L.dem + I.j;
+    a.o_tu = L.tab_u + I.j;
+    a.o_th = L.tab_h + I.j;
+    a.o_tl = L.tab_l + I.j;
+    a.o_twh = L.tab_wh + I.j;
+    a.o_twl = L.tab_wl + I.j;
+    a.o_twe = L.tab_we + I.j;
+    a.o_gout = a.o_gin = L.g0 + I.j;
+    a.o_gord = L.gord + I.j;
+    a.S_ = S;
+    a.Wn_ = Wn;
+    a.nsup_ = nsup;
+    a.Ws_ = D.store_slots;
+    a.Ww_ = D.warehouse_slots;
+    a.whs = S * D.store_slots;
+    a.flags = (D.lost_demand ? 1 : 0) | (D.maximize_profit ? 2 : 0) | ((Wn && d.io.wh_edge_costs.p) ? 4 : 0);
+    return a;
 }
 
 // rows r = r0, r0 + 16, ... < n of a [row][16] LDS array or of a global history.  The trip count is UNIFORM (scalar branch) and the
@@ -211,12 +252,6 @@ __device__ __forceinline__ f32x4 layer64(const float (&aW)[16], const float* hx,
     return acc + acc1;
 }
 
-// what warehouse w ships for scenario j, from the order block in LDS: the four Sum4 partials by one lane (independent chains)
-__device__ __forceinline__ float shipped_one_lane(const NicEnvStepIO& io, int w, int j) {
-    return nic::combine4(nic::env_ship_partial(io, w, j, 0), nic::env_ship_partial(io, w, j, 1), nic::env_ship_partial(io, w, j, 2),
-                         nic::env_ship_partial(io, w, j, 3));
-}
-
 // ------------------------------------------------------------------------------------------------------------------------
 // Global memory discipline of both kernels: vmcnt counts loads and stores in issue order, so waiting for ANY prefetched value also
 // drains every store issued before it.  All global traffic of a period is therefore issued in ONE burst at the top of the period
@@ -238,7 +273,7 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
     const int FD = S * D.store_slots + Wn * Ww, n_ord = S * nsup + Wn, NOp = up(d.n_out, 16);
     const int H1 = d.head_mode == 0 ? d.H1 : 0, H2 = d.head_mode == 0 ? d.H2 : 0;   // (tape modes: no layers, every weight guard false)
     const HzLayout L = hz_layout(D, d.n_out, false);
-    NicEnvStepIO io = hz_stage_tables(d, L, lds, I, b);
+    LdsEnv env = hz_stage_tables(d, L, lds, I, b);
     const int rows_st = (L.st1 - L.st0) / NB;
 
     // ---- resident weight fragments: A lane (g, j) holds W[tile row j][k(step, g)] ----
@@ -338,8 +373,9 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
                 if (ok) state_hist[(uint32_t)r * hs + (uint32_t)t * ld + b] = cur[r * NB + I.j];
             });
         HZ_STAMP(t, 1);
-        io.store_inv = cur;
-        io.wh_inv = cur + S * D.store_slots * NB;
+        env.o_st = ((t & 1) ? L.st1 : L.st0) + I.j;
+        env.o_nx = ((t & 1) ? L.st0 : L.st1) + I.j;
+        const float* wh_now = cur + S * D.store_slots * NB;
         float* so = lds + L.ord;
         float* wo = lds + L.ord + S * nsup * NB;
         const float* Z = lds + L.z;
@@ -397,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
             lds_barrier();
             for (int w = I.r0; w < Wn; w += 16) {
                 float avail = 0.f;
-                for (int k = 0; k < Ww; ++k) avail += io.wh_inv[(w * Ww + k) * NB + I.j];
+                for (int k = 0; k < Ww; ++k) avail += wh_now[(w * Ww + k) * NB + I.j];
                 float sum = 0.f;
                 for (int s0 = 0; s0 < S; s0 += nic::kHeadBatch) {
                     float a[nic::kHeadBatch];
@@ -433,15 +469,15 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
                 const float a = fmaxf(Z[s * NB + I.j], 0.f);
                 so[s * NB + I.j] = d.round_orders ? rintf(a) : a;
             }
-            lds[L.cst + s * NB + I.j] = nic::env_fwd_one_store<MAXW>(io, nxt, I.j, s);
+            lds[L.cst + s * NB + I.j] = nic::env_fwd_store_t<MAXW>(env, s);
         }
         lds_barrier();
         HZ_STAMP(t, 6);
         // ---- warehouses (tasks 0 .. Wn-1) and the Sum4 partials of the store costs (tasks Wn .. Wn+3) ----
         for (int k = I.r0; k < Wn + nic::kQuad; k += 16) {
             if (k < Wn) {
-                const float shipped = shipped_one_lane(io, k, I.j);
-                lds[L.cw + k * NB + I.j] = nic::env_fwd_warehouse<MAXW>(io, nxt + S * D.store_slots * NB, k, shipped, I.j);
+                const float shipped = nic::env_shipped_t(env, k);
+                lds[L.cw + k * NB + I.j] = nic::env_fwd_warehouse_t<MAXW>(env, k, shipped);
                 lds[L.ord + (n_ord + k) * NB + I.j] = shipped;   // (history: the backward does not re-sum the orders)
             } else {
                 float r = 0.f;
@@ -494,9 +530,8 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
     const int mode = d.head_mode;   // 0: policy MLP + data_driven head; 2: order-up-to levels from a tape (1 has no gradient)
     const int H1 = mode == 0 ? d.H1 : 0, H2 = mode == 0 ? d.H2 : 0, n_t1 = FDp / 16;
     const HzLayout L = hz_layout(D, d.n_out, true);
-    NicEnvStepIO io = hz_stage_tables(d, L, lds, I, b);
-    io.store_inv = lds + L.st0;
-    io.wh_inv = lds + L.st0 + S * D.store_slots * NB;
+    LdsEnv env = hz_stage_tables(d, L, lds, I, b);
+    const float* wh_now = lds + L.st0 + S * D.store_slots * NB;
 
     // ---- resident transposed fragments: A lane (g, j) holds W[k(step, g)][tile row j] ----
     float aW3t[MAXS3], aW2t[16], aW1t[MAXT1][16];
@@ -582,12 +617,11 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
         float* g_next_wh = g_next + S * D.store_slots * NB;
         float* g_cur_wh = g_cur + S * D.store_slots * NB;
         const float* Z = lds + L.z;
-        for (int w = I.r0; w < Wn; w += 16)
-            (void)nic::env_bwd_warehouse<MAXW>(io, g_next_wh, gr, 0.f, w, shipped[w * NB + I.j], g_cur_wh, gwo, I.j);
+        env.o_gout = (((d.T - 1 - t) & 1) ? L.g1 : L.g0) + I.j;
+        env.o_gin = (((d.T - 1 - t) & 1) ? L.g0 : L.g1) + I.j;
+        for (int w = I.r0; w < Wn; w += 16) (void)nic::env_bwd_warehouse_t<MAXW>(env, gr, w, shipped[w * NB + I.j]);
         for (int s = I.r0; s < S; s += 16) {
-            nic::env_bwd_one_store<MAXW>(io, g_next, gr,
-                                         [&](int w) { return nic::env_bwd_wh_g_after(io, g_next_wh, gr, w, shipped[w * NB + I.j], I.j); },
-                                         g_cur, gso, I.j, s);
+            nic::env_bwd_store_t<MAXW>(env, gr, [&](int w) { return nic::env_bwd_wh_g_after_t(env, gr, w, shipped[w * NB + I.j]); }, s);
             if (mode == 2) {   // order = clip(level - pipeline total, 0): clamp(min = 0) passes the gradient where its input is >= 0
                 float pos = 0.f;
                 for (int k = 0; k < D.store_slots; ++k) pos += lds[L.st0 + (s * D.store_slots + k) * NB + I.j];
@@ -613,7 +647,7 @@ __global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d,
             // per warehouse: sums in store order (head_data_driven_bwd_one's), scale / common term for its stores' logits
             for (int w = I.r0; w < Wn; w += 16) {
                 float avail = 0.f;
-                for (int k = 0; k < Ww; ++k) avail += io.wh_inv[(w * Ww + k) * NB + I.j];
+                for (int k = 0; k < Ww; ++k) avail += wh_now[(w * Ww + k) * NB + I.j];
                 float sum = 0.f, dot = 0.f;
                 for (int s0 = 0; s0 < S; s0 += nic::kHeadBatch) {
                     float a[nic::kHeadBatch], pr[nic::kHeadBatch];

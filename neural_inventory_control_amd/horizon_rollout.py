@@ -50,6 +50,13 @@ class HorizonPlan:
         return d
 
 
+def offsets_ok(prob: EnvProblem, T, t_last, hidden=0):
+    """The kernels address every history with 32-bit element offsets (rows x T x ldb) and the demand trace likewise
+    ((t_last + 1) x S x ldb): long evaluation horizons on big batches do not qualify (the C side re-checks)."""
+    rows = max(prob.S * prob.Ws + prob.Wn * prob.Ww, prob.S * prob.nsup + 2 * prob.Wn, hidden)
+    return (rows + 1) * T * prob.ldb < 2 ** 31 and (t_last + 2) * prob.S * prob.ldb < 2 ** 31
+
+
 def horizon_ok(desc):
     return bool(_lib.lib().nic_horizon_rollout_ok(desc))
 

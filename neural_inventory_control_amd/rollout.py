@@ -193,7 +193,7 @@ class FusedRollout:
     def _setup(self, prob, T, train, extra_rows=0):
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin,
                self.eval_history, self.small_wgrad_in_kernel, extra_rows, self.small_lane_scenarios, self.use_horizon,
-               self.horizon_max_scenarios)
+               self.horizon_max_scenarios, getattr(self, "_shift_hint", 0))
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
@@ -249,7 +249,8 @@ class FusedRollout:
             return
         self.horizon = None
         if (self.use_horizon and extra_rows > 0 and prob.B <= self.horizon_max_scenarios and all(m.bias is not None for m in lins)
-                and hz.HorizonPlan.supports(prob, self.head, dims)):
+                and hz.HorizonPlan.supports(prob, self.head, dims)
+                and hz.offsets_ok(prob, T, T + getattr(self, "_shift_hint", 0), hz.MAX_HIDDEN)):
             # ---- whole-horizon route for data_driven: one forward kernel, one backward kernel, four GEMMs over (period x scenario)
             # columns (the observation rows' share of the first layer; one weight gradient per layer).  Histories [row][T][ld].
             plan = self.horizon = hz.HorizonPlan(prob, dims)
@@ -407,6 +408,7 @@ class FusedRollout:
                 raise ValueError("data_driven needs a past-demand window and the days_from_christmas time feature")
             P_ = observation_params["demand"]["past_periods"]
             extra = prob.S * P_ + 2 * prob.S + data["days_from_christmas"].shape[1] + prob.S * data["lead_times"].shape[2]
+        self._shift_hint = observation_params["demand"]["period_shift"] if observation_params else 0
         self._setup(prob, T, train, extra)
         if self._graph_on():
             # a captured graph holds raw pointers: keep the first call's table tensors and refresh their CONTENTS

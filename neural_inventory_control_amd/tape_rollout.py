@@ -69,8 +69,10 @@ class TapeRollout:
         self._probs = ProblemCache()
         self._key = None
 
-    def shapes_ok(self, data):
+    def shapes_ok(self, data, periods=1, period_shift=0):
         p = self._probs.get(self.problem_params, data, self.device)
+        if not hz.offsets_ok(p, periods, periods + period_shift):
+            return False
         ok = p.E == 0 and p.S <= hz.MAX_STORES and p.S * p.Ws + p.Wn * p.Ww <= hz.MAX_STATE_ROWS and 2 <= p.Ws <= hz.MAX_SLOTS \
             and (p.Wn == 0 or 2 <= p.Ww <= hz.MAX_SLOTS) and p.S * p.nsup + p.Wn <= hz.MAX_OUT
         return ok and (self.jit or p.Wn == 0)

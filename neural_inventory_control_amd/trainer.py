@@ -239,7 +239,7 @@ class Trainer:
             eng = self._engines.get((id(model), "tape", bool(train)))
             if eng is None or eng.model is not model:
                 eng = self._engines[(id(model), "tape", bool(train))] = TapeRollout(model, problem_params, self.device)
-            if eng.shapes_ok(data_batch):
+            if eng.shapes_ok(data_batch, periods, (observation_params["demand"] or {}).get("period_shift") or 0):
                 self._last_engine = eng
                 return eng.run(data_batch, periods, ignore_periods, train=train, observation_params=observation_params,
                                discrete_allocation=discrete_allocation)

@@ -34,18 +34,15 @@ template <int MAXW>
 static void fwd_per_store(const NicEnvStepIO& io, float* so, float* wo, float* r) {
     const NicEnvDims& d = io.dims;
     for (int64_t b = 0; b < d.n_scenarios; ++b) {
+        const nic::IoAccess a{io, b, so, wo, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         float cst[256], rq[nic::kQuad] = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < d.n_stores; ++s) cst[s] = nic::env_fwd_one_store<MAXW>(io, so, b, s);
+        for (int s = 0; s < d.n_stores; ++s) cst[s] = nic::env_fwd_store_t<MAXW>(a, s);
         for (int q = 0; q < nic::kQuad; ++q)
             for (int s = q; s < d.n_stores; s += nic::kQuad) rq[q] += cst[s];
         float total = nic::combine4(rq[0], rq[1], rq[2], rq[3]);
         if (d.n_warehouses > 0) {
             float r_wh = 0.f;
-            for (int w = 0; w < d.n_warehouses; ++w) {
-                const float shipped = nic::combine4(nic::env_ship_partial(io, w, b, 0), nic::env_ship_partial(io, w, b, 1),
-                                                    nic::env_ship_partial(io, w, b, 2), nic::env_ship_partial(io, w, b, 3));
-                r_wh += nic::env_fwd_warehouse<MAXW>(io, wo, w, shipped, b);
-            }
+            for (int w = 0; w < d.n_warehouses; ++w) r_wh += nic::env_fwd_warehouse_t<MAXW>(a, w, nic::env_shipped_t(a, w));
             total += r_wh;
         }
         r[b] = total;
@@ -56,16 +53,15 @@ static void bwd_per_store(const NicEnvStepIO& io, const float* gso, const float*
                           float* gas, float* gaw) {
     const NicEnvDims& d = io.dims;
     for (int64_t b = 0; b < d.n_scenarios; ++b) {
+        const nic::IoAccess a{io, b, nullptr, nullptr, gso, gwo, gsi, gwi, gas, gaw};
         const float gr = gr_t.p[b * gr_t.scn_stride];
         float shipped[NIC_MAX_WAREHOUSES];
         for (int w = 0; w < d.n_warehouses; ++w) {
-            shipped[w] = nic::combine4(nic::env_ship_partial(io, w, b, 0), nic::env_ship_partial(io, w, b, 1),
-                                       nic::env_ship_partial(io, w, b, 2), nic::env_ship_partial(io, w, b, 3));
-            (void)nic::env_bwd_warehouse<MAXW>(io, gwo, gr, 0.f, w, shipped[w], gwi, gaw, b);
+            shipped[w] = nic::env_shipped_t(a, w);
+            (void)nic::env_bwd_warehouse_t<MAXW>(a, gr, w, shipped[w]);
         }
         for (int s = 0; s < d.n_stores; ++s)
-            nic::env_bwd_one_store<MAXW>(io, gso, gr, [&](int w) { return nic::env_bwd_wh_g_after(io, gwo, gr, w, shipped[w], b); },
-                                         gsi, gas, b, s);
+            nic::env_bwd_store_t<MAXW>(a, gr, [&](int w) { return nic::env_bwd_wh_g_after_t(a, gr, w, shipped[w]); }, s);
     }
 }
 

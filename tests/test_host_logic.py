@@ -363,3 +363,17 @@ def test_symmetry_aware_policy_is_registered_and_its_oracle_allocations_are_feas
     assert bool((act["stores"].sum(dim=(1, 2)) <= env.obs["warehouse_inventories"][:, 0, 0] + 1e-4).all())
     res, _, grads = orc.train_step_gradients(pol, 6, setting["problem_params"], data, obs)
     assert torch.isfinite(res.total) and all(torch.isfinite(g).all() for g in grads)
+
+
+def test_whole_horizon_routes_refuse_histories_beyond_32_bit_offsets():
+    """csrc/horizon_rollout.hip addresses every history with 32-bit element offsets: the host side must route long evaluation
+    horizons on big batches to the per-period kernels / the generic loop instead of handing the launcher sizes it refuses."""
+    from types import SimpleNamespace
+    from neural_inventory_control_amd import horizon_rollout as hz
+    real = SimpleNamespace(S=21, Ws=6, Wn=3, Ww=3, nsup=3, ldb=128)
+    assert hz.offsets_ok(real, 95, 111, hz.MAX_HIDDEN) and hz.offsets_ok(real, 5000, 5016, hz.MAX_HIDDEN)
+    big = SimpleNamespace(S=21, Ws=6, Wn=3, Ww=3, nsup=3, ldb=8192)
+    assert hz.offsets_ok(big, 95, 111, hz.MAX_HIDDEN)
+    assert not hz.offsets_ok(big, 5000, 5016, hz.MAX_HIDDEN)          # 135 rows x 5,000 x 8,192 elements
+    wide = SimpleNamespace(S=64, Ws=2, Wn=0, Ww=0, nsup=1, ldb=8192)
+    assert not hz.offsets_ok(wide, 10, 5000, 0)                       # the demand trace alone: 5,002 x 64 x 8,192
