@@ -171,6 +171,28 @@ def test_bench_epoch_workload_line():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 2e-3 and 0 < rf["frac"] < 1
 
 
+def test_bench_real_data_epoch_workload_line():
+    """`bench.py --workload real_data_yaml`: the shipped real-data YAML pair (stand-in files) through Trainer.do_one_epoch - 288
+    products in 4 batches of 72 x 95 weeks on the whole-horizon kernels, with the same epoch on the per-period kernels (eager and
+    replayed) reported beside it."""
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "real_data_yaml", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert cfg["samples"] == 288 and cfg["batch_size"] == 72 and cfg["batches_per_epoch"] == 4 and cfg["periods"] == 95
+    assert cfg["stores"] == 21 and cfg["route"] == "FusedRollout (whole-horizon kernels)"
+    assert abs(out["value"] - 288 * 21 * 95 / (out["ms_per_epoch"] * 1e-3)) <= 1e-6 * out["value"]
+    ev = cfg["epoch_variants"]
+    # one launch per direction instead of ~1,050: well below the per-period kernels however they are launched
+    assert out["ms_per_epoch"] < 0.6 * ev["per_period_route_graph_ms_per_epoch"] < ev["per_period_route_eager_ms_per_epoch"]
+    assert {"horizon_fwd", "horizon_bwd"} <= set(out["kernels"])
+    assert out["kernels"]["horizon_fwd"]["launches_per_step"] == 1.0 and out["kernels"]["horizon_bwd"]["launches_per_step"] == 1.0
+
+
 def test_library_mapped_before_any_torch_device_use_still_launches():
     """build() and smoke() in one process: the C-ABI library is mapped (and its code objects registered with the HIP runtime)
     before PyTorch has touched the device.  `load_library` initialises torch's device first; without that every launch from
