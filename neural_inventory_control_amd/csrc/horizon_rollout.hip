@@ -229,10 +229,7 @@ __device__ __forceinline__ void for_rows(int n, int r0, F&& f) {
 // second output tile of wave w (logits rows beyond 64)
 __device__ __forceinline__ int out_tile(int wave, int u) { return u == 0 ? wave : 4 + (3 - wave); }
 
-// Workgroup barrier that publishes LDS only.  __syncthreads() is a workgroup-scope release: it also waits for every outstanding
-// GLOBAL load and store of the wave (s_waitcnt vmcnt(0)).  Nothing the wavefronts of a workgroup exchange goes through global
-// memory here, so only the LDS counter has to drain.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+using nic::lds_barrier;   // (nic_common.h: s_waitcnt lgkmcnt(0); s_barrier - nothing the wavefronts exchange goes through global memory)
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 

@@ -57,6 +57,14 @@ inline int cu_count() {
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+#if defined(__HIPCC__)
+// Workgroup barrier that publishes LDS only.  __syncthreads() is a workgroup-scope release / acquire: in front of the s_barrier it
+// waits for every outstanding GLOBAL load and store of the wave (s_waitcnt vmcnt(0)) - a full round trip to L2 / HBM whenever the
+// wave has just written results.  Where the lanes of a workgroup exchange data through LDS alone (quad partial sums, layer-to-layer
+// activations) only the LDS counter has to drain.  NOT a substitute where one lane reads global memory another lane wrote.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
 }  // namespace nic
 
 #define NIC_REQUIRE(cond, ...) \
