@@ -84,7 +84,14 @@ class Trainer:
     def _step_graph_on(self, model, observation_params):
         """`use_step_graph` resolved for a policy: "auto" = the closed-form policies (whole-horizon kernel inside the captured step)."""
         if self.use_step_graph == "auto":
-            return bool(self.use_fused_rollout and ClosedFormRollout.supports(model) and self._plain_observation(observation_params))
+            if not self.use_fused_rollout:
+                return False
+            if ClosedFormRollout.supports(model) and self._plain_observation(observation_params):
+                return True
+            # the trainable quantile policies on the tape route: two whole-horizon launches inside ~40 small torch launches (the
+            # batched forecaster pass, the interpolation and its autograd): launch-bound at every batch size the reference uses
+            return bool(self.use_tape_rollout and TapeRollout.supports(model) and getattr(model, "trainable", True)
+                        and type(model).__name__ != "JustInTime" and TapeRollout.observation_ok(model, observation_params))
         return bool(self.use_step_graph)
 
     # ---- training / evaluation loops (trainer.py:29-141) ---------------------------------------------------------
@@ -236,9 +243,13 @@ class Trainer:
             # quantile policies / just-in-time: the decisions of all periods do not depend on the state - one batched pass computes
             # them (the forecaster runs once), one whole-horizon launch per direction does the rest (tape_rollout.py); the
             # returned total is differentiable with respect to the policy's parameters like the closed-form engine's
-            eng = self._engines.get((id(model), "tape", bool(train)))
+            # (a captured step holds the engine's buffers by address: with a step graph every (batch size, horizon, train / eval)
+            # context keeps its own engine - as for the closed-form engine above)
+            ekey = ((id(model), "tape", len(data_batch["demands"]), periods, bool(train))
+                    if self._step_graph_on(model, observation_params) else (id(model), "tape", bool(train)))
+            eng = self._engines.get(ekey)
             if eng is None or eng.model is not model:
-                eng = self._engines[(id(model), "tape", bool(train))] = TapeRollout(model, problem_params, self.device)
+                eng = self._engines[ekey] = TapeRollout(model, problem_params, self.device)
             if eng.shapes_ok(data_batch, periods, (observation_params["demand"] or {}).get("period_shift") or 0):
                 self._last_engine = eng
                 return eng.run(data_batch, periods, ignore_periods, train=train, observation_params=observation_params,
@@ -305,8 +316,9 @@ class Trainer:
         if global_batch is None:
             global_batch = getattr(self, "_global_batch", None) or len(data_batch["demands"])
         scale = 1.0 / (global_batch * periods * problem_params["n_stores"])
-        if st is None:  # eager warm-up run
-            self._step_graphs[key] = {"static": None, "model": model}
+        if st is None or st.get("eager_only"):  # eager warm-up run (or a shape whose capture was refused, see below)
+            if st is None:
+                self._step_graphs[key] = {"static": None, "model": model}
             total, rep = self.simulate_batch(loss_function, simulator, model, periods, problem_params, data_batch,
                                              observation_params, ignore_periods, False, train=True)
             (total * scale).backward()
@@ -324,18 +336,48 @@ class Trainer:
             st["grads"] = [p.grad for p in params]
             stream = torch.cuda.Stream()
             stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):  # one more eager run on the side stream (allocator / autograd warm-up)
-                total, rep = self.simulate_batch(loss_function, simulator, model, periods, problem_params, static,
-                                                 observation_params, ignore_periods, False, train=True)
-                (total * scale).backward()
+            # Gradients go into the static tensors through torch.autograd.grad + copy_, NOT through .backward(): a parameter's
+            # AccumulateGrad node is bound to the stream of the graph that created it and lives as long as any earlier result
+            # the caller still holds (a `total` of an eager simulate_batch on the default stream, say) - re-used from the capture
+            # stream it invalidates the capture, and ending an invalidated capture takes the process down on this stack.
+            def grads_into_static(loss):
+                for p, g_ in zip(params, torch.autograd.grad(loss, params, allow_unused=True)):
+                    if g_ is None:
+                        p.grad.zero_()
+                    else:
+                        p.grad.copy_(g_)
+            import warnings
+            warn_always = torch.is_warn_always_enabled()
+            torch.set_warn_always(True)   # (the hazard below is reported through a warn-once channel)
+            try:
+                with warnings.catch_warnings(record=True) as caught:
+                    warnings.simplefilter("always")
+                    with torch.cuda.stream(stream):  # one more eager run on the side stream (allocator / autograd warm-up)
+                        total, rep = self.simulate_batch(loss_function, simulator, model, periods, problem_params, static,
+                                                         observation_params, ignore_periods, False, train=True)
+                        grads_into_static(total * scale)
+            finally:
+                torch.set_warn_always(warn_always)
             torch.cuda.current_stream().wait_stream(stream)
+            pinned = [w for w in caught if "AccumulateGrad node's stream" in str(w.message)]
+            for w in caught:
+                if w not in pinned:
+                    warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+            if pinned:
+                # Something outside still holds an autograd graph of this policy from an eager step on the default stream (a
+                # `total` returned by simulate_batch, say): the parameters' gradient accumulators stay bound to that stream, the
+                # autograd engine then synchronises the capture stream with it, and that invalidates a capture (on this stack the
+                # process dies in hipStreamEndCapture).  This batch shape keeps eager steps; the run above already was one.
+                warnings.warn("use_step_graph: an autograd graph from an earlier eager step of this policy is still alive (e.g. a "
+                              "returned `total` that was not released); its training steps are not captured into a HIP graph")
+                st["eager_only"] = True
+                self._fused_grads_ready = True
+                return total.detach(), rep.detach() if torch.is_tensor(rep) else rep
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                for p in params:
-                    p.grad.zero_()
                 total, rep = self.simulate_batch(loss_function, simulator, model, periods, problem_params, static,
                                                  observation_params, ignore_periods, False, train=True)
-                (total * scale).backward()
+                grads_into_static(total * scale)
                 out_total, out_rep = total.detach(), (rep.detach() if torch.is_tensor(rep) else rep)
             # the captured env-step launches read the compact cost / lead-time tables of THIS EnvProblem (built from
             # `static` at capture time), not `static` itself: they are refreshed from every incoming batch below

@@ -1311,6 +1311,112 @@ def test_step_graph_survives_dev_passes_of_another_horizon_at_the_same_batch_siz
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", QUANTILE_TRAINABLE)
+def test_tape_route_training_step_replayed_from_a_graph_equals_eager_epochs(name):
+    """The trainable quantile policies on the tape route are launch-bound (two whole-horizon launches inside ~40 small torch
+    launches): `Trainer.use_step_graph = "auto"` captures their whole training step.  Four training epochs interleaved with dev
+    passes of another horizon at the same batch size (and allocator churn in between), through `Trainer.do_one_epoch`: losses and
+    parameters equal the eager run's; the training steps were replayed, the dev passes took the tape engine eagerly."""
+    import time
+    g = Golden(name)
+    c = g.fresh_config()
+    ds = MyDataset(c["n"], {k: v.clone() for k, v in g.data.items()})
+
+    def run(graph):
+        torch.manual_seed(0)
+        model = _model(g, c)
+        sim = Simulator(device=DEV)
+        with torch.no_grad():
+            obs0, _ = sim.reset(c["periods"], c["problem_params"], {k: v.to(DEV) for k, v in g.data.items()},
+                                c["observation_params"])
+            o = dict(obs0)
+            o["internal_data"] = sim._internal_data
+            model(o)
+        _load(model, g)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        tr = Trainer(device=DEV)
+        tr.use_step_graph = graph
+        loader = DeviceBatches(ds, c["n"], shuffle=False, device=DEV)
+        out, t_train = [], 0.0
+        for ep in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out.append(tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, c["periods"] - 3, c["problem_params"],
+                                       c["observation_params"], train=True, ignore_periods=2)[0])
+            torch.cuda.synchronize()
+            if ep >= 3:
+                t_train += time.perf_counter() - t0
+            junk = [torch.full((c["n"] * 64,), float("nan"), device=DEV) for _ in range(8)]
+            out.append(tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, c["periods"], c["problem_params"],
+                                       c["observation_params"], train=False, ignore_periods=2)[1])
+            del junk
+        assert any(type(e).__name__ == "TapeRollout" for e in tr._engines.values())
+        assert bool(tr._step_graphs) == (graph in ("auto", True))
+        return out, [p.detach().clone() for p in model.parameters()], t_train / 3
+
+    (le, pe, te), (lg, pg, tg_) = run(False), run("auto")
+    print(f"{name}: training epoch {te * 1e3:.2f} ms eager, {tg_ * 1e3:.2f} ms replayed")
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-6 * abs(a), (le, lg)
+    for a, b in zip(pe, pg):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    assert le[0] != le[2]   # (the optimizer moved the policy)
+
+
+def test_step_graph_refuses_capture_while_an_earlier_autograd_graph_is_alive():
+    """A `total` returned by an eager `simulate_batch` and still held by the caller keeps the policy's gradient accumulators bound
+    to the default stream; the autograd engine then synchronises the capture stream with it, which invalidates a capture (on this
+    stack the process died in hipStreamEndCapture).  `_graphed_generic_step` notices during its side-stream warm-up, warns, and
+    keeps eager steps for that batch shape: same losses as a trainer without step graphs; once the tensor is released a fresh
+    trainer captures again."""
+    import warnings
+    g = Golden("f4_real_one_store_fixed_quantile")
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    ds = MyDataset(c["n"], {k: v.clone() for k, v in g.data.items()})
+    loader = DeviceBatches(ds, c["n"], shuffle=False, device=DEV)
+
+    def fresh():
+        torch.manual_seed(0)
+        model = _model(g, g.fresh_config())
+        sim = Simulator(device=DEV)
+        with torch.no_grad():
+            o = dict(sim.reset(c["periods"], c["problem_params"], data, c["observation_params"])[0])
+            o["internal_data"] = sim._internal_data
+            model(o)
+        _load(model, g)
+        return model, sim, torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    def epochs(tr, model, sim, opt, n=4):
+        return [tr.do_one_epoch(opt, loader, PolicyLoss(), sim, model, c["periods"], c["problem_params"], c["observation_params"],
+                                train=True, ignore_periods=c["ignore"])[0] for _ in range(n)]
+
+    model, sim, opt = fresh()
+    tr0 = Trainer(device=DEV)
+    held, _ = tr0.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data, c["observation_params"],
+                                 c["ignore"], False)     # an eager result the caller keeps (its autograd graph stays alive)
+    assert held.requires_grad
+    tr = Trainer(device=DEV)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = epochs(tr, model, sim, opt)
+    assert any("not captured into a HIP graph" in str(w.message) for w in caught)
+    assert all(st.get("eager_only") for st in tr._step_graphs.values())
+    model2, sim2, opt2 = fresh()
+    tr2 = Trainer(device=DEV)
+    tr2.use_step_graph = False
+    want = epochs(tr2, model2, sim2, opt2)
+    for a, b in zip(got, want):
+        assert abs(a - b) <= 2e-6 * abs(b), (got, want)
+    del held
+    model3, sim3, opt3 = fresh()
+    tr3 = Trainer(device=DEV)
+    again = epochs(tr3, model3, sim3, opt3)
+    assert any("graph" in st for st in tr3._step_graphs.values())      # captured this time
+    for a, b in zip(again, want):
+        assert abs(a - b) <= 2e-6 * abs(b), (again, want)
+
+
 # ---- closed-form policies: whole horizon + forward-mode gradient in one kernel (csrc/closed_form.hip) -------------------
 
 CLOSED_FORM_CASES = ["cfg2_one_store_backlogged_base_stock", "cfg2_one_store_backlogged_capped", "cfg4_serial_echelon_stock"]

@@ -66,6 +66,32 @@ def main():
                 torch.cuda.synchronize()
                 rec[route + "_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
                 rec["trainable"] = bool(tot.requires_grad)
+            if rec["trainable"]:   # the same step through Trainer.do_one_epoch (one batch), replayed from a HIP graph (use_step_graph = "auto")
+                from neural_inventory_control_amd.data_handling import DeviceBatches, MyDataset
+                ds = MyDataset(c["n"] * tile, {k: v.cpu() for k, v in data.items()})
+                loader = DeviceBatches(ds, c["n"] * tile, shuffle=False, device=DEV)
+                for label, mode in (("tape_epoch_eager_ms", False), ("tape_epoch_graph_ms", "auto")):
+                    # (a fresh policy per mode: parameters that already went through eager backward passes on the default stream
+                    # carry gradient accumulators bound to it, which a later capture on a side stream does not survive)
+                    m2 = tg._model(g, g.fresh_config())
+                    with torch.no_grad():
+                        o = dict(sim.reset(c["periods"], c["problem_params"], data, c["observation_params"])[0])
+                        o["internal_data"] = sim._internal_data
+                        m2(o)
+                    tg._load(m2, g)
+                    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-4)
+                    tr = Trainer(device=DEV)
+                    tr.use_step_graph = mode
+                    ep = lambda: tr.do_one_epoch(opt2, loader, PolicyLoss(), sim, m2, c["periods"], c["problem_params"],   # noqa: E731
+                                                 c["observation_params"], train=True, ignore_periods=c["ignore"])
+                    for _ in range(4):
+                        ep()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        ep()
+                    torch.cuda.synchronize()
+                    rec[label] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
             rec["speedup"] = round(rec["generic_ms"] / rec["tape_ms"], 1)
             out[f"{name}_x{tile}"] = rec
             print(name, tile, rec, file=sys.stderr, flush=True)
