@@ -149,7 +149,9 @@ def real_data(n_products=288, n_stores=21, n_warehouses=3, weeks=171, past_perio
     for s_ in range(n_stores):  # every store keeps at least one supplier
         if not any(adj[w][s_] for w in range(n_warehouses)):
             adj[0][s_] = 1
-    lead = [[rnd.randint(4, 6), rnd.randint(1, 2), rnd.randint(4, 6)][:n_warehouses] for _ in range(n_stores)]
+    lead = [[(rnd.randint(1, 2) if w % 3 == 1 else rnd.randint(4, 6)) for w in range(max(n_warehouses, 3))][:n_warehouses]
+            for _ in range(n_stores)]
+    cyc = lambda v: [v[w % len(v)] for w in range(n_warehouses)]  # noqa: E731   (more than three warehouses: the values repeat)
     feats = {"holding_costs": True, "underage_costs": True, "lead_times": True, "mean": False, "std": False}
     return {
         "seeds": dict(_SEEDS, warehouse=10),
@@ -166,8 +168,7 @@ def real_data(n_products=288, n_stores=21, n_warehouses=3, weeks=171, past_perio
             "lead_time": _const(lead), "holding_cost": _per_store(0.7, 1.3),
             "underage_cost": {"sample_across_stores": True, "vary_across_samples": True, "expand": False, "range": [6.3, 11.7]},
             "initial_inventory": {"sample": False, "inventory_periods": 6}},
-        "warehouse_params": {"holding_cost": [0.3, 0.4, 0.2][:n_warehouses], "lead_time": 3,
-                             "edge_cost": [0.5, 1.5, 0.7][:n_warehouses]},
+        "warehouse_params": {"holding_cost": cyc([0.3, 0.4, 0.2]), "lead_time": 3, "edge_cost": cyc([0.5, 1.5, 0.7])},
         "echelon_params": None,
     }
 

@@ -247,3 +247,46 @@ def test_data_driven_whole_horizon_route_at_the_reference_batch(n):
         parts.append([p.grad.detach().clone() for p in model.parameters()])
     for gf, ga, gb in zip(g_full, *parts):
         assert float((gf - (ga + gb)).norm()) <= 3e-5 * float(gf.norm()) + 1e-12, float((gf - (ga + gb)).norm() / gf.norm())
+
+
+@pytest.mark.parametrize("S,Wn,hidden,n,T,P", [(8, 2, [48, 16], 19, 9, 5), (3, 1, [16, 64], 5, 4, 3), (30, 4, [64, 32], 33, 6, 4),
+                                              (21, 3, [64, 64], 130, 7, 16)])
+def test_data_driven_whole_horizon_route_on_other_shapes(S, Wn, hidden, n, T, P):
+    """The whole-horizon data_driven kernels away from the reference's own shape: other store / warehouse counts (30 x 4 = 124
+    logits rows: the second output tile of every wavefront; 3 x 1: one ragged tile of everything), unequal hidden widths below 64,
+    short past-demand windows, batches that leave the last workgroup ragged (19, 5, 33) or span nine of them (130) - against the
+    per-period route of the same engine: per-period rewards, final state, gradients."""
+    from neural_inventory_control_amd.data_handling import DatasetCreator
+    setting = workloads.real_data(n_products=n, n_stores=S, n_warehouses=Wn, weeks=P + T + 6, past_periods=P, seed=S)
+    policy = workloads.data_driven_policy()
+    policy["neurons_per_hidden_layer"] = {"master": list(hidden)}
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    shift = obs["demand"]["period_shift"]
+    sc = Scenario(shift + T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
+                  n, obs, setting["seeds"], device=DEV)
+    data = {k: v.to(DEV) for k, v in DatasetCreator().split_by_period(sc, [f"(0, {shift + T})"])[0].items()}
+    torch.manual_seed(3)
+    model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+    eng = FusedRollout(model, setting["problem_params"], DEV)
+    eng.materialize(eng.input_rows(data, obs))
+    with torch.no_grad():   # (weights away from their initialisation: logits of both signs, allocation scale both clipped and not)
+        for p_ in model.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))
+    out = {}
+    for route in ("horizon", "periods"):
+        eng.use_horizon = route == "horizon"
+        tot, rep = eng.run(data, T, 2, train=True, observation_params=obs)
+        torch.cuda.synchronize()
+        assert (eng.horizon is not None) == (route == "horizon")
+        out[route] = (float(tot), float(rep), eng.per_period_rewards().clone(), {k: v.clone() for k, v in eng.final_state().items()},
+                      [p_.grad.detach().clone() for p_ in model.parameters()])
+        with torch.no_grad():
+            t2, _ = eng.run(data, T, 2, train=False, observation_params=obs)
+        assert float(t2) == float(tot)
+    a, b = out["horizon"], out["periods"]
+    assert abs(a[0] - b[0]) <= 5e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 5e-6 * abs(b[1])
+    torch.testing.assert_close(a[2], b[2], rtol=2e-5, atol=2e-3)
+    for k in b[3]:
+        torch.testing.assert_close(a[3][k], b[3][k], rtol=2e-5, atol=2e-3)
+    for ga, gb in zip(a[4], b[4]):
+        assert float(gb.norm()) > 0 and float((ga - gb).norm()) <= 1e-4 * float(gb.norm()), float((ga - gb).norm() / gb.norm())
