@@ -40,7 +40,8 @@ def main():
         # the dev horizon instead of the YAML's 5,000 periods to keep this check short
         setting, hyper, _ = workloads.get_epoch(which)
         hyper["trainer_params"].update(epochs=epochs, print_results_every_n_epochs=10 ** 6)
-        setting["params_by_dataset"]["test"].update(periods=200, ignore_periods=100)
+        if not (setting.get("sample_data_params") or {}).get("split_by_period"):   # (real data: the test split has its own 37 weeks)
+            setting["params_by_dataset"]["test"].update(periods=200, ignore_periods=100)
         reference_value = None
     else:
         setting, hyper = configs(epochs)
