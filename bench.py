@@ -365,6 +365,7 @@ def bench_epoch(args):
     for _ in range(max(1, args.warmup) + 2):   # eager run, auto-graph measurement / capture run, steady state
         epoch()
     eng = tr._engines.get((id(model), True))
+    is_gnn = type(eng).__name__ == "GnnRollout"
     if world > 1:
         torch.distributed.barrier()
     dt, last = timed(n_epochs)
@@ -419,8 +420,10 @@ def bench_epoch(args):
         eng.timer = None
         tr.use_rollout_graph = was
         prob = eng.prob
-        shape = dict(n=pbd["batch_size"], T=T, S=S, Wn=prob.Wn, E=prob.E, Ws=prob.Ws, Ww=prob.Ww, We=prob.We, F=eng.dims[0],
-                     nh=len(eng.dims) - 2, n_out=eng.dims[-1], train=True, gnn=None, hidden=list(eng.dims[1:-1]))
+        dims = [0, 0] if is_gnn else eng.dims
+        shape = dict(n=pbd["batch_size"], T=T, S=S, Wn=prob.Wn, E=prob.E, Ws=prob.Ws, Ww=prob.Ww, We=prob.We, F=dims[0],
+                     nh=len(dims) - 2, n_out=dims[-1], train=True, hidden=list(dims[1:-1]),
+                     gnn={m.name: (m.K, m.n_out, m.n_live, getattr(m, "fold_rows", 0)) for m in eng.mlp.values()} if is_gnn else None)
         kernels = kernel_report(timer, shape, n_batches)
         rated = {k: v for k, v in kernels.items() if "bound" in v}
         if rated:

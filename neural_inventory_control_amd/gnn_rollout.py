@@ -240,12 +240,21 @@ class GnnRollout:
         self.fused_bwd = None
         self.keep_inputs = False  # "hist": True = also keep a copy of the gathered MLP inputs (while it fits) instead of reading
         #                         them again from their per-period sources in the backward (same speed, 40 % more history)
-        self.use_graph = False   # replay the (static) launch sequence of a rollout from a HIP graph after one eager run
+        # replay the (static) launch sequence of a rollout from a HIP graph after one eager run: True / False, or "auto" (what
+        # `Trainer` sets, as on the MLP engine) = decided by MEASUREMENT on the second training run of a shape - if the host needs
+        # longer to enqueue the ~27 launches per period than the GPU needs to run them, later runs are replayed (the reference's
+        # shipped batch of 1,024 scenarios: 19.2 -> 14.6 ms per step; 8,192 scenarios are GPU-bound and stay eager)
+        self.use_graph = False
+        self._auto_graph = None
+        self.auto_graph_probe = None
         self._probs = ProblemCache()
         self._key = None
 
     def _k(self, tag, fn, *a, **kw):
         return fn(*a, **kw) if self.timer is None else self.timer.call(tag, fn, *a, **kw)
+
+    def _graph_on(self):
+        return self.use_graph is True or (self.use_graph == "auto" and self._auto_graph is True)
 
     # ---- setup --------------------------------------------------------------------------------------------------------------
     def shapes_ok(self, data):
@@ -312,7 +321,7 @@ class GnnRollout:
                                self._mode_now, self._keep_inputs and bool(self.keep_inputs),
                                n_live=P.n_live if name in ("edge_update", "output") else None)
                     for name, k, ne in zip(MODULES, ks, ents)}
-        self._graphs, self._eager_runs = {}, 0
+        self._graphs, self._eager_runs, self._auto_graph = {}, 0, None   # (a new shape is measured afresh)
         self.agg = z(T, 32, 2 * N, ld)   # message aggregation: [:, :N] over incoming edges, [:, N:] over outgoing edges
         self.nodes1, self.edges1 = z(T, 32, N, ld), z(T, 32, E, ld)
         self.sums, self.ratio, self.scale = z(T, Wn, ld), z(T, Wn, ld), z(T, Wn, ld)
@@ -370,7 +379,7 @@ class GnnRollout:
             f[:, mi + 1, :Wn, :B] = data["warehouse_edge_costs"].t()
         for r, k in enumerate(("holding_costs", "underage_costs", "mean", "std")):
             f[:, mi + r, Wn:, :B] = data[k].t()
-        if self.use_graph:  # captured launches point at engine-owned buffers: keep the demand trace in one of them
+        if self._graph_on():  # captured launches point at engine-owned buffers: keep the demand trace in one of them
             if getattr(self, "_demand_buf", None) is None or self._demand_buf.shape != demand_soa.shape:
                 self._demand_buf, self._graphs, self._eager_runs = torch.empty_like(demand_soa), {}, 0
             if self._demand_buf.data_ptr() != demand_soa.data_ptr():
@@ -385,6 +394,13 @@ class GnnRollout:
         def forward():
             for t in range(T):
                 self._forward_period(t, prob, demand_soa, shift)
+        probe = None
+        if self.use_graph == "auto" and self._auto_graph is None and train and self._eager_runs >= 1 and self.timer is None:
+            import time
+            probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            torch.cuda.synchronize()
+            probe[0].record()
+            probe_t0 = time.perf_counter()
         self._replay_or_capture(("fwd", T, shift, bool(train)), forward)
         total = self.rewards.sum()
         reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
@@ -407,6 +423,13 @@ class GnnRollout:
                 g_next, g_cur = g_cur, g_next
             self._weight_gradients(T, prob)
         self._replay_or_capture(("bwd", T, shift), backward)
+        if probe is not None:   # host time to enqueue the step against GPU time to run it (one synchronisation, once per shape)
+            host_ms = (time.perf_counter() - probe_t0) * 1e3
+            probe[1].record()
+            probe[1].synchronize()
+            gpu_ms = probe[0].elapsed_time(probe[1])
+            self._auto_graph = host_ms > 0.85 * gpu_ms
+            self.auto_graph_probe = {"host_enqueue_ms": host_ms, "gpu_ms": gpu_ms, "replay": self._auto_graph}
         self._eager_runs += 1
         if assign_grads:
             for p, g in self.param_grads():
@@ -421,7 +444,7 @@ class GnnRollout:
     def _replay_or_capture(self, name, fn):
         """The launch sequence of a rollout is identical from call to call (same buffers, same shapes): after one eager run
         it is captured into a HIP graph and replayed, which removes the host cost of ~3,000 launches and descriptor builds."""
-        if not self.use_graph or self.timer is not None or self._eager_runs < 1:
+        if not self._graph_on() or self.timer is not None or self._eager_runs < 1:
             return fn()
         g = self._graphs.get(name)
         if g is None:

@@ -269,8 +269,7 @@ class Trainer:
             eng = self._engines.get((id(model), train))
             if eng is None or eng.model is not model:  # (the engine holds the model, so its id cannot be recycled)
                 eng = self._engines[(id(model), train)] = engine_cls(model, problem_params, self.device)
-            if engine_cls is FusedRollout:
-                eng.use_graph = self.use_rollout_graph
+            eng.use_graph = self.use_rollout_graph   # (both engines: True / False / "auto" = by measurement per shape)
             if direct and train:
                 total, reported = eng.run(data_batch, periods, ignore_periods, train=True,
                                           observation_params=observation_params, grad_scale=1.0, assign_grads=False)

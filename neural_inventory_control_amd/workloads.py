@@ -299,6 +299,12 @@ EPOCH_WORKLOADS["real_data_yaml"] = (
     "x 3 warehouses, 4 batches of 72 x T=95 (ignore 16), one training epoch through Trainer.do_one_epoch")
 
 
+EPOCH_WORKLOADS["gnn_yaml"] = (
+    lambda: _as_shipped(one_warehouse(5)), lambda: _hyperparams(gnn_policy(), lr=0.001),
+    "one_warehouse_lost_demand.yml + gnn.yml as shipped: 5 stores, 8192 samples in batches of 1024 x T=50 (ignore 30), one training "
+    "epoch through Trainer.do_one_epoch on the fused gather-MLP engine")
+
+
 def get_epoch(name):
     setting, hyper, desc = EPOCH_WORKLOADS[name]
     return copy.deepcopy(setting()), copy.deepcopy(hyper()), desc

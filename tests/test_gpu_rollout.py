@@ -1579,25 +1579,44 @@ def test_gnn_graph_replay_matches_eager(name):
     data2 = dict(data)
     data2["demands"] = (data["demands"] * 1.3 + 0.25).contiguous()
     out = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "auto"):
         model = _model(g, c)
         eng = GnnRollout(model, c["problem_params"], DEV)
-        eng.use_graph = mode == "graph"
+        eng.use_graph = {"eager": False, "graph": True, "auto": "auto"}[mode]
         eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
         _load(model, g)
         res = []
-        for d in (data, data2, data, data2):
+        for d in (data, data2, data, data2, data, data2):
             total, rep = eng.run(d, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
             torch.cuda.synchronize()
             res.append((float(total), float(rep), [p.grad.clone() for p in model.parameters()]))
         out[mode] = res
         if mode == "graph":
             assert len(eng._graphs) == 2
-    for a, b in zip(out["eager"], out["graph"]):
-        assert a[0] == b[0] and a[1] == b[1]
-        for x, y in zip(a[2], b[2]):
-            assert torch.equal(x, y)
+        if mode == "auto":
+            # round 4: decided by measurement on the second training run (what `Trainer` sets on its engines) - a fixture-sized
+            # batch is launch-bound on any host, so the later runs were replayed
+            assert eng.auto_graph_probe is not None and eng.auto_graph_probe["replay"] is True and len(eng._graphs) == 2
+    for mode in ("graph", "auto"):
+        for a, b in zip(out["eager"], out[mode]):
+            assert a[0] == b[0] and a[1] == b[1]
+            for x, y in zip(a[2], b[2]):
+                assert torch.equal(x, y)
     assert out["eager"][0][0] != out["eager"][1][0]
+    # ... and `Trainer.simulate_batch` hands its own setting to the engine it creates
+    tr = Trainer(device=DEV)
+    model = _model(g, c)
+    sim = Simulator(device=DEV)
+    with torch.no_grad():
+        o = dict(sim.reset(c["periods"], c["problem_params"], data, c["observation_params"])[0])
+        o["internal_data"] = sim._internal_data
+        model(o)
+    _load(model, g)
+    if "mean" in data and "std" in data:
+        tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data, c["observation_params"], c["ignore"],
+                          False, train=True)
+        engines = [e for e in tr._engines.values() if isinstance(e, GnnRollout)]
+        assert engines and engines[0].use_graph == "auto"
 
 
 @pytest.mark.parametrize("setting_name", ["cfg3", "cfg2"])
