@@ -136,15 +136,26 @@ class TapeRollout:
         lt, wlt = data["lead_times"], data["warehouse_lead_times"]
         adj = torch.tensor(self.problem_params["warehouse_store_adjacency"], dtype=torch.float32)
         mean_lt = lt.mean(dim=0).cpu()   # (the fastest connected warehouse per store, from the batch-mean lead times: :695-699)
-        alloc = torch.zeros(T, B, S, prob.Wn, device=dev)
-        wh = torch.zeros(T, B, prob.Wn, device=dev)
+        served, fastest = [], []
         for st in range(S):
             conn = adj[:, st].nonzero(as_tuple=True)[0]
-            if len(conn) == 0:
-                continue
-            w = int(conn[torch.argmin(mean_lt[st, conn])])
-            alloc[:, :, st, w] = future(st, lt[:, st, w])
-            wh[:, :, w] += future(st, wlt[:, w] + lt[:, st, w])
+            if len(conn):
+                served.append(st)
+                fastest.append(int(conn[torch.argmin(mean_lt[st, conn])]))
+        alloc = torch.zeros(T, B, S, prob.Wn, device=dev)
+        wh = torch.zeros(T, B, prob.Wn, device=dev)
+        if served:
+            sv, fw = torch.tensor(served, device=dev), torch.tensor(fastest, device=dev)
+            lt_sel = lt[:, sv, fw].long()                                                  # [B][m] lead time from the chosen warehouse
+            dem_t = dem[:, sv].unsqueeze(0).expand(T, B, len(served), n_t)                  # (a view: no copy)
+            t_idx = cur.view(T, 1, 1)
+
+            def future_all(extra):   # demand of every served store at period t + shift + extra[b, store] (clipped), [T][B][m]
+                return dem_t.gather(3, torch.clamp(t_idx + extra.unsqueeze(0), max=n_t - 1).unsqueeze(3)).squeeze(3)
+            alloc[:, :, sv, fw] = future_all(lt_sel)
+            via_wh = future_all(wlt[:, fw].long() + lt_sel)
+            for k, w in enumerate(fastest):   # (accumulated store by store, in store order, as upstream's `wh[:, w] += ...`)
+                wh[:, :, w] += via_wh[:, :, k]
         return torch.cat([torch.clip(alloc, min=0).reshape(T, B, S * prob.Wn), torch.clip(wh, min=0)], dim=2)
 
     # ---- one batch ---------------------------------------------------------------------------------------------------
