@@ -481,6 +481,10 @@ def main():
     ap.add_argument("--eval", action="store_true",
                     help="SURVEY 8(f2): time the forward-only evaluation pass (Trainer.test: no gradients, discrete allocation "
                          "for Poisson demand) instead of a training step; use with --periods 5000 for the reference's test horizon")
+    ap.add_argument("--no-horizon", action="store_true",
+                    help="data_driven workloads: the per-period kernels instead of the whole-horizon kernels (A/B)")
+    ap.add_argument("--horizon-max-scenarios", type=int, default=0,
+                    help="data_driven workloads: largest batch that takes the whole-horizon kernels (default: the engine's 8192)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -522,6 +526,10 @@ def main():
     elif eng is not None:  # materialise the lazy layers now so that replicas can be synchronised before the first step
         eng.materialize(eng.input_rows(data, setting["observation_params"]))
         eng.small_lane_scenarios = args.lane_scenarios
+        if args.no_horizon:
+            eng.use_horizon = False
+        if args.horizon_max_scenarios:
+            eng.horizon_max_scenarios = args.horizon_max_scenarios
         parallel.broadcast_model(model, src=0)
     opt = torch.optim.Adam(model.parameters(), lr=3e-4)
     if args.graph and eng is not None and not closed_form:

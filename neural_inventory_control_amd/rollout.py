@@ -137,9 +137,12 @@ class FusedRollout:
         self.batch_wgrad = True  # hidden-layer weight gradients contracted over all periods in one launch
         self.fuse_head_env = True  # vanilla_warehouse: head + env step (and their adjoints) in one launch each (csrc/head_env.hip)
         # data_driven on small batches (what the reference trains it on: 72 products): all periods in ONE forward and ONE backward
-        # launch (csrc/horizon_rollout.hip) while the batch gives every workgroup of 16 scenarios its own CU a few times over
+        # launch (csrc/horizon_rollout.hip).  Measured against the per-period kernels on the real-data shape (tools/
+        # horizon_crossover.py, profiles/r04_horizon_crossover.json): 2.3 vs 8.7 ms (replayed) at 72 scenarios, 3.4 vs 10.2 at 4,096,
+        # 7.2 vs 12.2 at 8,192 (one workgroup of 16 scenarios per CU: 512 workgroups are two rounds), 14.2 vs 16.0 at 16,384,
+        # 29.2 vs 23.1 at 32,768
         self.use_horizon = True
-        self.horizon_max_scenarios = 8192
+        self.horizon_max_scenarios = 16384
         self.horizon = None     # HorizonPlan when the current shapes take that route
         self.eval_history = None  # evaluation keeps per-period states/orders/logits: None = while small, True / False = forced
         self.small = None       # SmallRolloutPlan when the current shapes take that route
