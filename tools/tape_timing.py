@@ -29,7 +29,7 @@ DEV = "cuda:0"
 def main():
     out = {}
     for name in [n for n in case_names() if n.startswith("f4_real") and not n.endswith("data_driven")]:
-        for tile in (1, 7):
+        for tile in tuple(int(v) for v in os.environ.get("TAPE_TILES", "1,7").split(",")):
             g = Golden(name)
             c = g.fresh_config()
             model = tg._model(g, c)
