@@ -184,9 +184,12 @@ def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None, settin
                  if k in data)
     if policy["name"] in ("base_stock", "capped_base_stock", "echelon_stock"):
         F = 1  # closed-form policies: one Linear fed the constant 0 (neural_networks.py:228)
-    if policy["name"] in ("gnn", "data_driven"):  # the oracle takes the (already materialised) weights of the device model
+    quantile = policy["name"] in ("transformed_nv", "fixed_quantile", "quantile_nv", "returns_nv")
+    if policy["name"] in ("gnn", "data_driven") or quantile:  # the oracle takes the (already materialised) weights of the device model
         state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        pol = orc.policy_from_state_dict(policy, state, setting["problem_params"])
+        fstate = ({k: v.detach().cpu() for k, v in model.fixed_nets["quantile_forecaster"].state_dict().items()}
+                  if quantile else None)   # (the frozen forecaster the policy inverts)
+        pol = orc.policy_from_state_dict(policy, state, setting["problem_params"], forecaster_state=fstate)
     else:
         pol = orc.init_policy(policy, setting["problem_params"], F, 1234, setting["store_params"])
     warm = {k: v[:max(8, sample_scenarios // 16)] for k, v in data.items()}
@@ -270,7 +273,8 @@ def algorithmic_work(tag, kernel, shape):
         # and the demand in; reward and the histories out (state rows, two hidden activations, logits, orders).  Backward: the
         # histories and the demand in, the three pre-activation gradients out.  (A latency-bound chain on n / 16 CUs: the
         # fraction of the HBM roofline is reported for completeness, microseconds per period is the figure of merit.)
-        h1, h2, no = shape["hidden"][0], shape["hidden"][1], shape["n_out"]
+        h1, h2 = (list(shape["hidden"]) + [0, 0])[:2]   # (tape modes: no layers; the tape row(s) stand in for z1_obs / the logits)
+        no = shape["n_out"] or n_ord
         hist_rows = f_state + h1 + h2 + no + n_ord
         if tag == "horizon_fwd":
             return "hbm", 4.0 * (h1 + S + 1 + (hist_rows if shape["train"] else 0)) * n * T, "B"
@@ -364,8 +368,8 @@ def bench_epoch(args):
     n_epochs = max(1, (args.steps + n_batches - 1) // n_batches)
     for _ in range(max(1, args.warmup) + 2):   # eager run, auto-graph measurement / capture run, steady state
         epoch()
-    eng = tr._engines.get((id(model), True))
-    is_gnn = type(eng).__name__ == "GnnRollout"
+    eng = next((e for k, e in tr._engines.items() if k[0] == id(model) and k[-1] is True), None)   # the training-pass engine
+    is_gnn, is_tape = type(eng).__name__ == "GnnRollout", type(eng).__name__ == "TapeRollout"
     if world > 1:
         torch.distributed.barrier()
     dt, last = timed(n_epochs)
@@ -387,17 +391,28 @@ def bench_epoch(args):
                       "parallelism": f"scenario-sharded dp{world}", "train_loss_per_store_period": last[1],
                       "route": (type(eng).__name__ + (" (whole-horizon kernels)" if getattr(eng, "horizon", None) is not None else ""))
                       if eng is not None else "generic",
-                      "rollout_graph": {"setting": tr.use_rollout_graph, "replaying": bool(eng is not None and eng._graph_on()),
-                                        "auto_probe": getattr(eng, "auto_graph_probe", None)}}}
+                      "rollout_graph": {"setting": tr.use_rollout_graph,
+                                        "replaying": bool(eng is not None and getattr(eng, "_graph_on", lambda: False)()),
+                                        "auto_probe": getattr(eng, "auto_graph_probe", None)},
+                      "step_graph": {"setting": tr.use_step_graph, "captured": bool(tr._step_graphs)}}}
     if eng is not None and not args.no_kernel_timing:
         # the other launch mode, and the reference-style host loader, on the same model (after the main figure)
         alt = {}
         was = tr.use_rollout_graph
-        for label, mode in (("eager", False), ("graph", True)):
-            tr.use_rollout_graph = mode
-            epoch(); epoch(); epoch()
-            alt[label + "_ms_per_epoch"] = round(timed(n_epochs)[0] * 1e3, 3)
-        tr.use_rollout_graph = was
+        if is_tape:   # the tape route's switches: the whole step as a HIP graph or not; the reference-style loop (Simulator.step) instead
+            was_step = tr.use_step_graph
+            for label, step_graph, tape in (("tape_route_step_graph_off", False, True), ("generic_route", False, False)):
+                tr.use_step_graph, tr.use_tape_rollout = step_graph, tape
+                epoch(); epoch()
+                alt[label + "_ms_per_epoch"] = round(timed(max(1, n_epochs // 2))[0] * 1e3, 3)
+            tr.use_step_graph, tr.use_tape_rollout = was_step, True
+            epoch()
+        else:
+            for label, mode in (("eager", False), ("graph", True)):
+                tr.use_rollout_graph = mode
+                epoch(); epoch(); epoch()
+                alt[label + "_ms_per_epoch"] = round(timed(n_epochs)[0] * 1e3, 3)
+            tr.use_rollout_graph = was
         if getattr(eng, "horizon", None) is not None:   # the same epoch on the per-period kernels (eager, then replayed)
             eng.use_horizon = False
             for label, mode in (("per_period_route_eager", False), ("per_period_route_graph", True)):
@@ -413,14 +428,18 @@ def bench_epoch(args):
         out["config"]["epoch_variants"] = alt
         # per-kernel figures of one eager epoch
         tr.use_rollout_graph = False
+        was_step, tr.use_step_graph = tr.use_step_graph, (False if is_tape else tr.use_step_graph)
+        if is_tape:   # (without a step graph the trainer keeps one engine per train / eval context)
+            epoch()
+            eng = next((e for k, e in tr._engines.items() if k[0] == id(model) and k[-1] is True and len(k) == 3), eng)
         epoch()
-        timer = eng.timer = KernelTimer(stride=args.timing_stride or 10)
+        timer = eng.timer = KernelTimer(stride=args.timing_stride or (1 if is_tape else 10))
         epoch()
         torch.cuda.synchronize()
         eng.timer = None
-        tr.use_rollout_graph = was
+        tr.use_rollout_graph, tr.use_step_graph = was, was_step
         prob = eng.prob
-        dims = [0, 0] if is_gnn else eng.dims
+        dims = [0, 0] if (is_gnn or is_tape) else eng.dims
         shape = dict(n=pbd["batch_size"], T=T, S=S, Wn=prob.Wn, E=prob.E, Ws=prob.Ws, Ww=prob.Ww, We=prob.We, F=dims[0],
                      nh=len(dims) - 2, n_out=dims[-1], train=True, hidden=list(dims[1:-1]),
                      gnn={m.name: (m.K, m.n_out, m.n_live, getattr(m, "fold_rows", 0)) for m in eng.mlp.values()} if is_gnn else None)

@@ -173,6 +173,68 @@ def real_data(n_products=288, n_stores=21, n_warehouses=3, weeks=171, past_perio
     }
 
 
+def real_data_one_store(n_products=32768, weeks=171, past_periods=16, seed=0):
+    """The shape of one_store_real_data_lost_demand.yml (32,768 (product, store) series x 171 weeks, lead times 4..6 and underage
+    costs per sample, 16 past demands + days-from-christmas in the observation, profit objective) on SYNTHETIC stand-in files
+    (see `real_data`)."""
+    import os
+    import tempfile
+    import torch
+    d = tempfile.mkdtemp(prefix="nic_real_data_1s_")
+    gen = torch.Generator().manual_seed(seed)
+    level = torch.rand(n_products, 1, 1, generator=gen) * 20.0 + 1.0
+    season = 1.0 + 0.3 * torch.sin(torch.arange(weeks, dtype=torch.float32) * (2 * 3.14159265 / 52.0))
+    sales = torch.clamp(level * season + torch.randn(n_products, 1, weeks, generator=gen) * level.sqrt() * 2.0, min=0.0)
+    torch.save(sales.round(decimals=3), os.path.join(d, "weekly_sales.pt"))
+    with open(os.path.join(d, "dates_with_info.csv"), "w") as f:
+        f.write("week,days_from_christmas\n")
+        for w in range(weeks):
+            f.write(f"{w},{(w * 7 + 180) % 365 - 182}\n")
+    feats = {"holding_costs": True, "underage_costs": True, "lead_times": True, "upper_bounds": False}
+    return {
+        "seeds": dict(_SEEDS),
+        "problem_params": {"n_stores": 1, "n_warehouses": 0, "n_extra_echelons": 0, "lost_demand": True, "maximize_profit": True},
+        "observation_params": {"include_warehouse_inventory": False, "include_static_features": feats,
+                               "demand": {"past_periods": past_periods, "period_shift": past_periods},
+                               "time_features_file": os.path.join(d, "dates_with_info.csv"),
+                               "time_features": ["days_from_christmas"], "sample_features": None},
+        "store_params": {
+            "demand": {"distribution": "real", "file_location": os.path.join(d, "weekly_sales.pt"), "sample_across_stores": False,
+                       "expand": False, "clip": False, "decimals": 3},
+            "lead_time": {"sample_across_stores": False, "vary_across_samples": True, "expand": False, "range": [4, 7]},
+            "holding_cost": _const(1.0),
+            "underage_cost": {"sample_across_stores": False, "vary_across_samples": True, "expand": False, "range": [6.3, 11.7]},
+            "initial_inventory": {"sample": False, "inventory_periods": 6}},
+        "warehouse_params": None,
+        "echelon_params": None,
+    }
+
+
+def standin_forecaster(lead_times=(4, 5, 6), seed=0):
+    """A file in the format of the reference's `quantile_forecasters/<id>.pt` (FullyConnectedForecaster [128, 128] over 16 past
+    demands + days from christmas, 19 quantiles x 3 lead times) with RANDOM weights, monotone in the quantile: the shipped file
+    does not travel to the GPU box; the quantile policies' arithmetic and cost do not depend on what the numbers are."""
+    import os
+    import tempfile
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    n_out = 19 * len(lead_times)
+    w = lambda *shape: torch.randn(*shape, generator=gen) * 0.05   # noqa: E731
+    bias = (torch.arange(19, dtype=torch.float32).repeat_interleave(len(lead_times)) + 5.0) * 4.0   # (quantile-major rows)
+    state = {"net.0.weight": w(128, 17), "net.0.bias": w(128), "net.2.weight": w(128, 128), "net.2.bias": w(128),
+             "net.4.weight": w(n_out, 128), "net.4.bias": bias}
+    path = os.path.join(tempfile.mkdtemp(prefix="nic_forecaster_"), "forecaster.pt")
+    torch.save(state, path)
+    return path
+
+
+def transformed_nv_policy():
+    """transformed_nv.yml: a 32 x 32 sigmoid net over the newsvendor quantile, inverted by the frozen quantile forecaster."""
+    return {"name": "transformed_nv", "inner_layer_activations": {"master": "elu"}, "output_layer_activation": {"master": "sigmoid"},
+            "neurons_per_hidden_layer": {"master": [32, 32]}, "initial_bias": None, "output_sizes": {"master": 1},
+            "forecaster_location": standin_forecaster(), "forecaster_lead_times": [4, 5, 6]}
+
+
 def data_driven_policy():
     """data_driven_net.yml: one 64 x 64 MLP over every observed feature, relu outputs."""
     return {"name": "data_driven", "inner_layer_activations": {"master": "elu"}, "output_layer_activation": {"master": "relu"},
@@ -299,6 +361,27 @@ EPOCH_WORKLOADS["real_data_yaml"] = (
     "x 3 warehouses, 4 batches of 72 x T=95 (ignore 16), one training epoch through Trainer.do_one_epoch")
 
 
+def _real_one_store_as_shipped():
+    """one_store_real_data_lost_demand.yml:19-45: 32,768 series split BY PERIOD, training batches of 8,192 x 95 weeks (16 ignored),
+    dev / test batches of 32,768 x 37."""
+    s_ = real_data_one_store()
+    s_["test_seeds"] = dict(_SEEDS, demand=65)
+    s_["sample_data_params"] = {"split_by_period": True, "train_periods": "(0, 111)", "dev_periods": "(88, 141)",
+                                "test_periods": "(118, 171)"}
+    s_["params_by_dataset"] = {"train": {"n_samples": 32768, "batch_size": 8192, "periods": 95, "ignore_periods": 16},
+                               "dev": {"n_samples": 32768, "batch_size": 32768, "periods": 37, "ignore_periods": 16},
+                               "test": {"n_samples": 32768, "batch_size": 32768, "periods": 37, "ignore_periods": 16}}
+    return s_
+
+
+EPOCH_WORKLOADS["one_store_real_yaml"] = (
+    _real_one_store_as_shipped, lambda: _hyperparams(data_driven_policy(), lr=0.003),
+    "one_store_real_data_lost_demand.yml + data_driven_net.yml as shipped (synthetic stand-in files): 32768 series x 1 store, 4 batches "
+    "of 8192 x T=95 (ignore 16), one training epoch through Trainer.do_one_epoch")
+EPOCH_WORKLOADS["one_store_real_transformed_nv_yaml"] = (
+    _real_one_store_as_shipped, lambda: _hyperparams(transformed_nv_policy(), lr=0.03),
+    "one_store_real_data_lost_demand.yml + transformed_nv.yml as shipped (stand-in files, stand-in forecaster weights): 32768 series x "
+    "1 store, 4 batches of 8192 x T=95 (ignore 16), one training epoch through Trainer.do_one_epoch")
 EPOCH_WORKLOADS["gnn_yaml"] = (
     lambda: _as_shipped(one_warehouse(5)), lambda: _hyperparams(gnn_policy(), lr=0.001),
     "one_warehouse_lost_demand.yml + gnn.yml as shipped: 5 stores, 8192 samples in batches of 1024 x T=50 (ignore 30), one training "

@@ -193,6 +193,25 @@ def test_bench_real_data_epoch_workload_line():
     assert out["kernels"]["horizon_fwd"]["launches_per_step"] == 1.0 and out["kernels"]["horizon_bwd"]["launches_per_step"] == 1.0
 
 
+def test_bench_one_store_real_data_quantile_epoch_workload_line():
+    """`bench.py --workload one_store_real_transformed_nv_yaml`: the shipped one-store real-data YAML with `transformed_nv.yml`
+    (stand-in files and forecaster weights) through Trainer.do_one_epoch - 4 batches of 8,192 series x 95 weeks on the tape route,
+    training steps replayed from a HIP graph; the reference-style loop (Simulator.step per period) reported beside it."""
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "one_store_real_transformed_nv_yaml", "--steps", "4",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert cfg["samples"] == 32768 and cfg["batch_size"] == 8192 and cfg["batches_per_epoch"] == 4 and cfg["periods"] == 95
+    assert cfg["stores"] == 1 and cfg["route"] == "TapeRollout" and cfg["step_graph"] == {"setting": "auto", "captured": True}
+    ev = cfg["epoch_variants"]
+    assert out["ms_per_epoch"] < 0.2 * ev["generic_route_ms_per_epoch"]
+    assert {"horizon_fwd", "horizon_bwd"} <= set(out["kernels"])
+
+
 def test_library_mapped_before_any_torch_device_use_still_launches():
     """build() and smoke() in one process: the C-ABI library is mapped (and its code objects registered with the HIP runtime)
     before PyTorch has touched the device.  `load_library` initialises torch's device first; without that every launch from

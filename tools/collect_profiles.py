@@ -158,8 +158,8 @@ def main():
         return
     workloads = sys.argv[2:] or ["cfg3", "cfg3_shard8", "cfg3_batch1024", "cfg3_yaml", "cfg5_yaml", "cfg2", "cfg4", "cfg5", "cfg1",
                                  "gnn", "gnn_many_warehouses", "base_stock", "base_stock_1m", "echelon_stock", "real_data_driven",
-                                 "real_data_yaml", "gnn_yaml"]
-    epoch = ("cfg3_yaml", "cfg5_yaml", "real_data_yaml", "gnn_yaml")   # a step = one batch of an epoch (8 or 4 batches): whole epochs
+                                 "real_data_yaml", "gnn_yaml", "one_store_real_yaml", "one_store_real_transformed_nv_yaml"]
+    epoch = ("cfg3_yaml", "cfg5_yaml", "real_data_yaml", "gnn_yaml", "one_store_real_yaml", "one_store_real_transformed_nv_yaml")   # a step = one batch of an epoch (8 or 4 batches): whole epochs
     out = os.path.join(ROOT, "gpurun_out", rnd)
     os.makedirs(out, exist_ok=True)
     for w in workloads:
