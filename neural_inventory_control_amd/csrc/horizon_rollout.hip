@@ -254,8 +254,10 @@ __device__ __forceinline__ f32x4 layer64(const float (&aW)[16], const float* hx,
 // drains every store issued before it.  All global traffic of a period is therefore issued in ONE burst at the top of the period
 // - the loads for the NEXT period first, then the stores of the PREVIOUS period's results (kept in registers / LDS until then) - and
 // nothing is waited for until the top of the next period, a whole period of the chain later.
+// (the smallest variant - one-store settings, which the reference trains in batches of 8,192 = 512 workgroups - is held to 256
+// registers so that two workgroups share a CU: one round instead of two)
 template <int MAXW, int MAXS1>
-__global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d, const float* __restrict__ z1_obs,
+__global__ __launch_bounds__(kThreads, MAXS1 == 16 ? 2 : 1) void horizon_fwd_kernel(NicHorizonDesc d, const float* __restrict__ z1_obs,
                                                                 const float* __restrict__ state0, float* __restrict__ rewards,
                                                                 float* __restrict__ state_final, float* __restrict__ state_hist,
                                                                 float* __restrict__ h1_hist, float* __restrict__ h2_hist,
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(kThreads) void horizon_fwd_kernel(NicHorizonDesc d,
 // contractions on resident TRANSPOSED weight fragments - the first layer's only over the state rows (nothing else of the input
 // carries a gradient back in time).
 template <int MAXW, int VAR>
-__global__ __launch_bounds__(kThreads) void horizon_bwd_kernel(NicHorizonDesc d, const float* __restrict__ state_hist,
+__global__ __launch_bounds__(kThreads, VAR == 0 ? 2 : 1) void horizon_bwd_kernel(NicHorizonDesc d, const float* __restrict__ state_hist,
                                                                 const float* __restrict__ h1_hist, const float* __restrict__ h2_hist,
                                                                 const float* __restrict__ logits_hist,
                                                                 const float* __restrict__ orders_hist, NicTable2 g_reward,
