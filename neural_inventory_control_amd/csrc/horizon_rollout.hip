@@ -12,13 +12,21 @@
 //   * weights live in registers as MFMA A fragments for the whole horizon (wave w owns rows 16 w .. 16 w + 15 of every layer);
 //     activations cross the four wavefronts through 4 KB of LDS per layer in a b128-friendly order;
 //   * state, logits, orders, demand of the period and every static table (costs, lead times) sit in LDS as [row][16 scenarios];
-//     head and env step are the SAME bodies the per-period kernels run (policy_heads_body.h, env_step_body.h), handed LDS
-//     pointers (scenario stride 16) instead of HBM rows - one wavefront, four lanes per scenario (the "quad" of env_step.hip);
+//     head and env step give every (scenario, store) pair its own lane (256 lanes for 16 x 21 pairs): the one-location bodies
+//     of env_step_body.h (`env_*_t`: the arithmetic of a store / warehouse of the per-period kernels, bit for bit, read through an
+//     accessor over 32-bit LDS offsets), the cross-store sums in the per-period kernels' Sum4 order, the data_driven head's
+//     per-warehouse sums in store order between two barriers.  (The first version ran them on ONE wavefront, four lanes per
+//     scenario: the env step alone was 6 us of a 13.7 us period.)
+//   * tape modes (NicHorizonDesc.head_mode): the same env phases driven by ORDERS (1: just-in-time) or order-up-to LEVELS (2: the
+//     quantile policies; the backward then returns d loss / d level) that the caller computed for all periods in one batched pass;
 //   * the backward kernel walks the periods in reverse over the stored histories (state rows, hidden activations, logits,
 //     orders), next period's loads issued a whole period ahead, and leaves the three pre-activation gradients per period; the
 //     weight gradients are then ordinary contractions over (period x scenario) columns (nic_linear_wgrad).
+//   * global memory: `vmcnt` retires loads and stores in issue order, so all global traffic of a period is issued in one burst at
+//     the top of the period (next period's loads first, then the previous period's results from registers / LDS) and nothing is
+//     waited for until the top of the next period; barriers publish LDS only (nic::lds_barrier).
 // Latency-bound by construction (5 of 256 CUs for a 72-product batch): the figure of merit is microseconds per period of the
-// dependent chain, not a roofline fraction.  History layout: element (row, t, b) at row * hist_stride + t * ldb + b.
+// dependent chain (9.5 forward / 12.4 backward at the reference's real-data shape), not a roofline fraction.  History layout: element (row, t, b) at row * hist_stride + t * ldb + b.
 // Built with -ffp-contract=off (head / env arithmetic rounds like the reference's separate aten ops); the MFMA chains are fma
 // by construction.  Same arithmetic as the per-period route except the summation order inside a layer's contraction.
 #include "env_step_body.h"
