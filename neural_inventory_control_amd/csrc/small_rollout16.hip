@@ -14,8 +14,10 @@
 // stands (the same trick as the 32-wide kernels), and the resident A fragments are loaded in that k order once.  The four lane
 // groups g replicate the per-scenario state, head and env step (small_rollout_body.h).
 // Hidden-activation history: the forward / backward pair of THIS file keeps it in a wave-native order - element e of lane l of
-// layer y, period t, 16-scenario block q at ((t * n_blocks + q) * n_hidden + y) * 512 + e * 64 + l (n_blocks = ldb / 16) - so that
-// every history store / load of a wavefront is one contiguous 256-byte access (in the [row][t][ldb] order of the 32-wide
+// layer y, period t, 16-scenario block q at ((t * n_blocks + q) * n_hidden + y) * 512 + l * 8 + e (n_blocks = ldb / 16; round 4:
+// lane-major, two 16-byte accesses per lane and layer - 2 KB contiguous per wavefront - instead of eight 4-byte ones: in-kernel
+// stamps had the history stores at a third of a forward period, ~100 cycles per store instruction) - so that
+// every history store / load of a wavefront is one contiguous access (in the [row][t][ldb] order of the 32-wide
 // kernels a 16-scenario wavefront would touch four 64-byte pieces per instruction: measured 0.26 of the HBM roofline against
 // 0.40).  Same buffer size; states and logits keep the [row][t][ldb] order.
 // Same arithmetic as the 32-wide kernels except the summation order inside a layer's contraction (k order differs): results
@@ -26,6 +28,19 @@
 
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// In-kernel timestamps of the forward kernel (tuning build only - tools/small_rollout_stamp_probe.py compiles its own copy of the
+// library with -DNIC_TUNING_BUILD; the product library contains none of this): the 100 MHz wall clock of workgroups 0 and 1 at 10
+// points of every period, [t][block < 2][point].
+#ifdef NIC_TUNING_BUILD
+__device__ unsigned long long* g_sr16_stamps = nullptr;
+#define SR_STAMP(t, point)                                                                                          \
+    do {                                                                                                            \
+        if (g_sr16_stamps != nullptr && blockIdx.x < 2 && lane == 0) g_sr16_stamps[((t) * 2 + blockIdx.x) * 16 + (point)] = wall_clock64(); \
+    } while (0)
+#else
+#define SR_STAMP(t, point) do { } while (0)
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int row16(int e, int g) { return 16 * (e >> 2) + 4 * g + (e & 3); }
@@ -123,11 +138,18 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_fwd_kernel(NicSmallRoll
     for (int k = 0; k < SR_MAXF; ++k) st[k] = k < d.F ? state0[(int64_t)k * ldb + b] : 0.f;
 
     const int64_t n_blk = ldb / 16;
-    auto hbase = [&](int t, int layer) { return (((int64_t)t * n_blk + blockIdx.x) * NL + layer) * 512 + lane; };
+    // (hidden history of a (period, block, layer): 512 floats, LANE-major - lane l's eight activations are 32 contiguous bytes, so a
+    // layer is two 16-byte stores per lane (2 KB contiguous per wavefront) instead of eight 4-byte ones: round 4, see the header)
+    auto hstore = [&](int t, int layer, const float (&h)[8]) {
+        f32x4* p = reinterpret_cast<f32x4*>(hidden_hist + (((int64_t)t * n_blk + blockIdx.x) * NL + layer) * 512 + lane * 8);
+        p[0] = f32x4{h[0], h[1], h[2], h[3]};
+        p[1] = f32x4{h[4], h[5], h[6], h[7]};
+    };
     float dem = demand[(int64_t)d.t0 * ldb + b];
     for (int t = 0; t < d.T; ++t) {
         f32x4 acc[2];
         float hcur[8];
+        SR_STAMP(t, 0);
         // layer 1: contraction over the state slots, k = 4 s + g
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot) {
@@ -137,7 +159,9 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_fwd_kernel(NicSmallRoll
                 acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(aW1[ot][s], sel4(g, st[4 * s], st[4 * s + 1], st[4 * s + 2], st[4 * s + 3]),
                                                                acc[ot], 0, 0, 0);
         }
+        SR_STAMP(t, 1);
         elu8(acc[0], acc[1], hcur);
+        SR_STAMP(t, 2);
         if (states_hist) {
             if (live && g == 0) {
 #pragma unroll
@@ -145,18 +169,20 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_fwd_kernel(NicSmallRoll
                     if (k < d.F) states_hist[k * tl + t * ldb + b] = st[k];
             }
             // (dead lanes store too: their slots of the block's wave-native history are read back by the backward's dead lanes)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) hidden_hist[hbase(t, 0) + e * 64] = hcur[e];
+            hstore(t, 0, hcur);
         }
+        SR_STAMP(t, 3);
 #pragma unroll
         for (int l = 1; l < NL; ++l) {
             layer32(aWh[l - 1], cB[l], hcur, acc);
+            if (l == 1) SR_STAMP(t, 4);
             elu8(acc[0], acc[1], hcur);
+            if (l == 1) SR_STAMP(t, 5);
             if (states_hist) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hidden_hist[hbase(t, l) + e * 64] = hcur[e];
+                hstore(t, l, hcur);
             }
         }
+        SR_STAMP(t, 6);
         // output layer: one 16-row tile; logit n lives in lane group n >> 2, register n & 3
         f32x4 zo = f32x4{cB[NL][0], cB[NL][1], cB[NL][2], cB[NL][3]};
 #pragma unroll
@@ -169,13 +195,16 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_fwd_kernel(NicSmallRoll
             for (int n = 0; n < SR_MAXOUT; ++n)
                 if (n < d.n_out) logits_hist[n * tl + t * ldb + b] = z[n];
         }
+        SR_STAMP(t, 7);
         const SrOrders o = sr_head(d, z, st);
+        SR_STAMP(t, 8);
         float nx[SR_MAXF];
         const float cost = sr_env_fwd(d, c, st, nx, dem, o);
         if (live && g == 0) rewards[(int64_t)t * ldb + b] = cost;
         dem = demand[(int64_t)(t + 1 < d.T ? t + 1 + d.t0 : t + d.t0) * ldb + b];
 #pragma unroll
         for (int k = 0; k < SR_MAXF; ++k) st[k] = nx[k];
+        SR_STAMP(t, 9);
     }
     if (live && g == 0) {
 #pragma unroll
@@ -285,9 +314,15 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_bwd_kernel(NicSmallRoll
         }
         fd = demand[(int64_t)(t + d.t0) * ldb + b];
 #pragma unroll
-        for (int l = 0; l < NL; ++l)
+        for (int l = 0; l < NL; ++l) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(hidden_hist + (((int64_t)t * n_blk + blockIdx.x) * NL + l) * 512 + lane * 8);
+            const f32x4 lo = p[0], hi = p[1];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fh[l][e] = hidden_hist[(((int64_t)t * n_blk + blockIdx.x) * NL + l) * 512 + e * 64 + lane];
+            for (int e = 0; e < 4; ++e) {
+                fh[l][e] = lo[e];
+                fh[l][4 + e] = hi[e];
+            }
+        }
     };
     fetch(d.T - 1, P0.st, P0.z, P0.dem, P0.hh);
     // one period: C = this period's set, N = the set the next (earlier) period's loads go to; gin / go = the state gradient
@@ -442,6 +477,13 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_bwd_kernel(NicSmallRoll
     }
 }
 }  // namespace
+
+#ifdef NIC_TUNING_BUILD
+extern "C" int nic_tuning_set_small_rollout_stamps(void* buf) {   // buf: device memory, [T][2][16] u64 (or null)
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sr16_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 namespace nic {
 
