@@ -33,6 +33,10 @@
 #include "nic_common.h"
 #include "policy_heads_body.h"
 
+#ifndef HZ_FORCE_OCC2
+#define HZ_FORCE_OCC2 0   // (experiment switch: every variant held to 256 registers = two workgroups per CU)
+#endif
+
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -265,7 +269,7 @@ __device__ __forceinline__ f32x4 layer64(const float (&aW)[16], const float* hx,
 // (the smallest variant - one-store settings, which the reference trains in batches of 8,192 = 512 workgroups - is held to 256
 // registers so that two workgroups share a CU: one round instead of two)
 template <int MAXW, int MAXS1>
-__global__ __launch_bounds__(kThreads, MAXS1 == 16 ? 2 : 1) void horizon_fwd_kernel(NicHorizonDesc d, const float* __restrict__ z1_obs,
+__global__ __launch_bounds__(kThreads, (MAXS1 == 16 || HZ_FORCE_OCC2) ? 2 : 1) void horizon_fwd_kernel(NicHorizonDesc d, const float* __restrict__ z1_obs,
                                                                 const float* __restrict__ state0, float* __restrict__ rewards,
                                                                 float* __restrict__ state_final, float* __restrict__ state_hist,
                                                                 float* __restrict__ h1_hist, float* __restrict__ h2_hist,
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(kThreads, MAXS1 == 16 ? 2 : 1) void horizon_fwd_ker
 // contractions on resident TRANSPOSED weight fragments - the first layer's only over the state rows (nothing else of the input
 // carries a gradient back in time).
 template <int MAXW, int VAR>
-__global__ __launch_bounds__(kThreads, VAR == 0 ? 2 : 1) void horizon_bwd_kernel(NicHorizonDesc d, const float* __restrict__ state_hist,
+__global__ __launch_bounds__(kThreads, (VAR == 0 || HZ_FORCE_OCC2) ? 2 : 1) void horizon_bwd_kernel(NicHorizonDesc d, const float* __restrict__ state_hist,
                                                                 const float* __restrict__ h1_hist, const float* __restrict__ h2_hist,
                                                                 const float* __restrict__ logits_hist,
                                                                 const float* __restrict__ orders_hist, NicTable2 g_reward,

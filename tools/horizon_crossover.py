@@ -23,7 +23,7 @@ DEV = "cuda:0"
 
 def main():
     T, out = 95, {}
-    for n in (72, 288, 1024, 2048, 4096, 8192, 16384, 32768):
+    for n in tuple(int(v) for v in os.environ.get("HC_SIZES", "72,288,1024,2048,4096,8192,16384,32768").split(",")):
         setting = workloads.real_data(n_products=n, seed=1)
         obs = defaultdict(lambda: None, setting["observation_params"])
         shift = obs["demand"]["period_shift"]
