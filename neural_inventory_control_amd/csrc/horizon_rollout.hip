@@ -484,17 +484,18 @@ __global__ __launch_bounds__(kThreads, (MAXS1 == 16 || HZ_FORCE_OCC2) ? 2 : 1) v
         }
         lds_barrier();
         HZ_STAMP(t, 6);
-        // ---- warehouses (tasks 0 .. Wn-1) and the Sum4 partials of the store costs (tasks Wn .. Wn+3) ----
-        for (int k = I.r0; k < Wn + nic::kQuad; k += 16) {
-            if (k < Wn) {
-                const float shipped = nic::env_shipped_t(env, k);
-                lds[L.cw + k * NB + I.j] = nic::env_fwd_warehouse_t<MAXW>(env, k, shipped);
-                lds[L.ord + (n_ord + k) * NB + I.j] = shipped;   // (history: the backward does not re-sum the orders)
-            } else {
-                float r = 0.f;
-                for (int s = k - Wn; s < S; s += nic::kQuad) r += lds[L.cst + s * NB + I.j];
-                lds[L.rq + (k - Wn) * NB + I.j] = r;
-            }
+        // ---- warehouses (row groups 0 .. Wn-1, ...) and the Sum4 partials of the store costs (the LAST four row groups: another
+        // wavefront than the first warehouses', so that neither walks through the other's branch) ----
+        for (int w = I.r0; w < Wn; w += 16) {
+            const float shipped = nic::env_shipped_t(env, w);
+            lds[L.cw + w * NB + I.j] = nic::env_fwd_warehouse_t<MAXW>(env, w, shipped);
+            lds[L.ord + (n_ord + w) * NB + I.j] = shipped;   // (history: the backward does not re-sum the orders)
+        }
+        if (I.r0 >= 16 - nic::kQuad) {
+            const int q = I.r0 - (16 - nic::kQuad);
+            float r = 0.f;
+            for (int s = q; s < S; s += nic::kQuad) r += lds[L.cst + s * NB + I.j];
+            lds[L.rq + q * NB + I.j] = r;
         }
         lds_barrier();
         HZ_STAMP(t, 7);
