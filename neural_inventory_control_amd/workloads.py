@@ -144,7 +144,7 @@ def real_data(n_products=288, n_stores=21, n_warehouses=3, weeks=171, past_perio
             f.write(f"{w},{(w * 7 + 180) % 365 - 182}\n")
     adj = [[1] * n_stores for _ in range(n_warehouses)]
     for w in range(n_warehouses):
-        for s_ in rnd.sample(range(n_stores), 2):
+        for s_ in rnd.sample(range(n_stores), min(2, n_stores - 1)):   # (two stores per warehouse lose their edge)
             adj[w][s_] = 0
     for s_ in range(n_stores):  # every store keeps at least one supplier
         if not any(adj[w][s_] for w in range(n_warehouses)):

@@ -290,3 +290,18 @@ def test_data_driven_whole_horizon_route_on_other_shapes(S, Wn, hidden, n, T, P)
         torch.testing.assert_close(a[3][k], b[3][k], rtol=2e-5, atol=2e-3)
     for ga, gb in zip(a[4], b[4]):
         assert float(gb.norm()) > 0 and float((ga - gb).norm()) <= 1e-4 * float(gb.norm()), float((ga - gb).norm() / gb.norm())
+
+
+def test_data_driven_whole_horizon_route_differential_fuzz():
+    """tools/horizon_fuzz.py, a dozen random shapes (1..30 stores, 1..4 warehouses, hidden widths 8..64, 1..250 scenarios, 2..20
+    periods): the whole-horizon kernels against the per-period route - totals to 1e-5, rewards to 1e-4, gradients to 1e-3 of their
+    norms (measured: 1e-7 .. 2e-6)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "horizon_fuzz.py"), "7", "12"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "suspicious: 0" in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("total ") == 12
