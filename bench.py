@@ -474,7 +474,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--workload", default="cfg3",
+                    help="one training step of: cfg1..cfg5 (BASELINE's configs; default cfg3), cfg3_shard8, cfg3_batch1024, base_stock, "
+                         "base_stock_1m, echelon_stock, gnn, gnn_many_warehouses, real_data_driven, cfg3_symmetry_aware; or one training "
+                         "EPOCH of a shipped YAML pair through Trainer.do_one_epoch: cfg3_yaml, cfg5_yaml, gnn_yaml, real_data_yaml, "
+                         "one_store_real_yaml, one_store_real_transformed_nv_yaml (neural_inventory_control_amd/workloads.py)")
     ap.add_argument("--scenarios", type=int, default=None, help="scenarios per GPU (default: the workload's)")
     ap.add_argument("--periods", type=int, default=None)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
