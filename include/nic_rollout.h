@@ -473,6 +473,20 @@ int nic_gnn_alloc_fwd(const float* out, const float* on_hand, float* orders, flo
 int nic_gnn_alloc_bwd(const float* out, const float* on_hand, const float* g_orders, const float* sums, const float* ratio,
                       const float* scale, float* d_out, float* g_on_hand, int32_t S, int32_t n_edges, int32_t e_self,
                       int32_t e_supplier, int32_t cap_at_one, int32_t n_scenarios, int32_t ldb, void* stream);
+/* The one-warehouse allocation head FOLLOWED by Simulator.step (neural_networks.py:1435-1492 -> environment.py:110-299) in ONE
+ * launch, and the adjoints in reverse order (csrc/gnn_alloc_env.hip): nic_gnn_alloc_fwd + nic_env_step_fwd /
+ * nic_env_step_bwd + nic_gnn_alloc_bwd with the same arguments, bit-identical results.  `io` as for nic_env_step_fwd, with its
+ * order tables pointing at the rows of `orders` [S + 1][ldb] (store orders, then the warehouse's own) and the warehouse's on-hand
+ * slot read from io->wh_inv; one supplying warehouse, no extra echelons.  Backward: g_orders [S + 1][ldb] is scratch written by the
+ * env adjoint and read by the head's; g_wh_in receives the env adjoint's warehouse gradient plus the allocation scale's. */
+int nic_gnn_alloc_env_fwd(const NicEnvStepIO* io, const float* out, float* orders, float* sums, float* ratio, float* scale,
+                          int32_t e_self, int32_t e_supplier, int32_t cap_at_one, float* store_inv_out, float* wh_inv_out, float* reward,
+                          void* stream);
+int nic_gnn_alloc_env_bwd(const NicEnvStepIO* io, const float* out, const float* sums, const float* ratio, const float* scale,
+                          int32_t n_edges, int32_t e_self, int32_t e_supplier, int32_t cap_at_one, const float* g_store_out,
+                          const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_orders, float* d_out,
+                          void* stream);
+
 /* The same allocation for SEVERAL supplying nodes (many-warehouse graphs: `_apply_proportional_allocation_to_graph`,
  * neural_networks.py:1435-1492, loops over every node with outgoing edges).  groups [n_groups][4] (device) = {first member edge,
  * member count, self-loop edge or -1, supplier edge} per warehouse - its internal edges are contiguous rows of `out`;

@@ -134,6 +134,8 @@ PROTOTYPES = {
     "nic_horizon_rollout_ok": (C.c_int, [C.POINTER(NicHorizonDesc)]),
     "nic_horizon_rollout_fwd": (C.c_int, [C.POINTER(NicHorizonDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_horizon_rollout_bwd": (C.c_int, [C.POINTER(NicHorizonDesc), _vp, _vp, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp]),
+    "nic_gnn_alloc_env_fwd": (C.c_int, [_IOP, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "nic_gnn_alloc_env_bwd": (C.c_int, [_IOP, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp]),
     "nic_round_orders": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "nic_mlp3_fwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp]),
     "nic_mlp3_fwd_residual": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -245,6 +245,7 @@ class GnnRollout:
         # longer to enqueue the ~27 launches per period than the GPU needs to run them, later runs are replayed (the reference's
         # shipped batch of 1,024 scenarios: 19.2 -> 14.6 ms per step; 8,192 scenarios are GPU-bound and stay eager)
         self.use_graph = False
+        self.fuse_alloc_env = True   # one-warehouse graphs: allocation head + env step (and their adjoints) in one launch each
         self._auto_graph = None
         self.auto_graph_probe = None
         self._probs = ProblemCache()
@@ -508,6 +509,11 @@ class GnnRollout:
         out = M["output"].Y[t][0]                                  # [E][ld] desired quantity per edge
         # proportional allocation of the warehouse's on-hand stock over its outgoing edges + self loop (:111-138, :1435-1492)
         orders = self.orders[t]
+        if P.Wn == 1 and self.fuse_alloc_env:   # allocation head + env step in one launch (round 4, csrc/gnn_alloc_env.hip)
+            self._k("alloc_env_fwd", ops.gnn_alloc_env_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), out, orders, self.sums[t],
+                    self.ratio[t], self.scale[t], P.e_self, P.e_supplier, not P.transshipment, self._views(self.states[t + 1], prob),
+                    self.rewards[t])
+            return
         if P.Wn == 1:
             ops.gnn_alloc_fwd(out, st.wh[0, 0], orders, self.sums[t], self.ratio[t], self.scale[t], S, P.e_self, P.e_supplier,
                               not P.transshipment, B)
@@ -524,10 +530,18 @@ class GnnRollout:
         ts, tw = self._order_tables(self.orders[t], prob)
         g_so, g_wo = self.g_orders[:S * P.Wn].view(S, P.Wn, -1), self.g_orders[S * P.Wn:]
         gc = self._views(g_cur, prob)
-        self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
-                self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=gc, g_orders=(g_so, g_wo, None))
+        fused = P.Wn == 1 and self.fuse_alloc_env
+        if fused:   # env-step adjoint + allocation adjoint in one launch
+            self._k("alloc_env_bwd", ops.gnn_alloc_env_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), M["output"].Y[t][0],
+                    self.orders[t], self.sums[t], self.ratio[t], self.scale[t], P.e_self, P.e_supplier, not P.transshipment,
+                    self._views(g_next, prob), Table(self.g_reward, 0, 1), gc, self.g_orders, self.d_out[0])
+        else:
+            self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
+                    self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=gc, g_orders=(g_so, g_wo, None))
         # allocation adjoint: alloc_e = out_e * min(1, on_hand / (sum + eps)) for the members, supplier edge passes through
-        if P.Wn == 1:
+        if fused:
+            pass
+        elif P.Wn == 1:
             ops.gnn_alloc_bwd(M["output"].Y[t][0], st.wh[0, 0], self.g_orders, self.sums[t], self.ratio[t], self.scale[t],
                               self.d_out[0], gc.wh[0, 0], S, P.e_self, P.e_supplier, not P.transshipment, B)
         else:

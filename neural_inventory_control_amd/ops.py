@@ -339,6 +339,27 @@ def gnn_alloc_bwd(out, on_hand, g_orders, sums, ratio, scale, d_out, g_on_hand, 
                                   n_scenarios, out.stride(0), current_stream()))
 
 
+def gnn_alloc_env_fwd(prob, state, demand: Table, out, orders, sums, ratio, scale, e_self, e_supplier, cap_at_one, next_state, reward):
+    """nic_gnn_alloc_env_fwd: allocation head + env step in one launch (one warehouse).  orders [S + 1][ldb]."""
+    _dev(out)
+    S, ld = prob.S, prob.ldb
+    io = prob.make_io(state.store, state.wh, None, demand, Table(orders[:S].view(S, 1, -1), ld, 1, ld), Table(orders[S:], ld, 1), None)
+    check(lib().nic_gnn_alloc_env_fwd(io, ptr(out), ptr(orders), ptr(sums), ptr(ratio), ptr(scale), -1 if e_self is None else e_self,
+                                      e_supplier, int(cap_at_one), ptr(next_state.store), ptr(next_state.wh), ptr(reward),
+                                      current_stream()))
+
+
+def gnn_alloc_env_bwd(prob, state, demand: Table, out, orders, sums, ratio, scale, e_self, e_supplier, cap_at_one, g_out, g_reward: Table,
+                      g_in, g_orders, d_out):
+    """nic_gnn_alloc_env_bwd: env-step adjoint + allocation adjoint in one launch.  g_out / g_in: EnvState of gradients."""
+    _dev(out)
+    S, ld = prob.S, prob.ldb
+    io = prob.make_io(state.store, state.wh, None, demand, Table(orders[:S].view(S, 1, -1), ld, 1, ld), Table(orders[S:], ld, 1), None)
+    check(lib().nic_gnn_alloc_env_bwd(io, ptr(out), ptr(sums), ptr(ratio), ptr(scale), d_out.shape[0], -1 if e_self is None else e_self,
+                                      e_supplier, int(cap_at_one), ptr(g_out.store), ptr(g_out.wh), g_reward.t2(), ptr(g_in.store),
+                                      ptr(g_in.wh), ptr(g_orders), ptr(d_out), current_stream()))
+
+
 def gnn_alloc_groups_fwd(out, on_hand, orders, sums, ratio, scale, groups, order_row, cap_at_one, n_scenarios):
     """Proportional allocation of several warehouses' stock, one launch (nic_gnn_alloc_groups_fwd).  on_hand [G][Ww][ldb]:
     slot 0 of every group's pipeline; sums / ratio / scale [G][ldb]."""

@@ -1619,6 +1619,36 @@ def test_gnn_graph_replay_matches_eager(name):
         assert engines and engines[0].use_graph == "auto"
 
 
+@pytest.mark.parametrize("name", ["f1_one_warehouse_gnn", "f1_one_warehouse_16_gnn", "f1_one_warehouse_gnn_transshipment"])
+def test_gnn_fused_alloc_env_launches_equal_the_separate_ones(name):
+    """Round 4: on one-warehouse graphs the GNN engine runs the allocation head and the env step in ONE launch per direction
+    (csrc/gnn_alloc_env.hip: the two bodies back to back with a workgroup barrier in between).  Same bodies, same order of
+    operations: costs, per-period rewards, final state and every gradient are BIT-IDENTICAL to the separate launches."""
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout
+    from neural_inventory_control_amd.rollout import KernelTimer
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    out = {}
+    for fused in (True, False):
+        model = _model(g, c)
+        eng = GnnRollout(model, c["problem_params"], DEV)
+        eng.fuse_alloc_env = fused
+        eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+        _load(model, g)
+        eng.timer = KernelTimer(record_order=True)
+        total, rep = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+        torch.cuda.synchronize()
+        tags = {t for t, _ in eng.timer.order}
+        assert ("alloc_env_fwd" in tags and "alloc_env_bwd" in tags and "env_fwd" not in tags) == fused
+        out[fused] = (float(total), float(rep), eng.rewards.clone(), eng.states[-1].clone(), [p.grad.clone() for p in model.parameters()])
+    a, b = out[True], out[False]
+    assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for x, y in zip(a[4], b[4]):
+        assert torch.equal(x, y)
+    assert abs(a[0] - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
+
+
 @pytest.mark.parametrize("setting_name", ["cfg3", "cfg2"])
 def test_per_sample_cost_tables_with_shuffled_batches_follow_the_oracle(setting_name):
     """`vary_across_samples: True` (data_handling.py:258-259): underage costs differ per SCENARIO, so every shuffled batch has
