@@ -258,6 +258,12 @@ def algorithmic_work(tag, kernel, shape):
         return "hbm", 4.0 * (2 * f_state + S + shape["n_out"] + n_ord + 1) * n, "B"
     if tag == "head_env_bwd":  # state, orders, demand, logits, incoming state gradient in; state gradient, order gradients, dZ out
         return "hbm", 4.0 * (3 * f_state + S + 2 * n_ord + 2 * shape["n_out"]) * n, "B"
+    if tag in ("alloc_env_fwd", "alloc_env_bwd"):   # GNN: allocation head + env step in one launch (one warehouse)
+        n_edges = shape["gnn"]["output"][2] if shape.get("gnn") else S + 2
+        if tag == "alloc_env_fwd":  # state read + write, demand, desired quantities of the member / self / supplier edges, orders, sums / ratio / scale, reward
+            return "hbm", 4.0 * (2 * f_state + S + (S + 2) + n_ord + 3 + 1) * n, "B"
+        # state, orders, demand, desired quantities, incoming state gradient in; state gradient, order gradients (scratch) and d_out out
+        return "hbm", 4.0 * (3 * f_state + S + 2 * n_ord + (S + 2) + 3 + n_edges) * n, "B"
     if tag == "head_fwd":  # logits + the warehouse / echelon on-hand row in, orders out
         return "hbm", 4.0 * (shape["n_out"] + Wn + E + n_ord) * n, "B"
     if tag == "head_bwd":  # logits, on-hand rows and order gradients in; logit gradients (+ on-hand gradients) out
@@ -705,7 +711,7 @@ def main():
                 if "other" in d:
                     out["roofline"]["other"] = d["other"]
             out["kernels"] = kernels
-            env_tag = "env_fwd" if "env_fwd" in kernels else "head_env_fwd"
+            env_tag = next((t_ for t_ in ("env_fwd", "head_env_fwd", "alloc_env_fwd") if t_ in kernels), "env_fwd")
             if env_tag in kernels and "bound" in kernels[env_tag]:
                 e = kernels[env_tag]
                 out["roofline_env_step"] = {"bound": "hbm", "achieved": e["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
