@@ -30,13 +30,16 @@ class _TapeTotal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, levels, eng, args):
         total, reported = eng._forward(levels.detach(), args, train=True)
-        ctx.eng, ctx.args, ctx.dtype = eng, args, levels.dtype
+        ctx.eng, ctx.args, ctx.dtype, ctx.run_id = eng, args, levels.dtype, eng._run_id
         ctx.mark_non_differentiable(reported)
         return total, reported
 
     @staticmethod
     def backward(ctx, g_total, _g_reported):
-        return ctx.eng._backward(g_total, ctx.args).to(ctx.dtype), None, None
+        if ctx.run_id != ctx.eng._run_id:   # the histories the adjoint reads belong to the engine, not to this graph
+            raise RuntimeError("TapeRollout: backward of a rollout whose histories a later run of the same engine has overwritten "
+                               "(call backward before the next simulate_batch, as Trainer.do_one_epoch does)")
+        return ctx.eng._backward(g_total, ctx.args).to(ctx.dtype, copy=True), None, None
 
 
 class TapeRollout:
@@ -68,6 +71,7 @@ class TapeRollout:
         self.timer = None
         self._probs = ProblemCache()
         self._key = None
+        self._run_id = 0   # bumped by every forward: a backward checks that the histories are still its own
 
     def shapes_ok(self, data, periods=1, period_shift=0):
         p = self._probs.get(self.problem_params, data, self.device)
@@ -209,6 +213,7 @@ class TapeRollout:
         """tape_values: [T][B][rows] (levels or orders; any float dtype - the interpolation is float64 upstream, the env step's
         operands float32)."""
         prob, T, _, ignore, _, _ = args
+        self._run_id += 1
         self.tape[:, :, :prob.B].copy_(tape_values.permute(2, 0, 1))
         desc = self._desc(args)
         hist = (self.state_hist, None, None, None, self.orders_hist) if train else (None,) * 5

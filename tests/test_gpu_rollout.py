@@ -496,6 +496,39 @@ def test_tape_engine_matches_reference(name):
     assert abs(float(r3) - float(ref.reported)) <= 1e-5 * abs(float(ref.reported))
 
 
+def test_tape_engine_refuses_the_backward_of_an_overwritten_rollout():
+    """The whole-horizon adjoint reads histories that belong to the ENGINE: a backward through an older rollout, after the same
+    engine has run again, would silently use the newer run's states - it raises instead; the usual order (forward, backward,
+    forward, backward) works and gives the same gradients twice."""
+    name = QUANTILE_TRAINABLE[1]
+    g = Golden(name)
+    c = g.fresh_config()
+    model = _model(g, c)
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    sim, tr = Simulator(device=DEV), Trainer(device=DEV)
+    obs, _ = sim.reset(c["periods"], c["problem_params"], data, c["observation_params"])
+    with torch.no_grad():
+        o = dict(obs)
+        o["internal_data"] = sim._internal_data
+        model(o)
+    _load(model, g)
+
+    def run():
+        return tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data, c["observation_params"],
+                                 c["ignore"], False)[0]
+    grads = []
+    for _ in range(2):
+        model.zero_grad()
+        run().backward()
+        grads.append([p_.grad.clone() for p_ in model.parameters()])
+    for a, b in zip(*grads):   # (autograd's scatter-adds behind the interpolation are atomic: not bit-reproducible)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+    first = run()
+    run()
+    with pytest.raises(RuntimeError, match="overwritten"):
+        first.backward()
+
+
 @pytest.mark.parametrize("name", [n for n in case_names() if n.startswith("f4_real")])
 def test_real_data_observations_and_dynamics_follow_the_reference_tape(name):
     """`Simulator.reset/step` on a real-data setting (period_shift 16, past-demand window of 16, days from
