@@ -241,6 +241,8 @@ int nic_head_serial_bwd(const float* Z, const float* wh_inv, const float* ech_in
 #define NIC_SR_MAX_INPUTS 16  /* F  = Ws + Wn*Ww + E*We */
 #define NIC_SR_HIDDEN 32      /* width of every hidden layer */
 #define NIC_SR_MAX_OUTPUTS 8
+#define NIC_SR16_STATE_ROWS(F) (((F) + 3) & ~3)
+#define NIC_SR16_LOGIT_ROWS(n_out) ((n_out) == 1 ? 1 : (((n_out) + 3) & ~3))
 typedef struct NicSmallRolloutDesc {
     int32_t n_scenarios, ldb, T, t0;       /* t0 = observation_params['demand']['period_shift'] */
     int32_t F, n_hidden, n_out, head;      /* n_hidden in 1..3; head 0: softplus(z+1), 1: sigmoid(z) * upstream on-hand */
@@ -252,9 +254,10 @@ typedef struct NicSmallRolloutDesc {
     float upper_bound;                     /* model.warehouse_upper_bound (head 1) */
     int32_t lane_scenarios;                /* scenarios per wavefront of the matrix-core kernels: 0 / 32 (v_mfma_f32_32x32x2_f32)
                                               or 16 (v_mfma_f32_16x16x4_f32: twice the wavefronts, half the chain per wavefront;
-                                              for batches that leave SIMDs idle at 32).  With 16 the hidden-activation history
-                                              is in a wave-native order private to nic_small_rollout_fwd /
-                                              nic_small_rollout_bwd_wgrad: pass the same value to both */
+                                              for batches that leave SIMDs idle at 32).  With 16 the histories are in a
+                                              wave-native order private to nic_small_rollout_fwd / nic_small_rollout_bwd_wgrad
+                                              (pass the same value to both), and states_hist / logits_hist hold
+                                              NIC_SR16_STATE_ROWS(F) / NIC_SR16_LOGIT_ROWS(n_out) rows of [T][ldb] floats */
     const float* weights;                  /* packed: [W1 32xF][b1 32] [W_l 32x32][b_l 32]... [Wout n_out x 32][bout n_out] */
     const float* demand;                   /* [T_total][ldb] */
     const float* state0;                   /* [F][ldb] */

@@ -19,7 +19,11 @@
 // stamps had the history stores at a third of a forward period, ~100 cycles per store instruction) - so that
 // every history store / load of a wavefront is one contiguous access (in the [row][t][ldb] order of the 32-wide
 // kernels a 16-scenario wavefront would touch four 64-byte pieces per instruction: measured 0.26 of the HBM roofline against
-// 0.40).  Same buffer size; states and logits keep the [row][t][ldb] order.
+// 0.40).  States and logits go the same way (round 4): a (period, block)'s state slots are [scenario j][Fp] (Fp = F rounded up to
+// 4: one 16-byte store per lane - lane group g owns slots 4 g .. 4 g + 3 -, Fp / 4 16-byte loads per lane in the backward,
+// instead of F 4-byte accesses of 64 bytes per wavefront each, which also fetched every 128-byte line twice: cfg4's backward moved
+// 1.25 x its algorithmic bytes), its logits [scenario j][NOp] (NOp = n_out rounded up to 4; n_out = 1: [scenario j], the old
+// position) - `sr16_state_rows` / `sr16_logit_rows` give the row counts the caller allocates ([rows][T][ldb] floats as before).
 // Same arithmetic as the 32-wide kernels except the summation order inside a layer's contraction (k order differs): results
 // agree to rounding, parity is against the golden vectors / the per-period route as before.
 #include "nic_common.h"
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_fwd_kernel(NicSmallRoll
     for (int k = 0; k < SR_MAXF; ++k) st[k] = k < d.F ? state0[(int64_t)k * ldb + b] : 0.f;
 
     const int64_t n_blk = ldb / 16;
+    const int Fp = sr16_state_rows(d.F), NOp = sr16_logit_rows(d.n_out);
     // (hidden history of a (period, block, layer): 512 floats, LANE-major - lane l's eight activations are 32 contiguous bytes, so a
     // layer is two 16-byte stores per lane (2 KB contiguous per wavefront) instead of eight 4-byte ones: round 4, see the header)
     auto hstore = [&](int t, int layer, const float (&h)[8]) {
@@ -163,12 +168,13 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_fwd_kernel(NicSmallRoll
         elu8(acc[0], acc[1], hcur);
         SR_STAMP(t, 2);
         if (states_hist) {
-            if (live && g == 0) {
-#pragma unroll
-                for (int k = 0; k < SR_MAXF; ++k)
-                    if (k < d.F) states_hist[k * tl + t * ldb + b] = st[k];
-            }
             // (dead lanes store too: their slots of the block's wave-native history are read back by the backward's dead lanes)
+            if (4 * g < Fp) {
+                static_assert(SR_MAXF == 16, "lane group g owns state slots 4 g .. 4 g + 3");
+                *reinterpret_cast<f32x4*>(states_hist + (((int64_t)t * n_blk + blockIdx.x) * 16 + j) * Fp + 4 * g) =
+                    f32x4{sel4(g, st[0], st[4], st[8], st[12]), sel4(g, st[1], st[5], st[9], st[13]),
+                          sel4(g, st[2], st[6], st[10], st[14]), sel4(g, st[3], st[7], st[11], st[15])};
+            }
             hstore(t, 0, hcur);
         }
         SR_STAMP(t, 3);
@@ -190,10 +196,12 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_fwd_kernel(NicSmallRoll
         float z[SR_MAXOUT];
 #pragma unroll
         for (int n = 0; n < SR_MAXOUT; ++n) z[n] = __shfl(zo[n & 3], j + 16 * (n >> 2));
-        if (logits_hist && live && g == 0) {
-#pragma unroll
-            for (int n = 0; n < SR_MAXOUT; ++n)
-                if (n < d.n_out) logits_hist[n * tl + t * ldb + b] = z[n];
+        if (logits_hist) {   // lane (j, g) holds logits 4 g .. 4 g + 3 of scenario j as they leave the matrix core
+            if (d.n_out == 1) {
+                if (live && g == 0) logits_hist[t * ldb + b] = zo[0];
+            } else if (4 * g < NOp) {
+                *reinterpret_cast<f32x4*>(logits_hist + (((int64_t)t * n_blk + blockIdx.x) * 16 + j) * NOp + 4 * g) = zo;
+            }
         }
         SR_STAMP(t, 7);
         const SrOrders o = sr_head(d, z, st);
@@ -300,17 +308,28 @@ __global__ __launch_bounds__(64, 2) void small_rollout16_bwd_kernel(NicSmallRoll
         return s_;
     };
     const int64_t n_blk = ldb / 16;
+    const int Fp = sr16_state_rows(d.F), NOp = sr16_logit_rows(d.n_out);
     auto fetch = [&](int t, float (&fs)[SR_MAXF], float (&fz)[SR_MAXOUT], float& fd, float (&fh)[NL][8]) {
-        const int64_t at = (int64_t)t * ldb + b;
+        const int64_t blk = ((int64_t)t * n_blk + blockIdx.x) * 16 + j;
+        const f32x4* sp = reinterpret_cast<const f32x4*>(states_hist + blk * Fp);
 #pragma unroll
-        for (int k = 0; k < SR_MAXF; ++k) {
-            const float v = states_hist[(k < d.F ? k : d.F - 1) * tl + at];
-            fs[k] = k < d.F ? v : 0.f;
+        for (int s = 0; s < SR_MAXF / 4; ++s) {
+            const f32x4 v = sp[4 * s < Fp ? s : 0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fs[4 * s + i] = 4 * s + i < d.F ? v[i] : 0.f;
         }
+        if (d.n_out == 1) {
+            fz[0] = logits_hist[(int64_t)t * ldb + b];
 #pragma unroll
-        for (int n = 0; n < SR_MAXOUT; ++n) {
-            const float v = logits_hist[(n < d.n_out ? n : d.n_out - 1) * tl + at];
-            fz[n] = n < d.n_out ? v : 0.f;
+            for (int n = 1; n < SR_MAXOUT; ++n) fz[n] = 0.f;
+        } else {
+            const f32x4* zp = reinterpret_cast<const f32x4*>(logits_hist + blk * NOp);
+#pragma unroll
+            for (int s = 0; s < SR_MAXOUT / 4; ++s) {
+                const f32x4 v = zp[4 * s < NOp ? s : 0];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fz[4 * s + i] = 4 * s + i < d.n_out ? v[i] : 0.f;
+            }
         }
         fd = demand[(int64_t)(t + d.t0) * ldb + b];
 #pragma unroll

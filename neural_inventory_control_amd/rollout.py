@@ -231,7 +231,10 @@ class FusedRollout:
             self.sr_state0 = z(F, ld)
             self.sr_weights = z(sr.packed_weight_count(F, nh, no))
             if train:
-                self.sr_states, self.sr_hidden, self.sr_logits = z(F, T, ld), z(nh * sr.H, T, ld), z(no, T, ld)
+                # (rows padded as the 16-wide kernels keep them - NIC_SR16_STATE_ROWS / NIC_SR16_LOGIT_ROWS; the 32-wide form
+                # uses the first F / n_out rows in [row][T][ld] order)
+                self.sr_states, self.sr_hidden = z((F + 3) // 4 * 4, T, ld), z(nh * sr.H, T, ld)
+                self.sr_logits = z(no if no == 1 else (no + 3) // 4 * 4, T, ld)
                 self.g_reward = z(ld)
                 if self.small_wgrad_in_kernel:
                     # weight gradients contracted inside the backward kernel: one partial gradient per wavefront in the
@@ -640,7 +643,7 @@ class FusedRollout:
         self._k("small_rollout_bwd", sr.small_rollout_bwd, desc, *hist, Table(self.g_reward, 0, 1), self.sr_dzh, self.sr_dzo)
         # weight gradients: contraction over (period, scenario) = T*ld columns; padding columns of dZ are zero
         n_cols, nh = T * ld, plan.n_hidden
-        inputs = [self.sr_states] + [self.sr_hidden[sr.H * l:sr.H * (l + 1)] for l in range(nh)]
+        inputs = [self.sr_states[:self.dims[0]]] + [self.sr_hidden[sr.H * l:sr.H * (l + 1)] for l in range(nh)]
         dzs = [self.sr_dzh[sr.H * l:sr.H * (l + 1)] for l in range(nh)] + [self.sr_dzo]
         for i, m in enumerate(lins):
             self.slabs[i].zero_()
