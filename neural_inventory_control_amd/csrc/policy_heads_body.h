@@ -11,6 +11,26 @@ namespace nic {
 
 NIC_HD float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// The softmax of the warehouse head on the device: e = exp(z - max) on the hardware exponential (v_exp_f32: the argument is <= 0,
+// relative error ~1 ulp + |z - max| 6e-8 from the exponent's rounding) and the share e / denom as e * rcp(denom) (v_rcp_f32, 1 ulp;
+// the reciprocal of a (scenario, warehouse) is computed once) instead of libm's expf (~15 instructions) and an IEEE division (~10)
+// per store - a lane of BASELINE cfg5's head walks 48 (store, warehouse) pairs.  The host build (tests/hostsim, the oracle's
+// twin) keeps expf and the division.
+NIC_HD float head_exp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __expf(x);
+#else
+    return expf(x);
+#endif
+}
+NIC_HD float head_share(float e, float denom) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return e * __builtin_amdgcn_rcpf(denom);
+#else
+    return e / denom;
+#endif
+}
+
 // softplus(z + 1) with nn.Softplus defaults (beta 1, threshold 20)   neural_networks.py:211-212
 NIC_HD float softplus1_fwd(float z) {
     const float x = z + 1.f;
@@ -57,7 +77,7 @@ NIC_HD void head_warehouse_fwd_one(const float* Z, const float* wh_inv, const in
             }
     }
     // pass 2: denominator
-    float denom = transshipment ? 0.f : expf(1.f - m);
+    float denom = transshipment ? 0.f : head_exp(1.f - m);
     for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
         float z[kHeadBatch];
         int a[kHeadBatch];
@@ -69,7 +89,7 @@ NIC_HD void head_warehouse_fwd_one(const float* Z, const float* wh_inv, const in
         }
 #pragma unroll
         for (int u = 0; u < kHeadBatch; ++u)
-            if (a[u]) denom += expf(z[u] - m);
+            if (a[u]) denom += head_exp(z[u] - m);
     }
     // pass 3: shares of the on-hand stock
     float* ow = store_orders + (int64_t)w * ldb + b;
@@ -83,7 +103,7 @@ NIC_HD void head_warehouse_fwd_one(const float* Z, const float* wh_inv, const in
             a[u] = s0 + u < S ? aw[s] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < kHeadBatch; ++u) o[u] = (a[u] && n_conn > 0) ? (expf(z[u] - m) / denom) * stock : 0.f;
+        for (int u = 0; u < kHeadBatch; ++u) o[u] = (a[u] && n_conn > 0) ? (head_share(head_exp(z[u] - m), denom)) * stock : 0.f;
 #pragma unroll
         for (int u = 0; u < kHeadBatch; ++u)
             if (s0 + u < S) ow[(s0 + u) * rs] = o[u];
@@ -121,7 +141,7 @@ NIC_HD void head_warehouse_bwd_one(const float* Z, const float* wh_inv, const in
         for (int u = 0; u < kHeadBatch; ++u)
             if (a[u]) m = z[u] > m ? z[u] : m;
     }
-    float denom = transshipment ? 0.f : expf(1.f - m);
+    float denom = transshipment ? 0.f : head_exp(1.f - m);
     for (int s0 = 0; s0 < S; s0 += kHeadBatch) {
         float z[kHeadBatch];
         int a[kHeadBatch];
@@ -133,7 +153,7 @@ NIC_HD void head_warehouse_bwd_one(const float* Z, const float* wh_inv, const in
         }
 #pragma unroll
         for (int u = 0; u < kHeadBatch; ++u)
-            if (a[u]) denom += expf(z[u] - m);
+            if (a[u]) denom += head_exp(z[u] - m);
     }
     // order_s = y_s * stock;  g_y_s = g_order_s * stock;  g_stock = sum_s g_order_s * y_s
     // softmax backward: dz_s = y_s * (g_y_s - sum_j y_j g_y_j)   (the keep column has g_y = 0)
@@ -151,7 +171,7 @@ NIC_HD void head_warehouse_bwd_one(const float* Z, const float* wh_inv, const in
 #pragma unroll
         for (int u = 0; u < kHeadBatch; ++u)
             if (a[u]) {
-                const float y = expf(z[u] - m) / denom;
+                const float y = head_share(head_exp(z[u] - m), denom);
                 dot += y * (go[u] * stock);
                 g_stock += go[u] * y;
             }
@@ -171,7 +191,7 @@ NIC_HD void head_warehouse_bwd_one(const float* Z, const float* wh_inv, const in
         for (int u = 0; u < kHeadBatch; ++u) {
             dz[u] = 0.f;
             if (a[u]) {
-                const float y = expf(z[u] - m) / denom;
+                const float y = head_share(head_exp(z[u] - m), denom);
                 dz[u] = y * (go[u] * stock - dot);
             }
         }
@@ -249,13 +269,13 @@ NIC_HD float head_quad_exp(HeadLane<MAXSQ>& L, float m) {
     float d = 0.f;
 #pragma unroll
     for (int u = 0; u < MAXSQ; ++u) {
-        L.e[u] = L.a[u] ? expf(L.z[u] - m) : 0.f;
+        L.e[u] = L.a[u] ? head_exp(L.z[u] - m) : 0.f;
         d += L.e[u];
     }
     return d;
 }
 NIC_HD float head_quad_denom(float d0, float d1, float d2, float d3, float m, int transshipment) {
-    return (transshipment ? 0.f : expf(1.f - m)) + combine4(d0, d1, d2, d3);
+    return (transshipment ? 0.f : head_exp(1.f - m)) + combine4(d0, d1, d2, d3);
 }
 template <int MAXSQ>
 NIC_HD void head_quad_fwd_store(const HeadLane<MAXSQ>& L, float denom, float stock, int n_conn, float* store_orders, int S, int Wn,
@@ -264,7 +284,7 @@ NIC_HD void head_quad_fwd_store(const HeadLane<MAXSQ>& L, float denom, float sto
     const int64_t rs = (int64_t)Wn * ldb;
     float o[MAXSQ];
 #pragma unroll
-    for (int u = 0; u < MAXSQ; ++u) o[u] = (L.a[u] && n_conn > 0) ? (L.e[u] / denom) * stock : 0.f;
+    for (int u = 0; u < MAXSQ; ++u) o[u] = (L.a[u] && n_conn > 0) ? head_share(L.e[u], denom) * stock : 0.f;
     if (S == kQuad * MAXSQ) {  // every lane owns MAXSQ stores: straight-line stores
 #pragma unroll
         for (int u = 0; u < MAXSQ; ++u) ow[(q + kQuad * u) * rs] = o[u];
@@ -281,7 +301,7 @@ NIC_HD void head_quad_bwd_dots(HeadLane<MAXSQ>& L, float denom, float stock, flo
     g_stock = 0.f;
 #pragma unroll
     for (int u = 0; u < MAXSQ; ++u) {  // (e is exactly 0 for stores that are not connected: their terms add +0)
-        L.e[u] = L.a[u] ? L.e[u] / denom : 0.f;
+        L.e[u] = L.a[u] ? head_share(L.e[u], denom) : 0.f;
         const float gz = L.a[u] ? L.g[u] : 0.f;
         dot += L.e[u] * (gz * stock);
         g_stock += gz * L.e[u];

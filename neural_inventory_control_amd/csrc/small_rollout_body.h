@@ -109,6 +109,48 @@ NIC_HD void sr_layer_out(const NicSmallRolloutDesc& d, const float (&x)[SR_H], f
     }
 }
 
+// ---- head transcendentals ------------------------------------------------------------------------------------------------
+// libm's log1pf(expf(x)) and 1 / (1 + expf(-x)) are ~100 / ~40 instructions per call on the device; the whole-horizon kernels are
+// bound by the length of a period's instruction stream, and in-kernel stamps had cfg2's ONE softplus per lane at
+// 0.75 of a 6-us forward period.  On the device: hardware exp / log / reciprocal (v_exp_f32, v_log_f32, v_rcp_f32: ~1 ulp each),
+// softplus as max(x, 0) + log1p(exp(-|x|)) with Kahan's correction log1p(e) = log(u) e / (u - 1), u = fl(1 + e), which keeps the
+// RELATIVE accuracy of small orders (x << 0) that log(1 + e) alone loses; relative error <= ~4e-7 for |x| <= 5, growing like
+// |x| 6e-8 with the exponent's rounding as in the ELU above.  With rounded orders (evaluation with discrete allocation) the libm
+// forms are used: a knife-edge order must round as the oracle's does.  The host build (tests/hostsim) keeps the libm forms.
+NIC_HD float sr_softplus1(float z, bool exact) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (exact) return softplus1_fwd(z);
+    const float x = z + 1.f;
+    const float e = __expf(-fabsf(x));   // (0, 1]
+    const float u = 1.f + e, dlt = u - 1.f;
+    const float l = dlt == 0.f ? e : __logf(u) * (e * __builtin_amdgcn_rcpf(dlt));
+    const float sp = fmaxf(x, 0.f) + l;
+    return x > 20.f ? x : sp;
+#else
+    (void)exact;
+    return softplus1_fwd(z);
+#endif
+}
+NIC_HD float sr_sigmoid(float x, bool exact) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (exact) return sigmoidf_(x);
+    return __builtin_amdgcn_rcpf(1.f + __expf(-x));
+#else
+    (void)exact;
+    return sigmoidf_(x);
+#endif
+}
+// d softplus(z + 1) / dz = sigmoid(z + 1) (1 above nn.Softplus's threshold)
+NIC_HD float sr_softplus1_grad(float z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float x = z + 1.f;
+    const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-x));
+    return x > 20.f ? 1.f : sg;
+#else
+    return softplus1_grad(z);
+#endif
+}
+
 // ---- orders from logits (heads) -------------------------------------------------------------------------------------
 struct SrOrders {
     float store, wh, ech[SR_MAXE];
@@ -120,7 +162,7 @@ NIC_HD SrOrders sr_head(const NicSmallRolloutDesc& d, const float (&z)[SR_MAXOUT
 #pragma unroll
     for (int e = 0; e < SR_MAXE; ++e) o.ech[e] = 0.f;
     if (d.head == 0) {
-        o.store = softplus1_fwd(z[0]);  // neural_networks.py:211-212
+        o.store = sr_softplus1(z[0], d.round_orders != 0);  // neural_networks.py:211-212
         if (d.round_orders) o.store = rintf(o.store);  // trainer.py:201-202
         return o;
     }
@@ -135,7 +177,7 @@ NIC_HD SrOrders sr_head(const NicSmallRolloutDesc& d, const float (&z)[SR_MAXOUT
                 if (j >= 1 && j <= d.E && k == d.Ws + d.Ww + (j - 1) * d.We) up = st[k];
                 if (j == d.E + 1 && k == d.Ws) up = st[k];
             }
-            const float a = sigmoidf_(z[j]) * up;
+            const float a = sr_sigmoid(z[j], d.round_orders != 0) * up;
             if (j < d.E) o.ech[j] = a;
             else if (j == d.E) o.wh = a;
             else o.store = a;
@@ -300,14 +342,14 @@ NIC_HD void sr_head_bwd(const NicSmallRolloutDesc& d, const float (&z)[SR_MAXOUT
 #pragma unroll
     for (int n = 0; n < SR_MAXOUT; ++n) dz[n] = 0.f;
     if (d.head == 0) {
-        dz[0] = g.store * softplus1_grad(z[0]);
+        dz[0] = g.store * sr_softplus1_grad(z[0]);
         return;
     }
 #pragma unroll
     for (int j = 0; j < SR_MAXE + 2; ++j) {
         if (j < d.E + 2) {
             const float gj = j < d.E ? g.ech[(j < SR_MAXE) ? j : 0] : (j == d.E ? g.wh : g.store);
-            const float sg = sigmoidf_(z[j]);
+            const float sg = sr_sigmoid(z[j], false);   // (training only: orders are never rounded here)
             float up = d.upper_bound;
             int up_idx = -1;
             if (j >= 1 && j <= d.E) up_idx = d.Ws + d.Ww + (j - 1) * d.We;
