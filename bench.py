@@ -510,6 +510,8 @@ def main():
     ap.add_argument("--eval", action="store_true",
                     help="SURVEY 8(f2): time the forward-only evaluation pass (Trainer.test: no gradients, discrete allocation "
                          "for Poisson demand) instead of a training step; use with --periods 5000 for the reference's test horizon")
+    ap.add_argument("--adam", choices=["fused", "foreach"], default="fused",
+                    help="torch.optim.Adam implementation: torch's one-kernel form (default) or its for-each form (torch's own default)")
     ap.add_argument("--no-horizon", action="store_true",
                     help="data_driven workloads: the per-period kernels instead of the whole-horizon kernels (A/B)")
     ap.add_argument("--horizon-max-scenarios", type=int, default=0,
@@ -560,7 +562,12 @@ def main():
         if args.horizon_max_scenarios:
             eng.horizon_max_scenarios = args.horizon_max_scenarios
         parallel.broadcast_model(model, src=0)
-    opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+    # the reference's optimizer (main_run.py: torch.optim.Adam); torch's single-kernel implementation of it where the parameters
+    # allow (same update rule; the default for-each form is six launches per step, 30 us of the small policies' ~1-ms steps)
+    from torch.nn.parameter import UninitializedParameter
+    fused_adam = (args.adam == "fused" and device.type == "cuda"
+                  and not any(isinstance(p_, UninitializedParameter) for p_ in model.parameters()))
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4, **({"fused": True} if fused_adam else {}))
     if args.graph and eng is not None and not closed_form:
         eng.use_graph = True
         args.no_kernel_timing = True
@@ -678,6 +685,8 @@ def main():
                                  if getattr(eng, "horizon", None) is not None else "per-period kernels"),
                        "mean_cost_per_store_period": loss},
         }
+        if not args.eval:
+            out["config"]["optimizer"] = "torch.optim.Adam(lr=3e-4" + (", fused=True)" if fused_adam else ")")
         if timer is not None and timer.order is not None:
             json.dump({"workload": args.workload, "n_scenarios": n, "periods": T, "steps": args.steps, "order": timer.order},
                       open(args.launch_order_out, "w"))

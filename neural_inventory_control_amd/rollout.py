@@ -235,13 +235,14 @@ class FusedRollout:
                 # uses the first F / n_out rows in [row][T][ld] order)
                 self.sr_states, self.sr_hidden = z((F + 3) // 4 * 4, T, ld), z(nh * sr.H, T, ld)
                 self.sr_logits = z(no if no == 1 else (no + 3) // 4 * 4, T, ld)
-                self.g_reward = z(ld)
+                self.g_reward, self._g_reward_key = z(ld), None
                 if self.small_wgrad_in_kernel:
                     # weight gradients contracted inside the backward kernel: one partial gradient per wavefront in the
                     # packed-weight layout, summed once; the per-layer gradients are views of that sum
                     n_packed = sr.packed_weight_count(F, nh, no)
                     self.sr_slab = z(sr.small_rollout_bwd_wgrad_slots(prob.B), (n_packed + 3) // 4 * 4)
                     self.sr_grad = z(self.sr_slab.shape[1])
+                    self.sr_slab16 = z(16, self.sr_slab.shape[1])   # first stage of the two-stage row sum (see _run_small)
                     sl = sr.layer_slices(F, nh, no)
                     self.gw = [self.sr_grad[o:o + n * k].view(n, k) for o, n, k, _ in sl]
                     self.gb = [self.sr_grad[bo:bo + n] for _, n, _, bo in sl]
@@ -277,7 +278,7 @@ class FusedRollout:
             if train:
                 self.hz_hist = [z(dims[1], T, ld), z(dims[2], T, ld), z(dims[3], T, ld), z(plan.n_ord + prob.Wn, T, ld)]  # h1, h2, logits, orders (+ shipped)
                 self.hz_dz = [z(dims[i + 1], T, ld) for i in range(L)]   # (padding columns stay zero: the kernel writes live ones only)
-                self.g_reward = z(ld)
+                self.g_reward, self._g_reward_key = z(ld), None
                 self.splits = [ops.wgrad_num_splits(dims[i + 1], dims[i], n_cols) for i in range(L)]
                 self.slabs = [z(self.splits[i], dims[i + 1], (dims[i] + 1 + 3) // 4 * 4) for i in range(L)]
                 self.gw = [torch.zeros_like(m.weight) for m in lins]
@@ -347,7 +348,7 @@ class FusedRollout:
             self.splits = [ops.wgrad_periods_num_splits(gd[i + 1], gd[i], prob.B, T) if by_periods[i]
                            else ops.wgrad_num_splits(gd[i + 1], gd[i], prob.B) for i in range(L)]
             self.slabs = [z(self.splits[i], gd[i + 1], (gd[i] + 1 + 3) // 4 * 4) for i in range(L)]
-            self.g_reward = z(ld)
+            self.g_reward, self._g_reward_key = z(ld), None
             self.gw = [torch.zeros_like(m.weight) for m in lins]
             self.gb = [torch.zeros_like(m.bias) if m.bias is not None else None for m in lins]
             if self.live_rows is not None:   # the compact logits layer reduces into these; scattered into gw / gb afterwards
@@ -494,8 +495,7 @@ class FusedRollout:
 
         if grad_scale is None:
             grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
-        self.g_reward.zero_()
-        self.g_reward[:B] = grad_scale
+        self._set_g_reward(B, grad_scale)
         for sl in self.slabs:
             sl.zero_()
         self.g_state[0].zero_()
@@ -589,6 +589,17 @@ class FusedRollout:
                 out.append((m.bias, self.gb[i]))
         return out
 
+    def _set_g_reward(self, B, grad_scale):
+        """g_reward[b] = d loss / d reward[b, t] for the live scenarios, 0 in the padding columns.  Two launches that a training
+        loop repeats with the same numbers every step: skipped while the buffer, the batch size and the (host-side) scale are the
+        ones of the previous call - the whole-horizon routes' steps are a handful of launches, these were two of them."""
+        key = (self.g_reward.data_ptr(), B, grad_scale) if isinstance(grad_scale, (int, float)) else None
+        if key is not None and key == getattr(self, "_g_reward_key", None):
+            return
+        self.g_reward.zero_()
+        self.g_reward[:B] = grad_scale
+        self._g_reward_key = key
+
     def _assign_grads(self, accumulate):
         for p, g in self.param_grads():
             if accumulate and p.grad is not None and p.grad is not g:
@@ -624,19 +635,31 @@ class FusedRollout:
                          lane_scenarios=width)
         hist = (self.sr_states, self.sr_hidden, self.sr_logits) if train else (None, None, None)
         self._k("small_rollout_fwd", sr.small_rollout_fwd, desc, self.rewards, self.sr_final, *hist)
-        total = self.rewards.sum()
-        reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
+        if T * ld >= (1 << 20) and not ignore_periods:
+            # (per scenario first, then over the scenarios: two single-pass reductions instead of one that torch finishes with a
+            # semaphore pass - memset + 14-us launch at 100 x 32,768; ~9 us)
+            total = reported = self.rewards.sum(dim=0).sum()
+        else:
+            total = self.rewards.sum()
+            reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
         if not train:
             return total, reported
         if grad_scale is None:
             grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
-        self.g_reward.zero_()
-        self.g_reward[:B] = grad_scale
+        self._set_g_reward(B, grad_scale)
         if self.small_wgrad_in_kernel:
             self._k("small_rollout_bwd", sr.small_rollout_bwd_wgrad, desc, *hist, Table(self.g_reward, 0, 1), self.sr_slab)
             # one partial gradient per wavefront: only the rows THIS width's launch wrote are summed (the slab is sized for the
             # 16-wide form; a 32-wide launch fills half of it and must not pick up an earlier 16-wide run's rows)
-            torch.sum(self.sr_slab[:(B + width - 1) // width], dim=0, out=self.sr_grad)
+            n_rows = (B + width - 1) // width
+            if n_rows % 16 == 0 and n_rows >= 256:
+                # two stages with thousands of outputs each instead of ONE reduction of n_rows x ~2,000 - which torch splits over
+                # workgroups along the rows and finishes with a semaphore pass (a memset + an 18-us launch at 2,048 rows: 23 us of
+                # a 1-ms step; these two take ~9)
+                torch.sum(self.sr_slab[:n_rows].view(16, n_rows // 16, -1), dim=1, out=self.sr_slab16)
+                torch.sum(self.sr_slab16, dim=0, out=self.sr_grad)
+            else:
+                torch.sum(self.sr_slab[:n_rows], dim=0, out=self.sr_grad)
             if assign_grads:
                 self._assign_grads(accumulate_grads)
             return total, reported
@@ -679,8 +702,7 @@ class FusedRollout:
             return total, reported
         if grad_scale is None:
             grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
-        self.g_reward.zero_()
-        self.g_reward[:B] = grad_scale
+        self._set_g_reward(B, grad_scale)
         self._k("horizon_bwd", hz.horizon_bwd, desc, *hist, Table(self.g_reward, 0, 1), *self.hz_dz)
         # weight gradients: contractions over (period, scenario) = T * ld columns; padding columns of the dz histories are zero
         inputs = [X, self.hz_hist[0], self.hz_hist[1]]
