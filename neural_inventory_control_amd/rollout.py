@@ -228,7 +228,7 @@ class FusedRollout:
             nh, no = plan.n_hidden, plan.n_out
             self.rewards = z(T, ld)
             self.sr_final = z(F, ld)
-            self.sr_state0 = z(F, ld)
+            self.sr_state0, self._copied = z(F, ld), {}
             self.sr_weights = z(sr.packed_weight_count(F, nh, no))
             if train:
                 # (rows padded as the 16-wide kernels keep them - NIC_SR16_STATE_ROWS / NIC_SR16_LOGIT_ROWS; the 32-wide form
@@ -589,6 +589,18 @@ class FusedRollout:
                 out.append((m.bias, self.gb[i]))
         return out
 
+    def _copy_if_changed(self, slot, dst, src):
+        """dst <- src.permute(1, 2, 0) unless `src` is the very tensor (same object, same in-place version) that was copied into
+        the same destination last time.  The tensor is kept referenced until the next call, so its memory cannot be handed to
+        another tensor in between (an epoch over ONE resident batch re-presents the same tensors every step)."""
+        cache = self.__dict__.setdefault("_copied", {})
+        key = (dst.data_ptr(), tuple(dst.shape), src._version)
+        hit = cache.get(slot)
+        if hit is not None and hit[0] is src and hit[1] == key:
+            return
+        dst.copy_(src.permute(1, 2, 0))
+        cache[slot] = (src, key)
+
     def _set_g_reward(self, B, grad_scale):
         """g_reward[b] = d loss / d reward[b, t] for the live scenarios, 0 in the padding columns.  Two launches that a training
         loop repeats with the same numbers every step: skipped while the buffer, the batch size and the (host-side) scale are the
@@ -617,11 +629,11 @@ class FusedRollout:
         plan, lins = self.small, self._linears()
         sr.pack_weights(lins, self.sr_weights)
         s0 = self._views(self.sr_state0, prob)
-        s0.store[:, :, :B].copy_(data["initial_inventories"].permute(1, 2, 0))
+        self._copy_if_changed("s0_store", s0.store[:, :, :B], data["initial_inventories"])
         if prob.Wn:
-            s0.wh[:, :, :B].copy_(data["initial_warehouse_inventories"].permute(1, 2, 0))
+            self._copy_if_changed("s0_wh", s0.wh[:, :, :B], data["initial_warehouse_inventories"])
         if prob.E:
-            s0.ech[:, :, :B].copy_(data["initial_echelon_inventories"].permute(1, 2, 0))
+            self._copy_if_changed("s0_ech", s0.ech[:, :, :B], data["initial_echelon_inventories"])
         ub = self._ub() if self.head != "softplus" else 0.0
         # Scenarios per wavefront.  Training: 16 (v_mfma_f32_16x16x4_f32, wave-native activation history) - measured against 32:
         # cfg1 0.55 -> 0.30 ms, cfg4 (16,384 scenarios: 32 leaves half the SIMDs without a wavefront) 0.83 -> 0.70 ms, cfg2

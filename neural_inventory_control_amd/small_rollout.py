@@ -24,10 +24,9 @@ def pack_weights(linears, out=None):
     parts = []
     for m in linears:
         parts += [m.weight.detach().reshape(-1), m.bias.detach().reshape(-1)]
-    flat = torch.cat(parts)
     if out is None:
-        return flat.contiguous()
-    out.copy_(flat)
+        return torch.cat(parts).contiguous()
+    torch.cat(parts, out=out)   # (one launch; `out` has exactly packed_weight_count elements)
     return out
 
 
