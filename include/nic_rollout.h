@@ -284,6 +284,15 @@ int nic_small_rollout_bwd_wgrad_slots(int32_t n_scenarios);
 int nic_small_rollout_bwd_wgrad(const NicSmallRolloutDesc* d, const float* states_hist, const float* hidden_hist,
                                 const float* logits_hist, NicTable2 g_reward, float* slab, int64_t slab_stride, void* stream);
 
+/* What follows the two launches in a training step of these policies, as two small launches: grad [P] = sum over the n_rows
+ * per-wavefront partial gradients of slab [n_rows][slab_stride >= P] (nic_small_rollout_bwd_wgrad), and totals[0] = sum of the
+ * n_reward_elems = T * ldb per-period costs, totals[1] = sum of those from element ignore_elems = ignore_periods * ldb on
+ * (trainer.py:207-210: total and reported reward; padding columns hold zeros).  Fixed summation order, no atomics.  Either pair
+ * (slab, grad) / (rewards, totals) may be NULL.  scratch: nic_small_rollout_reduce_scratch(...) floats. */
+int64_t nic_small_rollout_reduce_scratch(int32_t n_rows, int32_t P, int64_t n_reward_elems);
+int nic_small_rollout_reduce(const float* slab, int32_t n_rows, int64_t slab_stride, int32_t P, float* grad, const float* rewards,
+                             int64_t n_reward_elems, int64_t ignore_elems, float* totals, float* scratch, void* stream);
+
 /* ---- whole-horizon rollout of the closed-form policies ---------------------------------------------------------
  * base_stock (neural_networks.py:216-229), capped_base_stock (:296-311) and echelon_stock (:231-294) for T periods of
  * Trainer.simulate_batch (trainer.py:190-213) in ONE launch, forward AND gradient: one lane per store chain, pipelines in

@@ -21,6 +21,7 @@ SOURCES = [
     ("sampler.hip", []),
     ("small_rollout.hip", ["-ffp-contract=off"]),
     ("small_rollout16.hip", ["-ffp-contract=off"]),
+    ("small_reduce.hip", ["-ffp-contract=off"]),
     ("closed_form.hip", ["-ffp-contract=off"]),
     ("horizon_rollout.hip", ["-ffp-contract=off"]),
     ("mlp3.hip", []),

@@ -242,7 +242,7 @@ class FusedRollout:
                     n_packed = sr.packed_weight_count(F, nh, no)
                     self.sr_slab = z(sr.small_rollout_bwd_wgrad_slots(prob.B), (n_packed + 3) // 4 * 4)
                     self.sr_grad = z(self.sr_slab.shape[1])
-                    self.sr_slab16 = z(16, self.sr_slab.shape[1])   # first stage of the two-stage row sum (see _run_small)
+                    self.sr_scratch = None
                     sl = sr.layer_slices(F, nh, no)
                     self.gw = [self.sr_grad[o:o + n * k].view(n, k) for o, n, k, _ in sl]
                     self.gb = [self.sr_grad[bo:bo + n] for _, n, _, bo in sl]
@@ -647,13 +647,15 @@ class FusedRollout:
                          lane_scenarios=width)
         hist = (self.sr_states, self.sr_hidden, self.sr_logits) if train else (None, None, None)
         self._k("small_rollout_fwd", sr.small_rollout_fwd, desc, self.rewards, self.sr_final, *hist)
-        if T * ld >= (1 << 20) and not ignore_periods:
-            # (per scenario first, then over the scenarios: two single-pass reductions instead of one that torch finishes with a
-            # semaphore pass - memset + 14-us launch at 100 x 32,768; ~9 us)
-            total = reported = self.rewards.sum(dim=0).sum()
-        else:
-            total = self.rewards.sum()
-            reported = self.rewards[ignore_periods:].sum() if ignore_periods else total
+        if train and self.small_wgrad_in_kernel:
+            total = reported = None   # (summed together with the partial gradients after the backward launch)
+        else:   # the same reduction, costs only: an evaluation pass returns the very bits a training pass does
+            need = sr.small_rollout_reduce_scratch(0, 0, self.rewards.numel())
+            if getattr(self, "sr_scratch", None) is None or self.sr_scratch.numel() < need:
+                self.sr_scratch, self.sr_totals = torch.empty(need, device=self.device), torch.zeros(2, device=self.device)
+            sr.small_rollout_reduce(None, 0, None, self.rewards, ignore_periods, self.sr_totals, self.sr_scratch)
+            tt = self.sr_totals.clone()
+            total, reported = tt[0], tt[1]
         if not train:
             return total, reported
         if grad_scale is None:
@@ -663,15 +665,17 @@ class FusedRollout:
             self._k("small_rollout_bwd", sr.small_rollout_bwd_wgrad, desc, *hist, Table(self.g_reward, 0, 1), self.sr_slab)
             # one partial gradient per wavefront: only the rows THIS width's launch wrote are summed (the slab is sized for the
             # 16-wide form; a 32-wide launch fills half of it and must not pick up an earlier 16-wide run's rows)
+            # ... and the step's two sums - partial gradients over the wavefronts, costs over (period, scenario) - in two small
+            # launches with a fixed order (csrc/small_reduce.hip).  As torch reductions these were four launches, 37-46 us of a
+            # 1-ms step (the row sums end in a semaphore pass with its own memset).
             n_rows = (B + width - 1) // width
-            if n_rows % 16 == 0 and n_rows >= 256:
-                # two stages with thousands of outputs each instead of ONE reduction of n_rows x ~2,000 - which torch splits over
-                # workgroups along the rows and finishes with a semaphore pass (a memset + an 18-us launch at 2,048 rows: 23 us of
-                # a 1-ms step; these two take ~9)
-                torch.sum(self.sr_slab[:n_rows].view(16, n_rows // 16, -1), dim=1, out=self.sr_slab16)
-                torch.sum(self.sr_slab16, dim=0, out=self.sr_grad)
-            else:
-                torch.sum(self.sr_slab[:n_rows], dim=0, out=self.sr_grad)
+            need = sr.small_rollout_reduce_scratch(n_rows, self.sr_grad.numel(), self.rewards.numel())
+            if getattr(self, "sr_scratch", None) is None or self.sr_scratch.numel() < need:
+                self.sr_scratch, self.sr_totals = torch.empty(need, device=self.device), torch.zeros(2, device=self.device)
+            self._k("small_rollout_reduce", sr.small_rollout_reduce, self.sr_slab, n_rows, self.sr_grad, self.rewards, ignore_periods,
+                    self.sr_totals, self.sr_scratch)
+            tt = self.sr_totals.clone()   # (the caller's tensors must not change under a later step)
+            total, reported = tt[0], tt[1]
             if assign_grads:
                 self._assign_grads(accumulate_grads)
             return total, reported

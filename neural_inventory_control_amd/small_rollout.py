@@ -106,3 +106,21 @@ def small_rollout_bwd_wgrad(desc, states_hist, hidden_hist, logits_hist, g_rewar
     ops._dev(slab)
     _lib.check(_lib.lib().nic_small_rollout_bwd_wgrad(desc, _lib.ptr(states_hist), _lib.ptr(hidden_hist), _lib.ptr(logits_hist),
                                                       g_reward.t2(), _lib.ptr(slab), slab.stride(0), _lib.current_stream()))
+
+
+def small_rollout_reduce_scratch(n_rows, P, n_reward_elems):
+    return int(_lib.lib().nic_small_rollout_reduce_scratch(int(n_rows), int(P), int(n_reward_elems)))
+
+
+def small_rollout_reduce(slab, n_rows, grad, rewards, ignore_periods, totals, scratch):
+    """grad <- sum of the first n_rows rows of slab; totals <- [sum of rewards [T][ldb], sum of its periods >= ignore_periods]:
+    two launches with a fixed summation order (csrc/small_reduce.hip).  Either pair may be None."""
+    ops._dev(scratch)
+    P = grad.numel() if grad is not None else 0
+    n_el = rewards.numel() if rewards is not None else 0
+    assert scratch.numel() >= small_rollout_reduce_scratch(n_rows if slab is not None else 0, P, n_el)
+    assert rewards is None or rewards.is_contiguous()
+    _lib.check(_lib.lib().nic_small_rollout_reduce(_lib.ptr(slab), int(n_rows), slab.stride(0) if slab is not None else 0, P,
+                                                   _lib.ptr(grad), _lib.ptr(rewards), n_el,
+                                                   int(ignore_periods) * rewards.shape[-1] if rewards is not None else 0,
+                                                   _lib.ptr(totals), _lib.ptr(scratch), _lib.current_stream()))

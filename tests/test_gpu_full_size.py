@@ -64,12 +64,15 @@ def test_whole_horizon_route_at_full_size(workload, n, T):
                                              b"sample_equicorrelated_kernel<1>")
     S = setting["problem_params"]["n_stores"]
     scale = 1.0 / (n * T * S)
+    from neural_inventory_control_amd.rollout import KernelTimer
+    eng.timer = KernelTimer()   # (records which kernel the C ABI launched for the forward)
     with torch.no_grad():
         eng.run(data, T, 0, train=False, observation_params=obs, demand_soa=sc.demands_soa)
     assert eng.small is not None  # the whole-horizon route
     # (the library picks 16 or 32 scenarios per wavefront from the batch size; the two forms sum a layer's contraction in
     # different orders, so the small batches below are run in the form the full batch took)
-    width = 16 if b"small_rollout16" in _lib.lib().nic_last_kernel() else 32
+    width = 16 if "small_rollout16" in eng.timer.names["small_rollout_fwd"] else 32
+    eng.timer = None
     r_full = eng.per_period_rewards().clone()
     assert r_full.shape == (T, n) and bool(torch.isfinite(r_full).all())
     # batch independence, bit for bit: a ragged 45-scenario batch from the middle of the grid and the last 33 scenarios

@@ -924,3 +924,34 @@ def test_gnn_allocation_head_matches_torch_autograd(S, e_self, cap):
     torch.testing.assert_close(d_out[:, :B].cpu().double(), o64.grad, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(g_on[:B].cpu().double() - 0.25, h64.grad, rtol=2e-5, atol=2e-5)
     assert float(d_out[:, B:].sub(9.0).abs().max()) == 0.0   # padding columns untouched
+
+
+@pytest.mark.parametrize("n_rows,P,stride,T,ld,ignore", [(2048, 2212, 2212, 100, 32768, 0), (1024, 1332, 1332, 100, 16384, 10),
+                                                         (16, 2212, 2212, 50, 256, 3), (5, 70, 72, 3, 32, 1), (333, 257, 260, 7, 96, 0),
+                                                         (64, 256, 256, 1, 32, 0)])
+def test_small_rollout_reduce_matches_float64_sums(n_rows, P, stride, T, ld, ignore):
+    """nic_small_rollout_reduce (csrc/small_reduce.hip): the sum of the per-wavefront partial gradients and the total / reported cost
+    of a training step of the small policies, against float64 sums of the same buffers; rows and columns past the live ones are
+    never read (NaN-poisoned); the same call twice gives the same bits; each pair alone."""
+    from neural_inventory_control_amd import small_rollout as sr
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(n_rows * 7 + P)
+    slab = torch.full((n_rows + 3, stride), float("nan"), device=dev)
+    slab[:n_rows, :P] = torch.randn(n_rows, P, device=dev, generator=g) * 3.0
+    rewards = torch.randn(T, ld, device=dev, generator=g).abs() * 10.0
+    grad, totals = torch.full((P,), float("nan"), device=dev), torch.zeros(2, device=dev)
+    scratch = torch.empty(sr.small_rollout_reduce_scratch(n_rows, P, rewards.numel()), device=dev)
+    sr.small_rollout_reduce(slab, n_rows, grad, rewards, ignore, totals, scratch)
+    want_g = slab[:n_rows, :P].double().sum(dim=0)
+    torch.testing.assert_close(grad.double(), want_g, rtol=2e-6, atol=2e-6 * float(slab[:n_rows, :P].abs().sum(dim=0).max()))
+    want_t, want_r = float(rewards.double().sum()), float(rewards[ignore:].double().sum())
+    assert abs(float(totals[0]) - want_t) <= 2e-6 * want_t and abs(float(totals[1]) - want_r) <= 2e-6 * want_r
+    g1, t1 = grad.clone(), totals.clone()
+    sr.small_rollout_reduce(slab, n_rows, grad, rewards, ignore, totals, scratch)
+    assert torch.equal(grad, g1) and torch.equal(totals, t1)
+    grad.fill_(float("nan"))
+    totals.fill_(float("nan"))
+    sr.small_rollout_reduce(slab, n_rows, grad, None, 0, None, scratch)
+    assert torch.equal(grad, g1) and bool(torch.isnan(totals).all())
+    sr.small_rollout_reduce(None, 0, None, rewards, ignore, totals, scratch)
+    assert torch.equal(totals, t1)

@@ -744,6 +744,7 @@ def test_small_route_in_kernel_weight_gradients_match_the_gemm_path(workload, n,
     that leave dead lanes in the last wavefront, which shadow scenario 0 and must not be counted)."""
     from collections import defaultdict
     from neural_inventory_control_amd import workloads
+    from neural_inventory_control_amd.rollout import KernelTimer
     setting, policy, _, _, _ = workloads.get(workload)
     obs = defaultdict(lambda: None, setting["observation_params"])
     sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
@@ -762,10 +763,12 @@ def test_small_route_in_kernel_weight_gradients_match_the_gemm_path(workload, n,
             F += sum(int(np.prod(data[k].shape[1:])) for k in ("initial_warehouse_inventories", "initial_echelon_inventories")
                      if k in data)
         eng.materialize(F)
+        eng.timer = KernelTimer()   # (records which kernel the C ABI launched for every class of the step)
         total, _ = eng.run(data, T, 0, train=True, observation_params=obs)
         torch.cuda.synchronize()
         assert eng.small is not None
-        assert (b"small_rollout16" in _lib.lib().nic_last_kernel()) == (width == 16)
+        for tag in ("small_rollout_fwd", "small_rollout_bwd"):
+            assert ("small_rollout16" in eng.timer.names[tag]) == (width == 16), eng.timer.names
         res[(in_kernel, width)] = (float(total), [p.grad.clone() for p in model.parameters()])
     ref = res[(False, 32)]
     assert res[(True, 32)][0] == ref[0]   # same forward kernel
