@@ -289,7 +289,7 @@ int nic_small_rollout_bwd_wgrad(const NicSmallRolloutDesc* d, const float* state
  * n_reward_elems = T * ldb per-period costs, totals[1] = sum of those from element ignore_elems = ignore_periods * ldb on
  * (trainer.py:207-210: total and reported reward; padding columns hold zeros).  Fixed summation order, no atomics.  Either pair
  * (slab, grad) / (rewards, totals) may be NULL.  scratch: nic_small_rollout_reduce_scratch(...) floats. */
-int64_t nic_small_rollout_reduce_scratch(int32_t n_rows, int32_t P, int64_t n_reward_elems);
+int nic_small_rollout_reduce_scratch(int32_t n_rows, int32_t P, int64_t n_reward_elems);
 int nic_small_rollout_reduce(const float* slab, int32_t n_rows, int64_t slab_stride, int32_t P, float* grad, const float* rewards,
                              int64_t n_reward_elems, int64_t ignore_elems, float* totals, float* scratch, void* stream);
 

@@ -131,7 +131,7 @@ PROTOTYPES = {
     "nic_small_rollout_bwd": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, NicTable2, _vp, _vp, _vp]),
     "nic_small_rollout_bwd_wgrad_slots": (C.c_int, [C.c_int32]),
     "nic_small_rollout_bwd_wgrad": (C.c_int, [C.POINTER(NicSmallRolloutDesc), _vp, _vp, _vp, NicTable2, _vp, _i64, _vp]),
-    "nic_small_rollout_reduce_scratch": (C.c_int64, [C.c_int32, C.c_int32, _i64]),
+    "nic_small_rollout_reduce_scratch": (C.c_int, [C.c_int32, C.c_int32, _i64]),
     "nic_small_rollout_reduce": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "nic_horizon_rollout_ok": (C.c_int, [C.POINTER(NicHorizonDesc)]),
     "nic_horizon_rollout_fwd": (C.c_int, [C.POINTER(NicHorizonDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

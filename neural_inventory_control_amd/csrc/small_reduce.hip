@@ -119,9 +119,9 @@ __global__ __launch_bounds__(kT) void sr_reduce_stage2(const float* __restrict__
 
 extern "C" {
 
-int64_t nic_small_rollout_reduce_scratch(int32_t n_rows, int32_t P, int64_t n_reward_elems) {
+int nic_small_rollout_reduce_scratch(int32_t n_rows, int32_t P, int64_t n_reward_elems) {
     const Plan p = plan_for(n_rows, P, n_reward_elems);
-    return (int64_t)p.cc * p.rg * kT + 2 * (int64_t)p.nb + 4;
+    return p.cc * p.rg * kT + 2 * p.nb + 4;   // (<= 64 row groups x the column chunks x 256 floats)
 }
 
 int nic_small_rollout_reduce(const float* slab, int32_t n_rows, int64_t slab_stride, int32_t P, float* grad, const float* rewards,
