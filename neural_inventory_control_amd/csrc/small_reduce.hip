@@ -2,7 +2,7 @@
 // instead of four torch reductions - the sum of the per-wavefront partial gradients (slab [n_rows][P] -> grad [P]) and the sum
 // of the per-period costs (rewards [T][ldb] -> total, and the total of the periods >= ignore_periods).  Stage 1: every workgroup
 // sums one (256-column chunk, row group) of the slab or one contiguous chunk of the rewards into `scratch`; stage 2: one
-// workgroup per column chunk (and one for the rewards) adds the partial sums in a fixed order.  No atomics, no semaphore pass:
+// workgroup per 64 columns (and one for the rewards) adds the partial sums in a fixed order.  No atomics, no semaphore pass:
 // the result depends on the shapes only (bit-reproducible from call to call).  Replaces trainer.py:169-173's `sum` of the costs
 // and autograd's accumulation of the weight gradients for these policies (csrc/small_rollout16.hip).
 #include "nic_common.h"
@@ -87,20 +87,27 @@ __global__ __launch_bounds__(kT) void sr_reduce_stage1(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(kT) void sr_reduce_stage2(const float* __restrict__ scratch, int P, int cc, int rg, int nb,
+// Stage 2: workgroup b < ceil(P / 64) owns 64 columns; its four wavefronts each add every fourth row group (independent loads in
+// flight), wavefront 0 adds the four partial sums in order.  The last workgroup adds the cost partials.
+__global__ __launch_bounds__(kT) void sr_reduce_stage2(const float* __restrict__ scratch, int P, int cc, int rg, int nb, int col_blocks,
                                                        float* __restrict__ grad, float* __restrict__ totals) {
     __shared__ float lds[kT];
     const int bid = blockIdx.x, tid = threadIdx.x;
-    if (bid < cc) {
-        const int col = bid * kT + tid;
+    if (bid < col_blocks) {
+        const int lane = tid & 63, w = tid >> 6, col = bid * 64 + lane;
+        const int c = col / kT, t = col % kT;
         float a0 = 0.f, a1 = 0.f;
-        int r = 0;
-        for (; r + 2 <= rg; r += 2) {
-            a0 += scratch[((int64_t)r * cc + bid) * kT + tid];
-            a1 += scratch[((int64_t)(r + 1) * cc + bid) * kT + tid];
+        if (col < cc * kT) {
+            int r = w;
+            for (; r + 4 < rg; r += 8) {
+                a0 += scratch[((int64_t)r * cc + c) * kT + t];
+                a1 += scratch[((int64_t)(r + 4) * cc + c) * kT + t];
+            }
+            if (r < rg) a0 += scratch[((int64_t)r * cc + c) * kT + t];
         }
-        if (r < rg) a0 += scratch[((int64_t)r * cc + bid) * kT + tid];
-        if (col < P) grad[col] = a0 + a1;
+        lds[tid] = a0 + a1;
+        __syncthreads();
+        if (w == 0 && col < P) grad[col] = (lds[lane] + lds[64 + lane]) + (lds[128 + lane] + lds[192 + lane]);
         return;
     }
     const float* part = scratch + (int64_t)cc * rg * kT;
@@ -141,7 +148,9 @@ int nic_small_rollout_reduce(const float* slab, int32_t n_rows, int64_t slab_str
     nic::note_kernelf("sr_reduce_stage1+2<%d,%d,%d>", p.cc, p.rg, p.nb);
     hipLaunchKernelGGL(sr_reduce_stage1, dim3(p.cc * p.rg + p.nb), dim3(kT), 0, s, slab, n_rows, slab_stride, P, p.cc, p.rg,
                        p.rows_per_group, rewards, n_reward_elems / 4, ignore_elems / 4, p.nb, scratch);
-    hipLaunchKernelGGL(sr_reduce_stage2, dim3(p.cc + (p.nb ? 1 : 0)), dim3(kT), 0, s, scratch, P, p.cc, p.rg, p.nb, grad, totals);
+    const int col_blocks = p.cc ? (P + 63) / 64 : 0;
+    hipLaunchKernelGGL(sr_reduce_stage2, dim3(col_blocks + (p.nb ? 1 : 0)), dim3(kT), 0, s, scratch, P, p.cc, p.rg, p.nb, col_blocks, grad,
+                       totals);
     return nic::check_launch("nic_small_rollout_reduce");
 }
 
