@@ -589,6 +589,16 @@ class FusedRollout:
                 out.append((m.bias, self.gb[i]))
         return out
 
+    def _cost_totals(self, ignore_periods):
+        """(total, reported) = sums of the per-period costs [T][ldb] (all periods / periods >= ignore_periods, trainer.py:207-210)
+        by `nic_small_rollout_reduce`: two launches, fixed order, no semaphore pass."""
+        need = sr.small_rollout_reduce_scratch(0, 0, self.rewards.numel())
+        if getattr(self, "sr_scratch", None) is None or self.sr_scratch.numel() < need:
+            self.sr_scratch, self.sr_totals = torch.empty(need, device=self.device), torch.zeros(2, device=self.device)
+        sr.small_rollout_reduce(None, 0, None, self.rewards, ignore_periods, self.sr_totals, self.sr_scratch)
+        tt = self.sr_totals.clone()   # (the caller's tensors must not change under a later step)
+        return tt[0], tt[1]
+
     def _copy_if_changed(self, slot, dst, src):
         """dst <- src.permute(1, 2, 0) unless `src` is the very tensor (same object, same in-place version) that was copied into
         the same destination last time.  The tensor is kept referenced until the next call, so its memory cannot be handed to
@@ -650,12 +660,7 @@ class FusedRollout:
         if train and self.small_wgrad_in_kernel:
             total = reported = None   # (summed together with the partial gradients after the backward launch)
         else:   # the same reduction, costs only: an evaluation pass returns the very bits a training pass does
-            need = sr.small_rollout_reduce_scratch(0, 0, self.rewards.numel())
-            if getattr(self, "sr_scratch", None) is None or self.sr_scratch.numel() < need:
-                self.sr_scratch, self.sr_totals = torch.empty(need, device=self.device), torch.zeros(2, device=self.device)
-            sr.small_rollout_reduce(None, 0, None, self.rewards, ignore_periods, self.sr_totals, self.sr_scratch)
-            tt = self.sr_totals.clone()
-            total, reported = tt[0], tt[1]
+            total, reported = self._cost_totals(ignore_periods)
         if not train:
             return total, reported
         if grad_scale is None:
