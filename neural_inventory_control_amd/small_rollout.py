@@ -26,7 +26,9 @@ def pack_weights(linears, out=None):
         parts += [m.weight.detach().reshape(-1), m.bias.detach().reshape(-1)]
     if out is None:
         return torch.cat(parts).contiguous()
-    torch.cat(parts, out=out)   # (one launch; `out` has exactly packed_weight_count elements)
+    if out.numel() != sum(p.numel() for p in parts):   # (torch.cat would silently re-allocate `out`: kernels hold its address)
+        raise ValueError("pack_weights: the output buffer does not have packed_weight_count elements")
+    torch.cat(parts, out=out)   # (one launch)
     return out
 
 
