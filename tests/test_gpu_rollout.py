@@ -1773,3 +1773,54 @@ def test_symmetry_aware_policy_matches_its_cpu_restatement(n_stores):
     named = dict(model.named_parameters())
     for key, gref in zip(pol.param_keys(), grads):
         assert _rel(named[key].grad, gref) <= GRAD_TOL, key
+
+
+def test_small_route_step_caches_follow_their_inputs():
+    """The small route skips three launches while their inputs are unchanged (initial-state copies, the d loss / d reward fill).
+    What must invalidate them does: an in-place change of the presented initial inventories, a new tensor, a different gradient
+    scale, a different batch size - each compared with a fresh engine."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    setting, policy, _, _, _ = workloads.get("cfg4")
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    T, n = 9, 200
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
+                  n, obs, setting["seeds"])
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    torch.manual_seed(11)
+    model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+    F = sum(int(np.prod(data[k].shape[1:])) for k in ("initial_inventories", "initial_warehouse_inventories",
+                                                        "initial_echelon_inventories") if k in data)
+
+    def fresh(d, scale):
+        e = FusedRollout(model, setting["problem_params"], DEV)
+        e.materialize(F)
+        tot, _ = e.run(d, T, 0, train=True, observation_params=obs, grad_scale=scale)
+        return float(tot), [p.grad.clone() for p in model.parameters()]
+
+    eng = FusedRollout(model, setting["problem_params"], DEV)
+    eng.materialize(F)
+
+    def same(d, scale):
+        tot, _ = eng.run(d, T, 0, train=True, observation_params=obs, grad_scale=scale)
+        got = (float(tot), [p.grad.clone() for p in model.parameters()])
+        want = fresh(d, scale)
+        assert got[0] == want[0]
+        for a, b in zip(got[1], want[1]):
+            assert torch.equal(a, b)
+        return got
+
+    first = same(data, 1e-3)
+    assert eng.small is not None
+    again = same(data, 1e-3)                       # (everything cached)
+    assert again[0] == first[0]
+    data["initial_inventories"].mul_(1.5)          # in place: same tensor object, new version
+    changed = same(data, 1e-3)
+    assert changed[0] != first[0]
+    d2 = dict(data)
+    d2["initial_warehouse_inventories"] = data["initial_warehouse_inventories"] + 3.0   # a new tensor
+    assert same(d2, 1e-3)[0] != changed[0]
+    scaled = same(d2, 2e-3)                         # a different gradient scale
+    for a, b in zip(scaled[1], same(d2, 1e-3)[1]):
+        torch.testing.assert_close(a, 2.0 * b, rtol=1e-6, atol=0)
+    same({k: v[:77].contiguous() for k, v in d2.items()}, 1e-3)   # a smaller batch (padding columns must be zero again)
