@@ -1,6 +1,7 @@
 """Host-side logic of the product package that needs no GPU: scenario generation (bit-equal to the reference's golden
 data), dataset plumbing, the policy factory, layout helpers, and the no-CPU-fallback contract."""
 import copy
+import ctypes
 import re
 import os
 
@@ -377,3 +378,23 @@ def test_whole_horizon_routes_refuse_histories_beyond_32_bit_offsets():
     assert not hz.offsets_ok(big, 5000, 5016, hz.MAX_HIDDEN)          # 135 rows x 5,000 x 8,192 elements
     wide = SimpleNamespace(S=64, Ws=2, Wn=0, Ww=0, nsup=1, ldb=8192)
     assert not hz.offsets_ok(wide, 10, 5000, 0)                       # the demand trace alone: 5,002 x 64 x 8,192
+
+
+def test_small_rollout_reduce_plan_and_argument_checks():
+    """nic_small_rollout_reduce (host side only: no GPU): the scratch size it asks for - (column chunks x row groups) x 256 partial
+    sums + two floats per cost block -, and the argument errors it reports instead of launching."""
+    from neural_inventory_control_amd import small_rollout as sr
+    assert sr.small_rollout_reduce_scratch(2048, 2212, 100 * 32768) == 9 * 64 * 256 + 2 * 256 + 4
+    assert sr.small_rollout_reduce_scratch(5, 70, 96) == 1 * 5 * 256 + 2 * 1 + 4      # one row per group, one cost block
+    assert sr.small_rollout_reduce_scratch(100, 256, 0) == 1 * 50 * 256 + 4            # 64 groups of 2 rows -> 50 non-empty ones
+    assert sr.small_rollout_reduce_scratch(0, 0, 4096) == 2 * 4 + 4
+    lib = _lib.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    for args in ((None, 4, 8, 8, None, None, 0, 0, None, p),          # nothing to reduce
+                 (p, 4, 8, 8, None, None, 0, 0, None, p),             # slab without grad
+                 (p, 4, 4, 8, p, None, 0, 0, None, p),                # row stride < columns
+                 (None, 0, 0, 0, None, p, 6, 0, p, p),                # costs not a multiple of 4 floats
+                 (p, 4, 8, 8, p, None, 0, 0, None, None)):            # no scratch
+        assert lib.nic_small_rollout_reduce(*args, None) != 0
+        assert b"nic_small_rollout_reduce" in lib.nic_last_error()
