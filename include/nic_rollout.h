@@ -202,6 +202,19 @@ int nic_head_env_bwd(const NicEnvStepIO* io, const float* Z, const int32_t* adja
                      int32_t transshipment, const float* g_store_out, const float* g_wh_out, NicTable2 g_reward,
                      float* g_store_in, float* g_wh_in, float* g_store_orders, float* g_wh_orders, float* dZ, void* stream);
 
+/* The same two with COMPACT logits: on a sparse many-warehouse graph the logits of (store, warehouse) pairs without an edge are
+ * never read upstream (`store_intermediate_outputs[:, connected_stores, w_idx]`, neural_networks.py:403-417), so the logits layer
+ * may compute the connected pairs only.  logit_rows [Wn][S] (int32, device): row of Z / dZ of pair (w, s) - any valid row for a pair
+ * without an edge (loaded, never used; no gradient row is written for it); first_wh_row: row of warehouse 0's own order logit
+ * (:422), warehouse w's is first_wh_row + w.  logit_rows == NULL (with first_wh_row < 0) is nic_head_env_fwd / _bwd. */
+int nic_head_env_fwd_rows(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
+                          int32_t first_wh_row, float upper_bound, int32_t transshipment, float* store_inv_out, float* wh_inv_out,
+                          float* reward, void* stream);
+int nic_head_env_bwd_rows(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
+                          int32_t first_wh_row, float upper_bound, int32_t transshipment, const float* g_store_out,
+                          const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_store_orders,
+                          float* g_wh_orders, float* dZ, void* stream);
+
 /* vanilla_one_store (neural_networks.py:200-214): orders[s][b] = softplus(Z[s][b] + 1)  (threshold 20 like
  * nn.Softplus).  rows = number of output rows (1 for the shipped config). */
 int nic_head_softplus_fwd(const float* Z, float* orders, int32_t rows, int32_t n_scenarios, int32_t ldb,

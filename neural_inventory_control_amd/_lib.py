@@ -107,6 +107,8 @@ PROTOTYPES = {
     "nic_env_step_bwd": (C.c_int, [_IOP, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_head_env_fwd": (C.c_int, [_IOP, _vp, _vp, C.c_float, _i32, _vp, _vp, _vp, _vp]),
     "nic_head_env_bwd": (C.c_int, [_IOP, _vp, _vp, C.c_float, _i32, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nic_head_env_fwd_rows": (C.c_int, [_IOP, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, _vp, _vp]),
+    "nic_head_env_bwd_rows": (C.c_int, [_IOP, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_linear_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_linear_fwd_thin_in_ok": (C.c_int, [_i32, _i32]),
     "nic_linear_fwd_thin_in": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -25,7 +25,8 @@ constexpr int kChunk = 8;  // warehouses whose shipment partials are exchanged p
 template <int MAXW, int MAXSQ>
 __global__ __launch_bounds__(kLanes * nic::kQuad) void head_env_fwd_kernel(NicEnvStepIO io, const float* Z, const int32_t* __restrict__ adj,
                                                                             float ub, int trans, float* store_out, float* wh_out,
-                                                                            float* __restrict__ reward) {
+                                                                            float* __restrict__ reward, const int32_t* __restrict__ zrow,
+                                                                            int first_wh_row) {
     __shared__ float xm[nic::kQuad][kLanes], xd[nic::kQuad][kLanes];
     __shared__ int xn[nic::kQuad][kLanes];
     __shared__ float part[kChunk][nic::kQuad][kLanes];
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(kLanes * nic::kQuad) void head_env_fwd_kernel(NicEn
         if (w > 0) __syncthreads();   // the exchange arrays are reused
         nic::HeadLane<MAXSQ> L;
         int nc;
-        xm[q][x] = nic::head_quad_load<MAXSQ, false>(L, Z, nullptr, adj, S, Wn, ldb, bb, w, q, nc);
+        xm[q][x] = nic::head_quad_load<MAXSQ, false>(L, Z, nullptr, adj, S, Wn, ldb, bb, w, q, nc, zrow);
         xn[q][x] = nc;
         const float stock = io.wh_inv[(int64_t)w * Ww * ldb + bb];
         __syncthreads();
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kLanes * nic::kQuad) void head_env_fwd_kernel(NicEn
         const float denom = nic::head_quad_denom(xd[0][x], xd[1][x], xd[2][x], xd[3][x], m, trans);
         if (live) {
             nic::head_quad_fwd_store<MAXSQ>(L, denom, stock, n_conn, so, S, Wn, ldb, b, w, q);
-            if (q == (w & 3)) nic::head_wh_order_fwd(Z, ub, wo, S, Wn, ldb, b, w);
+            if (q == (w & 3)) nic::head_wh_order_fwd(Z, ub, wo, S, Wn, ldb, b, w, first_wh_row);
         }
     }
     __syncthreads();   // (every order row a lane reads below was written by that lane; the barrier orders the global accesses)
@@ -84,7 +85,7 @@ template <int MAXW, int MAXSQ>
 __global__ __launch_bounds__(kLanes * nic::kQuad) void head_env_bwd_kernel(
     NicEnvStepIO io, const float* Z, const int32_t* __restrict__ adj, float ub, int trans, const float* g_store_out,
     const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_store_orders, float* g_wh_orders,
-    float* dZ) {
+    float* dZ, const int32_t* __restrict__ zrow, int first_wh_row) {
     __shared__ float part[kChunk][nic::kQuad][kLanes];
     __shared__ float gwa[NIC_MAX_WAREHOUSES][kLanes];
     __shared__ float xm[nic::kQuad][kLanes], xd[nic::kQuad][kLanes], xt[nic::kQuad][kLanes], xs[nic::kQuad][kLanes];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kLanes * nic::kQuad) void head_env_bwd_kernel(
         if (w > 0) __syncthreads();
         nic::HeadLane<MAXSQ> L;
         int nc;
-        xm[q][x] = nic::head_quad_load<MAXSQ, true>(L, Z, g_store_orders, adj, S, Wn, ldb, bb, w, q, nc);
+        xm[q][x] = nic::head_quad_load<MAXSQ, true>(L, Z, g_store_orders, adj, S, Wn, ldb, bb, w, q, nc, zrow);
         const float stock = io.wh_inv[(int64_t)w * Ww * ldb + bb];
         __syncthreads();
         const float m = nic::head_quad_max(xm[0][x], xm[1][x], xm[2][x], xm[3][x], trans);
@@ -129,10 +130,10 @@ __global__ __launch_bounds__(kLanes * nic::kQuad) void head_env_bwd_kernel(
         __syncthreads();
         if (live) {
             const float dot = nic::combine4(xt[0][x], xt[1][x], xt[2][x], xt[3][x]);
-            nic::head_quad_bwd_store<MAXSQ>(L, dot, stock, dZ, S, Wn, ldb, b, w, q);
+            nic::head_quad_bwd_store<MAXSQ>(L, dot, stock, dZ, S, Wn, ldb, b, w, q, zrow);
             if (q == (w & 3)) {
                 g_wh_in[(int64_t)w * Ww * ldb + b] += nic::combine4(xs[0][x], xs[1][x], xs[2][x], xs[3][x]);
-                nic::head_wh_order_bwd(Z, ub, g_wh_orders, dZ, S, Wn, ldb, b, w);
+                nic::head_wh_order_bwd(Z, ub, g_wh_orders, dZ, S, Wn, ldb, b, w, first_wh_row);
             }
         }
     }
@@ -180,15 +181,23 @@ extern "C" {
 
 int nic_head_env_fwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, float upper_bound, int32_t transshipment,
                      float* store_inv_out, float* wh_inv_out, float* reward, void* stream) {
+    return nic_head_env_fwd_rows(io, Z, adjacency, nullptr, -1, upper_bound, transshipment, store_inv_out, wh_inv_out, reward, stream);
+}
+
+int nic_head_env_fwd_rows(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
+                          int32_t first_wh_row, float upper_bound, int32_t transshipment, float* store_inv_out, float* wh_inv_out,
+                          float* reward, void* stream) {
     if (int e = validate(io, Z, adjacency, "nic_head_env_fwd")) return e;
     NIC_REQUIRE(store_inv_out && wh_inv_out && reward, "nic_head_env_fwd: null output");
+    NIC_REQUIRE((logit_rows == nullptr) == (first_wh_row < 0), "nic_head_env_fwd_rows: logit_rows and first_wh_row go together");
     const NicEnvDims& d = io->dims;
     const dim3 grid(nic::ceil_div(d.n_scenarios, kLanes)), block(kLanes * nic::kQuad);
     hipStream_t s = nic::as_stream(stream);
     nic::note_kernelf("head_env_fwd_kernel<%d,%d>", max_slots(d) <= 4 ? 4 : (max_slots(d) <= 8 ? 8 : NIC_MAX_SLOTS),
                       d.n_stores <= 16 ? 4 : 16);
-#define NIC_L(MW, SQ) \
-    hipLaunchKernelGGL((head_env_fwd_kernel<MW, SQ>), grid, block, 0, s, *io, Z, adjacency, upper_bound, transshipment, store_inv_out, wh_inv_out, reward)
+#define NIC_L(MW, SQ)                                                                                                          \
+    hipLaunchKernelGGL((head_env_fwd_kernel<MW, SQ>), grid, block, 0, s, *io, Z, adjacency, upper_bound, transshipment, store_inv_out, \
+                       wh_inv_out, reward, logit_rows, first_wh_row)
     NIC_HEAD_ENV_DISPATCH(NIC_L);
 #undef NIC_L
     return nic::check_launch("nic_head_env_fwd");
@@ -197,8 +206,17 @@ int nic_head_env_fwd(const NicEnvStepIO* io, const float* Z, const int32_t* adja
 int nic_head_env_bwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, float upper_bound, int32_t transshipment,
                      const float* g_store_out, const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in,
                      float* g_store_orders, float* g_wh_orders, float* dZ, void* stream) {
+    return nic_head_env_bwd_rows(io, Z, adjacency, nullptr, -1, upper_bound, transshipment, g_store_out, g_wh_out, g_reward, g_store_in,
+                                 g_wh_in, g_store_orders, g_wh_orders, dZ, stream);
+}
+
+int nic_head_env_bwd_rows(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
+                          int32_t first_wh_row, float upper_bound, int32_t transshipment, const float* g_store_out,
+                          const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_store_orders,
+                          float* g_wh_orders, float* dZ, void* stream) {
     if (int e = validate(io, Z, adjacency, "nic_head_env_bwd")) return e;
     NIC_REQUIRE(g_reward.p && g_store_in && g_wh_in && g_store_orders && g_wh_orders && dZ, "nic_head_env_bwd: null buffer");
+    NIC_REQUIRE((logit_rows == nullptr) == (first_wh_row < 0), "nic_head_env_bwd_rows: logit_rows and first_wh_row go together");
     const NicEnvDims& d = io->dims;
     const dim3 grid(nic::ceil_div(d.n_scenarios, kLanes)), block(kLanes * nic::kQuad);
     hipStream_t s = nic::as_stream(stream);
@@ -206,7 +224,7 @@ int nic_head_env_bwd(const NicEnvStepIO* io, const float* Z, const int32_t* adja
                       d.n_stores <= 16 ? 4 : 16);
 #define NIC_L(MW, SQ)                                                                                                          \
     hipLaunchKernelGGL((head_env_bwd_kernel<MW, SQ>), grid, block, 0, s, *io, Z, adjacency, upper_bound, transshipment, g_store_out, \
-                       g_wh_out, g_reward, g_store_in, g_wh_in, g_store_orders, g_wh_orders, dZ)
+                       g_wh_out, g_reward, g_store_in, g_wh_in, g_store_orders, g_wh_orders, dZ, logit_rows, first_wh_row)
     NIC_HEAD_ENV_DISPATCH(NIC_L);
 #undef NIC_L
     return nic::check_launch("nic_head_env_bwd");

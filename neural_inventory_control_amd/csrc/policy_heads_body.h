@@ -227,22 +227,39 @@ struct HeadLane {
 };
 
 // loads this lane's logits (and, backward, the order gradients); returns the lane's maximum over connected stores and counts them
+// `zrow` (optional, [Wn][S]): the row of Z / dZ that holds the logit of (warehouse w, store s) when the logits layer only
+// computes the connected pairs (compact logits: the rollout engine on sparse many-warehouse graphs); pairs without an edge hold
+// any valid row (their value is loaded and never used).  nullptr: the reference's row s * Wn + w.
 template <int MAXSQ, bool BWD>
 NIC_HD float head_quad_load(HeadLane<MAXSQ>& L, const float* Z, const float* g_store_orders, const int32_t* adj, int S, int Wn,
-                            int64_t ldb, int64_t b, int w, int q, int& n_conn) {
+                            int64_t ldb, int64_t b, int w, int q, int& n_conn, const int32_t* zrow = nullptr) {
     const float* Zw = Z + (int64_t)w * ldb + b;
     const float* gw = BWD ? g_store_orders + (int64_t)w * ldb + b : nullptr;
     const int64_t rs = (int64_t)Wn * ldb;
     const int32_t* aw = adj + w * S;
     // every load is unconditional and its value is used unconditionally (a load that only feeds one side of a select gets sunk
     // into a branch by hipcc and then costs one exposed round trip PER STORE: 16 x vmcnt(0) in the first version of this piece)
+    if (zrow) {
+        int zr[MAXSQ];
 #pragma unroll
-    for (int u = 0; u < MAXSQ; ++u) {
-        const int s = q + kQuad * u;
-        const int sc = s < S ? s : S - 1;
-        L.z[u] = Zw[sc * rs];
-        if (BWD) L.g[u] = gw[sc * rs];
-        L.a[u] = aw[sc];
+        for (int u = 0; u < MAXSQ; ++u) {
+            const int s = q + kQuad * u;
+            const int sc = s < S ? s : S - 1;
+            zr[u] = zrow[w * S + sc];
+            if (BWD) L.g[u] = gw[sc * rs];
+            L.a[u] = aw[sc];
+        }
+#pragma unroll
+        for (int u = 0; u < MAXSQ; ++u) L.z[u] = Z[(int64_t)zr[u] * ldb + b];
+    } else {
+#pragma unroll
+        for (int u = 0; u < MAXSQ; ++u) {
+            const int s = q + kQuad * u;
+            const int sc = s < S ? s : S - 1;
+            L.z[u] = Zw[sc * rs];
+            if (BWD) L.g[u] = gw[sc * rs];
+            L.a[u] = aw[sc];
+        }
     }
 #pragma unroll
     for (int u = 0; u < MAXSQ; ++u) L.a[u] &= -(int)(q + kQuad * u < S);   // stores past S are not connected
@@ -309,12 +326,20 @@ NIC_HD void head_quad_bwd_dots(HeadLane<MAXSQ>& L, float denom, float stock, flo
 }
 template <int MAXSQ>
 NIC_HD void head_quad_bwd_store(const HeadLane<MAXSQ>& L, float dot, float stock, float* dZ, int S, int Wn, int64_t ldb, int64_t b,
-                                int w, int q) {
+                                int w, int q, const int32_t* zrow = nullptr) {
     float* dw = dZ + (int64_t)w * ldb + b;
     const int64_t rs = (int64_t)Wn * ldb;
     float d[MAXSQ];
 #pragma unroll
     for (int u = 0; u < MAXSQ; ++u) d[u] = L.a[u] ? L.e[u] * (L.g[u] * stock - dot) : 0.f;
+    if (zrow) {   // compact logits: only connected pairs have a row
+#pragma unroll
+        for (int u = 0; u < MAXSQ; ++u) {
+            const int s = q + kQuad * u;
+            if (s < S && L.a[u]) dZ[(int64_t)zrow[w * S + s] * ldb + b] = d[u];
+        }
+        return;
+    }
     if (S == kQuad * MAXSQ) {
 #pragma unroll
         for (int u = 0; u < MAXSQ; ++u) dw[(q + kQuad * u) * rs] = d[u];
@@ -325,13 +350,17 @@ NIC_HD void head_quad_bwd_store(const HeadLane<MAXSQ>& L, float dot, float stock
     }
 }
 // the warehouse's own order (:422) and its gradient: one lane per (scenario, warehouse)
-NIC_HD void head_wh_order_fwd(const float* Z, float ub, float* wh_orders, int S, int Wn, int64_t ldb, int64_t b, int w) {
-    wh_orders[(int64_t)w * ldb + b] = sigmoidf_(Z[((int64_t)S * Wn + w) * ldb + b]) * ub;
+// (first_wh_row: row of Z / dZ of warehouse 0's own logit; < 0 = the reference's S * Wn)
+NIC_HD void head_wh_order_fwd(const float* Z, float ub, float* wh_orders, int S, int Wn, int64_t ldb, int64_t b, int w,
+                              int first_wh_row = -1) {
+    const int64_t row = (first_wh_row >= 0 ? first_wh_row : S * Wn) + w;
+    wh_orders[(int64_t)w * ldb + b] = sigmoidf_(Z[row * ldb + b]) * ub;
 }
 NIC_HD void head_wh_order_bwd(const float* Z, float ub, const float* g_wh_orders, float* dZ, int S, int Wn, int64_t ldb,
-                              int64_t b, int w) {
-    const float sg = sigmoidf_(Z[((int64_t)S * Wn + w) * ldb + b]);
-    dZ[((int64_t)S * Wn + w) * ldb + b] = g_wh_orders[(int64_t)w * ldb + b] * ub * sg * (1.f - sg);
+                              int64_t b, int w, int first_wh_row = -1) {
+    const int64_t row = (first_wh_row >= 0 ? first_wh_row : S * Wn) + w;
+    const float sg = sigmoidf_(Z[row * ldb + b]);
+    dZ[row * ldb + b] = g_wh_orders[(int64_t)w * ldb + b] * ub * sg * (1.f - sg);
 }
 
 // host-side composition of the quad pieces (what the device kernels do with LDS in between): tests/hostsim

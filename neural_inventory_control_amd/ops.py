@@ -171,24 +171,26 @@ def head_warehouse_bwd(Z, wh_inv, adjacency, ub, transshipment, g_store_orders, 
 
 
 def head_env_fwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders: Table, wh_orders: Table, Z, adjacency, ub,
-                 transshipment, out: EnvState, reward):
+                 transshipment, out: EnvState, reward, logit_rows=None, first_wh_row=-1):
     """nic_head_env_fwd: vanilla_warehouse head + env step in one launch.  `store_orders` / `wh_orders` are the dense
-    [S][Wn][ldb] / [Wn][ldb] blocks the orders are WRITTEN to (and consumed from)."""
+    [S][Wn][ldb] / [Wn][ldb] blocks the orders are WRITTEN to (and consumed from).  logit_rows / first_wh_row: compact logits
+    (nic_head_env_fwd_rows)."""
     _dev(Z)
     io = prob.make_io(state.store, state.wh, None, demand, store_orders, wh_orders, None)
-    check(lib().nic_head_env_fwd(io, ptr(Z), ptr(adjacency), float(ub), int(transshipment), ptr(out.store), ptr(out.wh),
-                                 ptr(reward), current_stream()))
+    check(lib().nic_head_env_fwd_rows(io, ptr(Z), ptr(adjacency), ptr(logit_rows), int(first_wh_row), float(ub), int(transshipment),
+                                      ptr(out.store), ptr(out.wh), ptr(reward), current_stream()))
     return out, reward
 
 
 def head_env_bwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders: Table, wh_orders: Table, Z, adjacency, ub,
-                 transshipment, g_out: EnvState, g_reward: Table, g_in: EnvState, g_orders, dZ):
-    """nic_head_env_bwd: env-step adjoint + head adjoint in one launch (g_orders: scratch (store, warehouse) blocks)."""
+                 transshipment, g_out: EnvState, g_reward: Table, g_in: EnvState, g_orders, dZ, logit_rows=None, first_wh_row=-1):
+    """nic_head_env_bwd: env-step adjoint + head adjoint in one launch (g_orders: scratch (store, warehouse) blocks).
+    logit_rows / first_wh_row: compact logits (nic_head_env_bwd_rows)."""
     _dev(Z)
     io = prob.make_io(state.store, state.wh, None, demand, store_orders, wh_orders, None)
-    check(lib().nic_head_env_bwd(io, ptr(Z), ptr(adjacency), float(ub), int(transshipment), ptr(g_out.store), ptr(g_out.wh),
-                                 g_reward.t2(), ptr(g_in.store), ptr(g_in.wh), ptr(g_orders[0]), ptr(g_orders[1]), ptr(dZ),
-                                 current_stream()))
+    check(lib().nic_head_env_bwd_rows(io, ptr(Z), ptr(adjacency), ptr(logit_rows), int(first_wh_row), float(ub), int(transshipment),
+                                      ptr(g_out.store), ptr(g_out.wh), g_reward.t2(), ptr(g_in.store), ptr(g_in.wh),
+                                      ptr(g_orders[0]), ptr(g_orders[1]), ptr(dZ), current_stream()))
     return g_in, dZ
 
 

@@ -298,6 +298,12 @@ class FusedRollout:
             if len(live) <= 0.85 * dims[-1]:
                 self.live_rows = torch.tensor(live, dtype=torch.long, device=dev)
                 gd[-1] = len(live)
+                # the fused head + env launches read / write the compact rows themselves (nic_head_env_*_rows): row of pair
+                # (w, s) in the compact block (0 for a pair without an edge: loaded, never used), then the warehouses' own rows
+                pos = {r: i for i, r in enumerate(live)}
+                self.zrow = torch.tensor([[pos.get(s_ * prob.Wn + w, 0) for s_ in range(prob.S)] for w in range(prob.Wn)],
+                                         dtype=torch.int32, device=dev)
+                self.first_wh_row = len(live) - prob.Wn
         self.gd = gd   # layer widths of the GEMMs (= dims unless the logits layer is compacted)
         n_ord = prob.S * prob.nsup + prob.Wn + prob.E
         f_tot = self.F_store + self.F_wh + self.F_ech + extra_rows
@@ -782,8 +788,16 @@ class FusedRollout:
                     self._k(f"fwd_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_fwd, Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)
                 x = y
             Z = self.logits[row]
+            rows_kw = {}
             if self.live_rows is None:
                 self._k(f"fwd_{self.gd[L]}x{self.gd[L - 1]}", ops.linear_fwd, Wv[L - 1], biases[L - 1], x, Z, B, _lib.NIC_ACT_NONE)
+            elif self._fused_head_env(prob):
+                # compact logits straight into the first rows of the period's logits block; the fused head + env launch reads
+                # them through the row map (no scatter into the head's [S * Wn + Wn] layout: one launch and 38 MB per period at
+                # cfg5)
+                Z = Z[:self.gd[L]]
+                self._k(f"fwd_{self.gd[L]}x{self.gd[L - 1]}", ops.linear_fwd, Wv[L - 1], biases[L - 1], x, Z, B, _lib.NIC_ACT_NONE)
+                rows_kw = dict(logit_rows=self.zrow, first_wh_row=self.first_wh_row)
             else:   # compact logits, then one row copy into the head's layout (rows of pairs without an edge stay 0: never read)
                 self._k(f"fwd_{self.gd[L]}x{self.gd[L - 1]}", ops.linear_fwd, Wv[L - 1], biases[L - 1], x, self.Zc, B,
                         _lib.NIC_ACT_NONE)
@@ -792,7 +806,7 @@ class FusedRollout:
             if self._fused_head_env(prob):   # head + env step in one launch (the orders still land in self.orders[row])
                 ts, tw, _ = self._order_tables(self.orders[row], prob)
                 self._k("head_env_fwd", ops.head_env_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, Z, self.adj, ub,
-                        bool(self.model.transshipment), self._views(self.states[nxt], prob), self.rewards[t])
+                        bool(self.model.transshipment), self._views(self.states[nxt], prob), self.rewards[t], **rows_kw)
                 continue
             if self.head == "warehouse":
                 self._k("head_fwd", ops.head_warehouse_fwd, Z, st.wh, self.adj, ub, bool(self.model.transshipment), so, wo,
@@ -829,7 +843,13 @@ class FusedRollout:
             hist, last_hist = self.dZhist, self.dZlast_hist
             compact = self.live_rows is not None
             dZ = last_hist[t] if (last_hist is not None and not compact) else self.dZ
-            if fused:   # env-step adjoint + head adjoint in one launch
+            if fused and compact:   # ... on the compact logits: the gradient of the live rows lands where the GEMMs read it
+                dZ = last_hist[t] if last_hist is not None else self.dZc
+                self._k("head_env_bwd", ops.head_env_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, Z[:self.gd[L]],
+                        self.adj, ub, bool(self.model.transshipment), self._views(g_next, prob), Table(self.g_reward, 0, 1), gc,
+                        (gso, gwo), dZ, logit_rows=self.zrow, first_wh_row=self.first_wh_row)
+                compact = False   # (nothing left to gather)
+            elif fused:   # env-step adjoint + head adjoint in one launch
                 self._k("head_env_bwd", ops.head_env_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, Z, self.adj, ub,
                         bool(self.model.transshipment), self._views(g_next, prob), Table(self.g_reward, 0, 1), gc, (gso, gwo), dZ)
             elif self.head == "warehouse":
