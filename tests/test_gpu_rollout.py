@@ -1824,3 +1824,58 @@ def test_small_route_step_caches_follow_their_inputs():
     for a, b in zip(scaled[1], same(d2, 1e-3)[1]):
         torch.testing.assert_close(a, 2.0 * b, rtol=1e-6, atol=0)
     same({k: v[:77].contiguous() for k, v in d2.items()}, 1e-3)   # a smaller batch (padding columns must be zero again)
+
+
+@pytest.mark.parametrize("S,Wn,seed", [(5, 2, 1), (10, 3, 2), (21, 4, 3), (64, 3, 4), (17, 2, 5)])
+def test_compact_logit_rows_through_the_fused_head_env_launches_on_random_graphs(S, Wn, seed):
+    """Sparse many-warehouse graphs drawn at random (every store served by one or two warehouses; store counts that do not fill the
+    four lanes of a scenario; a warehouse that may end up with a single store): the fused head + env launches on the COMPACT
+    logits (`nic_head_env_fwd_rows` / `_bwd_rows`: only connected (store, warehouse) pairs have a logit row) against the separate
+    head and env launches on the scattered [S * Wn + Wn] layout - rewards, states, orders and parameter gradients bit for bit."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    setting = workloads.many_warehouses(min(S, 64), min(Wn, 3), seed=seed) if Wn <= 3 else None
+    if setting is None:   # (the builder's cost lists stop at three warehouses)
+        import random
+        rnd = random.Random(seed)
+        setting = workloads.many_warehouses(S, 3, seed=seed)
+        adj = [[0] * S for _ in range(Wn)]
+        lead = [[0] * Wn for _ in range(S)]
+        for s_ in range(S):
+            for w in rnd.sample(range(Wn), rnd.choice([1, 2])):
+                adj[w][s_], lead[s_][w] = 1, rnd.randint(1, 6)
+        setting["problem_params"].update({"n_warehouses": Wn, "warehouse_store_adjacency": adj})
+        setting["store_params"]["lead_time"] = workloads._const(lead)
+        setting["warehouse_params"] = {"holding_cost": [0.3, 0.4, 0.2, 0.35][:Wn], "lead_time": 3,
+                                       "edge_cost": [0.5, 1.5, 0.7, 0.9][:Wn]}
+    policy = workloads.get("cfg5")[1]
+    import copy
+    policy = copy.deepcopy(policy)
+    policy["output_sizes"]["master"] = S * Wn + Wn
+    policy["neurons_per_hidden_layer"]["master"] = [64, 64]
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    T, n = 7, 150
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
+                  n, obs, setting["seeds"])
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    out = {}
+    for fuse in (True, False):
+        torch.manual_seed(21)
+        model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+        eng = FusedRollout(model, setting["problem_params"], DEV)
+        eng.fuse_head_env = fuse
+        eng.materialize(eng.input_rows(data, obs))
+        total, _ = eng.run(data, T, 0, train=True, observation_params=obs)
+        torch.cuda.synchronize()
+        assert eng.small is None and eng.horizon is None
+        compact = eng.live_rows is not None
+        out[fuse] = (float(total), eng.per_period_rewards().clone(), eng.states.clone(), eng.orders.clone(),
+                     [p.grad.clone() for p in model.parameters()], compact)
+    a, b = out[True], out[False]
+    assert a[5] and b[5], "the graph was meant to be sparse enough for the compact logits layer"
+    assert a[0] == b[0]
+    for x, y in zip(a[1:4], b[1:4]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[4], b[4]):
+        assert torch.equal(x, y)
+    assert all(bool(torch.isfinite(g_).all()) for g_ in a[4])
