@@ -258,6 +258,17 @@ def algorithmic_work(tag, kernel, shape):
         return "hbm", 4.0 * (2 * f_state + S + shape["n_out"] + n_ord + 1) * n, "B"
     if tag == "head_env_bwd":  # state, orders, demand, logits, incoming state gradient in; state gradient, order gradients, dZ out
         return "hbm", 4.0 * (3 * f_state + S + 2 * n_ord + 2 * shape["n_out"]) * n, "B"
+    if tag in ("tail_fwd", "tail_bwd") and shape.get("hidden"):
+        # fused per-period tail (csrc/period_tail.hip).  Forward: last hidden activation in (K rows), next period's first hidden
+        # activation out (N1 rows) + the fused head / env step's bytes.  Backward: the first layer's pre-activation gradient of the
+        # next period in (N1), last hidden activation in and its gradient out (2 K) + the adjoints' bytes; the slab slot is
+        # read-modify-written once per workgroup (not per column: not counted).  MFMA work (padded rows excluded) as `other`.
+        K, N1, no, F = shape["hidden"][-1], shape["hidden"][0], shape["n_out"], f_state
+        if tag == "tail_fwd":
+            return ("hbm", 4.0 * (K + N1 + 2 * f_state + S + no + n_ord + 1) * n, "B",
+                    ("mfma", 2.0 * (no * K + N1 * (F + 1)) * n, "FLOP"))
+        return ("hbm", 4.0 * (N1 + 2 * K + 3 * f_state + S + n_ord + no) * n, "B",
+                ("mfma", 2.0 * (F * N1 + 2 * no * K) * n, "FLOP"))
     if tag in ("alloc_env_fwd", "alloc_env_bwd"):   # GNN: allocation head + env step in one launch (one warehouse)
         n_edges = shape["gnn"]["output"][2] if shape.get("gnn") else S + 2
         if tag == "alloc_env_fwd":  # state read + write, demand, desired quantities of the member / self / supplier edges, orders, sums / ratio / scale, reward

@@ -215,6 +215,48 @@ int nic_head_env_bwd_rows(const NicEnvStepIO* io, const float* Z, const int32_t*
                           const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_store_orders,
                           float* g_wh_orders, float* dZ, void* stream);
 
+/* ---- the whole per-period "tail" of the vanilla_warehouse rollout in one launch per direction (round 5) -------------------
+ * Between two periods' hidden-layer GEMMs the rollout of trainer.py:190-213 runs, forward, the logits layer
+ * (neural_networks.py:88-106, last nn.Linear), the softmax head (:393-426, :140-166), Simulator.step (environment.py:110-299)
+ * and the NEXT period's first layer + ELU (its input is the state the step just produced); backward the adjoints in reverse.
+ * Every stage is column-local, so one workgroup carries a block of 32 scenarios through all of them on LDS tiles:
+ *   nic_period_tail_fwd = nic_linear_fwd (logits) + nic_head_env_fwd + nic_linear_fwd_thin_in (ELU, bias as row F of Wt_in)
+ *   nic_period_tail_bwd = nic_linear_dgrad (first layer of period t+1, accumulate) + nic_head_env_bwd + nic_linear_bwd_thin
+ * with the same arithmetic and summation orders as those launches take at small batches (bit for bit: rewards, orders, states,
+ * logits, hidden activations, state and activation gradients; the logits layer's WEIGHT gradient is summed per workgroup in a
+ * different order: 1e-6).  Shapes: nic_period_tail_ok (<= 16 stores, (S + 1) Wn = n_out <= 32 logits, S Ws + Wn Ww + 1 <= 52
+ * state rows, pipelines <= 8 slots, K <= 512, ldb % 64 == 0; weight rows padded to 16 bytes, padding finite). */
+typedef struct NicPeriodTail {
+    NicEnvStepIO io;           /* period t.  store_inv / wh_inv: ONE [S Ws + Wn Ww][ldb] block (the MLP's input rows);
+                                * store_orders / wh_orders: ONE dense [S Wn + Wn][ldb] block (forward: written; backward: read);
+                                * demand: a [S][ld] block (scn_stride 1) */
+    const int32_t* adjacency;  /* [Wn][S] */
+    float upper_bound;
+    int32_t transshipment;
+    const float* W_out;        /* logits layer [n_out][ldw_out] (rows padded to 16 bytes) */
+    int64_t ldw_out;
+    const float* b_out;        /* [n_out] or NULL */
+    int32_t n_out, K;          /* K = width of the last hidden layer */
+    const float* Wt_in;        /* first layer TRANSPOSED [F + 1][ldwt_in], row F = its bias (F = S Ws + Wn Ww) */
+    int64_t ldwt_in;
+    int32_t N1;                /* width of the first hidden layer */
+} NicPeriodTail;
+int nic_period_tail_ok(const NicEnvDims* dims, int32_t n_out, int32_t K, int32_t N1);
+/* H_last [K][ldb]: last hidden activation of period t.  Writes Z [n_out][ldb] (logits), the orders (io), state_out [F][ldb]
+ * (state of period t+1; row F of that block - the ones row - is the caller's), reward [ldb], and H_first_next [N1][ldb] =
+ * ELU(first layer) of period t+1 (NULL: last period, stage skipped). */
+int nic_period_tail_fwd(const NicPeriodTail* t, const float* H_last, float* Z, float* state_out, float* reward,
+                        float* H_first_next, void* stream);
+/* dZ_first_next [N1][ldb]: pre-activation gradient of period t+1's first layer; g_state_next [F][ldb]: what this call left in
+ * g_state_out for period t+1 (both NULL for the last period: the state after it carries no gradient).  Writes g_state_out
+ * [F][ldb] (the env + head part of d loss / d state(t); the first layer's part is added by the NEXT call), dH_last [K][ldb]
+ * (ELU' applied) and adds the logits layer's weight / bias gradient to slab slot = workgroup ([n_slots][n_out][lds], lds >= K + 1,
+ * n_slots = nic_period_tail_bwd_slots(n_scenarios); first != 0: the slot is overwritten - no memset per sweep). */
+int nic_period_tail_bwd_slots(int32_t n_scenarios);
+int nic_period_tail_bwd(const NicPeriodTail* t, const float* Z, const float* H_last, const float* dZ_first_next,
+                        const float* g_state_next, NicTable2 g_reward, float* g_state_out, float* dH_last, float* slab,
+                        int64_t lds, int32_t n_slots, int32_t first, void* stream);
+
 /* vanilla_one_store (neural_networks.py:200-214): orders[s][b] = softplus(Z[s][b] + 1)  (threshold 20 like
  * nn.Softplus).  rows = number of output rows (1 for the shipped config). */
 int nic_head_softplus_fwd(const float* Z, float* orders, int32_t rows, int32_t n_scenarios, int32_t ldb,

@@ -47,6 +47,12 @@ class NicEnvStepIO(C.Structure):
     ]
 
 
+class NicPeriodTail(C.Structure):
+    _fields_ = [("io", NicEnvStepIO), ("adjacency", C.c_void_p), ("upper_bound", C.c_float), ("transshipment", C.c_int32),
+                ("W_out", C.c_void_p), ("ldw_out", C.c_int64), ("b_out", C.c_void_p), ("n_out", C.c_int32), ("K", C.c_int32),
+                ("Wt_in", C.c_void_p), ("ldwt_in", C.c_int64), ("N1", C.c_int32)]
+
+
 class NicSmallRolloutDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in (
         "n_scenarios", "ldb", "T", "t0", "F", "n_hidden", "n_out", "head", "Ws", "Wn", "Ww", "E", "We", "lost_demand",
@@ -109,6 +115,10 @@ PROTOTYPES = {
     "nic_head_env_bwd": (C.c_int, [_IOP, _vp, _vp, C.c_float, _i32, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_head_env_fwd_rows": (C.c_int, [_IOP, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, _vp, _vp]),
     "nic_head_env_bwd_rows": (C.c_int, [_IOP, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nic_period_tail_ok": (C.c_int, [C.POINTER(NicEnvDims), _i32, _i32, _i32]),
+    "nic_period_tail_fwd": (C.c_int, [C.POINTER(NicPeriodTail), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nic_period_tail_bwd_slots": (C.c_int, [_i32]),
+    "nic_period_tail_bwd": (C.c_int, [C.POINTER(NicPeriodTail), _vp, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "nic_linear_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_linear_fwd_thin_in_ok": (C.c_int, [_i32, _i32]),
     "nic_linear_fwd_thin_in": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -16,6 +16,7 @@ SOURCES = [
     ("env_step.hip", ["-ffp-contract=off"]),
     ("policy_heads.hip", ["-ffp-contract=off"]),
     ("head_env.hip", ["-ffp-contract=off"]),
+    ("period_tail.hip", ["-ffp-contract=off"]),
     ("linear_mfma.hip", []),
     ("thin_layer.hip", []),
     ("sampler.hip", []),

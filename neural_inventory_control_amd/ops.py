@@ -194,6 +194,45 @@ def head_env_bwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders:
     return g_in, dZ
 
 
+def period_tail_ok(prob: EnvProblem, n_out, K, N1):
+    """shapes the fused per-period tail takes (nic_period_tail_ok)"""
+    return bool(lib().nic_period_tail_ok(prob.dims(), int(n_out), int(K), int(N1)))
+
+
+def period_tail_bwd_slots(n_scenarios):
+    return lib().nic_period_tail_bwd_slots(int(n_scenarios))
+
+
+def period_tail_desc(prob: EnvProblem, state_block, demand: Table, orders_block, adjacency, ub, transshipment, W_out, b_out, Wt_in):
+    """NicPeriodTail of one period.  state_block: [F (+ ...)][ldb] rows [store | warehouse]; orders_block: [S Wn + Wn][ldb];
+    W_out [n_out][ldw] (rows padded to 16 bytes); Wt_in [F + 1][ldwt] = the first layer transposed with its bias as row F."""
+    S, Wn, ld = prob.S, prob.Wn, prob.ldb
+    F_store = S * prob.Ws
+    store = state_block[:F_store]
+    wh = state_block[F_store:F_store + Wn * prob.Ww]
+    t = _lib.NicPeriodTail()
+    t.io = prob.make_io(store, wh, None, demand, Table(orders_block[:S * Wn], Wn * ld, 1, ld), Table(orders_block[S * Wn:], ld, 1), None)
+    t.adjacency, t.upper_bound, t.transshipment = ptr(adjacency), float(ub), int(transshipment)
+    t.W_out, t.ldw_out, t.b_out = ptr(W_out), _ld(W_out), ptr(b_out)
+    t.n_out, t.K = W_out.shape[0], W_out.shape[1]
+    t.Wt_in, t.ldwt_in, t.N1 = ptr(Wt_in), _ld(Wt_in), Wt_in.shape[1]
+    t._keep = (state_block, demand, orders_block, adjacency, W_out, b_out, Wt_in)
+    return t
+
+
+def period_tail_fwd(desc, H_last, Z, state_out, reward, H_first_next):
+    """nic_period_tail_fwd: logits layer + head + env step + next period's first layer (ELU) in one launch."""
+    _dev(H_last)
+    check(lib().nic_period_tail_fwd(desc, ptr(H_last), ptr(Z), ptr(state_out), ptr(reward), ptr(H_first_next), current_stream()))
+
+
+def period_tail_bwd(desc, Z, H_last, dZ_first_next, g_state_next, g_reward: Table, g_state_out, dH_last, slab, first):
+    """nic_period_tail_bwd: first layer's input gradient of period t+1 + env / head adjoints + logits layer backward."""
+    _dev(Z)
+    check(lib().nic_period_tail_bwd(desc, ptr(Z), ptr(H_last), ptr(dZ_first_next), ptr(g_state_next), g_reward.t2(), ptr(g_state_out),
+                                    ptr(dH_last), ptr(slab), slab.stride(1), slab.shape[0], int(bool(first)), current_stream()))
+
+
 def head_data_driven_fwd(Z, wh, mask, store_orders, wh_orders, S, Wn, Ww, B):
     """nic_head_data_driven_fwd: ReLU, adjacency mask and proportional allocation of the data_driven policy (one launch)."""
     _dev(Z)

@@ -136,6 +136,10 @@ class FusedRollout:
         self.use_thin = True    # fused backward of thin (<= 32 rows) output layers (csrc/thin_layer.hip)
         self.batch_wgrad = True  # hidden-layer weight gradients contracted over all periods in one launch
         self.fuse_head_env = True  # vanilla_warehouse: head + env step (and their adjoints) in one launch each (csrc/head_env.hip)
+        # ... and, where the shapes allow (<= 16 stores, <= 32 logits, <= 51 state rows: BASELINE cfg3 and the shipped one-warehouse
+        # YAML), the whole per-period TAIL in one launch per direction (csrc/period_tail.hip): logits layer + head + env step + the
+        # next period's first layer forward; first layer's input gradient + env / head adjoints + logits layer backward
+        self.fuse_tail = True
         # data_driven on small batches (what the reference trains it on: 72 products): all periods in ONE forward and ONE backward
         # launch (csrc/horizon_rollout.hip).  Measured against the per-period kernels on the real-data shape (tools/
         # horizon_crossover.py, profiles/r04_horizon_crossover.json): 2.3 vs 8.7 ms (replayed) at 72 scenarios, 3.4 vs 10.2 at 4,096,
@@ -159,6 +163,10 @@ class FusedRollout:
         echelons, no order rounding between head and env step (discrete allocation keeps the three separate launches)."""
         return (self.fuse_head_env and self.head == "warehouse" and prob.S <= 64 and prob.E == 0 and prob.Wn >= 1
                 and not self._round)
+
+    def _use_tail(self):
+        """the fused per-period tail launches (csrc/period_tail.hip) run for the current shapes and options"""
+        return self._tail_shapes and not self._round
 
     def _graph_on(self):
         return self.use_graph is True or (self.use_graph == "auto" and self._auto_graph is True)
@@ -196,7 +204,7 @@ class FusedRollout:
     def _setup(self, prob, T, train, extra_rows=0):
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin,
                self.eval_history, self.small_wgrad_in_kernel, extra_rows, self.small_lane_scenarios, self.use_horizon,
-               self.horizon_max_scenarios, getattr(self, "_shift_hint", 0))
+               self.horizon_max_scenarios, getattr(self, "_shift_hint", 0), self.fuse_tail, self.fuse_head_env)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
@@ -305,6 +313,10 @@ class FusedRollout:
                                          dtype=torch.int32, device=dev)
                 self.first_wh_row = len(live) - prob.Wn
         self.gd = gd   # layer widths of the GEMMs (= dims unless the logits layer is compacted)
+        # the fused per-period tail (csrc/period_tail.hip): the shapes decide here (slab slots below), discrete allocation per run
+        self._tail_shapes = bool(self.fuse_tail and self.fuse_head_env and self.head == "warehouse" and self.live_rows is None
+                                 and extra_rows == 0 and L >= 2 and self.use_thin and all(m.bias is not None for m in lins)
+                                 and ops.period_tail_ok(prob, dims[-1], dims[-2], dims[1]))
         n_ord = prob.S * prob.nsup + prob.Wn + prob.E
         f_tot = self.F_store + self.F_wh + self.F_ech + extra_rows
         # evaluation keeps the state / order / logit history only while it is small (tests and short horizons read it);
@@ -353,6 +365,8 @@ class FusedRollout:
                           and not (i == L - 1 and self.dZlast_hist is None) for i in range(L)]   # (as _launch_backward decides)
             self.splits = [ops.wgrad_periods_num_splits(gd[i + 1], gd[i], prob.B, T) if by_periods[i]
                            else ops.wgrad_num_splits(gd[i + 1], gd[i], prob.B) for i in range(L)]
+            if self._tail_shapes:   # the logits layer's weight gradient: one slab slot per workgroup of the fused tail
+                self.splits[L - 1] = ops.period_tail_bwd_slots(prob.B)
             self.slabs = [z(self.splits[i], gd[i + 1], (gd[i] + 1 + 3) // 4 * 4) for i in range(L)]
             self.g_reward, self._g_reward_key = z(ld), None
             self.gw = [torch.zeros_like(m.weight) for m in lins]
@@ -502,9 +516,12 @@ class FusedRollout:
         if grad_scale is None:
             grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
         self._set_g_reward(B, grad_scale)
-        for sl in self.slabs:
-            sl.zero_()
-        self.g_state[0].zero_()
+        tail = self._use_tail()
+        for i, sl in enumerate(self.slabs):
+            if not (tail and i == len(self.slabs) - 1):   # (the fused tail's first launch of a sweep overwrites its slab slots)
+                sl.zero_()
+        if not tail:   # (the fused tail reads no gradient of the state after the last period)
+            self.g_state[0].zero_()
         # layers whose backward is ONE fused pass over their input (nic_linear_bwd_thin): thin output, not the first
         thin = [i > 0 and self.use_thin and ops.linear_bwd_thin_ok(self.gd[i + 1], self.gd[i]) for i in range(len(lins))]
         if thin != getattr(self, "_thin", None):
@@ -750,7 +767,7 @@ class FusedRollout:
         loading is not capturable); timers force eager mode."""
         if not self._graph_on() or self.timer is not None or self._eager_runs < 1:
             return fn()
-        variant = (self._round, self._ctx[4], self.fuse_head_env)  # options baked into the captured launch sequence
+        variant = (self._round, self._ctx[4], self.fuse_head_env, self.fuse_tail)  # options baked into the captured launch sequence
         if getattr(self, "_graph_variant", variant) != variant:
             self._graphs = {}
         self._graph_variant = variant
@@ -772,6 +789,8 @@ class FusedRollout:
         # the ones row sits right behind the MLP's input rows when the input IS the whole state block (every head of this engine)
         self._thin_in_aug = (self._thin_in and self.F + 1 == self.states.shape[1]
                              and ops.linear_fwd_thin_in_ok(self.gd[1], self.gd[0] + 1))
+        if self._use_tail():
+            return self._launch_forward_tail()
         for t in range(T):
             cur, nxt, row = (t, t + 1, t) if hist else (t & 1, (t + 1) & 1, 0)
             st = self._views(self.states[cur], prob)
@@ -824,8 +843,70 @@ class FusedRollout:
             self._k("env_fwd", ops.env_step_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, te,
                     out=self._views(self.states[nxt], prob), reward=self.rewards[t])
 
+    def _tail_desc(self, t, state_block, orders_block):
+        prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
+        return ops.period_tail_desc(prob, state_block, Table(demand_soa[t + shift], ld, 1), orders_block, self.adj, self._ub_now,
+                                    bool(self.model.transshipment), Wv[L - 1], biases[L - 1], self.Wt[0][:self.F + 1, :self.gd[1]])
+
+    def _launch_forward_tail(self):
+        """Forward sweep with the fused tail: [first layer of period 0], then per period the hidden-layer GEMMs and ONE tail launch
+        (logits + head + env step + first layer of period t+1) - L - 1 launches per period instead of L + 1."""
+        prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
+        hist = self._hist
+        if self._thin_in and self._thin_in_aug:   # first layer of period 0 (later periods': the tail launch of the period before)
+            self._k(f"fwd_{self.gd[1]}x{self.gd[0]}", ops.linear_fwd_thin_in, self.Wt[0][:self.F + 1, :self.gd[1]], None,
+                    self.states[0][:self.F + 1], self.hidden[0][0], B, _lib.NIC_ACT_ELU)
+        else:
+            self._k(f"fwd_{self.gd[1]}x{self.gd[0]}", ops.linear_fwd, Wv[0], biases[0], self.states[0][:self.F], self.hidden[0][0], B,
+                    _lib.NIC_ACT_ELU)
+        for t in range(T):
+            cur, nxt, row = (t, t + 1, t) if hist else (t & 1, (t + 1) & 1, 0)
+            hs, hs_next = (t, t + 1) if train else (0, 0)
+            x = self.hidden[0][hs]
+            for i in range(1, L - 1):
+                y = self.hidden[i][hs]
+                self._k(f"fwd_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_fwd, Wv[i], biases[i], x, y, B, _lib.NIC_ACT_ELU)
+                x = y
+            desc = self._tail_desc(t, self.states[cur], self.orders[row])
+            self._k("tail_fwd", ops.period_tail_fwd, desc, x, self.logits[row], self.states[nxt], self.rewards[t],
+                    self.hidden[0][hs_next] if t + 1 < T else None)
+
+    def _launch_backward_tail(self):
+        """Backward sweep with the fused tail: per period ONE tail launch (first layer's input gradient of period t+1 + env / head
+        adjoints + logits layer backward with its weight gradient) and the hidden layers' input gradients."""
+        prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
+        g_next, g_cur = self.g_state
+        hist = self.dZhist
+        g_rew = Table(self.g_reward, 0, 1)
+        dz1_buf = lambda t: hist[0][t] if hist is not None else self.dH[1 & 1][:self.gd[1]]  # noqa: E731
+        for t in range(T - 1, -1, -1):
+            desc = self._tail_desc(t, self.states[t], self.orders[t])
+            dx = hist[L - 2][t] if hist is not None else self.dH[(L - 1) & 1][:self.gd[L - 1]]
+            last = t == T - 1
+            self._k("tail_bwd", ops.period_tail_bwd, desc, self.logits[t], self.hidden[L - 2][t], None if last else dz1_buf(t + 1),
+                    None if last else g_next, g_rew, g_cur, dx, self.slabs[L - 1], last)
+            d = dx
+            for i in range(L - 2, -1, -1):
+                x_in = self.hidden[i - 1][t] if i > 0 else self.states[t][:self.F]
+                if hist is None:
+                    self._k(f"wgrad_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_wgrad, d, x_in, self.slabs[i], B)
+                if i > 0:
+                    dxi = hist[i - 1][t] if hist is not None else self.dH[i & 1][:self.gd[i]]
+                    self._k(f"dgrad_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_dgrad, Wtv[i], d, x_in, dxi, B, _lib.NIC_ACT_ELU, False)
+                    d = dxi
+                # (i == 0: the first layer's input gradient is the first stage of the NEXT tail launch; period 0's is not needed)
+            g_next, g_cur = g_cur, g_next
+        if hist is not None:
+            for i in range(L - 1):
+                x_hist = self.hidden[i - 1] if i > 0 else self.states[:T, :self.F]
+                self._k(f"wgradT_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_wgrad_periods, hist[i], x_hist, self.slabs[i], B)
+        for i in range(L):
+            ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], self.gd[i], 1.0)
+
     def _launch_backward(self):
         prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
+        if self._use_tail():
+            return self._launch_backward_tail()
         ub = self._ub_now
         g_next, g_cur = self.g_state
         detached_input = self.head == "serial"  # the reference detaches VanillaSerial's MLP input (:329)

@@ -1879,3 +1879,121 @@ def test_compact_logit_rows_through_the_fused_head_env_launches_on_random_graphs
     for x, y in zip(a[4], b[4]):
         assert torch.equal(x, y)
     assert all(bool(torch.isfinite(g_).all()) for g_ in a[4])
+
+
+# ---- round 5: the fused per-period tail (csrc/period_tail.hip) ---------------------------------------------------------------
+TAIL_CASES = ["cfg3_one_warehouse_16_vanilla", "cfg3_one_warehouse_5_vanilla", "x_transshipment_backlogged_vanilla"]
+
+
+def _run_engine(model, pp, data, T, ignore, obs, fuse_tail, train=True):
+    from neural_inventory_control_amd.rollout import KernelTimer
+    eng = FusedRollout(model, pp, DEV)
+    eng.fuse_tail = fuse_tail
+    eng.materialize(eng.input_rows(data, obs))
+    eng.timer = KernelTimer(record_order=True)
+    total, rep = eng.run(data, T, ignore, train=train, observation_params=obs)
+    torch.cuda.synchronize()
+    tags = {t for t, _ in eng.timer.order}
+    return eng, float(total), float(rep), tags
+
+
+@pytest.mark.parametrize("name", TAIL_CASES)
+def test_fused_tail_launches_on_the_warehouse_fixtures(name):
+    """Round 5 (csrc/period_tail.hip): the fixtures whose shapes the fused tail takes (<= 16 stores, <= 32 logits, <= 51 state rows)
+    run it by default - forward: logits layer + head + env step + next period's first layer in ONE launch; backward: first layer's
+    input gradient + env / head adjoints + logits layer backward in ONE launch.  Against the separate launches: rewards, orders and
+    states agree to fp32 round-off of the two GEMM stages (the tail carries the first layer's bias inside the contraction and splits
+    the logits contraction over four wavefronts; at these widths the separate launches do neither), gradients <= 1e-5; against the
+    reference's golden numbers: the usual bars."""
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    out = {}
+    for fuse in (True, False):
+        model = _model(g, c)
+        eng = FusedRollout(model, c["problem_params"], DEV)
+        eng.materialize(eng.input_rows(data, c["observation_params"]))
+        _load(model, g)
+        eng, total, rep, tags = _run_engine(model, c["problem_params"], data, c["periods"], c["ignore"], c["observation_params"], fuse)
+        assert ("tail_fwd" in tags and "tail_bwd" in tags and "head_env_fwd" not in tags and "head_env_bwd" not in tags) == fuse, tags
+        out[fuse] = (total, rep, eng.per_period_rewards().clone(), eng.states.clone(), eng.orders.clone(),
+                     [p.grad.clone() for p in model.parameters()])
+        if fuse:
+            _check_grads(model, g, GRAD_TOL)
+            exp = _Expected(g, c)
+            assert abs(total - exp.total) <= 1e-5 * abs(exp.total) and abs(rep - exp.reported) <= 1e-5 * abs(exp.reported)
+            torch.testing.assert_close(eng.per_period_rewards().cpu(), exp.rewards, rtol=1e-5, atol=1e-5)
+    a, b = out[True], out[False]
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 2e-6 * abs(b[1])
+    torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a[3], b[3], **STATE_TOL)
+    torch.testing.assert_close(a[4], b[4], **STATE_TOL)
+    for x, y in zip(a[5], b[5]):
+        assert float((x - y).norm()) <= 1e-5 * float(y.norm()) + 1e-12
+
+
+@pytest.mark.parametrize("n,T,hidden", [(100, 5, [256, 256, 256]), (24, 4, [512, 512]), (2048 + 17, 3, [256, 512])])
+def test_fused_tail_is_bit_identical_to_the_separate_launches_where_they_take_the_same_contraction_order(n, T, hidden):
+    """BASELINE cfg3's setting (16 stores, 51 state rows, 17 logits) with hidden layers >= 256 wide at small batches: there the
+    separate launches are thin_in_fwd (bias inside the contraction), gemm_wx_stream_kernel<1, 4> (logits / first layer's input
+    gradient: contraction split over four wavefronts) and thin_bwd - exactly the arithmetic the tail kernels restate.  Per-period
+    rewards, states, orders, logits, hidden activations, the pre-activation gradient histories and every hidden layer's weight
+    gradient are BIT-IDENTICAL; the logits layer's weight gradient is summed per workgroup instead of per scenario split: 1e-6.
+    Ragged batches (100 = three blocks + 4 scenarios; 2,065: more blocks than a group)."""
+    import copy
+    from neural_inventory_control_amd import workloads
+    from collections import defaultdict
+    setting, policy, _, _, _ = workloads.get("cfg3")
+    policy = copy.deepcopy(policy)
+    policy["neurons_per_hidden_layer"]["master"] = list(hidden)
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"], n,
+                  obs, setting["seeds"], sampler="hip", device=DEV)
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    out = {}
+    for fuse in (True, False):
+        torch.manual_seed(11)
+        model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+        eng, total, rep, tags = _run_engine(model, setting["problem_params"], data, T, 0, obs, fuse)
+        assert ("tail_fwd" in tags) == fuse and ("tail_bwd" in tags) == fuse, tags
+        out[fuse] = (total, eng.per_period_rewards().clone(), eng.states.clone(), eng.orders.clone(), eng.logits.clone(),
+                     [h.clone() for h in eng.hidden], [h.clone() for h in eng.dZhist], [p.grad.clone() for p in model.parameters()])
+    a, b = out[True], out[False]
+    if n <= 1024:   # (beyond that the separate logits GEMM takes the LDS-DMA kernel: one wavefront per contraction)
+        assert a[0] == b[0]
+        for x, y in zip(a[1:5], b[1:5]):
+            assert torch.equal(x, y)
+        for x, y in zip(a[5] + a[6], b[5] + b[6]):
+            assert torch.equal(x, y)
+        for x, y in zip(a[7][:-2], b[7][:-2]):
+            assert torch.equal(x, y)
+    else:
+        assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0])
+        torch.testing.assert_close(a[1], b[1], rtol=1e-5, atol=1e-5)
+    for x, y in zip(a[7], b[7]):
+        assert float((x - y).norm()) <= 2e-6 * float(y.norm()) + 1e-12
+
+
+def test_fused_tail_evaluation_without_history_and_discrete_allocation_falls_back():
+    """Evaluation through the tail without the state / order history (two rolling state blocks), and discrete allocation
+    (orders rounded between head and env step) keeping the separate launches."""
+    g = Golden("cfg3_one_warehouse_16_vanilla")
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    res = {}
+    for hist in (True, False):
+        model = _model(g, c)
+        eng = FusedRollout(model, c["problem_params"], DEV)
+        eng.eval_history = hist
+        eng.materialize(eng.input_rows(data, c["observation_params"]))
+        _load(model, g)
+        with torch.no_grad():
+            total, _ = eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"])
+        assert eng._use_tail()
+        res[hist] = (float(total), eng.per_period_rewards().clone(), {k: v.clone() for k, v in eng.final_state().items()})
+    assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1])
+    for k in res[True][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k])
+    with torch.no_grad():
+        eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"], discrete_allocation=True)
+    assert not eng._use_tail()
