@@ -82,6 +82,10 @@ typedef struct NicEnvStepIO {
 
 /* ---- library ------------------------------------------------------------------------------------------- */
 int nic_abi_version(void);
+/* Identity of the SOURCES the library was built from: the first 16 hex digits of a sha256 over every HIP source (with its
+ * compiler flags) and header of the build (neural_inventory_control_amd/build.py::source_id).  A binding that ships next to the
+ * sources compares the two at load time and refuses a stale binary ("unknown": built outside build.py). */
+const char* nic_build_id(void);
 const char* nic_last_error(void);
 /* Name (with template arguments) of the kernel the calling thread's most recent nic_* call launched; "" before the first.
  * Measurement aid: bench.py labels its roofline object with it instead of keeping a shape -> kernel table by hand. */

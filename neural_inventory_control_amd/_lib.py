@@ -106,6 +106,7 @@ _IOP = C.POINTER(NicEnvStepIO)
 # name -> (restype, argtypes); every symbol include/nic_rollout.h declares
 PROTOTYPES = {
     "nic_abi_version": (C.c_int, []),
+    "nic_build_id": (C.c_char_p, []),
     "nic_last_error": (C.c_char_p, []),
     "nic_last_kernel": (C.c_char_p, []),
     "nic_device_count": (C.c_int, []),
@@ -209,9 +210,27 @@ def load_library(path=None):
         fn.argtypes = args
     if lib.nic_abi_version() != 1:
         raise NicError("ABI version mismatch")
+    check_build_id(lib, os.path.dirname(p))
     if path is None:
         _lib = lib
     return lib
+
+
+def check_build_id(lib, csrc_dir):
+    """The library must have been built from the sources that lie next to it: `nic_build_id()` (baked in by build.py) against
+    the hash of those files now.  A stale binary - a checkout or an edited header after the last build - raises here, at load
+    time, instead of running an old kernel until some golden test fails.  Skipped when the sources are not there (an installed
+    binary without its tree)."""
+    from . import build as _build
+    try:
+        want = _build.source_id(csrc_dir)
+    except OSError:
+        return None
+    got = (lib.nic_build_id() or b"").decode()
+    if got != want:
+        raise NicError(f"{os.path.join(csrc_dir, 'libnic_hip.so')} was built from other sources (library id {got}, sources {want}): "
+                       "run `python -m neural_inventory_control_amd.build`")
+    return got
 
 
 def lib():

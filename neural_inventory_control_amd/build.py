@@ -39,36 +39,94 @@ def _hipcc():
     return "hipcc"
 
 
-def _stale(target, deps):
-    if not os.path.isfile(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
+BASE_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _sha(parts):
+    import hashlib
+    h = hashlib.sha256()
+    for p in parts:
+        h.update(p if isinstance(p, bytes) else str(p).encode())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def _read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def source_id(csrc=CSRC):
+    """Identity of what the library is built FROM: sha256 over every HIP source with its flags and every header (names +
+    contents), first 16 hex digits.  `nic_build_id()` of a library built by `build()` returns this string; `_lib.load_library`
+    compares the two, so a stale libnic_hip.so next to newer sources (a checkout, an edited header) is an error at load time
+    instead of a silently old kernel.  Content-based: touching a file without changing it changes nothing."""
+    parts = []
+    for src, extra in SOURCES:
+        parts += [src, " ".join(BASE_FLAGS + extra), _read(os.path.join(csrc, src))]
+    for h in HEADERS:
+        parts += [os.path.basename(h), _read(os.path.join(csrc, h))]
+    return _sha(parts)[:16]
+
+
+def _object_key(csrc, src, extra, build_id):
+    """what an object file depends on: its source, every header, its flags (the ABI unit also carries the build id)"""
+    parts = [src, " ".join(BASE_FLAGS + extra), _read(os.path.join(csrc, src))]
+    for h in HEADERS:
+        parts += [os.path.basename(h), _read(os.path.join(csrc, h))]
+    if src == "nic_abi.hip":
+        parts.append(build_id)
+    return _sha(parts)
+
+
+def _key_of(obj):
+    try:
+        with open(obj + ".key") as f:
+            return f.read().strip()
+    except OSError:
+        return None
 
 
 def build(force=False, verbose=True):
+    """Compiles what changed (by CONTENT: every object remembers the hash of its source + headers + flags in `<obj>.key`) and
+    links libnic_hip.so with the build id of the sources inside.  Returns the library path; `build.last_action` says whether
+    anything was compiled ("rebuilt <id>") or the library on disk already matched the sources ("reused <id>")."""
     hipcc = _hipcc()
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objs = []
+    bid = source_id()
+    objs, compiled = [], []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o] + extra
+        key = _object_key(CSRC, src, extra, bid)
+        if force or not os.path.isfile(o) or _key_of(o) != key:
+            cmd = [hipcc] + BASE_FLAGS + ["-c", s, "-o", o] + extra
+            if src == "nic_abi.hip":
+                cmd.append(f'-DNIC_BUILD_ID="{bid}"')
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+            with open(o + ".key", "w") as f:
+                f.write(key)
+            compiled.append(src)
         objs.append(o)
-    if force or _stale(OUT, objs):
+    if force or compiled or not os.path.isfile(OUT) or _key_of(OUT) != bid:
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(OUT + ".key", "w") as f:
+            f.write(bid)
         import ctypes
         from ._lib import _init_torch_device_first
         _init_torch_device_first()   # (on a GPU box: torch's HIP context first, see _lib.load_library)
         ctypes.CDLL(OUT)  # fail the build on unresolved symbols
+        build.last_action = f"rebuilt {bid}" + (f" ({len(compiled)} of {len(SOURCES)} units compiled)" if compiled else " (relinked)")
+    else:
+        build.last_action = f"reused {bid}"
     return OUT
+
+
+build.last_action = None
 
 
 if __name__ == "__main__":
