@@ -523,6 +523,8 @@ def main():
                          "for Poisson demand) instead of a training step; use with --periods 5000 for the reference's test horizon")
     ap.add_argument("--adam", choices=["fused", "foreach"], default="fused",
                     help="torch.optim.Adam implementation: torch's one-kernel form (default) or its for-each form (torch's own default)")
+    ap.add_argument("--tail", choices=("auto", "on", "off"), default="auto",
+                    help="fused per-period tail launches (csrc/period_tail.hip): the engine's choice, forced on, forced off")
     ap.add_argument("--no-horizon", action="store_true",
                     help="data_driven workloads: the per-period kernels instead of the whole-horizon kernels (A/B)")
     ap.add_argument("--horizon-max-scenarios", type=int, default=0,
@@ -570,6 +572,8 @@ def main():
         eng.small_lane_scenarios = args.lane_scenarios
         if args.no_horizon:
             eng.use_horizon = False
+        if args.tail != "auto" and hasattr(eng, "fuse_tail"):
+            eng.fuse_tail = args.tail == "on"
         if args.horizon_max_scenarios:
             eng.horizon_max_scenarios = args.horizon_max_scenarios
         parallel.broadcast_model(model, src=0)

@@ -26,6 +26,8 @@
 // MFMA-time floors per block are 4.5 us forward / 6.1 us backward (17 -> 32 and 51 -> 64 row padding included).
 // Built with -ffp-contract=off (head / env arithmetic rounds like the reference's separate aten ops); MFMA chains are fma by
 // construction.  Reference: neural_networks.py:393-426 (+ :140-166), environment.py:110-299, trainer.py:190-213.
+#include <type_traits>
+
 #include "env_step_body.h"
 #include "nic_common.h"
 #include "policy_heads_body.h"
@@ -40,6 +42,20 @@ constexpr int kThreads = 256;
 constexpr int kChunk = 8;     // warehouses whose shipment partials are exchanged per barrier round (as head_env.hip)
 constexpr int kMaxWh = 16;    // (S + 1) Wn <= 32 rows of logits
 constexpr int kStateRows = 52;  // F + 1 <= 52 (thin_in_fwd's 26 steps of two rows)
+constexpr int kTabRows = 68;    // static tables of a block: 2 S + S Wn + 3 Wn rows (<= 66 for S <= 16, (S + 1) Wn <= 32)
+
+// In-kernel timestamps (tuning build only: tools/tail_stamp_probe.py compiles its own copy of the library with -DNIC_TUNING_BUILD;
+// the product library contains none of this): the 100 MHz wall clock of workgroup 0's four wavefronts at up to 16 points.
+#ifdef NIC_TUNING_BUILD
+__device__ unsigned long long* g_tail_stamps = nullptr;
+#define TAIL_STAMP(point)                                                                         \
+    do {                                                                                          \
+        if (g_tail_stamps != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0)               \
+            g_tail_stamps[(threadIdx.x >> 6) * 16 + (point)] = wall_clock64();                    \
+    } while (0)
+#else
+#define TAIL_STAMP(point) do { } while (0)
+#endif
 
 __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ float elu_f(float x) {   // (csrc/thin_layer.hip::thin_elu = csrc/linear_mfma.hip::elu_f)
@@ -94,8 +110,11 @@ struct TailParams {
     int n_blocks;
 };
 
-// the block's NicEnvStepIO: state / demand / orders in LDS tiles, static tables moved to the block's first scenario
-__device__ __forceinline__ NicEnvStepIO block_io(const NicEnvStepIO& g, int c0, int nlive, float* st, float* dm, float* od) {
+// the block's NicEnvStepIO: state / demand / orders AND the static cost / lead-time tables in LDS tiles.  (The first version
+// left the static tables in HBM / L2, moved to the block's first scenario: every store of the env step then began with a round
+// trip to L2 - 2.3 us of a 19 us forward launch, 4.1 us of a 30 us backward launch, tools/tail_stamp_probe.py.)
+// Table tile rows: [underage S | holding S | lead times S x Wn | warehouse holding Wn | warehouse lead Wn | edge cost Wn].
+__device__ __forceinline__ NicEnvStepIO block_io(const NicEnvStepIO& g, int nlive, float* st, float* dm, float* od, float* tb) {
     NicEnvStepIO io = g;
     const int S = g.dims.n_stores, Wn = g.dims.n_warehouses;
     io.dims.n_scenarios = nlive;
@@ -106,14 +125,67 @@ __device__ __forceinline__ NicEnvStepIO block_io(const NicEnvStepIO& g, int c0, 
     io.demand = NicTable2{dm, LDT, 1};
     io.store_orders = NicTable3{od, (int64_t)Wn * LDT, LDT, 1};
     io.wh_orders = NicTable2{od + S * Wn * LDT, LDT, 1};
-    auto move2 = [&](NicTable2& t) { if (t.p) t.p += (int64_t)c0 * t.scn_stride; };
-    move2(io.underage);
-    move2(io.holding);
-    move2(io.wh_holding);
-    move2(io.wh_lead_times);
-    move2(io.wh_edge_costs);
-    io.lead_times.p += (int64_t)c0 * io.lead_times.scn_stride;
+    io.underage = NicTable2{tb, LDT, 1};
+    io.holding = NicTable2{tb + S * LDT, LDT, 1};
+    io.lead_times = NicTable3{tb + 2 * S * LDT, (int64_t)Wn * LDT, LDT, 1};
+    const int r3 = 2 * S + S * Wn;
+    io.wh_holding = NicTable2{tb + r3 * LDT, LDT, 1};
+    io.wh_lead_times = NicTable2{tb + (r3 + Wn) * LDT, LDT, 1};
+    if (g.wh_edge_costs.p) io.wh_edge_costs = NicTable2{tb + (r3 + 2 * Wn) * LDT, LDT, 1};
     return io;
+}
+
+// the block's static tables -> registers (thread t: column t % 32, rows t / 32 + 8 i of each table), branch-free: every load is
+// unconditional through a clamped row index, so a thread's fourteen loads issue back to back (the first version selected one
+// of six pointers per element and hipcc turned the selects into 54 branches with a wait behind each).  Dead columns shadow the
+// last live scenario.  Table tile rows: see block_io.
+struct TabRegs {
+    float u[2], h[2], l[4], wh[2], wl[2], we[2];   // <= 16 stores, <= 32 (store, warehouse) pairs, <= 16 warehouses
+};
+__device__ __forceinline__ void tables_fetch(const NicEnvStepIO& g, int c0, int nlive, TabRegs& v) {
+    const int S = g.dims.n_stores, Wn = g.dims.n_warehouses;
+    const int t = threadIdx.x, col = t & 31;
+    int row0 = t >> 5;
+    asm volatile("" : "+v"(row0));   // (opaque: the addresses below are recomputed per block, not hoisted out of the caller's loops)
+    const int64_t b = c0 + (col < nlive ? col : nlive - 1);
+    const NicTable2& we = g.wh_edge_costs.p ? g.wh_edge_costs : g.wh_holding;   // (no edge costs: any valid table, never stored)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rs = min(row0 + 8 * i, S - 1), rw = min(row0 + 8 * i, Wn - 1);
+        v.u[i] = g.underage.p[rs * g.underage.loc_stride + b * g.underage.scn_stride];
+        v.h[i] = g.holding.p[rs * g.holding.loc_stride + b * g.holding.scn_stride];
+        v.wh[i] = g.wh_holding.p[rw * g.wh_holding.loc_stride + b * g.wh_holding.scn_stride];
+        v.wl[i] = g.wh_lead_times.p[rw * g.wh_lead_times.loc_stride + b * g.wh_lead_times.scn_stride];
+        v.we[i] = we.p[rw * we.loc_stride + b * we.scn_stride];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = min(row0 + 8 * i, S * Wn - 1), ls = r / Wn, lw = r - ls * Wn;
+        v.l[i] = g.lead_times.p[ls * g.lead_times.loc_stride + lw * g.lead_times.sup_stride + b * g.lead_times.scn_stride];
+    }
+}
+__device__ __forceinline__ void tables_put(float* tb, const NicEnvStepIO& g, const TabRegs& v) {
+    const int S = g.dims.n_stores, Wn = g.dims.n_warehouses;
+    const int t = threadIdx.x, col = t & 31, row0 = t >> 5;
+    const int r2 = 2 * S, r3 = r2 + S * Wn;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = row0 + 8 * i;
+        if (r < S) {
+            tb[r * LDT + col] = v.u[i];
+            tb[(S + r) * LDT + col] = v.h[i];
+        }
+        if (r < Wn) {
+            tb[(r3 + r) * LDT + col] = v.wh[i];
+            tb[(r3 + Wn + r) * LDT + col] = v.wl[i];
+            tb[(r3 + 2 * Wn + r) * LDT + col] = v.we[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 8 * i;
+        if (r < S * Wn) tb[(r2 + r) * LDT + col] = v.l[i];
+    }
 }
 
 // [rows][32] tile <-> [rows][ldb] block, float4 per lane (thread t: row t / 8 (+ 32 per pass), columns 4 (t % 8) ..)
@@ -241,7 +313,9 @@ struct Lds {
 template <int MAXW, int MAXSQ, int KS>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))) void tail_fwd_kernel(TailParams p) {
     constexpr int SMAX = 4 * MAXSQ;
-    constexpr int o_sn = Lds::dm + SMAX * LDT;            // state(t+1) + ones row + zero rows  [52][LDT]
+    constexpr int o_tb = Lds::dm + SMAX * LDT;            // static tables                       [68][LDT]
+    constexpr int o_adj = o_tb + kTabRows * LDT;          // adjacency (int)                     [Wn][S] <= 32
+    constexpr int o_sn = o_adj + 32;                      // state(t+1) + ones row + zero rows  [52][LDT]
     constexpr int o_od = o_sn + kStateRows * LDT;         // orders                              [32][LDT]
     constexpr int o_ex = o_od + 32 * LDT;                 // exchange arrays
     constexpr int o_xm = o_ex, o_xd = o_xm + 4 * NB, o_xn = o_xd + 4 * NB, o_rq = o_xn + 4 * NB, o_cw = o_rq + 4 * NB,
@@ -252,6 +326,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
     float* zt = lds + Lds::zt;
     float* st = lds + Lds::st;
     float* dm = lds + Lds::dm;
+    float* tb = lds + o_tb;
+    int* adj_l = reinterpret_cast<int*>(lds + o_adj);
     float* sn = lds + o_sn;
     float* od = lds + o_od;
     float* red = lds + o_sn;
@@ -271,15 +347,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
     const int nlive = min(NB, B - c0);
     const int ncols = (B + 3) / 4 * 4;   // columns the GEMM stages write (as nic_linear_fwd)
 
+    TAIL_STAMP(0);
     // ---- state and demand of the period: requested now, parked in registers until the logits are done
     float4 pst[2], pdm[(SMAX + 31) / 32];
+    TabRegs ptb;
     tile_fetch<2>(p.io.store_inv, ldb, c0, p.F, pst);
     tile_fetch<(SMAX + 31) / 32>(p.io.demand.p, p.io.demand.loc_stride, c0, S, pdm);
+    tables_fetch(p.io, c0, nlive, ptb);
+    const int padj = p.adj[tid < S * Wn ? tid : 0];
 
     // ---- A: logits
     {
         f32x16 acc[1];
         ksplit_contract<1>(p.W, p.ldw, p.n_out, p.H, ldb, p.K, c0, acc);
+        TAIL_STAMP(1);
         float aux[16];
         if (wave == 0) {
 #pragma unroll
@@ -303,6 +384,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
         }
         tile_put<2>(st, p.F, pst);
         tile_put<(SMAX + 31) / 32>(dm, S, pdm);
+        tables_put(tb, p.io, ptb);
+        if (tid < 32) adj_l[tid] = padj;
     }
     // first fragments of phase C: in flight while the head and the env step run
     const __amdgpu_buffer_rsrc_t rW = make_rsrc(p.Wt, (int64_t)(p.F + 1) * p.ldwt);
@@ -316,7 +399,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
         for (int s = 0; s < KS; ++s) a[s] = ldf(rW, vw, 2 * s * lw4);
     };
     if (p.Y != nullptr && nb_lo < nb_hi) load_block(nb_lo);
+    TAIL_STAMP(2);
     __syncthreads();   // logits, state and demand tiles published; the reduction buffer is dead
+    TAIL_STAMP(3);
 
     // next-state tile: zeros (padding columns, rows past F + 1), ones in row F (the bias row of the first layer)
     for (int i = tid; i < kStateRows * LDT; i += kThreads) sn[i] = (i / LDT == p.F) ? 1.f : 0.f;
@@ -326,13 +411,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
     const int x = tid & (NB - 1), q = (tid >> 5) & 3;
     const bool live = active && x < nlive;
     const int bb = x < nlive ? x : nlive - 1;   // dead lanes shadow the last live scenario (loads only)
-    const NicEnvStepIO io = block_io(p.io, c0, nlive, st, dm, od);
+    const NicEnvStepIO io = block_io(p.io, nlive, st, dm, od, tb);
     float* od_wh = od + S * Wn * LDT;
     for (int w = 0; w < Wn; ++w) {
         if (w > 0) nic::lds_barrier();
         nic::HeadLane<MAXSQ> L;
         int nc;
-        const float mq = nic::head_quad_load<MAXSQ, false>(L, zt, nullptr, p.adj, S, Wn, LDT, bb, w, q, nc, nullptr);
+        const float mq = nic::head_quad_load<MAXSQ, false>(L, zt, nullptr, adj_l, S, Wn, LDT, bb, w, q, nc, nullptr);
         if (active) {
             xm[q][x] = mq;
             xn[q][x] = nc;
@@ -351,6 +436,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
         }
     }
     nic::lds_barrier();
+    TAIL_STAMP(4);
     float* sn_wh = sn + S * d.store_slots * LDT;
     {
         // this lane's stores s = q, q + 4, ... one at a time (env_fwd_store_t: the arithmetic of one store of env_fwd_stores, bit
@@ -361,6 +447,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
             for (int s_ = q; s_ < S; s_ += nic::kQuad) r += nic::env_fwd_store_t<MAXW>(ac, s_);
         if (active) rq[q][x] = r;
     }
+    TAIL_STAMP(5);
     for (int wc = 0; wc < Wn; wc += kChunk) {
         for (int i = 0; i < kChunk && wc + i < Wn; ++i) {
             const float v = live ? nic::env_ship_partial(io, wc + i, x, q) : 0.f;
@@ -380,9 +467,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
         for (int w = 0; w < Wn; ++w) r_wh += cw[w][x];
         p.reward[c0 + x] = total + r_wh;
     }
+    TAIL_STAMP(6);
     // orders and next state of the live scenarios -> HBM (the backward sweep and the next period's GEMMs read them)
     tile_store(od, const_cast<float*>(p.io.store_orders.p), ldb, c0, S * Wn + Wn, nlive);
     tile_store(sn, p.state_out, ldb, c0, p.F, nlive);
+    TAIL_STAMP(7);
     if (p.Y == nullptr || nb_lo >= nb_hi) return;
 
     // ---- C: first layer of period t+1 (thin_in_fwd_kernel<KS, false>: K + 1 rows, the bias inside the contraction)
@@ -394,21 +483,33 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
     const int vo = 4 * h * ld4 + li * 4;
     const bool col_live = c0 + li < ncols;
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first fragments (and this wavefront's tile stores)
-    for (int nb = nb_lo; nb < nb_hi; ++nb) {
-        f32x16 y;
+    // One wavefront per SIMD at the batches this kernel is for: the MFMA chain of block b + 1 (26 x 64 cycles on the matrix pipe) and
+    // the ELUs of block b (16 x ~15 VALU instructions) are written interleaved, one ELU behind every MFMA, so that the two pipes
+    // run side by side; thin_in_fwd_kernel gets the same overlap from four wavefronts per SIMD.  Same chains, same bits.
+    f32x16 y, yn;
+    auto chain = [&](int nb_reload, f32x16& acc, auto with_elu) {
+        const int vw = h * lw4 + (nb_reload * 32 + li) * 4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = 0.f;
-        const int nb_next = nb + 1 < nb_hi ? nb + 1 : nb;
-        const int vw = h * lw4 + (nb_next * 32 + li) * 4;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            y = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], xs[s], y, 0, 0, 0);
-            a[s] = ldf(rW, vw, 2 * s * lw4);
+        for (int s = 0; s < (KS > 16 ? KS : 16); ++s) {
+            if (s < KS) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], xs[s], acc, 0, 0, 0);
+                a[s] = ldf(rW, vw, 2 * s * lw4);
+            }
+            if (decltype(with_elu)::value && s < 16) y[s] = elu_f(y[s]);
         }
+    };
+    chain(nb_lo + 1 < nb_hi ? nb_lo + 1 : nb_lo, y, std::false_type{});
+    for (int nb = nb_lo; nb < nb_hi; ++nb) {
+        if (nb + 1 < nb_hi) {
+            chain(nb + 2 < nb_hi ? nb + 2 : nb + 1, yn, std::true_type{});
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            y[r] = elu_f(y[r]);
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < 16; ++r) {
+                y[r] = elu_f(y[r]);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         if (col_live) {
@@ -416,7 +517,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[r]), rY, vo, (nb * 32 + (r & 3) + 8 * (r >> 2)) * ld4, 0);
         }
+        y = yn;
     }
+    TAIL_STAMP(8);
 }
 
 // ================================================================================================================================
@@ -431,7 +534,7 @@ constexpr int kGroup = 4;      // blocks of a workgroup whose adjoints run befor
 // accumulators (64 registers per lane) alive only there, then one read-modify-write of the workgroup's slab slot.  (With one
 // loop over blocks the accumulators are alive across the env / head adjoints and the kernel needs ~340 registers.)
 template <int MAXW, int MAXSQ, int NS>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void tail_bwd_kernel(TailParams p) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void tail_bwd_kernel(TailParams p) {
     constexpr int SMAX = 4 * MAXSQ;
     constexpr int o_dz = 0;                               // logits gradients of the group  [kGroup][32][LDT]
     constexpr int o_w = o_dz + kGroup * 32 * LDT;         // ---- working tiles of stages A' / B' (dead in stage C') ----
@@ -444,7 +547,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int o_go = o_gi + kStateRows * LDT;         // order gradients           [32][LDT]
     constexpr int o_ex = o_go + 32 * LDT;
     constexpr int o_xm = o_ex, o_xd = o_xm + 4 * NB, o_xt = o_xd + 4 * NB, o_xs = o_xt + 4 * NB, o_gwa = o_xs + 4 * NB,
-                  o_part = o_gwa + kMaxWh * NB, o_wend = o_part + kChunk * 4 * NB;
+                  o_part = o_gwa + kMaxWh * NB, o_tb = o_part + kChunk * 4 * NB, o_adj = o_tb + kTabRows * LDT, o_wend = o_adj + 32;
     constexpr int RED = 3 * 2 * 16 * 64;                  // K-split reduction buffer (two row tiles): aliases [o_gi, ...)
     constexpr int XT = 4 * 32 * kXLD;                     // four wave-private H chunks (stage C'): alias the working tiles
     constexpr int o_end0 = (o_gi + RED > o_wend) ? o_gi + RED : o_wend;
@@ -457,6 +560,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     float* gs = lds + o_gs;
     float* gi = lds + o_gi;
     float* go = lds + o_go;
+    float* tb = lds + o_tb;
+    int* adj_l = reinterpret_cast<int*>(lds + o_adj);
     float* red = lds + o_gi;
     float (*xm)[NB] = reinterpret_cast<float (*)[NB]>(lds + o_xm);
     float (*xd)[NB] = reinterpret_cast<float (*)[NB]>(lds + o_xd);
@@ -497,9 +602,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             const bool live = active && x < nlive;
             const int bb = x < nlive ? x : nlive - 1;
             if (j > 0) __syncthreads();   // the previous block's working tiles are dead
+            if (j == 0 && first_group) TAIL_STAMP(0);
 
             // ---- tiles of period t: state, demand, orders, logits; the env part of the next state's gradient
             float4 pst[2], pdm[(SMAX + 31) / 32], pod[1], pzt[1], pgs[2];
+            TabRegs ptb;
+            tables_fetch(p.io, c0, nlive, ptb);
+            const int padj = p.adj[tid < S * Wn ? tid : 0];
             tile_fetch<2>(p.io.store_inv, ldb, c0, p.F, pst);
             tile_fetch<(SMAX + 31) / 32>(p.io.demand.p, p.io.demand.loc_stride, c0, S, pdm);
             tile_fetch<1>(p.io.store_orders.p, ldb, c0, n_ord, pod);
@@ -510,7 +619,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             // ---- A': G = Wt_in[:F] dZ1(t+1), two 32-row tiles, + the env part (gemm_wx_stream_kernel<1, 4, EPI_DGRAD>, accumulate)
             if (p.dZ1 != nullptr) {
                 f32x16 acc[2];
-                ksplit_contract<2, 2>(p.Wt, p.ldwt, p.F, p.dZ1, ldb, p.N1, c0, acc);
+                ksplit_contract<2, 4>(p.Wt, p.ldwt, p.F, p.dZ1, ldb, p.N1, c0, acc);
+                if (j == 0 && first_group) TAIL_STAMP(1);
                 ksplit_publish<2>(red, acc);
                 __syncthreads();
                 if (wave == 0) {
@@ -539,11 +649,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             tile_put<(SMAX + 31) / 32>(dm, S, pdm);
             tile_put<1>(od, n_ord, pod);
             tile_put<1>(zt, p.n_out, pzt);
+            tables_put(tb, p.io, ptb);
+            if (tid < 32) adj_l[tid] = padj;
             for (int i = tid; i < 32 * LDT; i += kThreads) dz[i] = 0.f;
+            if (j == 0 && first_group) TAIL_STAMP(2);
             __syncthreads();
+            if (j == 0 && first_group) TAIL_STAMP(3);
 
             // ---- B': env adjoint + head adjoint (head_env_bwd_kernel's bodies on LDS tiles)
-            const NicEnvStepIO io = block_io(p.io, c0, nlive, st, dm, od);
+            const NicEnvStepIO io = block_io(p.io, nlive, st, dm, od, tb);
             const float gr = live ? p.g_reward.p[(int64_t)(c0 + x) * p.g_reward.scn_stride] : 0.f;
             float* gs_wh = gs + S * d.store_slots * LDT;
             float* gi_wh = gi + S * d.store_slots * LDT;
@@ -566,11 +680,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int s_ = q; s_ < S; s_ += nic::kQuad) nic::env_bwd_store_t<MAXW>(ac, gr, [&](int w) { return gwa[w][x]; }, s_);
             }
             nic::lds_barrier();
+            if (j == 0 && first_group) TAIL_STAMP(4);
             for (int w = 0; w < Wn; ++w) {
                 if (w > 0) nic::lds_barrier();
                 nic::HeadLane<MAXSQ> L;
                 int nc;
-                const float mq = nic::head_quad_load<MAXSQ, true>(L, zt, go, p.adj, S, Wn, LDT, bb, w, q, nc, nullptr);
+                const float mq = nic::head_quad_load<MAXSQ, true>(L, zt, go, adj_l, S, Wn, LDT, bb, w, q, nc, nullptr);
                 if (active) xm[q][x] = mq;
                 const float stock = io.wh_inv[w * Ww * LDT + bb];
                 nic::lds_barrier();
@@ -596,9 +711,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
             nic::lds_barrier();
+            if (j == 0 && first_group) TAIL_STAMP(5);
             tile_store(gi, p.g_out, ldb, c0, p.F, nlive);
+            if (j == 0 && first_group) TAIL_STAMP(6);
         }
         __syncthreads();   // every block's logits gradient is in LDS; the working tiles are dead (the H chunks take their place)
+        if (first_group) TAIL_STAMP(7);
 
         // ---- C': logits layer backward of the group, this wavefront's row chunks of H (thin_bwd_kernel's arithmetic on
         // 32-scenario blocks); wave-private from here to the slab update: no workgroup barrier
@@ -622,7 +740,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int u = 0; u < 4; ++u)
                 xv[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rH, vx, (ch * 32 + 8 * u) * ldbo * 4, 0));
         };
-        if (wave < n_chunks_all) load_x(g0 * NB, wave);
+        // W_out^T fragments of a chunk: A[i = k][kk = n], n = 2 s + h (L2-resident), fetched one chunk ahead like the H chunk
+        float aW[NS];
+        auto load_w = [&](int ch) {
+            int ldwo = (int)p.ldw;
+            asm volatile("" : "+s"(ldwo));
+            const int vw_ = (h * ldwo + li) * 4;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) aW[s] = ldf(rWo, vw_, (2 * s * ldwo + ch * 32) * 4);
+        };
+        if (wave < n_chunks_all) {
+            load_x(g0 * NB, wave);
+            load_w(wave);
+        }
 #pragma clang loop unroll(disable)
         for (int j = 0; j < n_in_group; ++j) {
             const int blk = g0 + j * stride;
@@ -657,13 +787,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 // next chunk (of this block, or the first one of the group's next block): in flight under this chunk's MFMAs
                 if (ch + 4 < n_chunks_all) load_x(c0, ch + 4);
                 else if (j + 1 < n_in_group) load_x((blk + stride) * NB, wave);
-                // W_out^T fragments of the chunk: A[i = k][kk = n], n = 2 s + h (L2-resident; consumed behind the 16 MFMAs below)
-                float aW[NS];
-                int ldwo = (int)p.ldw;
-                asm volatile("" : "+s"(ldwo));
-                const int vw_ = (h * ldwo + li) * 4;
+                float aWc[NS];   // this chunk's fragments (the next chunk's are requested below)
 #pragma unroll
-                for (int s = 0; s < NS; ++s) aW[s] = ldf(rWo, vw_, (2 * s * ldwo + ch * 32) * 4);
+                for (int s = 0; s < NS; ++s) aWc[s] = aW[s];
                 // weight gradient: D[n][k] += sum_b dZ[n][b] H[k][b], 16 MFMA steps over the 32 scenarios
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
@@ -679,7 +805,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aW[s], dz[(2 * s + h) * LDT + li], acc, 0, 0, 0);
+                for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aWc[s], dz[(2 * s + h) * LDT + li], acc, 0, 0, 0);
+                if (ch + 4 < n_chunks_all) load_w(ch + 4);
+                else if (j + 1 < n_in_group) load_w(wave);
                 if (li < nlive) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -691,6 +819,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
 
+        if (first_group) TAIL_STAMP(8);
         // ---- slab slot of this workgroup: D layout lane (j = k, h), register r <-> output row n = crow(r, h).  Buffer addressing
         // (rows >= n_out lie beyond the descriptor: loads return 0, stores are dropped) with the row stride laundered like ldbo.
         const bool overwrite = p.first && first_group;
@@ -698,21 +827,34 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         asm volatile("" : "+s"(ldso));
         const __amdgpu_buffer_rsrc_t rS = make_rsrc(p.slab + (int64_t)blockIdx.x * p.n_out * p.lds_, (int64_t)p.n_out * p.lds_);
         const int vs_ = (4 * h * ldso + li) * 4;
+        // (all loads of the slot first, then the sums and stores: one L2 round trip per workgroup instead of one per chunk; columns
+        // of a ragged last chunk - the slab row ends at K + 1 - are sent beyond the descriptor)
+        auto vs_k = [&](int ch) { return ch * 32 + li < p.K ? vs_ : 0x7fffff00; };
+        f32x16 old[KC];
+        if (!overwrite) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int ch = wave + 4 * c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ku = (r & 3) + 8 * (r >> 2);
+                    old[c][r] = ch < n_chunks_all ? ldf(rS, vs_k(ch), (ku * ldso + ch * 32) * 4) : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[c][r] = 0.f;
+        }
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             const int ch = wave + 4 * c;
             if (ch >= n_chunks_all) break;
-            if (ch * 32 + li >= p.K) continue;   // (columns of a ragged last chunk: the slab row ends at K + 1)
-            float old[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ku = (r & 3) + 8 * (r >> 2);
-                old[r] = overwrite ? 0.f : ldf(rS, vs_, (ku * ldso + ch * 32) * 4);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ku = (r & 3) + 8 * (r >> 2);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old[r] + wacc[c][r]), rS, vs_, (ku * ldso + ch * 32) * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old[c][r] + wacc[c][r]), rS, vs_k(ch), (ku * ldso + ch * 32) * 4, 0);
             }
         }
         if (wave == 0) {
@@ -722,6 +864,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 *cell = (overwrite ? 0.f : *cell) + total;
             }
         }
+        if (first_group) TAIL_STAMP(9);
     }
 }
 
@@ -783,6 +926,13 @@ TailParams base_params(const NicPeriodTail* t) {
 
 }  // namespace
 
+#ifdef NIC_TUNING_BUILD
+extern "C" int nic_tuning_set_tail_stamps(void* buf) {   // buf: device memory, [4][16] u64 (or null)
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tail_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" {
 
 int nic_period_tail_ok(const NicEnvDims* dims, int32_t n_out, int32_t K, int32_t N1) {
@@ -791,7 +941,7 @@ int nic_period_tail_ok(const NicEnvDims* dims, int32_t n_out, int32_t K, int32_t
 
 int nic_period_tail_bwd_slots(int32_t n_scenarios) {
     const int blocks = nic::ceil_div(n_scenarios > 0 ? n_scenarios : 1, NB);
-    const int cap = 2 * nic::cu_count();
+    const int cap = nic::cu_count();   // (the backward kernel holds ~370 registers: one workgroup per CU; more blocks: groups)
     return blocks < cap ? blocks : cap;
 }
 

@@ -139,7 +139,10 @@ class FusedRollout:
         # ... and, where the shapes allow (<= 16 stores, <= 32 logits, <= 51 state rows: BASELINE cfg3 and the shipped one-warehouse
         # YAML), the whole per-period TAIL in one launch per direction (csrc/period_tail.hip): logits layer + head + env step + the
         # next period's first layer forward; first layer's input gradient + env / head adjoints + logits layer backward
-        self.fuse_tail = True
+        # "auto": up to `tail_max_scenarios` scenarios, where the per-period launches are latency-bound (measured crossover, see
+        # DESIGN section 4); larger batches keep the separate, bandwidth-efficient launches
+        self.fuse_tail = "auto"
+        self.tail_max_scenarios = 16384
         # data_driven on small batches (what the reference trains it on: 72 products): all periods in ONE forward and ONE backward
         # launch (csrc/horizon_rollout.hip).  Measured against the per-period kernels on the real-data shape (tools/
         # horizon_crossover.py, profiles/r04_horizon_crossover.json): 2.3 vs 8.7 ms (replayed) at 72 scenarios, 3.4 vs 10.2 at 4,096,
@@ -204,7 +207,8 @@ class FusedRollout:
     def _setup(self, prob, T, train, extra_rows=0):
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin,
                self.eval_history, self.small_wgrad_in_kernel, extra_rows, self.small_lane_scenarios, self.use_horizon,
-               self.horizon_max_scenarios, getattr(self, "_shift_hint", 0), self.fuse_tail, self.fuse_head_env)
+               self.horizon_max_scenarios, getattr(self, "_shift_hint", 0), self.fuse_tail, self.tail_max_scenarios,
+               self.fuse_head_env)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
@@ -314,7 +318,8 @@ class FusedRollout:
                 self.first_wh_row = len(live) - prob.Wn
         self.gd = gd   # layer widths of the GEMMs (= dims unless the logits layer is compacted)
         # the fused per-period tail (csrc/period_tail.hip): the shapes decide here (slab slots below), discrete allocation per run
-        self._tail_shapes = bool(self.fuse_tail and self.fuse_head_env and self.head == "warehouse" and self.live_rows is None
+        want_tail = self.fuse_tail is True or (self.fuse_tail == "auto" and prob.B <= self.tail_max_scenarios)
+        self._tail_shapes = bool(want_tail and self.fuse_head_env and self.head == "warehouse" and self.live_rows is None
                                  and extra_rows == 0 and L >= 2 and self.use_thin and all(m.bias is not None for m in lins)
                                  and ops.period_tail_ok(prob, dims[-1], dims[-2], dims[1]))
         n_ord = prob.S * prob.nsup + prob.Wn + prob.E

@@ -28,8 +28,16 @@ def _tuning_library():
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "libnic_hip_tuning.so")
     srcs = [os.path.join(nb.CSRC, s) for s, _ in nb.SOURCES]
+    key = nb.source_id() + "-tuning"   # (a copy built in the container travels to the GPU box: reused while the sources match)
+    try:
+        if os.path.isfile(out) and open(out + ".key").read().strip() == key:
+            return out
+    except OSError:
+        pass
     subprocess.check_call([nb._hipcc(), f"--offload-arch={nb.ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNIC_TUNING_BUILD",
                            "-ffp-contract=off", "-o", out] + srcs)
+    with open(out + ".key", "w") as f:
+        f.write(key)
     return out
 
 
