@@ -523,6 +523,9 @@ def main():
                          "for Poisson demand) instead of a training step; use with --periods 5000 for the reference's test horizon")
     ap.add_argument("--adam", choices=["fused", "foreach"], default="fused",
                     help="torch.optim.Adam implementation: torch's one-kernel form (default) or its for-each form (torch's own default)")
+    ap.add_argument("--no-dist-init", action="store_true",
+                    help="N = 1: do not create the one-rank RCCL process group (default: created, so that the gradient all-reduce of the "
+                         "sharded path really runs and the line's `collective` object describes it)")
     ap.add_argument("--tail", choices=("auto", "on", "off"), default="auto",
                     help="fused per-period tail launches (csrc/period_tail.hip): the engine's choice, forced on, forced off")
     ap.add_argument("--no-horizon", action="store_true",
@@ -539,7 +542,22 @@ def main():
         return bench_epoch(args)
     from neural_inventory_control_amd import _lib, parallel
     from neural_inventory_control_amd.rollout import KernelTimer
-    rank, world, device = parallel.init_from_env()
+    dist_error = None
+    if args.gpus == 1 and "RANK" not in os.environ and not args.no_dist_init:
+        os.environ.setdefault("NIC_DIST_FORCE_INIT", "1")   # one rank, real backend: the collective path is exercised and described
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+    try:
+        rank, world, device = parallel.init_from_env()
+    except Exception as e:   # (a one-rank group that cannot be created must not cost the single-GPU number)
+        if args.gpus > 1:
+            raise
+        dist_error = f"{type(e).__name__}: {e}"[:300]
+        os.environ["NIC_DIST_FORCE_INIT"] = "0"
+        rank, world, device = parallel.init_from_env()
     _lib.require_device()
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
@@ -588,6 +606,11 @@ def main():
         args.no_kernel_timing = True
     sharded = parallel.active()  # a process group exists (N ranks, or one rank under NIC_DIST_FORCE_INIT=1)
     reducer = parallel.GradientAllReducer.get(model) if sharded else None
+    # every rank's device, gathered once: an N-rank job must have run on N distinct devices
+    idents = parallel.device_identities(device)
+    if len({(h, d) for _, h, d in idents}) != world:
+        print(f"bench.py: {world} ranks but only {len({(h, d) for _, h, d in idents})} distinct devices: {idents}", file=sys.stderr)
+        sys.exit(2)
     global_b = n * world
     grad_scale = 1.0 / (global_b * T * S)
 
@@ -662,6 +685,8 @@ def main():
         whole = closed_form or (not gnn and (eng.small is not None or getattr(eng, "horizon", None) is not None))
         stride = args.timing_stride or (1 if whole else (10 if gnn else 40))
         timer = eng.timer = KernelTimer(stride=stride)
+    if reducer is not None:
+        reducer.timing, reducer._events, reducer.calls = True, [], 0
     if sharded:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -678,6 +703,16 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax)
     loss = float(last) / (global_b * T * S)
+    collective = {"backend": torch.distributed.get_backend() if sharded else None, "world_size": world,
+                  "ranks_seen": len(idents), "distinct_devices": len({(h, d) for _, h, d in idents}),
+                  "devices": [d for _, _, d in idents], "op": "all_reduce(SUM) of one flat fp32 buffer [gradients..., total, reported]"}
+    if reducer is not None:
+        reducer.timing = False
+        st_ = reducer.collective_stats()
+        collective.update(allreduce_bytes=st_["allreduce_bytes"], allreduces_per_step=st_["allreduce_calls"] / max(args.steps, 1),
+                          allreduce_ms=None if st_["allreduce_ms"] is None else round(st_["allreduce_ms"], 4))
+    if dist_error:
+        collective["init_error"] = dist_error
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -686,7 +721,7 @@ def main():
             "value": global_b * S * T * args.steps / dt, "unit": "scenario-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic", "collective": collective,
             "config": {"workload": desc + ("; evaluation pass = forward rollout only" + (", discrete allocation" if discrete else "")
                                            if args.eval else
                                            "; training step = rollout fwd + bwd + Adam" + (" + RCCL grad all-reduce" if sharded else "")),

@@ -57,6 +57,24 @@ def init_from_env(backend=None):
     return rank(), world_size(), (torch.device("cuda", local) if use_cuda else torch.device("cpu"))
 
 
+def device_identities(device):
+    """[(rank, host, device uuid or PCI bus id)] of every rank, gathered over the process group: the evidence that an N-rank job
+    ran on N DISTINCT devices (a launcher that maps two ranks to one GPU would otherwise still print a plausible number)."""
+    import socket
+    ident = "cpu"
+    if device.type == "cuda":
+        props = torch.cuda.get_device_properties(device)
+        ident = str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or device.index)
+        if ident in ("None", ""):
+            ident = f"cuda:{device.index}"
+    mine = (rank(), socket.gethostname(), ident)
+    if not active():
+        return [mine]
+    out = [None] * world_size()
+    dist.all_gather_object(out, mine)
+    return out
+
+
 def shard_range(n_total, rank_, world):
     """Contiguous block [lo, hi) of scenarios owned by `rank_` (SURVEY §8e 'Partitioning')."""
     per = (n_total + world - 1) // world
@@ -143,6 +161,15 @@ class GradientAllReducer:
     def __init__(self, model):
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.flat, self.views, self.n_scalars = None, None, 0
+        self.timing = False      # bench.py: bracket the collective with device events (on the stream it is enqueued behind)
+        self._events, self.calls = [], 0
+
+    def collective_stats(self):
+        """What the per-step collective was, for the bench line: bytes of the flat buffer, how many all-reduces ran and their mean
+        duration (events recorded on torch's current stream right around the call; call after a synchronize)."""
+        ms = [a.elapsed_time(b) for a, b in self._events]
+        return {"allreduce_bytes": int(self.flat.numel() * 4) if self.flat is not None else 0, "allreduce_calls": self.calls,
+                "allreduce_ms": (sum(ms) / len(ms)) if ms else None}
 
     def _layout(self, n_scalars, device):
         n = sum(p.numel() for p in self.params)
@@ -170,7 +197,15 @@ class GradientAllReducer:
         if scalars:
             self.tail.copy_(torch.stack([s.detach().float().reshape(()) for s in scalars]))
         if active():
+            ev = None
+            if self.timing and self.flat.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             _collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM), self.flat)
+            self.calls += 1
+            if ev is not None:
+                ev[1].record()
+                self._events.append(ev)
         back_dst, back_src = [], []
         for p, v in zip(params, self.views):
             if p.grad is None:

@@ -233,6 +233,16 @@ class FusedRollout:
         self.dims = dims
         L = len(lins)
         z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+
+        def zpad(*shape):
+            """A history buffer every live column of which is written before it is read (hidden activations, pre-activation
+            gradients): uninitialised storage with only the padding columns [B, ldb) zeroed.  (As torch.zeros the histories of
+            BASELINE cfg3 were 80 GB of fill at set-up - 53 launches of 2^31 bytes that a profile of a few steps shows as its
+            largest `FillFunctor` rows although no step issues them.)"""
+            t_ = torch.empty(*shape, device=dev)
+            if shape[-1] > prob.B:
+                t_[..., prob.B:] = 0.0
+            return t_
         self.small = None
         if self.use_small and all(m.bias is not None for m in lins) and sr.SmallRolloutPlan.supports(prob, self.head, dims):
             # ---- whole-horizon route: one forward kernel, one backward kernel, one wgrad GEMM per layer ------------------
@@ -338,7 +348,7 @@ class FusedRollout:
         self.rewards = z(T, ld)
         self.logits = z(T if self._hist else 1, dims[-1], ld)
         keep = T if train else 1
-        self.hidden = [z(keep, dims[i + 1], ld) for i in range(L - 1)]
+        self.hidden = [zpad(keep, dims[i + 1], ld) for i in range(L - 1)]
         # engine copies of the weights: rows padded to a multiple of 32 floats so every A-tile load is a float4
         self.Wp = [z(gd[i + 1], _pad32(gd[i])) for i in range(L)]
         self.Wt = [z(gd[i] + (1 if i == 0 else 0), _pad32(gd[i + 1])) for i in range(L)]   # (layer 0: + the bias row, see above)
@@ -359,7 +369,7 @@ class FusedRollout:
                           if dev.type == "cuda" else 0)
             # not enough HBM left for the gradient history -> accumulate weight gradients period by period
             batch = self.batch_wgrad and hist_bytes <= 0.6 * free_bytes
-            self.dZhist = [z(T, dims[i + 1], ld) for i in range(L - 1)] if batch else None
+            self.dZhist = [zpad(T, dims[i + 1], ld) for i in range(L - 1)] if batch else None
             # ... and the logits gradient too, unless the logits layer takes the fused thin-layer backward (per period)
             thin_last = L > 1 and self.use_thin and ops.linear_bwd_thin_ok(gd[L], gd[L - 1])
             self.dZlast_hist = z(T, gd[-1], ld) if batch and not thin_last else None

@@ -81,10 +81,58 @@ class Trainer:
     def reset(self):
         self.all_train_losses, self.all_dev_losses, self.all_test_losses = [], [], []
 
+    _hazard_guard = {}   # device index -> does this torch build REPORT the stream hazard `_graphed_generic_step` must see?
+
+    @staticmethod
+    def _autograd_stream_warnings(caught):
+        """Warnings of a side-stream autograd run that mean "a gradient accumulator of this parameter is bound to another
+        stream": recognised by WHERE they come from (torch's autograd package) or by the node they name - not by one sentence."""
+        def hit(w):
+            fn, msg = (getattr(w, "filename", "") or "").replace("\\", "/"), str(w.message)
+            return "/torch/autograd/" in fn or "AccumulateGrad" in msg
+        return [w for w in caught if hit(w)]
+
+    @classmethod
+    def _stream_hazard_is_reported(cls, device):
+        """Self-test of the guard, once per device: build the very hazard on a 4-element parameter (an autograd graph alive on the
+        default stream, a gradient taken on a side stream, nothing captured) and look for the report.  A torch build that stopped
+        reporting it (reworded into another channel, or dropped) would leave `_graphed_generic_step` blind - and an invalidated
+        capture ends the PROCESS in hipStreamEndCapture - so "auto" then never captures (explicit `use_step_graph = True` still
+        does, at the caller's risk)."""
+        import warnings
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            return False
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in cls._hazard_guard:
+            ok = False
+            try:
+                p_ = torch.nn.Parameter(torch.ones(4, device=dev))
+                keep = (p_ * 2.0).sum()   # noqa: F841  (holds the graph, and with it the accumulator bound to the default stream)
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                was = torch.is_warn_always_enabled()
+                torch.set_warn_always(True)
+                try:
+                    with warnings.catch_warnings(record=True) as caught:
+                        warnings.simplefilter("always")
+                        with torch.cuda.stream(side):
+                            torch.autograd.grad((p_ * 3.0).sum(), [p_])
+                finally:
+                    torch.set_warn_always(was)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                ok = bool(cls._autograd_stream_warnings(caught))
+            except Exception:
+                ok = False
+            cls._hazard_guard[key] = ok
+        return cls._hazard_guard[key]
+
     def _step_graph_on(self, model, observation_params):
-        """`use_step_graph` resolved for a policy: "auto" = the closed-form policies (whole-horizon kernel inside the captured step)."""
+        """`use_step_graph` resolved for a policy: "auto" = the closed-form policies (whole-horizon kernel inside the captured step)
+        and the trainable quantile policies - provided this torch build reports the one condition under which a capture must
+        be refused (`_stream_hazard_is_reported`)."""
         if self.use_step_graph == "auto":
-            if not self.use_fused_rollout:
+            if not self.use_fused_rollout or not self._stream_hazard_is_reported(self.device):
                 return False
             if ClosedFormRollout.supports(model) and self._plain_observation(observation_params):
                 return True
@@ -358,7 +406,7 @@ class Trainer:
             finally:
                 torch.set_warn_always(warn_always)
             torch.cuda.current_stream().wait_stream(stream)
-            pinned = [w for w in caught if "AccumulateGrad node's stream" in str(w.message)]
+            pinned = self._autograd_stream_warnings(caught)
             for w in caught:
                 if w not in pinned:
                     warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)

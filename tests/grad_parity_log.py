@@ -3,6 +3,7 @@ import json
 import os
 
 RECORDS = {}
+REFEREE = {}   # tests whose bar is an fp64 referee instead of the plain 1e-5: per-tensor figures, kept as evidence
 
 
 def note(worst, tol):
@@ -11,14 +12,25 @@ def note(worst, tol):
     rec["worst_rel_l2"] = max(rec["worst_rel_l2"], float(worst))
 
 
+def note_referee(tensor, e_hip, e_ref, e_hip_vs_fp32, bar):
+    """One parameter tensor of a referee test: |HIP - fp64|, |reference fp32 - fp64|, |HIP - reference fp32| (relative L2) and the
+    bar the first one was held to."""
+    test_id = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    REFEREE.setdefault(test_id, []).append({"tensor": tensor, "hip_vs_fp64": float(e_hip), "reference_fp32_vs_fp64": float(e_ref),
+                                            "hip_vs_reference_fp32": float(e_hip_vs_fp32), "bar": float(bar)})
+
+
 def dump(path):
-    if not RECORDS:
+    if not RECORDS and not REFEREE:
         return
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         json.dump({"note": "worst relative L2 error of d(mean_loss)/d(theta) per parameter tensor against the reference's golden "
                            "gradients (or the oracle's), per GPU test; bar = north_star's 1e-5",
-                   "worst_overall": max(v["worst_rel_l2"] for v in RECORDS.values()),
-                   "tests": dict(sorted(RECORDS.items()))}, open(path, "w"), indent=1)
+                   "worst_overall": max([v["worst_rel_l2"] for v in RECORDS.values()] or [0.0]),
+                   "tests": dict(sorted(RECORDS.items())),
+                   "referee_note": "tests at benchmark width and horizon (2 x 10^5 fp32 terms per weight, summed in different orders on "
+                                   "the two sides): bar per tensor = max(2 x |reference fp32 - fp64|, 1e-5) on |HIP - fp64|",
+                   "referee_tests": dict(sorted(REFEREE.items()))}, open(path, "w"), indent=1)
     except OSError:
         pass

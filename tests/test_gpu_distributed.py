@@ -227,3 +227,43 @@ def test_library_mapped_before_any_torch_device_use_still_launches():
             "torch.cuda.synchronize(); assert float(y.sum()) == 128.0; print('LAUNCH_OK')\n") % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "LAUNCH_OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_two_ranks_under_real_rccl_describes_its_collective():
+    """`bench.py --gpus 2 --workload cfg4` under the real `nccl` (= RCCL) backend: two ranks on two distinct devices, one flat
+    gradient all-reduce per step, described in the line's `collective` object.  Needs two GPUs: skipped on a one-GPU box."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cfg4", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = line["collective"]
+    assert line["n_gpus"] == 2 and c["backend"] == "nccl" and c["world_size"] == 2 and c["ranks_seen"] == 2
+    assert c["distinct_devices"] == 2 and c["allreduces_per_step"] == 1 and c["allreduce_bytes"] > 0 and c["allreduce_ms"] > 0
+    assert line["config"]["global_scenarios"] == 2 * line["config"]["scenarios_per_gpu"]
+
+
+def test_bench_single_rank_line_carries_the_collective_of_a_one_rank_rccl_group():
+    """The default N = 1 run creates a one-rank RCCL group (NIC_DIST_FORCE_INIT), so the sharded path's all-reduce really runs
+    and the line says which backend, how many bytes and how long."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "cfg4", "--scenarios", "2048", "--periods", "10",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = line["collective"]
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["distinct_devices"] == 1, c
+    assert c["allreduces_per_step"] == 1 and c["allreduce_bytes"] == 4 * (1700 + 2) and c["allreduce_ms"] is not None, c

@@ -1171,6 +1171,7 @@ def test_gradient_parity_at_benchmark_width_and_horizon():
     for i, (p, ref32, ref64) in enumerate(zip(model.parameters(), grads, g64)):
         e_hip, e_ref = _rel(p.grad, ref64), _rel(ref32, ref64)
         print(f"tensor {i}: |HIP - fp64| = {e_hip:.2e}   |reference fp32 - fp64| = {e_ref:.2e}   |HIP - fp32| = {_rel(p.grad, ref32):.2e}")
+        grad_parity_log.note_referee(i, e_hip, e_ref, _rel(p.grad, ref32), max(2.0 * e_ref, GRAD_TOL))
         assert e_hip <= max(2.0 * e_ref, GRAD_TOL), (i, e_hip, e_ref)  # (tensors already inside the 2e-5 bar need no referee)
 
 
@@ -1997,3 +1998,12 @@ def test_fused_tail_evaluation_without_history_and_discrete_allocation_falls_bac
     with torch.no_grad():
         eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"], discrete_allocation=True)
     assert not eng._use_tail()
+
+
+def test_step_graph_guard_sees_the_stream_hazard_on_this_torch_build():
+    """`use_step_graph = "auto"` only captures training steps when this torch build REPORTS the condition under which a capture
+    must be refused (an autograd graph alive on another stream): the guard's self-test builds that condition on a dummy
+    parameter and must see the report - recognised by its origin (torch/autograd) or the node it names, not by one sentence."""
+    Trainer._hazard_guard.clear()
+    assert Trainer._stream_hazard_is_reported(DEV) is True
+    assert Trainer._stream_hazard_is_reported("cpu") is False
