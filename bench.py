@@ -160,6 +160,20 @@ def _certified_ratio():
     return None
 
 
+def _full_batch_record(workload):
+    """The committed one-off measurement of the CPU baseline at the GPU run's full batch (tools/cpu_baseline_full.py on the GPU
+    box's host cores; profiles/*cpu_baseline_full.json), quoted beside the bounded sample a default run times."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cpu_baseline_full.json")), reverse=True):
+        try:
+            rec = json.load(open(f))["workloads"].get(workload)
+            if rec and rec.get("value"):
+                return dict(rec, source=os.path.basename(f))
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None, setting_policy=None):
     """The oracle (CPU restatement of the reference path, PyTorch eager) timed on this host's cores: training steps
     (rollout + backward) of the same workload on a bounded sample of scenarios; 1 warm-up + `reps` timed repetitions,
@@ -207,7 +221,10 @@ def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None, settin
         if sum(times) > 45.0:  # keep the default run within minutes on a slow host
             break
     dt = statistics.median(times)
+    full = _full_batch_record(workload)
     return {"value": sample_scenarios * S * periods / dt, "unit": "scenario-steps/s", "cores": cores,
+            **({"full_batch_value": full["value"], "full_batch": {k: full.get(k) for k in ("scenarios", "periods", "cores", "is_full_batch", "source")}}
+               if full else {}),
             "thread_probe_s": probe, "oracle_over_reference_wall_time": _certified_ratio(),
             "host_cores": avail, "kind": "port",
             "sample": f"oracle (PyTorch-CPU eager restatement of the reference path), training step fwd+bwd on "
@@ -244,12 +261,12 @@ def algorithmic_work(tag, kernel, shape):
         K, n_out, n_ent, fold = shape["gnn"][tag[len("mlp3_fwd_"):]]
         rows = (K + 64 + n_out + fold) if tag.startswith("mlp3_fwd_") else (2 * K + 64 + 2 * n_out)
         return "hbm", 4.0 * rows * n_ent * n, "B"
-    if tag.startswith("bwd_thin_"):
-        N, K = (int(v) for v in tag[len("bwd_thin_"):].split("x"))
-        return "hbm", 4.0 * (2 * K + N) * n, "B"      # layer input read once, input gradient written once, dY read
     S, Wn, E = shape["S"], shape["Wn"], shape["E"]
     f_state = S * shape["Ws"] + Wn * shape["Ww"] + E * shape["We"]
     n_ord = S * max(Wn, 1) + Wn + E
+    if tag.startswith("bwd_thin_"):
+        N, K = (int(v) for v in tag[len("bwd_thin_"):].split("x"))
+        return "hbm", 4.0 * (2 * K + N) * n, "B"      # layer input read once, input gradient written once, dY read
     if tag == "env_fwd":  # state read + write, demand, orders, reward (static tables amortised over T)
         return "hbm", 4.0 * (2 * f_state + S + n_ord + 1) * n, "B"
     if tag == "env_bwd":  # state + orders + demand read, incoming state gradient read, state / order gradients written
@@ -258,6 +275,15 @@ def algorithmic_work(tag, kernel, shape):
         return "hbm", 4.0 * (2 * f_state + S + shape["n_out"] + n_ord + 1) * n, "B"
     if tag == "head_env_bwd":  # state, orders, demand, logits, incoming state gradient in; state gradient, order gradients, dZ out
         return "hbm", 4.0 * (3 * f_state + S + 2 * n_ord + 2 * shape["n_out"]) * n, "B"
+    if tag in ("wide_fwd", "wide_bwd") and shape.get("hidden"):
+        # whole-horizon kernels of the wide policy (csrc/wide_rollout.hip): every layer of every period of every scenario on the
+        # matrix cores (forward: first layer, hidden layers, logits; backward: their input gradients); the activation histories
+        # (forward: hidden rows out; backward: hidden rows in, their gradients out) are the HBM side, reported as `other`
+        hid, no = shape["hidden"], shape["n_out"]
+        F = S * shape["Ws"] + Wn * shape["Ww"]
+        per_col = 2.0 * ((F + 1) * hid[0] + sum(a_ * b_ for a_, b_ in zip(hid[:-1], hid[1:])) + no * hid[-1])
+        hist = 4.0 * sum(hid) * (1 if tag == "wide_fwd" else 2)
+        return "mfma", per_col * n * T, "FLOP", ("hbm", (hist + 4.0 * (2 * F + S + no + n_ord + 1)) * n * T, "B")
     if tag in ("tail_fwd", "tail_bwd") and shape.get("hidden"):
         # fused per-period tail (csrc/period_tail.hip).  Forward: last hidden activation in (K rows), next period's first hidden
         # activation out (N1 rows) + the fused head / env step's bytes.  Backward: the first layer's pre-activation gradient of the
@@ -528,6 +554,8 @@ def main():
                          "sharded path really runs and the line's `collective` object describes it)")
     ap.add_argument("--tail", choices=("auto", "on", "off"), default="auto",
                     help="fused per-period tail launches (csrc/period_tail.hip): the engine's choice, forced on, forced off")
+    ap.add_argument("--wide", choices=("auto", "on", "off"), default="auto",
+                    help="whole-horizon forward kernel of the 512-wide policy (csrc/wide_rollout.hip): the engine's choice, on, off")
     ap.add_argument("--no-horizon", action="store_true",
                     help="data_driven workloads: the per-period kernels instead of the whole-horizon kernels (A/B)")
     ap.add_argument("--horizon-max-scenarios", type=int, default=0,
@@ -590,6 +618,8 @@ def main():
         eng.small_lane_scenarios = args.lane_scenarios
         if args.no_horizon:
             eng.use_horizon = False
+        if args.wide != "auto" and hasattr(eng, "use_wide"):
+            eng.use_wide = args.wide == "on"
         if args.tail != "auto" and hasattr(eng, "fuse_tail"):
             eng.fuse_tail = args.tail == "on"
         if args.horizon_max_scenarios:

@@ -261,6 +261,44 @@ int nic_period_tail_bwd(const NicPeriodTail* t, const float* Z, const float* H_l
                         const float* g_state_next, NicTable2 g_reward, float* g_state_out, float* dH_last, float* slab,
                         int64_t lds, int32_t n_slots, int32_t first, void* stream);
 
+/* ---- whole-horizon rollout of the WIDE vanilla_warehouse policy: one launch per direction for all T periods (round 5) -------
+ * Trainer.simulate_batch's loop (trainer.py:190-213) for VanillaWarehouse (neural_networks.py:358-427) with 512-wide hidden
+ * layers: a workgroup carries a block of 32 scenarios through every period - hidden layers on the FP32 matrix cores with the
+ * weights streamed from L2 as pre-packed MFMA fragments and the activations in LDS, logits contracted straight from the last
+ * layer's accumulators, softmax head + Simulator.step (environment.py:110-299) on LDS tiles, next period's first layer from the
+ * new state tile - and leaves the histories the backward sweep and the weight-gradient contractions read.
+ * Histories: element (t, row, b) at base + t * period stride + row * ldb + b.  Packed weights (built by the caller once per
+ * optimizer step; neural_inventory_control_amd/wide_rollout.py):
+ *   Wp_hidden[l]  layer l (1 <= l < n_hidden), [H/32][H/8][64 lanes][4]: lane (r, h) of (tile, group g) holds
+ *                 W_l[32 tile + r][8 g + 2 j + h], j = 0..3
+ *   Wq_out        logits layer, [H/32][16][64]: lane (n, h) of (tile, r) holds W_out[n][32 tile + (r & 3) + 8 (r >> 2) + 4 h]
+ *                 (0 for n >= n_out)
+ * Shapes: nic_wide_rollout_ok (H == 512, 2..4 hidden layers, <= 16 stores, (S + 1) Wn = n_out <= 32, S Ws + Wn Ww <= 51, pipelines
+ * <= 4 slots, ldb % 64 == 0). */
+typedef struct NicWideRollout {
+    NicEnvStepIO io;            /* dims + static tables (underage, holding, lead_times, wh_*); state / demand / order members unused */
+    const int32_t* adjacency;   /* [Wn][S] */
+    float upper_bound;
+    int32_t transshipment;
+    int32_t T, H, n_hidden, n_out;
+    const float* demand;        /* [T][S][ld_demand], period stride ps_demand (elements) */
+    int64_t ps_demand, ld_demand;
+    float* states;              /* [T + 1][F (+ 1)][ldb]: block 0 = the initial state (input); blocks 1..T written (rows < F) */
+    float* orders;              /* [T][S Wn + Wn][ldb] */
+    float* logits;              /* [T][n_out][ldb] */
+    float* rewards;             /* [T][ldb] */
+    float* hidden[4];           /* [T][H][ldb] post-ELU activation of hidden layer l, or NULL (evaluation: nothing kept) */
+    int64_t ps_state, ps_orders, ps_logits, ps_hidden;
+    const float* Wt_in;         /* first layer transposed [F + 1][ldwt_in], row F = its bias */
+    int64_t ldwt_in;
+    const float* Wp_hidden[4];  /* [l] for 1 <= l < n_hidden */
+    const float* b_hidden[4];
+    const float* Wq_out;
+    const float* b_out;         /* [n_out] or NULL */
+} NicWideRollout;
+int nic_wide_rollout_ok(const NicEnvDims* dims, int32_t n_out, int32_t H, int32_t n_hidden);
+int nic_wide_rollout_fwd(const NicWideRollout* w, void* stream);
+
 /* vanilla_one_store (neural_networks.py:200-214): orders[s][b] = softplus(Z[s][b] + 1)  (threshold 20 like
  * nn.Softplus).  rows = number of output rows (1 for the shipped config). */
 int nic_head_softplus_fwd(const float* Z, float* orders, int32_t rows, int32_t n_scenarios, int32_t ldb,

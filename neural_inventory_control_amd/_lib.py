@@ -53,6 +53,16 @@ class NicPeriodTail(C.Structure):
                 ("Wt_in", C.c_void_p), ("ldwt_in", C.c_int64), ("N1", C.c_int32)]
 
 
+class NicWideRollout(C.Structure):
+    _fields_ = ([("io", NicEnvStepIO), ("adjacency", C.c_void_p), ("upper_bound", C.c_float), ("transshipment", C.c_int32)]
+                + [(n, C.c_int32) for n in ("T", "H", "n_hidden", "n_out")]
+                + [("demand", C.c_void_p), ("ps_demand", C.c_int64), ("ld_demand", C.c_int64), ("states", C.c_void_p),
+                   ("orders", C.c_void_p), ("logits", C.c_void_p), ("rewards", C.c_void_p), ("hidden", C.c_void_p * 4)]
+                + [(n, C.c_int64) for n in ("ps_state", "ps_orders", "ps_logits", "ps_hidden")]
+                + [("Wt_in", C.c_void_p), ("ldwt_in", C.c_int64), ("Wp_hidden", C.c_void_p * 4), ("b_hidden", C.c_void_p * 4),
+                   ("Wq_out", C.c_void_p), ("b_out", C.c_void_p)])
+
+
 class NicSmallRolloutDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in (
         "n_scenarios", "ldb", "T", "t0", "F", "n_hidden", "n_out", "head", "Ws", "Wn", "Ww", "E", "We", "lost_demand",
@@ -120,6 +130,8 @@ PROTOTYPES = {
     "nic_period_tail_fwd": (C.c_int, [C.POINTER(NicPeriodTail), _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_period_tail_bwd_slots": (C.c_int, [_i32]),
     "nic_period_tail_bwd": (C.c_int, [C.POINTER(NicPeriodTail), _vp, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "nic_wide_rollout_ok": (C.c_int, [C.POINTER(NicEnvDims), _i32, _i32, _i32]),
+    "nic_wide_rollout_fwd": (C.c_int, [C.POINTER(NicWideRollout), _vp]),
     "nic_linear_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_linear_fwd_thin_in_ok": (C.c_int, [_i32, _i32]),
     "nic_linear_fwd_thin_in": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -17,6 +17,7 @@ SOURCES = [
     ("policy_heads.hip", ["-ffp-contract=off"]),
     ("head_env.hip", ["-ffp-contract=off"]),
     ("period_tail.hip", ["-ffp-contract=off"]),
+    ("wide_rollout.hip", ["-ffp-contract=off"]),
     ("linear_mfma.hip", []),
     ("thin_layer.hip", []),
     ("sampler.hip", []),
@@ -28,7 +29,7 @@ SOURCES = [
     ("mlp3.hip", []),
     ("gnn_alloc_env.hip", ["-ffp-contract=off"]),
 ]
-HEADERS = ["nic_common.h", "env_step_body.h", "policy_heads_body.h", "small_rollout_body.h", "small_rollout16.h", "closed_form_body.h", "gnn_alloc_body.h", os.path.join("..", "..", "include", "nic_rollout.h")]
+HEADERS = ["nic_common.h", "env_step_body.h", "policy_heads_body.h", "tail_pieces.h", "small_rollout_body.h", "small_rollout16.h", "closed_form_body.h", "gnn_alloc_body.h", os.path.join("..", "..", "include", "nic_rollout.h")]
 ARCH = "gfx950"
 
 

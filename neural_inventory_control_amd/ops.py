@@ -233,6 +233,62 @@ def period_tail_bwd(desc, Z, H_last, dZ_first_next, g_state_next, g_reward: Tabl
                                     ptr(dH_last), ptr(slab), slab.stride(1), slab.shape[0], int(bool(first)), current_stream()))
 
 
+def wide_rollout_ok(prob: EnvProblem, n_out, H, n_hidden):
+    """shapes the whole-horizon kernels of the wide vanilla_warehouse policy take (nic_wide_rollout_ok)"""
+    return bool(lib().nic_wide_rollout_ok(prob.dims(), int(n_out), int(H), int(n_hidden)))
+
+
+def wide_pack_hidden(W, out=None):
+    """[N][K] weight of an H x H layer -> MFMA A fragments [N/32][K/8][64 lanes][4]: lane (r, h) of (tile, group g) holds
+    W[32 tile + r][8 g + 2 j + h], j = 0..3 (NicWideRollout.Wp_hidden)."""
+    N, K = W.shape
+    src = W.detach().reshape(N // 32, 32, K // 8, 4, 2).permute(0, 2, 4, 1, 3)   # [tile][group][h][r][j]
+    if out is None:
+        return src.contiguous()
+    out.view(N // 32, K // 8, 2, 32, 4).copy_(src)
+    return out
+
+
+def wide_pack_out_index(n_out, H, device):
+    """(row, column) gather indices of NicWideRollout.Wq_out: [H/32][16][64]; lane (n, h) of (tile, r) holds
+    W_out[n][32 tile + (r & 3) + 8 (r >> 2) + 4 h] (rows >= n_out come from a zero row)."""
+    lane = torch.arange(64, device=device)
+    r = torch.arange(16, device=device)
+    tile = torch.arange(H // 32, device=device)
+    col = 32 * tile[:, None, None] + ((r & 3) + 8 * (r >> 2))[None, :, None] + 4 * (lane >> 5)[None, None, :]
+    row = (lane & 31)[None, None, :].expand_as(col)
+    return row.contiguous(), col.contiguous()
+
+
+def wide_rollout_desc(prob: EnvProblem, T, adjacency, ub, transshipment, demand_soa, shift, states, orders, logits, rewards, hidden,
+                      Wt_in, Wp_hidden, b_hidden, Wq_out, b_out):
+    """NicWideRollout over the rollout engine's history buffers (states [T+1][F+1][ld], orders [T][.][ld], logits [T][.][ld],
+    rewards [T][ld], hidden[l] [T][H][ld] or None); demand_soa [T'][S][ld], first period `shift`."""
+    w = _lib.NicWideRollout()
+    w.io = prob.make_io(None, None, None, Table.null(), Table(None, 0, 0, 0), None, None)
+    w.adjacency, w.upper_bound, w.transshipment = ptr(adjacency), float(ub), int(transshipment)
+    w.T, w.H, w.n_hidden, w.n_out = int(T), Wt_in.shape[1], len(Wp_hidden) + 1, logits.shape[1]
+    d = demand_soa[shift:]
+    w.demand, w.ps_demand, w.ld_demand = ptr(d), demand_soa.stride(0), demand_soa.stride(1)
+    w.states, w.orders, w.logits, w.rewards = ptr(states), ptr(orders), ptr(logits), ptr(rewards)
+    w.ps_state, w.ps_orders, w.ps_logits = states.stride(0), orders.stride(0), logits.stride(0)
+    for l in range(4):
+        h = hidden[l] if hidden is not None and l < len(hidden) else None
+        w.hidden[l] = ptr(h)
+        if h is not None:
+            w.ps_hidden = h.stride(0)
+    w.Wt_in, w.ldwt_in = ptr(Wt_in), _ld(Wt_in)
+    for l in range(1, w.n_hidden):
+        w.Wp_hidden[l], w.b_hidden[l] = ptr(Wp_hidden[l - 1]), ptr(b_hidden[l - 1])
+    w.Wq_out, w.b_out = ptr(Wq_out), ptr(b_out)
+    w._keep = (adjacency, demand_soa, d, states, orders, logits, rewards, hidden, Wt_in, Wp_hidden, b_hidden, Wq_out, b_out)
+    return w
+
+
+def wide_rollout_fwd(desc):
+    check(lib().nic_wide_rollout_fwd(desc, current_stream()))
+
+
 def head_data_driven_fwd(Z, wh, mask, store_orders, wh_orders, S, Wn, Ww, B):
     """nic_head_data_driven_fwd: ReLU, adjacency mask and proportional allocation of the data_driven policy (one launch)."""
     _dev(Z)

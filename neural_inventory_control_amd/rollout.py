@@ -143,6 +143,9 @@ class FusedRollout:
         # DESIGN section 4); larger batches keep the separate, bandwidth-efficient launches
         self.fuse_tail = "auto"
         self.tail_max_scenarios = 16384
+        # ... and, for 512-wide hidden layers (BASELINE cfg3), ALL periods in one forward launch (csrc/wide_rollout.hip): a workgroup
+        # carries a block of 32 scenarios through the whole horizon, weights streamed from L2 as pre-packed MFMA fragments
+        self.use_wide = True
         # data_driven on small batches (what the reference trains it on: 72 products): all periods in ONE forward and ONE backward
         # launch (csrc/horizon_rollout.hip).  Measured against the per-period kernels on the real-data shape (tools/
         # horizon_crossover.py, profiles/r04_horizon_crossover.json): 2.3 vs 8.7 ms (replayed) at 72 scenarios, 3.4 vs 10.2 at 4,096,
@@ -166,6 +169,10 @@ class FusedRollout:
         echelons, no order rounding between head and env step (discrete allocation keeps the three separate launches)."""
         return (self.fuse_head_env and self.head == "warehouse" and prob.S <= 64 and prob.E == 0 and prob.Wn >= 1
                 and not self._round)
+
+    def _use_wide(self):
+        """the whole-horizon forward kernel of the wide policy (csrc/wide_rollout.hip) runs for the current shapes and options"""
+        return getattr(self, "_wide_shapes", False) and not self._round
 
     def _use_tail(self):
         """the fused per-period tail launches (csrc/period_tail.hip) run for the current shapes and options"""
@@ -208,7 +215,7 @@ class FusedRollout:
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin,
                self.eval_history, self.small_wgrad_in_kernel, extra_rows, self.small_lane_scenarios, self.use_horizon,
                self.horizon_max_scenarios, getattr(self, "_shift_hint", 0), self.fuse_tail, self.tail_max_scenarios,
-               self.fuse_head_env)
+               self.fuse_head_env, self.use_wide)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
@@ -352,6 +359,16 @@ class FusedRollout:
         # engine copies of the weights: rows padded to a multiple of 32 floats so every A-tile load is a float4
         self.Wp = [z(gd[i + 1], _pad32(gd[i])) for i in range(L)]
         self.Wt = [z(gd[i] + (1 if i == 0 else 0), _pad32(gd[i + 1])) for i in range(L)]   # (layer 0: + the bias row, see above)
+        # whole-horizon forward of the wide policy: every hidden layer 512 wide, history kept, shapes in the kernel's range
+        self._wide_shapes = bool(self.use_wide and self.head == "warehouse" and self.live_rows is None and extra_rows == 0 and L >= 3
+                                 and self._hist and all(m.bias is not None for m in lins) and len(set(dims[1:-1])) == 1
+                                 and ops.wide_rollout_ok(prob, dims[-1], dims[1], L - 1))
+        if self._wide_shapes:
+            Hh = dims[1]
+            self.Wpk = [z(Hh // 32, Hh // 8, 64, 4) for _ in range(L - 2)]
+            self.Wq = z(Hh // 32, 16, 64)
+            self._wq_index = ops.wide_pack_out_index(dims[-1], Hh, dev)
+            self._wq_pad = z(32, Hh)
         self.Zc = z(gd[-1], ld) if self.live_rows is not None else None
         self.bias_c = z(gd[-1]) if self.live_rows is not None else None
         if train:
@@ -782,7 +799,7 @@ class FusedRollout:
         loading is not capturable); timers force eager mode."""
         if not self._graph_on() or self.timer is not None or self._eager_runs < 1:
             return fn()
-        variant = (self._round, self._ctx[4], self.fuse_head_env, self.fuse_tail)  # options baked into the captured launch sequence
+        variant = (self._round, self._ctx[4], self.fuse_head_env, self.fuse_tail, self.use_wide)  # options baked into the captured launch sequence
         if getattr(self, "_graph_variant", variant) != variant:
             self._graphs = {}
         self._graph_variant = variant
@@ -804,6 +821,8 @@ class FusedRollout:
         # the ones row sits right behind the MLP's input rows when the input IS the whole state block (every head of this engine)
         self._thin_in_aug = (self._thin_in and self.F + 1 == self.states.shape[1]
                              and ops.linear_fwd_thin_in_ok(self.gd[1], self.gd[0] + 1))
+        if self._use_wide():
+            return self._launch_forward_wide()
         if self._use_tail():
             return self._launch_forward_tail()
         for t in range(T):
@@ -862,6 +881,22 @@ class FusedRollout:
         prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
         return ops.period_tail_desc(prob, state_block, Table(demand_soa[t + shift], ld, 1), orders_block, self.adj, self._ub_now,
                                     bool(self.model.transshipment), Wv[L - 1], biases[L - 1], self.Wt[0][:self.F + 1, :self.gd[1]])
+
+    def _launch_forward_wide(self):
+        """Forward sweep of the wide policy in ONE launch (csrc/wide_rollout.hip); the histories it leaves are the per-period
+        route's (states, orders, logits, hidden activations, rewards), so the backward sweep is unchanged."""
+        prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
+        lins = self._linears()
+        for l in range(1, L - 1):
+            ops.wide_pack_hidden(lins[l].weight, self.Wpk[l - 1])
+        self._wq_pad[:self.dims[-1]].copy_(lins[L - 1].weight.detach())
+        rows, cols = self._wq_index
+        self.Wq.copy_(self._wq_pad[rows, cols])
+        desc = ops.wide_rollout_desc(prob, T, self.adj, self._ub_now, bool(self.model.transshipment), demand_soa, shift, self.states,
+                                     self.orders, self.logits, self.rewards, self.hidden if train else None,
+                                     self.Wt[0][:self.F + 1, :self.gd[1]], self.Wpk, [biases[l] for l in range(1, L - 1)], self.Wq,
+                                     biases[L - 1])
+        self._k("wide_fwd", ops.wide_rollout_fwd, desc)
 
     def _launch_forward_tail(self):
         """Forward sweep with the fused tail: [first layer of period 0], then per period the hidden-layer GEMMs and ONE tail launch

@@ -74,12 +74,14 @@ def test_bench_over_a_one_rank_rccl_group(workload):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline"] + size
     outs = []
-    for extra in ({}, {"NIC_DIST_FORCE_INIT": "1", "MASTER_PORT": "29557"}):
-        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **extra), timeout=600, cwd=root)
+    # (round 5: the default N = 1 run creates the one-rank group itself; `--no-dist-init` is the run without any process group)
+    for more, extra in ((["--no-dist-init"], {}), ([], {"NIC_DIST_FORCE_INIT": "1", "MASTER_PORT": "29557"})):
+        r = subprocess.run(cmd + more, capture_output=True, text=True, env=dict(os.environ, **extra), timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
     plain, forced = outs
     assert forced["n_gpus"] == 1 and "RCCL" in json.dumps(forced["config"]) and "RCCL" not in json.dumps(plain["config"])
+    assert forced["collective"]["backend"] == "nccl" and plain["collective"]["backend"] is None
     a, b = (o["config"]["mean_cost_per_store_period"] for o in outs)
     assert abs(a - b) <= 1e-6 * abs(a), (a, b)
 

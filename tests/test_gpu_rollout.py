@@ -2007,3 +2007,50 @@ def test_step_graph_guard_sees_the_stream_hazard_on_this_torch_build():
     Trainer._hazard_guard.clear()
     assert Trainer._stream_hazard_is_reported(DEV) is True
     assert Trainer._stream_hazard_is_reported("cpu") is False
+
+
+# ---- round 5: the whole-horizon forward of the wide policy (csrc/wide_rollout.hip) -------------------------------------------
+@pytest.mark.parametrize("n,T,hidden", [(100, 5, [512, 512, 512]), (2048 + 17, 3, [512, 512]), (8192, 4, [512, 512, 512])])
+def test_wide_whole_horizon_forward_matches_the_per_period_route(n, T, hidden):
+    """BASELINE cfg3's setting with 512-wide hidden layers: ALL periods in one forward launch (a workgroup carries 32 scenarios
+    through the horizon; weights streamed as packed MFMA fragments, activations in LDS, logits from the accumulators) against the
+    per-period launches: per-period rewards / per-scenario totals <= 1e-5, states and orders to the usual state tolerance, hidden
+    activation and logit histories <= 1e-5, and - the backward sweep running on the histories the kernel left - gradients
+    <= 1e-5 per parameter tensor.  Ragged batches (100 = three blocks + 4; 2,065), one block per CU (8,192)."""
+    import copy
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from neural_inventory_control_amd.rollout import KernelTimer
+    setting, policy, _, _, _ = workloads.get("cfg3")
+    policy = copy.deepcopy(policy)
+    policy["neurons_per_hidden_layer"]["master"] = list(hidden)
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"], n,
+                  obs, setting["seeds"], sampler="hip", device=DEV)
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    out = {}
+    for wide in (True, False):
+        torch.manual_seed(11)
+        model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+        eng = FusedRollout(model, setting["problem_params"], DEV)
+        eng.use_wide = wide
+        eng.materialize(eng.input_rows(data, obs))
+        eng.timer = KernelTimer(record_order=True)
+        total, rep = eng.run(data, T, 0, train=True, observation_params=obs)
+        torch.cuda.synchronize()
+        tags = {t for t, _ in eng.timer.order}
+        assert ("wide_fwd" in tags) == wide, tags
+        out[wide] = (float(total), eng.per_period_rewards().clone(), eng.states.clone(), eng.orders.clone(), eng.logits.clone(),
+                     [h_.clone() for h_ in eng.hidden], [p.grad.clone() for p in model.parameters()])
+    a, b = out[True], out[False]
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0])
+    tot_a, tot_b = a[1].sum(0), b[1].sum(0)
+    assert float(((tot_a - tot_b).abs() / tot_b.abs().clamp_min(1e-9)).max()) <= 1e-5
+    torch.testing.assert_close(a[1], b[1], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a[2], b[2], **STATE_TOL)
+    torch.testing.assert_close(a[3], b[3], **STATE_TOL)
+    torch.testing.assert_close(a[4][:, :, :n], b[4][:, :, :n], rtol=1e-4, atol=1e-4)
+    for x, y in zip(a[5], b[5]):
+        torch.testing.assert_close(x[:, :, :n], y[:, :, :n], rtol=1e-4, atol=1e-4)
+    for x, y in zip(a[6], b[6]):
+        assert float((x - y).norm()) <= 1e-5 * float(y.norm()) + 1e-12
