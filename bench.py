@@ -571,6 +571,7 @@ def main():
     from neural_inventory_control_amd import _lib, parallel
     from neural_inventory_control_amd.rollout import KernelTimer
     dist_error = None
+    os.environ["NCCL_DEBUG"] = os.environ.get("NIC_NCCL_DEBUG", "WARN")   # (no RCCL version banner between the lines of stdout)
     if args.gpus == 1 and "RANK" not in os.environ and not args.no_dist_init:
         os.environ.setdefault("NIC_DIST_FORCE_INIT", "1")   # one rank, real backend: the collective path is exercised and described
         if "MASTER_PORT" not in os.environ:
@@ -816,9 +817,10 @@ def main():
             except Exception as e:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "scenario-steps/s", "cores": None, "host_cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(out))
     if sharded:
         torch.distributed.destroy_process_group()
+    if rank == 0:   # (after the process group is gone: RCCL prints a version banner on stdout when a communicator is torn down -
+        print(json.dumps(out), flush=True)   # the JSON line stays the LAST line of the output)
 
 
 if __name__ == "__main__":

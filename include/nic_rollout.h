@@ -298,6 +298,19 @@ typedef struct NicWideRollout {
 } NicWideRollout;
 int nic_wide_rollout_ok(const NicEnvDims* dims, int32_t n_out, int32_t H, int32_t n_hidden);
 int nic_wide_rollout_fwd(const NicWideRollout* w, void* stream);
+/* Backward sweep over the histories nic_wide_rollout_fwd left (w->hidden[l] must be set for every hidden layer): for t = T-1 .. 0
+ * the first layer's input gradient of period t+1 (contracted from the registers that hold its pre-activation gradient), the env /
+ * head adjoints on LDS tiles, the logits layer's input gradient and the hidden layers' input gradients with ELU' from the
+ * activation history.  Writes dZ_hidden[l] ([T][H][ldb], period stride ps_dz: pre-activation gradient of hidden layer l) and
+ * dZ_out ([T][n_out][ldb], ps_dzout: logits gradient) - the operands of the weight-gradient contractions
+ * (nic_linear_wgrad_periods).  g_reward as for nic_env_step_bwd.  Packed weights:
+ *   WpT_hidden[l]  (1 <= l < n_hidden) the TRANSPOSE of layer l packed like Wp_hidden
+ *   Wq_in          first layer, [2][H/32][16][64]: lane (f, h) of (mt, tile, r) holds W_in[32 tile + (r & 3) + 8 (r >> 2) + 4 h][32 mt + f]
+ *                  (0 for state rows 32 mt + f >= F)
+ *   Wo_t           logits layer, [H/32][NS][64], NS = 4 / 9 / 16 >= ceil(n_out / 2): lane (k, h) of (tile, s) holds
+ *                  W_out[2 s + h][32 tile + k] (0 for rows >= n_out) */
+int nic_wide_rollout_bwd(const NicWideRollout* w, NicTable2 g_reward, float* const* dZ_hidden, int64_t ps_dz, float* dZ_out,
+                         int64_t ps_dzout, const float* const* WpT_hidden, const float* Wq_in, const float* Wo_t, void* stream);
 
 /* vanilla_one_store (neural_networks.py:200-214): orders[s][b] = softplus(Z[s][b] + 1)  (threshold 20 like
  * nn.Softplus).  rows = number of output rows (1 for the shipped config). */

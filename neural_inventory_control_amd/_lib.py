@@ -132,6 +132,8 @@ PROTOTYPES = {
     "nic_period_tail_bwd": (C.c_int, [C.POINTER(NicPeriodTail), _vp, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "nic_wide_rollout_ok": (C.c_int, [C.POINTER(NicEnvDims), _i32, _i32, _i32]),
     "nic_wide_rollout_fwd": (C.c_int, [C.POINTER(NicWideRollout), _vp]),
+    "nic_wide_rollout_bwd": (C.c_int, [C.POINTER(NicWideRollout), NicTable2, C.POINTER(C.c_void_p * 4), _i64, _vp, _i64,
+                                       C.POINTER(C.c_void_p * 4), _vp, _vp, _vp]),
     "nic_linear_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_linear_fwd_thin_in_ok": (C.c_int, [_i32, _i32]),
     "nic_linear_fwd_thin_in": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -64,6 +64,10 @@ __device__ __forceinline__ int bl(int k, int c) { return (((k >> 3) * 2 + (k & 1
 // from LDS one group ahead.
 template <int RT, int PF>
 __device__ __forceinline__ void stream_layer(const float4* __restrict__ Wp, int K, int wave, const float* hin, f32x16 (&acc)[RT]) {
+    // Two register sets of PF k groups each: while the MFMAs of one set run (PF x 4 RT x 64 cycles = 1.7 us at RT = 4), the
+    // loads of the other set are in flight, all of them issued in FRONT of those MFMAs.  (hipcc waits for EVERYTHING outstanding
+    // at the head of a loop whose loads cross the back edge - s_waitcnt vmcnt(0) - so loads issued group by group behind the
+    // MFMAs that free their registers, the textbook rotation, expose the whole L2 latency once per trip: measured 0.46 of peak.)
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int ng = K / 8;
     const __amdgpu_buffer_rsrc_t rW = make_rsrc(reinterpret_cast<const float*>(Wp), (int64_t)K * K);
@@ -75,18 +79,24 @@ __device__ __forceinline__ void stream_layer(const float4* __restrict__ Wp, int 
     int tile_off[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) tile_off[i] = (wave * RT + i) * ng * 1024;
-    float4 a[PF][RT];
-#pragma unroll
-    for (int d = 0; d < PF; ++d)
-#pragma unroll
-        for (int i = 0; i < RT; ++i) a[d][i] = buf_load4(rW, vw + tile_off[i] + d * 1024);
-    const float4* hb = reinterpret_cast<const float4*>(hin) + h * 32 + c;
-    float4 b = hb[0];
-    for (int g0 = 0; g0 < ng; g0 += PF) {
+    float4 a0[PF][RT], a1[PF][RT];
+    auto fetch = [&](float4 (&a)[PF][RT], int g0) {   // groups g0 .. g0 + PF - 1 (past the end: the last groups again, unused)
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
-            const int g = g0 + d;
-            const float4 bn = hb[(g + 1 < ng ? g + 1 : g) * 64];
+            const int g = g0 + d < ng ? g0 + d : ng - 1;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) a[d][i] = buf_load4(rW, vw + tile_off[i] + g * 1024);
+        }
+    };
+    const float4* hb = reinterpret_cast<const float4*>(hin) + h * 32 + c;
+    auto run = [&](const float4 (&a)[PF][RT], int g0) {
+        float4 bq[2];   // (two named sets: with one, hipcc issues each group's LDS read behind the previous group's last MFMA)
+        bq[0] = hb[g0 * 64];
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            if (d + 1 < PF) bq[(d + 1) & 1] = hb[(g0 + d + 1) * 64];
+            __builtin_amdgcn_sched_barrier(0);   // (the next group's LDS read stays in FRONT of this group's MFMAs)
+            const float4 b = bq[d & 1];
 #pragma unroll
             for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][i].x, b.x, acc[i], 0, 0, 0);
 #pragma unroll
@@ -95,11 +105,18 @@ __device__ __forceinline__ void stream_layer(const float4* __restrict__ Wp, int 
             for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][i].z, b.z, acc[i], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][i].w, b.w, acc[i], 0, 0, 0);
-            const int gn = g + PF < ng ? g + PF : g;   // (the last groups re-read themselves: no branch in the chain)
-#pragma unroll
-            for (int i = 0; i < RT; ++i) a[d][i] = buf_load4(rW, vw + tile_off[i] + gn * 1024);
-            b = bn;
         }
+    };
+    fetch(a0, 0);
+    for (int g0 = 0; g0 < ng; g0 += 2 * PF) {   // (ng % (2 PF) == 0)
+        fetch(a1, g0 + PF);
+        __builtin_amdgcn_sched_barrier(0);
+        run(a0, g0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(a0, g0 + 2 * PF);
+        __builtin_amdgcn_sched_barrier(0);
+        run(a1, g0 + PF);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -354,6 +371,279 @@ __global__ __launch_bounds__(kThreads) void wide_fwd_kernel(WideParams p) {
     }
 }
 
+// ================================================================================================================================
+// backward
+// ================================================================================================================================
+struct WideBwdParams {
+    NicEnvStepIO io;
+    const int32_t* adj;
+    float ub;
+    int trans;
+    int F, T, H, n_hidden, n_out;
+    int n_blocks;
+    const float* demand;
+    int64_t ps_demand, ld_demand;
+    const float* states;      // histories the forward sweep left
+    const float* orders;
+    const float* logits;
+    const float* hidden[kMaxHidden];
+    int64_t ps_state, ps_orders, ps_logits, ps_hidden;
+    NicTable2 g_reward;
+    float* dZ[kMaxHidden];    // [T][H][ldb] pre-activation gradient history of hidden layer l (written)
+    float* dZ_out;            // [T][n_out][ldb] logits gradient history (written)
+    int64_t ps_dz, ps_dzout;
+    const float4* WpT[kMaxHidden];   // hidden layer l (1 <= l < n_hidden): its TRANSPOSE packed like Wp
+    const float* Wq_in;       // first layer for register-fed B operands: [2][H / 32][16][64]: lane (f, h) of (mt, tile, r) holds
+                              // W_in^T[32 mt + f][32 tile + crow(r, h)] (0 for state rows >= F)
+    const float* Wo_t;        // logits layer transposed fragments: [H / 32][NS][64]: lane (k, h) of (tile, s) holds W_out[2 s + h][32 tile + k]
+};
+
+// this wavefront's rows of an activation history block ([H][ldb] at the block's first scenario) in accumulator layout
+template <int RT>
+__device__ __forceinline__ void load_act(const float* g, int wave, int ldb, int H, float (&v)[RT][16]) {
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rG = make_rsrc(g, (int64_t)H * ldb);
+    const int vg = (4 * h * ldb + c) * 4;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[i][r] = ldf(rG, vg, ((wave * RT + i) * 32 + (r & 3) + 8 * (r >> 2)) * ldb * 4);
+}
+
+// acc <- acc * ELU'(act) (act = the layer's post-activation output); to the gradient history (gout) and / or LDS in B layout
+template <int RT>
+__device__ __forceinline__ void dgrad_epilogue(f32x16 (&acc)[RT], const float (&act)[RT][16], int wave, float* hout, float* gout, int ldb,
+                                               int n_store, int H) {
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rG = make_rsrc(gout, (int64_t)H * ldb);
+    const int vg = (4 * h * ldb + c) * 4;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int row0 = (wave * RT + i) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ku = (r & 3) + 8 * (r >> 2);
+            const float y = acc[i][r] * elu_grad_from_out(act[i][r]);
+            acc[i][r] = y;
+            if (hout) hout[bl(row0 + ku + 4 * h, c)] = y;
+            if (c < n_store) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rG, vg, (row0 + ku) * ldb * 4, 0);
+        }
+    }
+}
+
+template <int MAXW, int NS, int RT>
+__global__ __launch_bounds__(kThreads) void wide_bwd_kernel(WideBwdParams p) {
+    constexpr int MAXSQ = 4, PF = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = p.H;
+    float* buf0 = lds;
+    float* buf1 = lds + H * NB;
+    float* gi = buf1 + H * NB;                  // env part of d loss / d state(t): written by stage B', read by the NEXT iteration
+    float* tb = gi + kStateRows * LDT;
+    int* adj_l = reinterpret_cast<int*>(tb + kTabRows * LDT);
+    // scratch of stages A' / B' (both activation buffers are free then); the logits gradient tile sits in buf1: stage C' reads it
+    // while it writes buf0
+    float* red = buf0;                           // 3 x 2 x 16 x 64
+    float* st = red + 3 * 2 * 16 * 64;
+    float* dm = st + kStateRows * LDT;
+    float* od = dm + 4 * MAXSQ * LDT;
+    float* zt = od + 32 * LDT;
+    float* gs = zt + 32 * LDT;                   // [64][LDT]
+    float* go = gs + 64 * LDT;
+    float* ex = go + 32 * LDT;                   // (ends 16 floats inside buf1)
+    float* dz = buf1 + 1024;
+    float (*xm)[NB] = reinterpret_cast<float (*)[NB]>(ex);
+    float (*xd)[NB] = reinterpret_cast<float (*)[NB]>(ex + 4 * NB);
+    float (*xt)[NB] = reinterpret_cast<float (*)[NB]>(ex + 8 * NB);
+    float (*xs)[NB] = reinterpret_cast<float (*)[NB]>(ex + 12 * NB);
+    float (*gwa)[NB] = reinterpret_cast<float (*)[NB]>(ex + 16 * NB);
+    float (*part)[4][NB] = reinterpret_cast<float (*)[4][NB]>(ex + 16 * NB + kMaxWh * NB);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h = lane >> 5;
+    const NicEnvDims& d = p.io.dims;
+    const int B = d.n_scenarios, S = d.n_stores, Wn = d.n_warehouses, Ww = d.warehouse_slots;
+    const int ldb = d.ldb;
+    const int ncols = (B + 3) / 4 * 4;
+    const int n_ord = S * Wn + Wn;
+    const bool active = tid < 4 * NB;
+    const int x = tid & (NB - 1), q = (tid >> 5) & 3;
+
+    // resident fragments: first layer (register-fed contraction of stage A'), logits layer transposed (stage C')
+    float aIn[2][RT][16], aO[RT][NS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aIn[mt][i][r] = p.Wq_in[(((mt * (H / 32)) + wave * RT + i) * 16 + r) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) aO[i][s] = p.Wo_t[((wave * RT + i) * NS + s) * 64 + lane];
+
+    for (int blk = blockIdx.x; blk < p.n_blocks; blk += gridDim.x) {
+        const int c0 = blk * NB;
+        const int nlive = min(NB, B - c0);
+        const int n_store = min(NB, ncols - c0);
+        const bool live = active && x < nlive;
+        const int bb = x < nlive ? x : nlive - 1;
+        if (blk != (int)blockIdx.x) __syncthreads();
+        {
+            TabRegs ptb;
+            tables_fetch(p.io, c0, nlive, ptb);
+            const int padj = p.adj[tid < S * Wn ? tid : 0];
+            tables_put(tb, p.io, ptb);
+            if (tid < 32) adj_l[tid] = padj;
+        }
+        const float gr = live ? p.g_reward.p[(int64_t)(c0 + x) * p.g_reward.scn_stride] : 0.f;
+        f32x16 dz1[RT];   // pre-activation gradient of the first hidden layer, period t + 1 (this wavefront's rows)
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz1[i][r] = 0.f;
+
+        for (int t = p.T - 1; t >= 0; --t) {
+            const bool has_next = t + 1 < p.T;
+            // ---- tiles of period t (parked in registers) and the last hidden layer's activations (for ELU' in stage C')
+            float4 pst[2], pdm[1], pod[1], pzt[1];
+            tile_fetch<2>(p.states + t * p.ps_state, ldb, c0, p.F, pst);
+            tile_fetch<1>(p.demand + t * p.ps_demand, p.ld_demand, c0, S, pdm);
+            tile_fetch<1>(p.orders + t * p.ps_orders, ldb, c0, n_ord, pod);
+            tile_fetch<1>(p.logits + t * p.ps_logits, ldb, c0, p.n_out, pzt);
+            float act[RT][16];
+            load_act<RT>(p.hidden[p.n_hidden - 1] + t * p.ps_hidden + c0, wave, ldb, H, act);
+            // ---- A': first layer's input gradient of period t + 1, contracted over this wavefront's rows of dZ1 from the registers
+            if (has_next) {
+                f32x16 g2[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) g2[mt][r] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < RT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) g2[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aIn[mt][i][r], dz1[i][r], g2[mt], 0, 0, 0);
+                }
+                ksplit_publish<2>(red, g2);
+                __syncthreads();
+                if (wave == 0) {
+                    ksplit_collect<2>(red, g2);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gs[(32 * mt + crow(r, h)) * LDT + li] = g2[mt][r];
+                }
+                __syncthreads();
+                // gs <- G + the env part the previous iteration left in gi
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = (tid >> 3) + 32 * i;
+                    if (r < p.F) {
+                        float4* cell = reinterpret_cast<float4*>(gs + r * LDT + (tid & 7) * 4);
+                        const float4 e = *reinterpret_cast<const float4*>(gi + r * LDT + (tid & 7) * 4);
+                        float4 g = *cell;
+                        g.x += e.x; g.y += e.y; g.z += e.z; g.w += e.w;
+                        *cell = g;
+                    }
+                }
+            } else {
+                for (int i = tid; i < 64 * LDT; i += kThreads) gs[i] = 0.f;
+            }
+            tile_put<2>(st, p.F, pst);
+            tile_put<1>(dm, S, pdm);
+            tile_put<1>(od, n_ord, pod);
+            tile_put<1>(zt, p.n_out, pzt);
+            for (int i = tid; i < 32 * LDT; i += kThreads) dz[i] = 0.f;
+            __syncthreads();
+
+            // ---- B': env adjoint + head adjoint (period_tail.hip, stage B')
+            const NicEnvStepIO io = block_io(p.io, nlive, st, dm, od, tb);
+            float* gs_wh = gs + S * d.store_slots * LDT;
+            float* gi_wh = gi + S * d.store_slots * LDT;
+            float* go_wh = go + S * Wn * LDT;
+            for (int wc = 0; wc < Wn; wc += kChunk) {
+                for (int i = 0; i < kChunk && wc + i < Wn; ++i) {
+                    const float v = live ? nic::env_ship_partial(io, wc + i, x, q) : 0.f;
+                    if (active) part[i][q][x] = v;
+                }
+                nic::lds_barrier();
+                for (int i = q; i < kChunk && wc + i < Wn; i += nic::kQuad) {
+                    const float shipped = nic::combine4(part[i][0][x], part[i][1][x], part[i][2][x], part[i][3][x]);
+                    const float v = live ? nic::env_bwd_warehouse<MAXW>(io, gs_wh, gr, 0.f, wc + i, shipped, gi_wh, go_wh, x) : 0.f;
+                    if (active) gwa[wc + i][x] = v;
+                }
+                nic::lds_barrier();
+            }
+            if (live) {
+                const nic::IoAccess ac{io, x, nullptr, nullptr, gs, gs_wh, gi, gi_wh, go, go_wh};
+                for (int s_ = q; s_ < S; s_ += nic::kQuad) nic::env_bwd_store_t<MAXW>(ac, gr, [&](int w) { return gwa[w][x]; }, s_);
+            }
+            nic::lds_barrier();
+            for (int w = 0; w < Wn; ++w) {
+                if (w > 0) nic::lds_barrier();
+                nic::HeadLane<MAXSQ> L;
+                int nc;
+                const float mq = nic::head_quad_load<MAXSQ, true>(L, zt, go, adj_l, S, Wn, LDT, bb, w, q, nc, nullptr);
+                if (active) xm[q][x] = mq;
+                const float stock = io.wh_inv[w * Ww * LDT + bb];
+                nic::lds_barrier();
+                const float m = nic::head_quad_max(xm[0][x], xm[1][x], xm[2][x], xm[3][x], p.trans);
+                const float dq = nic::head_quad_exp<MAXSQ>(L, m);
+                if (active) xd[q][x] = dq;
+                nic::lds_barrier();
+                const float denom = nic::head_quad_denom(xd[0][x], xd[1][x], xd[2][x], xd[3][x], m, p.trans);
+                float tq, sq;
+                nic::head_quad_bwd_dots<MAXSQ>(L, denom, stock, tq, sq);
+                if (active) {
+                    xt[q][x] = tq;
+                    xs[q][x] = sq;
+                }
+                nic::lds_barrier();
+                if (live) {
+                    const float dot = nic::combine4(xt[0][x], xt[1][x], xt[2][x], xt[3][x]);
+                    nic::head_quad_bwd_store<MAXSQ>(L, dot, stock, dz, S, Wn, LDT, x, w, q, nullptr);
+                    if (q == (w & 3)) {
+                        gi_wh[w * Ww * LDT + x] += nic::combine4(xs[0][x], xs[1][x], xs[2][x], xs[3][x]);
+                        nic::head_wh_order_bwd(zt, p.ub, go_wh, dz, S, Wn, LDT, x, w, -1);
+                    }
+                }
+            }
+            __syncthreads();   // dz complete; every scratch tile in buf0 is dead
+            tile_store(dz, p.dZ_out + t * p.ps_dzout, ldb, c0, p.n_out, nlive);
+
+            // ---- C': input gradient of the logits layer for this wavefront's rows, ELU' from the activation history
+            f32x16 acc[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aO[i][s], dz[(2 * s + h) * LDT + li], acc[i], 0, 0, 0);
+            }
+            {
+                const int l = p.n_hidden - 1;
+                dgrad_epilogue<RT>(acc, act, wave, l >= 1 ? buf0 : nullptr, p.dZ[l] + t * p.ps_dz + c0, ldb, n_store, H);
+            }
+            __syncthreads();
+            // ---- hidden layers' input gradients, last to first; the first layer's stays in registers for the next iteration
+            float* hin = buf0;
+            float* hout = buf1;
+            for (int l = p.n_hidden - 1; l >= 1; --l) {
+                load_act<RT>(p.hidden[l - 1] + t * p.ps_hidden + c0, wave, ldb, H, act);
+                stream_layer<RT, PF>(p.WpT[l], H, wave, hin, acc);
+                dgrad_epilogue<RT>(acc, act, wave, l - 1 >= 1 ? hout : nullptr, p.dZ[l - 1] + t * p.ps_dz + c0, ldb, n_store, H);
+                __syncthreads();
+                float* tmp = hin;
+                hin = hout;
+                hout = tmp;
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i) dz1[i] = acc[i];
+        }
+    }
+}
+
 int wide_max_slots(const NicEnvDims& d) { return d.store_slots > d.warehouse_slots ? d.store_slots : d.warehouse_slots; }
 
 int wide_shapes_ok(const NicEnvDims& d, int n_out, int H, int n_hidden) {
@@ -437,6 +727,69 @@ int nic_wide_rollout_fwd(const NicWideRollout* w, void* stream) {
     else NIC_L(26);
 #undef NIC_L
     return nic::check_launch("nic_wide_rollout_fwd");
+}
+
+
+int nic_wide_rollout_bwd(const NicWideRollout* w, NicTable2 g_reward, float* const* dZ_hidden, int64_t ps_dz, float* dZ_out,
+                         int64_t ps_dzout, const float* const* WpT_hidden, const float* Wq_in, const float* Wo_t, void* stream) {
+    NIC_REQUIRE(w != nullptr && dZ_hidden != nullptr && WpT_hidden != nullptr, "nic_wide_rollout_bwd: null argument");
+    const NicEnvDims& d = w->io.dims;
+    NIC_REQUIRE(wide_shapes_ok(d, w->n_out, w->H, w->n_hidden), "nic_wide_rollout_bwd: shapes outside the kernel's range (nic_wide_rollout_ok)");
+    NIC_REQUIRE(w->T >= 1 && w->adjacency && w->demand && w->states && w->orders && w->logits && g_reward.p && dZ_out && Wq_in && Wo_t,
+                "nic_wide_rollout_bwd: null buffer");
+    for (int l = 0; l < w->n_hidden; ++l)
+        NIC_REQUIRE(w->hidden[l] && dZ_hidden[l] && (l == 0 || WpT_hidden[l]), "nic_wide_rollout_bwd: history / weights of hidden layer %d missing", l);
+    NIC_REQUIRE(ps_dz % 4 == 0 && ps_dzout % 4 == 0, "nic_wide_rollout_bwd: period strides must keep rows 16-byte aligned");
+    WideBwdParams p{};
+    p.io = w->io;
+    p.adj = w->adjacency;
+    p.ub = w->upper_bound;
+    p.trans = w->transshipment;
+    p.F = d.n_stores * d.store_slots + d.n_warehouses * d.warehouse_slots;
+    p.T = w->T;
+    p.H = w->H;
+    p.n_hidden = w->n_hidden;
+    p.n_out = w->n_out;
+    p.n_blocks = nic::ceil_div(d.n_scenarios, NB);
+    p.demand = w->demand;
+    p.ps_demand = w->ps_demand;
+    p.ld_demand = w->ld_demand;
+    p.states = w->states;
+    p.orders = w->orders;
+    p.logits = w->logits;
+    p.ps_state = w->ps_state;
+    p.ps_orders = w->ps_orders;
+    p.ps_logits = w->ps_logits;
+    p.ps_hidden = w->ps_hidden;
+    p.g_reward = g_reward;
+    p.dZ_out = dZ_out;
+    p.ps_dz = ps_dz;
+    p.ps_dzout = ps_dzout;
+    for (int l = 0; l < kMaxHidden; ++l) {
+        p.hidden[l] = l < w->n_hidden ? w->hidden[l] : nullptr;
+        p.dZ[l] = l < w->n_hidden ? dZ_hidden[l] : nullptr;
+        p.WpT[l] = (l >= 1 && l < w->n_hidden) ? reinterpret_cast<const float4*>(WpT_hidden[l]) : nullptr;
+    }
+    p.Wq_in = Wq_in;
+    p.Wo_t = Wo_t;
+    const int cus = nic::cu_count();
+    const dim3 grid(p.n_blocks < cus ? p.n_blocks : cus), block(kThreads);
+    const size_t lds = sizeof(float) * ((size_t)2 * p.H * NB + kStateRows * LDT + kTabRows * LDT + 32);
+    hipStream_t s = nic::as_stream(stream);
+    const int ns = (p.n_out + 1) / 2;
+    nic::note_kernelf("wide_bwd_kernel<4,%d,4>", ns <= 4 ? 4 : (ns <= 9 ? 9 : 16));
+#define NIC_L(NS_)                                                                                                                   \
+    do {                                                                                                                             \
+        NIC_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_bwd_kernel<4, NS_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds) == hipSuccess,                                                                     \
+                    "nic_wide_rollout_bwd: %zu bytes of LDS refused", lds);                                                          \
+        hipLaunchKernelGGL((wide_bwd_kernel<4, NS_, 4>), grid, block, lds, s, p);                                                     \
+    } while (0)
+    if (ns <= 4) NIC_L(4);
+    else if (ns <= 9) NIC_L(9);
+    else NIC_L(16);
+#undef NIC_L
+    return nic::check_launch("nic_wide_rollout_bwd");
 }
 
 }  // extern "C"

@@ -5,6 +5,8 @@ kernel on torch's current stream and never synchronises.  There is no CPU path: 
 """
 import torch
 
+import ctypes
+
 from . import _lib
 from ._lib import check, current_stream, lib, ptr
 from .layout import EnvProblem, Table
@@ -287,6 +289,47 @@ def wide_rollout_desc(prob: EnvProblem, T, adjacency, ub, transshipment, demand_
 
 def wide_rollout_fwd(desc):
     check(lib().nic_wide_rollout_fwd(desc, current_stream()))
+
+
+def wide_pack_in_index(F, H, device):
+    """gather indices of nic_wide_rollout_bwd's Wq_in ([2][H/32][16][64]) into the first layer's weight W_in [H][F] padded to 64
+    input columns: lane (f, h) of (mt, tile, r) holds W_in[32 tile + (r & 3) + 8 (r >> 2) + 4 h][32 mt + f]."""
+    lane = torch.arange(64, device=device)
+    r = torch.arange(16, device=device)
+    tile = torch.arange(H // 32, device=device)
+    mt = torch.arange(2, device=device)
+    unit = (32 * tile[:, None, None] + ((r & 3) + 8 * (r >> 2))[None, :, None] + 4 * (lane >> 5)[None, None, :])[None].expand(2, -1, -1, -1)
+    f = (32 * mt[:, None, None, None] + (lane & 31)[None, None, None, :]).expand_as(unit)
+    return unit.contiguous(), f.contiguous()
+
+
+def wide_ns(n_out):
+    ns = (n_out + 1) // 2
+    return 4 if ns <= 4 else (9 if ns <= 9 else 16)
+
+
+def wide_pack_out_t_index(n_out, H, device):
+    """gather indices of Wo_t ([H/32][NS][64]) into W_out padded to 2 NS rows: lane (k, h) of (tile, s) holds W_out[2 s + h][32 tile + k]."""
+    NS = wide_ns(n_out)
+    lane = torch.arange(64, device=device)
+    s_ = torch.arange(NS, device=device)
+    tile = torch.arange(H // 32, device=device)
+    row = (2 * s_[None, :, None] + (lane >> 5)[None, None, :]).expand(H // 32, -1, -1)
+    col = (32 * tile[:, None, None] + (lane & 31)[None, None, :]).expand(-1, NS, -1)
+    return row.contiguous(), col.contiguous()
+
+
+def wide_rollout_bwd(desc, g_reward: Table, dZ_hidden, dZ_out, WpT_hidden, Wq_in, Wo_t):
+    """nic_wide_rollout_bwd.  dZ_hidden: list of [T][H][ld] tensors (hidden layer 0 ..), dZ_out [T][n_out][ld]; WpT_hidden: packed
+    transposes of hidden layers 1 .. (list, index 0 = layer 1)."""
+    dz = (ctypes.c_void_p * 4)()
+    wt = (ctypes.c_void_p * 4)()
+    for l, t_ in enumerate(dZ_hidden):
+        dz[l] = ptr(t_)
+    for l, t_ in enumerate(WpT_hidden):
+        wt[l + 1] = ptr(t_)
+    check(lib().nic_wide_rollout_bwd(desc, g_reward.t2(), dz, dZ_hidden[0].stride(0), ptr(dZ_out), dZ_out.stride(0), wt, ptr(Wq_in),
+                                     ptr(Wo_t), current_stream()))
 
 
 def head_data_driven_fwd(Z, wh, mask, store_orders, wh_orders, S, Wn, Ww, B):

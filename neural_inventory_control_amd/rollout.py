@@ -143,9 +143,12 @@ class FusedRollout:
         # DESIGN section 4); larger batches keep the separate, bandwidth-efficient launches
         self.fuse_tail = "auto"
         self.tail_max_scenarios = 16384
-        # ... and, for 512-wide hidden layers (BASELINE cfg3), ALL periods in one forward launch (csrc/wide_rollout.hip): a workgroup
-        # carries a block of 32 scenarios through the whole horizon, weights streamed from L2 as pre-packed MFMA fragments
-        self.use_wide = True
+        # ... and, for 512-wide hidden layers (BASELINE cfg3), ALL periods in one launch per direction (csrc/wide_rollout.hip): a
+        # workgroup carries a block of 32 scenarios through the whole horizon, weights streamed from L2 as pre-packed MFMA fragments.
+        # OFF by default: measured it matches the per-period launches at an 8-GPU shard (29.2 vs 28.2 ms at 8,192
+        # scenarios) and loses at the full batch (231 vs 180 ms) - its H x H layers run at the tiled GEMM's rate (36-40 us per 8,192
+        # columns) while the head / env / first-layer stages of a block serialise behind them on one wavefront per SIMD
+        self.use_wide = False
         # data_driven on small batches (what the reference trains it on: 72 products): all periods in ONE forward and ONE backward
         # launch (csrc/horizon_rollout.hip).  Measured against the per-period kernels on the real-data shape (tools/
         # horizon_crossover.py, profiles/r04_horizon_crossover.json): 2.3 vs 8.7 ms (replayed) at 72 scenarios, 3.4 vs 10.2 at 4,096,
@@ -369,6 +372,13 @@ class FusedRollout:
             self.Wq = z(Hh // 32, 16, 64)
             self._wq_index = ops.wide_pack_out_index(dims[-1], Hh, dev)
             self._wq_pad = z(32, Hh)
+            if train:   # the backward kernel's packed operands (transposed hidden layers, first layer, logits layer transposed)
+                self.WpkT = [z(Hh // 32, Hh // 8, 64, 4) for _ in range(L - 2)]
+                self._win_index = ops.wide_pack_in_index(self.F, Hh, dev)
+                self._win_pad = z(Hh, 64)
+                self._wot_index = ops.wide_pack_out_t_index(dims[-1], Hh, dev)
+                self._wot_pad = z(2 * ops.wide_ns(dims[-1]), Hh)
+            self._tail_shapes = False   # (one route per shape: the whole-horizon kernels replace the per-period tail launches)
         self.Zc = z(gd[-1], ld) if self.live_rows is not None else None
         self.bias_c = z(gd[-1]) if self.live_rows is not None else None
         if train:
@@ -389,11 +399,16 @@ class FusedRollout:
             self.dZhist = [zpad(T, dims[i + 1], ld) for i in range(L - 1)] if batch else None
             # ... and the logits gradient too, unless the logits layer takes the fused thin-layer backward (per period)
             thin_last = L > 1 and self.use_thin and ops.linear_bwd_thin_ok(gd[L], gd[L - 1])
+            # (the whole-horizon backward kernel leaves the logits gradient history: its layer's weight gradient is contracted over
+            # all periods like the hidden layers')
+            self._wide_bwd = bool(self._wide_shapes and batch)
+            if self._wide_bwd:
+                thin_last = False
             self.dZlast_hist = z(T, gd[-1], ld) if batch and not thin_last else None
             self.dZc = z(gd[-1], ld) if self.live_rows is not None else None
             # slab slots per layer: layers contracted over ALL periods in one launch split the (period x scenario) range into
             # (period groups x scenario chunks) so that a batch of 1,024 or 8,192 scenarios still gives every CU a workgroup
-            by_periods = [batch and not (i > 0 and self.use_thin and ops.linear_bwd_thin_ok(gd[i + 1], gd[i]))
+            by_periods = [batch and (self._wide_bwd or not (i > 0 and self.use_thin and ops.linear_bwd_thin_ok(gd[i + 1], gd[i])))
                           and not (i == L - 1 and self.dZlast_hist is None) for i in range(L)]   # (as _launch_backward decides)
             self.splits = [ops.wgrad_periods_num_splits(gd[i + 1], gd[i], prob.B, T) if by_periods[i]
                            else ops.wgrad_num_splits(gd[i + 1], gd[i], prob.B) for i in range(L)]
@@ -892,11 +907,38 @@ class FusedRollout:
         self._wq_pad[:self.dims[-1]].copy_(lins[L - 1].weight.detach())
         rows, cols = self._wq_index
         self.Wq.copy_(self._wq_pad[rows, cols])
-        desc = ops.wide_rollout_desc(prob, T, self.adj, self._ub_now, bool(self.model.transshipment), demand_soa, shift, self.states,
-                                     self.orders, self.logits, self.rewards, self.hidden if train else None,
+        self._k("wide_fwd", ops.wide_rollout_fwd, self._wide_desc(train))
+
+    def _wide_desc(self, with_hidden):
+        prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
+        return ops.wide_rollout_desc(prob, T, self.adj, self._ub_now, bool(self.model.transshipment), demand_soa, shift, self.states,
+                                     self.orders, self.logits, self.rewards, self.hidden if with_hidden else None,
                                      self.Wt[0][:self.F + 1, :self.gd[1]], self.Wpk, [biases[l] for l in range(1, L - 1)], self.Wq,
                                      biases[L - 1])
-        self._k("wide_fwd", ops.wide_rollout_fwd, desc)
+
+    def _launch_backward_wide(self):
+        """Backward sweep of the wide policy: ONE launch walks the periods in reverse over the histories the forward kernel left and
+        writes every layer's pre-activation gradient history; the weight gradients are then one (period x scenario) contraction
+        per layer, as on the per-period route."""
+        prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
+        lins = self._linears()
+        for l in range(1, L - 1):
+            ops.wide_pack_hidden(lins[l].weight.detach().t(), self.WpkT[l - 1])
+        self._win_pad[:, :self.F].copy_(lins[0].weight.detach())
+        unit, f = self._win_index
+        Wq_in = self._win_pad[unit, f]
+        self._wot_pad[:self.dims[-1]].copy_(lins[L - 1].weight.detach())
+        row, col = self._wot_index
+        Wo_t = self._wot_pad[row, col]
+        self._wide_keep = (Wq_in, Wo_t)
+        desc = self._wide_desc(True)
+        self._k("wide_bwd", ops.wide_rollout_bwd, desc, Table(self.g_reward, 0, 1), self.dZhist, self.dZlast_hist, self.WpkT, Wq_in, Wo_t)
+        for i in range(L):
+            x_hist = self.hidden[i - 1] if i > 0 else self.states[:T, :self.F]
+            dz_hist = self.dZhist[i] if i < L - 1 else self.dZlast_hist
+            self._k(f"wgradT_{self.gd[i + 1]}x{self.gd[i]}", ops.linear_wgrad_periods, dz_hist, x_hist, self.slabs[i], B)
+        for i in range(L):
+            ops.wgrad_reduce(self.slabs[i], self.gw[i], self.gb[i], self.gd[i], 1.0)
 
     def _launch_forward_tail(self):
         """Forward sweep with the fused tail: [first layer of period 0], then per period the hidden-layer GEMMs and ONE tail launch
@@ -955,6 +997,8 @@ class FusedRollout:
 
     def _launch_backward(self):
         prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
+        if self._use_wide() and getattr(self, "_wide_bwd", False):
+            return self._launch_backward_wide()
         if self._use_tail():
             return self._launch_backward_tail()
         ub = self._ub_now

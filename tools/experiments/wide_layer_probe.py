@@ -36,7 +36,7 @@ def main():
         X = torch.randn(H, n, device="cuda")
         Y = torch.empty_like(X)
         stream = torch.cuda.current_stream().cuda_stream
-        for pf in (2, 4, 8):
+        for pf in (2, 4):
             # correctness: one and three chained layers
             for it in (1, 3):
                 assert lib.wide_layer_probe(Wp.data_ptr(), b.data_ptr(), X.data_ptr(), Y.data_ptr(), H, n, n, it, pf, 0, None, stream) == 0
