@@ -62,6 +62,26 @@ def spawn_ranks(n_gpus, argv):
     return 0
 
 
+_REAL_STDOUT = None
+
+
+def _quiet_stdout():
+    """From here on file descriptor 1 is stderr: RCCL writes version banners and warnings to stdout (at communicator set-up and
+    tear-down, some without a trailing newline), and the contract is ONE JSON line there.  The line itself goes out through a
+    duplicate of the original descriptor (`_emit`)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def _emit(out):
+    f = _REAL_STDOUT or sys.stdout
+    f.write(json.dumps(out) + "\n")
+    f.flush()
+
+
 def build_case(workload, device, rank, world, scenarios=None, periods=None, generic_route=False):
     from collections import defaultdict
     from neural_inventory_control_amd import workloads
@@ -395,6 +415,10 @@ def bench_epoch(args):
         tr.use_rollout_graph = True
     elif args.no_graph:
         tr.use_rollout_graph = False
+    if args.tail != "auto":
+        tr.fuse_tail = args.tail == "on"
+    if args.wide != "auto":
+        tr.use_wide = args.wide == "on"
 
     def epoch(loader=None):
         return tr.do_one_epoch(opt, loader or loaders["train"], c["loss_function"], c["simulator"], model, T, pp,
@@ -411,7 +435,8 @@ def bench_epoch(args):
     n_epochs = max(1, (args.steps + n_batches - 1) // n_batches)
     for _ in range(max(1, args.warmup) + 2):   # eager run, auto-graph measurement / capture run, steady state
         epoch()
-    eng = next((e for k, e in tr._engines.items() if k[0] == id(model) and k[-1] is True), None)   # the training-pass engine
+    # the training-pass engine (MLP / GNN engines: the one of the epoch's main batch shape; tape / closed-form: their own keys)
+    eng = tr._engines.get((id(model), True)) or next((e for k, e in tr._engines.items() if k[0] == id(model) and k[-1] is True), None)
     is_gnn, is_tape = type(eng).__name__ == "GnnRollout", type(eng).__name__ == "TapeRollout"
     if world > 1:
         torch.distributed.barrier()
@@ -507,9 +532,9 @@ def bench_epoch(args):
         except Exception as e:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"value": None, "unit": "scenario-steps/s", "cores": None, "host_cores": os.cpu_count(),
                                    "kind": "port", "sample": f"failed: {e!r}"}
-    print(json.dumps(out))
     if parallel.active():
         torch.distributed.destroy_process_group()
+    _emit(out)
 
 
 def main():
@@ -565,6 +590,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
+    _quiet_stdout()
     from neural_inventory_control_amd import workloads as _w
     if args.workload in _w.EPOCH_WORKLOADS:
         return bench_epoch(args)
@@ -639,7 +665,8 @@ def main():
     reducer = parallel.GradientAllReducer.get(model) if sharded else None
     # every rank's device, gathered once: an N-rank job must have run on N distinct devices
     idents = parallel.device_identities(device)
-    if len({(h, d) for _, h, d in idents}) != world:
+    # (enforced for the real backend; the shared-GPU test mode - NIC_DIST_BACKEND=gloo, N ranks on one device - only records it)
+    if len({(h, d) for _, h, d in idents}) != world and (not sharded or torch.distributed.get_backend() == "nccl"):
         print(f"bench.py: {world} ranks but only {len({(h, d) for _, h, d in idents})} distinct devices: {idents}", file=sys.stderr)
         sys.exit(2)
     global_b = n * world
@@ -819,8 +846,8 @@ def main():
                                        "kind": "port", "sample": f"failed: {e!r}"}
     if sharded:
         torch.distributed.destroy_process_group()
-    if rank == 0:   # (after the process group is gone: RCCL prints a version banner on stdout when a communicator is torn down -
-        print(json.dumps(out), flush=True)   # the JSON line stays the LAST line of the output)
+    if rank == 0:   # (the only thing this process writes to its real stdout, see _quiet_stdout)
+        _emit(out)
 
 
 if __name__ == "__main__":

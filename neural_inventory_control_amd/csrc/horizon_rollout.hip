@@ -325,7 +325,13 @@ __global__ __launch_bounds__(kThreads, (MAXS1 == 16 || HZ_FORCE_OCC2) ? 2 : 1) v
     // head_mode 0: the policy MLP + data_driven head.  1: the orders of every period come from a tape (policies that do not read the
     // state: just-in-time).  2: order-up-to levels from a tape (the quantile policies: order = clip(level - pipeline total, 0))
     const int mode = d.head_mode, n_tape = mode == 1 ? n_ord : (mode == 2 ? S : 0);
-    float z1[4], dem_pf[kMaxStores / 16], tape_pf[kMaxOut / 16];
+    // (zero-initialised: a head mode's prefetch only fills the registers that mode reads - z1 with the MLP, tape_pf with a tape -
+    // and the period loop copies all of them forward)
+    float z1[4] = {0.f, 0.f, 0.f, 0.f}, dem_pf[kMaxStores / 16], tape_pf[kMaxOut / 16];
+#pragma unroll
+    for (int i = 0; i < kMaxOut / 16; ++i) tape_pf[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxStores / 16; ++i) dem_pf[i] = 0.f;
     auto prefetch = [&](int t) {
         if (mode == 0) {
 #pragma unroll

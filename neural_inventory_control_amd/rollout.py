@@ -34,6 +34,10 @@ def _pad32(n):
     return (n + 31) // 32 * 32
 
 
+class _HorizonRefused(Exception):
+    """nic_horizon_rollout_ok refused a shape the Python-side plan accepted (FusedRollout.run falls back to the per-period route)."""
+
+
 class KernelTimer:
     """Optional per-launch timing with HIP events recorded on the stream the kernels are launched on (torch's current
     stream).  bench.py uses it to report the dominant kernel's average duration over the timed region."""
@@ -143,6 +147,12 @@ class FusedRollout:
         # DESIGN section 4); larger batches keep the separate, bandwidth-efficient launches
         self.fuse_tail = "auto"
         self.tail_max_scenarios = 16384
+        # the BACKWARD tail launch ("auto"): from this batch size up, and below it whenever the launch sequence is NOT replayed from
+        # a HIP graph.  At the reference's shipped batch of 1,024 its dependent chain (28.7 us per launch, rocprof) is longer than
+        # the three launches it replaces (9.5 + 6.2 + 8.5 us): replayed, the separate launches win (5.17 vs 5.39 ms per batch); launched
+        # eagerly the step is launch-bound and two launches fewer per period win (5.46 vs 6.65 ms at T = 100).  The forward one wins
+        # either way (15.7 against 4.9 + 6.0 + 7.9 us); at 8,192 both win
+        self.tail_bwd_min_scenarios = 2048
         # ... and, for 512-wide hidden layers (BASELINE cfg3), ALL periods in one launch per direction (csrc/wide_rollout.hip): a
         # workgroup carries a block of 32 scenarios through the whole horizon, weights streamed from L2 as pre-packed MFMA fragments.
         # OFF by default: measured it matches the per-period launches at an 8-GPU shard (29.2 vs 28.2 ms at 8,192
@@ -181,6 +191,11 @@ class FusedRollout:
         """the fused per-period tail launches (csrc/period_tail.hip) run for the current shapes and options"""
         return self._tail_shapes and not self._round
 
+    def _use_tail_bwd(self):
+        """the backward tail launch: forced on -> always; "auto" -> from tail_bwd_min_scenarios up, or when launched eagerly"""
+        return (self._use_tail() and getattr(self, "_tail_slots", 0) > 0
+                and (self.fuse_tail is True or self.prob.B >= self.tail_bwd_min_scenarios or not self._graph_on()))
+
     def _graph_on(self):
         return self.use_graph is True or (self.use_graph == "auto" and self._auto_graph is True)
 
@@ -218,7 +233,7 @@ class FusedRollout:
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.E, prob.Ws, prob.Ww, prob.We, self.batch_wgrad, self.use_thin,
                self.eval_history, self.small_wgrad_in_kernel, extra_rows, self.small_lane_scenarios, self.use_horizon,
                self.horizon_max_scenarios, getattr(self, "_shift_hint", 0), self.fuse_tail, self.tail_max_scenarios,
-               self.fuse_head_env, self.use_wide)
+               self.tail_bwd_min_scenarios, self.fuse_head_env, self.use_wide)
         if self._key == key:
             return
         dev, ld = self.device, prob.ldb
@@ -412,8 +427,9 @@ class FusedRollout:
                           and not (i == L - 1 and self.dZlast_hist is None) for i in range(L)]   # (as _launch_backward decides)
             self.splits = [ops.wgrad_periods_num_splits(gd[i + 1], gd[i], prob.B, T) if by_periods[i]
                            else ops.wgrad_num_splits(gd[i + 1], gd[i], prob.B) for i in range(L)]
-            if self._tail_shapes:   # the logits layer's weight gradient: one slab slot per workgroup of the fused tail
-                self.splits[L - 1] = ops.period_tail_bwd_slots(prob.B)
+            # the logits layer's slab serves either backward: one slot per workgroup of the fused tail, or the thin layer's splits
+            self._tail_slots = ops.period_tail_bwd_slots(prob.B) if self._tail_shapes else 0
+            self.splits[L - 1] = max(self.splits[L - 1], self._tail_slots)
             self.slabs = [z(self.splits[i], gd[i + 1], (gd[i] + 1 + 3) // 4 * 4) for i in range(L)]
             self.g_reward, self._g_reward_key = z(ld), None
             self.gw = [torch.zeros_like(m.weight) for m in lins]
@@ -514,8 +530,16 @@ class FusedRollout:
             return self._run_small(data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale,
                                    accumulate_grads, assign_grads)
         if self.horizon is not None:
-            return self._run_horizon(data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale,
-                                     accumulate_grads, assign_grads, observation_params)
+            try:
+                return self._run_horizon(data, prob, T, B, ld, shift, demand_soa, ignore_periods, train, grad_scale,
+                                         accumulate_grads, assign_grads, observation_params)
+            except _HorizonRefused:
+                # the C side's own limits (LDS bytes, 32-bit history offsets: nic_horizon_rollout_ok) said no to a shape the
+                # Python-side plan took: this engine keeps the per-period launches from here on (a fallback, not a launch error)
+                self.use_horizon = False
+                return self.run(data, periods, ignore_periods, train=train, observation_params=observation_params,
+                                demand_soa=demand_soa, grad_scale=grad_scale, accumulate_grads=accumulate_grads,
+                                discrete_allocation=discrete_allocation, assign_grads=assign_grads)
 
         # engine copies of the weights (tiny) — refreshed every call because the optimizer moves them
         lins = self._linears()
@@ -563,10 +587,12 @@ class FusedRollout:
         if grad_scale is None:
             grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
         self._set_g_reward(B, grad_scale)
-        tail = self._use_tail()
+        tail = self._use_tail_bwd()
         for i, sl in enumerate(self.slabs):
-            if not (tail and i == len(self.slabs) - 1):   # (the fused tail's first launch of a sweep overwrites its slab slots)
+            if not (tail and i == len(self.slabs) - 1):
                 sl.zero_()
+            elif sl.shape[0] > self._tail_slots:   # (the fused tail's first launch of a sweep overwrites the slots it uses; the
+                sl[self._tail_slots:].zero_()       # rest - the other backward's splits - must not carry an earlier run's sums)
         if not tail:   # (the fused tail reads no gradient of the state after the last period)
             self.g_state[0].zero_()
         # layers whose backward is ONE fused pass over their input (nic_linear_bwd_thin): thin output, not the first
@@ -785,6 +811,10 @@ class FusedRollout:
         self._k(f"fwdT_{dims[1]}x{Fo}", ops.linear_fwd, self.hz_W1obs[:, :Fo], lins[0].bias.detach(), X[FD:].view(Fo, n_cols),
                 self.hz_z1.view(dims[1], n_cols), n_cols, _lib.NIC_ACT_NONE)
         desc = plan.desc(prob, T, shift, lins, self.edge_mask, demand_soa, n_cols, round_orders=self._round)
+        if getattr(self, "_hz_checked", None) != self._key:   # once per shape: the library's own limits
+            if not hz.horizon_ok(desc):
+                raise _HorizonRefused()
+            self._hz_checked = self._key
         hist = ([X] + self.hz_hist) if train else [None] * 5
         self._k("horizon_fwd", hz.horizon_fwd, desc, self.hz_z1, self.hz_state0, self.rewards, self.hz_final, *hist)
         total = self.rewards.sum()
@@ -814,7 +844,7 @@ class FusedRollout:
         loading is not capturable); timers force eager mode."""
         if not self._graph_on() or self.timer is not None or self._eager_runs < 1:
             return fn()
-        variant = (self._round, self._ctx[4], self.fuse_head_env, self.fuse_tail, self.use_wide)  # options baked into the captured launch sequence
+        variant = (self._round, self._ctx[4], self.fuse_head_env, self.fuse_tail, self.use_wide, self._use_tail_bwd())  # options baked into the captured launch sequence
         if getattr(self, "_graph_variant", variant) != variant:
             self._graphs = {}
         self._graph_variant = variant
@@ -999,7 +1029,7 @@ class FusedRollout:
         prob, T, B, ld, shift, train, Wv, Wtv, biases, L, demand_soa = self._ctx
         if self._use_wide() and getattr(self, "_wide_bwd", False):
             return self._launch_backward_wide()
-        if self._use_tail():
+        if self._use_tail_bwd():
             return self._launch_backward_tail()
         ub = self._ub_now
         g_next, g_cur = self.g_state

@@ -51,6 +51,25 @@ class _FusedTotal(torch.autograd.Function):
         return (None, None) + (None,) * len(ctx.saved_tensors) + tuple(g * d for d in ctx.saved_tensors)
 
 
+_OPTIMIZER_IMPL_KEYS = ("fused", "foreach", "capturable")
+
+
+def _portable_optimizer_state(sd):
+    """An optimizer state dict a DEFAULT torch.optim.Adam can load on any device - the reference's `load_model` calls
+    `optimizer.load_state_dict` on one (trainer.py:300-312): implementation switches (`fused` & co.) are dropped from the parameter
+    groups and the per-parameter `step` counters become host floats (a fused Adam keeps them as device tensors; loaded into a
+    default Adam they would cost a device sync per step, and on a CPU-only box they cannot be stepped at all)."""
+    out = {"state": {}, "param_groups": []}
+    for k, st in sd.get("state", {}).items():
+        st = dict(st)
+        if torch.is_tensor(st.get("step")):
+            st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+        out["state"][k] = st
+    for g in sd.get("param_groups", []):
+        out["param_groups"].append({k: v for k, v in g.items() if k not in _OPTIMIZER_IMPL_KEYS})
+    return out
+
+
 class Trainer:
     def __init__(self, device="cpu"):
         self.all_train_losses = []
@@ -317,7 +336,27 @@ class Trainer:
             eng = self._engines.get((id(model), train))
             if eng is None or eng.model is not model:  # (the engine holds the model, so its id cannot be recycled)
                 eng = self._engines[(id(model), train)] = engine_cls(model, problem_params, self.device)
+            # A batch of ANOTHER shape (the short last batch of an epoch) gets its own engine while a graph mode is on: re-sizing
+            # one engine back and forth drops its buffers, its captured graphs and its measured replay decision - every epoch
+            # would pay a reallocation, an eager run, a probed run and a fresh capture for each of the two shapes.
+            shape = (len(data_batch["demands"]), periods)
+            first = getattr(eng, "_trainer_shape", None)
+            if first is None:
+                eng._trainer_shape = shape
+            elif first != shape and self.use_rollout_graph in (True, "auto"):
+                key2 = (id(model), shape, train)
+                eng2 = self._engines.get(key2)
+                if eng2 is None or eng2.model is not model:
+                    others = [k for k in self._engines if len(k) == 3 and k[0] == id(model) and isinstance(k[1], tuple) and k[2] == train]
+                    for k in others[:-1]:   # (at most two extra shapes per policy and pass: the oldest goes)
+                        del self._engines[k]
+                    eng2 = self._engines[key2] = engine_cls(model, problem_params, self.device)
+                    eng2._trainer_shape = shape
+                eng = eng2
             eng.use_graph = self.use_rollout_graph   # (both engines: True / False / "auto" = by measurement per shape)
+            for opt_ in ("fuse_tail", "use_wide"):   # (A/B switches of the MLP engine's routes: set on the trainer, handed on)
+                if hasattr(self, opt_) and hasattr(eng, opt_):
+                    setattr(eng, opt_, getattr(self, opt_))
             if direct and train:
                 total, reported = eng.run(data_batch, periods, ignore_periods, train=True,
                                           observation_params=observation_params, grad_scale=1.0, assign_grads=False)
@@ -465,7 +504,7 @@ class Trainer:
         torch.save({
             "epoch": epoch,
             "model_state_dict": self.best_performance_data["model_params_to_save"],
-            "optimizer_state_dict": optimizer.state_dict(),
+            "optimizer_state_dict": _portable_optimizer_state(optimizer.state_dict()),
             "best_train_loss": self.best_performance_data["dev_loss"],
             "best_dev_loss": self.all_train_losses,
             "all_train_losses": self.all_train_losses,
@@ -533,7 +572,12 @@ class Trainer:
             warnings.warn(f"{model_path}: falling back to the unsafe pickle loader (allow_pickled_checkpoints)")
             checkpoint = torch.load(model_path, map_location=self.device, weights_only=False)
         model.load_state_dict(checkpoint["model_state_dict"])
-        optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+        # (the implementation switches of THIS optimizer - fused / foreach / capturable - stay its own: a checkpoint written by a
+        # fused Adam must not turn a default one into a fused one, nor the other way round)
+        own = [{k: g.get(k) for k in _OPTIMIZER_IMPL_KEYS if k in g} for g in optimizer.param_groups]
+        optimizer.load_state_dict(_portable_optimizer_state(checkpoint["optimizer_state_dict"]))
+        for g, keep in zip(optimizer.param_groups, own):
+            g.update(keep)
         self.all_train_losses = checkpoint["all_train_losses"]
         self.all_dev_losses = checkpoint["all_dev_losses"]
         self.all_test_losses = checkpoint["all_test_losses"]

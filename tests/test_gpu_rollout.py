@@ -629,8 +629,15 @@ def test_full_size_properties_cfg3():
     states = eng.states.clone()
     orders = eng.orders.clone()
     eng_s = FusedRollout(model, c["problem_params"], DEV)
+    eng_s.fuse_tail = False   # (the same launches as the full batch: bit for bit)
     eng_s.run(small, T, 0, train=False, observation_params=c["observation_params"])
     assert torch.equal(eng_s.per_period_rewards(), r_big)
+    # round 5: a batch this small takes the fused tail launches by default (another association of the same products in the
+    # logits contraction, the first layer's bias inside its contraction): fp32 round-off of the per-period cost
+    eng_t = FusedRollout(model, c["problem_params"], DEV)
+    eng_t.run(small, T, 0, train=False, observation_params=c["observation_params"])
+    assert eng_t._use_tail() and not eng._use_tail()
+    torch.testing.assert_close(eng_t.per_period_rewards(), r_big, rtol=2e-6, atol=1e-4)
     # conservation over all 65,536 scenarios
     S, Ws = 16, 3
     for t in range(T):
@@ -873,6 +880,7 @@ def test_fused_thin_layer_backward_equals_separate_gemms(name):
         model = _model(g, c)
         eng = FusedRollout(model, c["problem_params"], DEV)
         eng.use_thin = thin
+        eng.fuse_tail = False   # (the separate launches are what this test compares)
         eng.materialize(F)
         _load(model, g)
         total, _ = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
@@ -1234,6 +1242,7 @@ def test_fused_head_env_launches_equal_the_separate_ones(name):
         model = _model(g, c)
         eng = FusedRollout(model, c["problem_params"], DEV)
         eng.fuse_head_env = fuse
+        eng.fuse_tail = False   # (round 5: these shapes would otherwise take the fused tail launches, tested further down)
         eng.materialize(eng.input_rows(data, c["observation_params"]))
         _load(model, g)
         from neural_inventory_control_amd.rollout import KernelTimer

@@ -113,7 +113,7 @@ def traffic_pass(rnd, w, out):
     """HBM bytes per launch of every kernel CLASS of a workload: FETCH_SIZE / WRITE_SIZE passes joined, template by template
     and in dispatch order, to the launch sequence bench.py recorded in the same process (--launch-order-out)."""
     few = ["--periods", "8"] if w in ("cfg3", "cfg5", "gnn", "cfg3_shard8") else []
-    args = ["--workload", w, "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + few
+    args = ["--workload", w, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-dist-init"] + few
     order_f = os.path.join(out, f"order_{w}.json")
     fetch = pmc_rows("FETCH_SIZE", os.path.join(out, f"pmc_fetch_{w}"), args + ["--launch-order-out", order_f])
     write = pmc_rows("WRITE_SIZE", os.path.join(out, f"pmc_write_{w}"), args + ["--launch-order-out", order_f])
@@ -171,7 +171,7 @@ def main():
         psteps = (["--steps", "8", "--warmup", "1", "--no-kernel-timing"] if w in epoch else
                   ["--steps", "2", "--warmup", "1"] if w in big else ["--steps", "5", "--warmup", "2"])
         run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", prof, "--", "python3", "bench.py",
-             "--workload", w, "--no-cpu-baseline"] + psteps, os.path.join(out, f"{rnd}_bench_{w}_under_rocprof.json"))
+             "--workload", w, "--no-cpu-baseline", "--no-dist-init"] + psteps, os.path.join(out, f"{rnd}_bench_{w}_under_rocprof.json"))
         traces = glob.glob(os.path.join(prof, "**", "*kernel_trace.csv"), recursive=True)
         if traces:
             stats_from_trace(traces[0], os.path.join(out, f"{rnd}_bench_{w}_kernel_stats.csv"),
