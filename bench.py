@@ -315,6 +315,18 @@ def algorithmic_work(tag, kernel, shape):
                     ("mfma", 2.0 * (no * K + N1 * (F + 1)) * n, "FLOP"))
         return ("hbm", 4.0 * (N1 + 2 * K + 3 * f_state + S + n_ord + no) * n, "B",
                 ("mfma", 2.0 * (F * N1 + 2 * no * K) * n, "FLOP"))
+    if tag == "gnn_period_fwd" and shape.get("gnn"):
+        # the GNN policy's period in one launch (csrc/gnn_period.hip): embeddings stay in LDS, so the HBM side is what the backward
+        # will read - per evaluated (entity, scenario) column the two hidden activations + the output (+ the residual sum), the
+        # aggregation rows (32 x 2 nodes), the node features' pipeline rows - plus the state in / out, demand, orders, reward of the
+        # allocation + env step; an evaluation pass keeps the last line only.  MFMA work of the five MLPs as `other`.
+        g = shape["gnn"]
+        n_nodes = g["initial_node"][2]
+        hist = sum((64 + n_out + (n_out if name in ("node_update", "edge_update") else 0)) * n_ent for name, (K, n_out, n_ent, _) in g.items())
+        hist += 32 * 2 * n_nodes + f_state
+        env = 2 * f_state + S + n_ord + 3 + 1 + g["output"][2]
+        flops = sum(2.0 * (K * 32 + 32 * 32 + 32 * n_out) * n_ent for K, n_out, n_ent, _ in g.values())
+        return "hbm", 4.0 * ((hist if shape["train"] else 0) + env) * n, "B", ("mfma", flops * n, "FLOP")
     if tag in ("alloc_env_fwd", "alloc_env_bwd"):   # GNN: allocation head + env step in one launch (one warehouse)
         n_edges = shape["gnn"]["output"][2] if shape.get("gnn") else S + 2
         if tag == "alloc_env_fwd":  # state read + write, demand, desired quantities of the member / self / supplier edges, orders, sums / ratio / scale, reward
@@ -567,6 +579,8 @@ def main():
                     help="A/B: run the workload on the generic per-period route even where a fused engine exists")
     ap.add_argument("--lane-scenarios", type=int, default=0, choices=(0, 16, 32),
                     help="whole-horizon route: scenarios per wavefront (0 = chosen by the library from the batch size)")
+    ap.add_argument("--gnn-period", choices=("auto", "on", "off"), default="auto",
+                    help="gnn: the forward of a period as ONE launch (csrc/gnn_period.hip): the engine's choice, forced on, forced off")
     ap.add_argument("--gnn-keep-inputs", action="store_true",
                     help="gnn: keep a copy of the gathered MLP inputs for the backward instead of reading them again (A/B)")
     ap.add_argument("--eval", action="store_true",
@@ -634,6 +648,7 @@ def main():
     if gnn:
         if args.gnn_keep_inputs:
             eng.keep_inputs = True
+        eng.use_period_kernel = {"auto": "auto", "on": True, "off": False}[args.gnn_period]
         eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
         parallel.broadcast_model(model, src=0)
     elif closed_form:

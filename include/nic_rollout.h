@@ -609,6 +609,62 @@ int nic_gnn_alloc_env_bwd(const NicEnvStepIO* io, const float* out, const float*
                           const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_orders, float* d_out,
                           void* stream);
 
+/* ---- the GNN policy's whole period in ONE launch (csrc/gnn_period.hip) ------------------------------------------
+ * initial_node -> initial_edge -> message aggregation -> node_update -> edge_update -> output (neural_networks.py:1105-1392),
+ * and on one-warehouse graphs the proportional allocation + Simulator.step behind them (what nic_gnn_alloc_env_fwd does): a
+ * workgroup owns 16 scenarios and keeps their node / edge embeddings in LDS between the five MLPs, so no embedding is read
+ * back from HBM inside a period.  What the launches above would have written for the backward (Y of every MLP, the residual
+ * sums, the aggregation, the hidden histories in nic_mlp3's NATIVE layout, the pipeline rows of the node features) is written
+ * when the pointers are given - nic_mlp3_bwd_hist then runs unchanged on it; an evaluation pass gives none and writes only the
+ * desired quantities, the next state and the reward.
+ * MLP order: 0 initial_node, 1 initial_edge, 2 node_update, 3 edge_update, 4 output.  Edges [0, n_live) are the ones the edge
+ * update / output MLPs are evaluated for (GraphPlan keeps the demand edges last).
+ * Packed weights of one MLP (first-layer rows in the order its inputs are contracted in, see ops.gnn_period_pack):
+ *   [L1: 2 row blocks x s1q groups x 64 lanes x 4][b1 32][L2: 2 x 2 x 64 x 4][b2 32][L3: nrb3 x 2 x 64 x 4][b3 32 (zero padded)],
+ *   fragment (rb, q, lane, j) of layer l = W_l[16 rb + (lane & 15)][k_l(4 q + j, lane >> 4)], 0 where k is past the layer's
+ *   inputs; layers 2 / 3: k(s, g) = 16 (s >> 2) + 4 g + (s & 3); layer 1: the same map per 32-row embedding segment, rows
+ *   4 s + g for the node features, row 64 at (s = 16, g = 0) for the edge MLP's lead time. */
+typedef struct NicGnnPeriodMlp {
+    const float* wpk;      /* packed weights, nic_gnn_period_pack_size(s1q, n_out) floats, 16-byte aligned */
+    float* Y;              /* [n_out][entities][ldb] (rows row_stride apart) or NULL; the output MLP's [1][n_edges][ldb] is required */
+    float* Ysum;           /* node_update: nodes1 = nodes0 + Y; edge_update: edges1 = edges0 + Y; else NULL */
+    float* H1;             /* hidden activations in nic_mlp3's native layout (NicMlp3Desc.hist_native), or NULL */
+    float* H2;
+    int64_t row_stride;    /* elements between feature rows of Y / Ysum */
+} NicGnnPeriodMlp;
+typedef struct NicGnnPeriod {
+    int32_t n_nodes, n_edges, n_live, n_scenarios, ldb;
+    int32_t Dn, max_inv;          /* node feature rows; the first max_inv are pipeline slots (zero past a node's own length) */
+    int32_t store_feat;           /* 1: write the pipeline rows of `feat` (the backward of initial_node reads them there) */
+    int32_t fuse_env;             /* 1: allocation head + env step behind the policy (one warehouse) */
+    int32_t e_self, e_supplier, cap_at_one;   /* as nic_gnn_alloc_env_fwd */
+    int32_t wb0_floats, wb1_floats;           /* set by the library */
+    const int32_t* src;           /* [n_edges] source / target node of an edge, -1: the virtual (all-zero) node */
+    const int32_t* tgt;
+    const int32_t* agg_off;       /* [2 n_nodes + 1]: CSR lists of a node's incoming edges, then of its outgoing edges */
+    const int32_t* agg_items;
+    const float* agg_scale;       /* [2 n_nodes] 1 / sqrt(degree) */
+    const float* lead;            /* [n_edges] per-edge lead-time input */
+    const int32_t* node_row0;     /* [n_nodes] first row of the node's pipeline in `state` */
+    const int32_t* node_slots;    /* [n_nodes] its length */
+    const float* state;           /* [rows][ldb] inventory state before the period */
+    float* feat;                  /* [Dn][n_nodes][ldb] node features: static rows (>= max_inv) read, pipeline rows written */
+    float* agg;                   /* [32][2 n_nodes][ldb] or NULL */
+    NicGnnPeriodMlp mlp[5];
+    NicEnvStepIO io;              /* fuse_env: as for nic_gnn_alloc_env_fwd */
+    float* orders;                /* [S + 1][ldb] */
+    float* sums;
+    float* ratio;
+    float* scale;
+    float* store_out;
+    float* wh_out;
+    float* reward;
+} NicGnnPeriod;
+int nic_gnn_period_pack_size(int32_t s1q, int32_t n_out);
+/* 1 if a graph's embeddings (n_nodes + n_edges tiles of 2 KB) and the staged weights fit in a workgroup's LDS */
+int nic_gnn_period_ok(int32_t n_nodes, int32_t n_edges, int32_t Dn);
+int nic_gnn_period_fwd(const NicGnnPeriod* p, void* stream);
+
 /* The same allocation for SEVERAL supplying nodes (many-warehouse graphs: `_apply_proportional_allocation_to_graph`,
  * neural_networks.py:1435-1492, loops over every node with outgoing edges).  groups [n_groups][4] (device) = {first member edge,
  * member count, self-loop edge or -1, supplier edge} per warehouse - its internal edges are contiguous rows of `out`;

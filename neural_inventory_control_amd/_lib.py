@@ -105,6 +105,20 @@ class NicMlp3Desc(C.Structure):
                    ("ent_row_stride", C.c_int64)])
 
 
+class NicGnnPeriodMlp(C.Structure):
+    _fields_ = [("wpk", C.c_void_p), ("Y", C.c_void_p), ("Ysum", C.c_void_p), ("H1", C.c_void_p), ("H2", C.c_void_p),
+                ("row_stride", C.c_int64)]
+
+
+class NicGnnPeriod(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("n_nodes", "n_edges", "n_live", "n_scenarios", "ldb", "Dn", "max_inv", "store_feat",
+                                          "fuse_env", "e_self", "e_supplier", "cap_at_one", "wb0_floats", "wb1_floats")]
+                + [(n, C.c_void_p) for n in ("src", "tgt", "agg_off", "agg_items", "agg_scale", "lead", "node_row0", "node_slots",
+                                             "state", "feat", "agg")]
+                + [("mlp", NicGnnPeriodMlp * 5), ("io", NicEnvStepIO)]
+                + [(n, C.c_void_p) for n in ("orders", "sums", "ratio", "scale", "store_out", "wh_out", "reward")])
+
+
 NIC_MLP3_MAX_K, NIC_MLP3_ACT_NONE, NIC_MLP3_ACT_ELU, NIC_MLP3_ACT_SOFTPLUS = 96, 0, 1, 2
 NIC_CF_MAX_LEVELS = 5
 NIC_CF_BASE_STOCK, NIC_CF_CAPPED, NIC_CF_ECHELON = 0, 1, 2
@@ -165,6 +179,9 @@ PROTOTYPES = {
     "nic_horizon_rollout_bwd": (C.c_int, [C.POINTER(NicHorizonDesc), _vp, _vp, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp]),
     "nic_gnn_alloc_env_fwd": (C.c_int, [_IOP, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "nic_gnn_alloc_env_bwd": (C.c_int, [_IOP, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp]),
+    "nic_gnn_period_pack_size": (C.c_int, [_i32, _i32]),
+    "nic_gnn_period_ok": (C.c_int, [_i32, _i32, _i32]),
+    "nic_gnn_period_fwd": (C.c_int, [C.POINTER(NicGnnPeriod), _vp]),
     "nic_round_orders": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "nic_mlp3_fwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp]),
     "nic_mlp3_fwd_residual": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -28,6 +28,7 @@ SOURCES = [
     ("horizon_rollout.hip", ["-ffp-contract=off"]),
     ("mlp3.hip", []),
     ("gnn_alloc_env.hip", ["-ffp-contract=off"]),
+    ("gnn_period.hip", ["-ffp-contract=off"]),
 ]
 HEADERS = ["nic_common.h", "env_step_body.h", "policy_heads_body.h", "tail_pieces.h", "small_rollout_body.h", "small_rollout16.h", "closed_form_body.h", "gnn_alloc_body.h", os.path.join("..", "..", "include", "nic_rollout.h")]
 ARCH = "gfx950"

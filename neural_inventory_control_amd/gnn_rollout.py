@@ -246,6 +246,10 @@ class GnnRollout:
         # shipped batch of 1,024 scenarios: 19.2 -> 14.6 ms per step; 8,192 scenarios are GPU-bound and stay eager)
         self.use_graph = False
         self.fuse_alloc_env = True   # one-warehouse graphs: allocation head + env step (and their adjoints) in one launch each
+        # Forward of a period as ONE launch (csrc/gnn_period.hip: the five MLPs on embeddings held in LDS, + allocation and env step
+        # on one-warehouse graphs) instead of ~8: "auto" = wherever the graph's embeddings fit in LDS and the backward reads the
+        # native histories (or nothing); True raises where that does not hold; False = the per-MLP launches
+        self.use_period_kernel = "auto"
         self._auto_graph = None
         self.auto_graph_probe = None
         self._probs = ProblemCache()
@@ -273,7 +277,7 @@ class GnnRollout:
 
     def _setup(self, prob, data, T, train):
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.Ws, prob.Ww, self.fused_bwd, self.keep_inputs,
-               data.get("warehouse_edge_costs") is not None)
+               data.get("warehouse_edge_costs") is not None, self.use_period_kernel)
         if key == self._key:
             return
         dev, ld, S = self.device, prob.ldb, prob.S
@@ -323,6 +327,21 @@ class GnnRollout:
                                n_live=P.n_live if name in ("edge_update", "output") else None)
                     for name, k, ne in zip(MODULES, ks, ents)}
         self._graphs, self._eager_runs, self._auto_graph = {}, 0, None   # (a new shape is measured afresh)
+        self._period, self._pdesc = False, {}
+        if self.use_period_kernel:
+            fits = ops.gnn_period_ok(N, E, self.Dn)
+            hist_ok = (not train) or self._mode_now == "fused" or (self._mode_now == "hist" and self.mlp["output"].native)
+            if fits and hist_ok:
+                kmaps = ops.gnn_period_kmaps(self.Dn)
+                self.ppack = {name: ops.GnnPeriodPack(self._linears(name), kmaps[name], 1 if name == "output" else 32, dev)
+                              for name in MODULES}
+                i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)  # noqa: E731
+                self.node_row0 = i32([self.F_store + w * prob.Ww for w in range(Wn)] + [s_ * prob.Ws for s_ in range(S)])
+                self.node_slots = i32([prob.Ww] * Wn + [prob.Ws] * S)
+                self._period = True
+            elif self.use_period_kernel is True:
+                raise ValueError("use_period_kernel: " + ("the backward mode keeps row-layout histories" if fits else
+                                                          f"{N} nodes + {E} edges do not fit in a workgroup's LDS"))
         self.agg = z(T, 32, 2 * N, ld)   # message aggregation: [:, :N] over incoming edges, [:, N:] over outgoing edges
         self.nodes1, self.edges1 = z(T, 32, N, ld), z(T, 32, E, ld)
         self.sums, self.ratio, self.scale = z(T, Wn, ld), z(T, Wn, ld), z(T, Wn, ld)
@@ -366,6 +385,10 @@ class GnnRollout:
         self.demand = demand_soa
         for m in self.mlp.values():
             m.pack()
+        self._train = bool(train)
+        if self._period:
+            for pk in self.ppack.values():
+                pk.pack()
         # per-edge lead-time input rows: sample 0 of THIS batch stands for the batch, as upstream re-reads it every forward
         # (:984) - refreshed on the device (no sync, capturable), so a later batch of the same shape never sees stale values
         P.lead[0, :P.n_int].copy_(data["lead_times"][0][P.lead_store, P.lead_wh])
@@ -493,9 +516,50 @@ class GnnRollout:
         m.fold_rows = m.n_out if Ysum is not None else 0
         self._k("mlp3_fwd_" + name, ops.mlp3_fwd, self._desc(m, segs[name], prob), m.Y[t], *hist, residual, Ysum)
 
+    def _period_desc(self, t, prob, demand_soa, shift):
+        """`NicGnnPeriod` of period t (cached: every buffer it names is engine-owned and fixed for a shape)."""
+        key = (demand_soa.data_ptr(), shift, self._train, id(prob))
+        d = self._pdesc.get(t)
+        if d is not None and d._key == key:
+            return d
+        P, ld, S, train = self.plan, prob.ldb, prob.S, self._train
+        d = _lib.NicGnnPeriod()
+        d.n_nodes, d.n_edges, d.n_live, d.n_scenarios, d.ldb = P.n_nodes, P.n_edges, P.n_live, prob.B, ld
+        d.Dn, d.max_inv, d.store_feat = self.Dn, self.max_inv, int(train)
+        p = _lib.ptr
+        d.src, d.tgt, d.agg_off, d.agg_items, d.agg_scale = p(P.src), p(P.tgt), p(P.agg_off), p(P.agg_items), p(P.agg_scale)
+        d.lead, d.node_row0, d.node_slots = p(P.lead), p(self.node_row0), p(self.node_slots)
+        d.state, d.feat = p(self.states[t]), p(self.feat[t])
+        d.agg = p(self.agg[t]) if train else None
+        for i, name in enumerate(MODULES):
+            m, q = self.mlp[name], d.mlp[i]
+            q.wpk, q.row_stride = p(self.ppack[name].buf), m.n_ent * ld
+            q.Y = p(m.Y[t]) if (train or name == "output") else None
+            if train and m.mode == "hist":
+                q.H1, q.H2 = p(m.hist(m.H1, t)), p(m.hist(m.H2, t))
+        if train:
+            d.mlp[2].Ysum, d.mlp[3].Ysum = p(self.nodes1[t]), p(self.edges1[t])
+        d.fuse_env = int(P.Wn == 1 and bool(self.fuse_alloc_env))
+        if d.fuse_env:
+            st, nxt, orders = self._views(self.states[t], prob), self._views(self.states[t + 1], prob), self.orders[t]
+            d.io = prob.make_io(st.store, st.wh, None, Table(demand_soa[t + shift], ld, 1), Table(orders[:S].view(S, 1, -1), ld, 1, ld),
+                                Table(orders[S:], ld, 1), None)
+            d.e_self, d.e_supplier, d.cap_at_one = (-1 if P.e_self is None else P.e_self), P.e_supplier, int(not P.transshipment)
+            d.orders, d.sums, d.ratio, d.scale = p(orders), p(self.sums[t]), p(self.ratio[t]), p(self.scale[t])
+            d.store_out, d.wh_out, d.reward = p(nxt.store), p(nxt.wh), p(self.rewards[t])
+        d._key = key
+        self._pdesc[t] = d
+        return d
+
     def _forward_period(self, t, prob, demand_soa, shift):
         P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
         st = self._views(self.states[t], prob)
+        if self._period:
+            d = self._period_desc(t, prob, demand_soa, shift)
+            self._k("gnn_period_fwd", ops.gnn_period_fwd, d)
+            if not d.fuse_env:
+                self._alloc_env_fwd(t, prob, demand_soa, shift, st)
+            return
         # node features: pipelines, padded to the longest one (:846-905)
         self.feat[t].view(-1, ld).index_copy_(0, self.feat_rows, self.states[t])
         segs = self._segments(t)
@@ -506,6 +570,10 @@ class GnnRollout:
         self._run_mlp("node_update", t, segs, prob, M["initial_node"].Y[t], self.nodes1[t])   # nodes1 = nodes0 + update
         self._run_mlp("edge_update", t, segs, prob, edges0, self.edges1[t])                   # edges1 = edges0 + update
         self._run_mlp("output", t, segs, prob)
+        self._alloc_env_fwd(t, prob, demand_soa, shift, st)
+
+    def _alloc_env_fwd(self, t, prob, demand_soa, shift, st):
+        P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
         out = M["output"].Y[t][0]                                  # [E][ld] desired quantity per edge
         # proportional allocation of the warehouse's on-hand stock over its outgoing edges + self loop (:111-138, :1435-1492)
         orders = self.orders[t]

@@ -451,6 +451,81 @@ def mlp3_bwd_hist(desc, dY, Y, X_hist, H1, H2, dX, slabs):
                                   s2.stride(1), ptr(s3), s3.stride(1), current_stream()))
 
 
+# ---- the GNN policy's period in one launch (csrc/gnn_period.hip) -------------------------------------------------------------
+
+GNN_PERIOD_MLPS = ("initial_node", "initial_edge", "node_update", "edge_update", "output")
+
+
+def gnn_period_ok(n_nodes, n_edges, Dn):
+    """True if a graph's embeddings and the staged weights fit in a workgroup's LDS (nic_gnn_period_ok)."""
+    return bool(lib().nic_gnn_period_ok(int(n_nodes), int(n_edges), int(Dn)))
+
+
+def _frag32(base):
+    """contraction steps of a 32-row operand held as an embedding tile: step s, lane group g -> row base + 16 (s >> 2) + 4 g + (s & 3)"""
+    return [[base + 16 * (s >> 2) + 4 * g + (s & 3) for g in range(4)] for s in range(8)]
+
+
+def gnn_period_kmaps(Dn):
+    """First-layer contraction order of the five MLPs (which input row lane group g feeds into step s; -1: none), each padded to
+    groups of four steps - the layout `nic_gnn_period_fwd` contracts in (include/nic_rollout.h)."""
+    pad = lambda steps: steps + [[-1] * 4] * (-len(steps) % 4)  # noqa: E731
+    node = [[4 * s_ + g if 4 * s_ + g < Dn else -1 for g in range(4)] for s_ in range(4 * ((Dn + 15) // 16))]
+    return {"initial_node": node,
+            "initial_edge": pad(_frag32(0) + _frag32(32) + [[64, -1, -1, -1]]),
+            "node_update": _frag32(0) + _frag32(32) + _frag32(64),
+            "edge_update": _frag32(0) + _frag32(32) + _frag32(64),
+            "output": _frag32(0)}
+
+
+def gnn_period_pack_index(kmap, K, nrb, device):
+    """Gather index into a [16 nrb][K + 1] weight matrix (last column zero) that lays a layer out as MFMA A fragments
+    [rb][group of 4 steps][lane][4]: (rb, q, lane, j) -> W[16 rb + (lane & 15)][kmap[4 q + j][lane >> 4]]."""
+    sq = len(kmap) // 4
+    lane = torch.arange(64)
+    km = torch.tensor(kmap, dtype=torch.long)                       # [steps][4]
+    km = torch.where(km < 0, torch.full_like(km, K), km)
+    col = km.view(sq, 4, 4)[:, :, lane >> 4].permute(0, 2, 1)       # [sq][lane][j]
+    row = (16 * torch.arange(nrb).view(nrb, 1) + (lane & 15).view(1, 64))   # [nrb][lane]
+    idx = row.view(nrb, 1, 64, 1) * (K + 1) + col.view(1, sq, 64, 4)
+    return idx.reshape(-1).to(device)
+
+
+class GnnPeriodPack:
+    """Packed weights of one MLP for `nic_gnn_period_fwd`, refreshed from the live parameters by `pack()`."""
+
+    def __init__(self, linears, kmap, n_out, device):
+        self.linears = linears
+        K = linears[0].weight.shape[1]
+        self.K, self.n_out, self.nrb3 = K, n_out, (2 if n_out > 16 else 1)
+        self.s1q = len(kmap) // 4
+        self.idx = [gnn_period_pack_index(kmap, K, 2, device), gnn_period_pack_index(_frag32(0), 32, 2, device),
+                    gnn_period_pack_index(_frag32(0), 32, self.nrb3, device)]
+        n = lib().nic_gnn_period_pack_size(self.s1q, n_out)
+        self.buf = torch.zeros(n, device=device)
+        self._pad = [torch.zeros(32, K + 1, device=device), torch.zeros(32, 33, device=device),
+                     torch.zeros(16 * self.nrb3, 33, device=device)]
+        assert n == sum(i.numel() for i in self.idx) + 96
+
+    def pack(self):
+        o = 0
+        for i, lin in enumerate(self.linears):
+            w, b = lin.weight.detach(), lin.bias.detach()
+            pad = self._pad[i]
+            pad[:w.shape[0], :w.shape[1]] = w
+            n = self.idx[i].numel()
+            torch.index_select(pad.view(-1), 0, self.idx[i], out=self.buf[o:o + n])
+            o += n
+            self.buf[o:o + b.numel()] = b
+            o += 32
+        return self.buf
+
+
+def gnn_period_fwd(desc):
+    _lib.require_device()
+    check(lib().nic_gnn_period_fwd(desc, current_stream()))
+
+
 def segment_sum_terms(dst, terms, accumulate=False):
     """dst [R][n_dst][ldb] = (accumulate ? dst : 0) + sum over terms, in order.  A term is (src, offsets, items, scale) - a segment
     sum of src's [R][.][ldb] rows - or (src, None, None, scale): src's own row n.  One launch (nic_segment_sum_terms)."""

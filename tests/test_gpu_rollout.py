@@ -1680,6 +1680,7 @@ def test_gnn_fused_alloc_env_launches_equal_the_separate_ones(name):
         model = _model(g, c)
         eng = GnnRollout(model, c["problem_params"], DEV)
         eng.fuse_alloc_env = fused
+        eng.use_period_kernel = False   # (the period kernel carries the allocation + env step itself; this is about the two launches)
         eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
         _load(model, g)
         eng.timer = KernelTimer(record_order=True)
@@ -1693,6 +1694,46 @@ def test_gnn_fused_alloc_env_launches_equal_the_separate_ones(name):
     for x, y in zip(a[4], b[4]):
         assert torch.equal(x, y)
     assert abs(a[0] - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
+
+
+@pytest.mark.parametrize("mode", ["hist", True, "eval"])
+@pytest.mark.parametrize("name", GNN_CASES)
+def test_gnn_period_kernel_matches_the_per_mlp_launches(name, mode):
+    """Round 5: ONE forward launch per period (csrc/gnn_period.hip: the five MLPs on node / edge embeddings held in LDS, then
+    allocation + env step on one-warehouse graphs) against the per-MLP launches of csrc/mlp3.hip on the same weights and batch.
+    Other MFMA shape, other accumulation order: equal to rounding (costs 1e-6, gradients 1e-5 per tensor), and the golden total."""
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout
+    from neural_inventory_control_amd.rollout import KernelTimer
+    g = Golden(name)
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    train = mode != "eval"
+    out = {}
+    for period in (True, False):
+        model = _model(g, c)
+        eng = GnnRollout(model, c["problem_params"], DEV)
+        eng.use_period_kernel = period
+        if train:
+            eng.fused_bwd = mode
+        eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+        _load(model, g)
+        eng.timer = KernelTimer(record_order=True)
+        total, rep = eng.run(data, c["periods"], c["ignore"], train=train, observation_params=c["observation_params"])
+        torch.cuda.synchronize()
+        tags = {t for t, _ in eng.timer.order}
+        assert ("gnn_period_fwd" in tags) == period and ("mlp3_fwd_initial_node" in tags) != period
+        if period and c["problem_params"]["n_warehouses"] == 1:
+            assert "alloc_env_fwd" not in tags and "env_fwd" not in tags    # allocation + env step ran inside the launch
+        out[period] = (float(total), float(rep), eng.rewards.clone(), eng.states[-1].clone(),
+                       [p.grad.clone() for p in model.parameters()] if train else [])
+    a, b = out[True], out[False]
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(b[1])
+    torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(a[3], b[3], rtol=1e-5, atol=1e-4)
+    for x, y in zip(a[4], b[4]):
+        assert float((x - y).norm() / (y.norm() + 1e-30)) <= 1e-5
+    want = _Expected(g, c).total
+    assert abs(a[0] - want) <= 1e-5 * abs(want)
 
 
 @pytest.mark.parametrize("setting_name", ["cfg3", "cfg2"])
