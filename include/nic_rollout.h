@@ -638,7 +638,8 @@ typedef struct NicGnnPeriod {
     int32_t store_feat;           /* 1: write the pipeline rows of `feat` (the backward of initial_node reads them there) */
     int32_t fuse_env;             /* 1: allocation head + env step behind the policy (one warehouse) */
     int32_t e_self, e_supplier, cap_at_one;   /* as nic_gnn_alloc_env_fwd */
-    int32_t wb0_floats, wb1_floats;           /* set by the library */
+    int32_t n_agg_items;                      /* length of agg_items */
+    int32_t wb0_floats, wb1_floats, tab_words;   /* set by the library */
     const int32_t* src;           /* [n_edges] source / target node of an edge, -1: the virtual (all-zero) node */
     const int32_t* tgt;
     const int32_t* agg_off;       /* [2 n_nodes + 1]: CSR lists of a node's incoming edges, then of its outgoing edges */

@@ -112,7 +112,7 @@ class NicGnnPeriodMlp(C.Structure):
 
 class NicGnnPeriod(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("n_nodes", "n_edges", "n_live", "n_scenarios", "ldb", "Dn", "max_inv", "store_feat",
-                                          "fuse_env", "e_self", "e_supplier", "cap_at_one", "wb0_floats", "wb1_floats")]
+                                          "fuse_env", "e_self", "e_supplier", "cap_at_one", "n_agg_items", "wb0_floats", "wb1_floats", "tab_words")]
                 + [(n, C.c_void_p) for n in ("src", "tgt", "agg_off", "agg_items", "agg_scale", "lead", "node_row0", "node_slots",
                                              "state", "feat", "agg")]
                 + [("mlp", NicGnnPeriodMlp * 5), ("io", NicEnvStepIO)]

@@ -9,19 +9,22 @@
 namespace nic {
 constexpr int kAllocBatch = 8;
 
-__device__ __forceinline__ void gnn_alloc_fwd_one(const float* __restrict__ out, const float* __restrict__ on_hand,
-                                                  float* __restrict__ orders, float* __restrict__ sums, float* __restrict__ ratio,
-                                                  float* __restrict__ scale, int S, int e_self, int e_sup, int cap_at_one, int64_t b,
-                                                  int64_t ldb) {
+// `out` rows are out_ld apart and this scenario is column out_b of them (the period kernel keeps the desired quantities of its
+// 16 scenarios in LDS: out_ld = 16, out_b = the scenario's index in the block); everything else is indexed by (b, ldb).
+__device__ __forceinline__ void gnn_alloc_fwd_one(const float* __restrict__ out, int64_t out_ld, int64_t out_b,
+                                                  const float* __restrict__ on_hand, float* __restrict__ orders,
+                                                  float* __restrict__ sums, float* __restrict__ ratio, float* __restrict__ scale, int S,
+                                                  int e_self, int e_sup, int cap_at_one, int64_t b, int64_t ldb) {
 #pragma clang fp contract(off)   // separate multiplies and adds, like the aten ops this replaces
     // rows fetched kAllocBatch at a time (unconditionally: a row past S reads row 0 and is dropped by a select), then added in
     // store order - as `sum += out[s]` in a loop with a run-time trip count every row was one dependent memory round trip
-    const float oh = on_hand[b], self_v = out[(int64_t)(e_self >= 0 ? e_self : 0) * ldb + b], sup_v = out[(int64_t)e_sup * ldb + b];
+    const float oh = on_hand[b], self_v = out[(int64_t)(e_self >= 0 ? e_self : 0) * out_ld + out_b],
+                sup_v = out[(int64_t)e_sup * out_ld + out_b];
     float sum = 0.f;
     for (int s0 = 0; s0 < S; s0 += kAllocBatch) {
         float v[kAllocBatch];
 #pragma unroll
-        for (int u = 0; u < kAllocBatch; ++u) v[u] = out[(int64_t)(s0 + u < S ? s0 + u : 0) * ldb + b];
+        for (int u = 0; u < kAllocBatch; ++u) v[u] = out[(int64_t)(s0 + u < S ? s0 + u : 0) * out_ld + out_b];
 #pragma unroll
         for (int u = 0; u < kAllocBatch; ++u) sum = s0 + u < S ? sum + v[u] : sum;
     }
@@ -34,12 +37,18 @@ __device__ __forceinline__ void gnn_alloc_fwd_one(const float* __restrict__ out,
     for (int s0 = 0; s0 < S; s0 += kAllocBatch) {
         float v[kAllocBatch];
 #pragma unroll
-        for (int u = 0; u < kAllocBatch; ++u) v[u] = out[(int64_t)(s0 + u < S ? s0 + u : 0) * ldb + b];
+        for (int u = 0; u < kAllocBatch; ++u) v[u] = out[(int64_t)(s0 + u < S ? s0 + u : 0) * out_ld + out_b];
 #pragma unroll
         for (int u = 0; u < kAllocBatch; ++u)
             if (s0 + u < S) orders[(int64_t)(s0 + u) * ldb + b] = v[u] * sc;
     }
     orders[(int64_t)S * ldb + b] = sup_v;
+}
+__device__ __forceinline__ void gnn_alloc_fwd_one(const float* __restrict__ out, const float* __restrict__ on_hand,
+                                                  float* __restrict__ orders, float* __restrict__ sums, float* __restrict__ ratio,
+                                                  float* __restrict__ scale, int S, int e_self, int e_sup, int cap_at_one, int64_t b,
+                                                  int64_t ldb) {
+    gnn_alloc_fwd_one(out, ldb, b, on_hand, orders, sums, ratio, scale, S, e_self, e_sup, cap_at_one, b, ldb);
 }
 
 // adjoint: g_orders [S+1][ldb] -> d_out [E][ldb] (every row written) and g_on_hand[b] += d_scale / (sum + eps).

@@ -23,10 +23,11 @@
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int NB = 16;          // scenarios per workgroup
-constexpr int kWaves = 8;
-constexpr int kThreads = kWaves * 64;
+// wavefronts per workgroup: 16 (four per SIMD: a tile's layers are a dependent MFMA -> ELU -> store chain, so a SIMD needs several
+// wavefronts in different phases to keep its matrix pipe fed) where the kernel fits in 128 registers, else 8
 constexpr int kTile = 512;      // floats of one entity's embedding tile
-constexpr int kEnvChunk = 8;
+constexpr int kEnvChunk = 1;                       // (the fused allocation + env step is for ONE warehouse)
+constexpr int kEnvScratch = (kEnvChunk + 1) * 4 * NB + NB;   // floats: quad partial sums, store costs, the warehouse's cost
 
 #ifdef NIC_TUNING_BUILD
 __device__ unsigned long long* g_gnn_stamps = nullptr;
@@ -35,8 +36,17 @@ __device__ unsigned long long* g_gnn_stamps = nullptr;
         if (g_gnn_stamps != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0)                \
             g_gnn_stamps[(threadIdx.x >> 6) * 16 + (point)] = wall_clock64();                     \
     } while (0)
+// ... and inside ONE tile (the first initial-edge tile of every wavefront): points 8..15, pinned by scheduling barriers
+#define GNN_TILE_STAMP(on, point)                                                                 \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if ((on) && g_gnn_stamps != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0)        \
+            g_gnn_stamps[(threadIdx.x >> 6) * 16 + (point)] = wall_clock64();                     \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
 #else
 #define GNN_STAMP(point) do { } while (0)
+#define GNN_TILE_STAMP(on, point) do { } while (0)
 #endif
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -94,25 +104,42 @@ __device__ __forceinline__ void l1_tile(const MlpL& W, int q0, const float* tile
     l1_group(W, q0 + 1, x1, lane, A);
 }
 
-// Where a tile's rows go in HBM (training runs): row r of the tile lives at p[r * row_stride] (+ the lane's scenario).
+// Where a tile's rows go in HBM (training runs): a buffer descriptor based at (row 0, the entity's column, the block's first
+// scenario); a store adds the row as a SCALAR offset and the lane's (4 g rows + scenario) as one 32-bit offset - no 64-bit address
+// per row in vector registers.  An absent output has zero records (its stores are dropped by the range check), and so is the
+// lane offset of a scenario past the batch.
 struct RowOut {
-    float* p;            // column (entity, first scenario of the block), or nullptr
-    int64_t row_stride;
+    __amdgpu_buffer_rsrc_t r;
+    int row_bytes;
 };
+__device__ __forceinline__ RowOut row_out(float* p, int64_t row_stride) {
+    static __device__ float sink;
+    RowOut o;
+    o.r = __builtin_amdgcn_make_buffer_rsrc(p ? p : &sink, 0, p ? 0x7fffffff : 0, 0x00020000);
+    o.row_bytes = (int)row_stride * 4;
+    return o;
+}
+constexpr int kDeadLane = 0x7fffffff;
 __device__ __forceinline__ void put_rows(const RowOut& o, int rb, f32x4 v, int g, int n, bool live) {
-    if (o.p == nullptr || !live) return;
-    float* q = o.p + (int64_t)(16 * rb + 4 * g) * o.row_stride + n;
+    const int voff = live ? 4 * g * o.row_bytes + 4 * n : kDeadLane;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[(int64_t)i * o.row_stride] = v[i];
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), o.r, voff, (16 * rb + i) * o.row_bytes, 0);
 }
 
 // Layers 2 and 3 behind the first layer's pre-activations; h1 / h2 go to the history blocks (if any), y is returned activated.
+template <bool TRAIN>
 __device__ __forceinline__ void finish_mlp(const MlpL& W, int lane, int softplus_out, const Acc2& Z1, const RowOut& H1, const RowOut& H2,
-                                           bool live, f32x4 (&y)[2]) {
+                                           bool live, f32x4 (&y)[2], bool stamp = false) {
     const int g = lane >> 4, n = lane & 15;
+    GNN_TILE_STAMP(stamp, 9);
     const f32x4 h10 = elu4(Z1.a0), h11 = elu4(Z1.a1);
-    put_rows(H1, 0, h10, g, n, live);
-    put_rows(H1, 1, h11, g, n, live);
+    GNN_TILE_STAMP(stamp, 10);
+    if (TRAIN) {
+        put_rows(H1, 0, h10, g, n, live);
+        put_rows(H1, 1, h11, g, n, live);
+    }
+    GNN_TILE_STAMP(stamp, 11);
     f32x4 c0 = lds4(W.b2 + 4 * g), c1 = lds4(W.b2 + 16 + 4 * g);
     {
         const f32x4 w00 = lds4(W.l2 + (0 * 64 + lane) * 4), w01 = lds4(W.l2 + (1 * 64 + lane) * 4);
@@ -128,9 +155,13 @@ __device__ __forceinline__ void finish_mlp(const MlpL& W, int lane, int softplus
             c1 = mfma4(w11[j], h11[j], c1);
         }
     }
+    GNN_TILE_STAMP(stamp, 12);
     const f32x4 h20 = elu4(c0), h21 = elu4(c1);
-    put_rows(H2, 0, h20, g, n, live);
-    put_rows(H2, 1, h21, g, n, live);
+    if (TRAIN) {
+        put_rows(H2, 0, h20, g, n, live);
+        put_rows(H2, 1, h21, g, n, live);
+    }
+    GNN_TILE_STAMP(stamp, 13);
     f32x4 d0 = lds4(W.b3 + 4 * g), d1 = lds4(W.b3 + 16 + 4 * g);
     {
         const f32x4 w00 = lds4(W.l3 + (0 * 64 + lane) * 4), w01 = lds4(W.l3 + (1 * 64 + lane) * 4);
@@ -146,6 +177,7 @@ __device__ __forceinline__ void finish_mlp(const MlpL& W, int lane, int softplus
             for (int j = 0; j < 4; ++j) d1 = mfma4(w11[j], h21[j], d1);
         }
     }
+    GNN_TILE_STAMP(stamp, 14);
     if (softplus_out) {   // one output row: lane group 0, register 0
         y[0] = f32x4{softplus1(d0[0]), 0.f, 0.f, 0.f};
         y[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -156,20 +188,59 @@ __device__ __forceinline__ void finish_mlp(const MlpL& W, int lane, int softplus
 }
 
 __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n_floats) {
-    for (int i = threadIdx.x * 4; i < n_floats; i += kThreads * 4)
+    for (int i = threadIdx.x * 4; i < n_floats; i += blockDim.x * 4)
         *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(src + i);
 }
+__device__ __forceinline__ void copy_words(int* dst, const void* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = reinterpret_cast<const int*>(src)[i];
+}
+// a wave-uniform word of an LDS table as a scalar (every index that steers a wavefront - its entity, the entity's endpoints, its
+// aggregation list - is uniform: as scalars they cost no vector registers, branch without exec masks and address LDS by immediates)
+__device__ __forceinline__ int uni(const int* tab, int i) { return __builtin_amdgcn_readfirstlane(tab[i]); }
 
-template <int MAXW>
-__global__ __launch_bounds__(kThreads) void gnn_period_fwd_kernel(const NicGnnPeriod P) {
+// The static graph in LDS (ints; floats bit-cast): [src E][tgt E][lead E][node_row0 N][node_slots N][agg_scale 2N][agg_off 2N+1][agg_items]
+struct GraphTabs {
+    const int *src, *tgt, *lead, *row0, *slots, *scale, *off, *items;
+};
+__host__ __device__ inline int graph_words(int N, int E, int n_items) { return 3 * E + 2 * N + 2 * N + (2 * N + 1) + n_items; }
+
+// The wavefronts of a SIMD leave a stage barrier together and would walk their tiles in lockstep - all in an MFMA phase, then all
+// in an ELU / store phase with the matrix pipe idle.  Delaying the k-th wavefront of a SIMD by k * kStagger cycles at the head of a
+// stage spreads the phases (NIC_GNN_STAGGER, 64-cycle units; 0 = off).
+#ifndef NIC_GNN_STAGGER
+#define NIC_GNN_STAGGER 8
+#endif
+#ifdef NIC_TUNING_BUILD
+__device__ int g_gnn_stagger = NIC_GNN_STAGGER;
+#define GNN_STAGGER_UNITS g_gnn_stagger
+#else
+#define GNN_STAGGER_UNITS NIC_GNN_STAGGER
+#endif
+__device__ __forceinline__ void stagger(int wave) {
+    const int units = (wave >> 2) * GNN_STAGGER_UNITS;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(1);
+}
+
+template <int MAXW, bool TRAIN, int kWaves>
+__global__ __launch_bounds__(kWaves * 64) void gnn_period_fwd_kernel(const NicGnnPeriod P) {
     extern __shared__ __align__(16) float lds[];
     const int N = P.n_nodes, E = P.n_edges;
     float* nodes = lds;
     float* edges = nodes + N * kTile;
     float* wb0 = edges + E * kTile;
     float* wb1 = wb0 + P.wb0_floats;
-    float* scratch = wb1 + P.wb1_floats;   // allocation + env step: [kEnvChunk + 1][4][16] + [NIC_MAX_WAREHOUSES][16]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    float* scratch = wb1 + P.wb1_floats;   // allocation + env step: [kEnvChunk + 1][4][16] + [1][16]
+    int* tabs = reinterpret_cast<int*>(scratch + kEnvScratch);
+    GraphTabs G;
+    G.src = tabs;
+    G.tgt = G.src + E;
+    G.lead = G.tgt + E;
+    G.row0 = G.lead + E;
+    G.slots = G.row0 + N;
+    G.scale = G.slots + N;
+    G.off = G.scale + 2 * N;
+    G.items = G.off + 2 * N + 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int64_t b0 = (int64_t)blockIdx.x * NB, ldb = P.ldb;
     const bool live = b0 + n < P.n_scenarios;
     const int s1q_in = (P.Dn + 15) / 16;
@@ -179,47 +250,58 @@ __global__ __launch_bounds__(kThreads) void gnn_period_fwd_kernel(const NicGnnPe
     copy_to_lds(wb0, P.mlp[0].wpk, sz_in);
     copy_to_lds(wb0 + sz_in, P.mlp[1].wpk, sz_ie);
     copy_to_lds(wb1, P.mlp[2].wpk, sz_nu);
+    copy_words(const_cast<int*>(G.src), P.src, E);
+    copy_words(const_cast<int*>(G.tgt), P.tgt, E);
+    copy_words(const_cast<int*>(G.lead), P.lead, E);
+    copy_words(const_cast<int*>(G.row0), P.node_row0, N);
+    copy_words(const_cast<int*>(G.slots), P.node_slots, N);
+    copy_words(const_cast<int*>(G.scale), P.agg_scale, 2 * N);
+    copy_words(const_cast<int*>(G.off), P.agg_off, 2 * N + 1);
+    copy_words(const_cast<int*>(G.items), P.agg_items, P.n_agg_items);
     __syncthreads();
     GNN_STAMP(1);
     const int64_t hblk = (b0 >> 5) * 1024 + (b0 & 31);   // the block's columns inside an entity's native history blocks
     const int64_t hent = (ldb / 32) * 1024;               // floats between entities there
-    auto hist = [&](float* H, int ent) { return RowOut{H ? H + ent * hent + hblk : nullptr, 32}; };
-    auto rows = [&](float* Y, const NicGnnPeriodMlp& m, int ent) { return RowOut{Y ? Y + (int64_t)ent * ldb + b0 : nullptr, m.row_stride}; };
+    auto hist = [&](float* H, int ent) { return row_out(TRAIN && H ? H + ent * hent + hblk : nullptr, 32); };
+    auto rows = [&](float* Y, const NicGnnPeriodMlp& m, int ent) {
+        return row_out(TRAIN && Y ? Y + (int64_t)ent * ldb + b0 : nullptr, m.row_stride);
+    };
+    auto put_tile = [&](float* tile, const f32x4 (&y)[2]) {
+        *reinterpret_cast<f32x4*>(tile + lane * 4) = y[0];
+        *reinterpret_cast<f32x4*>(tile + 256 + lane * 4) = y[1];
+    };
 
     // ---- initial node embeddings: features = [pipeline slots padded to max_inv | static rows] (neural_networks.py:846-905)
     {
         const MlpL W = mlp_at(wb0, s1q_in, 2);
+        stagger(wave);
         const NicGnnPeriodMlp& M = P.mlp[0];
         for (int v = wave; v < N; v += kWaves) {
-            const int row0 = P.node_row0[v], slots = P.node_slots[v];
+            const int row0 = uni(G.row0, v), slots = uni(G.slots, v);
             Acc2 A = l1_begin(W, g);
             for (int q = 0; q < s1q_in; ++q) {
                 f32x4 x;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; ++j) {   // every lane loads (a clamped address), a select drops what is not a feature
                     const int k = 16 * q + 4 * j + g;
-                    float val = 0.f;
-                    if (live && k < P.Dn) {
-                        if (k < P.max_inv) {
-                            if (k < slots) {
-                                val = P.state[(int64_t)(row0 + k) * ldb + b0 + n];
-                                if (P.store_feat) P.feat[((int64_t)k * N + v) * ldb + b0 + n] = val;
-                            }
-                        } else {
-                            val = P.feat[((int64_t)k * N + v) * ldb + b0 + n];
-                        }
-                    }
-                    x[j] = val;
+                    const bool pipe = k < P.max_inv;
+                    const bool has = live && k < P.Dn && (!pipe || k < slots);
+                    const float* src = pipe ? P.state + (int64_t)(row0 + (k < slots ? k : 0)) * ldb
+                                            : P.feat + ((int64_t)(k < P.Dn ? k : 0) * N + v) * ldb;
+                    const float val = src[live ? b0 + n : 0];
+                    x[j] = has ? val : 0.f;
+                    if (TRAIN && P.store_feat && has && pipe) P.feat[((int64_t)k * N + v) * ldb + b0 + n] = val;
                 }
                 l1_group(W, q, x, lane, A);
             }
             f32x4 y[2];
-            finish_mlp(W, lane, 0, A, hist(M.H1, v), hist(M.H2, v), live, y);
-            *reinterpret_cast<f32x4*>(nodes + v * kTile + lane * 4) = y[0];
-            *reinterpret_cast<f32x4*>(nodes + v * kTile + 256 + lane * 4) = y[1];
-            const RowOut o = rows(M.Y, M, v);
-            put_rows(o, 0, y[0], g, n, live);
-            put_rows(o, 1, y[1], g, n, live);
+            finish_mlp<TRAIN>(W, lane, 0, A, hist(M.H1, v), hist(M.H2, v), live, y);
+            put_tile(nodes + v * kTile, y);
+            if (TRAIN) {
+                const RowOut o = rows(M.Y, M, v);
+                put_rows(o, 0, y[0], g, n, live);
+                put_rows(o, 1, y[1], g, n, live);
+            }
         }
     }
     __syncthreads();
@@ -227,20 +309,25 @@ __global__ __launch_bounds__(kThreads) void gnn_period_fwd_kernel(const NicGnnPe
     // ---- initial edge embeddings: [source node | target node | lead time] (:984-1062); a missing endpoint is the all-zero node
     {
         const MlpL W = mlp_at(wb0 + sz_in, 5, 2);
+        stagger(wave);
         const NicGnnPeriodMlp& M = P.mlp[1];
         for (int e = wave; e < E; e += kWaves) {
-            const int s = P.src[e], t = P.tgt[e];
+            const int s_ = uni(G.src, e), t_ = uni(G.tgt, e);
+            const float lead = __int_as_float(uni(G.lead, e));
+            GNN_TILE_STAMP(e == wave, 8);
             Acc2 A = l1_begin(W, g);
-            if (s >= 0) l1_tile(W, 0, nodes + s * kTile, lane, A);
-            if (t >= 0) l1_tile(W, 2, nodes + t * kTile, lane, A);
-            l1_first_step(W, 4, g == 0 ? P.lead[e] : 0.f, lane, A);
+            if (s_ >= 0) l1_tile(W, 0, nodes + s_ * kTile, lane, A);
+            if (t_ >= 0) l1_tile(W, 2, nodes + t_ * kTile, lane, A);
+            l1_first_step(W, 4, g == 0 ? lead : 0.f, lane, A);
             f32x4 y[2];
-            finish_mlp(W, lane, 0, A, hist(M.H1, e), hist(M.H2, e), live, y);
-            *reinterpret_cast<f32x4*>(edges + e * kTile + lane * 4) = y[0];
-            *reinterpret_cast<f32x4*>(edges + e * kTile + 256 + lane * 4) = y[1];
-            const RowOut o = rows(M.Y, M, e);
-            put_rows(o, 0, y[0], g, n, live);
-            put_rows(o, 1, y[1], g, n, live);
+            finish_mlp<TRAIN>(W, lane, 0, A, hist(M.H1, e), hist(M.H2, e), live, y, e == wave);
+            put_tile(edges + e * kTile, y);
+            if (TRAIN) {
+                const RowOut o = rows(M.Y, M, e);
+                put_rows(o, 0, y[0], g, n, live);
+                put_rows(o, 1, y[1], g, n, live);
+            }
+            GNN_TILE_STAMP(e == wave, 15);
         }
     }
     __syncthreads();   // (also: wb0 is free from here on)
@@ -251,6 +338,7 @@ __global__ __launch_bounds__(kThreads) void gnn_period_fwd_kernel(const NicGnnPe
     // the sums taken in the reference's edge order; nodes1 = nodes0 + update, in place
     {
         const MlpL W = mlp_at(wb1, 6, 2);
+        stagger(wave);
         const NicGnnPeriodMlp& M = P.mlp[2];
         for (int v = wave; v < N; v += kWaves) {
             Acc2 A = l1_begin(W, g);
@@ -260,18 +348,28 @@ __global__ __launch_bounds__(kThreads) void gnn_period_fwd_kernel(const NicGnnPe
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 const int list = side * N + v;
-                const int lo = P.agg_off[list], hi = P.agg_off[list + 1];
+                const int lo = uni(G.off, list), hi = uni(G.off, list + 1);
                 f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-                for (int p = lo; p < hi; ++p) {
-                    const float* tile = edges + P.agg_items[p] * kTile;
-                    s0 += lds4(tile + lane * 4);
-                    s1 += lds4(tile + 256 + lane * 4);
+                for (int p0 = lo; p0 < hi; p0 += 4) {   // four edges' tiles in flight, added in list order
+                    f32x4 t0[4], t1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float* tile = edges + uni(G.items, p0 + u < hi ? p0 + u : p0) * kTile;
+                        t0[u] = lds4(tile + lane * 4);
+                        t1[u] = lds4(tile + 256 + lane * 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (p0 + u < hi) {
+                            s0 += t0[u];
+                            s1 += t1[u];
+                        }
                 }
-                const float sc = P.agg_scale[list];
+                const float sc = __int_as_float(uni(G.scale, list));
                 s0 *= sc;
                 s1 *= sc;
-                if (P.agg) {
-                    const RowOut o{P.agg + (int64_t)list * ldb + b0, (int64_t)2 * N * ldb};
+                if (TRAIN && P.agg) {
+                    const RowOut o = row_out(P.agg + (int64_t)list * ldb + b0, (int64_t)2 * N * ldb);
                     put_rows(o, 0, s0, g, n, live);
                     put_rows(o, 1, s1, g, n, live);
                 }
@@ -279,54 +377,70 @@ __global__ __launch_bounds__(kThreads) void gnn_period_fwd_kernel(const NicGnnPe
                 l1_group(W, 3 + 2 * side, s1, lane, A);
             }
             f32x4 y[2];
-            finish_mlp(W, lane, 0, A, hist(M.H1, v), hist(M.H2, v), live, y);
-            const RowOut o = rows(M.Y, M, v), os = rows(M.Ysum, M, v);
-            put_rows(o, 0, y[0], g, n, live);
-            put_rows(o, 1, y[1], g, n, live);
+            finish_mlp<TRAIN>(W, lane, 0, A, hist(M.H1, v), hist(M.H2, v), live, y);
+            if (TRAIN) {
+                const RowOut o = rows(M.Y, M, v);
+                put_rows(o, 0, y[0], g, n, live);
+                put_rows(o, 1, y[1], g, n, live);
+            }
             y[0] += old0;
             y[1] += old1;
-            *reinterpret_cast<f32x4*>(nodes + v * kTile + lane * 4) = y[0];
-            *reinterpret_cast<f32x4*>(nodes + v * kTile + 256 + lane * 4) = y[1];
-            put_rows(os, 0, y[0], g, n, live);
-            put_rows(os, 1, y[1], g, n, live);
+            put_tile(nodes + v * kTile, y);
+            if (TRAIN) {
+                const RowOut os = rows(M.Ysum, M, v);
+                put_rows(os, 0, y[0], g, n, live);
+                put_rows(os, 1, y[1], g, n, live);
+            }
         }
     }
     __syncthreads();
     GNN_STAMP(4);
     // ---- edge update [edge | updated source | updated target] (:1322-1340) and, on the sum still in registers, the output MLP
     // (:1367-1392) - for the live edges only (a demand edge's update feeds nothing, csrc/mlp3.hip)
+    float* outl = scratch + kEnvScratch + P.tab_words;   // [n_live][16] desired quantities
     {
         const MlpL W = mlp_at(wb0, 6, 2), WO = mlp_at(wb0 + sz_eu, 2, 1);
+        stagger(wave);
         const NicGnnPeriodMlp &M = P.mlp[3], &MO = P.mlp[4];
         for (int e = wave; e < P.n_live; e += kWaves) {
-            const int s = P.src[e], t = P.tgt[e];
+            const int s_ = uni(G.src, e), t_ = uni(G.tgt, e);
             Acc2 A = l1_begin(W, g);
             const f32x4 old0 = lds4(edges + e * kTile + lane * 4), old1 = lds4(edges + e * kTile + 256 + lane * 4);
             l1_group(W, 0, old0, lane, A);
             l1_group(W, 1, old1, lane, A);
-            if (s >= 0) l1_tile(W, 2, nodes + s * kTile, lane, A);
-            if (t >= 0) l1_tile(W, 4, nodes + t * kTile, lane, A);
+            if (s_ >= 0) l1_tile(W, 2, nodes + s_ * kTile, lane, A);
+            if (t_ >= 0) l1_tile(W, 4, nodes + t_ * kTile, lane, A);
             f32x4 y[2];
-            finish_mlp(W, lane, 0, A, hist(M.H1, e), hist(M.H2, e), live, y);
-            const RowOut o = rows(M.Y, M, e), os = rows(M.Ysum, M, e);
-            put_rows(o, 0, y[0], g, n, live);
-            put_rows(o, 1, y[1], g, n, live);
+            finish_mlp<TRAIN>(W, lane, 0, A, hist(M.H1, e), hist(M.H2, e), live, y);
+            if (TRAIN) {
+                const RowOut o = rows(M.Y, M, e);
+                put_rows(o, 0, y[0], g, n, live);
+                put_rows(o, 1, y[1], g, n, live);
+            }
             y[0] += old0;
             y[1] += old1;
-            put_rows(os, 0, y[0], g, n, live);
-            put_rows(os, 1, y[1], g, n, live);
+            if (TRAIN) {
+                const RowOut os = rows(M.Ysum, M, e);
+                put_rows(os, 0, y[0], g, n, live);
+                put_rows(os, 1, y[1], g, n, live);
+            }
             Acc2 B = l1_begin(WO, g);
             l1_group(WO, 0, y[0], lane, B);
             l1_group(WO, 1, y[1], lane, B);
             f32x4 z[2];
-            finish_mlp(WO, lane, 1, B, hist(MO.H1, e), hist(MO.H2, e), live, z);
-            if (g == 0 && live) MO.Y[(int64_t)e * ldb + b0 + n] = z[0][0];
+            finish_mlp<TRAIN>(WO, lane, 1, B, hist(MO.H1, e), hist(MO.H2, e), live, z);
+            if (g == 0) {
+                outl[e * NB + n] = z[0][0];
+                if (live && (TRAIN || !P.fuse_env)) MO.Y[(int64_t)e * ldb + b0 + n] = z[0][0];
+            }
         }
     }
     GNN_STAMP(5);
     if (!P.fuse_env) return;
-    __syncthreads();   // the desired quantities go through global memory and are read by other lanes of the workgroup
-    // ---- proportional allocation + one period of dynamics (csrc/gnn_alloc_env.hip, on 16 scenarios x 4 quad lanes = wavefront 0)
+    __syncthreads();
+    // ---- proportional allocation + one period of dynamics (csrc/gnn_alloc_env.hip's bodies, on 16 scenarios x 4 quad lanes =
+    // wavefront 0).  The desired quantities are read from LDS (the head's `out` with a row stride of 16), the orders go through
+    // global memory and are read by the other lanes of the quad behind a barrier.
     {
         const NicEnvStepIO& io = P.io;
         const int x = n, q = g, Wn = io.dims.n_warehouses;
@@ -336,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void gnn_period_fwd_kernel(const NicGnnPe
         float(*rq)[NB] = reinterpret_cast<float(*)[NB]>(scratch + kEnvChunk * 4 * NB);
         float(*cw)[NB] = reinterpret_cast<float(*)[NB]>(scratch + (kEnvChunk + 1) * 4 * NB);
         if (act && q == 0)
-            nic::gnn_alloc_fwd_one(P.mlp[4].Y, io.wh_inv, P.orders, P.sums, P.ratio, P.scale, io.dims.n_stores, P.e_self, P.e_supplier,
+            nic::gnn_alloc_fwd_one(outl, NB, x, io.wh_inv, P.orders, P.sums, P.ratio, P.scale, io.dims.n_stores, P.e_self, P.e_supplier,
                                    P.cap_at_one, b, ldb);
         __syncthreads();
         if (on) rq[q][x] = act ? nic::env_fwd_stores<MAXW>(io, P.store_out, b, q) : 0.f;
@@ -366,13 +480,15 @@ int lds_floats(const NicGnnPeriod& p, int* wb0, int* wb1) {
     const int a = pack_floats(s1q_in, 2) + pack_floats(5, 2), b = pack_floats(6, 2) + pack_floats(2, 1);
     *wb0 = a > b ? a : b;
     *wb1 = pack_floats(6, 2);
-    return (p.n_nodes + p.n_edges) * kTile + *wb0 + *wb1 + (kEnvChunk + 1) * 4 * NB + NIC_MAX_WAREHOUSES * NB;
+    const int tab = (graph_words(p.n_nodes, p.n_edges, p.n_agg_items) + 3) / 4 * 4;
+    return (p.n_nodes + p.n_edges) * kTile + *wb0 + *wb1 + kEnvScratch + tab + p.n_live * NB;
 }
 constexpr int kLdsLimit = 160 * 1024;
 
 int check(const NicGnnPeriod* p, const char* who) {
     NIC_REQUIRE(p != nullptr, "%s: descriptor is null", who);
-    NIC_REQUIRE(p->n_nodes > 0 && p->n_edges > 0 && p->n_live > 0 && p->n_live <= p->n_edges, "%s: bad graph sizes", who);
+    NIC_REQUIRE(p->n_nodes > 0 && p->n_edges > 0 && p->n_live > 0 && p->n_live <= p->n_edges && p->n_agg_items >= 0 &&
+                    p->n_agg_items <= 4 * p->n_edges, "%s: bad graph sizes", who);
     NIC_REQUIRE(p->n_scenarios > 0 && p->ldb >= p->n_scenarios && p->ldb % 32 == 0, "%s: bad scenario sizes (ldb a multiple of 32)", who);
     NIC_REQUIRE(p->Dn > 0 && p->Dn <= 64 && p->max_inv >= 0 && p->max_inv <= p->Dn, "%s: node feature rows outside [1,64]", who);
     NIC_REQUIRE(p->src && p->tgt && p->agg_off && p->agg_items && p->agg_scale && p->lead && p->node_row0 && p->node_slots && p->state &&
@@ -409,6 +525,8 @@ int nic_gnn_period_ok(int32_t n_nodes, int32_t n_edges, int32_t Dn) {
     NicGnnPeriod p{};
     p.n_nodes = n_nodes;
     p.n_edges = n_edges;
+    p.n_live = n_edges;
+    p.n_agg_items = 2 * n_edges;
     p.Dn = Dn;
     int a, b;
     return n_nodes > 0 && n_edges > 0 && Dn > 0 && Dn <= 64 && lds_floats(p, &a, &b) * 4 <= kLdsLimit;
@@ -418,33 +536,43 @@ int nic_gnn_period_fwd(const NicGnnPeriod* p, void* stream) {
     if (int e = check(p, "nic_gnn_period_fwd")) return e;
     NicGnnPeriod q = *p;
     const int bytes = lds_floats(q, &q.wb0_floats, &q.wb1_floats) * 4;
-    const dim3 grid(nic::ceil_div(q.n_scenarios, NB)), block(kThreads);
+    q.tab_words = (graph_words(q.n_nodes, q.n_edges, q.n_agg_items) + 3) / 4 * 4;
+    const bool train = q.mlp[0].Y != nullptr;
+    const dim3 grid(nic::ceil_div(q.n_scenarios, NB));
     hipStream_t s = nic::as_stream(stream);
     int m = 4;
     if (q.fuse_env) {
         const int sl = q.io.dims.store_slots > q.io.dims.warehouse_slots ? q.io.dims.store_slots : q.io.dims.warehouse_slots;
         m = sl <= 4 ? 4 : (sl <= 8 ? 8 : NIC_MAX_SLOTS);
     }
-    nic::note_kernelf("gnn_period_fwd_kernel<%d>", m);
-#define NIC_GP_FWD(MW)                                                                                                      \
+    nic::note_kernelf("gnn_period_fwd_kernel<%d,%s,%d>", m, train ? "true" : "false", m == 4 ? 16 : 8);
+#define NIC_GP_FWD(MW, TR)                                                                                                  \
     do {                                                                                                                    \
+        constexpr int NW = (MW) == 4 ? 16 : 8;                                                                              \
         static bool attr_set = false;                                                                                       \
         if (!attr_set) {                                                                                                    \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_period_fwd_kernel<MW>),                               \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_period_fwd_kernel<MW, TR, NW>),                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit) != hipSuccess)                   \
                 return nic::fail("nic_gnn_period_fwd: cannot raise the dynamic LDS limit");                                 \
             attr_set = true;                                                                                                \
         }                                                                                                                   \
-        hipLaunchKernelGGL(gnn_period_fwd_kernel<MW>, grid, block, bytes, s, q);                                            \
+        hipLaunchKernelGGL((gnn_period_fwd_kernel<MW, TR, NW>), grid, dim3(NW * 64), bytes, s, q);                          \
     } while (0)
-    if (m == 4) NIC_GP_FWD(4);
-    else if (m == 8) NIC_GP_FWD(8);
-    else NIC_GP_FWD(NIC_MAX_SLOTS);
+#define NIC_GP_FWD2(MW)        \
+    do {                       \
+        if (train) NIC_GP_FWD(MW, true); \
+        else NIC_GP_FWD(MW, false);      \
+    } while (0)
+    if (m == 4) NIC_GP_FWD2(4);
+    else if (m == 8) NIC_GP_FWD2(8);
+    else NIC_GP_FWD2(NIC_MAX_SLOTS);
+#undef NIC_GP_FWD2
 #undef NIC_GP_FWD
     return nic::check_launch("nic_gnn_period_fwd");
 }
 
 #ifdef NIC_TUNING_BUILD
+int nic_tuning_set_gnn_stagger(int units) { return hipMemcpyToSymbol(HIP_SYMBOL(g_gnn_stagger), &units, sizeof(units)) == hipSuccess ? 0 : 1; }
 int nic_tuning_set_gnn_stamps(unsigned long long* buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_gnn_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
 }

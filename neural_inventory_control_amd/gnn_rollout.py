@@ -88,6 +88,7 @@ class GraphPlan:
         out = [[eng[r] for r in range(E) if r_src[r] == n and r not in r_supplier] for n in range(self.n_nodes)]
         # both aggregations as ONE segment sum into a [rows][2 * n_nodes][ldb] buffer (incoming sums first, then outgoing)
         self.agg_off, self.agg_items = _csr(inc + out, device)
+        self.n_agg_items = sum(len(l) for l in inc + out)
         self.in_scale = torch.tensor([1.0 / max(d, 1) ** 0.5 for d in in_deg], device=device)
         self.out_scale = torch.tensor([1.0 / max(d, 1) ** 0.5 for d in out_deg], device=device)
         self.agg_scale = torch.cat([self.in_scale, self.out_scale])
@@ -529,6 +530,7 @@ class GnnRollout:
         p = _lib.ptr
         d.src, d.tgt, d.agg_off, d.agg_items, d.agg_scale = p(P.src), p(P.tgt), p(P.agg_off), p(P.agg_items), p(P.agg_scale)
         d.lead, d.node_row0, d.node_slots = p(P.lead), p(self.node_row0), p(self.node_slots)
+        d.n_agg_items = int(P.n_agg_items)
         d.state, d.feat = p(self.states[t]), p(self.feat[t])
         d.agg = p(self.agg[t]) if train else None
         for i, name in enumerate(MODULES):

@@ -34,8 +34,17 @@ def _tuning_library():
             return out
     except OSError:
         pass
-    subprocess.check_call([nb._hipcc(), f"--offload-arch={nb.ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNIC_TUNING_BUILD",
-                           "-ffp-contract=off", "-o", out] + srcs)
+    # one object per source with the product's own per-file flags (+ -DNIC_TUNING_BUILD), eight compilers at a time, then one link
+    from concurrent.futures import ThreadPoolExecutor
+    objs = [os.path.join(out_dir, s_.replace(".hip", ".tuning.o")) for s_, _ in nb.SOURCES]
+
+    def compile_one(job):
+        (src, extra), obj = job
+        subprocess.check_call([nb._hipcc()] + nb.BASE_FLAGS + ["-DNIC_TUNING_BUILD", "-ffp-contract=off"] + list(extra) +
+                              ["-c", os.path.join(nb.CSRC, src), "-o", obj])
+    with ThreadPoolExecutor(8) as pool:
+        list(pool.map(compile_one, zip(nb.SOURCES, objs)))
+    subprocess.check_call([nb._hipcc(), f"--offload-arch={nb.ARCH}", "-shared", "-fPIC", "-o", out] + objs)
     with open(out + ".key", "w") as f:
         f.write(key)
     return out

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--eval", action="store_true")
     ap.add_argument("--workload", default="gnn")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--stagger", type=int, default=None, help="tuning build: 64-cycle units the k-th wavefront of a SIMD waits at a stage head")
     args = ap.parse_args()
     from neural_inventory_control_amd import _lib
     from gemm_probe import _tuning_library
@@ -32,8 +33,10 @@ def main():
     setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, dev, 0, 1, args.scenarios, args.periods, False)
     eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
     lib.nic_tuning_set_gnn_stamps.argtypes = [C.c_void_p]
-    stamps = torch.zeros(8 * 16, dtype=torch.int64, device=dev)
-    res = {"workload": args.workload, "scenarios": n, "periods": T, "train": not args.eval}
+    if args.stagger is not None:
+        assert lib.nic_tuning_set_gnn_stagger(args.stagger) == 0
+    stamps = torch.zeros(16 * 16, dtype=torch.int64, device=dev)
+    res = {"workload": args.workload, "scenarios": n, "periods": T, "train": not args.eval, "stagger": args.stagger}
     for period in (True, False):
         eng.use_period_kernel = period
         for _ in range(2):
@@ -48,11 +51,17 @@ def main():
         res["period_kernel" if period else "per_mlp_launches"] = {k: round(ms * 1e3, 2) for k, ms in fwd.items()}
         res[("period_kernel" if period else "per_mlp_launches") + "_fwd_us_per_period"] = round(sum(fwd.values()) * 1e3, 2)
         eng.timer = None
-    st = stamps.cpu().view(8, 16)
+    st = stamps.cpu().view(16, 16)
+    st = st[st[:, 1] != 0]   # the wavefronts the launch had
+    nw = st.shape[0]
     t0 = int(st[:, 0].min())
-    res["stamps_us_wave_by_point"] = [[round((int(st[w, p]) - t0) / 100.0, 2) if int(st[w, p]) else None for p in range(7)] for w in range(8)]
+    res["stamps_us_wave_by_point"] = [[round((int(st[w, p]) - t0) / 100.0, 2) if int(st[w, p]) else None for p in range(7)] for w in range(nw)]
     res["stage_us_slowest_wave"] = {STAGES[p - 1]: round((int(st[:, p].max()) - int(st[:, p - 1].max())) / 100.0, 2)
                                     for p in range(1, 7) if int(st[:, p].max())}
+    names = ["first layer (8 or 16 steps + lead)", "ELU 1", "H1 stores", "second layer", "ELU 2 + H2 stores", "third layer", "ELU 3 + tile -> LDS + Y stores"]
+    res["first_initial_edge_tile_us_by_wave"] = [
+        {names[p - 9]: round((int(st[w, p]) - int(st[w, p - 1])) / 100.0, 2) for p in range(9, 16) if int(st[w, p]) and int(st[w, p - 1])}
+        for w in range(nw)]
     print(json.dumps(res, indent=1))
     if args.out:
         json.dump(res, open(args.out, "w"), indent=1)
