@@ -431,6 +431,8 @@ def bench_epoch(args):
         tr.fuse_tail = args.tail == "on"
     if args.wide != "auto":
         tr.use_wide = args.wide == "on"
+    if args.gnn_period != "auto":
+        tr.use_period_kernel = args.gnn_period == "on"
 
     def epoch(loader=None):
         return tr.do_one_epoch(opt, loader or loaders["train"], c["loss_function"], c["simulator"], model, T, pp,
@@ -802,7 +804,8 @@ def main():
                        "periods": T, "parallelism": f"scenario-sharded dp{world}",
                        "route": ("generic (Simulator.step + autograd)" if eng is None else
                                  "whole-horizon closed-form kernel (forward-mode gradient)" if closed_form else
-                                 "per-period fused gather-MLP kernels over the static supply graph" if gnn else
+                                 (("one forward launch per period (five MLPs on LDS-resident embeddings + allocation + env step), per-MLP backward launches"
+                                   if getattr(eng, "_period", False) else "per-period fused gather-MLP kernels over the static supply graph")) if gnn else
                                  "whole-horizon kernels" if eng.small is not None else
                                  "whole-horizon kernels (16 scenarios per workgroup) + (period x scenario) GEMMs"
                                  if getattr(eng, "horizon", None) is not None else "per-period kernels"),

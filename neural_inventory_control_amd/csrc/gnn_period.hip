@@ -204,23 +204,6 @@ struct GraphTabs {
 };
 __host__ __device__ inline int graph_words(int N, int E, int n_items) { return 3 * E + 2 * N + 2 * N + (2 * N + 1) + n_items; }
 
-// The wavefronts of a SIMD leave a stage barrier together and would walk their tiles in lockstep - all in an MFMA phase, then all
-// in an ELU / store phase with the matrix pipe idle.  Delaying the k-th wavefront of a SIMD by k * kStagger cycles at the head of a
-// stage spreads the phases (NIC_GNN_STAGGER, 64-cycle units; 0 = off).
-#ifndef NIC_GNN_STAGGER
-#define NIC_GNN_STAGGER 8
-#endif
-#ifdef NIC_TUNING_BUILD
-__device__ int g_gnn_stagger = NIC_GNN_STAGGER;
-#define GNN_STAGGER_UNITS g_gnn_stagger
-#else
-#define GNN_STAGGER_UNITS NIC_GNN_STAGGER
-#endif
-__device__ __forceinline__ void stagger(int wave) {
-    const int units = (wave >> 2) * GNN_STAGGER_UNITS;
-    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(1);
-}
-
 template <int MAXW, bool TRAIN, int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void gnn_period_fwd_kernel(const NicGnnPeriod P) {
     extern __shared__ __align__(16) float lds[];
@@ -274,7 +257,6 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_fwd_kernel(const NicGn
     // ---- initial node embeddings: features = [pipeline slots padded to max_inv | static rows] (neural_networks.py:846-905)
     {
         const MlpL W = mlp_at(wb0, s1q_in, 2);
-        stagger(wave);
         const NicGnnPeriodMlp& M = P.mlp[0];
         for (int v = wave; v < N; v += kWaves) {
             const int row0 = uni(G.row0, v), slots = uni(G.slots, v);
@@ -309,7 +291,6 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_fwd_kernel(const NicGn
     // ---- initial edge embeddings: [source node | target node | lead time] (:984-1062); a missing endpoint is the all-zero node
     {
         const MlpL W = mlp_at(wb0 + sz_in, 5, 2);
-        stagger(wave);
         const NicGnnPeriodMlp& M = P.mlp[1];
         for (int e = wave; e < E; e += kWaves) {
             const int s_ = uni(G.src, e), t_ = uni(G.tgt, e);
@@ -338,7 +319,6 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_fwd_kernel(const NicGn
     // the sums taken in the reference's edge order; nodes1 = nodes0 + update, in place
     {
         const MlpL W = mlp_at(wb1, 6, 2);
-        stagger(wave);
         const NicGnnPeriodMlp& M = P.mlp[2];
         for (int v = wave; v < N; v += kWaves) {
             Acc2 A = l1_begin(W, g);
@@ -400,7 +380,6 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_fwd_kernel(const NicGn
     float* outl = scratch + kEnvScratch + P.tab_words;   // [n_live][16] desired quantities
     {
         const MlpL W = mlp_at(wb0, 6, 2), WO = mlp_at(wb0 + sz_eu, 2, 1);
-        stagger(wave);
         const NicGnnPeriodMlp &M = P.mlp[3], &MO = P.mlp[4];
         for (int e = wave; e < P.n_live; e += kWaves) {
             const int s_ = uni(G.src, e), t_ = uni(G.tgt, e);
@@ -572,7 +551,6 @@ int nic_gnn_period_fwd(const NicGnnPeriod* p, void* stream) {
 }
 
 #ifdef NIC_TUNING_BUILD
-int nic_tuning_set_gnn_stagger(int units) { return hipMemcpyToSymbol(HIP_SYMBOL(g_gnn_stagger), &units, sizeof(units)) == hipSuccess ? 0 : 1; }
 int nic_tuning_set_gnn_stamps(unsigned long long* buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_gnn_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
 }

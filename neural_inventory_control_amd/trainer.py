@@ -354,7 +354,7 @@ class Trainer:
                     eng2._trainer_shape = shape
                 eng = eng2
             eng.use_graph = self.use_rollout_graph   # (both engines: True / False / "auto" = by measurement per shape)
-            for opt_ in ("fuse_tail", "use_wide"):   # (A/B switches of the MLP engine's routes: set on the trainer, handed on)
+            for opt_ in ("fuse_tail", "use_wide", "use_period_kernel"):   # (A/B switches of the engines' routes: set on the trainer, handed on)
                 if hasattr(self, opt_) and hasattr(eng, opt_):
                     setattr(eng, opt_, getattr(self, opt_))
             if direct and train:

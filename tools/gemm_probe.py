@@ -26,9 +26,11 @@ def _tuning_library():
     from neural_inventory_control_amd import build as nb
     out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build")
     os.makedirs(out_dir, exist_ok=True)
-    out = os.path.join(out_dir, "libnic_hip_tuning.so")
+    defines = os.environ.get("NIC_TUNING_DEFINES", "").split()   # e.g. "-DNIC_GNN_WAVES=8": one library per set of defines
+    tag = "".join(c if c.isalnum() else "_" for c in "".join(defines))
+    out = os.path.join(out_dir, f"libnic_hip_tuning{tag}.so")
     srcs = [os.path.join(nb.CSRC, s) for s, _ in nb.SOURCES]
-    key = nb.source_id() + "-tuning"   # (a copy built in the container travels to the GPU box: reused while the sources match)
+    key = nb.source_id() + "-tuning" + tag   # (a copy built in the container travels to the GPU box: reused while the sources match)
     try:
         if os.path.isfile(out) and open(out + ".key").read().strip() == key:
             return out
@@ -36,11 +38,11 @@ def _tuning_library():
         pass
     # one object per source with the product's own per-file flags (+ -DNIC_TUNING_BUILD), eight compilers at a time, then one link
     from concurrent.futures import ThreadPoolExecutor
-    objs = [os.path.join(out_dir, s_.replace(".hip", ".tuning.o")) for s_, _ in nb.SOURCES]
+    objs = [os.path.join(out_dir, s_.replace(".hip", f".tuning{tag}.o")) for s_, _ in nb.SOURCES]
 
     def compile_one(job):
         (src, extra), obj = job
-        subprocess.check_call([nb._hipcc()] + nb.BASE_FLAGS + ["-DNIC_TUNING_BUILD", "-ffp-contract=off"] + list(extra) +
+        subprocess.check_call([nb._hipcc()] + nb.BASE_FLAGS + ["-DNIC_TUNING_BUILD", "-ffp-contract=off"] + defines + list(extra) +
                               ["-c", os.path.join(nb.CSRC, src), "-o", obj])
     with ThreadPoolExecutor(8) as pool:
         list(pool.map(compile_one, zip(nb.SOURCES, objs)))

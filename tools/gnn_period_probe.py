@@ -22,7 +22,6 @@ def main():
     ap.add_argument("--eval", action="store_true")
     ap.add_argument("--workload", default="gnn")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--stagger", type=int, default=None, help="tuning build: 64-cycle units the k-th wavefront of a SIMD waits at a stage head")
     args = ap.parse_args()
     from neural_inventory_control_amd import _lib
     from gemm_probe import _tuning_library
@@ -33,10 +32,8 @@ def main():
     setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, dev, 0, 1, args.scenarios, args.periods, False)
     eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
     lib.nic_tuning_set_gnn_stamps.argtypes = [C.c_void_p]
-    if args.stagger is not None:
-        assert lib.nic_tuning_set_gnn_stagger(args.stagger) == 0
     stamps = torch.zeros(16 * 16, dtype=torch.int64, device=dev)
-    res = {"workload": args.workload, "scenarios": n, "periods": T, "train": not args.eval, "stagger": args.stagger}
+    res = {"workload": args.workload, "scenarios": n, "periods": T, "train": not args.eval}
     for period in (True, False):
         eng.use_period_kernel = period
         for _ in range(2):
