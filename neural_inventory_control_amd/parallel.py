@@ -194,8 +194,8 @@ class GradientAllReducer:
                 dst.append(v)
         if dst:
             torch._foreach_copy_(dst, src)
-        if scalars:
-            self.tail.copy_(torch.stack([s.detach().float().reshape(()) for s in scalars]))
+        if scalars:   # (one launch: the stack writes straight into the buffer's tail)
+            torch.stack([s.detach().float().reshape(()) for s in scalars], out=self.tail)
         if active():
             ev = None
             if self.timing and self.flat.is_cuda:
@@ -215,4 +215,5 @@ class GradientAllReducer:
                 back_src.append(v)
         if back_dst:
             torch._foreach_copy_(back_dst, back_src)
-        return tuple(self.tail[i].clone() for i in range(len(scalars)))
+        out = self.tail.clone()   # (the caller's scalars must not change under the next step's collective)
+        return tuple(out[i] for i in range(len(scalars)))

@@ -653,9 +653,13 @@ def test_full_size_properties_cfg3():
 
 @pytest.mark.parametrize("name", ["cfg2_one_store_backlogged_vanilla", "cfg4_serial_vanilla", "cfg3_one_warehouse_5_vanilla",
                                   "cfg5_many_warehouses_3x64_vanilla"])   # (the last one: compacted logits layer, row copies)
-def test_graph_replay_matches_eager(name):
+@pytest.mark.parametrize("tail", [True, False])
+def test_graph_replay_matches_eager(name, tail):
     """HIP-graph replay of the launch sequence (use_graph) is bit-identical to eager launches, also after the batch
-    contents change between calls (the captured graph points at engine-owned buffers that are refreshed per call)."""
+    contents change between calls (the captured graph points at engine-owned buffers that are refreshed per call).
+    `tail`: the fused per-period tail launches forced on (both directions, where the shapes qualify) / off - under "auto" the
+    engine picks the backward tail by batch size AND replay mode, so eager and replayed runs may legitimately sum the logits
+    layer's weight gradient in different orders."""
     g = Golden(name)
     c = g.fresh_config()
     data = {k: v.to(DEV) for k, v in g.data.items()}
@@ -671,6 +675,7 @@ def test_graph_replay_matches_eager(name):
         model = _model(g, c)
         eng = FusedRollout(model, c["problem_params"], DEV)
         eng.use_graph = mode == "graph"
+        eng.fuse_tail = tail
         eng.use_small = False  # the whole-horizon route is three launches; graphs matter for the per-period route
         eng.materialize(F)
         _load(model, g)

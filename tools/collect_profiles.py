@@ -178,6 +178,11 @@ def main():
                              os.path.join(out, f"{rnd}_bench_{w}_kernel_by_grid.csv"))
         import shutil
         shutil.rmtree(prof, ignore_errors=True)   # (the raw traces are tens of MB; the summaries above are what is kept)
+        if w in ("cfg1", "cfg2", "cfg4", "base_stock", "base_stock_1m", "echelon_stock"):
+            # sub-millisecond steps: the one-rank RCCL all-reduce the default line includes (5 - 7 launches) is 10 - 30 % of them;
+            # the same step without a process group, for comparison with the rounds that had none
+            run(["python3", "bench.py", "--workload", w, "--no-dist-init", "--no-cpu-baseline"] + steps,
+                os.path.join(out, f"{rnd}_bench_{w}_no_collective.json"))
         if w in ("base_stock", "echelon_stock"):   # launch-bound steps: also replayed from one HIP graph
             run(["python3", "bench.py", "--workload", w, "--graph", "--no-cpu-baseline"] + steps,
                 os.path.join(out, f"{rnd}_bench_{w}_graph.json"))

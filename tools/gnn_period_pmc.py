@@ -34,7 +34,7 @@ def main():
                 k = row["Kernel_Name"]
                 if "gnn_period" not in k and "mlp3" not in k:
                     continue
-                k = k.split("(")[0][-60:]
+                k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:80]
                 e = res["kernels"].setdefault(k, {})
                 c = row["Counter_Name"]
                 e[c] = e.get(c, 0.0) + float(row["Counter_Value"])
