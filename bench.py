@@ -660,6 +660,7 @@ def main():
     elif eng is not None:  # materialise the lazy layers now so that replicas can be synchronised before the first step
         eng.materialize(eng.input_rows(data, setting["observation_params"]))
         eng.small_lane_scenarios = args.lane_scenarios
+        eng.inputs_versioned = True   # (the bench's batch is written once, before the first step: unchanged tensors are not re-copied)
         if args.no_horizon:
             eng.use_horizon = False
         if args.wide != "auto" and hasattr(eng, "use_wide"):

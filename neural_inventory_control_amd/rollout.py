@@ -696,9 +696,13 @@ class FusedRollout:
         return tt[0], tt[1]
 
     def _copy_if_changed(self, slot, dst, src):
-        """dst <- src.permute(1, 2, 0) unless `src` is the very tensor (same object, same in-place version) that was copied into
-        the same destination last time.  The tensor is kept referenced until the next call, so its memory cannot be handed to
-        another tensor in between (an epoch over ONE resident batch re-presents the same tensors every step)."""
+        """dst <- src.permute(1, 2, 0); with `inputs_versioned` (opt-in: bench.py, whose batch nobody writes) the copy is skipped
+        when `src` is the very tensor (same object, same in-place version) that was copied into the same destination last time.
+        torch's version counter does not see every write - raw-pointer kernels (the HIP sampler), `.data` assignments, `set_()` -
+        so by default every presented batch is copied: one small launch."""
+        if not getattr(self, "inputs_versioned", False):
+            dst.copy_(src.permute(1, 2, 0))
+            return
         cache = self.__dict__.setdefault("_copied", {})
         key = (dst.data_ptr(), tuple(dst.shape), src._version)
         hit = cache.get(slot)

@@ -1701,6 +1701,35 @@ def test_gnn_fused_alloc_env_launches_equal_the_separate_ones(name):
     assert abs(a[0] - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
 
 
+def test_initial_inventories_written_behind_torchs_back_are_seen():
+    """A batch tensor rewritten WITHOUT a version bump (`.data` copy - what a raw-pointer kernel or `set_()` also looks like to
+    torch) must still reach the whole-horizon kernels: by default every presented batch is copied into the engine's state
+    block; only `inputs_versioned = True` (bench.py) may skip the copy of an 'unchanged' tensor - and then does miss it."""
+    g = Golden("cfg2_one_store_backlogged_vanilla")
+    c = g.fresh_config()
+    data = {k: v.to(DEV).clone() for k, v in g.data.items()}
+    out = {}
+    for versioned in (False, True):
+        model = _model(g, c)
+        eng = FusedRollout(model, c["problem_params"], DEV)
+        eng.inputs_versioned = versioned
+        eng.materialize(data["initial_inventories"].shape[1] * data["initial_inventories"].shape[2])
+        _load(model, g)
+        inv = data["initial_inventories"]
+        keep = inv.clone()
+        t1, _ = eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"])
+        assert eng.small is not None   # (the route that keeps the state block)
+        v0 = inv._version
+        inv.data.copy_(keep + 3.0)   # no version bump
+        assert inv._version == v0
+        t2, _ = eng.run(data, c["periods"], c["ignore"], train=False, observation_params=c["observation_params"])
+        out[versioned] = (float(t1), float(t2))
+        inv.data.copy_(keep)
+    assert out[False][0] == out[True][0]
+    assert out[False][1] != out[False][0]        # default: the write is seen
+    assert out[True][1] == out[True][0]          # opt-in skip: it is not (documented)
+
+
 @pytest.mark.parametrize("mode", ["hist", True, "eval"])
 @pytest.mark.parametrize("name", GNN_CASES)
 def test_gnn_period_kernel_matches_the_per_mlp_launches(name, mode):
