@@ -7,9 +7,11 @@
 #include "closed_form_body.h"
 
 namespace {
-constexpr int kBlock = 64;
+constexpr int kBlock = 64;    // one wavefront per workgroup (32k chains already spread over every CU; 256-thread workgroups measured
+                              // the same at 10^6 chains: the CU's workgroup slots do not cap the resident wavefronts)
+constexpr int kWave = 64;
 
-template <int NP, int MF, bool CHAIN>
+template <int NP, int MF, bool CHAIN, int WC = 0>
 __global__ __launch_bounds__(kBlock) void closed_form_kernel(NicClosedFormDesc d, const float* __restrict__ levels,
                                                               const float* __restrict__ demand,
                                                               const float* __restrict__ state0, float* __restrict__ reward_hist,
@@ -23,14 +25,16 @@ __global__ __launch_bounds__(kBlock) void closed_form_kernel(NicClosedFormDesc d
     float g[NP > 0 ? NP : 1];
 #pragma unroll
     for (int j = 0; j < (NP > 0 ? NP : 1); ++j) g[j] = 0.f;
-    if (b < d.n_scenarios) nic::closed_form_chain<NP, MF, CHAIN>(d, reward_hist, totals, state_final, s, b, g);
+    if (b < d.n_scenarios) nic::closed_form_chain<NP, MF, CHAIN, WC>(d, reward_hist, totals, state_final, s, b, g);
     if (NP > 0 && g_partial) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             float v = g[j];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-            if (threadIdx.x == 0) g_partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + j] = v;
+            const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;   // one partial per wavefront of chains
+            const int64_t n_waves = (d.n_scenarios + kWave - 1) / kWave;
+            if ((threadIdx.x & (kWave - 1)) == 0 && wave_id < n_waves) g_partial[((int64_t)blockIdx.y * n_waves + wave_id) * NP + j] = v;
         }
     }
 }
@@ -62,7 +66,7 @@ extern "C" {
 
 int nic_closed_form_num_partials(int32_t n_scenarios, int32_t S) {
     if (n_scenarios <= 0 || S <= 0) return 0;
-    return nic::ceil_div(n_scenarios, kBlock) * S;
+    return nic::ceil_div(n_scenarios, kWave) * S;
 }
 
 int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
@@ -76,7 +80,11 @@ int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, floa
     int w = d->Ws;  // register slots per pipeline: the longest live pipeline, rounded up to 4 / 8 / 16
     if (chain) w = w > d->Ww ? w : d->Ww, w = w > d->We ? w : d->We;
     const int mf = w <= 4 ? 4 : (w <= 8 ? 8 : 16);
-    nic::note_kernelf("closed_form_kernel<%d,%d,%s>", np, mf, chain ? "true" : "false");
+    // single-store chains with pipelines of 2..4 slots whose lead time does not vary over the scenarios (table stride 0: every
+    // shipped setting): the variant with the pipeline length compiled in and the order placed by a wave-uniform branch
+    const int wc = (!chain && mf == 4 && d->lead.scn_stride == 0) ? d->Ws : 0;
+    if (wc) nic::note_kernelf("closed_form_kernel<%d,%d,false,%d>", np, mf, wc);
+    else nic::note_kernelf("closed_form_kernel<%d,%d,%s>", np, mf, chain ? "true" : "false");
 #define NIC_CF_LAUNCH(NP, MF, CH)                                                                                          \
     hipLaunchKernelGGL((closed_form_kernel<NP, MF, CH>), grid, block, 0, s, *d, d->levels, d->demand, d->state0, reward_hist, \
                        totals, state_final, g_levels_partial)
@@ -99,10 +107,24 @@ int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, floa
         else if (np == 1) NIC_CF_LAUNCH(1, MF, false);          \
         else NIC_CF_LAUNCH(2, MF, false);                       \
     } while (0)
-        if (mf == 4) NIC_CF_STORE(4);
+#define NIC_CF_LAUNCH_C(NP, WCV)                                                                                               \
+    hipLaunchKernelGGL((closed_form_kernel<NP, 4, false, WCV>), grid, block, 0, s, *d, d->levels, d->demand, d->state0, reward_hist, \
+                       totals, state_final, g_levels_partial)
+#define NIC_CF_STORE_C(WCV)                                     \
+    do {                                                        \
+        if (np == 0) NIC_CF_LAUNCH_C(0, WCV);                   \
+        else if (np == 1) NIC_CF_LAUNCH_C(1, WCV);              \
+        else NIC_CF_LAUNCH_C(2, WCV);                           \
+    } while (0)
+        if (wc == 2) NIC_CF_STORE_C(2);
+        else if (wc == 3) NIC_CF_STORE_C(3);
+        else if (wc == 4) NIC_CF_STORE_C(4);
+        else if (mf == 4) NIC_CF_STORE(4);
         else if (mf == 8) NIC_CF_STORE(8);
         else NIC_CF_STORE(16);
 #undef NIC_CF_STORE
+#undef NIC_CF_STORE_C
+#undef NIC_CF_LAUNCH_C
     }
 #undef NIC_CF_LAUNCH
     return nic::check_launch("nic_closed_form_rollout");

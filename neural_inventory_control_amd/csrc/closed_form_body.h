@@ -173,6 +173,39 @@ NIC_HD Dual<NP> cf_pipe_sum(const CfPipe<NP, MW>& p, int W) {
     return r;
 }
 
+// The same two functions for a pipeline whose length WC is a compile-time constant and whose lead time is the same for every
+// lane of the wavefront (a scenario-uniform lead-time table - every shipped setting): no select on W, and the order is placed by
+// ONE wave-uniform branch instead of a compare + two selects per slot.  Same additions in the same order (round 5: the period loop
+// of the 10^6-chain launch is bound by vector issue - 75 instructions per wave-period, a third of them these selects).
+template <int NP, int MW, int WC>
+NIC_HD Dual<NP> cf_pipe_sum_c(const CfPipe<NP, MW>& p) {
+    Dual<NP> r = p.s[0];
+#pragma unroll
+    for (int k = 1; k < WC; ++k) r = r + p.s[k];
+    return r;
+}
+template <int NP, int MW, int WC>
+NIC_HD CfPipe<NP, MW> cf_pipe_step_c(const CfPipe<NP, MW>& old, const Dual<NP>& after, const Dual<NP>& a, int uniform_slot) {
+    CfPipe<NP, MW> nw;
+    const bool place = a.v != 0.f;  // zero orders are filtered out before the put (:426-429)
+#pragma unroll
+    for (int k = 0; k < MW; ++k) {
+        Dual<NP> v = dconst<NP>(0.f);
+        if (k + 1 < MW && k < WC - 1) v = old.s[k + 1 < MW ? k + 1 : k];
+        if (k == 0) v = after + v;
+        nw.s[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < MW; ++k)
+        if (k == uniform_slot) {   // (uniform: a scalar branch)
+            const Dual<NP> w = nw.s[k] + a;
+            nw.s[k].v = place ? w.v : nw.s[k].v;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) nw.s[k].d[j] = place ? w.d[j] : nw.s[k].d[j];
+        }
+    return nw;
+}
+
 // new[0] = after + old[1]; new[k] = old[k+1]; new[W-1] = 0; new[L-1] += a if a != 0   (environment.py:405-432)
 template <int NP, int MW>
 NIC_HD CfPipe<NP, MW> cf_pipe_step(const CfPipe<NP, MW>& old, int W, const Dual<NP>& after, const Dual<NP>& a, float lead) {
@@ -200,15 +233,20 @@ struct CfState {
 
 // one period of dynamics of the chain (environment.py:179-299 for S = 1, Wn <= 1); returns the period cost.
 // CHAIN = false compiles the single-store form only (Wn = E = 0 known at compile time: base_stock / capped_base_stock)
-template <int NP, int MW, bool CHAIN>
+// FL: -1 = the setting's switches are read from the descriptor; 0..7 = compiled in (bit 0 round_orders, 1 lost_demand,
+// 2 maximize_profit): the whole-horizon loop of the specialised variant is instantiated per combination, so that a wave-uniform
+// switch costs one branch in front of the loop instead of a select per value and derivative in every period
+template <int NP, int MW, bool CHAIN, int WC = 0, int FL = -1>
 NIC_HD Dual<NP> cf_env_step(const NicClosedFormDesc& d, const CfStatics& c, CfState<NP, MW, CHAIN>& st, float dem,
-                            const CfOrders<NP>& o) {
+                            const CfOrders<NP>& o, int uniform_slot = -2) {
+    const bool maximize_profit = FL < 0 ? (bool)d.maximize_profit : (bool)(FL & 4);
+    const bool lost_demand = FL < 0 ? (bool)d.lost_demand : (bool)(FL & 2);
     const Dual<NP> on_hand = st.store.s[0];
     Dual<NP> after = dsub(on_hand, dem);
     Dual<NP> cost;
-    if (d.maximize_profit) cost = dscale(-c.p, dmin_const(on_hand, dem)) + dscale(c.h, drelu(after));  // :191-194
+    if (maximize_profit) cost = dscale(-c.p, dmin_const(on_hand, dem)) + dscale(c.h, drelu(after));  // :191-194
     else cost = dscale(c.p, drelu(dneg(after))) + dscale(c.h, drelu(after));                            // :198-201
-    if (d.lost_demand) after = drelu(after);                                                            // :204-205
+    if (lost_demand) after = drelu(after);                                                            // :204-205
     Dual<NP> total = cost;
     if (CHAIN) {
         // the warehouse ships what the store ordered (no clip, :249); echelon e ships what its downstream neighbour ordered
@@ -229,19 +267,20 @@ NIC_HD Dual<NP> cf_env_step(const NicClosedFormDesc& d, const CfStatics& c, CfSt
         total = total + r_e;
         st.wh = cf_pipe_step(st.wh, d.Ww, w_after, o.wh, c.wh_lead);
     }
-    st.store = cf_pipe_step(st.store, d.Ws, after, o.store, c.lead);
+    if (WC > 0) st.store = cf_pipe_step_c<NP, MW, (WC > 0 ? WC : 1)>(st.store, after, o.store, uniform_slot);
+    else st.store = cf_pipe_step(st.store, d.Ws, after, o.store, c.lead);
     return total;
 }
 
 // orders of the closed-form policies from the current state and the levels
-template <int NP, int MW, bool CHAIN>
+template <int NP, int MW, bool CHAIN, int WC = 0, int FL = -1>
 NIC_HD CfOrders<NP> cf_policy(const NicClosedFormDesc& d, const Dual<NP> (&lv)[NIC_CF_MAX_LEVELS],
                               const CfState<NP, MW, CHAIN>& st) {
     CfOrders<NP> o;
     o.store = o.wh = dconst<NP>(0.f);
 #pragma unroll
     for (int e = 0; e < CF_MAXE; ++e) o.ech[e] = dconst<NP>(0.f);
-    const Dual<NP> store_pos = cf_pipe_sum(st.store, d.Ws);
+    const Dual<NP> store_pos = WC > 0 ? cf_pipe_sum_c<NP, MW, (WC > 0 ? WC : 1)>(st.store) : cf_pipe_sum(st.store, d.Ws);
     if (!CHAIN && d.policy == NIC_CF_BASE_STOCK) {  // clip(level - position, min=0)            neural_networks.py:227-229
         o.store = drelu(lv[0] - store_pos);
     } else if (!CHAIN) {                           // clip(level - position, min=0, max=cap)   :306-311
@@ -286,7 +325,7 @@ NIC_HD CfOrders<NP> cf_policy(const NicClosedFormDesc& d, const Dual<NP> (&lv)[N
             }
         }
     }
-    if (d.round_orders) {  // discrete allocation (trainer.py:201-202)
+    if (FL < 0 ? (bool)d.round_orders : (bool)(FL & 1)) {  // discrete allocation (trainer.py:201-202)
         o.store = dround(o.store);
         o.wh = dround(o.wh);
 #pragma unroll
@@ -313,7 +352,40 @@ NIC_HD void cf_pipe_store(const CfPipe<NP, MW>& p, float* dst, int W, int64_t ld
 //   totals      [2][S][ldb]   sum over all periods / over periods >= ignore_periods
 //   state_final [S][F][ldb]
 //   g_levels    [NP] (returned through `g`): d(totals[0]) / d(level_j) of this chain
-template <int NP, int MW, bool CHAIN>
+constexpr int kCfAhead = 8;   // periods of demand fetched per batch (one batch in flight beside the one being simulated)
+// the period loop of a chain (see closed_form_chain), one instantiation per combination of the setting's switches where they
+// are compiled in
+template <int NP, int MW, bool CHAIN, int WC, int FL>
+NIC_HD void cf_horizon(const NicClosedFormDesc& d, const CfStatics& c, const Dual<NP> (&lv)[NIC_CF_MAX_LEVELS],
+                       CfState<NP, MW, CHAIN>& st, const float* dem_p, int64_t dem_stride, int uniform_slot, float* reward_hist,
+                       int s, int64_t b, int64_t ldb, Dual<NP>& total, float& reported) {
+    float cur[kCfAhead], nxt[kCfAhead];
+#pragma unroll
+    for (int j = 0; j < kCfAhead; ++j) cur[j] = dem_p[(int64_t)(j < d.T ? j : d.T - 1) * dem_stride];
+    for (int t0 = 0; t0 < d.T; t0 += kCfAhead) {
+#pragma unroll
+        for (int j = 0; j < kCfAhead; ++j) {
+            const int tn = t0 + kCfAhead + j;
+            nxt[j] = dem_p[(int64_t)(tn < d.T ? tn : d.T - 1) * dem_stride];
+        }
+#pragma unroll
+        for (int j = 0; j < kCfAhead; ++j) {
+            const int t = t0 + j;
+            if (t < d.T) {
+                const CfOrders<NP> o = cf_policy<NP, MW, CHAIN, WC, FL>(d, lv, st);
+                const Dual<NP> r = cf_env_step<NP, MW, CHAIN, WC, FL>(d, c, st, cur[j], o, uniform_slot);
+                total = total + r;
+                if (t >= d.ignore_periods) reported += r.v;
+                if (reward_hist) reward_hist[((int64_t)t * d.S + s) * ldb + b] = r.v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kCfAhead; ++j) cur[j] = nxt[j];
+    }
+}
+
+// WC > 0: the store pipeline has exactly WC slots and its lead time is wave-uniform (the caller checked both) - see cf_pipe_step_c
+template <int NP, int MW, bool CHAIN, int WC = 0>
 NIC_HD void closed_form_chain(const NicClosedFormDesc& d, float* reward_hist, float* totals, float* state_final, int s,
                               int64_t b, float (&g)[NP > 0 ? NP : 1]) {
     const int64_t ldb = d.ldb;
@@ -333,16 +405,31 @@ NIC_HD void closed_form_chain(const NicClosedFormDesc& d, float* reward_hist, fl
     float reported = 0.f;
     const float* dem_p = d.demand + ((int64_t)d.t0 * d.S + s) * ldb + b;
     const int64_t dem_stride = (int64_t)d.S * ldb;
-    float dem = dem_p[0];
-    for (int t = 0; t < d.T; ++t) {
-        const float dem_next = t + 1 < d.T ? dem_p[(int64_t)(t + 1) * dem_stride] : 0.f;  // next period's demand in flight
-        const CfOrders<NP> o = cf_policy<NP, MW, CHAIN>(d, lv, st);
-        const Dual<NP> r = cf_env_step<NP, MW, CHAIN>(d, c, st, dem, o);
-        total = total + r;
-        if (t >= d.ignore_periods) reported += r.v;
-        if (reward_hist) reward_hist[((int64_t)t * d.S + s) * ldb + b] = r.v;
-        dem = dem_next;
+    // The demand rows do not depend on the state: kCfAhead periods are fetched at a time, one batch ahead of the batch being
+    // simulated (unconditional loads of a clamped row; round 5: with ONE period in flight the SQ counters showed the waves of the
+    // 10^6-chain launch parked at s_waitcnt for 54 % of their cycles and the vector unit 58 % busy - the next row was issued only
+    // ~75 instructions before its use).  Same arithmetic in the same order: results are bit-identical.
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int uniform_slot = WC > 0 ? __builtin_amdgcn_readfirstlane((int)c.lead - 1) : -2;
+#else
+    const int uniform_slot = WC > 0 ? (int)c.lead - 1 : -2;
+#endif
+#define NIC_CF_RUN(FLV) cf_horizon<NP, MW, CHAIN, WC, FLV>(d, c, lv, st, dem_p, dem_stride, uniform_slot, reward_hist, s, b, ldb, total, reported)
+    if (WC > 0) {
+        switch ((d.round_orders ? 1 : 0) | (d.lost_demand ? 2 : 0) | (d.maximize_profit ? 4 : 0)) {
+            case 0: NIC_CF_RUN(0); break;
+            case 1: NIC_CF_RUN(1); break;
+            case 2: NIC_CF_RUN(2); break;
+            case 3: NIC_CF_RUN(3); break;
+            case 4: NIC_CF_RUN(4); break;
+            case 5: NIC_CF_RUN(5); break;
+            case 6: NIC_CF_RUN(6); break;
+            default: NIC_CF_RUN(7); break;
+        }
+    } else {
+        NIC_CF_RUN(-1);
     }
+#undef NIC_CF_RUN
     if (totals) {
         totals[(int64_t)s * ldb + b] = total.v;
         totals[((int64_t)d.S + s) * ldb + b] = reported;
