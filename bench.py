@@ -354,8 +354,8 @@ def algorithmic_work(tag, kernel, shape):
         if tag == "horizon_fwd":
             return "hbm", 4.0 * (h1 + S + 1 + (hist_rows if shape["train"] else 0)) * n * T, "B"
         return "hbm", 4.0 * (hist_rows + S + h1 + h2 + no) * n * T, "B"
-    if tag == "closed_form_fwd":  # whole-horizon closed-form policy: the demand trace + one state load / store + totals
-        return "hbm", 4.0 * (S * T + 2 * f_state + 2 * S) * n, "B"
+    if tag == "closed_form_fwd":  # whole-horizon closed-form policy: the demand trace + one state load / store (sums leave per wavefront)
+        return "hbm", 4.0 * (S * T + 2 * f_state) * n, "B"
     return None
 
 

@@ -439,6 +439,12 @@ int nic_closed_form_num_partials(int32_t n_scenarios, int32_t S);
  * (b >= n_scenarios) of the outputs are left untouched. */
 int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
                             float* g_levels_partial, void* stream);
+/* The same launch with the per-chain sums added over each wavefront of chains as well: partial [num_partials][partial_stride],
+ * row = [d(total)/d(level_j) for j < n_levels if with_grad][total, reported if with_sums] - the caller adds the rows and needs
+ * neither `totals` (8 B per chain written, then reduced by a second kernel over all chains) nor a separate gradient buffer.
+ * (Round 5: at 10^6 chains the reduction of `totals` took longer than the rollout.) */
+int nic_closed_form_rollout_sums(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final, float* partial,
+                                 int32_t partial_stride, int32_t with_grad, int32_t with_sums, void* stream);
 
 /* ---- whole-horizon rollout of the data_driven policy for small batches (csrc/horizon_rollout.hip) --------------------
  * The reference trains DataDrivenNet (neural_networks.py:430-515, data_driven_net.yml: two 64-wide hidden layers) on batches of

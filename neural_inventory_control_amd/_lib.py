@@ -198,6 +198,7 @@ PROTOTYPES = {
     "nic_segment_sum": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_closed_form_num_partials": (C.c_int, [_i32, _i32]),
     "nic_closed_form_rollout": (C.c_int, [C.POINTER(NicClosedFormDesc), _vp, _vp, _vp, _vp, _vp]),
+    "nic_closed_form_rollout_sums": (C.c_int, [C.POINTER(NicClosedFormDesc), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "nic_sample_demand": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i64, _u64, _i32, _vp, _vp, _i32, _vp]),
     "nic_sample_demand_equicorrelated": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i64, _u64, _vp, _vp, _f32, _i32, _vp]),
     "nic_axpy": (C.c_int, [_vp, _vp, _f32, _i64, _vp]),

@@ -93,6 +93,7 @@ class ClosedFormRollout:
         self.model, self.problem_params, self.device = model, problem_params, torch.device(device)
         self.name = model.nn_args["name"]
         self.keep_rewards = False   # per-period rewards [T][S][ldb] (inspection / tests); the trainer only needs the totals
+        self.keep_chain_totals = False   # per-chain totals [2][S][ldb] (inspection); the step's two sums come from per-wavefront partials
         self.timer = None
         self._probs = ProblemCache()
         self._key = None
@@ -101,14 +102,14 @@ class ClosedFormRollout:
         return supports_shapes(self.name, self._probs.get(self.problem_params, data, self.device))
 
     def _setup(self, prob, T):
-        key = (prob.B, T, prob.S, prob.Ws, prob.Wn, prob.Ww, prob.E, prob.We, self.keep_rewards)
+        key = (prob.B, T, prob.S, prob.Ws, prob.Wn, prob.Ww, prob.E, prob.We, self.keep_rewards, self.keep_chain_totals)
         if key == self._key:
             return
         dev, ld = self.device, prob.ldb
         F = prob.Ws + prob.Wn * prob.Ww + prob.E * prob.We
         self.state0 = torch.zeros(prob.S, F, ld, device=dev)
         self.state_final = torch.zeros(prob.S, F, ld, device=dev)
-        self.totals = torch.zeros(2, prob.S, ld, device=dev)
+        self.totals = torch.zeros(2, prob.S, ld, device=dev) if self.keep_chain_totals else None
         self.rewards = torch.zeros(T, prob.S, ld, device=dev) if self.keep_rewards else None
         self.n_partials = _lib.lib().nic_closed_form_num_partials(prob.B, prob.S)
         self._key = key
@@ -144,16 +145,19 @@ class ClosedFormRollout:
     def _launch(self, levels, args, want_grad):
         prob, T, shift, ignore, demand_soa, rounded = args
         desc = make_desc(prob, self.name, T, shift, ignore, levels, demand_soa, self.state0, rounded)
-        partial = torch.empty(self.n_partials, levels.numel(), device=self.device) if want_grad else None
-        call = lambda: _lib.check(_lib.lib().nic_closed_form_rollout(  # noqa: E731
-            desc, _lib.ptr(self.rewards), _lib.ptr(self.totals), _lib.ptr(self.state_final), _lib.ptr(partial),
-            _lib.current_stream()))
+        # one row per wavefront of chains: [d total / d level_j ...][total, reported]; ONE small sum gives the step's numbers (the
+        # reduction of per-chain totals - 2 x 10^6 floats into 2 - was the longest launch of the 10^6-chain step)
+        ng = levels.numel() if want_grad else 0
+        partial = torch.empty(self.n_partials, ng + 2, device=self.device)
+        call = lambda: _lib.check(_lib.lib().nic_closed_form_rollout_sums(  # noqa: E731
+            desc, _lib.ptr(self.rewards), _lib.ptr(self.totals), _lib.ptr(self.state_final), _lib.ptr(partial), ng + 2,
+            int(want_grad), 1, _lib.current_stream()))
         if self.timer is not None:
             self.timer.call("closed_form_fwd", call)
         else:
             call()
-        sums = self.totals.sum(dim=(1, 2))
-        return sums[0], sums[1], (partial.sum(dim=0) if want_grad else None)
+        sums = partial.sum(dim=0)
+        return sums[ng], sums[ng + 1], (sums[:ng] if want_grad else None)
 
     # ---- inspection helpers used by the parity tests ------------------------------------------------------------------
     def per_period_rewards(self):

@@ -16,25 +16,37 @@ __global__ __launch_bounds__(kBlock) void closed_form_kernel(NicClosedFormDesc d
                                                               const float* __restrict__ demand,
                                                               const float* __restrict__ state0, float* __restrict__ reward_hist,
                                                               float* __restrict__ totals, float* __restrict__ state_final,
-                                                              float* __restrict__ g_partial) {
+                                                              float* __restrict__ partial, int partial_stride, int sums_at) {
     const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int s = blockIdx.y;
     d.levels = levels;
     d.demand = demand;
     d.state0 = state0;
     float g[NP > 0 ? NP : 1];
+    float sums[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < (NP > 0 ? NP : 1); ++j) g[j] = 0.f;
-    if (b < d.n_scenarios) nic::closed_form_chain<NP, MF, CHAIN, WC>(d, reward_hist, totals, state_final, s, b, g);
-    if (NP > 0 && g_partial) {
+    if (b < d.n_scenarios) nic::closed_form_chain<NP, MF, CHAIN, WC>(d, reward_hist, totals, state_final, s, b, g, sums);
+    if (partial) {   // one row per wavefront of chains: [d total / d level_j ...][total, reported from column sums_at on, if >= 0]
+        const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+        const int64_t n_waves = (d.n_scenarios + kWave - 1) / kWave;
+        float* row = partial + ((int64_t)blockIdx.y * n_waves + wave_id) * partial_stride;
+        const bool writer = (threadIdx.x & (kWave - 1)) == 0 && wave_id < n_waves;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             float v = g[j];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-            const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;   // one partial per wavefront of chains
-            const int64_t n_waves = (d.n_scenarios + kWave - 1) / kWave;
-            if ((threadIdx.x & (kWave - 1)) == 0 && wave_id < n_waves) g_partial[((int64_t)blockIdx.y * n_waves + wave_id) * NP + j] = v;
+            if (writer) row[j] = v;
+        }
+        if (sums_at >= 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v = sums[j];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+                if (writer) row[sums_at + j] = v;
+            }
         }
     }
 }
@@ -69,10 +81,15 @@ int nic_closed_form_num_partials(int32_t n_scenarios, int32_t S) {
     return nic::ceil_div(n_scenarios, kWave) * S;
 }
 
-int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
-                            float* g_levels_partial, void* stream) {
+int nic_closed_form_rollout_sums(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final, float* partial,
+                                 int32_t partial_stride, int32_t with_grad, int32_t with_sums, void* stream) {
+    float* g_levels_partial = with_grad ? partial : nullptr;
     if (int e = validate(d)) return e;
     NIC_REQUIRE(!(d->round_orders && g_levels_partial), "nic_closed_form_rollout: rounded orders have no gradient");
+    NIC_REQUIRE(!(with_grad || with_sums) || (partial && partial_stride >= (with_grad ? d->n_levels : 0) + (with_sums ? 2 : 0)),
+                "nic_closed_form_rollout: partial buffer missing or its rows too short");
+    const int sums_at = with_sums ? (with_grad ? d->n_levels : 0) : -1;
+    float* part = (with_grad || with_sums) ? partial : nullptr;
     const dim3 grid(nic::ceil_div(d->n_scenarios, kBlock), d->S), block(kBlock);
     hipStream_t s = nic::as_stream(stream);
     const int np = g_levels_partial ? d->n_levels : 0;
@@ -87,7 +104,7 @@ int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, floa
     else nic::note_kernelf("closed_form_kernel<%d,%d,%s>", np, mf, chain ? "true" : "false");
 #define NIC_CF_LAUNCH(NP, MF, CH)                                                                                          \
     hipLaunchKernelGGL((closed_form_kernel<NP, MF, CH>), grid, block, 0, s, *d, d->levels, d->demand, d->state0, reward_hist, \
-                       totals, state_final, g_levels_partial)
+                       totals, state_final, part, partial_stride, sums_at)
     if (chain) {  // echelon_stock on the serial system: E + 2 = 3..5 levels
 #define NIC_CF_CHAIN(MF)                                        \
     do {                                                        \
@@ -109,7 +126,7 @@ int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, floa
     } while (0)
 #define NIC_CF_LAUNCH_C(NP, WCV)                                                                                               \
     hipLaunchKernelGGL((closed_form_kernel<NP, 4, false, WCV>), grid, block, 0, s, *d, d->levels, d->demand, d->state0, reward_hist, \
-                       totals, state_final, g_levels_partial)
+                       totals, state_final, part, partial_stride, sums_at)
 #define NIC_CF_STORE_C(WCV)                                     \
     do {                                                        \
         if (np == 0) NIC_CF_LAUNCH_C(0, WCV);                   \
@@ -128,5 +145,11 @@ int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, floa
     }
 #undef NIC_CF_LAUNCH
     return nic::check_launch("nic_closed_form_rollout");
+}
+
+int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
+                            float* g_levels_partial, void* stream) {
+    return nic_closed_form_rollout_sums(d, reward_hist, totals, state_final, g_levels_partial, d ? d->n_levels : 0,
+                                        g_levels_partial != nullptr, 0, stream);
 }
 }

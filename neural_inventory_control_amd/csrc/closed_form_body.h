@@ -387,7 +387,7 @@ NIC_HD void cf_horizon(const NicClosedFormDesc& d, const CfStatics& c, const Dua
 // WC > 0: the store pipeline has exactly WC slots and its lead time is wave-uniform (the caller checked both) - see cf_pipe_step_c
 template <int NP, int MW, bool CHAIN, int WC = 0>
 NIC_HD void closed_form_chain(const NicClosedFormDesc& d, float* reward_hist, float* totals, float* state_final, int s,
-                              int64_t b, float (&g)[NP > 0 ? NP : 1]) {
+                              int64_t b, float (&g)[NP > 0 ? NP : 1], float* chain_sums = nullptr) {
     const int64_t ldb = d.ldb;
     const int F = d.Ws + d.Wn * d.Ww + d.E * d.We;
     const CfStatics c = cf_load_statics(d, s, b);
@@ -433,6 +433,10 @@ NIC_HD void closed_form_chain(const NicClosedFormDesc& d, float* reward_hist, fl
     if (totals) {
         totals[(int64_t)s * ldb + b] = total.v;
         totals[((int64_t)d.S + s) * ldb + b] = reported;
+    }
+    if (chain_sums) {   // (the caller's registers: the kernel adds them over the wavefront)
+        chain_sums[0] = total.v;
+        chain_sums[1] = reported;
     }
     if (state_final) {
         float* f0 = state_final + (int64_t)s * F * ldb + b;
