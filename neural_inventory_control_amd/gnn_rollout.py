@@ -140,11 +140,13 @@ class _Mlp:
     """Packed weights, gradient slabs and per-period history of one of the policy's five MLPs."""
 
     def __init__(self, name, linears, K, n_out, out_act, n_ent, ld, T, P, device, train, mode="hist", keep_inputs=True,
-                 n_live=None):
+                 n_live=None, dense=False):
         self.name, self.linears, self.K, self.n_out, self.out_act, self.n_ent = name, linears, K, n_out, out_act, n_ent
         self.n_live = n_ent if n_live is None else n_live   # entities the MLP is evaluated for (the first n_live of its buffers)
         z = lambda *s: torch.zeros(*s, device=device)  # noqa: E731
         self.packed = z(32 * K + 32 + 32 * 32 + 32 + n_out * 32 + n_out)
+        if dense:   # every column is a scenario: the forward writes all of what the backward reads - no 10-GB zero fill at set-up
+            z = lambda *s: torch.empty(*s, device=device)  # noqa: E731
         self.Y = z(T, n_out, n_ent, ld)
         self.P, self.G = P, (T + P - 1) // P
         self.hist_stride = 0
@@ -165,16 +167,16 @@ class _Mlp:
             self.native = not keep_inputs
             self.H1, self.H2 = (z(G, P, 32 * n_ent * ld), z(G, P, 32 * n_ent * ld)) if self.native else \
                                (z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld))
-            self.slabs = [z(ops.mlp3_bwd_hist_slots(), n, (k + 1 + 3) // 4 * 4) for n, k in dims]
-            self.dX = z(K, n_ent, ld)
+            self.slabs = [torch.zeros(ops.mlp3_bwd_hist_slots(), n, (k + 1 + 3) // 4 * 4, device=device) for n, k in dims]
+            self.dX = torch.zeros(K, n_ent, ld, device=device)
             self.gw = [torch.zeros_like(m.weight) for m in linears]
             self.gb = [torch.zeros_like(m.bias) for m in linears]
         elif train and mode == "fused":
             # history-free backward (nic_mlp3_bwd_fused): the kernel re-gathers the inputs, recomputes the hidden layers and
             # contracts the weight gradients itself; one slab slot per wavefront, accumulated over the periods
             slots = ops.mlp3_bwd_fused_slots()
-            self.slabs = [z(slots, n, (k + 1 + 3) // 4 * 4) for n, k in dims]
-            self.dX = z(K, n_ent, ld)
+            self.slabs = [torch.zeros(slots, n, (k + 1 + 3) // 4 * 4, device=device) for n, k in dims]
+            self.dX = torch.zeros(K, n_ent, ld, device=device)
             self.gw = [torch.zeros_like(m.weight) for m in linears]
             self.gb = [torch.zeros_like(m.bias) for m in linears]
         elif train:
@@ -322,10 +324,15 @@ class GnnRollout:
             self._keep_inputs = h_bytes + x_bytes <= 0.6 * free
         self._mode_now = mode or "hist"
         self._fused_bwd_now = self._mode_now == "fused"
+        native_hist = self._mode_now == "hist" and not (self._keep_inputs and bool(self.keep_inputs))
+        will_period = bool(self.use_period_kernel) and ops.gnn_period_ok(N, E, self.Dn) and \
+            ((not train) or self._mode_now == "fused" or native_hist)
+        dense = will_period and train and prob.B == ld and native_hist
         self.mlp = {name: _Mlp(name, self._linears(name), k, 1 if name == "output" else 32,
                                A.NIC_MLP3_ACT_SOFTPLUS if name == "output" else A.NIC_MLP3_ACT_ELU, ne, ld, T, P_, dev, train,
                                self._mode_now, self._keep_inputs and bool(self.keep_inputs),
-                               n_live=P.n_live if name in ("edge_update", "output") else None)
+                               n_live=P.n_live if name in ("edge_update", "output") else None,
+                               dense=dense)
                     for name, k, ne in zip(MODULES, ks, ents)}
         self._graphs, self._eager_runs, self._auto_graph = {}, 0, None   # (a new shape is measured afresh)
         self._period, self._pdesc = False, {}
@@ -343,8 +350,9 @@ class GnnRollout:
             elif self.use_period_kernel is True:
                 raise ValueError("use_period_kernel: " + ("the backward mode keeps row-layout histories" if fits else
                                                           f"{N} nodes + {E} edges do not fit in a workgroup's LDS"))
-        self.agg = z(T, 32, 2 * N, ld)   # message aggregation: [:, :N] over incoming edges, [:, N:] over outgoing edges
-        self.nodes1, self.edges1 = z(T, 32, N, ld), z(T, 32, E, ld)
+        zb = (lambda *s_: torch.empty(*s_, device=dev)) if dense else z   # (written in full by the period kernel before any read)
+        self.agg = zb(T, 32, 2 * N, ld)   # message aggregation: [:, :N] over incoming edges, [:, N:] over outgoing edges
+        self.nodes1, self.edges1 = zb(T, 32, N, ld), zb(T, 32, E, ld)
         self.sums, self.ratio, self.scale = z(T, Wn, ld), z(T, Wn, ld), z(T, Wn, ld)
         if train:
             self.g_state = [z(f_tot, ld), z(f_tot, ld)]
