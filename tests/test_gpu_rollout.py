@@ -1701,6 +1701,42 @@ def test_gnn_fused_alloc_env_launches_equal_the_separate_ones(name):
     assert abs(a[0] - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
 
 
+@pytest.mark.parametrize("n", [1000, 8192 + 5])
+def test_gnn_period_kernel_at_ragged_batch_sizes(n):
+    """The period kernel's 16-scenario blocks at batch sizes that are not a multiple of 16 (a half-filled last block: its dead
+    lanes compute on zeros and must store nothing) and not a multiple of 32 (half a native history block per entity): costs,
+    per-period rewards, final state and every gradient against the per-MLP launches on the bench's GNN workload; the padding
+    columns of the state stay zero."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout
+    setting, policy, _, _, _ = workloads.get("gnn")
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    T = 6
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
+                  n, obs, dict(setting["seeds"]), sampler="hip", device=DEV)
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    out = {}
+    for period in (True, False):
+        torch.manual_seed(3)
+        model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+        eng = GnnRollout(model, setting["problem_params"], DEV)
+        eng.use_period_kernel = period
+        eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+        total, rep = eng.run(data, T, 2, train=True, observation_params=setting["observation_params"], demand_soa=sc.demands_soa)
+        torch.cuda.synchronize()
+        assert eng._period == period
+        assert float(eng.states[:, :, n:].abs().max()) == 0.0 if eng.states.shape[2] > n else True
+        out[period] = (float(total), float(rep), eng.rewards[:, :n].clone(), eng.states[-1][:, :n].clone(),
+                       [p.grad.clone() for p in model.parameters()])
+    a, b = out[True], out[False]
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(b[1])
+    torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(a[3], b[3], rtol=1e-5, atol=1e-4)
+    for x, y in zip(a[4], b[4]):
+        assert float((x - y).norm() / (y.norm() + 1e-30)) <= 1e-5
+
+
 def test_initial_inventories_written_behind_torchs_back_are_seen():
     """A batch tensor rewritten WITHOUT a version bump (`.data` copy - what a raw-pointer kernel or `set_()` also looks like to
     torch) must still reach the whole-horizon kernels: by default every presented batch is copied into the engine's state
