@@ -1737,6 +1737,49 @@ def test_gnn_period_kernel_at_ragged_batch_sizes(n):
         assert float((x - y).norm() / (y.norm() + 1e-30)) <= 1e-5
 
 
+@pytest.mark.parametrize("slots,variant", [(7, "gnn_period_fwd_kernel<8,"), (11, "gnn_period_fwd_kernel<16,")])
+def test_gnn_period_kernel_with_long_pipelines(slots, variant):
+    """The period kernel's variants for store pipelines of more than 4 slots (env bodies instantiated for 8 / 16 slots, eight
+    wavefronts per workgroup instead of sixteen) - no golden fixture has such pipelines on a one-warehouse graph: training and
+    evaluation runs against the per-MLP launches + `nic_gnn_alloc_env_fwd` on a 5-store setting with lead times up to `slots`."""
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout
+    from neural_inventory_control_amd.rollout import KernelTimer
+    setting, policy, _, _, _ = workloads.get("gnn")
+    setting["problem_params"]["n_stores"] = 5
+    setting["store_params"]["lead_time"] = {"sample_across_stores": True, "vary_across_samples": False, "expand": False,
+                                            "range": [2, slots + 1]}
+    setting["store_params"]["initial_inventory"]["inventory_periods"] = slots
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    T, n = 2 * slots, 200
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
+                  n, obs, dict(setting["seeds"]), sampler="hip", device=DEV)
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    assert data["initial_inventories"].shape[2] == slots and int(data["lead_times"].max()) > 4
+    for train in (True, False):
+        out = {}
+        for period in (True, False):
+            torch.manual_seed(3)
+            model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+            eng = GnnRollout(model, setting["problem_params"], DEV)
+            eng.use_period_kernel = period
+            eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+            eng.timer = KernelTimer(record_order=True)
+            total, rep = eng.run(data, T, 3, train=train, observation_params=setting["observation_params"], demand_soa=sc.demands_soa)
+            torch.cuda.synchronize()
+            if period:
+                assert any(k.startswith(variant) for _, k in eng.timer.order), sorted({k for _, k in eng.timer.order})
+            out[period] = (float(total), float(rep), eng.rewards[:, :n].clone(), eng.states[-1][:, :n].clone(),
+                           [p.grad.clone() for p in model.parameters()] if train else [])
+        a, b = out[True], out[False]
+        assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(b[1])
+        torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(a[3], b[3], rtol=1e-5, atol=1e-4)
+        for x, y in zip(a[4], b[4]):
+            assert float((x - y).norm() / (y.norm() + 1e-30)) <= 1e-5
+
+
 def test_initial_inventories_written_behind_torchs_back_are_seen():
     """A batch tensor rewritten WITHOUT a version bump (`.data` copy - what a raw-pointer kernel or `set_()` also looks like to
     torch) must still reach the whole-horizon kernels: by default every presented batch is copied into the engine's state
