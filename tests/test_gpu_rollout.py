@@ -1525,6 +1525,64 @@ def test_trainer_takes_closed_form_route_and_matches_reference(name):
     assert res[(True, "disc")] != res[True]
 
 
+@pytest.mark.parametrize("policy_name", ["base_stock", "capped_base_stock"])
+@pytest.mark.parametrize("Ws", [2, 3, 4])
+def test_closed_form_specialised_variants_equal_the_generic_kernel(policy_name, Ws):
+    """Round 5: single-store chains whose lead-time table does not vary over the scenarios run `closed_form_kernel<NP,4,false,Ws>`
+    (pipeline length compiled in, the order placed by one wave-uniform branch, lost-demand / profit / rounding resolved in front
+    of the period loop).  Same arithmetic in the same order as the generic kernel: rewards, totals, final state and the level
+    gradients are BIT-IDENTICAL, for every combination of the three switches, pipeline lengths 2-4, lead times 1..Ws, with and
+    without tangents, on a batch that does not fill its last wavefront.  (The generic kernel is reached by handing the same
+    lead times over as a per-scenario table.)"""
+    from neural_inventory_control_amd import closed_form as cf, _lib as L
+    from neural_inventory_control_amd.layout import EnvProblem
+    B, S, T = 300, 3, 13
+    gen = torch.Generator().manual_seed(Ws * 7 + len(policy_name))
+    for lost in (True, False):
+        for profit in (True, False):
+            for rounded in (False, True):
+                pp = {"n_stores": S, "n_warehouses": 0, "n_extra_echelons": 0, "lost_demand": lost, "maximize_profit": profit}
+                lead = torch.randint(1, Ws + 1, (S,), generator=gen).float()
+                data = {"demands": (torch.rand(B, S, T, generator=gen) * 8).to(DEV),
+                        "initial_inventories": (torch.rand(B, S, Ws, generator=gen) * 6).to(DEV),
+                        "underage_costs": torch.full((B, S), 9.0, device=DEV), "holding_costs": torch.full((B, S), 1.0, device=DEV),
+                        "lead_times": lead.to(DEV).expand(B, S).contiguous()}
+                prob = EnvProblem(pp, data, DEV)
+                assert prob.lead.scn_stride == 0 and prob.Ws == Ws
+                ld = prob.ldb
+                levels = torch.tensor([11.5, 7.25][:1 if policy_name == "base_stock" else 2], device=DEV)
+                demand = torch.zeros(T, S, ld, device=DEV)
+                demand[:, :, :B] = data["demands"].permute(2, 1, 0)
+                state0 = cf.pack_state0(data, prob)
+                per_scn = torch.zeros(S, ld, device=DEV)
+                per_scn[:, :B] = lead.to(DEV)[:, None]
+                res = {}
+                for which in ("specialised", "generic"):
+                    desc = cf.make_desc(prob, policy_name, T, 0, 4, levels, demand, state0, round_orders=rounded)
+                    if which == "generic":
+                        desc.lead = L.NicTable2(per_scn.data_ptr(), ld, 1)
+                    outs = []
+                    for want_grad in ([False] if rounded else [True, False]):
+                        rewards, totals, final = torch.zeros(T, S, ld, device=DEV), torch.zeros(2, S, ld, device=DEV), \
+                            torch.zeros(S, Ws, ld, device=DEV)
+                        n_part = L.lib().nic_closed_form_num_partials(B, S)
+                        part = torch.zeros(n_part, levels.numel() + 2, device=DEV)
+                        L.check(L.lib().nic_closed_form_rollout_sums(desc, rewards.data_ptr(), totals.data_ptr(), final.data_ptr(),
+                                                                     part.data_ptr(), levels.numel() + 2, int(want_grad), 1,
+                                                                     L.current_stream()))
+                        torch.cuda.synchronize()
+                        name = (L.lib().nic_last_kernel() or b"").decode()
+                        assert name.endswith(f",false,{Ws}>") == (which == "specialised"), name
+                        ng = levels.numel() if want_grad else 0
+                        # the per-wavefront sums add up to the per-chain totals
+                        assert abs(float(part[:, ng].double().sum()) - float(totals[0].double().sum())) <= 1e-6 * abs(float(totals[0].double().sum()))
+                        outs.append((rewards, totals, final, part))
+                    res[which] = outs
+                for a, b in zip(res["specialised"], res["generic"]):
+                    for x, y in zip(a, b):
+                        assert torch.equal(x, y), (lost, profit, rounded)
+
+
 def test_closed_form_multi_store_and_training():
     """base_stock on 5 independent stores (Wn = 0): every store is its own chain (grid.y); a few Adam steps through
     `Trainer.do_one_epoch` lower the cost, and the fused route follows the generic route step for step."""
