@@ -85,13 +85,20 @@ class _HipLinearForward:
     fused_act = _lib.NIC_ACT_NONE
 
     def forward(self, x):
+        # while a compiler traces the policy the layer is the registered operator `nic::linear` (library.py: fake-tensor kernel +
+        # autograd formula, so the traced graph survives); eager calls take the autograd.Function - same kernels, no dispatcher
+        if torch.compiler.is_compiling():
+            from . import library  # noqa: F401  (registers the operators)
+            apply = lambda x2, w, b, act: torch.ops.nic.linear(x2, w, b, act)  # noqa: E731
+        else:
+            apply = _LinearFunction.apply
         if x.dim() == 1:  # closed-form policies feed a constant scalar input (neural_networks.py:228 in the reference)
-            return _LinearFunction.apply(x.unsqueeze(0), self.weight, self.bias, self.fused_act).squeeze(0)
+            return apply(x.unsqueeze(0), self.weight, self.bias, self.fused_act).squeeze(0)
         if x.dim() > 2:  # (batch, nodes-or-edges, features): every leading index is one GEMM column (GNN policy)
             lead = x.shape[:-1]
-            y = _LinearFunction.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias, self.fused_act)
+            y = apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias, self.fused_act)
             return y.reshape(*lead, y.shape[-1])
-        return _LinearFunction.apply(x, self.weight, self.bias, self.fused_act)
+        return apply(x, self.weight, self.bias, self.fused_act)
 
 
 class HipLinear(_HipLinearForward, nn.Linear):
