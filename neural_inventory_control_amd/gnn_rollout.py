@@ -253,6 +253,16 @@ class GnnRollout:
         # on one-warehouse graphs) instead of ~8: "auto" = wherever the graph's embeddings fit in LDS and the backward reads the
         # native histories (or nothing); True raises where that does not hold; False = the per-MLP launches
         self.use_period_kernel = "auto"
+        # What happens to a non-zero store order booked on a column whose lead time is 0 (only the GNN on a sparse many-warehouse
+        # graph produces such orders: upstream writes store s's j-th CONNECTED edge into action column j, neural_networks.py:1423-1428).
+        #   "drop"      (default) the HIP env step discards it (it still leaves the warehouse): scenarios stay independent, which
+        #               is what scenario sharding needs
+        #   "upstream"  the reference's own result: its flat-index put (environment.py:415-432) adds the order to the element IN
+        #               FRONT of the store's pipeline - the last slot of the previous store, for store 0 of the previous SCENARIO,
+        #               for scenario 0 of the batch's last scenario - reproduced here as a fix-up after the env step and its adjoint
+        #               in the sweep, so that this engine matches the reference's golden numbers on such graphs (single process only:
+        #               the coupling crosses shard boundaries)
+        self.zero_lead_orders = "drop"
         self._auto_graph = None
         self.auto_graph_probe = None
         self._probs = ProblemCache()
@@ -400,6 +410,10 @@ class GnnRollout:
                 pk.pack()
         # per-edge lead-time input rows: sample 0 of THIS batch stands for the batch, as upstream re-reads it every forward
         # (:984) - refreshed on the device (no sync, capturable), so a later batch of the same shape never sees stale values
+        if self.zero_lead_orders == "upstream":
+            if P.Wn == 1:
+                raise ValueError("zero_lead_orders='upstream' only matters on many-warehouse graphs (one warehouse: every store has its edge)")
+            self._lead_times_sample0, self._zl_pairs = data["lead_times"][0].detach().cpu(), None   # (one host read per run)
         P.lead[0, :P.n_int].copy_(data["lead_times"][0][P.lead_store, P.lead_wh])
         P.lead[0, P.n_int:P.n_int + P.Wn].copy_(data["warehouse_lead_times"][0, :P.Wn])
         s0 = self._views(self.states[0], prob)
@@ -601,6 +615,23 @@ class GnnRollout:
         ts, tw = self._order_tables(orders, prob)
         self._k("env_fwd", ops.env_step_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
                 out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
+        if self.zero_lead_orders == "upstream":
+            nxt = self._views(self.states[t + 1], prob).store            # [S][Ws][ld]
+            for s_, j_ in self._zero_lead_pairs(prob):
+                v = orders[s_ * P.Wn + j_, :B]
+                if s_ >= 1:
+                    nxt[s_ - 1, prob.Ws - 1, :B] += v
+                else:   # in front of scenario b's first store lies scenario b - 1's last one (b = 0: the batch's last scenario)
+                    nxt[S - 1, prob.Ws - 1, :B] += torch.roll(v, -1)
+
+    def _zero_lead_pairs(self, prob):
+        """(store, action column) pairs whose lead time is 0 (sample 0 stands for the batch, as upstream reads it)."""
+        pairs = getattr(self, "_zl_pairs", None)
+        if pairs is None or self._zl_key != id(prob):
+            lt = self._lead_times_sample0   # [S][Wn] on the host
+            pairs = self._zl_pairs = [(s_, j_) for s_ in range(lt.shape[0]) for j_ in range(lt.shape[1]) if float(lt[s_, j_]) == 0.0]
+            self._zl_key = id(prob)
+        return pairs
 
     def _backward_period(self, t, prob, demand_soa, shift, g_next, g_cur):
         P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
@@ -616,6 +647,14 @@ class GnnRollout:
         else:
             self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
                     self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=gc, g_orders=(g_so, g_wo, None))
+        if self.zero_lead_orders == "upstream" and not fused:
+            # adjoint of the fix-up: the order's gradient is the state gradient of the element it was added to - where it was
+            # added at all (upstream filters zero orders out before the put: no gradient through them)
+            gn = self._views(g_next, prob).store
+            for s_, j_ in self._zero_lead_pairs(prob):
+                row = s_ * P.Wn + j_
+                g_t = gn[s_ - 1, prob.Ws - 1, :B] if s_ >= 1 else torch.roll(gn[S - 1, prob.Ws - 1, :B], 1)
+                self.g_orders[row, :B] += g_t * (self.orders[t][row, :B] != 0)
         # allocation adjoint: alloc_e = out_e * min(1, on_hand / (sum + eps)) for the members, supplier edge passes through
         if fused:
             pass

@@ -1867,6 +1867,34 @@ def test_initial_inventories_written_behind_torchs_back_are_seen():
     assert out[True][1] == out[True][0]          # opt-in skip: it is not (documented)
 
 
+@pytest.mark.parametrize("period", [True, False])
+def test_gnn_upstream_zero_lead_mode_matches_the_reference_itself(period):
+    """`GnnRollout.zero_lead_orders = "upstream"`: on the sparse many-warehouse fixture - where the reference's GNN books some
+    store orders on a column whose lead time is 0 and its env step then adds them to the element in front of the store's pipeline
+    (previous store / previous scenario) - the engine reproduces the REFERENCE's own golden numbers (rewards, totals, final state,
+    all 30 gradients), not the oracle's "drop" variant the default mode is compared with."""
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout
+    g = Golden("f1_many_warehouses_2x10_gnn")
+    c = g.fresh_config()
+    model = _model(g, c)
+    eng = GnnRollout(model, c["problem_params"], DEV)
+    eng.zero_lead_orders = "upstream"
+    eng.use_period_kernel = period
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+    _load(model, g)
+    total, reported = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
+    torch.cuda.synchronize()
+    assert eng._zero_lead_pairs(eng.prob)   # the fixture does have such columns
+    torch.testing.assert_close(eng.per_period_rewards().cpu(), g.tensor("rewards"), rtol=1e-5, atol=1e-4)
+    assert abs(float(total) - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
+    assert abs(float(reported) - float(g.z["reported"])) <= 1e-5 * abs(float(g.z["reported"]))
+    final = eng.final_state()
+    for k, v in g.states(c["periods"]).items():
+        torch.testing.assert_close(final[k].cpu(), v, **STATE_TOL)
+    _check_grads(model, g, GRAD_TOL)
+
+
 @pytest.mark.parametrize("mode", ["hist", True, "eval"])
 @pytest.mark.parametrize("name", GNN_CASES)
 def test_gnn_period_kernel_matches_the_per_mlp_launches(name, mode):
