@@ -76,6 +76,11 @@ class Simulator:
         self.observation_space = None
         self._prob = None
         self._t = 0
+        # what becomes of a non-zero store order on a (store, supplier) pair whose lead time is 0: "drop" (the kernel's rule,
+        # default) or "upstream" (the reference's flat-index put, environment.py:415-432: the order is added to the element in
+        # front of the store's pipeline - previous store / previous scenario - reproduced as a differentiable fix-up behind the
+        # kernel; single process only, see gnn_rollout.GnnRollout.zero_lead_orders)
+        self.zero_lead_orders = "drop"
 
     # ---- reset (environment.py:24-75, 301-345) ----------------------------------------------------------------
     def reset(self, periods, problem_params, data, observation_params):
@@ -98,6 +103,7 @@ class Simulator:
 
         prob = self._problem_for(problem_params, data, dev)
         self._prob = prob
+        self._lead_times = data["lead_times"]
         # demand trace in [T][S][ldb]: the per-period read of the kernel is then one contiguous (S x ldb) panel instead
         # of the reference's stride-T gather (environment.py:177)
         d = data["demands"]
@@ -135,6 +141,21 @@ class Simulator:
         self.maximize_profit = problem_params["maximize_profit"]
         return self.observation, None
 
+    def _add_zero_lead_orders(self, store, a_store):
+        """Upstream's treatment of non-zero orders with lead time 0 (which the kernel dropped): each is added to the flat element in
+        front of its store's pipeline.  Plain torch ops on the scenario-minor state, so autograd carries the order's gradient."""
+        lt = self._lead_times
+        B, S, Ws = self.batch_size, self.n_stores, store.shape[1]
+        if lt.dim() == 2:
+            lt = lt.unsqueeze(2)
+        hit = (lt.to(a_store.device) == 0) & (a_store.detach() != 0)            # (B, S, suppliers)
+        u = (a_store * hit).sum(dim=2)                                           # (B, S): what each store's misplaced orders add up to
+        delta = torch.zeros_like(store)                                          # [S][Ws][ld]
+        if S > 1:
+            delta[:S - 1, Ws - 1, :B] = u[:, 1:].t()                             # store s >= 1 -> last slot of store s - 1
+        delta[S - 1, Ws - 1, :B] = delta[S - 1, Ws - 1, :B] + torch.roll(u[:, 0], -1)   # store 0 -> previous scenario's last store
+        return store + delta
+
     def _problem_for(self, problem_params, data, dev):
         """EnvProblem of a batch, cached per presented tensors (layout.ProblemCache: entries pin the tensors they were
         keyed on), so a rollout over a batch seen before contains no host sync at all - a requirement for capturing it
@@ -168,6 +189,8 @@ class Simulator:
         demand = Table(self._demand_soa[tt], prob.ldb, 1)
         st = self._state
         store, wh, ech, reward = _EnvStepFunction.apply(prob, demand, st.store, st.wh, st.ech, a_store, a_wh, a_ech)
+        if self.zero_lead_orders == "upstream":
+            store = self._add_zero_lead_orders(store, a_store)
         self._state = EnvState(store, wh, ech)
         B = self.batch_size
         obs["store_inventories"] = ref_view(store, B)

@@ -354,6 +354,8 @@ class Trainer:
                     eng2._trainer_shape = shape
                 eng = eng2
             eng.use_graph = self.use_rollout_graph   # (both engines: True / False / "auto" = by measurement per shape)
+            if hasattr(eng, "zero_lead_orders"):   # (the Simulator's rule for orders without a lead time also holds on the fused route)
+                eng.zero_lead_orders = getattr(simulator, "zero_lead_orders", "drop")
             for opt_ in ("fuse_tail", "use_wide", "use_period_kernel"):   # (A/B switches of the engines' routes: set on the trainer, handed on)
                 if hasattr(self, opt_) and hasattr(eng, opt_):
                     setattr(eng, opt_, getattr(self, opt_))

@@ -1867,6 +1867,50 @@ def test_initial_inventories_written_behind_torchs_back_are_seen():
     assert out[True][1] == out[True][0]          # opt-in skip: it is not (documented)
 
 
+def test_simulator_upstream_zero_lead_mode_on_the_hand_computed_period_and_the_fixture():
+    """`Simulator.zero_lead_orders = "upstream"`: (1) the hand-computed period of kernel_checks.zero_lead_micro_case - the order of 4
+    on a column without a lead time lands on the LAST element of the batch (one scenario: store 1's last slot), everything else as
+    in "drop" mode, and its gradient is the gradient of that element; (2) `Trainer.simulate_batch` on the reference's sparse
+    many-warehouse GNN fixture reproduces the reference's own totals on BOTH routes (generic Simulator.step loop, fused engine) -
+    the trainer hands the simulator's rule to the engine."""
+    import kernel_checks as kc
+    problem, data, action, want, obs_params = kc.zero_lead_micro_case()
+    sim = Simulator(device=DEV)
+    sim.zero_lead_orders = "upstream"
+    sim.reset(1, problem, {k: v.to(DEV) for k, v in data.items()}, obs_params)
+    a = {k: v.to(DEV).requires_grad_() for k, v in action.items()}
+    obs, reward, _, _, _ = sim.step(a)
+    leak = want["store_inventories"].clone()
+    leak[0, 1, 2] += 4.0
+    assert torch.equal(obs["store_inventories"].detach().cpu(), leak)
+    assert torch.equal(obs["warehouse_inventories"].detach().cpu(), want["warehouse_inventories"])
+    assert torch.equal(reward.detach().cpu(), want["reward"])
+    obs["store_inventories"][0, 1, 2].backward()
+    g_a = a["stores"].grad.cpu()
+    assert float(g_a[0, 0, 0]) == 1.0 and float(g_a[0, 1, 0]) == 1.0   # the misplaced 4, and store 1's own order with lead time 3
+    g = Golden("f1_many_warehouses_2x10_gnn")
+    c = g.fresh_config()
+    data = {k: v.to(DEV) for k, v in g.data.items()}
+    for fused in (False, True):
+        model = _model(g, c)
+        sim, tr = Simulator(device=DEV), Trainer(device=DEV)
+        sim.zero_lead_orders = "upstream"
+        tr.use_fused_rollout = fused
+        with torch.no_grad():
+            obs0, _ = sim.reset(c["periods"], c["problem_params"], data, c["observation_params"])
+            o = dict(obs0)
+            o["internal_data"] = sim._internal_data
+            model(o)
+        _load(model, g)
+        model.zero_grad()
+        total, reported = tr.simulate_batch(PolicyLoss(), sim, model, c["periods"], c["problem_params"], data,
+                                            c["observation_params"], c["ignore"], False)
+        (total / (c["n"] * c["periods"] * c["problem_params"]["n_stores"])).backward()
+        assert abs(float(total) - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"])), fused
+        assert abs(float(reported) - float(g.z["reported"])) <= 1e-5 * abs(float(g.z["reported"]))
+        _check_grads(model, g, GRAD_TOL)
+
+
 @pytest.mark.parametrize("period", [True, False])
 def test_gnn_upstream_zero_lead_mode_matches_the_reference_itself(period):
     """`GnnRollout.zero_lead_orders = "upstream"`: on the sparse many-warehouse fixture - where the reference's GNN books some
