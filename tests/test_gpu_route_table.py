@@ -1,0 +1,53 @@
+"""The route each engine picks for the benchmark workloads, in ONE table: which engine `bench.build_case` / the Trainer
+instantiates and which route its `_setup` selects per batch size.  Thresholds live in the engines; this pins what they amount to."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0) if torch.cuda.is_available() else None
+
+# workload, scenarios per GPU, periods -> (engine class, route)
+TABLE = [
+    ("cfg1", 256, 6, "FusedRollout", "small"),                      # whole-horizon kernels of the 32-wide policies
+    ("cfg2", 4096, 6, "FusedRollout", "small"),
+    ("cfg4", 2048, 6, "FusedRollout", "small"),
+    ("cfg3", 1024, 4, "FusedRollout", "per-period+tail"),           # fused per-period tail up to 16,384 scenarios
+    ("cfg3", 8192, 4, "FusedRollout", "per-period+tail"),
+    ("cfg3", 32768, 2, "FusedRollout", "per-period"),               # beyond: the separate bandwidth-efficient launches
+    ("cfg5", 1024, 3, "FusedRollout", "per-period"),                # 64 stores per warehouse: outside the tail's shapes
+    ("real_data_driven", None, None, "FusedRollout", "horizon"),    # data_driven on the real-data batch: one launch per direction
+    ("base_stock", 4096, 6, "ClosedFormRollout", "closed_form_kernel<1,4,false,"),   # compiled-in pipeline length variant
+    ("echelon_stock", 2048, 6, "ClosedFormRollout", "closed_form_kernel<4,4,true>"),
+    ("gnn", 512, 3, "GnnRollout", "period-kernel"),                 # graph fits in LDS: one forward launch per period
+    ("gnn_many_warehouses", 256, 3, "GnnRollout", "per-mlp"),       # 19 nodes + 70 edges do not
+]
+
+
+@pytest.mark.parametrize("workload,n,T,engine,route", TABLE)
+def test_route_table(workload, n, T, engine, route):
+    import bench
+    from neural_inventory_control_amd import _lib
+    setting, policy, sc, data, model, eng, n2, T2, desc = bench.build_case(workload, DEV, 0, 1, n, T, False)
+    assert type(eng).__name__ == engine
+    obs = setting["observation_params"]
+    if engine == "GnnRollout":
+        eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+        eng.run(data, T2, 0, train=True, observation_params=obs, demand_soa=sc.demands_soa)
+        assert ("period-kernel" if eng._period else "per-mlp") == route
+        return
+    if engine == "ClosedFormRollout":
+        with torch.no_grad():
+            eng.model.closed_form_levels()
+        eng.run(data, T2, 0, train=True, observation_params=obs, demand_soa=sc.demands_soa)
+        assert (_lib.lib().nic_last_kernel() or b"").decode().startswith(route)
+        return
+    eng.materialize(eng.input_rows(data, obs))
+    eng.run(data, T2, 0, train=True, observation_params=obs, demand_soa=sc.demands_soa)
+    got = ("small" if eng.small is not None else "horizon" if getattr(eng, "horizon", None) is not None
+           else "per-period+tail" if eng._use_tail() else "per-period")
+    assert got == route
