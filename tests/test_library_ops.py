@@ -114,6 +114,9 @@ def test_policy_of_hip_linear_layers_survives_torch_compile(backend):
     want = [y.detach().clone()] + [p.grad.clone() for p in model.parameters()]
     model.zero_grad()
     torch._dynamo.reset()
+    if backend == "inductor":   # compile in this process: no worker pool (processes started behind an initialised GPU are refused on the pool's boxes)
+        import torch._inductor.config as icfg
+        icfg.compile_threads = 1
     compiled = torch.compile(model, backend=backend, fullgraph=True)
     y2 = compiled(x)
     y2.sum().backward()
