@@ -323,3 +323,53 @@ def test_tape_route_differential_fuzz():
     assert r.returncode == 0, r.stderr[-2000:]
     assert "suspicious: 0" in r.stdout, r.stdout[-3000:]
     assert r.stdout.count("totals ") == 12
+
+
+def test_gnn_period_kernel_at_full_size_properties():
+    """The GNN policy's one-launch-per-period forward (csrc/gnn_period.hip) at the benchmark's size (8,192 scenarios x 16 stores,
+    T = 12): batch independence (the first 4,096 scenarios reproduce a run of those scenarios alone - same blocks of 16, same
+    arithmetic: per-period rewards bit for bit), additivity of the training step (gradient of the batch = sum of its halves'
+    under the same normalisation: every 16-scenario block contributes once), and stock conservation of the stores over every
+    scenario (lost demand: pipeline' = pipeline - sales + what arrives from the warehouse's allocation)."""
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout
+    setting, policy, _, _, _ = workloads.get("gnn")
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    n, T = 8192, 12
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"], n,
+                  obs, setting["seeds"], sampler="hip", device=DEV)
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    torch.manual_seed(7)
+    model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+    S = setting["problem_params"]["n_stores"]
+    scale = 1.0 / (n * T * S)
+
+    def engine():
+        e = GnnRollout(model, setting["problem_params"], DEV)
+        e.use_period_kernel = True
+        e.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+        return e
+    eng = engine()
+    eng.run(data, T, 0, train=True, observation_params=obs, grad_scale=scale)
+    torch.cuda.synchronize()
+    assert eng._period
+    full_rewards = eng.rewards[:, :n].clone()
+    full_grads = [p.grad.detach().clone() for p in model.parameters()]
+    # stock conservation of the stores: sum of the pipeline changes by (received from the warehouse) - (sales)
+    st = eng.states[:, :eng.F_store, :n].view(T + 1, S, -1, n)
+    orders = eng.orders[:, :S, :n]                       # one warehouse: row s = what store s receives (after allocation)
+    demand = sc.demands_soa[:T, :, :n]
+    sales = torch.minimum(st[:-1, :, 0], demand)
+    lhs = st[1:].sum(dim=2)
+    rhs = st[:-1].sum(dim=2) - sales + orders
+    assert float((lhs - rhs).abs().max()) < 2e-3
+    half_grads = None
+    for lo, hi in ((0, n // 2), (n // 2, n)):
+        e2 = engine()
+        e2.run(_slice(data, lo, hi), T, 0, train=True, observation_params=obs, grad_scale=scale)
+        torch.cuda.synchronize()
+        if lo == 0:
+            assert torch.equal(e2.rewards[:, :n // 2], full_rewards[:, :n // 2])
+        g = [p.grad.detach().clone() for p in model.parameters()]
+        half_grads = g if half_grads is None else [a + b for a, b in zip(half_grads, g)]
+    for a, b in zip(full_grads, half_grads):
+        assert float((a - b).norm() / (a.norm() + 1e-30)) <= 2e-5
