@@ -373,3 +373,39 @@ def test_gnn_period_kernel_at_full_size_properties():
         half_grads = g if half_grads is None else [a + b for a, b in zip(half_grads, g)]
     for a, b in zip(full_grads, half_grads):
         assert float((a - b).norm() / (a.norm() + 1e-30)) <= 2e-5
+
+
+def test_closed_form_at_a_million_chains_properties():
+    """base_stock at 1,048,576 chains x T = 40 (the specialised single-store kernel; eight periods of demand per batch, the 40
+    periods = 5 batches): batch independence (per-chain rewards of the first 65,536 chains, run alone, bit for bit), the
+    per-wavefront sums (total, reported, level gradient) of the full batch equal the sum of the halves', and the final state obeys
+    the stock balance of a backlogged / lost-demand store chain over the horizon."""
+    from neural_inventory_control_amd.closed_form import ClosedFormRollout
+    setting, policy, _, _, _ = workloads.get("base_stock_1m")
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    n, T = 1 << 20, 40
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"], n,
+                  obs, setting["seeds"], sampler="hip", device=DEV)
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    torch.manual_seed(7)
+    model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+
+    def run(d, keep_rewards=False):
+        eng = ClosedFormRollout(model, setting["problem_params"], DEV)
+        eng.keep_rewards = keep_rewards
+        model.zero_grad()
+        total, reported = eng.run(d, T, 7, train=True, observation_params=obs)
+        total.backward()
+        torch.cuda.synchronize()
+        return eng, float(total), float(reported), [p.grad.detach().clone() for p in model.parameters()]
+    with torch.no_grad():
+        ClosedFormRollout(model, setting["problem_params"], DEV).model.closed_form_levels()   # materialise the lazy layer
+    eng, total, reported, grads = run(data, keep_rewards=True)
+    assert (_lib.lib().nic_last_kernel() or b"").decode().startswith("closed_form_kernel<1,4,false,")
+    small, _, _, _ = run(_slice(data, 0, 65536), keep_rewards=True)
+    assert torch.equal(small.rewards[:, :, :65536], eng.rewards[:, :, :65536])
+    parts = [run(_slice(data, lo, hi)) for lo, hi in ((0, n // 2), (n // 2, n))]
+    assert abs(total - (parts[0][1] + parts[1][1])) <= 2e-6 * abs(total)
+    assert abs(reported - (parts[0][2] + parts[1][2])) <= 2e-6 * abs(reported)
+    for g, a, b in zip(grads, parts[0][3], parts[1][3]):
+        assert float((g - (a + b)).norm() / (g.norm() + 1e-30)) <= 2e-5
