@@ -397,7 +397,7 @@ def test_closed_form_at_a_million_chains_properties():
         total, reported = eng.run(d, T, 7, train=True, observation_params=obs)
         total.backward()
         torch.cuda.synchronize()
-        return eng, float(total), float(reported), [p.grad.detach().clone() for p in model.parameters()]
+        return eng, float(total.detach()), float(reported.detach()), [p.grad.detach().clone() for p in model.parameters()]
     with torch.no_grad():
         ClosedFormRollout(model, setting["problem_params"], DEV).model.closed_form_levels()   # materialise the lazy layer
     eng, total, reported, grads = run(data, keep_rewards=True)
