@@ -1838,6 +1838,58 @@ def test_gnn_period_kernel_with_long_pipelines(slots, variant):
             assert float((x - y).norm() / (y.norm() + 1e-30)) <= 1e-5
 
 
+def test_gnn_period_kernel_differential_fuzz():
+    """The period kernel against the per-MLP launches on random one-warehouse settings the fixtures do not cover: 2-16 stores (16:
+    the largest one-warehouse graph whose embeddings fit in LDS), store / warehouse pipelines of 2-9 / 2-5 slots, with and without transshipment,
+    edge costs on and off, batches of 17-300 scenarios, training and evaluation."""
+    import random
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout
+    rng = random.Random(20260501)
+    for trial in range(8):
+        S = rng.choice([2, 3, 5, 9, 12, 14, 16])
+        Ws, wlead = rng.randint(2, 9), rng.randint(2, 5)
+        setting, policy, _, _, _ = workloads.get("gnn")
+        setting["problem_params"]["n_stores"] = S
+        setting["store_params"]["lead_time"] = {"sample_across_stores": True, "vary_across_samples": False, "expand": False,
+                                                "range": [1, Ws + 1]}
+        setting["store_params"]["initial_inventory"]["inventory_periods"] = Ws
+        setting["warehouse_params"]["lead_time"] = wlead
+        if rng.random() < 0.5:
+            setting["warehouse_params"]["edge_cost"] = 0.7
+        policy["transshipment"] = rng.random() < 0.4
+        obs = defaultdict(lambda: None, setting["observation_params"])
+        n, T = rng.randint(17, 300), rng.randint(3, 6)
+        sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
+                      n, obs, dict(setting["seeds"]), sampler="hip", device=DEV)
+        data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+        train = trial % 3 != 2
+        out = {}
+        for period in (True, False):
+            torch.manual_seed(trial)
+            model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+            if not GnnRollout.supports(model, setting["problem_params"]):
+                break
+            eng = GnnRollout(model, setting["problem_params"], DEV)
+            eng.use_period_kernel = period
+            eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+            total, rep = eng.run(data, T, 1, train=train, observation_params=setting["observation_params"], demand_soa=sc.demands_soa)
+            torch.cuda.synchronize()
+            assert eng._period == period, (S, Ws, wlead)
+            out[period] = (float(total), float(rep), eng.rewards[:, :n].clone(), eng.states[-1][:, :n].clone(),
+                           [p.grad.clone() for p in model.parameters()] if train else [])
+        if len(out) < 2:
+            continue
+        a, b = out[True], out[False]
+        tag = dict(trial=trial, S=S, Ws=Ws, wlead=wlead, n=n, T=T, train=train, trans=policy["transshipment"])
+        assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 2e-6 * abs(b[1]), tag
+        torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(a[3], b[3], rtol=1e-5, atol=1e-4)
+        for x, y in zip(a[4], b[4]):   # (+ an absolute floor: a horizon shorter than the lead times leaves gradients of ~1e-11)
+            assert float((x - y).norm()) <= 1e-5 * float(y.norm()) + 1e-9, tag
+
+
 def test_initial_inventories_written_behind_torchs_back_are_seen():
     """A batch tensor rewritten WITHOUT a version bump (`.data` copy - what a raw-pointer kernel or `set_()` also looks like to
     torch) must still reach the whole-horizon kernels: by default every presented batch is copied into the engine's state
