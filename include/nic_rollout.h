@@ -672,6 +672,64 @@ int nic_gnn_period_pack_size(int32_t s1q, int32_t n_out);
 int nic_gnn_period_ok(int32_t n_nodes, int32_t n_edges, int32_t Dn);
 int nic_gnn_period_fwd(const NicGnnPeriod* p, void* stream);
 
+/* ---- ... and its BACKWARD in one launch (csrc/gnn_period_bwd.hip) -------------------------------------------------
+ * The adjoint of nic_gnn_period_fwd's five MLPs (neural_networks.py:1105-1392 under autograd), behind the env-step / allocation
+ * adjoint (nic_gnn_alloc_env_bwd, or nic_env_step_bwd + nic_gnn_alloc_groups_bwd) that leaves d_out [n_edges][ldb] (gradient of
+ * the output MLP's desired quantities) and the state gradient g_state [rows][ldb] of the period: replaces five
+ * nic_mlp3_bwd_hist launches, three nic_segment_sum_terms launches and the row adds into g_state.  Reads what the forward wrote
+ * (Y of every MLP, nodes1 / edges1, the aggregation, the node features, the hidden histories in the native layout), adds the
+ * weight gradients of the period to the slab slot of each workgroup (same slabs as nic_mlp3_bwd_hist: [slots][N][lds], bias
+ * in column K; slots >= nic_gnn_period_bwd_max_grid()) and the pipeline rows of d features to g_state.  Any graph size: tiles
+ * that cross a stage go through `scratch` (nic_gnn_period_bwd_scratch_floats).  A workgroup owns n_sub blocks of 16 scenarios.
+ * MLP order as above.  list k: node -> edges it is the source of (k = 0, live edges only; k = 2, all edges) / the target of
+ * (k = 1 live, k = 3 all), CSR offsets [n_nodes + 1] + items, in the order the sums are to be taken.
+ * Transposed packs (ops.GnnPeriodBwdPack): [L3^T][L2^T][L1^T per 32-row input segment], a 32 x 32 block = fragments
+ * (rb, q, lane, j) = M[16 rb + (lane & 15)][16 (s >> 2) + 4 (lane >> 4) + (s & 3)], s = 4 q + j, M = the transposed weights
+ * (rows past the inputs zero); the output MLP's 32 x 1 last layer is one contraction step (512 floats). */
+typedef struct NicGnnPeriodBwdMlp {
+    const float* wpk_t;    /* nic_gnn_period_bwd_pack_size(n_out, segments) floats, 16-byte aligned */
+    const float* Y;        /* forward output [n_out][entities][ldb], rows row_stride apart */
+    const float* H1;       /* hidden activations, native layout */
+    const float* H2;
+    int64_t row_stride;
+    float* slab1;          /* [slots][32][lds1]: dW1 (columns < K), bias gradient in column K */
+    int64_t lds1;
+    float* slab2;          /* [slots][32][lds2] */
+    int64_t lds2;
+    float* slab3;          /* [slots][n_out][lds3] */
+    int64_t lds3;
+} NicGnnPeriodBwdMlp;
+typedef struct NicGnnPeriodBwd {
+    int32_t n_nodes, n_edges, n_live, n_scenarios, ldb, Dn;
+    int32_t n_sub;                /* 16-scenario blocks per workgroup (1 .. 4) */
+    int32_t reserved;
+    int32_t n_items[4];           /* lengths of list_items[k] */
+    const int32_t* src;           /* [n_edges], -1: the virtual node */
+    const int32_t* tgt;
+    const float* lead;            /* [n_edges] */
+    const int32_t* node_row0;     /* [n_nodes] first row of the node's pipeline in g_state */
+    const int32_t* node_slots;
+    const float* agg_scale;       /* [2 n_nodes] */
+    const int32_t* list_off[4];
+    const int32_t* list_items[4];
+    const float* feat;            /* [Dn][n_nodes][ldb] */
+    const float* nodes0;          /* [32][n_nodes][ldb] = Y of initial_node */
+    const float* nodes1;          /* nodes0 + node update */
+    const float* edges0;          /* [32][n_edges][ldb] = Y of initial_edge */
+    const float* edges1;
+    const float* agg;             /* [32][2 n_nodes][ldb] */
+    int64_t node_row_stride;      /* elements between rows of feat / nodes0 / nodes1 (agg: twice that) */
+    int64_t edge_row_stride;      /* ... of edges0 / edges1 */
+    const float* d_out;           /* [n_edges][ldb] */
+    float* g_state;               /* [rows][ldb], pipeline rows of d features are ADDED */
+    float* scratch;
+    NicGnnPeriodBwdMlp mlp[5];
+} NicGnnPeriodBwd;
+int nic_gnn_period_bwd_pack_size(int32_t n_out, int32_t n_segments);
+int nic_gnn_period_bwd_max_grid(void);
+int64_t nic_gnn_period_bwd_scratch_floats(int32_t n_nodes, int32_t n_edges, int32_t n_live, int32_t n_scenarios, int32_t n_sub);
+int nic_gnn_period_bwd(const NicGnnPeriodBwd* p, void* stream);
+
 /* The same allocation for SEVERAL supplying nodes (many-warehouse graphs: `_apply_proportional_allocation_to_graph`,
  * neural_networks.py:1435-1492, loops over every node with outgoing edges).  groups [n_groups][4] (device) = {first member edge,
  * member count, self-loop edge or -1, supplier edge} per warehouse - its internal edges are contiguous rows of `out`;

@@ -119,6 +119,23 @@ class NicGnnPeriod(C.Structure):
                 + [(n, C.c_void_p) for n in ("orders", "sums", "ratio", "scale", "store_out", "wh_out", "reward")])
 
 
+class NicGnnPeriodBwdMlp(C.Structure):
+    _fields_ = [("wpk_t", C.c_void_p), ("Y", C.c_void_p), ("H1", C.c_void_p), ("H2", C.c_void_p), ("row_stride", C.c_int64),
+                ("slab1", C.c_void_p), ("lds1", C.c_int64), ("slab2", C.c_void_p), ("lds2", C.c_int64),
+                ("slab3", C.c_void_p), ("lds3", C.c_int64)]
+
+
+class NicGnnPeriodBwd(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("n_nodes", "n_edges", "n_live", "n_scenarios", "ldb", "Dn", "n_sub", "reserved")]
+                + [("n_items", C.c_int32 * 4)]
+                + [(n, C.c_void_p) for n in ("src", "tgt", "lead", "node_row0", "node_slots", "agg_scale")]
+                + [("list_off", C.c_void_p * 4), ("list_items", C.c_void_p * 4)]
+                + [(n, C.c_void_p) for n in ("feat", "nodes0", "nodes1", "edges0", "edges1", "agg")]
+                + [("node_row_stride", C.c_int64), ("edge_row_stride", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("d_out", "g_state", "scratch")]
+                + [("mlp", NicGnnPeriodBwdMlp * 5)])
+
+
 NIC_MLP3_MAX_K, NIC_MLP3_ACT_NONE, NIC_MLP3_ACT_ELU, NIC_MLP3_ACT_SOFTPLUS = 96, 0, 1, 2
 NIC_CF_MAX_LEVELS = 5
 NIC_CF_BASE_STOCK, NIC_CF_CAPPED, NIC_CF_ECHELON = 0, 1, 2
@@ -182,6 +199,10 @@ PROTOTYPES = {
     "nic_gnn_period_pack_size": (C.c_int, [_i32, _i32]),
     "nic_gnn_period_ok": (C.c_int, [_i32, _i32, _i32]),
     "nic_gnn_period_fwd": (C.c_int, [C.POINTER(NicGnnPeriod), _vp]),
+    "nic_gnn_period_bwd_pack_size": (C.c_int, [_i32, _i32]),
+    "nic_gnn_period_bwd_max_grid": (C.c_int, []),
+    "nic_gnn_period_bwd_scratch_floats": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]),
+    "nic_gnn_period_bwd": (C.c_int, [C.POINTER(NicGnnPeriodBwd), _vp]),
     "nic_round_orders": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "nic_mlp3_fwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp]),
     "nic_mlp3_fwd_residual": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

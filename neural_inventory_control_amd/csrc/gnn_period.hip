@@ -528,13 +528,10 @@ int nic_gnn_period_fwd(const NicGnnPeriod* p, void* stream) {
 #define NIC_GP_FWD(MW, TR)                                                                                                  \
     do {                                                                                                                    \
         constexpr int NW = (MW) == 4 ? 16 : 8;                                                                              \
-        static bool attr_set = false;                                                                                       \
-        if (!attr_set) {                                                                                                    \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_period_fwd_kernel<MW, TR, NW>),                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit) != hipSuccess)                   \
-                return nic::fail("nic_gnn_period_fwd: cannot raise the dynamic LDS limit");                                 \
-            attr_set = true;                                                                                                \
-        }                                                                                                                   \
+        /* (per launch: the attribute belongs to the CURRENT device's copy of the kernel) */                                \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_period_fwd_kernel<MW, TR, NW>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit) != hipSuccess)                       \
+            return nic::fail("nic_gnn_period_fwd: cannot raise the dynamic LDS limit");                                     \
         hipLaunchKernelGGL((gnn_period_fwd_kernel<MW, TR, NW>), grid, dim3(NW * 64), bytes, s, q);                          \
     } while (0)
 #define NIC_GP_FWD2(MW)        \

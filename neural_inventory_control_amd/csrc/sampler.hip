@@ -94,6 +94,51 @@ __global__ __launch_bounds__(kBlock) void sample_equicorrelated_kernel(float* __
     }
 }
 
+// ---- ONE store: every word of a Philox block is used -----------------------------------------------------------------------
+// With one store there is no common factor to share (a correlation has nothing to act on: d ~ N(mean, std^2) whatever rho is), and
+// the form above spends a whole block (+ a quarter of the common one) on every output: 0.10-0.12 of the HBM write roofline at
+// 10^6 scenarios x T = 100 (round 5) against 0.5 for 16 stores.  Here the four normals of block (scenario, t / 4, kOwn) are the
+// demands of FOUR CONSECUTIVE PERIODS of the scenario, and a lane owns four consecutive scenarios: four blocks -> sixteen outputs,
+// written as four 16-byte stores (one per period; a wavefront writes 1 KB contiguous per period).  The mapping (seed, global
+// scenario, period) -> number is again independent of launch geometry and sharding.
+constexpr uint32_t kOwn = 0xFFFFFFFEu;
+__global__ __launch_bounds__(kBlock) void sample_one_store_kernel(float* __restrict__ out, int T, int B, int64_t ldb,
+                                                                  int64_t scenario_offset, uint32_t k0, uint32_t k1,
+                                                                  const float* __restrict__ mean_p, const float* __restrict__ std_p,
+                                                                  int clip) {
+    const float mean = mean_p[0], std_ = std_p[0];
+    const int64_t b = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    const int tg = blockIdx.y;
+    if (b >= B) return;
+    float z[4][4];   // [scenario][period]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t gb = (uint64_t)(b + i + scenario_offset);
+        normal4(philox4x32_10(U4{(uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)tg, kOwn}, k0, k1), z[i]);
+    }
+    const bool full = b + 3 < B;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = 4 * tg + u;
+        if (t < T) {
+            float d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i] = mean + std_ * z[i][u];
+                if (clip && d[i] < 0.f) d[i] = 0.f;
+            }
+            float* dst = out + (int64_t)t * ldb + b;
+            if (full) {
+                *reinterpret_cast<float4*>(dst) = make_float4(d[0], d[1], d[2], d[3]);
+            } else {   // the batch's last, partial group of four: the padding columns stay as they are
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (b + i < B) dst[i] = d[i];
+            }
+        }
+    }
+}
+
 // ---- general covariance: d = mean + L z, z in registers, L in LDS ---------------------------------------------------------
 template <int SMAX>
 __global__ __launch_bounds__(kBlock) void sample_cholesky_kernel(float* __restrict__ out, int T, int S, int B, int64_t ldb,
@@ -223,6 +268,13 @@ int nic_sample_demand_equicorrelated(float* out, int32_t T, int32_t S, int32_t n
     if (int e = check_common("nic_sample_demand_equicorrelated", out, mean, T, S, n_scenarios, ldb)) return e;
     NIC_REQUIRE(std_, "nic_sample_demand_equicorrelated: null std");
     NIC_REQUIRE(rho >= 0.f && rho <= 1.f, "nic_sample_demand_equicorrelated: correlation %g outside [0, 1]", (double)rho);
+    if (S == 1 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {   // (one store: rho has nothing to act on)
+        const dim3 grid1(nic::ceil_div(nic::ceil_div(n_scenarios, 4), kBlock), (T + 3) / 4), block1(kBlock);
+        nic::note_kernel("sample_one_store_kernel");
+        hipLaunchKernelGGL(sample_one_store_kernel, grid1, block1, 0, nic::as_stream(stream), out, T, n_scenarios, (int64_t)ldb,
+                           scenario_offset, (uint32_t)seed, (uint32_t)(seed >> 32), mean, std_, clip);
+        return nic::check_launch("nic_sample_demand_equicorrelated");
+    }
     const bool per4 = S <= 32 && (int64_t)n_scenarios * T >= (4ll << 20);
     const dim3 grid(nic::ceil_div(n_scenarios, kBlock), per4 ? (T + 3) / 4 : T), block(kBlock);
     nic::note_kernelf("sample_equicorrelated_kernel<%d>", per4 ? 4 : 1);

@@ -118,6 +118,7 @@ class Scenario:
         self.adjust_seeds_for_consistency(problem_params, store_params, seeds)
         kind = demand_params["distribution"]
         if self.sampler == "hip" and kind in ("normal", "poisson"):
+            self._device_sampler_args = (problem_params, demand_params, seeds["demand"])   # (bench.py times the same launch again)
             return self._generate_on_device(problem_params, demand_params, seeds["demand"])
         gen = {"normal": self.generate_normal_demand, "poisson": self.generate_poisson_demand,
                "real": self.read_real_demand_data}[kind]
@@ -174,28 +175,37 @@ class Scenario:
             np.random.seed(seed)
         return np.random.poisson(demand_params["mean"], size=(self.num_samples, problem_params["n_stores"], self.periods))
 
-    def _generate_on_device(self, problem_params, demand_params, seed):
-        """HIP Philox sampler (csrc/sampler.hip); returns the reference-shaped (N, S, T) view of the SoA trace."""
+    def _generate_on_device(self, problem_params, demand_params, seed, out=None, events=None):
+        """HIP Philox sampler (csrc/sampler.hip); returns the reference-shaped (N, S, T) view of the SoA trace.  With `out` (a
+        [T][S][ldb] buffer, bench.py's timing of the sampler launch) the trace is drawn into it and nothing else changes; `events`
+        = (start, end) torch events recorded right around the launch (its operands already on the device)."""
         dev = torch.device(self.device or "cuda")
         S, N, T = problem_params["n_stores"], self.num_samples, self.periods
-        mean = torch.as_tensor(np.broadcast_to(np.asarray(demand_params["mean"], dtype=np.float32), (S,)).copy())
-        out = torch.zeros(T, S, pad_ld(N), device=dev)
+        mean = torch.as_tensor(np.broadcast_to(np.asarray(demand_params["mean"], dtype=np.float32), (S,)).copy()).to(dev)
+        keep = out is None
+        if keep:
+            out = torch.zeros(T, S, pad_ld(N), device=dev)
         clip = bool(demand_params["clip"])
+        mark = (lambda i: events[i].record()) if events is not None else (lambda i: None)
         if demand_params["distribution"] == "poisson":
-            ops.sample_demand(out, T, S, N, self.scenario_offset, int(seed), 1, mean.to(dev), None, clip)
+            mark(0)
+            ops.sample_demand(out, T, S, N, self.scenario_offset, int(seed), 1, mean, None, clip)
         else:
-            std = torch.as_tensor(np.broadcast_to(np.asarray(demand_params["std"], dtype=np.float32), (S,)).copy())
+            std = torch.as_tensor(np.broadcast_to(np.asarray(demand_params["std"], dtype=np.float32), (S,)).copy()).to(dev)
             rho = float(demand_params.get("correlation", 0.0) or 0.0) if S > 1 else 0.0
             if 0.0 <= rho <= 1.0:
                 # the reference's covariance (rho s_i s_j off the diagonal, data_handling.py:194-201) through its
                 # one-factor form: S + 1 normals per (scenario, period), no factor matrix
-                ops.sample_demand_equicorrelated(out, T, S, N, self.scenario_offset, int(seed), mean.to(dev), std.to(dev),
-                                                 rho, clip)
+                mark(0)
+                ops.sample_demand_equicorrelated(out, T, S, N, self.scenario_offset, int(seed), mean, std, rho, clip)
             else:  # a negative correlation has no one-factor form: general Cholesky path
                 cov = np.asarray(self._covariance(demand_params), dtype=np.float64)
                 chol = torch.as_tensor(np.linalg.cholesky(cov).astype(np.float32)).contiguous().to(dev)
-                ops.sample_demand(out, T, S, N, self.scenario_offset, int(seed), 0, mean.to(dev), chol, clip)
-        self.demands_soa = out
+                mark(0)
+                ops.sample_demand(out, T, S, N, self.scenario_offset, int(seed), 0, mean, chol, clip)
+        mark(1)
+        if keep:
+            self.demands_soa = out
         return out[:, :, :N].permute(2, 1, 0)
 
     def sample_normal_mean_and_std(self, problem_params, demand_params, seeds):

@@ -91,6 +91,10 @@ class Simulator:
                 "Simulator(device='cpu'): this engine only runs on the GPU (no CPU fallback); pass device='cuda:0'")
         self.problem_params = problem_params
         self.observation_params = observation_params
+        if self.zero_lead_orders == "upstream":
+            from . import parallel
+            if parallel.active() and parallel.world_size() > 1:   # (the rule adds an order to the NEIGHBOURING scenario's state)
+                raise ValueError("zero_lead_orders='upstream' couples neighbouring scenarios across shard boundaries: single process only")
         data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
         self.batch_size, self.n_stores, self.periods = len(data["initial_inventories"]), problem_params["n_stores"], periods
         B = self.batch_size

@@ -107,6 +107,10 @@ class GraphPlan:
                                    for n in range(self.n_nodes)], device)
         self.n_as_tgt_live = _csr([[eng[r] for r in range(E) if r_tgt[r] == n and r not in r_demand]
                                    for n in range(self.n_nodes)], device)
+        # (lengths of the four lists above in the order nic_gnn_period_bwd takes them: source / target over live edges, over all)
+        self.list_len = [sum(1 for r in range(E) if r_src[r] >= 0 and r not in r_demand),
+                         sum(1 for r in range(E) if r_tgt[r] >= 0 and r not in r_demand),
+                         sum(1 for r in range(E) if r_src[r] >= 0), sum(1 for r in range(E) if r_tgt[r] >= 0)]
         # per-edge constant input row: lead time of internal / supplier edges, 0 for self loops and demand edges; refreshed on
         # the device from every batch's lead-time tensors through these two index lists (GnnRollout.run)
         self.lead = torch.zeros(1, E, dtype=torch.float32, device=device)
@@ -253,6 +257,11 @@ class GnnRollout:
         # on one-warehouse graphs) instead of ~8: "auto" = wherever the graph's embeddings fit in LDS and the backward reads the
         # native histories (or nothing); True raises where that does not hold; False = the per-MLP launches
         self.use_period_kernel = "auto"
+        # Backward of a period's five MLPs + every adjoint gather / aggregation + the row adds into the state gradient as ONE launch
+        # (csrc/gnn_period_bwd.hip, round 6) instead of five `nic_mlp3_bwd_hist` + three `nic_segment_sum_terms` launches + two
+        # tensor ops: "auto" = wherever the backward reads native histories ("hist" without the stored input copy) and the node
+        # features have at most 32 rows; True raises where that does not hold; False = the per-MLP launches.  Any graph size.
+        self.use_period_bwd = "auto"
         # What happens to a non-zero store order booked on a column whose lead time is 0 (only the GNN on a sparse many-warehouse
         # graph produces such orders: upstream writes store s's j-th CONNECTED edge into action column j, neural_networks.py:1423-1428).
         #   "drop"      (default) the HIP env step discards it (it still leaves the warehouse): scenarios stay independent, which
@@ -290,7 +299,7 @@ class GnnRollout:
 
     def _setup(self, prob, data, T, train):
         key = (prob.B, T, bool(train), prob.S, prob.Wn, prob.Ws, prob.Ww, self.fused_bwd, self.keep_inputs,
-               data.get("warehouse_edge_costs") is not None, self.use_period_kernel)
+               data.get("warehouse_edge_costs") is not None, self.use_period_kernel, self.use_period_bwd)
         if key == self._key:
             return
         dev, ld, S = self.device, prob.ldb, prob.S
@@ -360,6 +369,23 @@ class GnnRollout:
             elif self.use_period_kernel is True:
                 raise ValueError("use_period_kernel: " + ("the backward mode keeps row-layout histories" if fits else
                                                           f"{N} nodes + {E} edges do not fit in a workgroup's LDS"))
+        self._period_bwd, self._bdesc = False, {}
+        if train and self.use_period_bwd:
+            ok = self._mode_now == "hist" and self.mlp["output"].native and self.Dn <= 32
+            if ok:
+                assert ops.gnn_period_bwd_max_grid() <= ops.mlp3_bwd_hist_slots()
+                self.bpack = {name: ops.GnnPeriodBwdPack(self._linears(name), 1 if name == "output" else 32, sg, dev)
+                              for name, sg in zip(MODULES, (1, 2, 3, 3, 1))}
+                n_blocks = (prob.B + 15) // 16
+                self._n_sub = 2 if n_blocks >= 2 * 256 else 1
+                self.bscratch = torch.empty(ops.gnn_period_bwd_scratch_floats(N, E, P.n_live, prob.B, self._n_sub), device=dev)
+                i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)  # noqa: E731
+                self.node_row0 = i32([self.F_store + w * prob.Ww for w in range(Wn)] + [s_ * prob.Ws for s_ in range(S)])
+                self.node_slots = i32([prob.Ww] * Wn + [prob.Ws] * S)
+                self._period_bwd = True
+            elif self.use_period_bwd is True:
+                raise ValueError("use_period_bwd: the backward mode keeps row-layout histories / stored inputs, or more than 32 "
+                                 "node feature rows")
         zb = (lambda *s_: torch.empty(*s_, device=dev)) if dense else z   # (written in full by the period kernel before any read)
         self.agg = zb(T, 32, 2 * N, ld)   # message aggregation: [:, :N] over incoming edges, [:, N:] over outgoing edges
         self.nodes1, self.edges1 = zb(T, 32, N, ld), zb(T, 32, E, ld)
@@ -408,12 +434,28 @@ class GnnRollout:
         if self._period:
             for pk in self.ppack.values():
                 pk.pack()
+        if train and self._period_bwd:
+            for pk in self.bpack.values():
+                pk.pack()
         # per-edge lead-time input rows: sample 0 of THIS batch stands for the batch, as upstream re-reads it every forward
         # (:984) - refreshed on the device (no sync, capturable), so a later batch of the same shape never sees stale values
-        if self.zero_lead_orders == "upstream":
-            if P.Wn == 1:
-                raise ValueError("zero_lead_orders='upstream' only matters on many-warehouse graphs (one warehouse: every store has its edge)")
-            self._lead_times_sample0, self._zl_pairs = data["lead_times"][0].detach().cpu(), None   # (one host read per run)
+        self._zl_pairs = ()
+        if self.zero_lead_orders == "upstream" and P.Wn > 1:   # (one warehouse: every store has its edge - the rule changes nothing)
+            from . import parallel
+            if parallel.active() and parallel.world_size() > 1:
+                raise ValueError("zero_lead_orders='upstream' couples neighbouring scenarios across shard boundaries: single process only")
+            pairs = getattr(prob, "_zero_lead_pairs", None)
+            if pairs is None:   # once per presented batch (ProblemCache pins the tensors an entry was keyed on): no sync on later runs
+                lt = data["lead_times"].detach()
+                if not bool((lt == lt[:1]).all()):
+                    raise ValueError("zero_lead_orders='upstream' on the fused GNN route needs lead times that are the same for "
+                                     "every scenario of the batch (the Simulator route takes per-scenario lead times)")
+                lt0 = lt[0].cpu()
+                pairs = prob._zero_lead_pairs = tuple((s_, j_) for s_ in range(lt0.shape[0]) for j_ in range(lt0.shape[1])
+                                                      if float(lt0[s_, j_]) == 0.0)
+            self._zl_pairs = pairs
+        if (self.zero_lead_orders, self._zl_pairs) != getattr(self, "_graph_rule", None):   # captured launches embody the rule
+            self._graph_rule, self._graphs, self._eager_runs = (self.zero_lead_orders, self._zl_pairs), {}, 0
         P.lead[0, :P.n_int].copy_(data["lead_times"][0][P.lead_store, P.lead_wh])
         P.lead[0, P.n_int:P.n_int + P.Wn].copy_(data["warehouse_lead_times"][0, :P.Wn])
         s0 = self._views(self.states[0], prob)
@@ -615,23 +657,14 @@ class GnnRollout:
         ts, tw = self._order_tables(orders, prob)
         self._k("env_fwd", ops.env_step_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
                 out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
-        if self.zero_lead_orders == "upstream":
+        if self._zl_pairs:
             nxt = self._views(self.states[t + 1], prob).store            # [S][Ws][ld]
-            for s_, j_ in self._zero_lead_pairs(prob):
+            for s_, j_ in self._zl_pairs:
                 v = orders[s_ * P.Wn + j_, :B]
                 if s_ >= 1:
                     nxt[s_ - 1, prob.Ws - 1, :B] += v
                 else:   # in front of scenario b's first store lies scenario b - 1's last one (b = 0: the batch's last scenario)
                     nxt[S - 1, prob.Ws - 1, :B] += torch.roll(v, -1)
-
-    def _zero_lead_pairs(self, prob):
-        """(store, action column) pairs whose lead time is 0 (sample 0 stands for the batch, as upstream reads it)."""
-        pairs = getattr(self, "_zl_pairs", None)
-        if pairs is None or self._zl_key != id(prob):
-            lt = self._lead_times_sample0   # [S][Wn] on the host
-            pairs = self._zl_pairs = [(s_, j_) for s_ in range(lt.shape[0]) for j_ in range(lt.shape[1]) if float(lt[s_, j_]) == 0.0]
-            self._zl_key = id(prob)
-        return pairs
 
     def _backward_period(self, t, prob, demand_soa, shift, g_next, g_cur):
         P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
@@ -647,11 +680,11 @@ class GnnRollout:
         else:
             self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
                     self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=gc, g_orders=(g_so, g_wo, None))
-        if self.zero_lead_orders == "upstream" and not fused:
+        if self._zl_pairs and not fused:
             # adjoint of the fix-up: the order's gradient is the state gradient of the element it was added to - where it was
             # added at all (upstream filters zero orders out before the put: no gradient through them)
             gn = self._views(g_next, prob).store
-            for s_, j_ in self._zero_lead_pairs(prob):
+            for s_, j_ in self._zl_pairs:
                 row = s_ * P.Wn + j_
                 g_t = gn[s_ - 1, prob.Ws - 1, :B] if s_ >= 1 else torch.roll(gn[S - 1, prob.Ws - 1, :B], 1)
                 self.g_orders[row, :B] += g_t * (self.orders[t][row, :B] != 0)
@@ -664,6 +697,9 @@ class GnnRollout:
         else:
             ops.gnn_alloc_groups_bwd(M["output"].Y[t][0], st.wh, self.g_orders, self.sums[t], self.ratio[t], self.scale[t],
                                      self.d_out[0], gc.wh, P.groups, P.order_row, P.e_demand, S, not P.transshipment, B)
+        if self._period_bwd:   # the five MLPs, every adjoint gather / aggregation and the row adds into g_cur: one launch
+            self._k("gnn_period_bwd", ops.gnn_period_bwd, self._period_bwd_desc(t, prob, g_cur))
+            return
         segs = self._segments(t)
         # output MLP -> edges1
         m = M["output"]
@@ -689,6 +725,32 @@ class GnnRollout:
         self._mlp_bwd(m, t, segs, prob, self.d_nodes0)
         gc.wh += m.dX[:prob.Ww, :P.Wn].permute(1, 0, 2)
         gc.store += m.dX[:prob.Ws, P.Wn:].permute(1, 0, 2)
+
+    def _period_bwd_desc(self, t, prob, g_cur):
+        """`NicGnnPeriodBwd` of period t (cached per (period, state-gradient buffer): every buffer it names is engine-owned)."""
+        key = (t, g_cur.data_ptr())
+        d = self._bdesc.get(key)
+        if d is not None:
+            return d
+        P, ld = self.plan, prob.ldb
+        d = _lib.NicGnnPeriodBwd()
+        d.n_nodes, d.n_edges, d.n_live, d.n_scenarios, d.ldb, d.Dn, d.n_sub = P.n_nodes, P.n_edges, P.n_live, prob.B, ld, self.Dn, self._n_sub
+        p = _lib.ptr
+        d.src, d.tgt, d.lead, d.node_row0, d.node_slots, d.agg_scale = (p(P.src), p(P.tgt), p(P.lead), p(self.node_row0),
+                                                                        p(self.node_slots), p(P.agg_scale))
+        for k, (off, items) in enumerate((P.n_as_src_live, P.n_as_tgt_live, P.n_as_src, P.n_as_tgt)):
+            d.list_off[k], d.list_items[k], d.n_items[k] = p(off), p(items), P.list_len[k]
+        M = self.mlp
+        d.feat, d.nodes0, d.nodes1 = p(self.feat[t]), p(M["initial_node"].Y[t]), p(self.nodes1[t])
+        d.edges0, d.edges1, d.agg = p(M["initial_edge"].Y[t]), p(self.edges1[t]), p(self.agg[t])
+        d.node_row_stride, d.edge_row_stride = P.n_nodes * ld, P.n_edges * ld
+        d.d_out, d.g_state, d.scratch = p(self.d_out), p(g_cur), p(self.bscratch)
+        for i, name in enumerate(MODULES):
+            m, q = M[name], d.mlp[i]
+            q.wpk_t, q.Y, q.H1, q.H2, q.row_stride = p(self.bpack[name].buf), p(m.Y[t]), p(m.hist(m.H1, t)), p(m.hist(m.H2, t)), m.n_ent * ld
+            (q.slab1, q.lds1), (q.slab2, q.lds2), (q.slab3, q.lds3) = [(p(sl), sl.stride(1)) for sl in m.slabs]
+        self._bdesc[key] = d
+        return d
 
     def _mlp_bwd(self, m, t, segs, prob, dY, dX=None):
         if m.mode == "hist":

@@ -36,9 +36,10 @@ def release_problem(handle):
 
 
 def _feature_major(x):
+    # a (B, K) view of a feature-major [K][ld] buffer is taken as is - only with ld = pad_ld(B), the column stride the fake kernels
+    # promise for the outputs (a wider buffer is copied: real and fake strides must agree for inductor's stride assertions)
     xt = x.t()
-    if x.is_cuda and xt.stride(1) == 1 and xt.stride(0) % 4 == 0 and xt.stride(0) >= x.shape[0] \
-            and xt.data_ptr() % 16 == 0 and x.dtype == torch.float32:
+    if x.is_cuda and xt.stride(1) == 1 and xt.stride(0) == pad_ld(x.shape[0]) and xt.data_ptr() % 16 == 0 and x.dtype == torch.float32:
         return xt
     return to_soa(x.float())
 

@@ -526,6 +526,54 @@ def gnn_period_fwd(desc):
     check(lib().nic_gnn_period_fwd(desc, current_stream()))
 
 
+class GnnPeriodBwdPack:
+    """TRANSPOSED weights of one MLP as MFMA A fragments for `nic_gnn_period_bwd` (include/nic_rollout.h): [L3^T][L2^T][L1^T of
+    every 32-row input segment] - the input gradient of a layer is W^T dz, contracted over the layer's 32 outputs in the order an
+    embedding tile holds them.  `segments` = number of 32-row blocks of the first layer's inputs that get an input gradient (the
+    edge MLP's lead-time row gets none; node features of fewer than 32 rows are one zero-padded block)."""
+
+    def __init__(self, linears, n_out, segments, device):
+        self.linears, self.n_out, self.segments = linears, n_out, segments
+        K1 = linears[0].weight.shape[1]
+        one = [[0, -1, -1, -1]] + [[-1] * 4] * 3
+        self.idx3 = gnn_period_pack_index(_frag32(0), 32, 2, device) if n_out == 32 else gnn_period_pack_index(one, 1, 2, device)
+        self.idx = gnn_period_pack_index(_frag32(0), 32, 2, device)
+        n = lib().nic_gnn_period_bwd_pack_size(n_out, segments)
+        assert n == self.idx3.numel() + (1 + segments) * 1024
+        self.buf = torch.zeros(n, device=device)
+        self._pad3 = torch.zeros(32, (32 if n_out == 32 else 1) + 1, device=device)
+        self._pad = torch.zeros(32, 33, device=device)
+        self.seg_rows = [min(32, K1 - 32 * s) for s in range(segments)]
+
+    def pack(self):
+        w1, w2, w3 = (lin.weight.detach() for lin in self.linears)
+        self._pad3[:, :self.n_out] = w3.t()
+        o = self.idx3.numel()
+        torch.index_select(self._pad3.view(-1), 0, self.idx3, out=self.buf[:o])
+        self._pad[:, :32] = w2.t()
+        torch.index_select(self._pad.view(-1), 0, self.idx, out=self.buf[o:o + 1024])
+        o += 1024
+        for s, rows in enumerate(self.seg_rows):
+            self._pad.zero_()
+            self._pad[:rows, :32] = w1[:, 32 * s:32 * s + rows].t()
+            torch.index_select(self._pad.view(-1), 0, self.idx, out=self.buf[o:o + 1024])
+            o += 1024
+        return self.buf
+
+
+def gnn_period_bwd_max_grid():
+    return lib().nic_gnn_period_bwd_max_grid()
+
+
+def gnn_period_bwd_scratch_floats(n_nodes, n_edges, n_live, n_scenarios, n_sub):
+    return int(lib().nic_gnn_period_bwd_scratch_floats(int(n_nodes), int(n_edges), int(n_live), int(n_scenarios), int(n_sub)))
+
+
+def gnn_period_bwd(desc):
+    _lib.require_device()
+    check(lib().nic_gnn_period_bwd(desc, current_stream()))
+
+
 def segment_sum_terms(dst, terms, accumulate=False):
     """dst [R][n_dst][ldb] = (accumulate ? dst : 0) + sum over terms, in order.  A term is (src, offsets, items, scale) - a segment
     sum of src's [R][.][ldb] rows - or (src, None, None, scale): src's own row n.  One launch (nic_segment_sum_terms)."""

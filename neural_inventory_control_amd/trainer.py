@@ -356,7 +356,7 @@ class Trainer:
             eng.use_graph = self.use_rollout_graph   # (both engines: True / False / "auto" = by measurement per shape)
             if hasattr(eng, "zero_lead_orders"):   # (the Simulator's rule for orders without a lead time also holds on the fused route)
                 eng.zero_lead_orders = getattr(simulator, "zero_lead_orders", "drop")
-            for opt_ in ("fuse_tail", "use_wide", "use_period_kernel"):   # (A/B switches of the engines' routes: set on the trainer, handed on)
+            for opt_ in ("fuse_tail", "use_wide", "use_period_kernel", "use_period_bwd"):   # (A/B switches of the engines' routes: set on the trainer, handed on)
                 if hasattr(self, opt_) and hasattr(eng, opt_):
                     setattr(eng, opt_, getattr(self, opt_))
             if direct and train:
@@ -577,9 +577,20 @@ class Trainer:
         # (the implementation switches of THIS optimizer - fused / foreach / capturable - stay its own: a checkpoint written by a
         # fused Adam must not turn a default one into a fused one, nor the other way round)
         own = [{k: g.get(k) for k in _OPTIMIZER_IMPL_KEYS if k in g} for g in optimizer.param_groups]
-        optimizer.load_state_dict(_portable_optimizer_state(checkpoint["optimizer_state_dict"]))
+        portable = _portable_optimizer_state(checkpoint["optimizer_state_dict"])
+        # torch decides where each `step` counter lives from the SAVED groups' fused / capturable flags: hand it this optimizer's
+        # own, so that a fused Adam gets its counters as device tensors and a default one keeps host floats
+        for g, keep in zip(portable["param_groups"], own):
+            g.update(keep)
+        optimizer.load_state_dict(portable)
         for g, keep in zip(optimizer.param_groups, own):
             g.update(keep)
+        for g in optimizer.param_groups:
+            on_device = bool(g.get("fused")) or bool(g.get("capturable"))
+            for p in g["params"]:
+                step = optimizer.state.get(p, {}).get("step")
+                if torch.is_tensor(step) and on_device and step.device != p.device:
+                    optimizer.state[p]["step"] = step.to(device=p.device, dtype=torch.float32)
         self.all_train_losses = checkpoint["all_train_losses"]
         self.all_dev_losses = checkpoint["all_dev_losses"]
         self.all_test_losses = checkpoint["all_test_losses"]

@@ -495,6 +495,38 @@ def test_sampler_equicorrelated_is_launch_geometry_independent():
     assert torch.equal(torch.cat(parts, dim=2), full)
 
 
+def test_sampler_one_store_form_is_sharding_invariant_at_ragged_sizes():
+    """Round 6: with one store a lane owns four consecutive scenarios x four consecutive periods (all four words of a Philox block
+    used, 16-byte stores).  Shards that start at scenario indices which are not multiples of four, batch sizes that are not
+    multiples of four and a horizon that is not a multiple of four must reproduce the single run bit for bit; padding columns stay
+    zero; moments of N(mean, std^2) with clipping at zero as the oracle's generator has them."""
+    dev = "cuda"
+    T, B = 7, 2001
+    mean, std = torch.tensor([5.0], device=dev), torch.tensor([1.6], device=dev)
+    full = torch.zeros(T, 1, pad_ld(B), device=dev)
+    ops.sample_demand_equicorrelated(full, T, 1, B, 0, 77, mean, std, 0.0, True)
+    assert _lib.lib().nic_last_kernel() == b"sample_one_store_kernel"
+    assert float(full[:, :, B:].abs().sum()) == 0.0
+    parts, off = [], 0
+    for n in (1001, 3, 997):
+        o = torch.zeros(T, 1, pad_ld(n), device=dev)
+        ops.sample_demand_equicorrelated(o, T, 1, n, off, 77, mean, std, 0.0, True)
+        assert float(o[:, :, n:].abs().sum()) == 0.0
+        parts.append(o[:, :, :n])
+        off += n
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts, dim=2), full[:, :, :B])
+    big = torch.zeros(40, 1, pad_ld(65536), device=dev)
+    ops.sample_demand_equicorrelated(big, 40, 1, 65536, 0, 78, mean, std, 0.5, False)   # (rho has nothing to act on with one store)
+    x = big[:, 0, :65536].double().cpu()
+    assert abs(float(x.mean()) - 5.0) < 0.01 and abs(float(x.std()) - 1.6) < 0.01
+    z = (x - x.mean()) / x.std()
+    assert abs(float((z ** 3).mean())) < 0.02 and abs(float((z ** 4).mean()) - 3.0) < 0.05
+    # independence across periods and across neighbouring scenarios (the words of one block / of neighbouring blocks)
+    assert abs(np.corrcoef(x[0].numpy(), x[1].numpy())[0, 1]) < 0.02 and abs(np.corrcoef(x[4].numpy(), x[3].numpy())[0, 1]) < 0.02
+    assert abs(np.corrcoef(x[:, :-1].reshape(-1).numpy(), x[:, 1:].reshape(-1).numpy())[0, 1]) < 0.01
+
+
 @pytest.mark.parametrize("S", [3, 16, 40, 64])
 def test_sampler_general_covariance(S):
     """Arbitrary (here: negatively correlated blocks) covariance through the Cholesky sampler: z kept in registers."""

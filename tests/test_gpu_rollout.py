@@ -734,6 +734,29 @@ def test_trainer_train_loop_checkpoint_and_test(tmp_path):
         assert torch.equal(v, best[k])
     _, rep = tr.test(PolicyLoss(), sim, model, loaders, opt, setting["problem_params"], obs, pbd)
     assert abs(rep - tr.best_performance_data["dev_loss"]) < 1e-4 * abs(rep)
+    # resume into a FUSED Adam (what main_run builds on a GPU, main_run.py:110) and into a default one, then train on: the fused
+    # one needs its `step` counters on the device, the default one on the host; both must take the same steps
+    after = {}
+    for kind, kw in (("fused", {"fused": True}), ("default", {})):
+        model3 = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+        FusedRollout(model3, setting["problem_params"], DEV).materialize(4)
+        opt3 = torch.optim.Adam(model3.parameters(), lr=3e-3, **kw)
+        tr3 = Trainer(device=DEV)
+        tr3.load_model(model3, opt3, str(tmp_path / "a" / "b" / "ckpt.pt"))
+        for g in opt3.param_groups:
+            assert bool(g.get("fused")) == (kind == "fused")
+            for p in g["params"]:
+                step = opt3.state[p]["step"]
+                assert (step.device == p.device) == (kind == "fused"), (kind, step.device)
+                assert float(step) > 0
+        loaders3 = {"train": DeviceBatches(train_ds, 256, shuffle=True, device=DEV, seed=7)}
+        tr3.do_one_epoch(opt3, loaders3["train"], PolicyLoss(), sim, model3, T, setting["problem_params"], obs, train=True,
+                         ignore_periods=10)
+        torch.cuda.synchronize()
+        after[kind] = [p.detach().clone() for p in model3.parameters()]
+        assert all(torch.isfinite(p).all() for p in after[kind])
+    for a, b in zip(after["fused"], after["default"]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("name", ["cfg1_one_store_lost_vanilla", "cfg2_one_store_backlogged_vanilla", "cfg4_serial_vanilla"])
@@ -1186,6 +1209,8 @@ def test_gradient_parity_at_benchmark_width_and_horizon():
         print(f"tensor {i}: |HIP - fp64| = {e_hip:.2e}   |reference fp32 - fp64| = {e_ref:.2e}   |HIP - fp32| = {_rel(p.grad, ref32):.2e}")
         grad_parity_log.note_referee(i, e_hip, e_ref, _rel(p.grad, ref32), max(2.0 * e_ref, GRAD_TOL))
         assert e_hip <= max(2.0 * e_ref, GRAD_TOL), (i, e_hip, e_ref)  # (tensors already inside the 2e-5 bar need no referee)
+        # ... and north_star's own bar against the reference's float32 gradient holds here too (recorded worst: 3.9e-6)
+        assert _rel(p.grad, ref32) <= 1e-5, (i, _rel(p.grad, ref32))
 
 
 @pytest.mark.parametrize("fused", [False, True])
@@ -1623,7 +1648,7 @@ GNN_CASES = ["f1_one_warehouse_gnn", "f1_one_warehouse_16_gnn", "f1_one_warehous
              "f1_many_warehouses_2x10_gnn", "f1_many_warehouses_3x8_dense_gnn"]
 
 
-@pytest.mark.parametrize("fused_bwd", [True, False, "hist", "hist_stored_inputs"])
+@pytest.mark.parametrize("fused_bwd", [True, False, "hist", "hist_stored_inputs", "period"])
 @pytest.mark.parametrize("name", GNN_CASES)
 def test_gnn_fused_rollout_matches_reference(name, fused_bwd):
     """`GnnRollout` (five fused gather-MLP launches per period, segment-sum aggregation, manual backward sweep) against the
@@ -1636,14 +1661,17 @@ def test_gnn_fused_rollout_matches_reference(name, fused_bwd):
     eng = GnnRollout(model, c["problem_params"], DEV)
     # history-free backward with in-kernel weight gradients / stored activations + GEMMs / stored activations with in-kernel
     # weight gradients, with and without the stored copy of the gathered inputs
-    eng.fused_bwd = "hist" if fused_bwd == "hist_stored_inputs" else fused_bwd
+    # ... "period": the whole backward of a period in one launch (csrc/gnn_period_bwd.hip, round 6) - "hist" keeps the per-MLP launches
+    eng.fused_bwd = "hist" if fused_bwd in ("hist_stored_inputs", "period") else fused_bwd
     eng.keep_inputs = fused_bwd == "hist_stored_inputs"
+    eng.use_period_bwd = fused_bwd == "period"
     data = {k: v.to(DEV) for k, v in g.data.items()}
     Dn = max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4
     eng.materialize(Dn)
     _load(model, g)
     total, reported = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
     torch.cuda.synchronize()
+    assert eng._period_bwd == (fused_bwd == "period")
     rewards = eng.per_period_rewards().cpu()
     want = _Expected(g, c)
     ref_r = want.rewards
@@ -2029,6 +2057,104 @@ def test_gnn_period_kernel_matches_the_per_mlp_launches(name, mode):
         assert float((x - y).norm() / (y.norm() + 1e-30)) <= 1e-5
     want = _Expected(g, c).total
     assert abs(a[0] - want) <= 1e-5 * abs(want)
+
+
+def _gnn_run_pair(setting, policy, n, T, seed, train=True, ignore=1, **switches):
+    """One GNN training run per value of the switches' tuples (e.g. use_period_bwd=(True, False)) on the same data and weights."""
+    from collections import defaultdict
+    from neural_inventory_control_amd.gnn_rollout import GnnRollout
+    from neural_inventory_control_amd.rollout import KernelTimer
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"],
+                  n, obs, dict(setting["seeds"]), sampler="hip", device=DEV)
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    out = []
+    for i in range(len(next(iter(switches.values())))):
+        torch.manual_seed(seed)
+        model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+        if not GnnRollout.supports(model, setting["problem_params"]):
+            return None
+        eng = GnnRollout(model, setting["problem_params"], DEV)
+        for k, v in switches.items():
+            setattr(eng, k, v[i])
+        eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
+        eng.timer = KernelTimer(record_order=True)
+        total, rep = eng.run(data, T, ignore, train=train, observation_params=setting["observation_params"], demand_soa=sc.demands_soa)
+        torch.cuda.synchronize()
+        out.append(dict(total=float(total), rep=float(rep), rewards=eng.rewards[:, :n].clone(), state=eng.states[-1][:, :n].clone(),
+                        grads=[p.grad.clone() for p in model.parameters()] if train else [],
+                        names=[k for k, _ in model.named_parameters()], tags={t for t, _ in eng.timer.order}, eng=eng))
+    return out
+
+
+def _assert_same_gradients(a, b, tol=1e-5, floor=1e-9, tag=None):
+    assert a["total"] == b["total"] and a["rep"] == b["rep"], tag     # (same forward)
+    for name, x, y in zip(a["names"], a["grads"], b["grads"]):
+        assert float((x - y).norm()) <= tol * float(y.norm()) + floor, (tag, name, float((x - y).norm() / (y.norm() + 1e-30)))
+
+
+@pytest.mark.parametrize("workload,n,T", [("gnn", 1000, 6), ("gnn", 8192 + 5, 3), ("gnn", 16400, 2), ("gnn_many_warehouses", 700, 5),
+                                          ("gnn_many_warehouses", 8192, 2)])
+def test_gnn_period_backward_matches_the_per_mlp_launches(workload, n, T):
+    """Round 6: the backward of a period as ONE launch (csrc/gnn_period_bwd.hip: five MLP adjoints with in-kernel weight gradients,
+    every adjoint gather as "sum the pre-activation gradients over a node's edges, multiply once", the aggregation's adjoint, the
+    row adds into the state gradient) against round 5's five `nic_mlp3_bwd_hist` + three `nic_segment_sum_terms` launches on the
+    bench's two GNN workloads: ragged batches (a half-filled last 16-scenario block, half a native history block), batches of one
+    and two blocks per workgroup, more than one round of workgroups, and a graph (89 entities) that no LDS-resident design holds."""
+    from neural_inventory_control_amd import workloads
+    setting, policy, _, _, _ = workloads.get(workload)
+    a, b = _gnn_run_pair(setting, policy, n, T, 3, use_period_bwd=(True, False))
+    assert a["eng"]._period_bwd and not b["eng"]._period_bwd
+    assert "gnn_period_bwd" in a["tags"] and not any(t.startswith("mlp3_bwd") for t in a["tags"])
+    assert "gnn_period_bwd" not in b["tags"] and "mlp3_bwd_edge_update" in b["tags"]
+    _assert_same_gradients(a, b, tag=(workload, n, T))
+
+
+def test_gnn_period_backward_differential_fuzz():
+    """... and on random settings: 2-16 stores on one warehouse, 2-3 warehouses with random (connected) adjacency, pipelines of 2-9 /
+    2-5 slots, transshipment, edge costs, 17-300 scenarios."""
+    import random
+    from neural_inventory_control_amd import workloads
+    rng = random.Random(20261004)
+    done = 0
+    for trial in range(10):
+        many = trial % 3 == 2
+        setting, policy, _, _, _ = workloads.get("gnn_many_warehouses" if many else "gnn")
+        if many:
+            S, Wn = rng.choice([4, 7, 16]), setting["problem_params"]["n_warehouses"]
+            setting["problem_params"]["n_stores"] = S
+            adj = [[1 if (w == 0 or rng.random() < 0.6) else 0 for _ in range(S)] for w in range(Wn)]
+            adj[0] = [1] * S
+            adj[1][0] = adj[2][0] = 1                      # some store sees every warehouse (GnnRollout.supports)
+            setting["problem_params"]["warehouse_store_adjacency"] = adj
+            for k in ("lead_time",):
+                if isinstance(setting["store_params"][k].get("value"), list):
+                    setting["store_params"][k]["value"] = [[rng.randint(1, 6) for _ in range(Wn)] for _ in range(S)]
+        else:
+            S = rng.choice([2, 3, 5, 9, 12, 16])
+            Ws, wlead = rng.randint(2, 9), rng.randint(2, 5)
+            setting["problem_params"]["n_stores"] = S
+            setting["store_params"]["lead_time"] = {"sample_across_stores": True, "vary_across_samples": False, "expand": False,
+                                                    "range": [1, Ws + 1]}
+            setting["store_params"]["initial_inventory"]["inventory_periods"] = Ws
+            setting["warehouse_params"]["lead_time"] = wlead
+            if rng.random() < 0.5:
+                setting["warehouse_params"]["edge_cost"] = 0.7
+            policy["transshipment"] = rng.random() < 0.4
+        n, T = rng.randint(17, 300), rng.randint(3, 6)
+        try:
+            pair = _gnn_run_pair(setting, policy, n, T, trial, use_period_bwd=(True, False))
+        except (KeyError, ValueError, IndexError) as e:     # (a store-parameter list the mutated store count does not match)
+            if many:
+                continue
+            raise
+        if pair is None:
+            continue
+        a, b = pair
+        assert a["eng"]._period_bwd and not b["eng"]._period_bwd
+        _assert_same_gradients(a, b, tag=dict(trial=trial, many=many, S=S, n=n, T=T))
+        done += 1
+    assert done >= 6
 
 
 @pytest.mark.parametrize("setting_name", ["cfg3", "cfg2"])

@@ -119,7 +119,7 @@ def test_layout_round_trip_and_uniform_tables():
 def test_c_abi_exports_every_declared_symbol():
     """The shared library loads on a machine without a GPU and exports exactly what include/nic_rollout.h declares."""
     header = open(os.path.join(ROOT, "include", "nic_rollout.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(nic_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(nic_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared == set(_lib.PROTOTYPES.keys()), declared ^ set(_lib.PROTOTYPES.keys())
     lib = _lib.load_library()
     for name in declared:
@@ -398,3 +398,37 @@ def test_small_rollout_reduce_plan_and_argument_checks():
                  (p, 4, 8, 8, p, None, 0, 0, None, None)):            # no scratch
         assert lib.nic_small_rollout_reduce(*args, None) != 0
         assert b"nic_small_rollout_reduce" in lib.nic_last_error()
+
+
+def test_load_model_puts_step_counters_where_this_optimizers_implementation_wants_them(tmp_path):
+    """`Trainer.load_model` (trainer.py:300-312) into an optimizer whose implementation keeps `step` on the parameter's device
+    (fused / capturable Adam - what main_run builds on a GPU) and into a default one: the checkpoint holds host floats, torch
+    decides from the SAVED groups' flags where a counter goes, so the loader must hand it this optimizer's own flags.  Checked
+    here with parameters on the `meta` device (no GPU needed to see where a counter lands)."""
+    from neural_inventory_control_amd.trainer import Trainer, _portable_optimizer_state
+    torch.manual_seed(0)
+    src = torch.nn.Linear(3, 2)
+    opt = torch.optim.Adam(src.parameters(), lr=1e-2)
+    src(torch.ones(4, 3)).sum().backward()
+    opt.step()
+    opt.step()
+    path = tmp_path / "ck.pt"
+    torch.save({"model_state_dict": src.state_dict(), "optimizer_state_dict": _portable_optimizer_state(opt.state_dict()),
+                "all_train_losses": [1.0], "all_dev_losses": [2.0], "all_test_losses": [], "warehouse_upper_bound": None}, path)
+
+    class OnMeta(torch.nn.Linear):  # parameters live on `meta`; the weights themselves are not what this test looks at
+        def load_state_dict(self, sd, *a, **k):
+            return None
+
+    for kw, on_device in (({"capturable": True}, True), ({}, False)):
+        dst = OnMeta(3, 2, device="meta")
+        opt2 = torch.optim.Adam(dst.parameters(), lr=1e-2, **kw)
+        Trainer(device="cpu").load_model(dst, opt2, str(path))
+        for g in opt2.param_groups:
+            assert bool(g.get("capturable")) == on_device
+            for p in g["params"]:
+                step = opt2.state[p]["step"]
+                assert torch.is_tensor(step) and step.dtype == torch.float32
+                assert (step.device.type == "meta") == on_device
+                if not on_device:
+                    assert float(step) == 2.0
