@@ -666,10 +666,13 @@ typedef struct NicGnnPeriod {
     float* store_out;
     float* wh_out;
     float* reward;
+    float* edge_scratch;          /* nic_gnn_period_ok() == 2: nic_gnn_period_edge_scratch_floats() floats for the edge tiles; else NULL */
 } NicGnnPeriod;
 int nic_gnn_period_pack_size(int32_t s1q, int32_t n_out);
-/* 1 if a graph's embeddings (n_nodes + n_edges tiles of 2 KB) and the staged weights fit in a workgroup's LDS */
+/* 1 if a graph's embeddings (n_nodes + n_edges tiles of 2 KB) and the staged weights fit in a workgroup's LDS; 2 if only the node
+ * tiles do - the edge tiles then live in `edge_scratch` (global memory, L2-resident); 0 if neither */
 int nic_gnn_period_ok(int32_t n_nodes, int32_t n_edges, int32_t Dn);
+int64_t nic_gnn_period_edge_scratch_floats(int32_t n_edges, int32_t n_scenarios);
 int nic_gnn_period_fwd(const NicGnnPeriod* p, void* stream);
 
 /* ---- ... and its BACKWARD in one launch (csrc/gnn_period_bwd.hip) -------------------------------------------------

@@ -116,7 +116,7 @@ class NicGnnPeriod(C.Structure):
                 + [(n, C.c_void_p) for n in ("src", "tgt", "agg_off", "agg_items", "agg_scale", "lead", "node_row0", "node_slots",
                                              "state", "feat", "agg")]
                 + [("mlp", NicGnnPeriodMlp * 5), ("io", NicEnvStepIO)]
-                + [(n, C.c_void_p) for n in ("orders", "sums", "ratio", "scale", "store_out", "wh_out", "reward")])
+                + [(n, C.c_void_p) for n in ("orders", "sums", "ratio", "scale", "store_out", "wh_out", "reward", "edge_scratch")])
 
 
 class NicGnnPeriodBwdMlp(C.Structure):
@@ -199,6 +199,7 @@ PROTOTYPES = {
     "nic_gnn_period_pack_size": (C.c_int, [_i32, _i32]),
     "nic_gnn_period_ok": (C.c_int, [_i32, _i32, _i32]),
     "nic_gnn_period_fwd": (C.c_int, [C.POINTER(NicGnnPeriod), _vp]),
+    "nic_gnn_period_edge_scratch_floats": (C.c_int64, [_i32, _i32]),
     "nic_gnn_period_bwd_pack_size": (C.c_int, [_i32, _i32]),
     "nic_gnn_period_bwd_max_grid": (C.c_int, []),
     "nic_gnn_period_bwd_scratch_floats": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]),

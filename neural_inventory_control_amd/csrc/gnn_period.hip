@@ -204,13 +204,17 @@ struct GraphTabs {
 };
 __host__ __device__ inline int graph_words(int N, int E, int n_items) { return 3 * E + 2 * N + 2 * N + (2 * N + 1) + n_items; }
 
-template <int MAXW, bool TRAIN, int kWaves>
+// SPILL (round 6): graphs whose node + edge embeddings do not fit in LDS (the 3 x 16 dense many-warehouse graph: 19 + 70 tiles = 178 KB)
+// keep the NODE tiles in LDS and the EDGE tiles in a per-workgroup scratch area in global memory, in the same lane order (2 KB
+// contiguous per tile, L2-resident: written by the initial-edge stage, read by the aggregation and the edge update); every other
+// line of the kernel is the same - the tile pointer's address space is a compile-time property of the instantiation.
+template <int MAXW, bool TRAIN, int kWaves, bool SPILL>
 __global__ __launch_bounds__(kWaves * 64) void gnn_period_fwd_kernel(const NicGnnPeriod P) {
     extern __shared__ __align__(16) float lds[];
     const int N = P.n_nodes, E = P.n_edges;
     float* nodes = lds;
-    float* edges = nodes + N * kTile;
-    float* wb0 = edges + E * kTile;
+    float* edges = SPILL ? P.edge_scratch + (int64_t)blockIdx.x * E * kTile : nodes + N * kTile;
+    float* wb0 = nodes + (SPILL ? N : N + E) * kTile;
     float* wb1 = wb0 + P.wb0_floats;
     float* scratch = wb1 + P.wb1_floats;   // allocation + env step: [kEnvChunk + 1][4][16] + [1][16]
     int* tabs = reinterpret_cast<int*>(scratch + kEnvScratch);
@@ -454,13 +458,13 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_fwd_kernel(const NicGn
     GNN_STAMP(6);
 }
 
-int lds_floats(const NicGnnPeriod& p, int* wb0, int* wb1) {
+int lds_floats(const NicGnnPeriod& p, int* wb0, int* wb1, bool spill = false) {
     const int s1q_in = (p.Dn + 15) / 16;
     const int a = pack_floats(s1q_in, 2) + pack_floats(5, 2), b = pack_floats(6, 2) + pack_floats(2, 1);
     *wb0 = a > b ? a : b;
     *wb1 = pack_floats(6, 2);
     const int tab = (graph_words(p.n_nodes, p.n_edges, p.n_agg_items) + 3) / 4 * 4;
-    return (p.n_nodes + p.n_edges) * kTile + *wb0 + *wb1 + kEnvScratch + tab + p.n_live * NB;
+    return (p.n_nodes + (spill ? 0 : p.n_edges)) * kTile + *wb0 + *wb1 + kEnvScratch + tab + p.n_live * NB;
 }
 constexpr int kLdsLimit = 160 * 1024;
 
@@ -481,8 +485,13 @@ int check(const NicGnnPeriod* p, const char* who) {
     NIC_REQUIRE(p->mlp[4].Y != nullptr, "%s: the output MLP's desired quantities [n_edges][ldb] are always written", who);
     int wb0, wb1;
     const int need = lds_floats(*p, &wb0, &wb1) * 4;
-    NIC_REQUIRE(need <= kLdsLimit, "%s: the graph's embeddings do not fit in LDS (%d bytes of %d); use the per-MLP launches", who, need,
-                kLdsLimit);
+    if (need > kLdsLimit) {
+        const int need2 = lds_floats(*p, &wb0, &wb1, true) * 4;
+        NIC_REQUIRE(need2 <= kLdsLimit, "%s: the graph's node embeddings and tables do not fit in LDS (%d bytes of %d); use the per-MLP launches",
+                    who, need2, kLdsLimit);
+        NIC_REQUIRE(p->edge_scratch != nullptr, "%s: the graph's embeddings do not fit in LDS (%d bytes of %d) and no edge_scratch was given",
+                    who, need, kLdsLimit);
+    }
     if (p->fuse_env) {
         const NicEnvDims& d = p->io.dims;
         NIC_REQUIRE(d.n_warehouses == 1 && d.n_echelons == 0, "%s: fused allocation + env step: one supplying warehouse, no extra echelons", who);
@@ -508,13 +517,20 @@ int nic_gnn_period_ok(int32_t n_nodes, int32_t n_edges, int32_t Dn) {
     p.n_agg_items = 2 * n_edges;
     p.Dn = Dn;
     int a, b;
-    return n_nodes > 0 && n_edges > 0 && Dn > 0 && Dn <= 64 && lds_floats(p, &a, &b) * 4 <= kLdsLimit;
+    if (!(n_nodes > 0 && n_edges > 0 && Dn > 0 && Dn <= 64)) return 0;
+    if (lds_floats(p, &a, &b) * 4 <= kLdsLimit) return 1;
+    return lds_floats(p, &a, &b, true) * 4 <= kLdsLimit ? 2 : 0;   // 2: with the edge tiles in NicGnnPeriod.edge_scratch
+}
+
+int64_t nic_gnn_period_edge_scratch_floats(int32_t n_edges, int32_t n_scenarios) {
+    return (int64_t)nic::ceil_div(n_scenarios, NB) * n_edges * kTile;
 }
 
 int nic_gnn_period_fwd(const NicGnnPeriod* p, void* stream) {
     if (int e = check(p, "nic_gnn_period_fwd")) return e;
     NicGnnPeriod q = *p;
-    const int bytes = lds_floats(q, &q.wb0_floats, &q.wb1_floats) * 4;
+    const bool spill = lds_floats(q, &q.wb0_floats, &q.wb1_floats) * 4 > kLdsLimit;
+    const int bytes = lds_floats(q, &q.wb0_floats, &q.wb1_floats, spill) * 4;
     q.tab_words = (graph_words(q.n_nodes, q.n_edges, q.n_agg_items) + 3) / 4 * 4;
     const bool train = q.mlp[0].Y != nullptr;
     const dim3 grid(nic::ceil_div(q.n_scenarios, NB));
@@ -524,20 +540,22 @@ int nic_gnn_period_fwd(const NicGnnPeriod* p, void* stream) {
         const int sl = q.io.dims.store_slots > q.io.dims.warehouse_slots ? q.io.dims.store_slots : q.io.dims.warehouse_slots;
         m = sl <= 4 ? 4 : (sl <= 8 ? 8 : NIC_MAX_SLOTS);
     }
-    nic::note_kernelf("gnn_period_fwd_kernel<%d,%s,%d>", m, train ? "true" : "false", m == 4 ? 16 : 8);
-#define NIC_GP_FWD(MW, TR)                                                                                                  \
+    nic::note_kernelf("gnn_period_fwd_kernel<%d,%s,%d%s>", m, train ? "true" : "false", m == 4 ? 16 : 8, spill ? ",spill" : "");
+#define NIC_GP_FWD(MW, TR, SP)                                                                                              \
     do {                                                                                                                    \
         constexpr int NW = (MW) == 4 ? 16 : 8;                                                                              \
         /* (per launch: the attribute belongs to the CURRENT device's copy of the kernel) */                                \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_period_fwd_kernel<MW, TR, NW>),                           \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_period_fwd_kernel<MW, TR, NW, SP>),                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit) != hipSuccess)                       \
             return nic::fail("nic_gnn_period_fwd: cannot raise the dynamic LDS limit");                                     \
-        hipLaunchKernelGGL((gnn_period_fwd_kernel<MW, TR, NW>), grid, dim3(NW * 64), bytes, s, q);                          \
+        hipLaunchKernelGGL((gnn_period_fwd_kernel<MW, TR, NW, SP>), grid, dim3(NW * 64), bytes, s, q);                      \
     } while (0)
-#define NIC_GP_FWD2(MW)        \
-    do {                       \
-        if (train) NIC_GP_FWD(MW, true); \
-        else NIC_GP_FWD(MW, false);      \
+#define NIC_GP_FWD2(MW)                          \
+    do {                                         \
+        if (train && spill) NIC_GP_FWD(MW, true, true);        \
+        else if (train) NIC_GP_FWD(MW, true, false);           \
+        else if (spill) NIC_GP_FWD(MW, false, true);           \
+        else NIC_GP_FWD(MW, false, false);                     \
     } while (0)
     if (m == 4) NIC_GP_FWD2(4);
     else if (m == 8) NIC_GP_FWD2(8);

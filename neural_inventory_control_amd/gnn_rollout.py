@@ -354,7 +354,7 @@ class GnnRollout:
                                dense=dense)
                     for name, k, ne in zip(MODULES, ks, ents)}
         self._graphs, self._eager_runs, self._auto_graph = {}, 0, None   # (a new shape is measured afresh)
-        self._period, self._pdesc = False, {}
+        self._period, self._pdesc, self.edge_scratch = False, {}, None
         if self.use_period_kernel:
             fits = ops.gnn_period_ok(N, E, self.Dn)
             hist_ok = (not train) or self._mode_now == "fused" or (self._mode_now == "hist" and self.mlp["output"].native)
@@ -366,6 +366,7 @@ class GnnRollout:
                 self.node_row0 = i32([self.F_store + w * prob.Ww for w in range(Wn)] + [s_ * prob.Ws for s_ in range(S)])
                 self.node_slots = i32([prob.Ww] * Wn + [prob.Ws] * S)
                 self._period = True
+                self.edge_scratch = torch.empty(ops.gnn_period_edge_scratch_floats(E, prob.B), device=dev) if fits == 2 else None
             elif self.use_period_kernel is True:
                 raise ValueError("use_period_kernel: " + ("the backward mode keeps row-layout histories" if fits else
                                                           f"{N} nodes + {E} edges do not fit in a workgroup's LDS"))
@@ -613,6 +614,7 @@ class GnnRollout:
             d.e_self, d.e_supplier, d.cap_at_one = (-1 if P.e_self is None else P.e_self), P.e_supplier, int(not P.transshipment)
             d.orders, d.sums, d.ratio, d.scale = p(orders), p(self.sums[t]), p(self.ratio[t]), p(self.scale[t])
             d.store_out, d.wh_out, d.reward = p(nxt.store), p(nxt.wh), p(self.rewards[t])
+        d.edge_scratch = p(self.edge_scratch) if self.edge_scratch is not None else None
         d._key = key
         self._pdesc[t] = d
         return d

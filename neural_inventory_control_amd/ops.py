@@ -457,8 +457,13 @@ GNN_PERIOD_MLPS = ("initial_node", "initial_edge", "node_update", "edge_update",
 
 
 def gnn_period_ok(n_nodes, n_edges, Dn):
-    """True if a graph's embeddings and the staged weights fit in a workgroup's LDS (nic_gnn_period_ok)."""
-    return bool(lib().nic_gnn_period_ok(int(n_nodes), int(n_edges), int(Dn)))
+    """1 if a graph's embeddings and the staged weights fit in a workgroup's LDS, 2 if the node embeddings do and the edge tiles go
+    to a scratch area in global memory (`gnn_period_edge_scratch_floats`), 0 if the period kernel cannot take the graph."""
+    return int(lib().nic_gnn_period_ok(int(n_nodes), int(n_edges), int(Dn)))
+
+
+def gnn_period_edge_scratch_floats(n_edges, n_scenarios):
+    return int(lib().nic_gnn_period_edge_scratch_floats(int(n_edges), int(n_scenarios)))
 
 
 def _frag32(base):

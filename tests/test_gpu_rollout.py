@@ -2009,7 +2009,7 @@ def test_gnn_upstream_zero_lead_mode_matches_the_reference_itself(period):
     _load(model, g)
     total, reported = eng.run(data, c["periods"], c["ignore"], train=True, observation_params=c["observation_params"])
     torch.cuda.synchronize()
-    assert eng._zero_lead_pairs(eng.prob)   # the fixture does have such columns
+    assert eng._zl_pairs   # the fixture does have such columns
     torch.testing.assert_close(eng.per_period_rewards().cpu(), g.tensor("rewards"), rtol=1e-5, atol=1e-4)
     assert abs(float(total) - float(g.z["total"])) <= 1e-5 * abs(float(g.z["total"]))
     assert abs(float(reported) - float(g.z["reported"])) <= 1e-5 * abs(float(g.z["reported"]))
@@ -2108,6 +2108,26 @@ def test_gnn_period_backward_matches_the_per_mlp_launches(workload, n, T):
     assert "gnn_period_bwd" in a["tags"] and not any(t.startswith("mlp3_bwd") for t in a["tags"])
     assert "gnn_period_bwd" not in b["tags"] and "mlp3_bwd_edge_update" in b["tags"]
     _assert_same_gradients(a, b, tag=(workload, n, T))
+
+
+@pytest.mark.parametrize("workload,stores,n,T,train", [("gnn_many_warehouses", 16, 700, 4, True), ("gnn_many_warehouses", 16, 8192 + 5, 2, True),
+                                                       ("gnn", 30, 333, 4, True), ("gnn", 24, 1000, 5, False)])
+def test_gnn_period_kernel_with_edge_tiles_in_global_scratch(workload, stores, n, T, train):
+    """Round 6: graphs whose embeddings do not fit in LDS (3 x 16 dense: 19 nodes + 70 edges; one warehouse with 24 / 30 stores: up to
+    31 + 62) run the period kernel with the EDGE tiles in a per-workgroup scratch area in global memory (`nic_gnn_period_ok` = 2) -
+    the one-warehouse ones with the allocation + env step fused behind, as on small graphs.  Against the per-MLP launches."""
+    from neural_inventory_control_amd import workloads
+    setting, policy, _, _, _ = workloads.get(workload)
+    if stores != setting["problem_params"]["n_stores"]:
+        setting["problem_params"]["n_stores"] = stores
+    a, b = _gnn_run_pair(setting, policy, n, T, 5, train=train, use_period_kernel=(True, False), use_period_bwd=(False, False))
+    assert a["eng"]._period and a["eng"].edge_scratch is not None and not b["eng"]._period
+    assert any("spill" in k for _, k in a["eng"].timer.order), sorted({k for _, k in a["eng"].timer.order})
+    assert abs(a["total"] - b["total"]) <= 2e-6 * abs(b["total"]) and abs(a["rep"] - b["rep"]) <= 2e-6 * abs(b["rep"])
+    torch.testing.assert_close(a["rewards"], b["rewards"], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(a["state"], b["state"], rtol=1e-5, atol=1e-4)
+    for x, y in zip(a["grads"], b["grads"]):
+        assert float((x - y).norm()) <= 1e-5 * float(y.norm()) + 1e-9
 
 
 def test_gnn_period_backward_differential_fuzz():

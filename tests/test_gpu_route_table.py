@@ -23,8 +23,8 @@ TABLE = [
     ("real_data_driven", None, None, "FusedRollout", "horizon"),    # data_driven on the real-data batch: one launch per direction
     ("base_stock", 4096, 6, "ClosedFormRollout", "closed_form_kernel<1,4,false,"),   # compiled-in pipeline length variant
     ("echelon_stock", 2048, 6, "ClosedFormRollout", "closed_form_kernel<4,4,true>"),
-    ("gnn", 512, 3, "GnnRollout", "period-kernel"),                 # graph fits in LDS: one forward launch per period
-    ("gnn_many_warehouses", 256, 3, "GnnRollout", "per-mlp"),       # 19 nodes + 70 edges do not
+    ("gnn", 512, 3, "GnnRollout", "period-kernel+period-bwd"),      # graph fits in LDS: one forward launch per period; one backward launch
+    ("gnn_many_warehouses", 256, 3, "GnnRollout", "period-kernel(spill)+period-bwd"),   # 19 nodes + 70 edges: edge tiles in global scratch
 ]
 
 
@@ -38,7 +38,9 @@ def test_route_table(workload, n, T, engine, route):
     if engine == "GnnRollout":
         eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
         eng.run(data, T2, 0, train=True, observation_params=obs, demand_soa=sc.demands_soa)
-        assert ("period-kernel" if eng._period else "per-mlp") == route
+        got = ("period-kernel" + ("(spill)" if eng.edge_scratch is not None else "") if eng._period else "per-mlp") + \
+            ("+period-bwd" if eng._period_bwd else "")
+        assert got == route
         return
     if engine == "ClosedFormRollout":
         with torch.no_grad():
