@@ -720,6 +720,14 @@ def main():
     fused_adam = (args.adam == "fused" and device.type == "cuda"
                   and not any(isinstance(p_, UninitializedParameter) for p_ in model.parameters()))
     opt = torch.optim.Adam(model.parameters(), lr=3e-4, **({"fused": True} if fused_adam else {}))
+    # closed-form policies: what `Trainer` does by default (`use_step_graph = "auto"`: their training step - level network, one
+    # whole-horizon launch, autograd through the level network, Adam - is captured once and replayed; the launch is 0.1 ms inside
+    # ~0.6 ms of host work per eager step).  `--no-graph` times the eager step; the kernel itself is timed in a separate eager pass
+    # behind the timed region either way (`kernels`, `roofline`).
+    args.no_kernel_timing_flag = bool(args.no_kernel_timing)
+    closed_form_replay = closed_form and not args.no_graph and not args.eval and not args.launch_order_out
+    if closed_form_replay:
+        args.graph = True
     if args.graph and eng is not None and not closed_form:
         eng.use_graph = True
         args.no_kernel_timing = True
@@ -801,6 +809,8 @@ def main():
     timer = None
     if args.launch_order_out and eng is not None:
         timer = eng.timer = KernelTimer(record_order=True)
+    elif closed_form_replay:
+        pass   # (timed behind the region, below)
     elif not args.no_kernel_timing:
         whole = closed_form or (not gnn and (eng.small is not None or getattr(eng, "horizon", None) is not None))
         stride = args.timing_stride or (1 if whole else (10 if gnn else 40))
@@ -822,6 +832,15 @@ def main():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax)
+    timer_steps = args.steps
+    if closed_form_replay and not getattr(args, "no_kernel_timing_flag", False):
+        # the whole-horizon kernel of the replayed step, timed in eager launches of the same engine on the same batch
+        timer = eng.timer = KernelTimer(stride=1)
+        timer_steps = 3
+        for _ in range(timer_steps):
+            eng.run(data, T, 0, train=True, observation_params=setting["observation_params"], demand_soa=sc.demands_soa)
+        torch.cuda.synchronize()
+        eng.timer = None
     loss = float(last) / (global_b * T * S)
     collective = {"backend": torch.distributed.get_backend() if sharded else None, "world_size": world,
                   "ranks_seen": len(idents), "distinct_devices": len({(h, d) for _, h, d in idents}),
@@ -848,7 +867,8 @@ def main():
                        "name": args.workload, "scenarios_per_gpu": n, "global_scenarios": global_b, "stores": S,
                        "periods": T, "parallelism": f"scenario-sharded dp{world}",
                        "route": ("generic (Simulator.step + autograd)" if eng is None else
-                                 "whole-horizon closed-form kernel (forward-mode gradient)" if closed_form else
+                                 ("whole-horizon closed-form kernel (forward-mode gradient)" +
+                                  (", training step replayed from a HIP graph (the Trainer's default for these policies)" if closed_form_replay else "")) if closed_form else
                                  ((("one forward launch per period (five MLPs on LDS-resident embeddings + allocation + env step)"
                                     if getattr(eng, "_period", False) else "per-period fused gather-MLP forward kernels over the static supply graph")
                                    + (", one backward launch per period behind the env / allocation adjoint (five MLP adjoints, adjoint gathers, in-kernel weight gradients)"
@@ -872,7 +892,7 @@ def main():
                          n_out=0 if (closed_form or gnn) else eng.dims[-1], train=not args.eval,
                          hidden=[] if (closed_form or gnn) else list(eng.dims[1:-1]),
                          gnn={m.name: (m.K, m.n_out, m.n_live, getattr(m, "fold_rows", 0)) for m in eng.mlp.values()} if gnn else None)
-            kernels = kernel_report(timer, shape, args.steps)
+            kernels = kernel_report(timer, shape, timer_steps)
             rated = {k: v for k, v in kernels.items() if "bound" in v}
             if rated:
                 dom = max(rated, key=lambda k: rated[k]["total_ms_per_step"])

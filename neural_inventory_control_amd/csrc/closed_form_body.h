@@ -163,13 +163,16 @@ struct CfPipe {
     Dual<NP> s[MW];
 };
 
-// sum of the live slots, left to right (x.sum(dim=2) over one pipeline, neural_networks.py:226)
+// sum of the live slots, left to right (x.sum(dim=2) over one pipeline, neural_networks.py:226).  INVARIANT of every pipeline
+// here: slots at or past its length W hold exact zeros with zero tangents (cf_pipe_load writes them, cf_pipe_step shifts a zero
+// in at the top and places orders below W only), so adding all MW register slots is the sum of the W live ones - same additions in
+// the same order followed by "+ 0" - and no select on W is needed (round 6: the echelon chain's period was ~1,500 instructions,
+// a third of them selects on the run-time lengths).
 template <int NP, int MW>
-NIC_HD Dual<NP> cf_pipe_sum(const CfPipe<NP, MW>& p, int W) {
+NIC_HD Dual<NP> cf_pipe_sum(const CfPipe<NP, MW>& p, int /*W*/) {
     Dual<NP> r = p.s[0];
 #pragma unroll
-    for (int k = 1; k < MW; ++k)
-        if (k < W) r = r + p.s[k];
+    for (int k = 1; k < MW; ++k) r = r + p.s[k];
     return r;
 }
 
@@ -207,17 +210,22 @@ NIC_HD CfPipe<NP, MW> cf_pipe_step_c(const CfPipe<NP, MW>& old, const Dual<NP>& 
 }
 
 // new[0] = after + old[1]; new[k] = old[k+1]; new[W-1] = 0; new[L-1] += a if a != 0   (environment.py:405-432)
+// (the shift needs no W either: old[W] is an exact zero, so new[W - 1] = old[W] IS the reference's "new[W-1] = 0".  The order
+// lands through m * a + v with m = 1 in its slot and 0 elsewhere: fma(1, a, v) = round(a + v), the reference's addition, and
+// fma(0, a, v) = v for the finite orders of these policies - one multiply-add per value and tangent instead of an add + a select)
 template <int NP, int MW>
-NIC_HD CfPipe<NP, MW> cf_pipe_step(const CfPipe<NP, MW>& old, int W, const Dual<NP>& after, const Dual<NP>& a, float lead) {
+NIC_HD CfPipe<NP, MW> cf_pipe_step(const CfPipe<NP, MW>& old, int /*W*/, const Dual<NP>& after, const Dual<NP>& a, float lead) {
     CfPipe<NP, MW> nw;
-    const int slot = (int)lead - 1;
-    const bool place = a.v != 0.f;  // zero orders are filtered out before the put (:426-429)
+    const int slot = (a.v != 0.f) ? (int)lead - 1 : -1;  // zero orders are filtered out before the put (:426-429)
 #pragma unroll
     for (int k = 0; k < MW; ++k) {
         Dual<NP> v = dconst<NP>(0.f);
-        if (k + 1 < MW && k < W - 1) v = old.s[k + 1 < MW ? k + 1 : k];
+        if (k + 1 < MW) v = old.s[k + 1 < MW ? k + 1 : k];
         if (k == 0) v = after + v;
-        if (place && k == slot) v = v + a;
+        const float m = k == slot ? 1.f : 0.f;
+        v.v = fmaf(m, a.v, v.v);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) v.d[j] = fmaf(m, a.d[j], v.d[j]);
         nw.s[k] = v;
     }
     return nw;
@@ -241,6 +249,7 @@ NIC_HD Dual<NP> cf_env_step(const NicClosedFormDesc& d, const CfStatics& c, CfSt
                             const CfOrders<NP>& o, int uniform_slot = -2) {
     const bool maximize_profit = FL < 0 ? (bool)d.maximize_profit : (bool)(FL & 4);
     const bool lost_demand = FL < 0 ? (bool)d.lost_demand : (bool)(FL & 2);
+    const int nE = (CHAIN && NP > 0) ? NP - 2 : d.E;   // training kernels of the chain: one level per location, E + 2 = NP, compiled in
     const Dual<NP> on_hand = st.store.s[0];
     Dual<NP> after = dsub(on_hand, dem);
     Dual<NP> cost;
@@ -257,8 +266,8 @@ NIC_HD Dual<NP> cf_env_step(const NicClosedFormDesc& d, const CfStatics& c, CfSt
         Dual<NP> r_e = dconst<NP>(0.f);
 #pragma unroll
         for (int e = 0; e < CF_MAXE; ++e) {
-            if (e < d.E) {
-                const Dual<NP> ship = (e < d.E - 1) ? o.ech[(e + 1 < CF_MAXE) ? e + 1 : e] : o.wh;
+            if (e < nE) {
+                const Dual<NP> ship = (e < nE - 1) ? o.ech[(e + 1 < CF_MAXE) ? e + 1 : e] : o.wh;
                 const Dual<NP> e_after = st.ech[CHAIN ? e : 0].s[0] - ship;
                 r_e = r_e + dscale(c.e_h[e], drelu(e_after));
                 st.ech[CHAIN ? e : 0] = cf_pipe_step(st.ech[CHAIN ? e : 0], d.We, e_after, o.ech[e], c.e_lead[e]);
@@ -280,6 +289,7 @@ NIC_HD CfOrders<NP> cf_policy(const NicClosedFormDesc& d, const Dual<NP> (&lv)[N
     o.store = o.wh = dconst<NP>(0.f);
 #pragma unroll
     for (int e = 0; e < CF_MAXE; ++e) o.ech[e] = dconst<NP>(0.f);
+    const int nE = (CHAIN && NP > 0) ? NP - 2 : d.E;
     const Dual<NP> store_pos = WC > 0 ? cf_pipe_sum_c<NP, MW, (WC > 0 ? WC : 1)>(st.store) : cf_pipe_sum(st.store, d.Ws);
     if (!CHAIN && d.policy == NIC_CF_BASE_STOCK) {  // clip(level - position, min=0)            neural_networks.py:227-229
         o.store = drelu(lv[0] - store_pos);
@@ -290,21 +300,21 @@ NIC_HD CfOrders<NP> cf_policy(const NicClosedFormDesc& d, const Dual<NP> (&lv)[N
         // positions of locations k..E+1; allocation = min(clip(level_k - sum, 0), on-hand of the location upstream of k)
         Dual<NP> pos[CF_MAXE];
 #pragma unroll
-        for (int e = 0; e < CF_MAXE; ++e) pos[e] = e < d.E ? cf_pipe_sum(st.ech[CHAIN ? e : 0], d.We) : dconst<NP>(0.f);
+        for (int e = 0; e < CF_MAXE; ++e) pos[e] = e < nE ? cf_pipe_sum(st.ech[CHAIN ? e : 0], d.We) : dconst<NP>(0.f);
         const Dual<NP> wh_pos = cf_pipe_sum(st.wh, d.Ww);
 #pragma unroll
         for (int k = 0; k < CF_MAXE + 2; ++k) {
-            if (k < d.E + 2) {
+            if (k < nE + 2) {
                 // pos[:, k:].sum(dim=1), in location order (echelons k.., warehouse, store)
                 Dual<NP> s = dconst<NP>(0.f);
                 bool first = true;
 #pragma unroll
                 for (int e = 0; e < CF_MAXE; ++e)
-                    if (e >= k && e < d.E) {
+                    if (e >= k && e < nE) {
                         s = first ? pos[e] : s + pos[e];
                         first = false;
                     }
-                if (k <= d.E) {
+                if (k <= nE) {
                     s = first ? wh_pos : s + wh_pos;
                     first = false;
                 }
@@ -312,15 +322,15 @@ NIC_HD CfOrders<NP> cf_policy(const NicClosedFormDesc& d, const Dual<NP> (&lv)[N
                 const Dual<NP> want = drelu(lv[k < NIC_CF_MAX_LEVELS ? k : 0] - s);
                 Dual<NP> a;
                 if (k == 0) a = dmin_const(want, 1000000.f);  // the outside supplier never binds (:262)
-                else if (k <= d.E) {                           // on hand of echelon k-1
+                else if (k <= nE) {                            // on hand of echelon k-1
                     Dual<NP> up = dconst<NP>(0.f);
 #pragma unroll
                     for (int e = 0; e < CF_MAXE; ++e)
                         if (e == k - 1) up = st.ech[CHAIN ? e : 0].s[0];
                     a = dmin(want, up);
                 } else a = dmin(want, st.wh.s[0]);             // on hand of the warehouse
-                if (k < d.E) o.ech[k < CF_MAXE ? k : 0] = a;
-                else if (k == d.E) o.wh = a;
+                if (k < nE) o.ech[k < CF_MAXE ? k : 0] = a;
+                else if (k == nE) o.wh = a;
                 else o.store = a;
             }
         }

@@ -107,6 +107,9 @@ class Simulator:
 
         prob = self._problem_for(problem_params, data, dev)
         self._prob = prob
+        from . import library   # (handle of the problem for `nic::env_step`, the operator `step` emits while a compiler traces)
+        library.release_problem(getattr(self, "_problem_handle", None))
+        self._problem_handle = library.register_problem(prob)
         self._lead_times = data["lead_times"]
         # demand trace in [T][S][ldb]: the per-period read of the kernel is then one contiguous (S x ldb) panel instead
         # of the reference's stride-T gather (environment.py:177)
@@ -192,7 +195,14 @@ class Simulator:
                 raise ValueError(f"action['{name}'] must be (B, n, 1): one outside supplier per location")
         demand = Table(self._demand_soa[tt], prob.ldb, 1)
         st = self._state
-        store, wh, ech, reward = _EnvStepFunction.apply(prob, demand, st.store, st.wh, st.ech, a_store, a_wh, a_ech)
+        if torch.compiler.is_compiling():
+            # while a compiler traces (torch.compile of a rollout loop), the period is the REGISTERED operator - same kernels,
+            # fake-tensor kernel and autograd formula known to the dispatcher (library.py); eager code keeps the Function
+            store, wh, ech, reward = torch.ops.nic.env_step(st.store, st.wh, st.ech, a_store, a_wh, a_ech, self._demand_soa[tt],
+                                                            self._problem_handle)
+            wh, ech = (wh if prob.Wn else None), (ech if prob.E else None)
+        else:
+            store, wh, ech, reward = _EnvStepFunction.apply(prob, demand, st.store, st.wh, st.ech, a_store, a_wh, a_ech)
         if self.zero_lead_orders == "upstream":
             store = self._add_zero_lead_orders(store, a_store)
         self._state = EnvState(store, wh, ech)

@@ -1,8 +1,15 @@
-"""`torch.library` registration of the engine's two plugin-facing operators (SURVEY §8b names them):
+"""`torch.library` registration of the engine's plugin-facing operators (SURVEY §8b names them):
 
-    nic::linear(x, weight, bias?, act) -> y            the policy layers' Linear(+ELU) on csrc/linear_mfma.hip
+    nic::linear(x, weight, bias?, act) -> y            the policy layers' Linear(+ELU) on csrc/linear_mfma.hip (= "mlp_layer_fwd";
+                                                       nic::linear_backward = "mlp_layer_bwd")
     nic::env_step(store, wh?, ech?, a_store, a_wh?, a_ech?, demand, problem) -> (store', wh', ech', reward)
                                                        one period of Simulator.step on csrc/env_step.hip
+    nic::softmax_alloc(z, wh_inv, adjacency, ub, transshipment, S, Wn) -> (store orders, warehouse orders)
+                                                       the warehouse policies' feasibility head on csrc/policy_heads.hip
+    nic::rollout_closed_form(levels, demand, state0, problem, policy, T, t0, ignore, round) -> (total, reported, d total / d levels)
+                                                       whole horizon of a closed-form policy on csrc/closed_form.hip
+    nic::sample_demand(mean, std?, rho, T, n, offset, seed, clip, poisson) -> demand [T][S][ldb]
+                                                       the batched demand sampler on csrc/sampler.hip (not differentiable)
 
 each with a fake-tensor kernel (shapes / strides without touching the device) and an autograd formula that calls the matching
 backward operator (`nic::linear_backward`, `nic::env_step_backward`), so a plugin policy built from `HipLinear` layers survives
@@ -199,3 +206,134 @@ def _env_backward(ctx, g_store, g_wh, g_ech, g_reward):
 
 
 env_step.register_autograd(_env_backward, setup_context=_env_setup)
+
+
+# ---- nic::softmax_alloc: the warehouse policies' feasibility head --------------------------------------------------------------
+
+@torch.library.custom_op("nic::softmax_alloc", mutates_args=())
+def softmax_alloc(z: torch.Tensor, wh_inv: torch.Tensor, adjacency: torch.Tensor, upper_bound: float, transshipment: bool,
+                  n_stores: int, n_warehouses: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`apply_softmax_feasibility_function` + the warehouse's own sigmoid order (neural_networks.py:140-166, :403-426) on
+    csrc/policy_heads.hip: z (B, S * Wn + Wn) logits, wh_inv (B, Wn, Ww) warehouse pipelines, adjacency [Wn][S] int32 ->
+    (store orders (B, S, Wn), warehouse orders (B, Wn, 1)), both views of scenario-minor buffers."""
+    if not z.is_cuda:
+        raise _lib.NicUnavailableError("nic::softmax_alloc needs device tensors (no CPU fallback)")
+    B, S, Wn = z.shape[0], n_stores, n_warehouses
+    Z = _feature_major(z)
+    ld = Z.stride(0)
+    Wh = to_soa(wh_inv, ld)
+    so, wo = torch.zeros(S, Wn, ld, device=z.device), torch.zeros(Wn, ld, device=z.device)
+    ops.head_warehouse_fwd(Z, Wh, adjacency, upper_bound, transshipment, so, wo, S, Wn, wh_inv.shape[2], B)
+    return ref_view(so, B), ref_view(wo, B).unsqueeze(2)
+
+
+@softmax_alloc.register_fake
+def _(z, wh_inv, adjacency, upper_bound, transshipment, n_stores, n_warehouses):
+    B, ld = z.shape[0], pad_ld(z.shape[0])
+    return (z.new_empty_strided((B, n_stores, n_warehouses), (1, n_warehouses * ld, ld), dtype=torch.float32),
+            z.new_empty_strided((B, n_warehouses, 1), (1, ld, 1), dtype=torch.float32))
+
+
+@torch.library.custom_op("nic::softmax_alloc_backward", mutates_args=())
+def softmax_alloc_backward(g_store: torch.Tensor, g_wh: torch.Tensor, z: torch.Tensor, wh_inv: torch.Tensor, adjacency: torch.Tensor,
+                           upper_bound: float, transshipment: bool, n_stores: int,
+                           n_warehouses: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(d z (B, S * Wn + Wn), d wh_inv (B, Wn, Ww)) of nic::softmax_alloc."""
+    B, S, Wn, Ww = z.shape[0], n_stores, n_warehouses, wh_inv.shape[2]
+    Z = _feature_major(z)
+    ld = Z.stride(0)
+    Wh = to_soa(wh_inv, ld)
+    Gs, Gw = to_soa(g_store, ld), to_soa(g_wh[:, :, 0], ld)
+    dZ, g_inv = torch.zeros(S * Wn + Wn, ld, device=z.device), torch.zeros(Wn, Ww, ld, device=z.device)
+    ops.head_warehouse_bwd(Z, Wh, adjacency, upper_bound, transshipment, Gs, Gw, dZ, g_inv, S, Wn, Ww, B)
+    return ref_view(dZ, B), ref_view(g_inv, B)
+
+
+@softmax_alloc_backward.register_fake
+def _(g_store, g_wh, z, wh_inv, adjacency, upper_bound, transshipment, n_stores, n_warehouses):
+    B, ld = z.shape[0], pad_ld(z.shape[0])
+    Wn, Ww = wh_inv.shape[1], wh_inv.shape[2]
+    return (z.new_empty_strided(z.shape, (1, ld), dtype=torch.float32),
+            z.new_empty_strided((B, Wn, Ww), (1, Ww * ld, ld), dtype=torch.float32))
+
+
+def _alloc_setup(ctx, inputs, output):
+    z, wh_inv, adjacency, ub, trans, S, Wn = inputs
+    ctx.meta = (ub, trans, S, Wn)
+    ctx.save_for_backward(z, wh_inv, adjacency)
+
+
+def _alloc_backward(ctx, g_so, g_wo):
+    z, wh_inv, adjacency = ctx.saved_tensors
+    ub, trans, S, Wn = ctx.meta
+    dz, g_inv = torch.ops.nic.softmax_alloc_backward(g_so, g_wo, z, wh_inv, adjacency, ub, trans, S, Wn)
+    return dz, g_inv, None, None, None, None, None
+
+
+softmax_alloc.register_autograd(_alloc_backward, setup_context=_alloc_setup)
+
+
+# ---- nic::rollout_closed_form: whole horizon of a closed-form policy, with the forward-mode level gradient -----------------------
+
+@torch.library.custom_op("nic::rollout_closed_form", mutates_args=())
+def rollout_closed_form(levels: torch.Tensor, demand: torch.Tensor, state0: torch.Tensor, problem: int, policy: int, periods: int,
+                        first_period: int, ignore_periods: int,
+                        round_orders: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """`Trainer.simulate_batch` (trainer.py:181-216) for base_stock / capped_base_stock / echelon_stock (policy = _lib.NIC_CF_*;
+    neural_networks.py:216-311) as ONE launch of csrc/closed_form.hip: levels [n_levels] (what the policy's tiny net outputs),
+    demand [T_total][S][ldb], state0 [S][F][ldb] (closed_form.pack_state0), problem = `register_problem` handle ->
+    (total cost, cost from period `ignore_periods` on, d total / d levels)."""
+    from . import closed_form
+    prob = _PROBLEMS[problem]
+    name = {v: k for k, v in closed_form.POLICY_ID.items()}[policy]
+    lv = levels.detach().float().contiguous()
+    desc = closed_form.make_desc(prob, name, periods, first_period, ignore_periods, lv, demand, state0, round_orders)
+    ng = 0 if round_orders else lv.numel()   # (rounded orders have no gradient)
+    partial = torch.empty(_lib.lib().nic_closed_form_num_partials(prob.B, prob.S), ng + 2, device=levels.device)
+    _lib.check(_lib.lib().nic_closed_form_rollout_sums(desc, None, None, None, _lib.ptr(partial), ng + 2, int(ng > 0), 1,
+                                                       _lib.current_stream()))
+    sums = partial.sum(dim=0)
+    return sums[ng].clone(), sums[ng + 1].clone(), (sums[:ng].clone() if ng else torch.zeros_like(lv))
+
+
+@rollout_closed_form.register_fake
+def _(levels, demand, state0, problem, policy, periods, first_period, ignore_periods, round_orders):
+    return (levels.new_empty((), dtype=torch.float32), levels.new_empty((), dtype=torch.float32),
+            levels.new_empty(levels.shape, dtype=torch.float32))
+
+
+def _cf_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[2])
+
+
+def _cf_backward(ctx, g_total, g_reported, g_glevels):
+    (g_levels,) = ctx.saved_tensors
+    return (g_total * g_levels,) + (None,) * 8
+
+
+rollout_closed_form.register_autograd(_cf_backward, setup_context=_cf_setup)
+
+
+# ---- nic::sample_demand: the batched demand sampler ------------------------------------------------------------------------------
+
+@torch.library.custom_op("nic::sample_demand", mutates_args=())
+def sample_demand(mean: torch.Tensor, std: Optional[torch.Tensor], correlation: float, periods: int, n_scenarios: int,
+                  scenario_offset: int, seed: int, clip: bool, poisson: bool) -> torch.Tensor:
+    """`Scenario.generate_normal_demand` / `generate_poisson_demand` (data_handling.py:178-211) on csrc/sampler.hip: mean [S]
+    (std [S] for normal demand, pairwise correlation in [0, 1]) -> demand trace [T][S][ldb], Philox keyed by the GLOBAL scenario
+    index (scenario_offset + column) so shards reproduce the single-process trace.  Not differentiable."""
+    if not mean.is_cuda:
+        raise _lib.NicUnavailableError("nic::sample_demand needs device tensors (no CPU fallback)")
+    S = mean.numel()
+    out = torch.zeros(periods, S, pad_ld(n_scenarios), device=mean.device)
+    if poisson:
+        ops.sample_demand(out, periods, S, n_scenarios, scenario_offset, seed, 1, mean.float().contiguous(), None, clip)
+    else:
+        ops.sample_demand_equicorrelated(out, periods, S, n_scenarios, scenario_offset, seed, mean.float().contiguous(),
+                                         std.float().contiguous(), correlation if S > 1 else 0.0, clip)
+    return out
+
+
+@sample_demand.register_fake
+def _(mean, std, correlation, periods, n_scenarios, scenario_offset, seed, clip, poisson):
+    return mean.new_empty((periods, mean.numel(), pad_ld(n_scenarios)), dtype=torch.float32)

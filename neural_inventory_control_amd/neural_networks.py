@@ -396,8 +396,13 @@ class VanillaWarehouse(MyNeuralNetwork):
         S, Wn = s_inv.size(1), w_inv.size(1)
         x = torch.cat((s_inv.flatten(start_dim=1), w_inv.flatten(start_dim=1)), dim=1)
         z = self.net["master"](x)
-        so, wo = _WarehouseHead.apply(z, w_inv, self.adjacency(S, Wn, z.device), _scalar(self.warehouse_upper_bound),
-                                      bool(self.transshipment), S, Wn)
+        if torch.compiler.is_compiling():   # the registered operator (library.py) while a compiler traces; same kernel
+            from . import library  # noqa: F401  (registers the operators)
+            so, wo = torch.ops.nic.softmax_alloc(z, w_inv, self.adjacency(S, Wn, z.device), _scalar(self.warehouse_upper_bound),
+                                                 bool(self.transshipment), S, Wn)
+        else:
+            so, wo = _WarehouseHead.apply(z, w_inv, self.adjacency(S, Wn, z.device), _scalar(self.warehouse_upper_bound),
+                                          bool(self.transshipment), S, Wn)
         return {"stores": so, "warehouses": wo}
 
 

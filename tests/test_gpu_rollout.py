@@ -1733,7 +1733,11 @@ def test_gnn_graph_replay_matches_eager(name):
         if mode == "auto":
             # round 4: decided by measurement on the second training run (what `Trainer` sets on its engines) - a fixture-sized
             # batch is launch-bound on any host, so the later runs were replayed
-            assert eng.auto_graph_probe is not None and eng.auto_graph_probe["replay"] is True and len(eng._graphs) == 2
+            # round 6: three launches per period - a fixture-sized step is no longer launch-bound on every host; what is checked is
+            # the probe's rule: later runs are replayed if and only if it said so
+            pr = eng.auto_graph_probe
+            assert pr is not None and pr["replay"] == (pr["host_enqueue_ms"] > 0.85 * pr["gpu_ms"])
+            assert len(eng._graphs) == (2 if pr["replay"] else 0)
     for mode in ("graph", "auto"):
         for a, b in zip(out["eager"], out[mode]):
             assert a[0] == b[0] and a[1] == b[1]
