@@ -860,6 +860,10 @@ def main():
             "value": global_b * S * T * args.steps / dt, "unit": "scenario-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling_note": ("BASELINE's '>= 6x further at 8 GPUs' is stated on the fixed 65,536-scenario problem = --scaling strong "
+                             "(predicted from 1-GPU shard steps: profiles/r06_scaling_prediction.json); the default, and this line"
+                             + ("" if (world > 1 and args.scaling == "strong") else " unless run with --scaling strong") +
+                             ", is WEAK scaling: the workload's scenario count PER GPU"),
             "data": "synthetic", "collective": collective,
             "config": {"workload": desc + ("; evaluation pass = forward rollout only" + (", discrete allocation" if discrete else "")
                                            if args.eval else

@@ -197,27 +197,22 @@ int nic_head_warehouse_bwd(const float* Z, const float* wh_inv, const int32_t* a
  * nic_env_step_fwd with n_echelons == 0, n_stores <= 64; io->store_orders / io->wh_orders must describe dense
  * [S][Wn][ldb] / [Wn][ldb] blocks: the kernel WRITES the orders there (the backward sweep reads them) and consumes them.
  * The warehouse on-hand the head allocates is io->wh_inv[w][0][b] - the state the env step then advances. */
-int nic_head_env_fwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, float upper_bound,
-                     int32_t transshipment, float* store_inv_out, float* wh_inv_out, float* reward, void* stream);
-/* The adjoint pair in one launch: nic_env_step_bwd (no echelons) then nic_head_warehouse_bwd.  g_store_orders /
+/* The adjoint pair in one launch (nic_head_env_bwd): nic_env_step_bwd (no echelons) then nic_head_warehouse_bwd.  g_store_orders /
  * g_wh_orders ([S][Wn][ldb] / [Wn][ldb]) are scratch outputs of the first half that the second half consumes; dZ receives the
- * logits' gradient, g_wh_in the warehouse state gradient INCLUDING the head's contribution to the on-hand slot. */
-int nic_head_env_bwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, float upper_bound,
-                     int32_t transshipment, const float* g_store_out, const float* g_wh_out, NicTable2 g_reward,
-                     float* g_store_in, float* g_wh_in, float* g_store_orders, float* g_wh_orders, float* dZ, void* stream);
-
-/* The same two with COMPACT logits: on a sparse many-warehouse graph the logits of (store, warehouse) pairs without an edge are
- * never read upstream (`store_intermediate_outputs[:, connected_stores, w_idx]`, neural_networks.py:403-417), so the logits layer
- * may compute the connected pairs only.  logit_rows [Wn][S] (int32, device): row of Z / dZ of pair (w, s) - any valid row for a pair
- * without an edge (loaded, never used; no gradient row is written for it); first_wh_row: row of warehouse 0's own order logit
- * (:422), warehouse w's is first_wh_row + w.  logit_rows == NULL (with first_wh_row < 0) is nic_head_env_fwd / _bwd. */
-int nic_head_env_fwd_rows(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
-                          int32_t first_wh_row, float upper_bound, int32_t transshipment, float* store_inv_out, float* wh_inv_out,
-                          float* reward, void* stream);
-int nic_head_env_bwd_rows(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
-                          int32_t first_wh_row, float upper_bound, int32_t transshipment, const float* g_store_out,
-                          const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_store_orders,
-                          float* g_wh_orders, float* dZ, void* stream);
+ * logits' gradient, g_wh_in the warehouse state gradient INCLUDING the head's contribution to the on-hand slot.
+ * COMPACT logits: on a sparse many-warehouse graph the logits of (store, warehouse) pairs without an edge are never read upstream
+ * (`store_intermediate_outputs[:, connected_stores, w_idx]`, neural_networks.py:403-417), so the logits layer may compute the
+ * connected pairs only.  logit_rows [Wn][S] (int32, device): row of Z / dZ of pair (w, s) - any valid row for a pair without an
+ * edge (loaded, never used; no gradient row is written for it); first_wh_row: row of warehouse 0's own order logit (:422),
+ * warehouse w's is first_wh_row + w.  logit_rows == NULL with first_wh_row < 0: dense logits, rows in (store, warehouse) order.
+ * (Round 6: one pair of entry points - the former dense-only wrappers and their `_rows` twins are these.) */
+int nic_head_env_fwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
+                     int32_t first_wh_row, float upper_bound, int32_t transshipment, float* store_inv_out, float* wh_inv_out,
+                     float* reward, void* stream);
+int nic_head_env_bwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
+                     int32_t first_wh_row, float upper_bound, int32_t transshipment, const float* g_store_out,
+                     const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_store_orders,
+                     float* g_wh_orders, float* dZ, void* stream);
 
 /* ---- the whole per-period "tail" of the vanilla_warehouse rollout in one launch per direction (round 5) -------------------
  * Between two periods' hidden-layer GEMMs the rollout of trainer.py:190-213 runs, forward, the logits layer
@@ -260,57 +255,6 @@ int nic_period_tail_bwd_slots(int32_t n_scenarios);
 int nic_period_tail_bwd(const NicPeriodTail* t, const float* Z, const float* H_last, const float* dZ_first_next,
                         const float* g_state_next, NicTable2 g_reward, float* g_state_out, float* dH_last, float* slab,
                         int64_t lds, int32_t n_slots, int32_t first, void* stream);
-
-/* ---- whole-horizon rollout of the WIDE vanilla_warehouse policy: one launch per direction for all T periods (round 5) -------
- * Trainer.simulate_batch's loop (trainer.py:190-213) for VanillaWarehouse (neural_networks.py:358-427) with 512-wide hidden
- * layers: a workgroup carries a block of 32 scenarios through every period - hidden layers on the FP32 matrix cores with the
- * weights streamed from L2 as pre-packed MFMA fragments and the activations in LDS, logits contracted straight from the last
- * layer's accumulators, softmax head + Simulator.step (environment.py:110-299) on LDS tiles, next period's first layer from the
- * new state tile - and leaves the histories the backward sweep and the weight-gradient contractions read.
- * Histories: element (t, row, b) at base + t * period stride + row * ldb + b.  Packed weights (built by the caller once per
- * optimizer step; neural_inventory_control_amd/wide_rollout.py):
- *   Wp_hidden[l]  layer l (1 <= l < n_hidden), [H/32][H/8][64 lanes][4]: lane (r, h) of (tile, group g) holds
- *                 W_l[32 tile + r][8 g + 2 j + h], j = 0..3
- *   Wq_out        logits layer, [H/32][16][64]: lane (n, h) of (tile, r) holds W_out[n][32 tile + (r & 3) + 8 (r >> 2) + 4 h]
- *                 (0 for n >= n_out)
- * Shapes: nic_wide_rollout_ok (H == 512, 2..4 hidden layers, <= 16 stores, (S + 1) Wn = n_out <= 32, S Ws + Wn Ww <= 51, pipelines
- * <= 4 slots, ldb % 64 == 0). */
-typedef struct NicWideRollout {
-    NicEnvStepIO io;            /* dims + static tables (underage, holding, lead_times, wh_*); state / demand / order members unused */
-    const int32_t* adjacency;   /* [Wn][S] */
-    float upper_bound;
-    int32_t transshipment;
-    int32_t T, H, n_hidden, n_out;
-    const float* demand;        /* [T][S][ld_demand], period stride ps_demand (elements) */
-    int64_t ps_demand, ld_demand;
-    float* states;              /* [T + 1][F (+ 1)][ldb]: block 0 = the initial state (input); blocks 1..T written (rows < F) */
-    float* orders;              /* [T][S Wn + Wn][ldb] */
-    float* logits;              /* [T][n_out][ldb] */
-    float* rewards;             /* [T][ldb] */
-    float* hidden[4];           /* [T][H][ldb] post-ELU activation of hidden layer l, or NULL (evaluation: nothing kept) */
-    int64_t ps_state, ps_orders, ps_logits, ps_hidden;
-    const float* Wt_in;         /* first layer transposed [F + 1][ldwt_in], row F = its bias */
-    int64_t ldwt_in;
-    const float* Wp_hidden[4];  /* [l] for 1 <= l < n_hidden */
-    const float* b_hidden[4];
-    const float* Wq_out;
-    const float* b_out;         /* [n_out] or NULL */
-} NicWideRollout;
-int nic_wide_rollout_ok(const NicEnvDims* dims, int32_t n_out, int32_t H, int32_t n_hidden);
-int nic_wide_rollout_fwd(const NicWideRollout* w, void* stream);
-/* Backward sweep over the histories nic_wide_rollout_fwd left (w->hidden[l] must be set for every hidden layer): for t = T-1 .. 0
- * the first layer's input gradient of period t+1 (contracted from the registers that hold its pre-activation gradient), the env /
- * head adjoints on LDS tiles, the logits layer's input gradient and the hidden layers' input gradients with ELU' from the
- * activation history.  Writes dZ_hidden[l] ([T][H][ldb], period stride ps_dz: pre-activation gradient of hidden layer l) and
- * dZ_out ([T][n_out][ldb], ps_dzout: logits gradient) - the operands of the weight-gradient contractions
- * (nic_linear_wgrad_periods).  g_reward as for nic_env_step_bwd.  Packed weights:
- *   WpT_hidden[l]  (1 <= l < n_hidden) the TRANSPOSE of layer l packed like Wp_hidden
- *   Wq_in          first layer, [2][H/32][16][64]: lane (f, h) of (mt, tile, r) holds W_in[32 tile + (r & 3) + 8 (r >> 2) + 4 h][32 mt + f]
- *                  (0 for state rows 32 mt + f >= F)
- *   Wo_t           logits layer, [H/32][NS][64], NS = 4 / 9 / 16 >= ceil(n_out / 2): lane (k, h) of (tile, s) holds
- *                  W_out[2 s + h][32 tile + k] (0 for rows >= n_out) */
-int nic_wide_rollout_bwd(const NicWideRollout* w, NicTable2 g_reward, float* const* dZ_hidden, int64_t ps_dz, float* dZ_out,
-                         int64_t ps_dzout, const float* const* WpT_hidden, const float* Wq_in, const float* Wo_t, void* stream);
 
 /* vanilla_one_store (neural_networks.py:200-214): orders[s][b] = softplus(Z[s][b] + 1)  (threshold 20 like
  * nn.Softplus).  rows = number of output rows (1 for the shipped config). */
@@ -437,9 +381,9 @@ int nic_closed_form_num_partials(int32_t n_scenarios, int32_t S);
  * over periods >= ignore_periods), state_final [S][F][ldb], g_levels_partial [num_partials][n_levels]: per-workgroup sums
  * over its chains of d(totals[0])/d(level_j) — the caller adds the rows (deterministic, no atomics).  Padding columns
  * (b >= n_scenarios) of the outputs are left untouched. */
-int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
-                            float* g_levels_partial, void* stream);
-/* The same launch with the per-chain sums added over each wavefront of chains as well: partial [num_partials][partial_stride],
+/* (nic_closed_form_rollout_sums with with_grad = (partial != NULL), with_sums = 0, partial_stride = n_levels is the launch just
+ * described; round 6 dropped the separate entry point.)
+ * The launch with the per-chain sums added over each wavefront of chains as well: partial [num_partials][partial_stride],
  * row = [d(total)/d(level_j) for j < n_levels if with_grad][total, reported if with_sums] - the caller adds the rows and needs
  * neither `totals` (8 B per chain written, then reduced by a second kernel over all chains) nor a separate gradient buffer.
  * (Round 5: at 10^6 chains the reduction of `totals` took longer than the rollout.) */
@@ -553,13 +497,10 @@ int nic_mlp3_fwd(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float
  * nodes1 = nodes0 + node_update(...), edges1 = edges0 + edge_update(...); neural_networks.py:1311-1340). */
 int nic_mlp3_fwd_residual(const NicMlp3Desc* d, float* Y, float* X_hist, float* H1, float* H2, const float* residual, float* Ysum,
                           void* stream);
-/* Backward of the same MLP from dY [n_out][n_entities][ldb] and the stored Y / H1 / H2: the pre-activation gradients dZ3
- * [n_out][..], dZ2, dZ1 [32][..] (the weight gradients are nic_linear_wgrad contractions of these with H2 / H1 / X_hist over
- * all columns) and dX [K][n_entities][ldb], the gradient with respect to the GATHERED inputs (dense per column; the caller
- * adds it back to the sources with nic_segment_sum over the transposed maps).  dX may be NULL. */
-int nic_mlp3_bwd(const NicMlp3Desc* d, const float* dY, const float* Y, const float* H1, const float* H2, float* dZ3,
-                 float* dZ2, float* dZ1, float* dX, void* stream);
-/* The same backward WITHOUT any stored history: the kernel gathers the inputs again, recomputes the two hidden layers, and
+/* (Round 6: the round-2 backward that wrote the three pre-activation gradients of every column for later nic_linear_wgrad
+ * contractions - `nic_mlp3_bwd` - is gone: it lost to the in-kernel weight gradients below by 10 % in round 2 and was kept only as a
+ * test mode.)
+ * Backward of the same MLP WITHOUT any stored history: the kernel gathers the inputs again, recomputes the two hidden layers, and
  * contracts the weight gradients itself — each wavefront keeps dW1 / dW2 / dW3 (+ bias columns) in registers across all the
  * (entity, 32-scenario) chunks it walks (operands transposed through LDS into the MFMA's row-owner layout) and adds them to
  * ITS slot of the slabs at the end:  slab_l[slot][n][k] += ..., column K_l = bias gradient, lds_l = slab row length.
@@ -666,13 +607,13 @@ typedef struct NicGnnPeriod {
     float* store_out;
     float* wh_out;
     float* reward;
-    float* edge_scratch;          /* nic_gnn_period_ok() == 2: nic_gnn_period_edge_scratch_floats() floats for the edge tiles; else NULL */
+    float* edge_scratch;          /* nic_gnn_period_ok() == 2: ceil(n_scenarios / 16) * n_edges * 512 floats for the edge tiles; else NULL */
 } NicGnnPeriod;
 int nic_gnn_period_pack_size(int32_t s1q, int32_t n_out);
 /* 1 if a graph's embeddings (n_nodes + n_edges tiles of 2 KB) and the staged weights fit in a workgroup's LDS; 2 if only the node
- * tiles do - the edge tiles then live in `edge_scratch` (global memory, L2-resident); 0 if neither */
+ * tiles do - the edge tiles then live in `edge_scratch` (global memory, L2-resident: ceil(n_scenarios / 16) * n_edges * 512 floats);
+ * 0 if neither */
 int nic_gnn_period_ok(int32_t n_nodes, int32_t n_edges, int32_t Dn);
-int64_t nic_gnn_period_edge_scratch_floats(int32_t n_edges, int32_t n_scenarios);
 int nic_gnn_period_fwd(const NicGnnPeriod* p, void* stream);
 
 /* ---- ... and its BACKWARD in one launch (csrc/gnn_period_bwd.hip) -------------------------------------------------
@@ -728,8 +669,8 @@ typedef struct NicGnnPeriodBwd {
     float* scratch;
     NicGnnPeriodBwdMlp mlp[5];
 } NicGnnPeriodBwd;
-int nic_gnn_period_bwd_pack_size(int32_t n_out, int32_t n_segments);
-int nic_gnn_period_bwd_max_grid(void);
+/* pack size: (n_out == 1 ? 512 : 1024) + 1024 (1 + segments) floats; workgroups per launch: at most nic_mlp3_bwd_hist_slots(), the
+ * slot count of the slabs both backwards share */
 int64_t nic_gnn_period_bwd_scratch_floats(int32_t n_nodes, int32_t n_edges, int32_t n_live, int32_t n_scenarios, int32_t n_sub);
 int nic_gnn_period_bwd(const NicGnnPeriodBwd* p, void* stream);
 
@@ -772,10 +713,6 @@ int nic_sample_demand(float* out, int32_t T, int32_t S, int32_t n_scenarios, int
 int nic_sample_demand_equicorrelated(float* out, int32_t T, int32_t S, int32_t n_scenarios, int32_t ldb,
                                      int64_t scenario_offset, uint64_t seed, const float* mean /* [S] */,
                                      const float* std /* [S] */, float rho, int32_t clip, void* stream);
-
-/* ---- small utilities on SoA buffers ---------------------------------------------------------------------- */
-/* out[b] += in[b] for b < n (per-scenario running cost); */
-int nic_axpy(float* out, const float* in, float alpha, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

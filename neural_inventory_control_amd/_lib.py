@@ -153,18 +153,12 @@ PROTOTYPES = {
     "nic_device_count": (C.c_int, []),
     "nic_env_step_fwd": (C.c_int, [_IOP, _vp, _vp, _vp, _vp, _vp]),
     "nic_env_step_bwd": (C.c_int, [_IOP, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "nic_head_env_fwd": (C.c_int, [_IOP, _vp, _vp, C.c_float, _i32, _vp, _vp, _vp, _vp]),
-    "nic_head_env_bwd": (C.c_int, [_IOP, _vp, _vp, C.c_float, _i32, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "nic_head_env_fwd_rows": (C.c_int, [_IOP, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, _vp, _vp]),
-    "nic_head_env_bwd_rows": (C.c_int, [_IOP, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nic_head_env_fwd": (C.c_int, [_IOP, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, _vp, _vp]),
+    "nic_head_env_bwd": (C.c_int, [_IOP, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_period_tail_ok": (C.c_int, [C.POINTER(NicEnvDims), _i32, _i32, _i32]),
     "nic_period_tail_fwd": (C.c_int, [C.POINTER(NicPeriodTail), _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_period_tail_bwd_slots": (C.c_int, [_i32]),
     "nic_period_tail_bwd": (C.c_int, [C.POINTER(NicPeriodTail), _vp, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "nic_wide_rollout_ok": (C.c_int, [C.POINTER(NicEnvDims), _i32, _i32, _i32]),
-    "nic_wide_rollout_fwd": (C.c_int, [C.POINTER(NicWideRollout), _vp]),
-    "nic_wide_rollout_bwd": (C.c_int, [C.POINTER(NicWideRollout), NicTable2, C.POINTER(C.c_void_p * 4), _i64, _vp, _i64,
-                                       C.POINTER(C.c_void_p * 4), _vp, _vp, _vp]),
     "nic_linear_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_linear_fwd_thin_in_ok": (C.c_int, [_i32, _i32]),
     "nic_linear_fwd_thin_in": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -199,15 +193,11 @@ PROTOTYPES = {
     "nic_gnn_period_pack_size": (C.c_int, [_i32, _i32]),
     "nic_gnn_period_ok": (C.c_int, [_i32, _i32, _i32]),
     "nic_gnn_period_fwd": (C.c_int, [C.POINTER(NicGnnPeriod), _vp]),
-    "nic_gnn_period_edge_scratch_floats": (C.c_int64, [_i32, _i32]),
-    "nic_gnn_period_bwd_pack_size": (C.c_int, [_i32, _i32]),
-    "nic_gnn_period_bwd_max_grid": (C.c_int, []),
     "nic_gnn_period_bwd_scratch_floats": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]),
     "nic_gnn_period_bwd": (C.c_int, [C.POINTER(NicGnnPeriodBwd), _vp]),
     "nic_round_orders": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "nic_mlp3_fwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp]),
     "nic_mlp3_fwd_residual": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "nic_mlp3_bwd": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_mlp3_bwd_fused_slots": (C.c_int, []),
     "nic_mlp3_bwd_fused": (C.c_int, [C.POINTER(NicMlp3Desc), _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "nic_mlp3_bwd_hist_slots": (C.c_int, []),
@@ -219,14 +209,29 @@ PROTOTYPES = {
     "nic_gnn_alloc_groups_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_segment_sum": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "nic_closed_form_num_partials": (C.c_int, [_i32, _i32]),
-    "nic_closed_form_rollout": (C.c_int, [C.POINTER(NicClosedFormDesc), _vp, _vp, _vp, _vp, _vp]),
     "nic_closed_form_rollout_sums": (C.c_int, [C.POINTER(NicClosedFormDesc), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "nic_sample_demand": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i64, _u64, _i32, _vp, _vp, _i32, _vp]),
     "nic_sample_demand_equicorrelated": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i64, _u64, _vp, _vp, _f32, _i32, _vp]),
-    "nic_axpy": (C.c_int, [_vp, _vp, _f32, _i64, _vp]),
+}
+
+# include/nic_experiments.h: present only in a library built with NIC_BUILD_EXPERIMENTS=1 (routes that lost their A/B)
+EXPERIMENTAL_PROTOTYPES = {
+    "nic_wide_rollout_ok": (C.c_int, [C.POINTER(NicEnvDims), _i32, _i32, _i32]),
+    "nic_wide_rollout_fwd": (C.c_int, [C.POINTER(NicWideRollout), _vp]),
+    "nic_wide_rollout_bwd": (C.c_int, [C.POINTER(NicWideRollout), NicTable2, C.POINTER(C.c_void_p * 4), _i64, _vp, _i64,
+                                       C.POINTER(C.c_void_p * 4), _vp, _vp, _vp]),
 }
 
 _lib = None
+
+
+def has_experiments():
+    """True if the loaded library carries the experimental entry points (built with NIC_BUILD_EXPERIMENTS=1)."""
+    try:
+        getattr(lib(), "nic_wide_rollout_fwd")
+        return True
+    except AttributeError:
+        return False
 
 
 def library_built():
@@ -260,6 +265,13 @@ def load_library(path=None):
     lib = C.CDLL(p)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    for name, (res, args) in EXPERIMENTAL_PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue
         fn.restype = res
         fn.argtypes = args
     if lib.nic_abi_version() != 1:

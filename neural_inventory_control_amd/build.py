@@ -17,7 +17,6 @@ SOURCES = [
     ("policy_heads.hip", ["-ffp-contract=off"]),
     ("head_env.hip", ["-ffp-contract=off"]),
     ("period_tail.hip", ["-ffp-contract=off"]),
-    ("wide_rollout.hip", ["-ffp-contract=off"]),
     ("linear_mfma.hip", []),
     ("thin_layer.hip", []),
     ("sampler.hip", []),
@@ -32,7 +31,13 @@ SOURCES = [
     ("gnn_period.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
     ("gnn_period_bwd.hip", ["-fno-slp-vectorize"]),
 ]
+# Routes that lost their A/B stay out of the default library (include/nic_experiments.h): NIC_BUILD_EXPERIMENTS=1 adds them.
+EXPERIMENTS = os.environ.get("NIC_BUILD_EXPERIMENTS", "") not in ("", "0")
+if EXPERIMENTS:
+    SOURCES.append((os.path.join(HERE, "..", "tools", "experiments", "wide_rollout.hip"), ["-ffp-contract=off", "-I", CSRC]))
 HEADERS = ["nic_common.h", "env_step_body.h", "policy_heads_body.h", "tail_pieces.h", "small_rollout_body.h", "small_rollout16.h", "closed_form_body.h", "gnn_alloc_body.h", os.path.join("..", "..", "include", "nic_rollout.h")]
+if EXPERIMENTS:
+    HEADERS.append(os.path.join("..", "..", "include", "nic_experiments.h"))
 ARCH = "gfx950"
 
 

@@ -146,10 +146,4 @@ int nic_closed_form_rollout_sums(const NicClosedFormDesc* d, float* reward_hist,
 #undef NIC_CF_LAUNCH
     return nic::check_launch("nic_closed_form_rollout");
 }
-
-int nic_closed_form_rollout(const NicClosedFormDesc* d, float* reward_hist, float* totals, float* state_final,
-                            float* g_levels_partial, void* stream) {
-    return nic_closed_form_rollout_sums(d, reward_hist, totals, state_final, g_levels_partial, d ? d->n_levels : 0,
-                                        g_levels_partial != nullptr, 0, stream);
-}
 }

@@ -522,9 +522,6 @@ int nic_gnn_period_ok(int32_t n_nodes, int32_t n_edges, int32_t Dn) {
     return lds_floats(p, &a, &b, true) * 4 <= kLdsLimit ? 2 : 0;   // 2: with the edge tiles in NicGnnPeriod.edge_scratch
 }
 
-int64_t nic_gnn_period_edge_scratch_floats(int32_t n_edges, int32_t n_scenarios) {
-    return (int64_t)nic::ceil_div(n_scenarios, NB) * n_edges * kTile;
-}
 
 int nic_gnn_period_fwd(const NicGnnPeriod* p, void* stream) {
     if (int e = check(p, "nic_gnn_period_fwd")) return e;

@@ -747,8 +747,6 @@ int check(const NicGnnPeriodBwd* p, const char* who) {
 
 extern "C" {
 
-int nic_gnn_period_bwd_pack_size(int32_t n_out, int32_t n_segments) { return packt_floats(n_out, n_segments); }
-int nic_gnn_period_bwd_max_grid(void) { return kMaxGrid; }
 int64_t nic_gnn_period_bwd_scratch_floats(int32_t n_nodes, int32_t n_edges, int32_t n_live, int32_t n_scenarios, int32_t n_sub) {
     const int64_t n_blocks = (n_scenarios + NB - 1) / NB;
     int64_t grid = (n_blocks + n_sub - 1) / n_sub;

@@ -179,17 +179,12 @@ extern "C" {
         }                                        \
     } while (0)
 
-int nic_head_env_fwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, float upper_bound, int32_t transshipment,
-                     float* store_inv_out, float* wh_inv_out, float* reward, void* stream) {
-    return nic_head_env_fwd_rows(io, Z, adjacency, nullptr, -1, upper_bound, transshipment, store_inv_out, wh_inv_out, reward, stream);
-}
-
-int nic_head_env_fwd_rows(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
-                          int32_t first_wh_row, float upper_bound, int32_t transshipment, float* store_inv_out, float* wh_inv_out,
-                          float* reward, void* stream) {
+int nic_head_env_fwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
+                     int32_t first_wh_row, float upper_bound, int32_t transshipment, float* store_inv_out, float* wh_inv_out,
+                     float* reward, void* stream) {
     if (int e = validate(io, Z, adjacency, "nic_head_env_fwd")) return e;
     NIC_REQUIRE(store_inv_out && wh_inv_out && reward, "nic_head_env_fwd: null output");
-    NIC_REQUIRE((logit_rows == nullptr) == (first_wh_row < 0), "nic_head_env_fwd_rows: logit_rows and first_wh_row go together");
+    NIC_REQUIRE((logit_rows == nullptr) == (first_wh_row < 0), "nic_head_env_fwd: logit_rows and first_wh_row go together");
     const NicEnvDims& d = io->dims;
     const dim3 grid(nic::ceil_div(d.n_scenarios, kLanes)), block(kLanes * nic::kQuad);
     hipStream_t s = nic::as_stream(stream);
@@ -203,20 +198,13 @@ int nic_head_env_fwd_rows(const NicEnvStepIO* io, const float* Z, const int32_t*
     return nic::check_launch("nic_head_env_fwd");
 }
 
-int nic_head_env_bwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, float upper_bound, int32_t transshipment,
-                     const float* g_store_out, const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in,
-                     float* g_store_orders, float* g_wh_orders, float* dZ, void* stream) {
-    return nic_head_env_bwd_rows(io, Z, adjacency, nullptr, -1, upper_bound, transshipment, g_store_out, g_wh_out, g_reward, g_store_in,
-                                 g_wh_in, g_store_orders, g_wh_orders, dZ, stream);
-}
-
-int nic_head_env_bwd_rows(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
-                          int32_t first_wh_row, float upper_bound, int32_t transshipment, const float* g_store_out,
-                          const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_store_orders,
-                          float* g_wh_orders, float* dZ, void* stream) {
+int nic_head_env_bwd(const NicEnvStepIO* io, const float* Z, const int32_t* adjacency, const int32_t* logit_rows,
+                     int32_t first_wh_row, float upper_bound, int32_t transshipment, const float* g_store_out,
+                     const float* g_wh_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_store_orders,
+                     float* g_wh_orders, float* dZ, void* stream) {
     if (int e = validate(io, Z, adjacency, "nic_head_env_bwd")) return e;
     NIC_REQUIRE(g_reward.p && g_store_in && g_wh_in && g_store_orders && g_wh_orders && dZ, "nic_head_env_bwd: null buffer");
-    NIC_REQUIRE((logit_rows == nullptr) == (first_wh_row < 0), "nic_head_env_bwd_rows: logit_rows and first_wh_row go together");
+    NIC_REQUIRE((logit_rows == nullptr) == (first_wh_row < 0), "nic_head_env_bwd: logit_rows and first_wh_row go together");
     const NicEnvDims& d = io->dims;
     const dim3 grid(nic::ceil_div(d.n_scenarios, kLanes)), block(kLanes * nic::kQuad);
     hipStream_t s = nic::as_stream(stream);

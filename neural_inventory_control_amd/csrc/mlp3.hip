@@ -352,99 +352,6 @@ __global__ __launch_bounds__(64 * kFwdWaves) void mlp3_fwd_kernel(NicMlp3Desc d,
     }
 }
 
-// KG = 32-row groups of the input gradient (K <= 32 * KG).  Weights staged in LDS in their natural row-major layout (the
-// transposed products read W[crow(s, h)][i]: consecutive words per lane); the stored activations of a chunk are fetched
-// before the first MFMA.
-template <int KG>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(3, 8))) void mlp3_bwd_kernel(NicMlp3Desc d, const float* __restrict__ weights,
-                                                               const float* __restrict__ dY, const float* __restrict__ Yo,
-                                                               const float* __restrict__ H1, const float* __restrict__ H2,
-                                                               float* __restrict__ dZ3, float* __restrict__ dZ2,
-                                                               float* __restrict__ dZ1, float* __restrict__ dX) {
-    __shared__ float w1[32 * 32 * KG], w2[32 * 32], w3[32 * 32];
-    const int K = d.K;
-    {
-        const float* W1 = weights;
-        const float* W2 = W1 + 32 * K + 32;
-        const float* W3 = W2 + 32 * 32 + 32;
-        for (int idx = threadIdx.x; idx < 32 * 32 * KG; idx += 64 * kWaves) {  // [row n][32 * KG input columns], zero padded
-            const int n = idx / (32 * KG), k = idx % (32 * KG);
-            w1[idx] = k < K ? W1[n * K + k] : 0.f;
-        }
-        for (int idx = threadIdx.x; idx < 32 * 32; idx += 64 * kWaves) {
-            w2[idx] = W2[idx];
-            w3[idx] = (idx >> 5) < d.n_out ? W3[idx] : 0.f;
-        }
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5, i = j;
-    const int e = blockIdx.y;
-    const int64_t ent_ld = d.ent_row_stride ? d.ent_row_stride : (int64_t)d.n_entities * d.ldb;
-    const int64_t hs = d.hist_row_stride ? d.hist_row_stride : ent_ld;
-#pragma unroll 1
-    for (int c = 0; c < kChunks; ++c) {
-        if ((int64_t)(blockIdx.x * kWaves + wv) * kChunks * 32 + (int64_t)c * 32 >= d.n_scenarios) break;
-        const int64_t b_raw = ((int64_t)(blockIdx.x * kWaves + wv) * kChunks + c) * 32 + j;
-        const bool live = b_raw < d.n_scenarios;
-        const int64_t b = live ? b_raw : 0;
-        const int64_t col = (int64_t)e * d.ldb + b;
-        // everything this chunk reads, issued up front (rows >= n_out re-read row 0 and are zeroed by a select)
-        float gy[16], yo[16], h2[16], h1[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = crow(r, h), rr = row < d.n_out ? row : 0;
-            gy[r] = dY[(int64_t)rr * ent_ld + col];
-            yo[r] = Yo[(int64_t)rr * ent_ld + col];
-            h2[r] = H2[(int64_t)row * hs + col];
-            h1[r] = H1[(int64_t)row * hs + col];
-        }
-        float dz[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = crow(r, h);
-            const float v = (row < d.n_out && live) ? gy[r] * out_act_grad(d.out_act, yo[r]) : 0.f;
-            dz[r] = v;
-            if (live && row < d.n_out) dZ3[(int64_t)row * hs + col] = v;
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[crow(s, h) * 32 + i], dz[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dz[r] = acc[r] * nic::elu1_grad_from_out(h2[r]);
-            if (live) dZ2[(int64_t)crow(r, h) * hs + col] = dz[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[crow(s, h) * 32 + i], dz[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dz[r] = acc[r] * nic::elu1_grad_from_out(h1[r]);
-            if (live) dZ1[(int64_t)crow(r, h) * hs + col] = dz[r];
-        }
-        if (dX) {
-#pragma unroll
-            for (int g = 0; g < KG; ++g) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[crow(s, h) * 32 * KG + 32 * g + i], dz[s], acc, 0, 0, 0);
-                if (live) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int k = 32 * g + crow(r, h);
-                        if (k < K) dX[(int64_t)k * ent_ld + col] = acc[r];
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---- history-free backward: gather again, recompute the hidden layers, contract the weight gradients in the kernel -------------
 // Layouts: the MLP chain runs "column-owner" (lane (h, c) holds rows crow(r, h) of column c: MFMA C layout / B operand); a weight
 // gradient dW[i][k] = sum_c dz[i][c] act[k][c] contracts over the COLUMNS, so both of its operands must be "row-owner" (lane
@@ -1323,23 +1230,6 @@ int nic_mlp3_fwd_residual(const NicMlp3Desc* d, float* Y, float* X_hist, float* 
 #undef NIC_MLP3_FWD2
 #undef NIC_MLP3_FWD
     return nic::check_launch("nic_mlp3_fwd");
-}
-
-int nic_mlp3_bwd(const NicMlp3Desc* d, const float* dY, const float* Y, const float* H1, const float* H2, float* dZ3, float* dZ2,
-                 float* dZ1, float* dX, void* stream) {
-    if (int e = validate(d, "nic_mlp3_bwd")) return e;
-    NIC_REQUIRE(dY && Y && H1 && H2 && dZ3 && dZ2 && dZ1, "nic_mlp3_bwd: null buffer");
-    NIC_REQUIRE(!d->hist_native, "nic_mlp3_bwd: the stored-gradient backward reads H1 / H2 as GEMM operands (row layout only)");
-    const dim3 grid(nic::ceil_div(d->n_scenarios, 32 * kWaves * kChunks), d->n_entities), block(64 * kWaves);
-    hipStream_t s = nic::as_stream(stream);
-    const int kg = (d->K + 31) / 32;
-    nic::note_kernelf("mlp3_bwd_kernel<%d>", kg);
-#define NIC_MLP3_BWD(KG) hipLaunchKernelGGL(mlp3_bwd_kernel<KG>, grid, block, 0, s, *d, d->weights, dY, Y, H1, H2, dZ3, dZ2, dZ1, dX)
-    if (kg == 1) NIC_MLP3_BWD(1);
-    else if (kg == 2) NIC_MLP3_BWD(2);
-    else NIC_MLP3_BWD(3);
-#undef NIC_MLP3_BWD
-    return nic::check_launch("nic_mlp3_bwd");
 }
 
 int nic_mlp3_bwd_fused_slots(void) { return kFusedBlocks * kFusedWaves; }

@@ -35,17 +35,4 @@ int nic_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
-
-__global__ void axpy_kernel(float* __restrict__ out, const float* __restrict__ in, float alpha, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] += alpha * in[i];
-}
-
-int nic_axpy(float* out, const float* in, float alpha, int64_t n, void* stream) {
-    NIC_REQUIRE(out && in, "nic_axpy: null buffer");
-    if (n <= 0) return 0;
-    nic::note_kernel("axpy_kernel");
-    hipLaunchKernelGGL(axpy_kernel, dim3(nic::ceil_div(n, 256)), dim3(256), 0, nic::as_stream(stream), out, in, alpha, n);
-    return nic::check_launch("nic_axpy");
-}
 }

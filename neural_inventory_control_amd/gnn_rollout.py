@@ -155,7 +155,7 @@ class _Mlp:
         self.P, self.G = P, (T + P - 1) // P
         self.hist_stride = 0
         self.native = False
-        self.mode = mode if train else None     # "hist" | "gemm" | "fused" (see GnnRollout.fused_bwd)
+        self.mode = mode if train else None     # "hist" | "fused" (see GnnRollout.fused_bwd)
         self.fused_bwd = mode == "fused"
         dims = [(32, K), (32, 32), (n_out, 32)]
         if train and mode == "hist":
@@ -181,19 +181,6 @@ class _Mlp:
             slots = ops.mlp3_bwd_fused_slots()
             self.slabs = [torch.zeros(slots, n, (k + 1 + 3) // 4 * 4, device=device) for n, k in dims]
             self.dX = torch.zeros(K, n_ent, ld, device=device)
-            self.gw = [torch.zeros_like(m.weight) for m in linears]
-            self.gb = [torch.zeros_like(m.bias) for m in linears]
-        elif train:
-            # histories [group][rows][P periods][entity][ldb]: one row holds P periods, so a weight gradient contracts over
-            # P * n_ent * ldb columns per launch (P is bounded by the GEMM kernels' 2^28-element operand limit)
-            G = self.G
-            self.hist_stride = P * n_ent * ld
-            self.X, self.H1, self.H2 = z(G, K, P, n_ent, ld), z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld)
-            self.dZ1, self.dZ2, self.dZ3 = z(G, 32, P, n_ent, ld), z(G, 32, P, n_ent, ld), z(G, n_out, P, n_ent, ld)
-            self.dX = z(K, n_ent, ld)
-            cols = P * n_ent * ld
-            self.splits = [ops.wgrad_num_splits(n, k, cols) for n, k in dims]
-            self.slabs = [z(sp, n, (k + 1 + 3) // 4 * 4) for sp, (n, k) in zip(self.splits, dims)]
             self.gw = [torch.zeros_like(m.weight) for m in linears]
             self.gb = [torch.zeros_like(m.bias) for m in linears]
 
@@ -241,7 +228,8 @@ class GnnRollout:
         self.timer = None
         # Backward of the MLPs.  None = "hist" while the stored activations fit in HBM, else the history-free kernel.
         #   "hist"  stored inputs / hidden activations, weight gradients contracted inside the backward kernel (nic_mlp3_bwd_hist)
-        #   False   ("gemm") stored activations AND pre-activation gradients, weight gradients by nic_linear_wgrad contractions
+        #           (the round-2 form that also stored the pre-activation gradients for separate nic_linear_wgrad contractions -
+        #           `fused_bwd = False` - was removed in round 6: it lost to "hist" by 10 % and was a test mode only)
         #   True    ("fused") nic_mlp3_bwd_fused: re-gather, recompute, in-kernel weight gradients; no per-period buffers at
         #           all, but its gathers are latency-exposed at two wavefronts per SIMD
         self.fused_bwd = None
@@ -331,7 +319,9 @@ class GnnRollout:
         ks = (self.Dn, 65, 96, 96, 32)
         ents = (N, E, N, E, E)
         P_ = max(1, min(T, (1 << 28) // (96 * E * ld)))   # periods per history row (see _Mlp)
-        mode = {None: None, True: "fused", False: "gemm", "hist": "hist", "gemm": "gemm", "fused": "fused"}[self.fused_bwd]
+        if self.fused_bwd is False or self.fused_bwd == "gemm":
+            raise ValueError("fused_bwd = False (stored pre-activation gradients + GEMM contractions) was removed in round 6: use 'hist'")
+        mode = {None: None, True: "fused", "hist": "hist", "fused": "fused"}[self.fused_bwd]
         self._keep_inputs = True
         if mode is None and train:
             # rows of history per period: H1 + H2 of the five MLPs, and their gathered inputs
@@ -374,7 +364,6 @@ class GnnRollout:
         if train and self.use_period_bwd:
             ok = self._mode_now == "hist" and self.mlp["output"].native and self.Dn <= 32
             if ok:
-                assert ops.gnn_period_bwd_max_grid() <= ops.mlp3_bwd_hist_slots()
                 self.bpack = {name: ops.GnnPeriodBwdPack(self._linears(name), 1 if name == "output" else 32, sg, dev)
                               for name, sg in zip(MODULES, (1, 2, 3, 3, 1))}
                 n_blocks = (prob.B + 15) // 16
@@ -546,14 +535,8 @@ class GnnRollout:
         g.replay()
 
     def _weight_gradients(self, T, prob):
-        """dW = sum over (period, entity, scenario) of dZ X^T per layer: one contraction per history group (P periods each)."""
+        """dW = sum over the slab slots the backward kernels added their per-workgroup weight gradients to."""
         for m in self.mlp.values():
-            for g in range(m.G if m.mode == "gemm" else 0):
-                n_per = min(m.P, T - g * m.P)
-                cols = n_per * m.n_ent * prob.ldb
-                for i, (dz, x) in enumerate(((m.dZ1, m.X), (m.dZ2, m.H1), (m.dZ3, m.H2))):
-                    self._k("wgrad_" + m.name, ops.linear_wgrad, dz[g].view(dz.shape[1], -1), x[g].view(x.shape[1], -1),
-                            m.slabs[i], cols)
             for i, lin in enumerate(m.linears):
                 ops.wgrad_reduce(m.slabs[i], m.gw[i], m.gb[i], lin.weight.shape[1], 1.0)
 
@@ -759,12 +742,8 @@ class GnnRollout:
             self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd_hist, self._desc(m, segs[m.name], prob), dY, m.Y[t],
                     m.hist(m.X, t) if m.X is not None else None, m.hist(m.H1, t), m.hist(m.H2, t), dX if dX is not None else m.dX, m.slabs)
             return
-        if m.mode == "fused":
-            self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd_fused, self._desc(m, segs[m.name], prob), dY, m.Y[t],
-                    dX if dX is not None else m.dX, m.slabs)
-            return
-        self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd, self._desc(m, segs[m.name], prob), dY, m.Y[t], m.hist(m.H1, t),
-                m.hist(m.H2, t), m.hist(m.dZ3, t), m.hist(m.dZ2, t), m.hist(m.dZ1, t), dX if dX is not None else m.dX)
+        self._k("mlp3_bwd_" + m.name, ops.mlp3_bwd_fused, self._desc(m, segs[m.name], prob), dY, m.Y[t],
+                dX if dX is not None else m.dX, m.slabs)
 
     # ---- inspection helpers used by the parity tests --------------------------------------------------------------------------
     def per_period_rewards(self):

@@ -175,11 +175,10 @@ def head_warehouse_bwd(Z, wh_inv, adjacency, ub, transshipment, g_store_orders, 
 def head_env_fwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders: Table, wh_orders: Table, Z, adjacency, ub,
                  transshipment, out: EnvState, reward, logit_rows=None, first_wh_row=-1):
     """nic_head_env_fwd: vanilla_warehouse head + env step in one launch.  `store_orders` / `wh_orders` are the dense
-    [S][Wn][ldb] / [Wn][ldb] blocks the orders are WRITTEN to (and consumed from).  logit_rows / first_wh_row: compact logits
-    (nic_head_env_fwd_rows)."""
+    [S][Wn][ldb] / [Wn][ldb] blocks the orders are WRITTEN to (and consumed from).  logit_rows / first_wh_row: compact logits."""
     _dev(Z)
     io = prob.make_io(state.store, state.wh, None, demand, store_orders, wh_orders, None)
-    check(lib().nic_head_env_fwd_rows(io, ptr(Z), ptr(adjacency), ptr(logit_rows), int(first_wh_row), float(ub), int(transshipment),
+    check(lib().nic_head_env_fwd(io, ptr(Z), ptr(adjacency), ptr(logit_rows), int(first_wh_row), float(ub), int(transshipment),
                                       ptr(out.store), ptr(out.wh), ptr(reward), current_stream()))
     return out, reward
 
@@ -187,10 +186,10 @@ def head_env_fwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders:
 def head_env_bwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders: Table, wh_orders: Table, Z, adjacency, ub,
                  transshipment, g_out: EnvState, g_reward: Table, g_in: EnvState, g_orders, dZ, logit_rows=None, first_wh_row=-1):
     """nic_head_env_bwd: env-step adjoint + head adjoint in one launch (g_orders: scratch (store, warehouse) blocks).
-    logit_rows / first_wh_row: compact logits (nic_head_env_bwd_rows)."""
+    logit_rows / first_wh_row: compact logits."""
     _dev(Z)
     io = prob.make_io(state.store, state.wh, None, demand, store_orders, wh_orders, None)
-    check(lib().nic_head_env_bwd_rows(io, ptr(Z), ptr(adjacency), ptr(logit_rows), int(first_wh_row), float(ub), int(transshipment),
+    check(lib().nic_head_env_bwd(io, ptr(Z), ptr(adjacency), ptr(logit_rows), int(first_wh_row), float(ub), int(transshipment),
                                       ptr(g_out.store), ptr(g_out.wh), g_reward.t2(), ptr(g_in.store), ptr(g_in.wh),
                                       ptr(g_orders[0]), ptr(g_orders[1]), ptr(dZ), current_stream()))
     return g_in, dZ
@@ -236,7 +235,11 @@ def period_tail_bwd(desc, Z, H_last, dZ_first_next, g_state_next, g_reward: Tabl
 
 
 def wide_rollout_ok(prob: EnvProblem, n_out, H, n_hidden):
-    """shapes the whole-horizon kernels of the wide vanilla_warehouse policy take (nic_wide_rollout_ok)"""
+    """shapes the whole-horizon kernels of the wide vanilla_warehouse policy take (nic_wide_rollout_ok).  An EXPERIMENT
+    (include/nic_experiments.h, tools/experiments/wide_rollout.hip): it ties or loses against the tiled launches, so the default
+    library does not carry it - False unless the library was built with NIC_BUILD_EXPERIMENTS=1."""
+    if not _lib.has_experiments():
+        return False
     return bool(lib().nic_wide_rollout_ok(prob.dims(), int(n_out), int(H), int(n_hidden)))
 
 
@@ -422,11 +425,6 @@ def mlp3_fwd(desc, Y, X_hist=None, H1=None, H2=None, residual=None, Ysum=None):
     return Y
 
 
-def mlp3_bwd(desc, dY, Y, H1, H2, dZ3, dZ2, dZ1, dX=None):
-    _dev(dY)
-    check(lib().nic_mlp3_bwd(desc, ptr(dY), ptr(Y), ptr(H1), ptr(H2), ptr(dZ3), ptr(dZ2), ptr(dZ1), ptr(dX), current_stream()))
-
-
 def mlp3_bwd_fused_slots():
     return lib().nic_mlp3_bwd_fused_slots()
 
@@ -463,7 +461,8 @@ def gnn_period_ok(n_nodes, n_edges, Dn):
 
 
 def gnn_period_edge_scratch_floats(n_edges, n_scenarios):
-    return int(lib().nic_gnn_period_edge_scratch_floats(int(n_edges), int(n_scenarios)))
+    """floats of `NicGnnPeriod.edge_scratch`: one 2-KB tile per (16-scenario block, edge)"""
+    return ((int(n_scenarios) + 15) // 16) * int(n_edges) * 512
 
 
 def _frag32(base):
@@ -543,8 +542,7 @@ class GnnPeriodBwdPack:
         one = [[0, -1, -1, -1]] + [[-1] * 4] * 3
         self.idx3 = gnn_period_pack_index(_frag32(0), 32, 2, device) if n_out == 32 else gnn_period_pack_index(one, 1, 2, device)
         self.idx = gnn_period_pack_index(_frag32(0), 32, 2, device)
-        n = lib().nic_gnn_period_bwd_pack_size(n_out, segments)
-        assert n == self.idx3.numel() + (1 + segments) * 1024
+        n = self.idx3.numel() + (1 + segments) * 1024   # (include/nic_rollout.h: (n_out == 1 ? 512 : 1024) + 1024 (1 + segments))
         self.buf = torch.zeros(n, device=device)
         self._pad3 = torch.zeros(32, (32 if n_out == 32 else 1) + 1, device=device)
         self._pad = torch.zeros(32, 33, device=device)
@@ -564,10 +562,6 @@ class GnnPeriodBwdPack:
             torch.index_select(self._pad.view(-1), 0, self.idx, out=self.buf[o:o + 1024])
             o += 1024
         return self.buf
-
-
-def gnn_period_bwd_max_grid():
-    return lib().nic_gnn_period_bwd_max_grid()
 
 
 def gnn_period_bwd_scratch_floats(n_nodes, n_edges, n_live, n_scenarios, n_sub):
@@ -671,8 +665,3 @@ def sample_demand_equicorrelated(out, T, S, n_scenarios, scenario_offset, seed, 
     check(lib().nic_sample_demand_equicorrelated(ptr(out), T, S, n_scenarios, out.stride(1), int(scenario_offset), int(seed),
                                                  ptr(mean), ptr(std), float(rho), int(clip), current_stream()))
     return out
-
-
-def axpy(out, x, alpha=1.0):
-    _dev(out)
-    check(lib().nic_axpy(ptr(out), ptr(x), float(alpha), out.numel(), current_stream()))

@@ -153,7 +153,8 @@ class FusedRollout:
         # eagerly the step is launch-bound and two launches fewer per period win (5.46 vs 6.65 ms at T = 100).  The forward one wins
         # either way (15.7 against 4.9 + 6.0 + 7.9 us); at 8,192 both win
         self.tail_bwd_min_scenarios = 2048
-        # ... and, for 512-wide hidden layers (BASELINE cfg3), ALL periods in one launch per direction (csrc/wide_rollout.hip): a
+        # ... and, for 512-wide hidden layers (BASELINE cfg3), ALL periods in one launch per direction - an EXPERIMENT that is not in
+        # the default library (tools/experiments/wide_rollout.hip, include/nic_experiments.h; NIC_BUILD_EXPERIMENTS=1 builds it): a
         # workgroup carries a block of 32 scenarios through the whole horizon, weights streamed from L2 as pre-packed MFMA fragments.
         # OFF by default: measured it matches the per-period launches at an 8-GPU shard (29.2 vs 28.2 ms at 8,192
         # scenarios) and loses at the full batch (231 vs 180 ms) - its H x H layers run at the tiled GEMM's rate (36-40 us per 8,192
@@ -378,6 +379,9 @@ class FusedRollout:
         self.Wp = [z(gd[i + 1], _pad32(gd[i])) for i in range(L)]
         self.Wt = [z(gd[i] + (1 if i == 0 else 0), _pad32(gd[i + 1])) for i in range(L)]   # (layer 0: + the bias row, see above)
         # whole-horizon forward of the wide policy: every hidden layer 512 wide, history kept, shapes in the kernel's range
+        if self.use_wide and not _lib.has_experiments():
+            raise ValueError("use_wide: the whole-horizon kernels of the wide policy are an experiment outside the default library "
+                             "(build with NIC_BUILD_EXPERIMENTS=1; include/nic_experiments.h)")
         self._wide_shapes = bool(self.use_wide and self.head == "warehouse" and self.live_rows is None and extra_rows == 0 and L >= 3
                                  and self._hist and all(m.bias is not None for m in lins) and len(set(dims[1:-1])) == 1
                                  and ops.wide_rollout_ok(prob, dims[-1], dims[1], L - 1))

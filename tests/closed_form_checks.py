@@ -36,8 +36,8 @@ def hip_launch():
     def run(desc, rewards, totals, final, n_levels, want_grad):
         n_part = _lib.lib().nic_closed_form_num_partials(desc.n_scenarios, desc.S)
         part = torch.zeros(n_part, n_levels, device=rewards.device) if want_grad else None
-        _lib.check(_lib.lib().nic_closed_form_rollout(desc, rewards.data_ptr(), totals.data_ptr(), final.data_ptr(),
-                                                      _lib.ptr(part), _lib.current_stream()))
+        _lib.check(_lib.lib().nic_closed_form_rollout_sums(desc, rewards.data_ptr(), totals.data_ptr(), final.data_ptr(),
+                                                           _lib.ptr(part), n_levels, int(want_grad), 0, _lib.current_stream()))
         torch.cuda.synchronize()
         return part.double().sum(dim=0).cpu() if want_grad else None
     return run

@@ -224,9 +224,9 @@ def test_library_mapped_before_any_torch_device_use_still_launches():
             "_lib.load_library()\n"
             "import torch\n"
             "from neural_inventory_control_amd import ops\n"
-            "x = torch.ones(64, device='cuda'); y = torch.zeros(64, device='cuda')\n"
-            "_lib.check(_lib.lib().nic_axpy(_lib.ptr(y), _lib.ptr(x), 2.0, 64, _lib.current_stream()))\n"
-            "torch.cuda.synchronize(); assert float(y.sum()) == 128.0; print('LAUNCH_OK')\n") % root
+            "y = torch.full((3, 64), 2.4, device='cuda'); y[1] = 3.5\n"
+            "ops.round_orders(y, 64)\n"
+            "torch.cuda.synchronize(); assert float(y.sum()) == 64 * (2.0 + 4.0 + 2.0); print('LAUNCH_OK')\n") % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "LAUNCH_OK" in r.stdout, r.stderr[-2000:]
 

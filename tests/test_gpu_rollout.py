@@ -1648,7 +1648,7 @@ GNN_CASES = ["f1_one_warehouse_gnn", "f1_one_warehouse_16_gnn", "f1_one_warehous
              "f1_many_warehouses_2x10_gnn", "f1_many_warehouses_3x8_dense_gnn"]
 
 
-@pytest.mark.parametrize("fused_bwd", [True, False, "hist", "hist_stored_inputs", "period"])
+@pytest.mark.parametrize("fused_bwd", [True, "hist", "hist_stored_inputs", "period"])
 @pytest.mark.parametrize("name", GNN_CASES)
 def test_gnn_fused_rollout_matches_reference(name, fused_bwd):
     """`GnnRollout` (five fused gather-MLP launches per period, segment-sum aggregation, manual backward sweep) against the
@@ -2326,7 +2326,7 @@ def test_small_route_step_caches_follow_their_inputs():
 def test_compact_logit_rows_through_the_fused_head_env_launches_on_random_graphs(S, Wn, seed):
     """Sparse many-warehouse graphs drawn at random (every store served by one or two warehouses; store counts that do not fill the
     four lanes of a scenario; a warehouse that may end up with a single store): the fused head + env launches on the COMPACT
-    logits (`nic_head_env_fwd_rows` / `_bwd_rows`: only connected (store, warehouse) pairs have a logit row) against the separate
+    logits (`nic_head_env_fwd` / `_bwd` with `logit_rows`: only connected (store, warehouse) pairs have a logit row) against the separate
     head and env launches on the scattered [S * Wn + Wn] layout - rewards, states, orders and parameter gradients bit for bit."""
     from collections import defaultdict
     from neural_inventory_control_amd import workloads
@@ -2504,7 +2504,21 @@ def test_step_graph_guard_sees_the_stream_hazard_on_this_torch_build():
     assert Trainer._stream_hazard_is_reported("cpu") is False
 
 
-# ---- round 5: the whole-horizon forward of the wide policy (csrc/wide_rollout.hip) -------------------------------------------
+# ---- round 5: the whole-horizon forward of the wide policy - since round 6 an EXPERIMENT outside the default library
+# (tools/experiments/wide_rollout.hip, include/nic_experiments.h): these tests run against a library built with NIC_BUILD_EXPERIMENTS=1
+def _needs_experiments():
+    if not torch.cuda.is_available():
+        return True
+    try:
+        return not _lib.has_experiments()
+    except Exception:
+        return True
+
+
+needs_experiments = pytest.mark.skipif(_needs_experiments(), reason="experimental entry points: build with NIC_BUILD_EXPERIMENTS=1")
+
+
+@needs_experiments
 @pytest.mark.parametrize("n,T,hidden", [(100, 5, [512, 512, 512]), (2048 + 17, 3, [512, 512]), (8192, 4, [512, 512, 512])])
 def test_wide_whole_horizon_forward_matches_the_per_period_route(n, T, hidden):
     """BASELINE cfg3's setting with 512-wide hidden layers: ALL periods in one forward launch (a workgroup carries 32 scenarios

@@ -26,6 +26,7 @@
 // Built with -ffp-contract=off (head / env arithmetic rounds like the reference's separate aten ops); MFMA chains are fma by
 // construction.  Same arithmetic as the per-period route except the summation order inside the logits contraction.
 #include "tail_pieces.h"
+#include "../../include/nic_experiments.h"
 
 namespace {
 
