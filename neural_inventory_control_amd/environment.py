@@ -193,7 +193,6 @@ class Simulator:
         for name, a in (("warehouses", a_wh), ("echelons", a_ech)):
             if a is not None and (a.dim() != 3 or a.shape[2] != 1):
                 raise ValueError(f"action['{name}'] must be (B, n, 1): one outside supplier per location")
-        demand = Table(self._demand_soa[tt], prob.ldb, 1)
         st = self._state
         if torch.compiler.is_compiling():
             # while a compiler traces (torch.compile of a rollout loop), the period is the REGISTERED operator - same kernels,
@@ -202,6 +201,7 @@ class Simulator:
                                                             self._problem_handle)
             wh, ech = (wh if prob.Wn else None), (ech if prob.E else None)
         else:
+            demand = Table(self._demand_soa[tt], prob.ldb, 1)
             store, wh, ech, reward = _EnvStepFunction.apply(prob, demand, st.store, st.wh, st.ech, a_store, a_wh, a_ech)
         if self.zero_lead_orders == "upstream":
             store = self._add_zero_lead_orders(store, a_store)

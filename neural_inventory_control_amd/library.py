@@ -211,13 +211,17 @@ env_step.register_autograd(_env_backward, setup_context=_env_setup)
 # ---- nic::softmax_alloc: the warehouse policies' feasibility head --------------------------------------------------------------
 
 @torch.library.custom_op("nic::softmax_alloc", mutates_args=())
-def softmax_alloc(z: torch.Tensor, wh_inv: torch.Tensor, adjacency: torch.Tensor, upper_bound: float, transshipment: bool,
+def softmax_alloc(z: torch.Tensor, wh_inv: torch.Tensor, adjacency: torch.Tensor, upper_bound: torch.Tensor, transshipment: bool,
                   n_stores: int, n_warehouses: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """`apply_softmax_feasibility_function` + the warehouse's own sigmoid order (neural_networks.py:140-166, :403-426) on
-    csrc/policy_heads.hip: z (B, S * Wn + Wn) logits, wh_inv (B, Wn, Ww) warehouse pipelines, adjacency [Wn][S] int32 ->
+    csrc/policy_heads.hip: z (B, S * Wn + Wn) logits, wh_inv (B, Wn, Ww) warehouse pipelines, adjacency [Wn][S] int32,
+    upper_bound = the policy's `warehouse_upper_bound` tensor (a launch argument: read on the host once per tensor version, as the
+    eager head does - a TENSOR here because a traced graph cannot hold a value read from the device) ->
     (store orders (B, S, Wn), warehouse orders (B, Wn, 1)), both views of scenario-minor buffers."""
     if not z.is_cuda:
         raise _lib.NicUnavailableError("nic::softmax_alloc needs device tensors (no CPU fallback)")
+    from .neural_networks import _scalar
+    upper_bound = _scalar(upper_bound)
     B, S, Wn = z.shape[0], n_stores, n_warehouses
     Z = _feature_major(z)
     ld = Z.stride(0)
@@ -236,9 +240,11 @@ def _(z, wh_inv, adjacency, upper_bound, transshipment, n_stores, n_warehouses):
 
 @torch.library.custom_op("nic::softmax_alloc_backward", mutates_args=())
 def softmax_alloc_backward(g_store: torch.Tensor, g_wh: torch.Tensor, z: torch.Tensor, wh_inv: torch.Tensor, adjacency: torch.Tensor,
-                           upper_bound: float, transshipment: bool, n_stores: int,
+                           upper_bound: torch.Tensor, transshipment: bool, n_stores: int,
                            n_warehouses: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """(d z (B, S * Wn + Wn), d wh_inv (B, Wn, Ww)) of nic::softmax_alloc."""
+    from .neural_networks import _scalar
+    upper_bound = _scalar(upper_bound)
     B, S, Wn, Ww = z.shape[0], n_stores, n_warehouses, wh_inv.shape[2]
     Z = _feature_major(z)
     ld = Z.stride(0)
@@ -259,13 +265,13 @@ def _(g_store, g_wh, z, wh_inv, adjacency, upper_bound, transshipment, n_stores,
 
 def _alloc_setup(ctx, inputs, output):
     z, wh_inv, adjacency, ub, trans, S, Wn = inputs
-    ctx.meta = (ub, trans, S, Wn)
-    ctx.save_for_backward(z, wh_inv, adjacency)
+    ctx.meta = (trans, S, Wn)
+    ctx.save_for_backward(z, wh_inv, adjacency, ub)
 
 
 def _alloc_backward(ctx, g_so, g_wo):
-    z, wh_inv, adjacency = ctx.saved_tensors
-    ub, trans, S, Wn = ctx.meta
+    z, wh_inv, adjacency, ub = ctx.saved_tensors
+    trans, S, Wn = ctx.meta
     dz, g_inv = torch.ops.nic.softmax_alloc_backward(g_so, g_wo, z, wh_inv, adjacency, ub, trans, S, Wn)
     return dz, g_inv, None, None, None, None, None
 

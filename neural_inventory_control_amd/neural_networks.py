@@ -398,8 +398,9 @@ class VanillaWarehouse(MyNeuralNetwork):
         z = self.net["master"](x)
         if torch.compiler.is_compiling():   # the registered operator (library.py) while a compiler traces; same kernel
             from . import library  # noqa: F401  (registers the operators)
-            so, wo = torch.ops.nic.softmax_alloc(z, w_inv, self.adjacency(S, Wn, z.device), _scalar(self.warehouse_upper_bound),
-                                                 bool(self.transshipment), S, Wn)
+            ub = self.warehouse_upper_bound
+            ub = ub if torch.is_tensor(ub) else torch.tensor([float(ub)])
+            so, wo = torch.ops.nic.softmax_alloc(z, w_inv, self.adjacency(S, Wn, z.device), ub, bool(self.transshipment), S, Wn)
         else:
             so, wo = _WarehouseHead.apply(z, w_inv, self.adjacency(S, Wn, z.device), _scalar(self.warehouse_upper_bound),
                                           bool(self.transshipment), S, Wn)

@@ -93,6 +93,10 @@ class Trainer:
         # engine measures host enqueue time against GPU time on a shape's second training step and replays only if the step is
         # launch-bound; `trainer_params.use_rollout_graph` in main_run)
         self.use_rollout_graph = "auto"
+        # captured steps copy every batch tensor into the graph's static buffers before a replay; True = skip tensors presented
+        # again unchanged (same object, address and version counter) - for callers that never rewrite a batch tensor in place
+        # through a raw pointer (bench.py: one resident batch)
+        self.inputs_versioned = False
         self._engines = {}
         self._step_graphs = {}
         self._fused_grads_ready = False
@@ -484,9 +488,17 @@ class Trainer:
                 return self._graphed_generic_step(loss_function, simulator, model, periods, problem_params, data_batch,
                                                   observation_params, ignore_periods, global_batch=global_batch)
             st["prob"].copy_tables_from(incoming)
+        seen = st.setdefault("seen", {})
         for k, v in data_batch.items():
             if torch.is_tensor(v):
+                # (opt-in `inputs_versioned`, as on the fused engines: a tensor presented again with the same identity, address and
+                # version counter is not copied a second time - at 10^6 chains the demand trace alone is 419 MB per step; a tensor
+                # rewritten behind torch's back, without a version bump, would be missed, hence not the default)
+                tag = (id(v), v.data_ptr(), v._version)
+                if self.inputs_versioned and seen.get(k) == tag:
+                    continue
                 st["static"][k].copy_(v)
+                seen[k] = tag
         for p, g in zip(params, st["grads"]):  # (someone set `.grad` to None / another tensor since the capture)
             if p.grad is not g:
                 p.grad = g

@@ -28,10 +28,10 @@ def test_operators_are_registered_with_fake_kernels():
         s2, w2, e2, r = torch.ops.nic.env_step(store, None, None, a_store, None, None, dem, 0)
         assert s2.shape == store.shape and w2.numel() == 0 and e2.numel() == 0 and tuple(r.shape) == (ld,)
         so, wo = torch.ops.nic.softmax_alloc(torch.empty(100, 3 * 2 + 2), torch.empty(100, 2, 3), torch.empty(2, 3, dtype=torch.int32),
-                                             40.0, False, 3, 2)
+                                             torch.empty(1), False, 3, 2)
         assert tuple(so.shape) == (100, 3, 2) and so.stride() == (1, 2 * ld, ld) and tuple(wo.shape) == (100, 2, 1)
         dz, gi = torch.ops.nic.softmax_alloc_backward(so, wo, torch.empty(100, 8), torch.empty(100, 2, 3),
-                                                      torch.empty(2, 3, dtype=torch.int32), 40.0, False, 3, 2)
+                                                      torch.empty(2, 3, dtype=torch.int32), torch.empty(1), False, 3, 2)
         assert tuple(dz.shape) == (100, 8) and tuple(gi.shape) == (100, 2, 3)
         tot, rep, gl = torch.ops.nic.rollout_closed_form(torch.empty(2), torch.empty(9, 1, ld), torch.empty(1, 4, ld), 0, 1, 9, 0, 2, False)
         assert tot.dim() == 0 and rep.dim() == 0 and tuple(gl.shape) == (2,)
@@ -149,9 +149,10 @@ def test_opcheck_softmax_alloc_closed_form_and_sampler():
     z0, wh0 = torch.randn(B, S * Wn + Wn, device=DEV), torch.rand(B, Wn, Ww, device=DEV) * 30
     adj = torch.tensor([[1, 1, 0, 1, 1], [1, 0, 1, 1, 1]], dtype=torch.int32, device=DEV)
     z, wh = z0.clone().requires_grad_(), wh0.clone().requires_grad_()
-    torch.library.opcheck(torch.ops.nic.softmax_alloc, (z, wh, adj, 90.0, False, S, Wn), test_utils=tests)
+    ub = torch.tensor([90.0], device=DEV)
+    torch.library.opcheck(torch.ops.nic.softmax_alloc, (z, wh, adj, ub, False, S, Wn), test_utils=tests)
     res = []
-    for fn in (lambda a, b: torch.ops.nic.softmax_alloc(a, b, adj, 90.0, False, S, Wn),
+    for fn in (lambda a, b: torch.ops.nic.softmax_alloc(a, b, adj, ub, False, S, Wn),
                lambda a, b: _WarehouseHead.apply(a, b, adj, 90.0, False, S, Wn)):
         a, b = z0.clone().requires_grad_(), wh0.clone().requires_grad_()
         so, wo = fn(a, b)
