@@ -687,10 +687,17 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 {   // rows row0 + k, k < slots, of the state gradient: every load first, then the adds and stores
                     const Rows GS = rows_at(P.g_state + (int64_t)row0 * ldb + b0, ldb);
                     const int nrb = slots > 16 ? 2 : 1;
-                    f32x4 old[2];
+                    f32x4 old[2];   // (rows past the node's pipeline are NOT touched: the last node's would lie past the buffer)
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
-                        if (rb < nrb) old[rb] = get_d(GS, rb, g, n, live);
+                        if (rb < nrb) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const bool has = live && 16 * rb + 4 * g + i < slots;
+                                old[rb][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                 GS.r, has ? 4 * g * GS.row_bytes + 4 * n : kDeadLane, (16 * rb + i) * GS.row_bytes, 0));
+                            }
+                        }
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
                         if (rb < nrb) {
