@@ -86,24 +86,14 @@ __device__ __forceinline__ f32x4 get_t(const Rows& o, int cb, int m, int q) {
 }
 __device__ __forceinline__ void add_rows(float* p, int64_t row_stride, int row, float v) { p[(int64_t)row * row_stride] += v; }
 
-// tiles in the workgroup's scratch area (global memory), in the lanes' own order: one buffer descriptor per sub-block, the tile as a
-// SCALAR offset, the lane's 16 bytes as the only vector offset (64-bit per-lane addresses of six tile classes were hoisted out of
-// the item loops and spilled)
+// tiles in the workgroup's scratch area (global memory), in the lanes' own order
 struct Tile2 {
     f32x4 a, b;
 };
-struct Tiles {
-    __amdgpu_buffer_rsrc_t r;
-};
-__device__ __forceinline__ Tiles tiles_at(float* p) { return Tiles{__builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7fffffff, 0x00020000)}; }
-__device__ __forceinline__ Tile2 tile_load(const Tiles& T, int tile, int lane) {
-    return Tile2{__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(T.r, lane * 16, tile * 2048, 0)),
-                 __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(T.r, lane * 16, tile * 2048 + 1024, 0))};
-}
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void tile_store(const Tiles& T, int tile, int lane, f32x4 a, f32x4 b) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a), T.r, lane * 16, tile * 2048, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, b), T.r, lane * 16, tile * 2048 + 1024, 0);
+__device__ __forceinline__ Tile2 tile_load(const float* t, int lane) { return Tile2{lds4(t + lane * 4), lds4(t + 256 + lane * 4)}; }
+__device__ __forceinline__ void tile_store(float* t, int lane, f32x4 a, f32x4 b) {
+    *reinterpret_cast<f32x4*>(t + lane * 4) = a;
+    *reinterpret_cast<f32x4*>(t + 256 + lane * 4) = b;
 }
 
 // o += M x for a packed 32 x 32 matrix ([rb][q][lane][4] A fragments in LDS) and x in D layout
@@ -321,43 +311,33 @@ __device__ __forceinline__ void flush(float* red, Acc<KS>& A, const NicGnnPeriod
     column_reduce<4>(red, p, dst, ld, rows, wave, lane);
 }
 
-// Packs go to LDS by LDS-DMA (csrc/linear_mfma.hip: dma16): a wavefront moves 1 KB per instruction without touching registers, all
-// instructions of the stage are in flight together (a load -> store loop through registers was 12 us for the 80 KB of the five MLPs).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void dma16(u32x4 desc, int voff, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(desc), "s"(lds_addr)
-                 : "memory");
-}
-__device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n_floats, int wave, int lane) {
-    const uint64_t a = reinterpret_cast<uint64_t>(src);
-    u32x4 d;
-    d.x = (unsigned)a;
-    d.y = (unsigned)(a >> 32) & 0xffffu;
-    d.z = (unsigned)(n_floats * 4);
-    d.w = 0x00020000u;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)dst);   // LDS byte address
-    for (int kb = wave; kb * 256 < n_floats; kb += kWaves)
-        dma16(d, kb * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(base + (unsigned)kb * 1024u));
+// Packs go to LDS through registers, four 16-byte pieces in flight per thread (one piece per trip was 12 us for the 80 KB).
+__device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n_floats) {
+    const int step = blockDim.x * 4;
+    for (int i0 = threadIdx.x * 4; i0 < n_floats; i0 += 4 * step) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (i0 + u * step < n_floats ? i0 + u * step : i0));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * step < n_floats) *reinterpret_cast<f32x4*>(dst + i0 + u * step) = v[u];
+    }
 }
 __device__ __forceinline__ void copy_words(int* dst, const void* __restrict__ src, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = reinterpret_cast<const int*>(src)[i];
 }
 
 // sum of the tiles a CSR list names, in list order, four loads in flight
-__device__ __forceinline__ Tile2 list_sum(const Tiles& T, int first, const int* off, const int* items, int v, int lane, bool& any) {
+__device__ __forceinline__ Tile2 list_sum(const float* tiles, const int* off, const int* items, int v, int lane, bool& any) {
     const int lo = uni(off, v), hi = uni(off, v + 1);
     f32x4 s0 = zero4(), s1 = zero4();
     for (int p0 = lo; p0 < hi; p0 += 4) {
         f32x4 t0[4], t1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const Tile2 t = tile_load(T, first + uni(items, p0 + u < hi ? p0 + u : p0), lane);
-            t0[u] = t.a;
-            t1[u] = t.b;
+            const float* t = tiles + (int64_t)uni(items, p0 + u < hi ? p0 + u : p0) * kTile;
+            t0[u] = lds4(t + lane * 4);
+            t1[u] = lds4(t + 256 + lane * 4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -413,11 +393,11 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     float* scr = scr_all + wave * kScr;
     GNNB_STAMP(0);
-    copy_to_lds(w_in, P.mlp[0].wpk_t, sz_in, wave, lane);
-    copy_to_lds(w_ie, P.mlp[1].wpk_t, sz_ie, wave, lane);
-    copy_to_lds(w_nu, P.mlp[2].wpk_t, sz_nu, wave, lane);
-    copy_to_lds(w_eu, P.mlp[3].wpk_t, sz_eu, wave, lane);
-    copy_to_lds(w_out, P.mlp[4].wpk_t, sz_out, wave, lane);
+    copy_to_lds(w_in, P.mlp[0].wpk_t, sz_in);
+    copy_to_lds(w_ie, P.mlp[1].wpk_t, sz_ie);
+    copy_to_lds(w_nu, P.mlp[2].wpk_t, sz_nu);
+    copy_to_lds(w_eu, P.mlp[3].wpk_t, sz_eu);
+    copy_to_lds(w_out, P.mlp[4].wpk_t, sz_out);
     copy_words(const_cast<int*>(G.src), P.src, E);
     copy_words(const_cast<int*>(G.tgt), P.tgt, E);
     copy_words(const_cast<int*>(G.lead), P.lead, E);
@@ -430,7 +410,6 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
         copy_words(const_cast<int*>(G.off[k]), P.list_off[k], N + 1);
         copy_words(const_cast<int*>(G.items[k]), P.list_items[k], P.n_items[k]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the DMA is outside hipcc's bookkeeping)
     __syncthreads();
     GNNB_STAMP(1);
     const PackT WIN = packt_at(w_in, 32), WIE = packt_at(w_ie, 32), WNU = packt_at(w_nu, 32), WEU = packt_at(w_eu, 32),
@@ -445,12 +424,12 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
 
     for (int first = blockIdx.x * nsub; first < n_blocks; first += gridDim.x * nsub) {
         // per-item geometry: sub-block `sub` of this round
-        auto block_of = [&](int sub, int64_t& b0, bool& live, int64_t& hblk, Tiles& tiles) {
+        auto block_of = [&](int sub, int64_t& b0, bool& live, int64_t& hblk, float*& tiles) {
             const int bk = first + sub;
             b0 = (int64_t)bk * NB;
             live = bk < n_blocks && b0 + n < P.n_scenarios;
             hblk = (b0 >> 5) * 1024 + (b0 & 31);
-            tiles = tiles_at(T0 + (int64_t)sub * per_sub * kTile);
+            tiles = T0 + (int64_t)sub * per_sub * kTile;
         };
         const int subs = (n_blocks - first) < nsub ? (n_blocks - first) : nsub;   // sub-blocks that exist in this round
 
@@ -463,12 +442,11 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 const int sub = item / L, e = item - sub * L;
                 int64_t b0, hblk;
                 bool live;
-                Tiles tiles;
+                float* tiles;
                 block_of(sub, b0, live, hblk, tiles);
                 const bool lane0 = live && g == 0;
-                const Rows DO = rows_at(P.d_out + (int64_t)e * ldb + b0, 0), YO = rows_at(M.Y + (int64_t)e * ldb + b0, 0);
-                const float gy = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(DO.r, lane0 ? 4 * n : kDeadLane, 0, 0));
-                const float yo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(YO.r, lane0 ? 4 * n : kDeadLane, 0, 0));
+                const float gy = lane0 ? P.d_out[(int64_t)e * ldb + b0 + n] : 0.f;
+                const float yo = lane0 ? M.Y[(int64_t)e * ldb + b0 + n] : 0.f;
                 const float dz = gy * (1.f - expf(-yo));
                 const Rows H2 = rows_at(M.H2 + e * hent + hblk, 32), H1 = rows_at(M.H1 + e * hent + hblk, 32);
                 const Rows X = rows_at(P.edges1 + (int64_t)e * ldb + b0, P.edge_row_stride);
@@ -478,7 +456,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 wgrad32(a1, xt, A.w1[0]);
                 f32x4 d0 = zero4(), d1 = zero4();
                 tmul32(WOUT.l1, dz1[0], dz1[1], lane, d0, d1);
-                tile_store(tiles, oDE + e, lane, d0, d1);
+                tile_store(tiles + (int64_t)(oDE + e) * kTile, lane, d0, d1);
             }
             flush<1>(red, A, M, 32, 1, -1, wave, lane);
         }
@@ -493,9 +471,9 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 const int sub = item / L, e = item - sub * L;
                 int64_t b0, hblk;
                 bool live;
-                Tiles tiles;
+                float* tiles;
                 block_of(sub, b0, live, hblk, tiles);
-                const Tile2 dy = tile_load(tiles, oDE + e, lane);
+                const Tile2 dy = tile_load(tiles + (int64_t)(oDE + e) * kTile, lane);
                 const Rows Y = rows_at(M.Y + (int64_t)e * ldb + b0, M.row_stride);
                 const f32x4 y0 = get_d(Y, 0, g, n, live), y1 = get_d(Y, 1, g, n, live);
                 const Rows H2 = rows_at(M.H2 + e * hent + hblk, 32), H1 = rows_at(M.H1 + e * hent + hblk, 32);
@@ -505,10 +483,10 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 mlp_bwd_tile<false, 3>(WEU, scr, lane, live, live ? elu_grad4(dy.a, y0) : zero4(), live ? elu_grad4(dy.b, y1) : zero4(), H2,
                                        H1, AEU, dz1, a1);
                 wgrad32(a1, xt, AEU.w1[0]);
-                tile_store(tiles, oSE + e, lane, dz1[0], dz1[1]);
+                tile_store(tiles + (int64_t)(oSE + e) * kTile, lane, dz1[0], dz1[1]);
                 f32x4 d0 = dy.a, d1 = dy.b;
                 tmul32(WEU.l1, dz1[0], dz1[1], lane, d0, d1);
-                tile_store(tiles, oDE + e, lane, d0, d1);
+                tile_store(tiles + (int64_t)(oDE + e) * kTile, lane, d0, d1);
             }
         }
         __syncthreads();
@@ -520,7 +498,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 const int sub = item / N, v = item - sub * N;
                 int64_t b0, hblk;
                 bool live;
-                Tiles tiles;
+                float* tiles;
                 block_of(sub, b0, live, hblk, tiles);
                 const Rows X = rows_at(P.nodes1 + (int64_t)v * ldb + b0, P.node_row_stride);
                 f32x4 xt[2] = {get_t(X, 0, n, g), get_t(X, 1, n, g)};
@@ -528,7 +506,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
                     bool any;
-                    const Tile2 s = list_sum(tiles, oSE, G.off[side], G.items[side], v, lane, any);
+                    const Tile2 s = list_sum(tiles + (int64_t)oSE * kTile, G.off[side], G.items[side], v, lane, any);
                     if (any) {
                         tmul32(WEU.l1 + 1024 * (1 + side), s.a, s.b, lane, d0, d1);
                         f32x4 a[2];
@@ -536,7 +514,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                         wgrad32(a, xt, AEU.w1[1 + side]);
                     }
                 }
-                tile_store(tiles, oDN + v, lane, d0, d1);
+                tile_store(tiles + (int64_t)(oDN + v) * kTile, lane, d0, d1);
             }
             flush<3>(red, AEU, P.mlp[3], 96, 32, -1, wave, lane);
         }
@@ -551,9 +529,9 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 const int sub = item / N, v = item - sub * N;
                 int64_t b0, hblk;
                 bool live;
-                Tiles tiles;
+                float* tiles;
                 block_of(sub, b0, live, hblk, tiles);
-                const Tile2 dy = tile_load(tiles, oDN + v, lane);
+                const Tile2 dy = tile_load(tiles + (int64_t)(oDN + v) * kTile, lane);
                 const Rows Y = rows_at(M.Y + (int64_t)v * ldb + b0, M.row_stride);
                 const f32x4 y0 = get_d(Y, 0, g, n, live), y1 = get_d(Y, 1, g, n, live);
                 const Rows H2 = rows_at(M.H2 + v * hent + hblk, 32), H1 = rows_at(M.H1 + v * hent + hblk, 32);
@@ -571,16 +549,16 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 wgrad32(a1, xt2, A.w1[2]);
                 f32x4 d0 = dy.a, d1 = dy.b;
                 tmul32(WNU.l1, dz1[0], dz1[1], lane, d0, d1);
-                tile_store(tiles, oDN + v, lane, d0, d1);
+                tile_store(tiles + (int64_t)(oDN + v) * kTile, lane, d0, d1);
                 const float si = __int_as_float(uni(G.in_scale, v)), so = __int_as_float(uni(G.out_scale, v));
                 d0 = zero4();
                 d1 = zero4();
                 tmul32(WNU.l1 + 1024, dz1[0], dz1[1], lane, d0, d1);
-                tile_store(tiles, oXI + v, lane, d0 * si, d1 * si);
+                tile_store(tiles + (int64_t)(oXI + v) * kTile, lane, d0 * si, d1 * si);
                 d0 = zero4();
                 d1 = zero4();
                 tmul32(WNU.l1 + 2048, dz1[0], dz1[1], lane, d0, d1);
-                tile_store(tiles, oXO + v, lane, d0 * so, d1 * so);
+                tile_store(tiles + (int64_t)(oXO + v) * kTile, lane, d0 * so, d1 * so);
             }
             flush<3>(red, A, M, 96, 32, -1, wave, lane);
         }
@@ -595,14 +573,14 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 const int sub = item / E, e = item - sub * E;
                 int64_t b0, hblk;
                 bool live;
-                Tiles tiles;
+                float* tiles;
                 block_of(sub, b0, live, hblk, tiles);
                 const int s_ = uni(G.src, e), t_ = uni(G.tgt, e);
                 const float lead = __int_as_float(uni(G.lead, e));
                 // (every tile is loaded - a missing one from a valid dummy address - and dropped by a select)
-                const Tile2 de = tile_load(tiles, oDE + (e < L ? e : 0), lane);
-                const Tile2 xi = tile_load(tiles, oXI + (t_ >= 0 ? t_ : 0), lane);
-                const Tile2 xo = tile_load(tiles, oXO + (s_ >= 0 ? s_ : 0), lane);
+                const Tile2 de = tile_load(tiles + (int64_t)(oDE + (e < L ? e : 0)) * kTile, lane);
+                const Tile2 xi = tile_load(tiles + (int64_t)(oXI + (t_ >= 0 ? t_ : 0)) * kTile, lane);
+                const Tile2 xo = tile_load(tiles + (int64_t)(oXO + (s_ >= 0 ? s_ : 0)) * kTile, lane);
                 f32x4 dy0 = e < L ? de.a : zero4(), dy1 = e < L ? de.b : zero4();
                 if (t_ >= 0) {
                     dy0 += xi.a;
@@ -620,7 +598,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                                        AIE, dz1, a1);
                 AIE.lead[0] += lead * sum4(a1[0]);
                 AIE.lead[1] += lead * sum4(a1[1]);
-                tile_store(tiles, oSI + e, lane, dz1[0], dz1[1]);
+                tile_store(tiles + (int64_t)(oSI + e) * kTile, lane, dz1[0], dz1[1]);
             }
         }
         __syncthreads();
@@ -631,16 +609,16 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 const int sub = item / N, v = item - sub * N;
                 int64_t b0, hblk;
                 bool live;
-                Tiles tiles;
+                float* tiles;
                 block_of(sub, b0, live, hblk, tiles);
                 const Rows X = rows_at(P.nodes0 + (int64_t)v * ldb + b0, P.node_row_stride);
                 f32x4 xt[2] = {get_t(X, 0, n, g), get_t(X, 1, n, g)};
-                const Tile2 dn = tile_load(tiles, oDN + v, lane);
+                const Tile2 dn = tile_load(tiles + (int64_t)(oDN + v) * kTile, lane);
                 f32x4 d0 = dn.a, d1 = dn.b;
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
                     bool any;
-                    const Tile2 s = list_sum(tiles, oSI, G.off[2 + side], G.items[2 + side], v, lane, any);
+                    const Tile2 s = list_sum(tiles + (int64_t)oSI * kTile, G.off[2 + side], G.items[2 + side], v, lane, any);
                     if (any) {
                         tmul32(WIE.l1 + 1024 * side, s.a, s.b, lane, d0, d1);
                         f32x4 a[2];
@@ -648,7 +626,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                         wgrad32(a, xt, AIE.w1[side]);
                     }
                 }
-                tile_store(tiles, oDN + v, lane, d0, d1);
+                tile_store(tiles + (int64_t)(oDN + v) * kTile, lane, d0, d1);
             }
             flush<2>(red, AIE, P.mlp[1], 65, 32, 64, wave, lane);
         }
@@ -663,9 +641,9 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 const int sub = item / N, v = item - sub * N;
                 int64_t b0, hblk;
                 bool live;
-                Tiles tiles;
+                float* tiles;
                 block_of(sub, b0, live, hblk, tiles);
-                const Tile2 dy = tile_load(tiles, oDN + v, lane);
+                const Tile2 dy = tile_load(tiles + (int64_t)(oDN + v) * kTile, lane);
                 const Rows Y = rows_at(M.Y + (int64_t)v * ldb + b0, M.row_stride);
                 const f32x4 y0 = get_d(Y, 0, g, n, live), y1 = get_d(Y, 1, g, n, live);
                 const Rows H2 = rows_at(M.H2 + v * hent + hblk, 32), H1 = rows_at(M.H1 + v * hent + hblk, 32);
@@ -684,32 +662,13 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
                 f32x4 d0 = zero4(), d1 = zero4();
                 tmul32(WIN.l1, dz1[0], dz1[1], lane, d0, d1);
                 const int row0 = uni(G.row0, v), slots = uni(G.slots, v);
-                {   // rows row0 + k, k < slots, of the state gradient: every load first, then the adds and stores
-                    const Rows GS = rows_at(P.g_state + (int64_t)row0 * ldb + b0, ldb);
-                    const int nrb = slots > 16 ? 2 : 1;
-                    f32x4 old[2];   // (rows past the node's pipeline are NOT touched: the last node's would lie past the buffer)
+                if (live) {
+                    float* gs = P.g_state + b0 + n;
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-                        if (rb < nrb) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const bool has = live && 16 * rb + 4 * g + i < slots;
-                                old[rb][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                 GS.r, has ? 4 * g * GS.row_bytes + 4 * n : kDeadLane, (16 * rb + i) * GS.row_bytes, 0));
-                            }
-                        }
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-                        if (rb < nrb) {
-                            const f32x4 dv = rb ? d1 : d0;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int k = 16 * rb + 4 * g + i;
-                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old[rb][i] + dv[i]), GS.r,
-                                                                      (live && k < slots) ? 4 * g * GS.row_bytes + 4 * n : kDeadLane,
-                                                                      (16 * rb + i) * GS.row_bytes, 0);
-                            }
-                        }
+                    for (int i = 0; i < 4; ++i) {
+                        if (4 * g + i < slots) add_rows(gs, ldb, row0 + 4 * g + i, d0[i]);
+                        if (16 + 4 * g + i < slots) add_rows(gs, ldb, row0 + 16 + 4 * g + i, d1[i]);
+                    }
                 }
             }
             flush<1>(red, A, M, P.Dn, 32, -1, wave, lane);

@@ -57,11 +57,10 @@ def _grads(eng, model, data, T, obs, scale):
 def test_whole_horizon_route_at_full_size(workload, n, T):
     """cfg2 (32,768 one-store scenarios) and cfg4 (16,384 per GPU and the whole 131,072-scenario job on one GPU): the
     whole-horizon kernels, one wavefront per 32 scenarios."""
-    # the demand trace is drawn at the BENCHMARK horizon (T = 100): at 131,072 scenarios that is the four-periods-per-lane form
-    # of the sampler (>= 4 M (scenario, period) pairs), otherwise the one-period form; the rollout uses the first T periods
+    # the demand trace is drawn at the BENCHMARK horizon (T = 100) by the one-store form of the sampler (round 6: four scenarios x
+    # four periods per lane, every word of a Philox block used); the rollout uses the first T periods
     setting, sc, data, model, eng, obs = _case(workload, n, T, T_demand=100)
-    assert _lib.lib().nic_last_kernel() == (b"sample_equicorrelated_kernel<4>" if n * 100 >= (4 << 20) else
-                                             b"sample_equicorrelated_kernel<1>")
+    assert _lib.lib().nic_last_kernel() == b"sample_one_store_kernel"
     S = setting["problem_params"]["n_stores"]
     scale = 1.0 / (n * T * S)
     from neural_inventory_control_amd.rollout import KernelTimer
