@@ -82,6 +82,14 @@ def _emit(out):
     f.flush()
 
 
+def _lib_id():
+    try:
+        from neural_inventory_control_amd import _lib
+        return (_lib.lib().nic_build_id() or b"").decode()
+    except Exception:
+        return None
+
+
 def build_case(workload, device, rank, world, scenarios=None, periods=None, generic_route=False):
     from collections import defaultdict
     from neural_inventory_control_amd import workloads
@@ -194,7 +202,7 @@ def _full_batch_record(workload):
     return None
 
 
-def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None, setting_policy=None):
+def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None, setting_policy=None, strict_reps=False):
     """The oracle (CPU restatement of the reference path, PyTorch eager) timed on this host's cores: training steps
     (rollout + backward) of the same workload on a bounded sample of scenarios; 1 warm-up + `reps` timed repetitions,
     median."""
@@ -238,7 +246,9 @@ def cpu_baseline(workload, sample_scenarios, periods, reps=3, model=None, settin
         t0 = time.perf_counter()
         orc.train_step_gradients(pol, periods, setting["problem_params"], data, obs)
         times.append(time.perf_counter() - t0)
-        if sum(times) > 45.0:  # keep the default run within minutes on a slow host
+        if strict_reps and len(times) >= reps:   # (the one-off full-batch record: exactly `reps` repetitions, however long)
+            break
+        if not strict_reps and sum(times) > 45.0:  # keep the default run within minutes on a slow host
             break
     dt = statistics.median(times)
     full = _full_batch_record(workload)
@@ -866,6 +876,9 @@ def main():
                              + ("" if (world > 1 and args.scaling == "strong") else " unless run with --scaling strong") +
                              ", is WEAK scaling: the workload's scenario count PER GPU"),
             "data": "synthetic", "collective": collective,
+            # what the numbers were measured on: the content hash of the HIP sources + flags + headers the library was built from
+            # (nic_build_id(); `python -c "from neural_inventory_control_amd import build; print(build.source_id())"` at a commit)
+            "library_id": (_lib_id() or None),
             "config": {"workload": desc + ("; evaluation pass = forward rollout only" + (", discrete allocation" if discrete else "")
                                            if args.eval else
                                            "; training step = rollout fwd + bwd + Adam" + (" + RCCL grad all-reduce" if sharded else "")),

@@ -183,9 +183,9 @@ def main():
             # the same step without a process group, for comparison with the rounds that had none
             run(["python3", "bench.py", "--workload", w, "--no-dist-init", "--no-cpu-baseline"] + steps,
                 os.path.join(out, f"{rnd}_bench_{w}_no_collective.json"))
-        if w in ("base_stock", "echelon_stock"):   # launch-bound steps: also replayed from one HIP graph
-            run(["python3", "bench.py", "--workload", w, "--graph", "--no-cpu-baseline"] + steps,
-                os.path.join(out, f"{rnd}_bench_{w}_graph.json"))
+        if w in ("base_stock", "base_stock_1m", "echelon_stock"):   # replayed by default since round 6: the eager step beside it
+            run(["python3", "bench.py", "--workload", w, "--no-graph", "--no-cpu-baseline"] + steps,
+                os.path.join(out, f"{rnd}_bench_{w}_eager.json"))
         print(w, open(os.path.join(out, f"{rnd}_bench_{w}.json")).read()[:300], flush=True)
     if "cfg3" in workloads:   # counter traffic of the headline workload rides along (bench.py reads it from profiles/ next time)
         traffic_pass(rnd, "cfg3", out)

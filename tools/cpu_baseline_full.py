@@ -30,7 +30,7 @@ def meminfo():
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".json") else os.path.join(ROOT, "gpurun_out", "r05_cpu_baseline_full.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".json") else os.path.join(ROOT, "gpurun_out", "r06_cpu_baseline_full.json")
     names = [a for a in sys.argv[1:] if not a.endswith(".json")] or ["cfg3", "cfg5"]
     mi = meminfo()
     cap = int(0.7 * mi["MemTotal"])
@@ -46,7 +46,7 @@ def main():
             sample //= 2
         t0 = time.time()
         try:
-            rec = bench.cpu_baseline(w, sample, T, reps=2)
+            rec = bench.cpu_baseline(w, sample, T, reps=3, strict_reps=True)   # 1 warm-up + >= 3 timed repetitions, median
             rec.update(full_batch=n, scenarios=sample, periods=T, is_full_batch=sample == n, wall_s=round(time.time() - t0, 1))
         except MemoryError as e:
             rec = {"value": None, "error": f"MemoryError at {sample} scenarios: {e}", "full_batch": n, "scenarios": sample, "periods": T}
