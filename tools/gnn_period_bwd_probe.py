@@ -13,8 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch  # noqa: E402
 
-STAGES = ["weights + tables staged", "A output MLP (+ flush)", "B edge update", "C1 node sums of dz1 (+ edge-update flush)",
-          "C2 node update (+ flush)", "D initial edge", "E1 node sums of dz1 (+ initial-edge flush)", "E2 initial node (+ flush)"]
+STAGES = ["weights + tables staged", "A output MLP (+ flush)", "B edge update (+ flush)", "C1 node sums of dz1 (+ flush of the endpoint columns)",
+          "C2 node update (+ flush)", "D initial edge (+ flush)", "E1 node sums of dz1, aggregation columns of the node update (+ flushes)",
+          "E2 initial node (+ flush)"]
 
 
 def main():
@@ -33,7 +34,7 @@ def main():
     setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, dev, 0, 1, args.scenarios, args.periods, False)
     eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
     lib.nic_tuning_set_gnn_bwd_stamps.argtypes = [C.c_void_p]
-    stamps = torch.zeros(8 * 16, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(16 * 16, dtype=torch.int64, device=dev)
     res = {"workload": args.workload, "scenarios": n, "periods": T}
     grads = {}
     for period in (True, False):
@@ -55,9 +56,12 @@ def main():
         res[name + "_n_sub"] = getattr(eng, "_n_sub", None) if period else None
         eng.timer = None
     res["worst_relative_gradient_difference"] = max(float((a - b).norm() / (b.norm() + 1e-30)) for a, b in zip(grads[True], grads[False]))
-    st = stamps.cpu().view(8, 16)
+    st = stamps.cpu().view(16, 16)
+    st = st[st[:, 1] != 0]   # the wavefronts the launch had
     t0 = int(st[:, 0].min())
-    res["stamps_us_wave_by_point"] = [[round((int(st[w, p]) - t0) / 100.0, 2) if int(st[w, p]) else None for p in range(9)] for w in range(8)]
+    res["wavefronts"] = int(st.shape[0])
+    res["stamps_us_wave_by_point"] = [[round((int(st[w, p]) - t0) / 100.0, 2) if int(st[w, p]) else None for p in range(9)]
+                                      for w in range(st.shape[0])]
     res["stage_us_slowest_wave"] = {STAGES[p - 1]: round((int(st[:, p].max()) - int(st[:, p - 1].max())) / 100.0, 2)
                                     for p in range(1, 9) if int(st[:, p].max())}
     res["workgroup_us"] = round((int(st[:, 8].max()) - t0) / 100.0, 2)

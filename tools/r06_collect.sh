@@ -1,0 +1,28 @@
+#!/bin/bash
+# round 6 evidence: every workload's bench line + rocprofv3 kernel summary, HBM counter traffic of the headline and the GNN workloads,
+# in-kernel stamps and SQ counters of the GNN backward kernel, the long-horizon evaluations, the scaling prediction from 1-GPU shard
+# steps and the full-batch CPU baseline (>= 3 repetitions).  Everything lands in gpurun_out/r06/ and is copied to profiles/.
+export TMPDIR=/tmp
+O=gpurun_out/r06
+mkdir -p $O
+python -c "from neural_inventory_control_amd import _lib, build; print('library id', _lib.lib().nic_build_id().decode(), '= source id', build.source_id())" > $O/r06_collection_manifest.txt 2>&1
+date -u >> $O/r06_collection_manifest.txt
+timeout 3600 python tools/collect_profiles.py r06 > $O/collect.log 2>&1
+echo "collect rc $?"
+timeout 900 python tools/collect_profiles.py r06 traffic:gnn traffic:gnn_many_warehouses > $O/collect_traffic.log 2>&1
+echo "traffic rc $?"
+for w in gnn gnn_many_warehouses; do
+  timeout 300 python tools/gnn_period_bwd_probe.py --workload $w --periods 6 --out $O/r06_gnn_period_bwd_stamps_$w.json > $O/probe_final_$w.log 2>&1
+  echo "probe $w rc $?"
+done
+timeout 600 python tools/gnn_period_pmc.py $O/r06_gnn_period_pmc.json > $O/pmc.log 2>&1
+echo "pmc rc $?"
+for w in cfg1 cfg2 cfg4 gnn; do
+  timeout 900 python bench.py --workload $w --eval --periods 5000 --steps 3 --warmup 1 --no-cpu-baseline > $O/r06_bench_${w}_eval_T5000.json 2> $O/eval_$w.err
+  echo "eval $w rc $?"; python tools/show_bench.py $O/r06_bench_${w}_eval_T5000.json | head -3
+done
+timeout 900 python tools/scaling_prediction.py --out $O/r06_scaling_prediction.json --steps 10 > $O/scaling.log 2>&1
+echo "scaling rc $?"
+timeout 1800 python tools/cpu_baseline_full.py $O/r06_cpu_baseline_full.json cfg3 cfg5 > $O/cpu_full.log 2>&1
+echo "cpu full rc $?"; tail -2 $O/cpu_full.log | cut -c1-300
+ls $O | wc -l
