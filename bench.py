@@ -738,6 +738,13 @@ def main():
     closed_form_replay = closed_form and not args.no_graph and not args.eval and not args.launch_order_out
     if closed_form_replay:
         args.graph = True
+    # GNN: what `Trainer` sets on its engines ("auto": the second training run measures host enqueue time against GPU time and later
+    # runs are replayed from HIP graphs if the host is the slower one - with three launches per period that depends on the HOST:
+    # 22 ms steps on a quiet box, 35+ ms with eager launches when its cores are busy).  Eager launches: --no-graph.  The per-kernel
+    # timer needs eager launches, so the kernels are timed in one extra step behind the timed region.
+    gnn_auto = gnn and not args.graph and not args.no_graph and not args.eval and not args.launch_order_out
+    if gnn_auto:
+        eng.use_graph = "auto"
     if args.graph and eng is not None and not closed_form:
         eng.use_graph = True
         args.no_kernel_timing = True
@@ -820,7 +827,7 @@ def main():
     timer = None
     if args.launch_order_out and eng is not None:
         timer = eng.timer = KernelTimer(record_order=True)
-    elif closed_form_replay:
+    elif closed_form_replay or gnn_auto:
         pass   # (timed behind the region, below)
     elif not args.no_kernel_timing:
         whole = closed_form or (not gnn and (eng.small is not None or getattr(eng, "horizon", None) is not None))
@@ -850,6 +857,12 @@ def main():
         timer_steps = 3
         for _ in range(timer_steps):
             eng.run(data, T, 0, train=True, observation_params=setting["observation_params"], demand_soa=sc.demands_soa)
+        torch.cuda.synchronize()
+        eng.timer = None
+    if gnn_auto and not getattr(args, "no_kernel_timing_flag", False):
+        timer = eng.timer = KernelTimer(stride=1)   # (with a timer attached the engine launches eagerly)
+        timer_steps = 1
+        eng.run(data, T, 0, train=True, observation_params=setting["observation_params"], demand_soa=sc.demands_soa, grad_scale=grad_scale)
         torch.cuda.synchronize()
         eng.timer = None
     loss = float(last) / (global_b * T * S)
@@ -896,6 +909,8 @@ def main():
                                  if getattr(eng, "horizon", None) is not None else "per-period kernels"),
                        "mean_cost_per_store_period": loss},
         }
+        if gnn and getattr(eng, "auto_graph_probe", None):   # host enqueue time against GPU time of the second step, and the decision
+            out["config"]["launch_mode"] = dict(eng.auto_graph_probe, note="replay = later steps replayed from HIP graphs (`use_graph = 'auto'`)")
         if not args.eval:
             out["config"]["optimizer"] = "torch.optim.Adam(lr=3e-4" + (", fused=True)" if fused_adam else ")")
         if timer is not None and timer.order is not None:

@@ -151,7 +151,7 @@ class _Mlp:
         self.packed = z(32 * K + 32 + 32 * 32 + 32 + n_out * 32 + n_out)
         if dense:   # every column is a scenario: the forward writes all of what the backward reads - no 10-GB zero fill at set-up
             z = lambda *s: torch.empty(*s, device=device)  # noqa: E731
-        self.Y = z(T, n_out, n_ent, ld)
+        self.Y = z(T if train else 1, n_out, n_ent, ld)   # (evaluation: one period's worth, reused - nothing reads an earlier one)
         self.P, self.G = P, (T + P - 1) // P
         self.hist_stride = 0
         self.native = False
@@ -310,7 +310,9 @@ class GnnRollout:
         self.states = z(T + 1, f_tot, ld)
         self.orders = z(T, S * Wn + Wn, ld)   # store orders [S][Wn] (columns a store has no edge for stay 0), warehouse orders [Wn]
         self.rewards = z(T, ld)
-        self.feat = z(T, self.Dn, N, ld)
+        Tp = T if train else 1   # periods of the policy's intermediate buffers kept: all for the backward sweep, one for an evaluation
+        self._Tp = Tp           # (at the reference's test horizon, T = 5,000, the per-period copies were 83 GB for the outputs alone)
+        self.feat = z(Tp, self.Dn, N, ld)
         # state row -> feature row (slot k of store s -> row k of node Wn + s, slot k of warehouse w -> row k of node w): the
         # pipeline part of the node features is ONE index_copy_ per period
         rows = [k * N + Wn + s_ for s_ in range(S) for k in range(prob.Ws)] + [k * N + w for w in range(Wn) for k in range(prob.Ww)]
@@ -377,8 +379,8 @@ class GnnRollout:
                 raise ValueError("use_period_bwd: the backward mode keeps row-layout histories / stored inputs, or more than 32 "
                                  "node feature rows")
         zb = (lambda *s_: torch.empty(*s_, device=dev)) if dense else z   # (written in full by the period kernel before any read)
-        self.agg = zb(T, 32, 2 * N, ld)   # message aggregation: [:, :N] over incoming edges, [:, N:] over outgoing edges
-        self.nodes1, self.edges1 = zb(T, 32, N, ld), zb(T, 32, E, ld)
+        self.agg = zb(Tp, 32, 2 * N, ld)   # message aggregation: [:, :N] over incoming edges, [:, N:] over outgoing edges
+        self.nodes1, self.edges1 = zb(Tp, 32, N, ld), zb(Tp, 32, E, ld)
         self.sums, self.ratio, self.scale = z(T, Wn, ld), z(T, Wn, ld), z(T, Wn, ld)
         if train:
             self.g_state = [z(f_tot, ld), z(f_tot, ld)]
@@ -547,6 +549,7 @@ class GnnRollout:
     def _segments(self, t):
         """Input segments of the five MLPs at period t (the graph's gathers; no concatenation is materialised)."""
         P, M = self.plan, self.mlp
+        t = t % self._Tp
         nodes0, edges0 = M["initial_node"].Y[t], M["initial_edge"].Y[t]
         return {
             "initial_node": [Mlp3Segment(self.feat[t])],
@@ -563,7 +566,7 @@ class GnnRollout:
         # rows the launch moves beyond [inputs | hidden activations | output]: the sum it also writes (the residual it adds is one
         # of its input segments in both uses here, i.e. already counted)
         m.fold_rows = m.n_out if Ysum is not None else 0
-        self._k("mlp3_fwd_" + name, ops.mlp3_fwd, self._desc(m, segs[name], prob), m.Y[t], *hist, residual, Ysum)
+        self._k("mlp3_fwd_" + name, ops.mlp3_fwd, self._desc(m, segs[name], prob), m.Y[t % self._Tp], *hist, residual, Ysum)
 
     def _period_desc(self, t, prob, demand_soa, shift):
         """`NicGnnPeriod` of period t (cached: every buffer it names is engine-owned and fixed for a shape)."""
@@ -579,16 +582,17 @@ class GnnRollout:
         d.src, d.tgt, d.agg_off, d.agg_items, d.agg_scale = p(P.src), p(P.tgt), p(P.agg_off), p(P.agg_items), p(P.agg_scale)
         d.lead, d.node_row0, d.node_slots = p(P.lead), p(self.node_row0), p(self.node_slots)
         d.n_agg_items = int(P.n_agg_items)
-        d.state, d.feat = p(self.states[t]), p(self.feat[t])
-        d.agg = p(self.agg[t]) if train else None
+        tp = t % self._Tp
+        d.state, d.feat = p(self.states[t]), p(self.feat[tp])
+        d.agg = p(self.agg[tp]) if train else None
         for i, name in enumerate(MODULES):
             m, q = self.mlp[name], d.mlp[i]
             q.wpk, q.row_stride = p(self.ppack[name].buf), m.n_ent * ld
-            q.Y = p(m.Y[t]) if (train or name == "output") else None
+            q.Y = p(m.Y[tp]) if (train or name == "output") else None
             if train and m.mode == "hist":
                 q.H1, q.H2 = p(m.hist(m.H1, t)), p(m.hist(m.H2, t))
         if train:
-            d.mlp[2].Ysum, d.mlp[3].Ysum = p(self.nodes1[t]), p(self.edges1[t])
+            d.mlp[2].Ysum, d.mlp[3].Ysum = p(self.nodes1[tp]), p(self.edges1[tp])
         d.fuse_env = int(P.Wn == 1 and bool(self.fuse_alloc_env))
         if d.fuse_env:
             st, nxt, orders = self._views(self.states[t], prob), self._views(self.states[t + 1], prob), self.orders[t]
@@ -612,20 +616,21 @@ class GnnRollout:
                 self._alloc_env_fwd(t, prob, demand_soa, shift, st)
             return
         # node features: pipelines, padded to the longest one (:846-905)
-        self.feat[t].view(-1, ld).index_copy_(0, self.feat_rows, self.states[t])
+        tp = t % self._Tp
+        self.feat[tp].view(-1, ld).index_copy_(0, self.feat_rows, self.states[t])
         segs = self._segments(t)
         self._run_mlp("initial_node", t, segs, prob)
         self._run_mlp("initial_edge", t, segs, prob)
-        edges0 = M["initial_edge"].Y[t]
-        ops.segment_sum(self.agg[t], edges0, P.agg_off, P.agg_items, P.agg_scale)
-        self._run_mlp("node_update", t, segs, prob, M["initial_node"].Y[t], self.nodes1[t])   # nodes1 = nodes0 + update
-        self._run_mlp("edge_update", t, segs, prob, edges0, self.edges1[t])                   # edges1 = edges0 + update
+        edges0 = M["initial_edge"].Y[tp]
+        ops.segment_sum(self.agg[tp], edges0, P.agg_off, P.agg_items, P.agg_scale)
+        self._run_mlp("node_update", t, segs, prob, M["initial_node"].Y[tp], self.nodes1[tp])   # nodes1 = nodes0 + update
+        self._run_mlp("edge_update", t, segs, prob, edges0, self.edges1[tp])                    # edges1 = edges0 + update
         self._run_mlp("output", t, segs, prob)
         self._alloc_env_fwd(t, prob, demand_soa, shift, st)
 
     def _alloc_env_fwd(self, t, prob, demand_soa, shift, st):
         P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
-        out = M["output"].Y[t][0]                                  # [E][ld] desired quantity per edge
+        out = M["output"].Y[t % self._Tp][0]                       # [E][ld] desired quantity per edge
         # proportional allocation of the warehouse's on-hand stock over its outgoing edges + self loop (:111-138, :1435-1492)
         orders = self.orders[t]
         if P.Wn == 1 and self.fuse_alloc_env:   # allocation head + env step in one launch (round 4, csrc/gnn_alloc_env.hip)
