@@ -432,6 +432,10 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
             tiles = T0 + (int64_t)sub * per_sub * kTile;
         };
         const int subs = (n_blocks - first) < nsub ? (n_blocks - first) : nsub;   // sub-blocks that exist in this round
+        // Items are dealt entity-major, sub-block-minor: neighbouring wavefronts work on the SAME entity's two 16-scenario halves at
+        // the same time, so both halves of every 128-byte line of the histories are asked for together (sub-block-major - all of
+        // sub-block 0, then all of sub-block 1 - fetched every line twice: rocprofv3 counted 1.33 GB of HBM traffic per launch for
+        // 0.44 GB of histories; profiles/r06_traffic_gnn.json)
 
         // ---- A: output MLP (live edges): dz3 = d_out * softplus'(z) = d_out * (1 - exp(-y)) ------------------------------------------
         {
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
             A.clear();
             const NicGnnPeriodBwdMlp& M = P.mlp[4];
             for (int item = wave; item < subs * L; item += kWaves) {
-                const int sub = item / L, e = item - sub * L;
+                const int e = item / subs, sub = item - e * subs;   // (the sub-blocks of an entity side by side)
                 int64_t b0, hblk;
                 bool live;
                 float* tiles;
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
         {
             const NicGnnPeriodBwdMlp& M = P.mlp[3];
             for (int item = wave; item < subs * L; item += kWaves) {
-                const int sub = item / L, e = item - sub * L;
+                const int e = item / subs, sub = item - e * subs;   // (the sub-blocks of an entity side by side)
                 int64_t b0, hblk;
                 bool live;
                 float* tiles;
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
         // update's dW1 columns of the endpoint segments (sum_e dz1[e] nodes1[src e]^T = sum_v (sum_{e: src = v} dz1[e]) nodes1[v]^T)
         {
             for (int item = wave; item < subs * N; item += kWaves) {
-                const int sub = item / N, v = item - sub * N;
+                const int v = item / subs, sub = item - v * subs;   // (the sub-blocks of an entity side by side)
                 int64_t b0, hblk;
                 bool live;
                 float* tiles;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
             A.clear();
             const NicGnnPeriodBwdMlp& M = P.mlp[2];
             for (int item = wave; item < subs * N; item += kWaves) {
-                const int sub = item / N, v = item - sub * N;
+                const int v = item / subs, sub = item - v * subs;   // (the sub-blocks of an entity side by side)
                 int64_t b0, hblk;
                 bool live;
                 float* tiles;
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
         {
             const NicGnnPeriodBwdMlp& M = P.mlp[1];
             for (int item = wave; item < subs * E; item += kWaves) {
-                const int sub = item / E, e = item - sub * E;
+                const int e = item / subs, sub = item - e * subs;   // (the sub-blocks of an entity side by side)
                 int64_t b0, hblk;
                 bool live;
                 float* tiles;
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
         // ---- E1: nodes: d nodes0[v] = DN[v] + W1_src^T sum dz1[e: src = v] + W1_tgt^T sum dz1[e: tgt = v] (all edges) -----------------
         {
             for (int item = wave; item < subs * N; item += kWaves) {
-                const int sub = item / N, v = item - sub * N;
+                const int v = item / subs, sub = item - v * subs;   // (the sub-blocks of an entity side by side)
                 int64_t b0, hblk;
                 bool live;
                 float* tiles;
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
             A.clear();
             const NicGnnPeriodBwdMlp& M = P.mlp[0];
             for (int item = wave; item < subs * N; item += kWaves) {
-                const int sub = item / N, v = item - sub * N;
+                const int v = item / subs, sub = item - v * subs;   // (the sub-blocks of an entity side by side)
                 int64_t b0, hblk;
                 bool live;
                 float* tiles;
