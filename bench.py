@@ -135,6 +135,9 @@ def build_case(workload, device, rank, world, scenarios=None, periods=None, gene
     return setting, policy, sc, data, model, eng, n, T, desc
 
 
+_TRAFFIC_WORKLOAD = None   # set by main(): counter passes of another workload's launches of the same kernel do not apply
+
+
 def _pmc_traffic(kernel_name, n_scenarios, label=None):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*traffic*.json): FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc passes and corrected as the files' notes say.  None if no pass has this kernel
@@ -146,6 +149,8 @@ def _pmc_traffic(kernel_name, n_scenarios, label=None):
         try:
             doc = json.load(open(f))
             if not isinstance(doc, dict) or doc.get("n_scenarios") != n_scenarios:
+                continue
+            if _TRAFFIC_WORKLOAD and doc.get("workload") and doc["workload"] != _TRAFFIC_WORKLOAD:
                 continue
             for e in doc.get("kernels", []):
                 if squash(e["kernel"]) == squash(kernel_name) and e.get("label", label) == label:
@@ -694,6 +699,8 @@ def main():
             print(f"bench.py: --scaling strong needs a scenario count ({total}) divisible by --gpus ({world})", file=sys.stderr)
             sys.exit(2)
         per_gpu = total // world
+    global _TRAFFIC_WORKLOAD
+    _TRAFFIC_WORKLOAD = args.workload
     setting, policy, sc, data, model, eng, n, T, desc = build_case(args.workload, device, rank, world, per_gpu,
                                                                    args.periods, args.generic_route)
     pp = setting["problem_params"]
