@@ -664,10 +664,27 @@ typedef struct NicGnnPeriodBwd {
     const float* agg;             /* [32][2 n_nodes][ldb] */
     int64_t node_row_stride;      /* elements between rows of feat / nodes0 / nodes1 (agg: twice that) */
     int64_t edge_row_stride;      /* ... of edges0 / edges1 */
-    const float* d_out;           /* [n_edges][ldb] */
+    float* d_out;                 /* [n_edges][ldb]: read; written first when fuse_env */
     float* g_state;               /* [rows][ldb], pipeline rows of d features are ADDED */
     float* scratch;
     NicGnnPeriodBwdMlp mlp[5];
+    /* fuse_env = 1 (one supplying warehouse): the env-step adjoint + allocation adjoint run in FRONT of the MLP adjoints on this
+     * launch's first wavefronts - what nic_gnn_alloc_env_bwd does, same bodies, same arguments - so that d_out and the env part of
+     * g_state need no launch of their own: io as for nic_gnn_alloc_env_bwd (its order tables = the rows of the orders the forward
+     * wrote), g_store_out / g_wh_out = the state gradient of the NEXT period, g_store_in / g_wh_in = the store / warehouse rows of
+     * g_state, g_orders [S + 1][ldb] scratch, sums / ratio / scale as the forward left them, the desired quantities = mlp[4].Y */
+    int32_t fuse_env;
+    int32_t e_self, e_supplier, cap_at_one;
+    NicEnvStepIO io;
+    const float* sums;
+    const float* ratio;
+    const float* scale;
+    const float* g_store_out;
+    const float* g_wh_out;
+    NicTable2 g_reward;
+    float* g_store_in;
+    float* g_wh_in;
+    float* g_orders;
 } NicGnnPeriodBwd;
 /* pack size: (n_out == 1 ? 512 : 1024) + 1024 (1 + segments) floats; workgroups per launch: at most nic_mlp3_bwd_hist_slots(), the
  * slot count of the slabs both backwards share */

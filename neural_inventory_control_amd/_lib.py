@@ -133,7 +133,12 @@ class NicGnnPeriodBwd(C.Structure):
                 + [(n, C.c_void_p) for n in ("feat", "nodes0", "nodes1", "edges0", "edges1", "agg")]
                 + [("node_row_stride", C.c_int64), ("edge_row_stride", C.c_int64)]
                 + [(n, C.c_void_p) for n in ("d_out", "g_state", "scratch")]
-                + [("mlp", NicGnnPeriodBwdMlp * 5)])
+                + [("mlp", NicGnnPeriodBwdMlp * 5)]
+                + [(n, C.c_int32) for n in ("fuse_env", "e_self", "e_supplier", "cap_at_one")]
+                + [("io", NicEnvStepIO)]
+                + [(n, C.c_void_p) for n in ("sums", "ratio", "scale", "g_store_out", "g_wh_out")]
+                + [("g_reward", NicTable2)]
+                + [(n, C.c_void_p) for n in ("g_store_in", "g_wh_in", "g_orders")])
 
 
 NIC_MLP3_MAX_K, NIC_MLP3_ACT_NONE, NIC_MLP3_ACT_ELU, NIC_MLP3_ACT_SOFTPLUS = 96, 0, 1, 2

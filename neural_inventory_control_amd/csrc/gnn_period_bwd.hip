@@ -25,6 +25,8 @@
 //   E1 nodes        DN[v] += W1_src^T sum SIE[e: src = v] + W1_tgt^T sum SIE[e: tgt = v];  initial edge's dW1 likewise
 //   E2 nodes        initial node backward; the pipeline rows of its input gradient are added to the state gradient
 // FP32 throughout.  Summation orders differ from the per-MLP launches' (which differ from autograd's): agreement to rounding.
+#include "env_step_body.h"
+#include "gnn_alloc_body.h"
 #include "nic_common.h"
 #include "small_rollout_body.h"
 
@@ -312,9 +314,9 @@ __device__ __forceinline__ void flush(float* red, Acc<KS>& A, const NicGnnPeriod
 }
 
 // Packs go to LDS through registers, four 16-byte pieces in flight per thread (one piece per trip was 12 us for the 80 KB).
-__device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n_floats) {
-    const int step = blockDim.x * 4;
-    for (int i0 = threadIdx.x * 4; i0 < n_floats; i0 += 4 * step) {
+__device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n_floats, int tid, int n_threads) {
+    const int step = n_threads * 4;
+    for (int i0 = tid * 4; i0 < n_floats; i0 += 4 * step) {
         f32x4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (i0 + u * step < n_floats ? i0 + u * step : i0));
@@ -323,8 +325,40 @@ __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict_
             if (i0 + u * step < n_floats) *reinterpret_cast<f32x4*>(dst + i0 + u * step) = v[u];
     }
 }
-__device__ __forceinline__ void copy_words(int* dst, const void* __restrict__ src, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = reinterpret_cast<const int*>(src)[i];
+__device__ __forceinline__ void copy_words(int* dst, const void* __restrict__ src, int n, int tid, int n_threads) {
+    for (int i = tid; i < n; i += n_threads) dst[i] = reinterpret_cast<const int*>(src)[i];
+}
+
+// Env-step adjoint + allocation adjoint of ONE 16-scenario block on ONE wavefront (16 scenarios x 4 quad lanes): what
+// csrc/gnn_alloc_env.hip's backward kernel does - the same bodies in the same order - with wavefront-scope synchronisation only, so
+// that the other wavefronts of the workgroup stage the weight packs meanwhile.  The quad's partial sums go through LDS, the order
+// gradients (written by the four lanes of a quad, read by its first) through global memory: both behind a fence that drains the
+// wavefront's stores before its next loads.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int MAXW>
+__device__ __forceinline__ void env_alloc_adjoint(const NicGnnPeriodBwd& P, int blk, float* part, int lane) {
+    const NicEnvStepIO& io = P.io;
+    const int x = lane & 15, q = lane >> 4, S = io.dims.n_stores;
+    const int64_t ldb = P.ldb, b = (int64_t)blk * NB + x;
+    const bool act = b < P.n_scenarios;
+    const float gr = act ? P.g_reward.p[b * P.g_reward.scn_stride] : 0.f;
+    float* g_store_orders = P.g_orders;
+    float* g_wh_orders = P.g_orders + (int64_t)S * ldb;
+    part[q * NB + x] = act ? nic::env_ship_partial(io, 0, b, q) : 0.f;
+    wave_sync();
+    if (q == 0) {
+        const float shipped = nic::combine4(part[0 * NB + x], part[1 * NB + x], part[2 * NB + x], part[3 * NB + x]);
+        part[4 * NB + x] = act ? nic::env_bwd_warehouse<MAXW>(io, P.g_wh_out, gr, 0.f, 0, shipped, P.g_wh_in, g_wh_orders, b) : 0.f;
+    }
+    wave_sync();
+    if (act) nic::env_bwd_stores<MAXW>(io, P.g_store_out, gr, [&](int) { return part[4 * NB + x]; }, P.g_store_in, g_store_orders, b, q);
+    wave_sync();   // the order gradients (and the warehouse's on-hand gradient) are read by the q = 0 lane of the quad
+    if (act && q == 0)
+        nic::gnn_alloc_bwd_one(P.mlp[4].Y, io.wh_inv, P.g_orders, P.sums, P.ratio, P.scale, P.d_out, P.g_wh_in, S, P.n_edges, P.e_self,
+                               P.e_supplier, P.cap_at_one, b, ldb);
 }
 
 // sum of the tiles a CSR list names, in list order, four loads in flight
@@ -359,6 +393,8 @@ __host__ __device__ inline int tab_words(int N, int E, const int32_t* n_items) {
     return 3 * E + 4 * N + 4 * (N + 1) + n_items[0] + n_items[1] + n_items[2] + n_items[3];
 }
 
+// MAXW: register slots of the env adjoint's pipelines (only used with fuse_env)
+template <int MAXW>
 __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGnnPeriodBwd P) {
     extern __shared__ __align__(16) float lds[];
     const int N = P.n_nodes, E = P.n_edges, L = P.n_live, nsub = P.n_sub;
@@ -393,22 +429,31 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     float* scr = scr_all + wave * kScr;
     GNNB_STAMP(0);
-    copy_to_lds(w_in, P.mlp[0].wpk_t, sz_in);
-    copy_to_lds(w_ie, P.mlp[1].wpk_t, sz_ie);
-    copy_to_lds(w_nu, P.mlp[2].wpk_t, sz_nu);
-    copy_to_lds(w_eu, P.mlp[3].wpk_t, sz_eu);
-    copy_to_lds(w_out, P.mlp[4].wpk_t, sz_out);
-    copy_words(const_cast<int*>(G.src), P.src, E);
-    copy_words(const_cast<int*>(G.tgt), P.tgt, E);
-    copy_words(const_cast<int*>(G.lead), P.lead, E);
-    copy_words(const_cast<int*>(G.row0), P.node_row0, N);
-    copy_words(const_cast<int*>(G.slots), P.node_slots, N);
-    copy_words(const_cast<int*>(G.in_scale), P.agg_scale, N);
-    copy_words(const_cast<int*>(G.out_scale), P.agg_scale + N, N);
+    const int n_blocks = (P.n_scenarios + NB - 1) / NB;
+    const int first0 = blockIdx.x * nsub;
+    // fuse_env: the first round's env / allocation adjoint on one wavefront per sub-block WHILE the others stage packs and tables
+    const int env_waves = P.fuse_env ? ((n_blocks - first0) < nsub ? (n_blocks - first0) : nsub) : 0;
+    if (wave < env_waves) {
+        env_alloc_adjoint<MAXW>(P, first0 + wave, red + wave * (5 * NB), lane);
+    } else {
+        const int tid = threadIdx.x - env_waves * 64, nt = (kWaves - env_waves) * 64;
+        copy_to_lds(w_in, P.mlp[0].wpk_t, sz_in, tid, nt);
+        copy_to_lds(w_ie, P.mlp[1].wpk_t, sz_ie, tid, nt);
+        copy_to_lds(w_nu, P.mlp[2].wpk_t, sz_nu, tid, nt);
+        copy_to_lds(w_eu, P.mlp[3].wpk_t, sz_eu, tid, nt);
+        copy_to_lds(w_out, P.mlp[4].wpk_t, sz_out, tid, nt);
+        copy_words(const_cast<int*>(G.src), P.src, E, tid, nt);
+        copy_words(const_cast<int*>(G.tgt), P.tgt, E, tid, nt);
+        copy_words(const_cast<int*>(G.lead), P.lead, E, tid, nt);
+        copy_words(const_cast<int*>(G.row0), P.node_row0, N, tid, nt);
+        copy_words(const_cast<int*>(G.slots), P.node_slots, N, tid, nt);
+        copy_words(const_cast<int*>(G.in_scale), P.agg_scale, N, tid, nt);
+        copy_words(const_cast<int*>(G.out_scale), P.agg_scale + N, N, tid, nt);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        copy_words(const_cast<int*>(G.off[k]), P.list_off[k], N + 1);
-        copy_words(const_cast<int*>(G.items[k]), P.list_items[k], P.n_items[k]);
+        for (int k = 0; k < 4; ++k) {
+            copy_words(const_cast<int*>(G.off[k]), P.list_off[k], N + 1, tid, nt);
+            copy_words(const_cast<int*>(G.items[k]), P.list_items[k], P.n_items[k], tid, nt);
+        }
     }
     __syncthreads();
     GNNB_STAMP(1);
@@ -420,9 +465,8 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
     const int per_sub = 2 * E + L + 3 * N;
     float* const T0 = P.scratch + (int64_t)blockIdx.x * nsub * per_sub * kTile;
     const int oDE = 0, oSE = E, oDN = E + L, oXI = E + L + N, oXO = E + L + 2 * N, oSI = E + L + 3 * N;
-    const int n_blocks = (P.n_scenarios + NB - 1) / NB;
 
-    for (int first = blockIdx.x * nsub; first < n_blocks; first += gridDim.x * nsub) {
+    for (int first = first0; first < n_blocks; first += gridDim.x * nsub) {
         // per-item geometry: sub-block `sub` of this round
         auto block_of = [&](int sub, int64_t& b0, bool& live, int64_t& hblk, float*& tiles) {
             const int bk = first + sub;
@@ -432,10 +476,10 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
             tiles = T0 + (int64_t)sub * per_sub * kTile;
         };
         const int subs = (n_blocks - first) < nsub ? (n_blocks - first) : nsub;   // sub-blocks that exist in this round
-        // Items are dealt entity-major, sub-block-minor: neighbouring wavefronts work on the SAME entity's two 16-scenario halves at
-        // the same time, so both halves of every 128-byte line of the histories are asked for together (sub-block-major - all of
-        // sub-block 0, then all of sub-block 1 - fetched every line twice: rocprofv3 counted 1.33 GB of HBM traffic per launch for
-        // 0.44 GB of histories; profiles/r06_traffic_gnn.json)
+        if (P.fuse_env && first != first0) {   // (later rounds of a grid smaller than the batch: the first round's ran beside the staging)
+            if (wave < subs) env_alloc_adjoint<MAXW>(P, first + wave, red + wave * (5 * NB), lane);
+            __syncthreads();
+        }
 
         // ---- A: output MLP (live edges): dz3 = d_out * softplus'(z) = d_out * (1 - exp(-y)) ------------------------------------------
         {
@@ -711,6 +755,18 @@ int check(const NicGnnPeriodBwd* p, const char* who) {
                         m.lds2 >= 33 && m.lds3 >= 33, "%s: MLP %d: strides", who, i);
     }
     NIC_REQUIRE(lds_bytes(*p) <= kLdsLimit, "%s: the graph's tables do not fit in LDS", who);
+    if (p->fuse_env) {
+        const NicEnvDims& d = p->io.dims;
+        NIC_REQUIRE(d.n_warehouses == 1 && d.n_echelons == 0, "%s: fused env / allocation adjoint: one supplying warehouse, no extra echelons", who);
+        NIC_REQUIRE(d.n_scenarios == p->n_scenarios && d.ldb == p->ldb && p->n_edges > d.n_stores, "%s: env dims differ from the policy's", who);
+        NIC_REQUIRE(d.store_slots >= 2 && d.store_slots <= NIC_MAX_SLOTS && d.warehouse_slots >= 2 && d.warehouse_slots <= NIC_MAX_SLOTS,
+                    "%s: pipeline lengths outside [2,%d]", who, NIC_MAX_SLOTS);
+        NIC_REQUIRE(p->io.store_inv && p->io.wh_inv && p->io.demand.p && p->io.store_orders.p && p->io.wh_orders.p && p->io.underage.p &&
+                        p->io.holding.p && p->io.lead_times.p && p->io.wh_holding.p && p->io.wh_lead_times.p,
+                    "%s: null env table", who);
+        NIC_REQUIRE(p->sums && p->ratio && p->scale && p->g_reward.p && p->g_store_in && p->g_wh_in && p->g_orders && p->e_supplier >= 0,
+                    "%s: null buffer of the fused env / allocation adjoint", who);
+    }
     return 0;
 }
 }  // namespace
@@ -731,11 +787,23 @@ int nic_gnn_period_bwd(const NicGnnPeriodBwd* p, void* stream) {
     int grid = nic::ceil_div(n_blocks, p->n_sub);
     if (grid > kMaxGrid) grid = kMaxGrid;
     hipStream_t s = nic::as_stream(stream);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_period_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit) !=
-        hipSuccess)
-        return nic::fail("nic_gnn_period_bwd: cannot raise the dynamic LDS limit");
-    nic::note_kernel("gnn_period_bwd_kernel");
-    hipLaunchKernelGGL(gnn_period_bwd_kernel, dim3(grid), dim3(kWaves * 64), bytes, s, *p);
+    int m = 4;
+    if (p->fuse_env) {
+        const int sl = p->io.dims.store_slots > p->io.dims.warehouse_slots ? p->io.dims.store_slots : p->io.dims.warehouse_slots;
+        m = sl <= 4 ? 4 : (sl <= 8 ? 8 : NIC_MAX_SLOTS);
+    }
+    nic::note_kernelf("gnn_period_bwd_kernel<%d>%s", m, p->fuse_env ? " (+ env / allocation adjoint)" : "");
+#define NIC_GPB(MW)                                                                                                                  \
+    do {                                                                                                                             \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_period_bwd_kernel<MW>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                kLdsLimit) != hipSuccess)                                                                            \
+            return nic::fail("nic_gnn_period_bwd: cannot raise the dynamic LDS limit");                                              \
+        hipLaunchKernelGGL(gnn_period_bwd_kernel<MW>, dim3(grid), dim3(kWaves * 64), bytes, s, *p);                                  \
+    } while (0)
+    if (m == 4) NIC_GPB(4);
+    else if (m == 8) NIC_GPB(8);
+    else NIC_GPB(NIC_MAX_SLOTS);
+#undef NIC_GPB
     return nic::check_launch("nic_gnn_period_bwd");
 }
 

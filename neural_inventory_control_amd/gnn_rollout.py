@@ -663,6 +663,10 @@ class GnnRollout:
         g_so, g_wo = self.g_orders[:S * P.Wn].view(S, P.Wn, -1), self.g_orders[S * P.Wn:]
         gc = self._views(g_cur, prob)
         fused = P.Wn == 1 and self.fuse_alloc_env
+        if fused and self._period_bwd:
+            # ... in the SAME launch as the MLP adjoints (round 6: the adjoint pair runs on the first wavefronts of nic_gnn_period_bwd)
+            self._k("gnn_period_bwd", ops.gnn_period_bwd, self._period_bwd_desc(t, prob, g_cur, demand_soa, shift, g_next))
+            return
         if fused:   # env-step adjoint + allocation adjoint in one launch
             self._k("alloc_env_bwd", ops.gnn_alloc_env_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), M["output"].Y[t][0],
                     self.orders[t], self.sums[t], self.ratio[t], self.scale[t], P.e_self, P.e_supplier, not P.transshipment,
@@ -716,9 +720,10 @@ class GnnRollout:
         gc.wh += m.dX[:prob.Ww, :P.Wn].permute(1, 0, 2)
         gc.store += m.dX[:prob.Ws, P.Wn:].permute(1, 0, 2)
 
-    def _period_bwd_desc(self, t, prob, g_cur):
-        """`NicGnnPeriodBwd` of period t (cached per (period, state-gradient buffer): every buffer it names is engine-owned)."""
-        key = (t, g_cur.data_ptr())
+    def _period_bwd_desc(self, t, prob, g_cur, demand_soa=None, shift=0, g_next=None):
+        """`NicGnnPeriodBwd` of period t (cached per (period, state-gradient buffers, demand trace): every other buffer it names is
+        engine-owned).  With `g_next` the env-step / allocation adjoint of the period runs inside the launch (one warehouse)."""
+        key = (t, g_cur.data_ptr(), None if g_next is None else (g_next.data_ptr(), demand_soa.data_ptr(), shift, id(prob)))
         d = self._bdesc.get(key)
         if d is not None:
             return d
@@ -739,6 +744,18 @@ class GnnRollout:
             m, q = M[name], d.mlp[i]
             q.wpk_t, q.Y, q.H1, q.H2, q.row_stride = p(self.bpack[name].buf), p(m.Y[t]), p(m.hist(m.H1, t)), p(m.hist(m.H2, t)), m.n_ent * ld
             (q.slab1, q.lds1), (q.slab2, q.lds2), (q.slab3, q.lds3) = [(p(sl), sl.stride(1)) for sl in m.slabs]
+        if g_next is not None:
+            S = prob.S
+            st, orders = self._views(self.states[t], prob), self.orders[t]
+            gn, gc = self._views(g_next, prob), self._views(g_cur, prob)
+            d.fuse_env = 1
+            d.io = prob.make_io(st.store, st.wh, None, Table(demand_soa[t + shift], ld, 1), Table(orders[:S].view(S, 1, -1), ld, 1, ld),
+                                Table(orders[S:], ld, 1), None)
+            d.e_self, d.e_supplier, d.cap_at_one = (-1 if P.e_self is None else P.e_self), P.e_supplier, int(not P.transshipment)
+            d.sums, d.ratio, d.scale = p(self.sums[t]), p(self.ratio[t]), p(self.scale[t])
+            d.g_store_out, d.g_wh_out, d.g_reward = p(gn.store), p(gn.wh), Table(self.g_reward, 0, 1).t2()
+            d.g_store_in, d.g_wh_in, d.g_orders = p(gc.store), p(gc.wh), p(self.g_orders)
+            d._keep = (st, gn, gc, orders)
         self._bdesc[key] = d
         return d
 

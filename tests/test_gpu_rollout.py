@@ -1776,6 +1776,7 @@ def test_gnn_fused_alloc_env_launches_equal_the_separate_ones(name):
         eng = GnnRollout(model, c["problem_params"], DEV)
         eng.fuse_alloc_env = fused
         eng.use_period_kernel = False   # (the period kernel carries the allocation + env step itself; this is about the two launches)
+        eng.use_period_bwd = False      # (... and so does the period backward kernel, round 6)
         eng.materialize(max(data["initial_inventories"].shape[2], data["initial_warehouse_inventories"].shape[2]) + 4)
         _load(model, g)
         eng.timer = KernelTimer(record_order=True)
@@ -2110,6 +2111,8 @@ def test_gnn_period_backward_matches_the_per_mlp_launches(workload, n, T):
     a, b = _gnn_run_pair(setting, policy, n, T, 3, use_period_bwd=(True, False))
     assert a["eng"]._period_bwd and not b["eng"]._period_bwd
     assert "gnn_period_bwd" in a["tags"] and not any(t.startswith("mlp3_bwd") for t in a["tags"])
+    if workload == "gnn":   # one warehouse: the env / allocation adjoint runs inside the same launch
+        assert "alloc_env_bwd" not in a["tags"] and "alloc_env_bwd" in b["tags"]
     assert "gnn_period_bwd" not in b["tags"] and "mlp3_bwd_edge_update" in b["tags"]
     _assert_same_gradients(a, b, tag=(workload, n, T))
 
