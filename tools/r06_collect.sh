@@ -17,7 +17,13 @@ for w in gnn gnn_many_warehouses; do
 done
 timeout 600 python tools/gnn_period_pmc.py $O/r06_gnn_period_pmc.json > $O/pmc.log 2>&1
 echo "pmc rc $?"
-for w in cfg1 cfg2 cfg4 gnn; do
+for w in gnn gnn_many_warehouses; do   # same-box A/B: eager launches with the per-kernel timer; the per-MLP backward; round 5's route replayed
+  timeout 300 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $O/r06_bench_${w}_eager.json 2>/dev/null
+  timeout 300 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-graph --gnn-bwd off > $O/r06_bench_${w}_per_mlp_backward.json 2>/dev/null
+  timeout 300 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --graph --gnn-bwd off --gnn-period $( [ $w = gnn ] && echo on || echo off ) > $O/r06_bench_${w}_round5_route_replayed.json 2>/dev/null
+done
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r06_bench_cfg3_driver_cmd.json 2>/dev/null
+for w in cfg1 cfg2 cfg4 gnn gnn_many_warehouses; do
   timeout 900 python bench.py --workload $w --eval --periods 5000 --steps 3 --warmup 1 --no-cpu-baseline > $O/r06_bench_${w}_eval_T5000.json 2> $O/eval_$w.err
   echo "eval $w rc $?"; python tools/show_bench.py $O/r06_bench_${w}_eval_T5000.json | head -3
 done
