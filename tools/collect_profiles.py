@@ -82,6 +82,9 @@ def note_name(k):
     m = re.match(r"(gemm_wgrad_dma_kernel<\d+, \d+, \d+, \d+), (true|false)>", k)
     if m:
         return (m.group(1) + (",skip>" if m.group(2) == "true" else ">")).replace(" ", "")
+    m = re.match(r"gnn_period_fwd_kernel<(\d+), (true|false), (\d+), (true|false)>", k)
+    if m:
+        return "gnn_period_fwd_kernel<%s,%s,%s%s>" % (m.group(1), m.group(2), m.group(3), ",spill" if m.group(4) == "true" else "")
     m = re.match(r"thin_in_fwd_kernel<(\d+), (?:true|false)>", k)
     if m:
         return "thin_in_fwd_kernel<%s>" % m.group(1)
@@ -123,8 +126,10 @@ def traffic_pass(rnd, w, out):
         by_kernel[kern.replace(" ", "")].append(tag)
     kernels = []
     for kern, tags in sorted(by_kernel.items()):
-        f_rows = [v for _, k, v in fetch if note_name(k) == kern]
-        w_rows = [v for _, k, v in write if note_name(k) == kern]
+        # (the ABI may qualify a name behind the template arguments - "gnn_period_bwd_kernel<4> (+ env / allocation adjoint)")
+        same = lambda k: note_name(k) == kern or kern.startswith(note_name(k) + "(")  # noqa: E731
+        f_rows = [v for _, k, v in fetch if same(k)]
+        w_rows = [v for _, k, v in write if same(k)]
         if len(f_rows) < len(tags) or len(w_rows) < len(tags):
             print("traffic: no counter rows for", kern, len(f_rows), len(w_rows), len(tags), flush=True)
             continue
