@@ -608,13 +608,6 @@ typedef struct NicGnnPeriod {
     float* wh_out;
     float* reward;
     float* edge_scratch;          /* nic_gnn_period_ok() == 2: ceil(n_scenarios / 16) * n_edges * 512 floats for the edge tiles; else NULL */
-    /* fuse_env with SEVERAL supplying warehouses (round 6): the allocation of nic_gnn_alloc_groups_fwd - groups [n_groups][4],
-     * order_row [n_edges] as there, orders [S * Wn + Wn][ldb], sums / ratio / scale [n_groups][ldb] - then the env step; n_groups = 0
-     * is the one-warehouse form above (e_self / e_supplier) */
-    const int32_t* groups;
-    const int32_t* order_row;
-    int32_t n_groups;
-    int32_t reserved2;
 } NicGnnPeriod;
 int nic_gnn_period_pack_size(int32_t s1q, int32_t n_out);
 /* 1 if a graph's embeddings (n_nodes + n_edges tiles of 2 KB) and the staged weights fit in a workgroup's LDS; 2 if only the node
@@ -692,12 +685,6 @@ typedef struct NicGnnPeriodBwd {
     float* g_store_in;
     float* g_wh_in;
     float* g_orders;
-    /* fuse_env with SEVERAL supplying warehouses: nic_env_step_bwd then nic_gnn_alloc_groups_bwd (groups / order_row as there;
-     * g_orders [S * Wn + Wn][ldb]; rows [zero_first, zero_first + zero_count) of d_out - the demand edges - are cleared);
-     * n_groups = 0 is the one-warehouse form */
-    const int32_t* groups;
-    const int32_t* order_row;
-    int32_t n_groups, zero_first, zero_count, reserved3;
 } NicGnnPeriodBwd;
 /* pack size: (n_out == 1 ? 512 : 1024) + 1024 (1 + segments) floats; workgroups per launch: at most nic_mlp3_bwd_hist_slots(), the
  * slot count of the slabs both backwards share */

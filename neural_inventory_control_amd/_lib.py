@@ -116,9 +116,7 @@ class NicGnnPeriod(C.Structure):
                 + [(n, C.c_void_p) for n in ("src", "tgt", "agg_off", "agg_items", "agg_scale", "lead", "node_row0", "node_slots",
                                              "state", "feat", "agg")]
                 + [("mlp", NicGnnPeriodMlp * 5), ("io", NicEnvStepIO)]
-                + [(n, C.c_void_p) for n in ("orders", "sums", "ratio", "scale", "store_out", "wh_out", "reward", "edge_scratch",
-                                             "groups", "order_row")]
-                + [("n_groups", C.c_int32), ("reserved2", C.c_int32)])
+                + [(n, C.c_void_p) for n in ("orders", "sums", "ratio", "scale", "store_out", "wh_out", "reward", "edge_scratch")])
 
 
 class NicGnnPeriodBwdMlp(C.Structure):
@@ -140,8 +138,7 @@ class NicGnnPeriodBwd(C.Structure):
                 + [("io", NicEnvStepIO)]
                 + [(n, C.c_void_p) for n in ("sums", "ratio", "scale", "g_store_out", "g_wh_out")]
                 + [("g_reward", NicTable2)]
-                + [(n, C.c_void_p) for n in ("g_store_in", "g_wh_in", "g_orders", "groups", "order_row")]
-                + [(n, C.c_int32) for n in ("n_groups", "zero_first", "zero_count", "reserved3")])
+                + [(n, C.c_void_p) for n in ("g_store_in", "g_wh_in", "g_orders")])
 
 
 NIC_MLP3_MAX_K, NIC_MLP3_ACT_NONE, NIC_MLP3_ACT_ELU, NIC_MLP3_ACT_SOFTPLUS = 96, 0, 1, 2

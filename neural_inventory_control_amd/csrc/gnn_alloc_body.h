@@ -94,55 +94,4 @@ __device__ __forceinline__ void gnn_alloc_bwd_one(const float* __restrict__ out,
     }
     g_on_hand[b] = goh + d_scale / den;
 }
-
-// ---- the same allocation for ONE of SEVERAL supplying nodes (many-warehouse graphs; csrc/mlp3.hip: nic_gnn_alloc_groups_fwd / _bwd and
-// the launches fused behind / in front of the policy, csrc/gnn_period*.hip).  groups [n][4] = {first member edge, member count, self-loop
-// edge or -1, supplier edge}; order_row [E] = row of `orders` an edge's quantity is written to.  `out` rows are out_ld apart and this
-// scenario is column out_b of them (see gnn_alloc_fwd_one); on_hand = slot 0 of group g's pipeline for this scenario's column.
-__device__ __forceinline__ void gnn_alloc_group_fwd_one(const float* __restrict__ out, int64_t out_ld, int64_t out_b, float oh,
-                                                        float* __restrict__ orders, float* __restrict__ sums, float* __restrict__ ratio,
-                                                        float* __restrict__ scale, const int32_t* __restrict__ groups,
-                                                        const int32_t* __restrict__ order_row, int g, int cap_at_one, int64_t b, int64_t ldb) {
-#pragma clang fp contract(off)
-    const int first = groups[4 * g], count = groups[4 * g + 1], e_self = groups[4 * g + 2], e_sup = groups[4 * g + 3];
-    const float sup_v = out[(int64_t)e_sup * out_ld + out_b];
-    orders[(int64_t)order_row[e_sup] * ldb + b] = sup_v;
-    if (count == 0 && e_self < 0) return;   // a warehouse that supplies nobody: its own order only
-    float sum = 0.f;
-    for (int i = 0; i < count; ++i) sum += out[(int64_t)(first + i) * out_ld + out_b];
-    if (e_self >= 0) sum += out[(int64_t)e_self * out_ld + out_b];
-    const float r = oh / (sum + 1e-10f);
-    const float sc = cap_at_one ? fminf(r, 1.f) : r;
-    sums[(int64_t)g * ldb + b] = sum;
-    ratio[(int64_t)g * ldb + b] = r;
-    scale[(int64_t)g * ldb + b] = sc;
-    for (int i = 0; i < count; ++i) orders[(int64_t)order_row[first + i] * ldb + b] = out[(int64_t)(first + i) * out_ld + out_b] * sc;
-}
-// adjoint; g_on_hand points at THIS scenario's on-hand gradient of group g; the lane of group 0 also clears the rows
-// [zero_first, zero_first + zero_count) of d_out (the demand edges)
-__device__ __forceinline__ void gnn_alloc_group_bwd_one(const float* __restrict__ out, float oh, const float* g_orders,
-                                                        const float* __restrict__ sums, const float* __restrict__ ratio,
-                                                        const float* __restrict__ scale, float* __restrict__ d_out, float* g_on_hand,
-                                                        const int32_t* __restrict__ groups, const int32_t* __restrict__ order_row, int g,
-                                                        int zero_first, int zero_count, int cap_at_one, int64_t b, int64_t ldb) {
-#pragma clang fp contract(off)
-    const int first = groups[4 * g], count = groups[4 * g + 1], e_self = groups[4 * g + 2], e_sup = groups[4 * g + 3];
-    if (g == 0)
-        for (int i = 0; i < zero_count; ++i) d_out[(int64_t)(zero_first + i) * ldb + b] = 0.f;
-    d_out[(int64_t)e_sup * ldb + b] = g_orders[(int64_t)order_row[e_sup] * ldb + b];
-    if (count == 0 && e_self < 0) return;
-    const int64_t gb = (int64_t)g * ldb + b;
-    const float rt = ratio[gb], sm = sums[gb], sc = scale[gb];
-    float dot = 0.f;
-    for (int i = 0; i < count; ++i)
-        dot += g_orders[(int64_t)order_row[first + i] * ldb + b] * out[(int64_t)(first + i) * ldb + b];
-    const float passes = cap_at_one ? (rt <= 1.f ? 1.f : 0.f) : 1.f;
-    const float d_scale = dot * passes;
-    const float den = sm + 1e-10f;
-    const float common = -(d_scale * oh / (den * den));
-    for (int i = 0; i < count; ++i)
-        d_out[(int64_t)(first + i) * ldb + b] = common + g_orders[(int64_t)order_row[first + i] * ldb + b] * sc;
-    if (e_self >= 0) d_out[(int64_t)e_self * ldb + b] = common;
-    *g_on_hand += d_scale / den;
-}
 }  // namespace nic

@@ -26,9 +26,8 @@ constexpr int NB = 16;          // scenarios per workgroup
 // wavefronts per workgroup: 16 (four per SIMD: a tile's layers are a dependent MFMA -> ELU -> store chain, so a SIMD needs several
 // wavefronts in different phases to keep its matrix pipe fed) where the kernel fits in 128 registers, else 8
 constexpr int kTile = 512;      // floats of one entity's embedding tile
-constexpr int kEnvChunk = 1;                       // warehouses per round of the env step's shipment sums
-constexpr int kEnvMaxWh = 8;                       // supplying warehouses the fused allocation + env step takes
-constexpr int kEnvScratch = (kEnvChunk + 1) * 4 * NB + kEnvMaxWh * NB;   // floats: quad partial sums, store costs, the warehouses' costs
+constexpr int kEnvChunk = 1;                       // (the fused allocation + env step is for ONE warehouse)
+constexpr int kEnvScratch = (kEnvChunk + 1) * 4 * NB + NB;   // floats: quad partial sums, store costs, the warehouse's cost
 
 #ifdef NIC_TUNING_BUILD
 __device__ unsigned long long* g_gnn_stamps = nullptr;
@@ -433,15 +432,9 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_fwd_kernel(const NicGn
         float(*part)[4][NB] = reinterpret_cast<float(*)[4][NB]>(scratch);
         float(*rq)[NB] = reinterpret_cast<float(*)[NB]>(scratch + kEnvChunk * 4 * NB);
         float(*cw)[NB] = reinterpret_cast<float(*)[NB]>(scratch + (kEnvChunk + 1) * 4 * NB);
-        if (P.n_groups > 0) {   // several supplying warehouses: one lane per (scenario, warehouse), as nic_gnn_alloc_groups_fwd
-            if (act)
-                for (int w = q; w < P.n_groups; w += nic::kQuad)
-                    nic::gnn_alloc_group_fwd_one(outl, NB, x, io.wh_inv[(int64_t)w * io.dims.warehouse_slots * ldb + b], P.orders, P.sums,
-                                                 P.ratio, P.scale, P.groups, P.order_row, w, P.cap_at_one, b, ldb);
-        } else if (act && q == 0) {
+        if (act && q == 0)
             nic::gnn_alloc_fwd_one(outl, NB, x, io.wh_inv, P.orders, P.sums, P.ratio, P.scale, io.dims.n_stores, P.e_self, P.e_supplier,
                                    P.cap_at_one, b, ldb);
-        }
         __syncthreads();
         if (on) rq[q][x] = act ? nic::env_fwd_stores<MAXW>(io, P.store_out, b, q) : 0.f;
         for (int wc = 0; wc < Wn; wc += kEnvChunk) {
@@ -501,17 +494,12 @@ int check(const NicGnnPeriod* p, const char* who) {
     }
     if (p->fuse_env) {
         const NicEnvDims& d = p->io.dims;
-        NIC_REQUIRE(d.n_warehouses >= 1 && d.n_warehouses <= kEnvMaxWh && d.n_echelons == 0,
-                    "%s: fused allocation + env step: 1..%d supplying warehouses, no extra echelons", who, kEnvMaxWh);
+        NIC_REQUIRE(d.n_warehouses == 1 && d.n_echelons == 0, "%s: fused allocation + env step: one supplying warehouse, no extra echelons", who);
         NIC_REQUIRE(d.n_scenarios == p->n_scenarios && d.ldb == p->ldb, "%s: env dims differ from the policy's", who);
-        NIC_REQUIRE(p->orders && p->sums && p->ratio && p->scale && p->store_out && p->wh_out && p->reward, "%s: null allocation / env buffer", who);
-        if (p->n_groups > 0)
-            NIC_REQUIRE(p->n_groups == d.n_warehouses && p->groups && p->order_row, "%s: one group per warehouse, with its tables", who);
-        else
-            NIC_REQUIRE(d.n_warehouses == 1 && p->e_supplier >= 0, "%s: the one-warehouse form needs e_supplier (several: groups)", who);
-        NIC_REQUIRE(p->io.store_orders.p == p->orders &&
-                        p->io.wh_orders.p == p->orders + (int64_t)d.n_stores * d.n_warehouses * d.ldb,
-                    "%s: io's order tables must be the rows of `orders` ([S * Wn + Wn][ldb])", who);
+        NIC_REQUIRE(p->orders && p->sums && p->ratio && p->scale && p->store_out && p->wh_out && p->reward && p->e_supplier >= 0,
+                    "%s: null allocation / env buffer", who);
+        NIC_REQUIRE(p->io.store_orders.p == p->orders && p->io.wh_orders.p == p->orders + (int64_t)d.n_stores * d.ldb,
+                    "%s: io's order tables must be the rows of `orders` ([S + 1][ldb])", who);
     }
     return 0;
 }

@@ -37,8 +37,6 @@ constexpr int kWaves = 8;        // two per SIMD: up to 80 accumulator registers
 constexpr int kTile = 512;       // floats of one tile
 constexpr int kScrLd = 20;       // padded row of the wave-private transposition tile ([32][20] floats: both access patterns conflict-free)
 constexpr int kScr = 32 * kScrLd;
-constexpr int kEnvMaxWh = 8;             // supplying warehouses the fused env / allocation adjoint takes
-constexpr int kEnvPart = (4 + kEnvMaxWh) * NB;   // floats of a wavefront's LDS area there: quad partial sums + the warehouses' gradients
 constexpr int kRed = kWaves * 4 * 256;   // floats of the cross-wave reduction area (four 16 x 16 blocks per wavefront)
 
 #ifdef NIC_TUNING_BUILD
@@ -343,35 +341,24 @@ __device__ __forceinline__ void wave_sync() {
 template <int MAXW>
 __device__ __forceinline__ void env_alloc_adjoint(const NicGnnPeriodBwd& P, int blk, float* part, int lane) {
     const NicEnvStepIO& io = P.io;
-    const int x = lane & 15, q = lane >> 4, S = io.dims.n_stores, Wn = io.dims.n_warehouses;
+    const int x = lane & 15, q = lane >> 4, S = io.dims.n_stores;
     const int64_t ldb = P.ldb, b = (int64_t)blk * NB + x;
     const bool act = b < P.n_scenarios;
     const float gr = act ? P.g_reward.p[b * P.g_reward.scn_stride] : 0.f;
-    float* g_store_orders = P.g_orders;                              // [S][Wn][ldb]
-    float* g_wh_orders = P.g_orders + (int64_t)S * Wn * ldb;         // [Wn][ldb]
-    float* gwa = part + 4 * NB;                                      // [Wn][NB]: gradient of each warehouse's post-shipping on-hand
-    for (int w = 0; w < Wn; ++w) {
-        part[q * NB + x] = act ? nic::env_ship_partial(io, w, b, q) : 0.f;
-        wave_sync();
-        if (q == 0) {
-            const float shipped = nic::combine4(part[0 * NB + x], part[1 * NB + x], part[2 * NB + x], part[3 * NB + x]);
-            gwa[w * NB + x] = act ? nic::env_bwd_warehouse<MAXW>(io, P.g_wh_out, gr, 0.f, w, shipped, P.g_wh_in, g_wh_orders, b) : 0.f;
-        }
-        wave_sync();
+    float* g_store_orders = P.g_orders;
+    float* g_wh_orders = P.g_orders + (int64_t)S * ldb;
+    part[q * NB + x] = act ? nic::env_ship_partial(io, 0, b, q) : 0.f;
+    wave_sync();
+    if (q == 0) {
+        const float shipped = nic::combine4(part[0 * NB + x], part[1 * NB + x], part[2 * NB + x], part[3 * NB + x]);
+        part[4 * NB + x] = act ? nic::env_bwd_warehouse<MAXW>(io, P.g_wh_out, gr, 0.f, 0, shipped, P.g_wh_in, g_wh_orders, b) : 0.f;
     }
-    if (act) nic::env_bwd_stores<MAXW>(io, P.g_store_out, gr, [&](int w) { return gwa[w * NB + x]; }, P.g_store_in, g_store_orders, b, q);
-    wave_sync();   // the order gradients (and the warehouses' on-hand gradients) are read by other lanes of the quad
-    if (P.n_groups > 0) {   // several supplying warehouses: one lane per (scenario, warehouse), as nic_gnn_alloc_groups_bwd
-        if (act)
-            for (int w = q; w < P.n_groups; w += nic::kQuad) {
-                const int64_t oh = (int64_t)w * io.dims.warehouse_slots * ldb + b;
-                nic::gnn_alloc_group_bwd_one(P.mlp[4].Y, io.wh_inv[oh], P.g_orders, P.sums, P.ratio, P.scale, P.d_out, P.g_wh_in + oh, P.groups,
-                                             P.order_row, w, P.zero_first, P.zero_count, P.cap_at_one, b, ldb);
-            }
-    } else if (act && q == 0) {
+    wave_sync();
+    if (act) nic::env_bwd_stores<MAXW>(io, P.g_store_out, gr, [&](int) { return part[4 * NB + x]; }, P.g_store_in, g_store_orders, b, q);
+    wave_sync();   // the order gradients (and the warehouse's on-hand gradient) are read by the q = 0 lane of the quad
+    if (act && q == 0)
         nic::gnn_alloc_bwd_one(P.mlp[4].Y, io.wh_inv, P.g_orders, P.sums, P.ratio, P.scale, P.d_out, P.g_wh_in, S, P.n_edges, P.e_self,
                                P.e_supplier, P.cap_at_one, b, ldb);
-    }
 }
 
 // sum of the tiles a CSR list names, in list order, four loads in flight
@@ -447,7 +434,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
     // fuse_env: the first round's env / allocation adjoint on one wavefront per sub-block WHILE the others stage packs and tables
     const int env_waves = P.fuse_env ? ((n_blocks - first0) < nsub ? (n_blocks - first0) : nsub) : 0;
     if (wave < env_waves) {
-        env_alloc_adjoint<MAXW>(P, first0 + wave, red + wave * kEnvPart, lane);
+        env_alloc_adjoint<MAXW>(P, first0 + wave, red + wave * (5 * NB), lane);
     } else {
         const int tid = threadIdx.x - env_waves * 64, nt = (kWaves - env_waves) * 64;
         copy_to_lds(w_in, P.mlp[0].wpk_t, sz_in, tid, nt);
@@ -490,7 +477,7 @@ __global__ __launch_bounds__(kWaves * 64) void gnn_period_bwd_kernel(const NicGn
         };
         const int subs = (n_blocks - first) < nsub ? (n_blocks - first) : nsub;   // sub-blocks that exist in this round
         if (P.fuse_env && first != first0) {   // (later rounds of a grid smaller than the batch: the first round's ran beside the staging)
-            if (wave < subs) env_alloc_adjoint<MAXW>(P, first + wave, red + wave * kEnvPart, lane);
+            if (wave < subs) env_alloc_adjoint<MAXW>(P, first + wave, red + wave * (5 * NB), lane);
             __syncthreads();
         }
 
@@ -770,20 +757,14 @@ int check(const NicGnnPeriodBwd* p, const char* who) {
     NIC_REQUIRE(lds_bytes(*p) <= kLdsLimit, "%s: the graph's tables do not fit in LDS", who);
     if (p->fuse_env) {
         const NicEnvDims& d = p->io.dims;
-        NIC_REQUIRE(d.n_warehouses >= 1 && d.n_warehouses <= kEnvMaxWh && d.n_echelons == 0,
-                    "%s: fused env / allocation adjoint: 1..%d supplying warehouses, no extra echelons", who, kEnvMaxWh);
-        if (p->n_groups > 0)
-            NIC_REQUIRE(p->n_groups == d.n_warehouses && p->groups && p->order_row && p->zero_first >= 0 && p->zero_count >= 0 &&
-                            p->zero_first + p->zero_count <= p->n_edges, "%s: one group per warehouse, with its tables", who);
-        else
-            NIC_REQUIRE(d.n_warehouses == 1 && p->e_supplier >= 0, "%s: the one-warehouse form needs e_supplier (several: groups)", who);
+        NIC_REQUIRE(d.n_warehouses == 1 && d.n_echelons == 0, "%s: fused env / allocation adjoint: one supplying warehouse, no extra echelons", who);
         NIC_REQUIRE(d.n_scenarios == p->n_scenarios && d.ldb == p->ldb && p->n_edges > d.n_stores, "%s: env dims differ from the policy's", who);
         NIC_REQUIRE(d.store_slots >= 2 && d.store_slots <= NIC_MAX_SLOTS && d.warehouse_slots >= 2 && d.warehouse_slots <= NIC_MAX_SLOTS,
                     "%s: pipeline lengths outside [2,%d]", who, NIC_MAX_SLOTS);
         NIC_REQUIRE(p->io.store_inv && p->io.wh_inv && p->io.demand.p && p->io.store_orders.p && p->io.wh_orders.p && p->io.underage.p &&
                         p->io.holding.p && p->io.lead_times.p && p->io.wh_holding.p && p->io.wh_lead_times.p,
                     "%s: null env table", who);
-        NIC_REQUIRE(p->sums && p->ratio && p->scale && p->g_reward.p && p->g_store_in && p->g_wh_in && p->g_orders,
+        NIC_REQUIRE(p->sums && p->ratio && p->scale && p->g_reward.p && p->g_store_in && p->g_wh_in && p->g_orders && p->e_supplier >= 0,
                     "%s: null buffer of the fused env / allocation adjoint", who);
     }
     return 0;

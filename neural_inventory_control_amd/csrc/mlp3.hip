@@ -1108,11 +1108,24 @@ __global__ void gnn_alloc_groups_fwd_kernel(const float* __restrict__ out, const
                                             float* __restrict__ orders, float* __restrict__ sums, float* __restrict__ ratio,
                                             float* __restrict__ scale, const int32_t* __restrict__ groups,
                                             const int32_t* __restrict__ order_row, int cap_at_one, int B, int64_t ldb) {
+#pragma clang fp contract(off)
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int g = blockIdx.y;
-    nic::gnn_alloc_group_fwd_one(out, ldb, b, on_hand[(int64_t)g * oh_stride + b], orders, sums, ratio, scale, groups, order_row, g,
-                                 cap_at_one, b, ldb);
+    const int first = groups[4 * g], count = groups[4 * g + 1], e_self = groups[4 * g + 2], e_sup = groups[4 * g + 3];
+    const float sup_v = out[(int64_t)e_sup * ldb + b];
+    orders[(int64_t)order_row[e_sup] * ldb + b] = sup_v;
+    if (count == 0 && e_self < 0) return;   // a warehouse that supplies nobody: its own order only
+    const float oh = on_hand[(int64_t)g * oh_stride + b];
+    float sum = 0.f;
+    for (int i = 0; i < count; ++i) sum += out[(int64_t)(first + i) * ldb + b];
+    if (e_self >= 0) sum += out[(int64_t)e_self * ldb + b];
+    const float r = oh / (sum + 1e-10f);
+    const float sc = cap_at_one ? fminf(r, 1.f) : r;
+    sums[(int64_t)g * ldb + b] = sum;
+    ratio[(int64_t)g * ldb + b] = r;
+    scale[(int64_t)g * ldb + b] = sc;
+    for (int i = 0; i < count; ++i) orders[(int64_t)order_row[first + i] * ldb + b] = out[(int64_t)(first + i) * ldb + b] * sc;
 }
 
 // adjoint; rows [zero_first, zero_first + zero_count) of d_out (the demand edges: they feed nothing) are cleared by group 0
@@ -1122,11 +1135,28 @@ __global__ void gnn_alloc_groups_bwd_kernel(const float* __restrict__ out, const
                                             float* __restrict__ d_out, float* __restrict__ g_on_hand,
                                             const int32_t* __restrict__ groups, const int32_t* __restrict__ order_row,
                                             int zero_first, int zero_count, int cap_at_one, int B, int64_t ldb) {
+#pragma clang fp contract(off)
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int g = blockIdx.y;
-    nic::gnn_alloc_group_bwd_one(out, on_hand[(int64_t)g * oh_stride + b], g_orders, sums, ratio, scale, d_out,
-                                 g_on_hand + (int64_t)g * oh_stride + b, groups, order_row, g, zero_first, zero_count, cap_at_one, b, ldb);
+    const int first = groups[4 * g], count = groups[4 * g + 1], e_self = groups[4 * g + 2], e_sup = groups[4 * g + 3];
+    if (g == 0)
+        for (int i = 0; i < zero_count; ++i) d_out[(int64_t)(zero_first + i) * ldb + b] = 0.f;
+    d_out[(int64_t)e_sup * ldb + b] = g_orders[(int64_t)order_row[e_sup] * ldb + b];
+    if (count == 0 && e_self < 0) return;
+    const int64_t gb = (int64_t)g * ldb + b;
+    const float rt = ratio[gb], sm = sums[gb], sc = scale[gb], oh = on_hand[(int64_t)g * oh_stride + b];
+    float dot = 0.f;
+    for (int i = 0; i < count; ++i)
+        dot += g_orders[(int64_t)order_row[first + i] * ldb + b] * out[(int64_t)(first + i) * ldb + b];
+    const float passes = cap_at_one ? (rt <= 1.f ? 1.f : 0.f) : 1.f;
+    const float d_scale = dot * passes;
+    const float den = sm + 1e-10f;
+    const float common = -(d_scale * oh / (den * den));
+    for (int i = 0; i < count; ++i)
+        d_out[(int64_t)(first + i) * ldb + b] = common + g_orders[(int64_t)order_row[first + i] * ldb + b] * sc;
+    if (e_self >= 0) d_out[(int64_t)e_self * ldb + b] = common;
+    g_on_hand[(int64_t)g * oh_stride + b] += d_scale / den;
 }
 
 int validate(const NicMlp3Desc* d, const char* who) {

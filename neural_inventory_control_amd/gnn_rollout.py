@@ -391,12 +391,6 @@ class GnnRollout:
             self.d_out = z(1, E, ld)
         self._key = key
 
-    def _fuse_env_ok(self):
-        """allocation + env step (and their adjoints) inside the period launches: one warehouse, or up to eight (round 6) unless
-        orders without a lead time take the upstream rule (a fix-up between the two that the fused launches have no place for)"""
-        P = self.plan
-        return bool(self.fuse_alloc_env) and (P.Wn == 1 or (P.Wn <= 8 and not self._zl_pairs))
-
     def _views(self, block, prob):
         store = block[:self.F_store].view(prob.S, prob.Ws, -1)
         wh = block[self.F_store:].view(prob.Wn, prob.Ww, -1)
@@ -454,7 +448,7 @@ class GnnRollout:
             self._zl_pairs = pairs
         if (self.zero_lead_orders, self._zl_pairs) != getattr(self, "_graph_rule", None):   # captured launches embody the rule
             self._graph_rule, self._graphs, self._eager_runs = (self.zero_lead_orders, self._zl_pairs), {}, 0
-            self._pdesc, self._bdesc = {}, {}   # (... and so do the cached launch descriptors: fused env step or not)
+            self._pdesc, self._bdesc = {}, {}   # (... and so do the cached launch descriptors)
         P.lead[0, :P.n_int].copy_(data["lead_times"][0][P.lead_store, P.lead_wh])
         P.lead[0, P.n_int:P.n_int + P.Wn].copy_(data["warehouse_lead_times"][0, :P.Wn])
         s0 = self._views(self.states[0], prob)
@@ -600,14 +594,12 @@ class GnnRollout:
                 q.H1, q.H2 = p(m.hist(m.H1, t)), p(m.hist(m.H2, t))
         if train:
             d.mlp[2].Ysum, d.mlp[3].Ysum = p(self.nodes1[tp]), p(self.edges1[tp])
-        d.fuse_env = int(self._fuse_env_ok())
+        d.fuse_env = int(P.Wn == 1 and bool(self.fuse_alloc_env))
         if d.fuse_env:
             st, nxt, orders = self._views(self.states[t], prob), self._views(self.states[t + 1], prob), self.orders[t]
-            ts, tw = self._order_tables(orders, prob)
-            d.io = prob.make_io(st.store, st.wh, None, Table(demand_soa[t + shift], ld, 1), ts, tw, None)
+            d.io = prob.make_io(st.store, st.wh, None, Table(demand_soa[t + shift], ld, 1), Table(orders[:S].view(S, 1, -1), ld, 1, ld),
+                                Table(orders[S:], ld, 1), None)
             d.e_self, d.e_supplier, d.cap_at_one = (-1 if P.e_self is None else P.e_self), P.e_supplier, int(not P.transshipment)
-            if P.Wn > 1:   # several supplying warehouses: the groups form of the allocation (round 6)
-                d.groups, d.order_row, d.n_groups = p(P.groups), p(P.order_row), P.Wn
             d.orders, d.sums, d.ratio, d.scale = p(orders), p(self.sums[t]), p(self.ratio[t]), p(self.scale[t])
             d.store_out, d.wh_out, d.reward = p(nxt.store), p(nxt.wh), p(self.rewards[t])
         d.edge_scratch = p(self.edge_scratch) if self.edge_scratch is not None else None
@@ -672,7 +664,7 @@ class GnnRollout:
         g_so, g_wo = self.g_orders[:S * P.Wn].view(S, P.Wn, -1), self.g_orders[S * P.Wn:]
         gc = self._views(g_cur, prob)
         fused = P.Wn == 1 and self.fuse_alloc_env
-        if self._period_bwd and self._fuse_env_ok():
+        if fused and self._period_bwd:
             # ... in the SAME launch as the MLP adjoints (round 6: the adjoint pair runs on the first wavefronts of nic_gnn_period_bwd)
             self._k("gnn_period_bwd", ops.gnn_period_bwd, self._period_bwd_desc(t, prob, g_cur, demand_soa, shift, g_next))
             return
@@ -758,11 +750,9 @@ class GnnRollout:
             st, orders = self._views(self.states[t], prob), self.orders[t]
             gn, gc = self._views(g_next, prob), self._views(g_cur, prob)
             d.fuse_env = 1
-            ts, tw = self._order_tables(orders, prob)
-            d.io = prob.make_io(st.store, st.wh, None, Table(demand_soa[t + shift], ld, 1), ts, tw, None)
+            d.io = prob.make_io(st.store, st.wh, None, Table(demand_soa[t + shift], ld, 1), Table(orders[:S].view(S, 1, -1), ld, 1, ld),
+                                Table(orders[S:], ld, 1), None)
             d.e_self, d.e_supplier, d.cap_at_one = (-1 if P.e_self is None else P.e_self), P.e_supplier, int(not P.transshipment)
-            if P.Wn > 1:
-                d.groups, d.order_row, d.n_groups, d.zero_first, d.zero_count = p(P.groups), p(P.order_row), P.Wn, P.e_demand, S
             d.sums, d.ratio, d.scale = p(self.sums[t]), p(self.ratio[t]), p(self.scale[t])
             d.g_store_out, d.g_wh_out, d.g_reward = p(gn.store), p(gn.wh), Table(self.g_reward, 0, 1).t2()
             d.g_store_in, d.g_wh_in, d.g_orders = p(gc.store), p(gc.wh), p(self.g_orders)
