@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import NicClosedFormDesc, NicTable2
-from .layout import EnvProblem, ProblemCache, pad_ld
+from .layout import EnvProblem, ProblemCache, demand_trace_soa, pad_ld
 
 POLICY_ID = {"base_stock": _lib.NIC_CF_BASE_STOCK, "capped_base_stock": _lib.NIC_CF_CAPPED,
              "echelon_stock": _lib.NIC_CF_ECHELON}
@@ -128,9 +128,7 @@ class ClosedFormRollout:
         self.prob = prob
         shift = observation_params["demand"]["period_shift"] if observation_params else 0
         if demand_soa is None:
-            d = data["demands"]
-            demand_soa = torch.zeros(d.shape[2], d.shape[1], ld, device=self.device)
-            demand_soa[:, :, :B] = d.permute(2, 1, 0)
+            demand_soa = demand_trace_soa(data["demands"], ld, self.device)
         if demand_soa.shape[0] < T + shift:
             raise ValueError("Current period is greater than the number of periods in the data")
         pack_state0(data, prob, self.state0)

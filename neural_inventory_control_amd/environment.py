@@ -12,7 +12,7 @@ Differences that are deliberate and invisible to callers:
 import torch
 
 from . import _lib, ops
-from .layout import EnvProblem, ProblemCache, Table, pad_ld, ref_view, to_soa
+from .layout import demand_trace_soa, EnvProblem, ProblemCache, Table, pad_ld, ref_view, to_soa
 from .ops import EnvState
 
 
@@ -113,9 +113,7 @@ class Simulator:
         self._lead_times = data["lead_times"]
         # demand trace in [T][S][ldb]: the per-period read of the kernel is then one contiguous (S x ldb) panel instead
         # of the reference's stride-T gather (environment.py:177)
-        d = data["demands"]
-        dem = torch.zeros(d.shape[2], d.shape[1], prob.ldb, device=dev)
-        dem[:, :, :B] = d.permute(2, 1, 0)
+        dem = demand_trace_soa(data["demands"], prob.ldb, dev)
         self._demand_soa = dem
         self._state = EnvState(
             to_soa(data["initial_inventories"], prob.ldb),

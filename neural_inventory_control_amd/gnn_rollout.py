@@ -19,7 +19,7 @@ they would compute there), and every sum over a node's edges still adds them in 
 import torch
 
 from . import _lib, ops
-from .layout import ProblemCache, Table
+from .layout import demand_trace_soa, ProblemCache, Table
 from .ops import EnvState, Mlp3Segment
 
 MODULES = ("initial_node", "initial_edge", "node_update", "edge_update", "output")
@@ -414,9 +414,7 @@ class GnnRollout:
         P = self.plan
         shift = observation_params["demand"]["period_shift"] if observation_params else 0
         if demand_soa is None:
-            d = data["demands"]
-            demand_soa = torch.zeros(d.shape[2], d.shape[1], ld, device=self.device)
-            demand_soa[:, :, :B] = d.permute(2, 1, 0)
+            demand_soa = demand_trace_soa(data["demands"], ld, self.device)
         if demand_soa.shape[0] < T + shift:
             raise ValueError("Current period is greater than the number of periods in the data")
         self.demand = demand_soa

@@ -23,7 +23,7 @@ import torch
 from . import _lib, ops
 from . import horizon_rollout as hz
 from . import small_rollout as sr
-from .layout import EnvProblem, ProblemCache, Table, pad_ld
+from .layout import demand_trace_soa, EnvProblem, ProblemCache, Table, pad_ld
 from .ops import EnvState
 
 _HEADS = {"vanilla_one_store": "softplus", "vanilla_warehouse": "warehouse", "vanilla_serial": "serial",
@@ -517,9 +517,7 @@ class FusedRollout:
         self.prob = prob
         shift = observation_params["demand"]["period_shift"] if observation_params else 0
         if demand_soa is None:
-            d = data["demands"]
-            demand_soa = torch.zeros(d.shape[2], d.shape[1], ld, device=dev)
-            demand_soa[:, :, :B] = d.permute(2, 1, 0)
+            demand_soa = demand_trace_soa(data["demands"], ld, dev)
         if self._graph_on():
             if self.demand_buf is None or self.demand_buf.shape != demand_soa.shape:
                 self.demand_buf, self._graphs, self._eager_runs = torch.empty_like(demand_soa), {}, 0

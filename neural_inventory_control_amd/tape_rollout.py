@@ -19,7 +19,7 @@ import torch
 from . import _lib
 from . import horizon_rollout as hz
 from ._lib import NicHorizonDesc
-from .layout import ProblemCache, Table
+from .layout import demand_trace_soa, ProblemCache, Table
 
 _QUANTILE = ("TransformedNV", "QuantileNV", "ReturnsNV", "FixedQuantile")
 
@@ -177,8 +177,7 @@ class TapeRollout:
         want_grad = bool(train) and torch.is_grad_enabled() and bool(getattr(self.model, "trainable", True)) and not self.jit
         self._setup(prob, T, want_grad)
         self.prob = prob
-        demand_soa = torch.zeros(d.shape[2], d.shape[1], ld, device=self.device)
-        demand_soa[:, :, :B] = d.permute(2, 1, 0)
+        demand_soa = demand_trace_soa(d, ld, self.device)
         a = prob.S * prob.Ws
         self.state0[:a].view(prob.S, prob.Ws, ld)[:, :, :B].copy_(data["initial_inventories"].permute(1, 2, 0))
         if prob.Wn:

@@ -432,3 +432,28 @@ def test_load_model_puts_step_counters_where_this_optimizers_implementation_want
                 assert (step.device.type == "meta") == on_device
                 if not on_device:
                     assert float(step) == 2.0
+
+
+def test_demand_trace_view_is_taken_only_for_full_kernel_layout_rows():
+    """layout.demand_trace_soa: a (B, S, T) batch that is a `ref_view` of a [T][S][ldb] trace with B == ldb comes back as that
+    storage; ragged rows (padding lanes of unknown content), other strides and other dtypes are transposed into a fresh buffer."""
+    import torch
+    from neural_inventory_control_amd.layout import demand_trace_soa, ref_view
+    for T, S, ld, B in ((5, 3, 64, 64), (5, 1, 128, 128), (1, 1, 64, 64), (5, 3, 64, 50), (4, 2, 64, 1)):
+        soa = torch.randn(T, S, ld)
+        soa[:, :, B:] = 0
+        d = soa[:, :, :B].permute(2, 1, 0)
+        v = demand_trace_soa(d, ld)
+        assert torch.equal(v, soa) and v.shape == (T, S, ld)
+        assert (v.data_ptr() == soa.data_ptr()) == (B == ld and B > 1)
+        c = d.clone()   # (what a captured step keeps as its static input: the strides of a dense view survive a clone)
+        assert torch.equal(demand_trace_soa(c, ld), soa)
+        x = torch.randn(B, S, T)
+        out = demand_trace_soa(x, ld)
+        assert torch.equal(out[:, :, :B], x.permute(2, 1, 0)) and not out[:, :, B:].any()
+        assert out.data_ptr() != x.data_ptr() or (S == 1 and T == 1)   # (one store, one period: the two layouts coincide)
+    wide = torch.randn(6, 2, 128)   # a (B = 64)-column window of a 128-wide trace: stride 128, not this batch's ldb
+    w = wide[:, :, :64].permute(2, 1, 0)
+    assert demand_trace_soa(w, 64).data_ptr() != wide.data_ptr()
+    dbl = torch.randn(4, 2, 64, dtype=torch.float64).permute(2, 1, 0)
+    assert demand_trace_soa(dbl, 64).dtype == torch.float32
