@@ -347,6 +347,15 @@ class GnnRollout:
                     for name, k, ne in zip(MODULES, ks, ents)}
         self._graphs, self._eager_runs, self._auto_graph = {}, 0, None   # (a new shape is measured afresh)
         self._period, self._pdesc, self.edge_scratch = False, {}, None
+        self._slab_flat = None
+        if train:   # the fifteen weight-gradient slabs as views of one allocation: one fill per step zeroes them all
+            sizes = [sl.numel() for m in self.mlp.values() for sl in m.slabs]
+            self._slab_flat = torch.zeros(sum(sizes), device=dev)
+            at = 0
+            for m in self.mlp.values():
+                for i, sl in enumerate(m.slabs):
+                    m.slabs[i] = self._slab_flat[at:at + sl.numel()].view(sl.shape)
+                    at += sl.numel()
         if self.use_period_kernel:
             fits = ops.gnn_period_ok(N, E, self.Dn)
             hist_ok = (not train) or self._mode_now == "fused" or (self._mode_now == "hist" and self.mlp["output"].native)
@@ -389,6 +398,13 @@ class GnnRollout:
             self.d_nodes0, self.d_nodes1 = z(32, N, ld), z(32, N, ld)
             self.d_edges0, self.d_edges1 = z(32, E, ld), z(32, E, ld)
             self.d_out = z(1, E, ld)
+        # every packed form of the weights (per-MLP launches, forward period kernel, backward period kernel) from ONE gather per run
+        items = [(m, ["packed", "packed_t"]) for m in self.mlp.values()]
+        if self._period:
+            items += [(pk, ["buf"]) for pk in self.ppack.values()]
+        if train and self._period_bwd:
+            items += [(pk, ["buf"]) for pk in self.bpack.values()]
+        self._wplan = ops.WeightPackPlan(items, dev)
         self._key = key
 
     def _views(self, block, prob):
@@ -418,15 +434,8 @@ class GnnRollout:
         if demand_soa.shape[0] < T + shift:
             raise ValueError("Current period is greater than the number of periods in the data")
         self.demand = demand_soa
-        for m in self.mlp.values():
-            m.pack()
+        self._wplan.pack()
         self._train = bool(train)
-        if self._period:
-            for pk in self.ppack.values():
-                pk.pack()
-        if train and self._period_bwd:
-            for pk in self.bpack.values():
-                pk.pack()
         # per-edge lead-time input rows: sample 0 of THIS batch stands for the batch, as upstream re-reads it every forward
         # (:984) - refreshed on the device (no sync, capturable), so a later batch of the same shape never sees stale values
         self._zl_pairs = ()
@@ -491,9 +500,7 @@ class GnnRollout:
             grad_scale = 1.0 / (B * T * self.problem_params["n_stores"])
         self.g_reward.zero_()
         self.g_reward[:B] = grad_scale
-        for m in self.mlp.values():
-            for sl in m.slabs:
-                sl.zero_()
+        self._slab_flat.zero_()
         self.g_state[0].zero_()
 
         def backward():

@@ -457,3 +457,29 @@ def test_demand_trace_view_is_taken_only_for_full_kernel_layout_rows():
     assert demand_trace_soa(w, 64).data_ptr() != wide.data_ptr()
     dbl = torch.randn(4, 2, 64, dtype=torch.float64).permute(2, 1, 0)
     assert demand_trace_soa(dbl, 64).dtype == torch.float32
+
+
+def test_weight_pack_plan_reproduces_every_packer_with_one_gather():
+    """ops.WeightPackPlan: the packers run once on stand-in parameters holding their own positions; afterwards ONE concatenation + ONE
+    gather refresh all their buffers - same contents as each packer's own `pack()`, also after the parameters change, and the
+    buffers are views of one allocation at 256-byte offsets."""
+    import torch
+    from neural_inventory_control_amd import ops
+    torch.manual_seed(3)
+    lins = [torch.nn.Linear(37, 32), torch.nn.Linear(32, 32), torch.nn.Linear(32, 32)]
+    outs = [torch.nn.Linear(45, 32), torch.nn.Linear(32, 32), torch.nn.Linear(32, 1)]
+    mk = lambda: [ops.GnnPeriodBwdPack(lins, 32, 2, "cpu"), ops.GnnPeriodBwdPack(outs, 1, 1, "cpu"),
+                  ops.GnnPeriodBwdPack(lins, 32, 1, "cpu")]   # noqa: E731  (the same layers packed twice, differently)
+    direct, planned = mk(), mk()
+    plan = ops.WeightPackPlan([(p, ["buf"]) for p in planned], "cpu")
+    for rnd in range(2):
+        for p in direct:
+            p.pack()
+        plan.pack()
+        for a, b in zip(direct, planned):
+            assert torch.equal(a.buf, b.buf) and a.buf.abs().sum() > 0
+            assert b.buf.untyped_storage().data_ptr() == plan.buf.untyped_storage().data_ptr() and b.buf.storage_offset() % 64 == 0
+        with torch.no_grad():
+            for lin in lins + outs:
+                lin.weight.add_(1.0)
+                lin.bias.mul_(2.0)
