@@ -2,7 +2,8 @@
 // store chain for all T periods; 64-lane workgroups (one wavefront) so that 32k scenarios already spread over every CU.
 // HBM traffic: 4 B of demand per chain-period, nothing else in the period loop unless reward_hist is requested.
 // Latency-bound below ~10^6 chains (one dependent ~60-instruction chain per period per lane); the next period's demand is
-// always in flight.
+// always in flight.  The echelon chain (4 levels) is bound by vector issue: ~265 vector instructions per wave-period, tangents as
+// packed pairs (closed_form_body.h).
 #include "nic_common.h"
 #include "closed_form_body.h"
 

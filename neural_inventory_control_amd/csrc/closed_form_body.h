@@ -22,41 +22,95 @@ namespace nic {
 
 constexpr int CF_MAXE = 3;
 
+// Tangents are held as PAIRS (two floats in an aligned register pair) plus, for an odd NP, one single float: every tangent
+// operation below is one packed instruction per pair (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 - the chain's period is bound by
+// vector issue) by construction, not by the vectoriser's choice (round 6: left to itself it also packed unrelated scalars and paid
+// 2-4 register moves per packed add).
+typedef float CfPair __attribute__((vector_size(8)));
+
+NIC_HD CfPair cf_pair(float x) {
+    CfPair r = {x, x};
+    return r;
+}
+NIC_HD CfPair cf_pair_fma(float m, CfPair a, CfPair v) {   // fma(m, a, v) per lane (one rounding)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_elementwise_fma(cf_pair(m), a, v);
+#else
+    CfPair r = {fmaf(m, a[0], v[0]), fmaf(m, a[1], v[1])};
+    return r;
+#endif
+}
+
+template <int NP>
+struct Tan {   // NP derivatives
+    static constexpr int kPairs = NP / 2;
+    static constexpr bool kOdd = (NP & 1) != 0;
+    CfPair p[kPairs > 0 ? kPairs : 1];
+    float t;   // the last derivative of an odd NP
+    NIC_HD float get(int j) const { return (kOdd && j == NP - 1) ? t : p[j >> 1][j & 1]; }
+};
+#define NIC_CF_TAN_OP(EXPR_PAIR, EXPR_TAIL)                            \
+    Tan<NP> r;                                                         \
+    _Pragma("unroll") for (int i = 0; i < Tan<NP>::kPairs; ++i) r.p[i] = (EXPR_PAIR); \
+    if (Tan<NP>::kPairs == 0) r.p[0] = cf_pair(0.f);                   \
+    r.t = Tan<NP>::kOdd ? (EXPR_TAIL) : 0.f;                           \
+    return r
+template <int NP>
+NIC_HD Tan<NP> tan_zero() { NIC_CF_TAN_OP(cf_pair(0.f), 0.f); }
+template <int NP>
+NIC_HD Tan<NP> tan_unit(int which) {
+    NIC_CF_TAN_OP((CfPair{2 * i == which ? 1.f : 0.f, 2 * i + 1 == which ? 1.f : 0.f}), which == NP - 1 ? 1.f : 0.f);
+}
+template <int NP>
+NIC_HD Tan<NP> operator+(const Tan<NP>& a, const Tan<NP>& b) { NIC_CF_TAN_OP(a.p[i] + b.p[i], a.t + b.t); }
+template <int NP>
+NIC_HD Tan<NP> operator-(const Tan<NP>& a, const Tan<NP>& b) { NIC_CF_TAN_OP(a.p[i] - b.p[i], a.t - b.t); }
+template <int NP>
+NIC_HD Tan<NP> operator-(const Tan<NP>& a) { NIC_CF_TAN_OP(-a.p[i], -a.t); }
+template <int NP>
+NIC_HD Tan<NP> operator*(float c, const Tan<NP>& a) { NIC_CF_TAN_OP(cf_pair(c) * a.p[i], c * a.t); }
+template <int NP>
+NIC_HD Tan<NP> tan_fma(float m, const Tan<NP>& a, const Tan<NP>& v) {   // fma(m, a, v) per derivative (one rounding)
+    NIC_CF_TAN_OP(cf_pair_fma(m, a.p[i], v.p[i]), fmaf(m, a.t, v.t));
+}
+template <int NP>
+NIC_HD Tan<NP> tan_select(bool c, const Tan<NP>& a, const Tan<NP>& b) {
+    NIC_CF_TAN_OP((CfPair{c ? a.p[i][0] : b.p[i][0], c ? a.p[i][1] : b.p[i][1]}), c ? a.t : b.t);
+}
+#undef NIC_CF_TAN_OP
+
 template <int NP>
 struct Dual {
     float v;
-    float d[NP > 0 ? NP : 1];
+    Tan<NP> d;
 };
 
 template <int NP>
 NIC_HD Dual<NP> dconst(float v) {
     Dual<NP> r;
     r.v = v;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.d[j] = 0.f;
+    r.d = tan_zero<NP>();
     return r;
 }
 template <int NP>
 NIC_HD Dual<NP> dparam(float v, int which) {  // d(level_which)/d(level_j) = [j == which]
-    Dual<NP> r = dconst<NP>(v);
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.d[j] = j == which ? 1.f : 0.f;
+    Dual<NP> r;
+    r.v = v;
+    r.d = tan_unit<NP>(which);
     return r;
 }
 template <int NP>
 NIC_HD Dual<NP> operator+(const Dual<NP>& a, const Dual<NP>& b) {
     Dual<NP> r;
     r.v = a.v + b.v;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.d[j] = a.d[j] + b.d[j];
+    r.d = a.d + b.d;
     return r;
 }
 template <int NP>
 NIC_HD Dual<NP> operator-(const Dual<NP>& a, const Dual<NP>& b) {
     Dual<NP> r;
     r.v = a.v - b.v;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.d[j] = a.d[j] - b.d[j];
+    r.d = a.d - b.d;
     return r;
 }
 template <int NP>
@@ -69,16 +123,14 @@ template <int NP>
 NIC_HD Dual<NP> dneg(const Dual<NP>& a) {
     Dual<NP> r;
     r.v = -a.v;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.d[j] = -a.d[j];
+    r.d = -a.d;
     return r;
 }
 template <int NP>
 NIC_HD Dual<NP> dscale(float c, const Dual<NP>& a) {
     Dual<NP> r;
     r.v = c * a.v;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.d[j] = c * a.d[j];
+    r.d = c * a.d;
     return r;
 }
 // torch.clip(x, min=0): value max(x, 0); clamp's backward passes the gradient where x >= min
@@ -86,13 +138,12 @@ template <int NP>
 NIC_HD Dual<NP> drelu(const Dual<NP>& a) {
     Dual<NP> r;
     r.v = a.v > 0.f ? a.v : 0.f;
-    const float m = a.v >= 0.f ? 1.f : 0.f;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.d[j] = m * a.d[j];
+    r.d = (a.v >= 0.f ? 1.f : 0.f) * a.d;
     return r;
 }
 // torch.clip(x, min=0 (constant tensor), max=cap (tensor)): clamp.Tensor — self gets the gradient where min <= x <= max, max
-// where x > max (or max < min)
+// where x > max (or max < min).  (Tangents: the second product is added by a fused multiply-add - every VALUE in this file keeps
+// the reference's separate multiply and add; at most one of the two factors is not 0 here, so the sum is exact either way)
 template <int NP>
 NIC_HD Dual<NP> dclamp0_cap(const Dual<NP>& x, const Dual<NP>& cap) {
     Dual<NP> r;
@@ -100,8 +151,7 @@ NIC_HD Dual<NP> dclamp0_cap(const Dual<NP>& x, const Dual<NP>& cap) {
     r.v = lo < cap.v ? lo : cap.v;
     const float mx = (x.v >= 0.f && x.v <= cap.v) ? 1.f : 0.f;
     const float mc = (x.v > cap.v || cap.v < 0.f) ? 1.f : 0.f;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.d[j] = mx * x.d[j] + mc * cap.d[j];
+    r.d = tan_fma(mx, x.d, mc * cap.d);
     return r;
 }
 // torch.minimum(a, b): the smaller operand gets the gradient, a tie splits it 0.5 / 0.5
@@ -110,18 +160,59 @@ NIC_HD Dual<NP> dmin(const Dual<NP>& a, const Dual<NP>& b) {
     Dual<NP> r;
     r.v = a.v < b.v ? a.v : b.v;
     const float wa = a.v < b.v ? 1.f : (a.v == b.v ? 0.5f : 0.f);
-    const float wb = 1.f - wa;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.d[j] = wa * a.d[j] + wb * b.d[j];
+    r.d = tan_fma(wa, a.d, (1.f - wa) * b.d);
     return r;
 }
 template <int NP>
 NIC_HD Dual<NP> dmin_const(const Dual<NP>& a, float c) {  // minimum(a, constant)
     Dual<NP> r;
     r.v = a.v < c ? a.v : c;
-    const float wa = a.v < c ? 1.f : (a.v == c ? 0.5f : 0.f);
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.d[j] = wa * a.d[j];
+    r.d = (a.v < c ? 1.f : (a.v == c ? 0.5f : 0.f)) * a.d;
+    return r;
+}
+// c * clip(a, min=0) and minimum(clip(x, min=0), up) with the clip's 0 / 1 mask folded into the factor of the tangents:
+// c * (m * d) = (c * m) * d and wa * (m * d) = (wa * m) * d exactly (m is 0 or 1, wa is 0, 0.5 or 1), one packed multiply less each
+// (round 6)
+template <int NP>
+NIC_HD Dual<NP> dscale_relu(float c, const Dual<NP>& a) {
+    Dual<NP> r;
+    r.v = c * (a.v > 0.f ? a.v : 0.f);
+    r.d = (c * (a.v >= 0.f ? 1.f : 0.f)) * a.d;
+    return r;
+}
+// acc + c * clip(a, min=0): the tangent's multiply and add are one fused multiply-add per pair (tangents only)
+template <int NP>
+NIC_HD Dual<NP> dadd_scale_relu(const Dual<NP>& acc, float c, const Dual<NP>& a) {
+    Dual<NP> r;
+    r.v = acc.v + c * (a.v > 0.f ? a.v : 0.f);
+    r.d = tan_fma(c * (a.v >= 0.f ? 1.f : 0.f), a.d, acc.d);
+    return r;
+}
+// p * clip(-a, min=0) + h * clip(a, min=0) (underage + holding cost of what is left after demand, environment.py:198-201): the
+// two clips pass the gradient on opposite sides of 0 (both at exactly 0), so the tangent is (h [a >= 0] - p [a <= 0]) * a'
+template <int NP>
+NIC_HD Dual<NP> dcost_backlog(float p, float h, const Dual<NP>& a) {
+    Dual<NP> r;
+    const float na = -a.v;
+    r.v = p * (na > 0.f ? na : 0.f) + h * (a.v > 0.f ? a.v : 0.f);
+    r.d = (h * (a.v >= 0.f ? 1.f : 0.f) - p * (na >= 0.f ? 1.f : 0.f)) * a.d;
+    return r;
+}
+template <int NP>
+NIC_HD Dual<NP> dmin_relu(const Dual<NP>& x, const Dual<NP>& b) {
+    Dual<NP> r;
+    const float want = x.v > 0.f ? x.v : 0.f;
+    r.v = want < b.v ? want : b.v;
+    const float wa = want < b.v ? 1.f : (want == b.v ? 0.5f : 0.f);
+    r.d = tan_fma(wa * (x.v >= 0.f ? 1.f : 0.f), x.d, (1.f - wa) * b.d);
+    return r;
+}
+template <int NP>
+NIC_HD Dual<NP> dmin_relu_const(const Dual<NP>& x, float c) {
+    Dual<NP> r;
+    const float want = x.v > 0.f ? x.v : 0.f;
+    r.v = want < c ? want : c;
+    r.d = ((want < c ? 1.f : (want == c ? 0.5f : 0.f)) * (x.v >= 0.f ? 1.f : 0.f)) * x.d;
     return r;
 }
 template <int NP>
@@ -161,6 +252,7 @@ struct CfOrders {
 template <int NP, int MW>
 struct CfPipe {
     Dual<NP> s[MW];
+    float hot[MW];   // 1 in the slot an order placed now lands in (lead - 1), else 0: fixed for the horizon (cf_pipe_set_lead)
 };
 
 // sum of the live slots, left to right (x.sum(dim=2) over one pipeline, neural_networks.py:226).  INVARIANT of every pipeline
@@ -197,14 +289,14 @@ NIC_HD CfPipe<NP, MW> cf_pipe_step_c(const CfPipe<NP, MW>& old, const Dual<NP>& 
         if (k + 1 < MW && k < WC - 1) v = old.s[k + 1 < MW ? k + 1 : k];
         if (k == 0) v = after + v;
         nw.s[k] = v;
+        nw.hot[k] = old.hot[k];
     }
 #pragma unroll
     for (int k = 0; k < MW; ++k)
         if (k == uniform_slot) {   // (uniform: a scalar branch)
             const Dual<NP> w = nw.s[k] + a;
             nw.s[k].v = place ? w.v : nw.s[k].v;
-#pragma unroll
-            for (int j = 0; j < NP; ++j) nw.s[k].d[j] = place ? w.d[j] : nw.s[k].d[j];
+            nw.s[k].d = tan_select(place, w.d, nw.s[k].d);
         }
     return nw;
 }
@@ -216,19 +308,34 @@ NIC_HD CfPipe<NP, MW> cf_pipe_step_c(const CfPipe<NP, MW>& old, const Dual<NP>& 
 template <int NP, int MW>
 NIC_HD CfPipe<NP, MW> cf_pipe_step(const CfPipe<NP, MW>& old, int /*W*/, const Dual<NP>& after, const Dual<NP>& a, float lead) {
     CfPipe<NP, MW> nw;
-    const int slot = (a.v != 0.f) ? (int)lead - 1 : -1;  // zero orders are filtered out before the put (:426-429)
+    // the slot's 0 / 1 factor = [the order is not 0] x [slot == lead - 1], both as floats in vector registers (round 6: as lane
+    // masks the second one lived in 32 scalar registers, and each slot's factor took a scalar AND between two vector
+    // instructions - a round trip through the scalar unit in the middle of the period's dependency chain)
+    const float placed = (a.v != 0.f) ? 1.f : 0.f;  // zero orders are filtered out before the put (:426-429)
+    (void)lead;
 #pragma unroll
     for (int k = 0; k < MW; ++k) {
         Dual<NP> v = dconst<NP>(0.f);
         if (k + 1 < MW) v = old.s[k + 1 < MW ? k + 1 : k];
         if (k == 0) v = after + v;
-        const float m = k == slot ? 1.f : 0.f;
+        const float m = placed * old.hot[k];
         v.v = fmaf(m, a.v, v.v);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) v.d[j] = fmaf(m, a.d[j], v.d[j]);
+        v.d = tan_fma(m, a.d, v.d);
         nw.s[k] = v;
+        nw.hot[k] = old.hot[k];
     }
     return nw;
+}
+template <int NP, int MW>
+NIC_HD void cf_pipe_set_lead(CfPipe<NP, MW>& p, float lead) {
+#pragma unroll
+    for (int k = 0; k < MW; ++k) {
+        float h = k == (int)lead - 1 ? 1.f : 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(h));   // (kept a number: the optimiser would otherwise fold the product above back into lane masks)
+#endif
+        p.hot[k] = h;
+    }
 }
 
 // state of one chain: the store's pipeline and, for CHAIN, the warehouse's and up to CF_MAXE echelons'
@@ -253,23 +360,22 @@ NIC_HD Dual<NP> cf_env_step(const NicClosedFormDesc& d, const CfStatics& c, CfSt
     const Dual<NP> on_hand = st.store.s[0];
     Dual<NP> after = dsub(on_hand, dem);
     Dual<NP> cost;
-    if (maximize_profit) cost = dscale(-c.p, dmin_const(on_hand, dem)) + dscale(c.h, drelu(after));  // :191-194
-    else cost = dscale(c.p, drelu(dneg(after))) + dscale(c.h, drelu(after));                            // :198-201
+    if (maximize_profit) cost = dscale(-c.p, dmin_const(on_hand, dem)) + dscale_relu(c.h, after);    // :191-194
+    else cost = dcost_backlog(c.p, c.h, after);                                                         // :198-201
     if (lost_demand) after = drelu(after);                                                            // :204-205
     Dual<NP> total = cost;
     if (CHAIN) {
         // the warehouse ships what the store ordered (no clip, :249); echelon e ships what its downstream neighbour ordered
         const Dual<NP> w_after = st.wh.s[0] - o.store;
-        Dual<NP> cw = dscale(c.wh_h, drelu(w_after));
-        if (d.wh_edge.p) cw = cw + dscale(c.wh_edge, o.wh);
-        total = total + cw;
+        if (d.wh_edge.p) total = total + (dscale_relu(c.wh_h, w_after) + dscale(c.wh_edge, o.wh));
+        else total = dadd_scale_relu(total, c.wh_h, w_after);
         Dual<NP> r_e = dconst<NP>(0.f);
 #pragma unroll
         for (int e = 0; e < CF_MAXE; ++e) {
             if (e < nE) {
                 const Dual<NP> ship = (e < nE - 1) ? o.ech[(e + 1 < CF_MAXE) ? e + 1 : e] : o.wh;
                 const Dual<NP> e_after = st.ech[CHAIN ? e : 0].s[0] - ship;
-                r_e = r_e + dscale(c.e_h[e], drelu(e_after));
+                r_e = dadd_scale_relu(r_e, c.e_h[e], e_after);
                 st.ech[CHAIN ? e : 0] = cf_pipe_step(st.ech[CHAIN ? e : 0], d.We, e_after, o.ech[e], c.e_lead[e]);
             }
         }
@@ -302,40 +408,52 @@ NIC_HD CfOrders<NP> cf_policy(const NicClosedFormDesc& d, const Dual<NP> (&lv)[N
 #pragma unroll
         for (int e = 0; e < CF_MAXE; ++e) pos[e] = e < nE ? cf_pipe_sum(st.ech[CHAIN ? e : 0], d.We) : dconst<NP>(0.f);
         const Dual<NP> wh_pos = cf_pipe_sum(st.wh, d.Ww);
+        // tangents of the sums pos[:, k:].sum(dim=1) for every k at once, from the store upwards (each is the next one plus one
+        // location: E + 1 packed additions per pair instead of (E + 1)(E + 2) / 2; the VALUES below are summed per k in the
+        // reference's order)
+        Dual<NP> suf[CF_MAXE + 2];
+        suf[CF_MAXE + 1] = store_pos;
+        suf[CF_MAXE] = wh_pos + store_pos;
+#pragma unroll
+        for (int e = CF_MAXE - 1; e >= 0; --e) suf[e] = e < nE ? pos[e] + suf[e + 1] : suf[e + 1];
 #pragma unroll
         for (int k = 0; k < CF_MAXE + 2; ++k) {
             if (k < nE + 2) {
                 // pos[:, k:].sum(dim=1), in location order (echelons k.., warehouse, store)
-                Dual<NP> s = dconst<NP>(0.f);
+                float sv = 0.f;
                 bool first = true;
 #pragma unroll
                 for (int e = 0; e < CF_MAXE; ++e)
                     if (e >= k && e < nE) {
-                        s = first ? pos[e] : s + pos[e];
+                        sv = first ? pos[e].v : sv + pos[e].v;
                         first = false;
                     }
                 if (k <= nE) {
-                    s = first ? wh_pos : s + wh_pos;
+                    sv = first ? wh_pos.v : sv + wh_pos.v;
                     first = false;
                 }
-                s = first ? store_pos : s + store_pos;
-                const Dual<NP> want = drelu(lv[k < NIC_CF_MAX_LEVELS ? k : 0] - s);
+                sv = first ? store_pos.v : sv + store_pos.v;
+                // (location k's suffix: echelon k for k < nE, the warehouse for k == nE, the store for k == nE + 1)
+                Dual<NP> s = k < nE ? suf[k < CF_MAXE ? k : 0] : (k == nE ? suf[CF_MAXE] : suf[CF_MAXE + 1]);
+                s.v = sv;
+                const Dual<NP> want = lv[k < NIC_CF_MAX_LEVELS ? k : 0] - s;   // (its clip(min=0) is inside the minimum below)
                 Dual<NP> a;
-                if (k == 0) a = dmin_const(want, 1000000.f);  // the outside supplier never binds (:262)
+                if (k == 0) a = dmin_relu_const(want, 1000000.f);  // the outside supplier never binds (:262)
                 else if (k <= nE) {                            // on hand of echelon k-1
                     Dual<NP> up = dconst<NP>(0.f);
 #pragma unroll
                     for (int e = 0; e < CF_MAXE; ++e)
                         if (e == k - 1) up = st.ech[CHAIN ? e : 0].s[0];
-                    a = dmin(want, up);
-                } else a = dmin(want, st.wh.s[0]);             // on hand of the warehouse
+                    a = dmin_relu(want, up);
+                } else a = dmin_relu(want, st.wh.s[0]);        // on hand of the warehouse
                 if (k < nE) o.ech[k < CF_MAXE ? k : 0] = a;
                 else if (k == nE) o.wh = a;
                 else o.store = a;
             }
         }
     }
-    if (FL < 0 ? (bool)d.round_orders : (bool)(FL & 1)) {  // discrete allocation (trainer.py:201-202)
+    // (a launch with tangents never rounds - the entry point refuses the combination: rounded orders have zero gradient)
+    if (NP == 0 && (FL < 0 ? (bool)d.round_orders : (bool)(FL & 1))) {  // discrete allocation (trainer.py:201-202)
         o.store = dround(o.store);
         o.wh = dround(o.wh);
 #pragma unroll
@@ -411,6 +529,10 @@ NIC_HD void closed_form_chain(const NicClosedFormDesc& d, float* reward_hist, fl
 #pragma unroll
     for (int e = 0; e < (CHAIN ? CF_MAXE : 1); ++e)
         cf_pipe_load(st.ech[e], s0 + (int64_t)(d.Ws + d.Ww + e * d.We) * ldb, (CHAIN && e < d.E) ? d.We : 0, ldb);
+    cf_pipe_set_lead(st.store, c.lead);
+    cf_pipe_set_lead(st.wh, c.wh_lead);
+#pragma unroll
+    for (int e = 0; e < (CHAIN ? CF_MAXE : 1); ++e) cf_pipe_set_lead(st.ech[e], c.e_lead[e < CF_MAXE ? e : 0]);
     Dual<NP> total = dconst<NP>(0.f);
     float reported = 0.f;
     const float* dem_p = d.demand + ((int64_t)d.t0 * d.S + s) * ldb + b;
@@ -459,7 +581,7 @@ NIC_HD void closed_form_chain(const NicClosedFormDesc& d, float* reward_hist, fl
         }
     }
 #pragma unroll
-    for (int j = 0; j < NP; ++j) g[j] = total.d[j];
+    for (int j = 0; j < NP; ++j) g[j] = total.d.get(j);
 }
 
 }  // namespace nic
