@@ -100,3 +100,65 @@ def check_against_golden(out):
         worst = max(worst, rel)
         assert rel <= 1e-5, (k, rel)
     return worst
+
+
+def random_serial_case(seed):
+    """A serial system drawn at random (1-3 extra echelons, lead times of 2-4 periods (a pipeline of one slot fails in the reference itself), costs, demand moments, lost demand / profit switches,
+    n and T off the kernel's batch sizes), its data from the oracle's restatement of the reference's `Scenario`, and an
+    echelon_stock policy with random levels."""
+    import random
+    from collections import defaultdict
+    from neural_inventory_control_amd import workloads
+    from oracle import inventory_oracle as orc
+    rnd = random.Random(seed)
+    s = workloads.serial_system()
+    E = rnd.choice([1, 2, 3])
+    s["problem_params"].update({"n_extra_echelons": E, "lost_demand": rnd.random() < 0.5, "maximize_profit": rnd.random() < 0.3})
+    s["store_params"]["lead_time"] = workloads._const(rnd.randint(2, 4))
+    s["store_params"]["holding_cost"] = workloads._const(round(rnd.uniform(0.5, 2.0), 2))
+    s["store_params"]["underage_cost"] = workloads._const(round(rnd.uniform(2.0, 12.0), 2))
+    s["store_params"]["demand"].update({"mean": round(rnd.uniform(3.0, 8.0), 2), "std": round(rnd.uniform(0.5, 3.0), 2)})
+    s["warehouse_params"] = {"holding_cost": round(rnd.uniform(0.2, 0.9), 2), "lead_time": rnd.randint(2, 4)}
+    s["echelon_params"] = {"holding_cost": [round(rnd.uniform(0.05, 0.4), 2) for _ in range(E)],
+                           "lead_time": [rnd.randint(2, 4) for _ in range(E)]}
+    s["seeds"] = dict(s["seeds"], demand=1000 + seed)
+    n, T = rnd.choice([70, 128, 200]), rnd.choice([5, 8, 13, 19])
+    obs = defaultdict(lambda: None, s["observation_params"])
+    data = orc.generate_scenario_data(T, s["problem_params"], s["store_params"], s["warehouse_params"], s["echelon_params"], n, obs,
+                                      s["seeds"])
+    nn = workloads._closed_form("echelon_stock", E + 2, None, None)
+    pol = orc.init_policy(nn, s["problem_params"], 1, 77 + seed, s["store_params"])
+    with torch.no_grad():   # levels of the order of a few periods of demand, different per location
+        pol.layers[0][1].copy_(torch.tensor([rnd.uniform(-9.0, -4.0) for _ in range(E + 2)]))
+    return s, nn, pol, data, obs, n, T
+
+
+def check_random_serial_case(seed, launch, dev):
+    """The chain kernel (or its host build) against the oracle's autograd on `random_serial_case(seed)`: per-period costs and
+    the gradient of the mean cost with respect to the policy's parameters."""
+    from oracle import inventory_oracle as orc
+    s, nn, pol, data, obs, n, T = random_serial_case(seed)
+    res, _, grads = orc.train_step_gradients(pol, T, s["problem_params"], data, obs)
+    dd = {k: v.to(dev) for k, v in data.items()}
+    prob = EnvProblem(s["problem_params"], dd, dev)
+    assert cf.supports_shapes("echelon_stock", prob), seed
+    params = {"net.master.0.weight": pol.layers[0][0].detach(), "net.master.0.bias": pol.layers[0][1].detach()}
+    levels, (w, b) = levels_from_params(nn, params)
+    lv = levels.detach().float().contiguous().to(dev)
+    ld, S = prob.ldb, prob.S
+    demand = torch.zeros(dd["demands"].shape[2], S, ld, device=dev)
+    demand[:, :, :n] = dd["demands"].permute(2, 1, 0)
+    state0 = cf.pack_state0(dd, prob)
+    rewards, totals, final = (torch.zeros(T, S, ld, device=dev), torch.zeros(2, S, ld, device=dev),
+                              torch.zeros(S, state0.shape[1], ld, device=dev))
+    desc = cf.make_desc(prob, "echelon_stock", T, 0, 0, lv, demand, state0)
+    g_levels = launch(desc, rewards, totals, final, lv.numel(), True)
+    torch.testing.assert_close(rewards[:, :, :n].sum(dim=1).cpu(), res.per_period, rtol=2e-6, atol=2e-5)
+    levels.backward((g_levels / (n * T)).float())
+    worst = 0.0
+    for got, ref in zip((w.grad, b.grad), grads):
+        if float(ref.abs().max()) == 0.0:
+            assert float(got.abs().max()) == 0.0
+            continue
+        worst = max(worst, float((got - ref).norm() / ref.norm()))
+    return worst

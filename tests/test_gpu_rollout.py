@@ -1506,6 +1506,15 @@ def test_closed_form_kernel_matches_reference(name):
     assert worst <= GRAD_TOL
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_closed_form_chain_on_random_serial_systems_matches_oracle(seed):
+    """1-3 extra echelons, random lead times / costs / demand moments / lost-demand and profit switches, n and T off the
+    kernel's batch sizes: the chain kernel through the C ABI against the oracle's autograd (per-period costs, gradient of the
+    mean cost with respect to the policy's parameters at 1e-5)."""
+    import closed_form_checks as cfc
+    assert cfc.check_random_serial_case(seed, cfc.hip_launch(), DEV) <= GRAD_TOL
+
+
 @pytest.mark.parametrize("name", CLOSED_FORM_CASES)
 def test_trainer_takes_closed_form_route_and_matches_reference(name):
     """`Trainer.simulate_batch` + the reference idiom `(total / n).backward()` on a closed-form policy: one kernel for the

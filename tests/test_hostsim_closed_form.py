@@ -31,3 +31,10 @@ def test_closed_form_profit_objective_matches_oracle(launch, name):
         if float(ref.abs().max()) == 0.0:
             continue
         assert float((got - ref).norm() / ref.norm()) <= 1e-5, k
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_closed_form_chain_on_random_serial_systems_matches_oracle(launch, seed):
+    """1-3 extra echelons, random lead times / costs / demand moments / switches, n and T off the kernel's batch sizes: the host
+    build of the chain body against the oracle's autograd (costs per period, gradient of the mean cost)."""
+    assert cfc.check_random_serial_case(seed, launch, "cpu") <= 1e-5
