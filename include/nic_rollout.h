@@ -98,7 +98,13 @@ int nic_device_count(void);
  * update (environment.py:179-299) incl. update_inventory_for_heterogeneous_lead_times (environment.py:391-434).
  * Writes the next state and reward[b] = per-scenario cost of the period (the `reward` Simulator.step returns). */
 int nic_env_step_fwd(const NicEnvStepIO* io, float* store_inv_out, float* wh_inv_out, float* ech_inv_out,
-                     float* reward /* [ldb] */, void* stream);
+                     float* reward /* [ldb] */, int32_t zero_lead_upstream, void* stream);
+/* zero_lead_upstream (both directions): what happens to a non-zero store order whose lead time is 0.  0: it is dropped - it has
+ * no slot to arrive in.  1: the reference's behaviour (environment.py:405-432 computes the flat index lead - 1 = -1 from the start
+ * of the store's pipeline and torch's put wraps it): it is added to the LAST slot of the store in front, for store 0 the last
+ * store of the scenario in front (scenario n_scenarios - 1 for scenario 0) - inside the same launch (round 6; before, the callers
+ * patched the state with torch ops between launches).  Scenarios are coupled through it: one process, lead times that do not vary
+ * over the scenarios. */
 
 /* Backward of the same period (what autograd derives from environment.py:179-299,405-432, including the
  * `allocation != 0` filter at :426-429 and torch's clamp / minimum tie rules).
@@ -107,7 +113,8 @@ int nic_env_step_fwd(const NicEnvStepIO* io, float* store_inv_out, float* wh_inv
 int nic_env_step_bwd(const NicEnvStepIO* io, const float* g_store_out, const float* g_wh_out,
                      const float* g_ech_out, NicTable2 g_reward, float* g_store_in, float* g_wh_in,
                      float* g_ech_in, float* g_store_orders /* [S][max(Wn,1)][ldb] */,
-                     float* g_wh_orders /* [Wn][ldb] */, float* g_ech_orders /* [E][ldb] */, void* stream);
+                     float* g_wh_orders /* [Wn][ldb] */, float* g_ech_orders /* [E][ldb] */,
+                     int32_t zero_lead_upstream, void* stream);
 
 /* ---- policy MLP layers (feature-major activations) ------------------------------------------------------
  * Replaces nn.Linear + activation inside MyNeuralNetwork.create_sequential_net (neural_networks.py:80-106):

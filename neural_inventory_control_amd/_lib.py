@@ -156,8 +156,8 @@ PROTOTYPES = {
     "nic_last_error": (C.c_char_p, []),
     "nic_last_kernel": (C.c_char_p, []),
     "nic_device_count": (C.c_int, []),
-    "nic_env_step_fwd": (C.c_int, [_IOP, _vp, _vp, _vp, _vp, _vp]),
-    "nic_env_step_bwd": (C.c_int, [_IOP, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nic_env_step_fwd": (C.c_int, [_IOP, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
+    "nic_env_step_bwd": (C.c_int, [_IOP, _vp, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "nic_head_env_fwd": (C.c_int, [_IOP, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, _vp, _vp]),
     "nic_head_env_bwd": (C.c_int, [_IOP, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, NicTable2, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nic_period_tail_ok": (C.c_int, [C.POINTER(NicEnvDims), _i32, _i32, _i32]),

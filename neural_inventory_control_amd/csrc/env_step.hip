@@ -23,7 +23,7 @@ template <int MAXW>
 __global__ __launch_bounds__(kLanes * nic::kQuad) void env_step_fwd_kernel(NicEnvStepIO io, float* __restrict__ store_out,
                                                                             float* __restrict__ wh_out,
                                                                             float* __restrict__ ech_out,
-                                                                            float* __restrict__ reward) {
+                                                                            float* __restrict__ reward, int zero_lead_upstream) {
     __shared__ float part[kChunk][nic::kQuad][kLanes];  // shipment partials of one warehouse chunk
     __shared__ float rq[nic::kQuad][kLanes];            // store-cost partials
     __shared__ float cw[NIC_MAX_WAREHOUSES][kLanes];    // warehouse costs
@@ -53,6 +53,27 @@ __global__ __launch_bounds__(kLanes * nic::kQuad) void env_step_fwd_kernel(NicEn
         if (io.dims.n_echelons > 0) total += nic::env_fwd_echelons<MAXW>(io, ech_out, nic::env_wh_orders_sum(io, b), b);
         reward[b] = total;
     }
+    // The reference's treatment of an order whose lead time is 0 (environment.py:405-432: its flat index is lead - 1 = -1 from
+    // the start of the store's pipeline, i.e. the LAST slot of the store in front - for store 0 the last store of the scenario
+    // in front, scenario B - 1 for scenario 0 - through torch's put with wrapped negative indices).  The launch above dropped
+    // such orders; with zero_lead_upstream each scenario adds what lands in ITS rows: the orders of its own store s + 1 into
+    // the last slot of store s, and the NEXT scenario's store-0 orders into the last slot of its last store (inputs of another
+    // workgroup, never its outputs: no race).  The barrier above made this workgroup's new state visible to all its lanes.
+    if (zero_lead_upstream && live) {
+        const NicEnvDims& d = io.dims;
+        const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
+        for (int s = q; s < d.n_stores; s += nic::kQuad) {
+            const int64_t bs = s > 0 ? b : (b + 1 < d.n_scenarios ? b + 1 : 0);
+            float u = 0.f;
+            for (int w = 0; w < nsup; ++w) {
+                const float a = nic::t3(io.store_orders, s, w, bs);
+                if (nic::t3(io.lead_times, s, w, bs) == 0.f && a != 0.f) u += a;
+            }
+            const int target = s > 0 ? s - 1 : d.n_stores - 1;
+            float* slot = store_out + ((int64_t)target * d.store_slots + d.store_slots - 1) * d.ldb + b;
+            *slot = *slot + u;
+        }
+    }
 }
 
 template <int MAXW>
@@ -60,7 +81,7 @@ __global__ __launch_bounds__(kLanes * nic::kQuad) void env_step_bwd_kernel(
     NicEnvStepIO io, const float* __restrict__ g_store_out, const float* __restrict__ g_wh_out,
     const float* __restrict__ g_ech_out, NicTable2 g_reward, float* __restrict__ g_store_in, float* __restrict__ g_wh_in,
     float* __restrict__ g_ech_in, float* __restrict__ g_store_orders, float* __restrict__ g_wh_orders,
-    float* __restrict__ g_ech_orders) {
+    float* __restrict__ g_ech_orders, int zero_lead_upstream) {
     __shared__ float part[kChunk][nic::kQuad][kLanes];
     __shared__ float gwa[NIC_MAX_WAREHOUSES][kLanes];  // gradient of each warehouse's post-shipping on-hand
     __shared__ float g2wh[kLanes];                     // d/d(sum_w wh_orders) from the echelon chain
@@ -86,6 +107,21 @@ __global__ __launch_bounds__(kLanes * nic::kQuad) void env_step_bwd_kernel(
     }
     if (live)
         nic::env_bwd_stores<MAXW>(io, g_store_out, gr, [&](int w) { return gwa[w][x]; }, g_store_in, g_store_orders, b, q);
+    // adjoint of the zero-lead rule (see the forward kernel): such an order's gradient is the gradient of the slot it was added
+    // to - the last slot of the store in front (store 0: of the PREVIOUS scenario's last store) - where the order is not 0.  The
+    // lane that wrote g_store_orders[s][.][b] above (lane q owns stores q, q + 4, ...) adds to it.
+    if (zero_lead_upstream && live && g_store_out) {
+        const NicEnvDims& d = io.dims;
+        const int nsup = d.n_warehouses > 0 ? d.n_warehouses : 1;
+        for (int s = q; s < d.n_stores; s += nic::kQuad) {
+            const int target = s > 0 ? s - 1 : d.n_stores - 1;
+            const int64_t bt = s > 0 ? b : (b > 0 ? b - 1 : d.n_scenarios - 1);
+            const float g = g_store_out[((int64_t)target * d.store_slots + d.store_slots - 1) * d.ldb + bt];
+            for (int w = 0; w < nsup; ++w)
+                if (nic::t3(io.lead_times, s, w, b) == 0.f && nic::t3(io.store_orders, s, w, b) != 0.f)
+                    g_store_orders[((int64_t)s * nsup + w) * d.ldb + b] += g;
+        }
+    }
 }
 
 int validate(const NicEnvStepIO* io, const char* who) {
@@ -123,7 +159,7 @@ int max_slots(const NicEnvDims& d) {
 extern "C" {
 
 int nic_env_step_fwd(const NicEnvStepIO* io, float* store_inv_out, float* wh_inv_out, float* ech_inv_out, float* reward,
-                     void* stream) {
+                     int32_t zero_lead_upstream, void* stream) {
     if (int e = validate(io, "nic_env_step_fwd")) return e;
     const NicEnvDims& d = io->dims;
     NIC_REQUIRE(store_inv_out && reward, "nic_env_step_fwd: null output");
@@ -134,18 +170,18 @@ int nic_env_step_fwd(const NicEnvStepIO* io, float* store_inv_out, float* wh_inv
     const int m = max_slots(d);
     nic::note_kernelf("env_step_fwd_kernel<%d>", m <= 4 ? 4 : (m <= 8 ? 8 : NIC_MAX_SLOTS));
     if (m <= 4)
-        hipLaunchKernelGGL(env_step_fwd_kernel<4>, grid, block, 0, s, *io, store_inv_out, wh_inv_out, ech_inv_out, reward);
+        hipLaunchKernelGGL(env_step_fwd_kernel<4>, grid, block, 0, s, *io, store_inv_out, wh_inv_out, ech_inv_out, reward, zero_lead_upstream);
     else if (m <= 8)
-        hipLaunchKernelGGL(env_step_fwd_kernel<8>, grid, block, 0, s, *io, store_inv_out, wh_inv_out, ech_inv_out, reward);
+        hipLaunchKernelGGL(env_step_fwd_kernel<8>, grid, block, 0, s, *io, store_inv_out, wh_inv_out, ech_inv_out, reward, zero_lead_upstream);
     else
         hipLaunchKernelGGL(env_step_fwd_kernel<NIC_MAX_SLOTS>, grid, block, 0, s, *io, store_inv_out, wh_inv_out,
-                           ech_inv_out, reward);
+                           ech_inv_out, reward, zero_lead_upstream);
     return nic::check_launch("nic_env_step_fwd");
 }
 
 int nic_env_step_bwd(const NicEnvStepIO* io, const float* g_store_out, const float* g_wh_out, const float* g_ech_out,
                      NicTable2 g_reward, float* g_store_in, float* g_wh_in, float* g_ech_in, float* g_store_orders,
-                     float* g_wh_orders, float* g_ech_orders, void* stream) {
+                     float* g_wh_orders, float* g_ech_orders, int32_t zero_lead_upstream, void* stream) {
     if (int e = validate(io, "nic_env_step_bwd")) return e;
     const NicEnvDims& d = io->dims;
     NIC_REQUIRE(g_reward.p, "nic_env_step_bwd: null g_reward");
@@ -158,7 +194,7 @@ int nic_env_step_bwd(const NicEnvStepIO* io, const float* g_store_out, const flo
     nic::note_kernelf("env_step_bwd_kernel<%d>", m <= 4 ? 4 : (m <= 8 ? 8 : NIC_MAX_SLOTS));
 #define NIC_LAUNCH_BWD(MW)                                                                                              \
     hipLaunchKernelGGL(env_step_bwd_kernel<MW>, grid, block, 0, s, *io, g_store_out, g_wh_out, g_ech_out, g_reward,      \
-                       g_store_in, g_wh_in, g_ech_in, g_store_orders, g_wh_orders, g_ech_orders)
+                       g_store_in, g_wh_in, g_ech_in, g_store_orders, g_wh_orders, g_ech_orders, zero_lead_upstream)
     if (m <= 4) NIC_LAUNCH_BWD(4);
     else if (m <= 8) NIC_LAUNCH_BWD(8);
     else NIC_LAUNCH_BWD(NIC_MAX_SLOTS);

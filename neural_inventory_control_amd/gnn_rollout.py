@@ -651,16 +651,10 @@ class GnnRollout:
             ops.gnn_alloc_groups_fwd(out, st.wh, orders, self.sums[t], self.ratio[t], self.scale[t], P.groups, P.order_row,
                                      not P.transshipment, B)
         ts, tw = self._order_tables(orders, prob)
+        # (zero_lead_orders="upstream": the launch itself adds the non-zero orders of zero-lead pairs where the reference's
+        # flat-index put leaves them - round 6; before, a handful of torch ops per pair patched the state between launches)
         self._k("env_fwd", ops.env_step_fwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
-                out=self._views(self.states[t + 1], prob), reward=self.rewards[t])
-        if self._zl_pairs:
-            nxt = self._views(self.states[t + 1], prob).store            # [S][Ws][ld]
-            for s_, j_ in self._zl_pairs:
-                v = orders[s_ * P.Wn + j_, :B]
-                if s_ >= 1:
-                    nxt[s_ - 1, prob.Ws - 1, :B] += v
-                else:   # in front of scenario b's first store lies scenario b - 1's last one (b = 0: the batch's last scenario)
-                    nxt[S - 1, prob.Ws - 1, :B] += torch.roll(v, -1)
+                out=self._views(self.states[t + 1], prob), reward=self.rewards[t], zero_lead_upstream=bool(self._zl_pairs))
 
     def _backward_period(self, t, prob, demand_soa, shift, g_next, g_cur):
         P, M, B, ld, S = self.plan, self.mlp, prob.B, prob.ldb, prob.S
@@ -679,15 +673,9 @@ class GnnRollout:
                     self._views(g_next, prob), Table(self.g_reward, 0, 1), gc, self.g_orders, self.d_out[0])
         else:
             self._k("env_bwd", ops.env_step_bwd, prob, st, Table(demand_soa[t + shift], ld, 1), ts, tw, None,
-                    self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=gc, g_orders=(g_so, g_wo, None))
-        if self._zl_pairs and not fused:
-            # adjoint of the fix-up: the order's gradient is the state gradient of the element it was added to - where it was
-            # added at all (upstream filters zero orders out before the put: no gradient through them)
-            gn = self._views(g_next, prob).store
-            for s_, j_ in self._zl_pairs:
-                row = s_ * P.Wn + j_
-                g_t = gn[s_ - 1, prob.Ws - 1, :B] if s_ >= 1 else torch.roll(gn[S - 1, prob.Ws - 1, :B], 1)
-                self.g_orders[row, :B] += g_t * (self.orders[t][row, :B] != 0)
+                    self._views(g_next, prob), Table(self.g_reward, 0, 1), g_in=gc, g_orders=(g_so, g_wo, None),
+                    zero_lead_upstream=bool(self._zl_pairs))   # (with the rule's adjoint: the order's gradient is the state
+            #                                                      gradient of the element it was added to, where it was not 0)
         # allocation adjoint: alloc_e = out_e * min(1, on_hand / (sum + eps)) for the members, supplier edge passes through
         if fused:
             pass

@@ -41,19 +41,21 @@ class EnvState:
 
 
 def env_step_fwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders: Table, wh_orders, ech_orders,
-                 out: EnvState = None, reward=None):
-    """nic_env_step_fwd.  Returns (next_state, reward[ldb])."""
+                 out: EnvState = None, reward=None, zero_lead_upstream=False):
+    """nic_env_step_fwd.  Returns (next_state, reward[ldb]).  zero_lead_upstream: the reference's treatment of non-zero orders with
+    lead time 0 inside the launch (include/nic_rollout.h; default: dropped)."""
     _dev(state.store)
     out = out or EnvState.zeros_like(prob)
     if reward is None:
         reward = torch.zeros(prob.ldb, device=prob.device)
     io = prob.make_io(state.store, state.wh, state.ech, demand, store_orders, wh_orders, ech_orders)
-    check(lib().nic_env_step_fwd(io, ptr(out.store), ptr(out.wh), ptr(out.ech), ptr(reward), current_stream()))
+    check(lib().nic_env_step_fwd(io, ptr(out.store), ptr(out.wh), ptr(out.ech), ptr(reward), int(bool(zero_lead_upstream)),
+                                 current_stream()))
     return out, reward
 
 
 def env_step_bwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders: Table, wh_orders, ech_orders,
-                 g_out: EnvState, g_reward: Table, g_in: EnvState = None, g_orders=None):
+                 g_out: EnvState, g_reward: Table, g_in: EnvState = None, g_orders=None, zero_lead_upstream=False):
     """nic_env_step_bwd.  g_out members may be None (zeros).  Returns (g_state_in, (g_store_orders [S][nsup][ldb],
     g_wh_orders [Wn][ldb] | None, g_ech_orders [E][ldb] | None))."""
     _dev(state.store)
@@ -66,7 +68,7 @@ def env_step_bwd(prob: EnvProblem, state: EnvState, demand: Table, store_orders:
     io = prob.make_io(state.store, state.wh, state.ech, demand, store_orders, wh_orders, ech_orders)
     check(lib().nic_env_step_bwd(io, ptr(g_out.store), ptr(g_out.wh), ptr(g_out.ech), g_reward.t2(), ptr(g_in.store),
                                  ptr(g_in.wh), ptr(g_in.ech), ptr(g_orders[0]), ptr(g_orders[1]), ptr(g_orders[2]),
-                                 current_stream()))
+                                 int(bool(zero_lead_upstream)), current_stream()))
     return g_in, g_orders
 
 

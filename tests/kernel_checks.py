@@ -65,12 +65,12 @@ class HipBackend:
     def _s():
         return _lib.current_stream()
 
-    def env_fwd(self, io, so, wo, eo, r):
-        _lib.check(self.l.nic_env_step_fwd(io, P(so), P(wo), P(eo), P(r), self._s()))
+    def env_fwd(self, io, so, wo, eo, r, zero_lead_upstream=0):
+        _lib.check(self.l.nic_env_step_fwd(io, P(so), P(wo), P(eo), P(r), zero_lead_upstream, self._s()))
 
-    def env_bwd(self, io, gso, gwo, geo, gr, gsi, gwi, gei, gas, gaw, gae):
+    def env_bwd(self, io, gso, gwo, geo, gr, gsi, gwi, gei, gas, gaw, gae, zero_lead_upstream=0):
         _lib.check(self.l.nic_env_step_bwd(io, P(gso), P(gwo), P(geo), gr, P(gsi), P(gwi), P(gei), P(gas), P(gaw), P(gae),
-                                           self._s()))
+                                           zero_lead_upstream, self._s()))
 
     def head_warehouse_fwd(self, Z, wh, adj, ub, trans, so, wo, S, Wn, Ww, B, ldb):
         _lib.check(self.l.nic_head_warehouse_fwd(P(Z), P(wh), P(adj), ub, trans, P(so), P(wo), S, Wn, Ww, B, ldb, self._s()))
@@ -240,6 +240,14 @@ def check_zero_lead_micro(be):
     assert torch.equal(ref_view(so, 1).cpu(), want["store_inventories"])
     assert torch.equal(ref_view(wo, 1).cpu(), want["warehouse_inventories"])
     assert torch.equal(r[:1].cpu(), want["reward"])
+    if isinstance(be, HipBackend):   # the HIP entry point's own upstream mode (round 6): the oracle's default numbers, same launch
+        so2, wo2, r2 = torch.zeros_like(s), torch.zeros_like(w), torch.zeros(prob.ldb, device=dev)
+        be.env_fwd(io, so2, wo2, None, r2, zero_lead_upstream=1)
+        be.sync()
+        leak = want["store_inventories"].clone()
+        leak[0, 1, 2] += 4.0
+        assert torch.equal(ref_view(so2, 1).cpu(), leak)
+        assert torch.equal(wo2, wo) and torch.equal(r2, r)
 
 
 def check_env_backward(be, name, profit):

@@ -56,9 +56,80 @@ def test_zero_lead_orders_hand_computed_period(be):
     kc.check_zero_lead_micro(be)
 
 
+@pytest.mark.parametrize("B,S,Wn", [(100, 5, 3), (64, 1, 2), (257, 9, 4), (1, 3, 2)])
+def test_env_step_zero_lead_rule_inside_the_launch_equals_the_torch_patch(B, S, Wn):
+    """nic_env_step_fwd / _bwd with zero_lead_upstream = 1 against the same launches with 0 followed by the torch formulation of
+    the rule (`Simulator._add_zero_lead_orders` and its adjoint): several zero-lead suppliers per store, zero orders on some of them
+    (filtered out, no gradient), B off the 64-scenario workgroup and the wrap from scenario B - 1 to scenario 0."""
+    from neural_inventory_control_amd.layout import EnvProblem, Table
+    from neural_inventory_control_amd.ops import EnvState
+    DEV = "cuda"
+    g = torch.Generator().manual_seed(B * 131 + S * 7 + Wn)
+    Ws, Ww = 3, 4
+    lead1 = torch.randint(0, 3, (S, Wn), generator=g).float()      # (0 on about a third of the pairs; the same for every scenario)
+    lead1[0, 0] = 0.0
+    problem = {"n_stores": S, "n_warehouses": Wn, "n_extra_echelons": 0, "lost_demand": True, "maximize_profit": False,
+               "warehouse_store_adjacency": [[1] * S for _ in range(Wn)]}
+    data = {"demands": torch.rand(B, S, 1, generator=g) * 5, "initial_inventories": torch.rand(B, S, Ws, generator=g) * 4,
+            "underage_costs": torch.full((B, S), 9.0), "holding_costs": torch.full((B, S), 1.0),
+            "lead_times": lead1.unsqueeze(0).expand(B, S, Wn).clone(),
+            "initial_warehouse_inventories": torch.rand(B, Wn, Ww, generator=g) * 30,
+            "warehouse_holding_costs": torch.full((B, Wn), 0.3), "warehouse_lead_times": torch.full((B, Wn), 3.0),
+            "warehouse_edge_costs": torch.full((B, Wn), 0.5)}
+    data = {k: v.to(DEV) for k, v in data.items()}
+    prob = EnvProblem(problem, data, DEV)
+    ld = prob.ldb
+    a_store = torch.rand(B, S, Wn, generator=g) * 3
+    a_store[torch.rand(B, S, Wn, generator=g) < 0.25] = 0.0
+    a_store, a_wh = a_store.to(DEV), (torch.rand(B, Wn, generator=g) * 6).to(DEV)
+    so = torch.zeros(S, Wn, ld, device=DEV)
+    so[:, :, :B] = a_store.permute(1, 2, 0)
+    wo = torch.zeros(Wn, ld, device=DEV)
+    wo[:, :B] = a_wh.t()
+    st = EnvState(torch.zeros(S, Ws, ld, device=DEV), torch.zeros(Wn, Ww, ld, device=DEV), None)
+    st.store[:, :, :B] = data["initial_inventories"].permute(1, 2, 0)
+    st.wh[:, :, :B] = data["initial_warehouse_inventories"].permute(1, 2, 0)
+    dem = torch.zeros(S, ld, device=DEV)
+    dem[:, :B] = data["demands"][:, :, 0].t()
+    ts, tw = Table(so, Wn * ld, 1, ld), Table(wo, ld, 1)
+    res = {}
+    for zl in (False, True):
+        out, reward = ops.env_step_fwd(prob, st, Table(dem, ld, 1), ts, tw, None, zero_lead_upstream=zl)
+        res[zl] = (out.store.clone(), out.wh.clone(), reward.clone())
+    hit = (data["lead_times"] == 0) & (a_store != 0)
+    u = torch.zeros(B, S, device=DEV)                                # (B, S), summed over the suppliers left to right like the kernel
+    for w in range(Wn):
+        u = u + a_store[:, :, w] * hit[:, :, w]
+    want = res[False][0].clone()
+    if S > 1:
+        want[:S - 1, Ws - 1, :B] += u[:, 1:].t()
+    want[S - 1, Ws - 1, :B] += torch.roll(u[:, 0], -1)
+    assert bool(hit.any())
+    assert torch.equal(res[True][0], want) and torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+    # backward: g_orders gains the gradient of the slot the order was added to, where the order is not 0
+    g_next = EnvState(torch.zeros(S, Ws, ld, device=DEV), torch.zeros(Wn, Ww, ld, device=DEV), None)
+    g_next.store[:, :, :B] = torch.randn(S, Ws, B, generator=g).to(DEV)
+    g_next.wh[:, :, :B] = torch.randn(Wn, Ww, B, generator=g).to(DEV)
+    g_reward = torch.zeros(ld, device=DEV)
+    g_reward[:B] = 1.0 / B
+    gres = {}
+    for zl in (False, True):
+        g_in, g_ord = ops.env_step_bwd(prob, st, Table(dem, ld, 1), ts, tw, None, g_next, Table(g_reward, 0, 1),
+                                       zero_lead_upstream=zl)
+        gres[zl] = (g_in.store.clone(), g_in.wh.clone(), g_ord[0].clone(), g_ord[1].clone())
+    gt = torch.zeros(B, S, device=DEV)
+    if S > 1:
+        gt[:, 1:] = g_next.store[:S - 1, Ws - 1, :B].t()
+    gt[:, 0] = torch.roll(g_next.store[S - 1, Ws - 1, :B], 1)
+    want_g = gres[False][2].clone()
+    want_g[:, :, :B] += (gt.unsqueeze(2) * hit).permute(1, 2, 0)
+    assert torch.equal(gres[True][2], want_g)
+    assert all(torch.equal(gres[True][i], gres[False][i]) for i in (0, 1, 3))
+
+
 def test_env_rejects_bad_arguments(be):
     io = _lib.NicEnvStepIO()
-    assert be.l.nic_env_step_fwd(io, None, None, None, None, None) != 0
+    assert be.l.nic_env_step_fwd(io, None, None, None, None, 0, None) != 0
     assert b"n_scenarios" in be.l.nic_last_error() or b"null" in be.l.nic_last_error()
 
 
