@@ -46,14 +46,23 @@ NIC_HD void shifted_pipeline(const float* old_slots, int64_t ldb, int W, float o
 }
 
 // add `a` into slot L-1 when a != 0 (the reference filters zero orders before the put, environment.py:426-432)
+// (round 6: "is anything placed, and inside the pipeline" is folded into the lane's slot INDEX, -1 = nowhere, kept in a vector
+// register - each slot is then one vector compare + select.  Written as `a != 0 && k == slot && k < W` the compiler keeps the
+// three conditions as lane masks in scalar registers and ANDs them on the scalar unit between two vector instructions, for
+// every slot of every order: the closed-form chain ran 25 % faster without those round trips)
+NIC_HD int order_slot(float a, float lead, int W) {
+    int slot = (int)lead - 1;
+    slot = (a != 0.f && slot < W) ? slot : -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(slot));   // (or the optimiser folds the select back into the compares)
+#endif
+    return slot;
+}
 template <int MAXW>
 NIC_HD void place_order(float (&nv)[MAXW], int W, float a, float lead) {
-    const int slot = (int)lead - 1;
-    if (a != 0.f) {
+    const int slot = order_slot(a, lead, W);
 #pragma unroll
-        for (int k = 0; k < MAXW; ++k)
-            if (k == slot && k < W) nv[k] += a;
-    }
+    for (int k = 0; k < MAXW; ++k) nv[k] = (k == slot) ? nv[k] + a : nv[k];
 }
 
 template <int MAXW>
@@ -65,10 +74,13 @@ NIC_HD void store_pipeline(float* out_slots, int64_t ldb, int W, const float (&n
 
 template <int MAXW>
 NIC_HD float pick(const float (&g)[MAXW], int W, int slot) {
+    int sl = slot < W ? slot : -1;   // (one lane-local index instead of two lane masks per slot: see order_slot)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(sl));
+#endif
     float r = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXW; ++k)
-        if (k == slot && k < W) r = g[k];
+    for (int k = 0; k < MAXW; ++k) r = (k == sl) ? g[k] : r;
     return r;
 }
 
