@@ -27,6 +27,12 @@ for w in cfg1 cfg2 cfg4 gnn gnn_many_warehouses; do
   timeout 900 python bench.py --workload $w --eval --periods 5000 --steps 3 --warmup 1 --no-cpu-baseline > $O/r06_bench_${w}_eval_T5000.json 2> $O/eval_$w.err
   echo "eval $w rc $?"; python tools/show_bench.py $O/r06_bench_${w}_eval_T5000.json | head -3
 done
+WL=echelon_stock bash tools/pmc_sq_probe.sh > $O/r06_sq_echelon_chain.txt 2>&1   # (SQ counters of the closed-form chain kernel)
+for w in cfg3 gnn base_stock_1m; do   # whole-step kernel timelines (launches by name, kernel vs idle time)
+  ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/tl_$w -- python3 $GRAFT_REPO_ROOT/bench.py --workload $w --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 )
+  python tools/step_timeline.py $O/tl_$w FusedOptimizer --steps 1 --out $O/r06_step_timeline_$w.txt > /dev/null 2>&1
+  rm -rf $O/tl_$w
+done
 timeout 900 python tools/scaling_prediction.py --out $O/r06_scaling_prediction.json --steps 10 > $O/scaling.log 2>&1
 echo "scaling rc $?"
 timeout 1800 python tools/cpu_baseline_full.py $O/r06_cpu_baseline_full.json cfg3 cfg5 > $O/cpu_full.log 2>&1
