@@ -523,7 +523,7 @@ def bench_epoch(args):
     out = {"metric": "scenario-steps/sec (scenarios x stores x T) per training step", "value": n_samples * S * T / dt,
            "unit": "scenario-steps/s", "n_gpus": world, "steps": n_epochs * n_batches, "warmup": args.warmup, "ms_per_step": ms_batch,
            "ms_per_epoch": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-           "data": "synthetic",
+           "data": "synthetic", "library_id": (_lib_id() or None),
            "config": {"workload": desc + "; training step = one shuffled batch: rollout fwd + bwd + Adam", "name": args.workload,
                       "samples": n_samples, "batch_size": pbd["batch_size"], "batches_per_epoch": n_batches, "stores": S, "periods": T,
                       "parallelism": f"scenario-sharded dp{world}", "train_loss_per_store_period": last[1],
