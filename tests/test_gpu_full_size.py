@@ -408,3 +408,65 @@ def test_closed_form_at_a_million_chains_properties():
     assert abs(reported - (parts[0][2] + parts[1][2])) <= 2e-6 * abs(reported)
     for g, a, b in zip(grads, parts[0][3], parts[1][3]):
         assert float((g - (a + b)).norm() / (g.norm() + 1e-30)) <= 2e-5
+
+
+def test_echelon_chain_at_the_workload_size_properties():
+    """echelon_stock on the serial system at the benchmark's 131,072 chains x T = 100 (the chain kernel with four levels' tangents as
+    packed pairs): batch independence (per-chain rewards of the first 4,096 chains, run alone, bit for bit), the costs of the
+    training launch equal the evaluation launch's bit for bit (values never depend on the tangents), the full batch's sums equal
+    the halves', and the level gradient agrees with a central finite difference of the total over the bias of the policy's net
+    (piecewise-linear cost: exact except for chains that cross a kink inside the step)."""
+    from neural_inventory_control_amd.closed_form import ClosedFormRollout
+    setting, policy, n, T, _ = workloads.get("echelon_stock")
+    obs = defaultdict(lambda: None, setting["observation_params"])
+    sc = Scenario(T, setting["problem_params"], setting["store_params"], setting["warehouse_params"], setting["echelon_params"], n,
+                  obs, setting["seeds"], sampler="hip", device=DEV)
+    data = {k: v.to(DEV) for k, v in sc.get_data().items()}
+    torch.manual_seed(11)
+    model = NeuralNetworkCreator().create_neural_network(sc, policy, device=DEV)
+    with torch.no_grad():
+        ClosedFormRollout(model, setting["problem_params"], DEV).model.closed_form_levels()   # materialise the lazy layer
+
+    def run(d, train=True, keep_rewards=False):
+        eng = ClosedFormRollout(model, setting["problem_params"], DEV)
+        eng.keep_rewards = keep_rewards
+        model.zero_grad()
+        if train:
+            total, reported = eng.run(d, T, 9, train=True, observation_params=obs)
+            total.backward()
+            grads = [p.grad.detach().clone() for p in model.parameters() if p.grad is not None]
+        else:
+            with torch.no_grad():
+                total, reported = eng.run(d, T, 9, train=False, observation_params=obs)
+            grads = []
+        torch.cuda.synchronize()
+        return eng, float(total.detach()), float(reported.detach()), grads
+    eng, total, reported, grads = run(data, keep_rewards=True)
+    assert (_lib.lib().nic_last_kernel() or b"").decode().startswith("closed_form_kernel<4,4,true")
+    ev, total_e, reported_e, _ = run(data, train=False, keep_rewards=True)
+    assert (_lib.lib().nic_last_kernel() or b"").decode().startswith("closed_form_kernel<0,4,true")
+    assert torch.equal(ev.rewards, eng.rewards)
+    # (the two scalars are torch sums over per-wavefront rows of different widths: equal to the reduction's rounding)
+    assert abs(total_e - total) <= 1e-6 * abs(total) and abs(reported_e - reported) <= 1e-6 * abs(reported)
+    small, _, _, _ = run(_slice(data, 0, 4096), keep_rewards=True)
+    assert torch.equal(small.rewards[:, :, :4096], eng.rewards[:, :, :4096])
+    parts = [run(_slice(data, lo, hi)) for lo, hi in ((0, n // 2), (n // 2, n))]
+    assert abs(total - (parts[0][1] + parts[1][1])) <= 2e-6 * abs(total)
+    assert abs(reported - (parts[0][2] + parts[1][2])) <= 2e-6 * abs(reported)
+    for g, a, b in zip(grads, parts[0][3], parts[1][3]):
+        assert float((g - (a + b)).norm() / (g.norm() + 1e-30)) <= 2e-5
+    # central finite difference over each bias entry, on per-period rewards summed in float64
+    bias = [p for p in model.parameters() if p.dim() == 1][0]
+    g_bias = [g for p, g in zip([q for q in model.parameters() if q.grad is not None], grads) if p is bias][0]
+    eps = 2e-2
+    for j in range(bias.numel()):
+        vals = []
+        for sgn in (+1.0, -1.0):
+            with torch.no_grad():
+                bias[j] += sgn * eps
+            e2, _, _, _ = run(data, train=False, keep_rewards=True)
+            vals.append(float(e2.rewards.double().sum()))
+            with torch.no_grad():
+                bias[j] -= sgn * eps
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        assert abs(fd - float(g_bias[j])) <= 0.03 * abs(float(g_bias[j])) + 1e-3 * abs(total) / n, (j, fd, float(g_bias[j]))
