@@ -46,9 +46,10 @@ def demand_trace_soa(d, ldb, device=None):
     view of its own storage when the batch fills its padded row (B == ldb: no padding lanes of unknown content; no zero-fill, no copy: at 10^6 chains x T=100 those were 0.22 ms of a 0.47 ms step); anything else
     is transposed into a fresh zero-padded buffer."""
     B, S, T = d.shape
-    device = device or d.device
+    device = torch.device(device) if device is not None else d.device
+    same_device = d.device.type == device.type and (device.index is None or d.device.index == device.index)   # ("cuda" = any index)
     st = d.stride()   # (the stride of a size-1 dimension is arbitrary)
-    if (d.dtype == torch.float32 and d.device == torch.device(device) and B == ldb and B > 1 and st[0] == 1 and (S == 1 or st[1] == ldb)
+    if (d.dtype == torch.float32 and same_device and B == ldb and B > 1 and st[0] == 1 and (S == 1 or st[1] == ldb)
             and (T == 1 or st[2] == S * ldb) and d.storage_offset() % 4 == 0
             and d.untyped_storage().nbytes() >= 4 * (d.storage_offset() + T * S * ldb)):
         return d.as_strided((T, S, ldb), (S * ldb, ldb, 1), d.storage_offset())
