@@ -85,6 +85,9 @@ def note_name(k):
     m = re.match(r"gnn_period_fwd_kernel<(\d+), (true|false), (\d+), (true|false)>", k)
     if m:
         return "gnn_period_fwd_kernel<%s,%s,%s%s>" % (m.group(1), m.group(2), m.group(3), ",spill" if m.group(4) == "true" else "")
+    m = re.match(r"closed_form_kernel<(\d+), (\d+), (true|false), (\d+)>", k)   # (the ABI spells the store variant's WC, not a chain's 0)
+    if m:
+        return "closed_form_kernel<%s,%s,%s%s>" % (m.group(1), m.group(2), m.group(3), "," + m.group(4) if m.group(4) != "0" else "")
     m = re.match(r"thin_in_fwd_kernel<(\d+), (?:true|false)>", k)
     if m:
         return "thin_in_fwd_kernel<%s>" % m.group(1)
