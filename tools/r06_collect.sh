@@ -11,6 +11,16 @@ timeout 3600 python tools/collect_profiles.py r06 > $O/collect.log 2>&1
 echo "collect rc $?"
 timeout 900 python tools/collect_profiles.py r06 traffic:gnn traffic:gnn_many_warehouses > $O/collect_traffic.log 2>&1
 echo "traffic rc $?"
+# (as run in round 6 the remaining counter passes came in a later call, with the files of the first copied to profiles/ in between:
+#  bench.py reads profiles/*traffic*.json, so a line only cites a traffic file that is already there)
+timeout 1500 python tools/collect_profiles.py r06 traffic:base_stock traffic:base_stock_1m traffic:echelon_stock traffic:cfg1 traffic:cfg2 \
+    traffic:cfg4 traffic:cfg5 traffic:cfg3_shard8 traffic:real_data_driven >> $O/collect_traffic.log 2>&1
+cp $O/r06_traffic_*.json profiles/ 2>/dev/null
+for w in base_stock base_stock_1m echelon_stock cfg1 cfg2 cfg4 real_data_driven; do
+  timeout 300 python bench.py --workload $w --steps 20 --warmup 3 > $O/r06_bench_$w.json 2>/dev/null
+done
+timeout 300 python bench.py --workload cfg5 --steps 5 --warmup 2 > $O/r06_bench_cfg5.json 2>/dev/null
+timeout 300 python bench.py --workload cfg3_shard8 --steps 8 --warmup 2 > $O/r06_bench_cfg3_shard8.json 2>/dev/null
 for w in gnn gnn_many_warehouses; do
   timeout 300 python tools/gnn_period_bwd_probe.py --workload $w --periods 6 --out $O/r06_gnn_period_bwd_stamps_$w.json > $O/probe_final_$w.log 2>&1
   echo "probe $w rc $?"
