@@ -582,7 +582,8 @@ class WeightPackPlan:
                 if id(lin) not in seen:
                     seen.add(id(lin))
                     lins.append(lin)
-        self.params, stand_in, o = [], {}, 1   # (position 0 of the concatenation is the zero every padding element reads)
+        self.lins = lins   # (the layers, not their parameters: a parameter replaced on a layer later is still the one that is read)
+        sizes, stand_in, o = [], {}, 1   # (position 0 of the concatenation is the zero every padding element reads)
         for lin in lins:
             w, b = lin.weight, lin.bias
             fw = torch.arange(o, o + w.numel(), dtype=torch.float32, device=device).view_as(w)
@@ -590,7 +591,8 @@ class WeightPackPlan:
             fb = torch.arange(o, o + b.numel(), dtype=torch.float32, device=device).view_as(b)
             o += b.numel()
             stand_in[id(lin)] = types.SimpleNamespace(weight=fw, bias=fb)
-            self.params += [w, b]
+            sizes += [tuple(w.shape), tuple(b.shape)]
+        self._sizes = sizes
         assert o < 2 ** 24   # (positions travel through the packers as float32)
         self.zero = torch.zeros(1, device=device)
         parts, places, n = [], [], 0
@@ -614,7 +616,10 @@ class WeightPackPlan:
             setattr(obj, name, self.buf[at:at + math.prod(shape)].view(shape))
 
     def pack(self):
-        flat = torch.cat([self.zero] + [p.detach().reshape(-1) for p in self.params])
+        params = [p for lin in self.lins for p in (lin.weight, lin.bias)]
+        if [tuple(p.shape) for p in params] != self._sizes:
+            raise RuntimeError("WeightPackPlan: a layer's shape changed since the plan was built")
+        flat = torch.cat([self.zero] + [p.detach().reshape(-1) for p in params])
         torch.index_select(flat, 0, self.index, out=self.buf)
         return self.buf
 

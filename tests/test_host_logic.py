@@ -483,3 +483,20 @@ def test_weight_pack_plan_reproduces_every_packer_with_one_gather():
             for lin in lins + outs:
                 lin.weight.add_(1.0)
                 lin.bias.mul_(2.0)
+
+
+def test_weight_pack_plan_reads_a_parameter_replaced_on_its_layer():
+    """The plan keeps the LAYERS: a `lin.weight = nn.Parameter(...)` after the plan was built is what the next pack reads (the
+    packers' own pack() always read the live attribute); a changed shape is refused."""
+    import torch
+    from neural_inventory_control_amd import ops
+    lins = [torch.nn.Linear(20, 32), torch.nn.Linear(32, 32), torch.nn.Linear(32, 32)]
+    direct, planned = ops.GnnPeriodBwdPack(lins, 32, 1, "cpu"), ops.GnnPeriodBwdPack(lins, 32, 1, "cpu")
+    plan = ops.WeightPackPlan([(planned, ["buf"])], "cpu")
+    lins[1].weight = torch.nn.Parameter(torch.randn(32, 32))
+    direct.pack()
+    plan.pack()
+    assert torch.equal(direct.buf, planned.buf)
+    lins[0].weight = torch.nn.Parameter(torch.randn(32, 21))
+    with pytest.raises(RuntimeError):
+        plan.pack()
